@@ -1,0 +1,234 @@
+"""ctypes loader for the CPU oracle (oracle/stevi_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (libstevi_amd) never imports this module.
+
+All functions take / return dense numpy arrays laid out as the C file documents
+(images [H][W] or [H][W][C], volumes [H][W][D], words [H][W][nW]).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libstevi_oracle.so")
+
+# enum values (reference: correlation/matching_costs.h:38-53, correlation_base.h:31-45,
+# cost_based_refinement.h:30-35)
+CC, NCC, SSD, SAD, ZCC, ZNCC, ZSSD, ZSAD, HAMMING, CENSUS = 0, 1, 2, 3, 4, 5, 6, 7, 10, 11
+COST, SCORE = 0, 1
+LEFT_TO_RIGHT, RIGHT_TO_LEFT = 0, 1
+TCV_SAME, TCV_REVERSED, TCV_BOTH = 0, 1, 2
+EQUIANGULAR, PARABOLA, GAUSSIAN = 0, 1, 2
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "stevi_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.so_round_word_through_float.restype = C.c_uint32
+        _lib.so_round_word_through_float.argtypes = [C.c_uint32]
+        _lib.so_refine_triplet.restype = C.c_float
+        _lib.so_refine_triplet.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _pad(pad):
+    if pad is None:
+        return None
+    return (C.c_int * 4)(*[int(x) for x in pad])
+
+
+def _img3(img):
+    img = _f32(img)
+    if img.ndim == 2:
+        img = img[:, :, None]
+    return np.ascontiguousarray(img)
+
+
+def num_threads():
+    return int(lib().so_num_threads())
+
+
+def set_num_threads(n):
+    lib().so_set_num_threads(int(n))
+
+
+def func_strategy(func):
+    return int(lib().so_func_strategy(int(func)))
+
+
+def census_words(F):
+    return (F - 1) // 32 + 1
+
+
+def unfold(img, h_r, v_r, pad=None):
+    """pad = (left, top, right, bottom) or None for the reference's auto padding."""
+    img = _img3(img)
+    H, W, Cc = img.shape
+    Ho, Wo, F = C.c_int(), C.c_int(), C.c_int()
+    lib().so_unfold_shape(H, W, Cc, h_r, v_r, _pad(pad), C.byref(Ho), C.byref(Wo), C.byref(F))
+    out = np.empty((max(Ho.value, 0), max(Wo.value, 0), F.value), np.float32)
+    if out.size:
+        lib().so_unfold(_p(img), H, W, Cc, h_r, v_r, _pad(pad), _p(out))
+    return out
+
+
+def census_features(feat):
+    feat = _f32(feat)
+    H, W, F = feat.shape
+    if F <= 1:
+        return np.empty((0, 0, 0), np.uint32)
+    out = np.empty((H, W, census_words(F)), np.uint32)
+    rc = lib().so_census_features(_p(feat), H, W, F, _p(out))
+    assert rc == 0
+    return out
+
+
+def census_transform(img, h_r, v_r, pad=None):
+    return census_features(unfold(img, h_r, v_r, pad))
+
+
+def round_word_through_float(w):
+    return int(lib().so_round_word_through_float(int(w) & 0xFFFFFFFF))
+
+
+def channels_mean(feat):
+    feat = _f32(feat)
+    H, W, F = feat.shape
+    out = np.empty((H, W), np.float32)
+    lib().so_channels_mean(_p(feat), H, W, F, _p(out))
+    return out
+
+
+def channels_norm(feat):
+    feat = _f32(feat)
+    H, W, F = feat.shape
+    out = np.empty((H, W), np.float32)
+    lib().so_channels_norm(_p(feat), H, W, F, _p(out))
+    return out
+
+
+def channels_zeromean_norm(feat):
+    feat = _f32(feat)
+    H, W, F = feat.shape
+    out = np.empty((H, W), np.float32)
+    lib().so_channels_zeromean_norm(_p(feat), H, W, F, _p(out))
+    return out
+
+
+def feature_cost_volume(func, feat_l, feat_r, D, ddir=RIGHT_TO_LEFT, disp_lower=0):
+    feat_l, feat_r = _f32(feat_l), _f32(feat_r)
+    H, Wl, F = feat_l.shape
+    Hr, Wr, Fr = feat_r.shape
+    if H != Hr or F != Fr:
+        return np.empty((0, 0, 0), np.float32)
+    Ws = Wr if ddir == RIGHT_TO_LEFT else Wl
+    cv = np.empty((H, Ws, D), np.float32)
+    rc = lib().so_feature_cost_volume(int(func), _p(feat_l), _p(feat_r), H, Wl, Wr, F, int(ddir), int(disp_lower), int(D), _p(cv))
+    if rc:
+        return np.empty((0, 0, 0), np.float32)
+    return cv
+
+
+def unfold_cost_volume(func, img_l, img_r, h_r, v_r, D, ddir=RIGHT_TO_LEFT, disp_lower=0):
+    img_l, img_r = _img3(img_l), _img3(img_r)
+    Hl, Wl, Cc = img_l.shape
+    Hr, Wr, Cr = img_r.shape
+    if Hl != Hr or Cc != Cr:
+        return np.empty((0, 0, 0), np.float32)
+    Ws = Wr if ddir == RIGHT_TO_LEFT else Wl
+    cv = np.empty((Hl, Ws, D), np.float32)
+    rc = lib().so_unfold_cost_volume(int(func), _p(img_l), _p(img_r), Hl, Wl, Hr, Wr, Cc, int(h_r), int(v_r),
+                                     int(ddir), int(disp_lower), int(D), _p(cv))
+    if rc:
+        return np.empty((0, 0, 0), np.float32)
+    return cv
+
+
+def sgm(cv, n_dir, strategy, P1, P2, margins=(0, 0, 0, 0), Pout=100.0, variant=1):
+    """margins = (left, top, right, bottom); variant 0 = literal O(D^2) loops, 1 = O(D)."""
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    out = np.empty_like(cv)
+    m = (C.c_int * 4)(*[int(x) for x in margins])
+    rc = lib().so_sgm(int(n_dir), int(strategy), _p(cv), H, W, D, C.c_float(P1), C.c_float(P2), m, C.c_float(Pout), _p(out), int(variant))
+    if rc:
+        raise ValueError("unsupported number of directions")
+    return out
+
+
+def sgm_add_direction(sgm_cv, cv, direction, strategy, P1, P2, margins=(0, 0, 0, 0), Pout=100.0, variant=1):
+    cv = _f32(cv)
+    assert sgm_cv.dtype == np.float32 and sgm_cv.flags.c_contiguous and sgm_cv.shape == cv.shape
+    H, W, D = cv.shape
+    m = (C.c_int * 4)(*[int(x) for x in margins])
+    rc = lib().so_sgm_add_direction(int(direction), int(strategy), _p(cv), H, W, D, C.c_float(P1), C.c_float(P2), m,
+                                    C.c_float(Pout), _p(sgm_cv), int(variant))
+    assert rc == 0
+    return sgm_cv
+
+
+def extract_index(cv, strategy):
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    idx = np.empty((H, W), np.int32)
+    lib().so_extract_index(int(strategy), _p(cv), H, W, D, _p(idx))
+    return idx
+
+
+def index_to_disp(idx, ddir=RIGHT_TO_LEFT, offset=0):
+    idx = _i32(idx)
+    H, W = idx.shape
+    out = np.empty_like(idx)
+    lib().so_index_to_disp(int(ddir), _p(idx), H, W, int(offset), _p(out))
+    return out
+
+
+def truncated_cost_volume(cv, idx, h_r, v_r, r, sdir=TCV_SAME, ddir=RIGHT_TO_LEFT):
+    cv, idx = _f32(cv), _i32(idx)
+    H, W, D = cv.shape
+    T = int(lib().so_truncated_cv_depth(int(sdir), int(r)))
+    out = np.empty((H, W, T), np.float32)
+    lib().so_truncated_cost_volume(int(sdir), int(ddir), _p(cv), _p(idx), H, W, D, int(h_r), int(v_r), int(r), _p(out))
+    return out
+
+
+def refine_triplet(kernel, cm1, c0, c1):
+    return float(lib().so_refine_triplet(int(kernel), C.c_float(cm1), C.c_float(c0), C.c_float(c1)))
+
+
+def refine_disp(tcv, raw, kernel=PARABOLA):
+    tcv, raw = _f32(tcv), _i32(raw)
+    H, W, T = tcv.shape
+    out = np.empty((H, W), np.float32)
+    rc = lib().so_refine_disp(int(kernel), _p(tcv), _p(raw), H, W, T, _p(out))
+    if rc:
+        return np.empty((0, 0), np.float32)
+    return out

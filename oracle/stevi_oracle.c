@@ -1,0 +1,689 @@
+/*
+ * stevi_oracle.c -- CPU restatement of LibStevi's correlation/ hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only
+ * as the checker / the CPU baseline.  The HIP library (libstevi_amd/csrc) never links it.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle"):
+ *   - the reference cannot be built in this image (MultidimArrays, StatusOptional, Eigen, FFTW
+ *     are absent; CMakeLists.txt:62-76,:92,:95) and its tests hold no golden vectors (all inputs
+ *     come from std::random_device, test/unittests/testCorrelationFilters.cpp:76-79);
+ *   - rows pinned by the reference's own property tests, restated in tests/test_oracle_pins.py:
+ *     unfold (testCorrelationFilters.cpp:384-445), ZCC/ZNCC volumes (:264-370,:462-500),
+ *     NCC/SSD/ZSSD/SAD/ZSAD arithmetic (testCorrelation2d.cpp:75-127 via
+ *     test/test_correlation_utils.h:9-310), parabola refinement (testCostRefinement.cpp:33-57);
+ *   - rows with NO reference test or fixture -- census, Hamming, SGM, extractSelectedIndex tie
+ *     rule, truncatedCostVolume: **parity unpinned**; they follow the cited lines operation by
+ *     operation and are cross-checked only against hand-computed cases.
+ *
+ * All arrays are dense, row-major, last index fastest:
+ *   images  [H][W][C]      feature volumes [H][W][F]      census words [H][W][nW]
+ *   cost volumes [H][W][D]  index / disparity maps [H][W]
+ * Each function cites the reference file:line it restates (paths relative to the LibStevi tree).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* enum values follow correlation/matching_costs.h:38-53 */
+enum { SO_CC = 0, SO_NCC = 1, SO_SSD = 2, SO_SAD = 3, SO_ZCC = 4, SO_ZNCC = 5, SO_ZSSD = 6,
+       SO_ZSAD = 7, SO_HAMMING = 10, SO_CENSUS = 11 };
+/* correlation/correlation_base.h:31-45 */
+enum { SO_COST = 0, SO_SCORE = 1 };
+enum { SO_LEFT_TO_RIGHT = 0, SO_RIGHT_TO_LEFT = 1 };
+enum { SO_TCV_SAME = 0, SO_TCV_REVERSED = 1, SO_TCV_BOTH = 2 };
+/* correlation/cost_based_refinement.h:30-35 */
+enum { SO_EQUIANGULAR = 0, SO_PARABOLA = 1, SO_GAUSSIAN = 2 };
+
+int so_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void so_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ---- traits: correlation/matching_costs.h:419-685 ------------------------------------------- */
+static int func_zero_mean(int f) { return f == SO_ZCC || f == SO_ZNCC || f == SO_ZSSD || f == SO_ZSAD; }
+static int func_normalized(int f) { return f == SO_NCC || f == SO_ZNCC; }
+static int func_census(int f) { return f == SO_HAMMING || f == SO_CENSUS; }
+int so_func_supported(int f) {
+    return f == SO_CC || f == SO_NCC || f == SO_SSD || f == SO_SAD || func_zero_mean(f) || func_census(f);
+}
+/* extractionStrategy of each trait class */
+int so_func_strategy(int f) {
+    return (f == SO_CC || f == SO_NCC || f == SO_ZCC || f == SO_ZNCC) ? SO_SCORE : SO_COST;
+}
+
+/* number of census words allocated / written: correlation/census.h:80 and :103-108 */
+int so_census_words(int F) { return (F - 1) / 32 + 1; }
+int so_census_words_written(int F) { return (F - 1) / 32; }
+
+/* ---- A1: unfold, correlation/unfold.h:247-344 (Rotate0 only) -------------------------------- *
+ * pad[4] = left, top, right, bottom; pad == NULL means PaddingMargins() "auto" = (h_r, v_r).     *
+ * Output shape (unfold.h:269-270): Ho = H - v + pt + pb + 1, Wo = W - h + pl + pr + 1.           */
+void so_unfold_shape(int H, int W, int C, int h_r, int v_r, const int *pad, int *Ho, int *Wo, int *F) {
+    int pl = pad ? pad[0] : h_r, pt = pad ? pad[1] : v_r, pr = pad ? pad[2] : h_r, pb = pad ? pad[3] : v_r;
+    int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    *Ho = H - v + pt + pb + 1;
+    *Wo = W - h + pl + pr + 1;
+    *F = h * v * C;
+}
+
+void so_unfold(const float *img, int H, int W, int C, int h_r, int v_r, const int *pad, float *out) {
+    int pl = pad ? pad[0] : h_r, pt = pad ? pad[1] : v_r;
+    int Ho, Wo, F;
+    so_unfold_shape(H, W, C, h_r, v_r, pad, &Ho, &Wo, &F);
+    int h = 2 * h_r + 1, v = 2 * v_r + 1;
+#pragma omp parallel for
+    for (int i = 0; i < Ho; i++) {
+        for (int j = 0; j < Wo; j++) {
+            float *o = out + ((size_t)i * Wo + j) * F;
+            for (int k = 0; k < v; k++) {
+                for (int l = 0; l < h; l++) {
+                    for (int ch = 0; ch < C; ch++) {
+                        /* channelFromCord, unfold.h:180 */
+                        int c = C * h * k + C * l + ch;
+                        int ii = i - pt + k, jj = j - pl + l;
+                        /* valueOrAlt(..., 0), unfold.h:284 / :335 */
+                        o[c] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? img[((size_t)ii * W + jj) * C + ch] : 0.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ---- A2: censusFeatures, correlation/census.h:69-115 ---------------------------------------- *
+ * ref = channel 0 (:89); bit b of the running word := ref > val (:98-101); the word is stored    *
+ * only when 32 bits are filled (:103-108), so the trailing partial word is never written.        *
+ * Unwritten words are defined as 0 here (rule E1 of SURVEY.md section 8a).                       */
+int so_census_features(const float *feat, int H, int W, int F, uint32_t *words) {
+    if (F <= 1) return 1; /* census.h:76-78: empty array */
+    int nW = so_census_words(F);
+    memset(words, 0, (size_t)H * W * nW * sizeof(uint32_t));
+#pragma omp parallel for
+    for (int i = 0; i < H; i++) {
+        for (int j = 0; j < W; j++) {
+            const float *f = feat + ((size_t)i * W + j) * F;
+            uint32_t *o = words + ((size_t)i * W + j) * nW;
+            float ref = f[0];
+            uint32_t d = 0;
+            unsigned b = 0;
+            int census_channel = 0;
+            for (int c = 1; c < F; c++) {
+                uint32_t g = (ref > f[c]) ? 1u : 0u;
+                d |= g << b;
+                b++;
+                if (b >= 32) {
+                    o[census_channel] = d;
+                    census_channel++;
+                    d = 0;
+                    b = 0;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* A3: censusTransform2D, correlation/census.h:117-131 = unfold then censusFeatures. */
+int so_census_transform(const float *img, int H, int W, int C, int h_r, int v_r, const int *pad, uint32_t *words) {
+    int Ho, Wo, F;
+    so_unfold_shape(H, W, C, h_r, v_r, pad, &Ho, &Wo, &F);
+    if (Ho <= 0 || Wo <= 0) return 1;
+    float *feat = (float *)malloc((size_t)Ho * Wo * F * sizeof(float));
+    if (!feat) return 2;
+    so_unfold(img, H, W, C, h_r, v_r, pad, feat);
+    int rc = so_census_features(feat, Ho, Wo, F, words);
+    free(feat);
+    return rc;
+}
+
+/* Rule E2: `float t = word; word' = t;` of correlation/cross_correlations.h:235-236.            *
+ * uint32 -> float is round-to-nearest-even; float -> uint32 of 2^32 is UB in C++ and is defined  *
+ * here as saturation (what v_cvt_u32_f32 and vcvttss2usi do).                                    */
+uint32_t so_round_word_through_float(uint32_t w) {
+    float t = (float)w;
+    if (t >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)t;
+}
+
+/* ---- A7: per-pixel channel statistics ------------------------------------------------------- */
+/* channelsMean, correlation/correlation_base.h:1100-1136: sequential sum then * float(1./f) */
+static void channels_mean(const float *feat, int H, int W, int F, float *mean) {
+    float scale = (float)(1. / (double)(float)F);
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const float *f = feat + ((size_t)i * W + j) * F;
+            float m = 0;
+            for (int c = 0; c < F; c++) m += f[c];
+            mean[(size_t)i * W + j] = m * scale;
+        }
+}
+/* channelsZeroMeanNorm, correlation/cross_correlations.h:61-104 (float branch) */
+static void channels_zeromean_norm(const float *feat, const float *mean, int H, int W, int F, float *norm) {
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const float *f = feat + ((size_t)i * W + j) * F;
+            float m = mean[(size_t)i * W + j];
+            float n = 0;
+            for (int c = 0; c < F; c++) {
+                float tmp = f[c] - m;
+                n += tmp * tmp;
+            }
+            norm[(size_t)i * W + j] = sqrtf(n);
+        }
+}
+/* channelsNorm, correlation/cross_correlations.h:149-191 (float branch) */
+static void channels_norm(const float *feat, int H, int W, int F, float *norm) {
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const float *f = feat + ((size_t)i * W + j) * F;
+            float n = 0;
+            for (int c = 0; c < F; c++) {
+                float tmp = f[c];
+                n += tmp * tmp;
+            }
+            norm[(size_t)i * W + j] = sqrtf(n);
+        }
+}
+
+void so_channels_mean(const float *feat, int H, int W, int F, float *mean) { channels_mean(feat, H, W, F, mean); }
+void so_channels_norm(const float *feat, int H, int W, int F, float *norm) { channels_norm(feat, H, W, F, norm); }
+void so_channels_zeromean_norm(const float *feat, int H, int W, int F, float *norm) {
+    float *mean = (float *)malloc((size_t)H * W * sizeof(float));
+    channels_mean(feat, H, W, F, mean);
+    channels_zeromean_norm(feat, mean, H, W, F, norm);
+    free(mean);
+}
+
+/* getFeatureVolumeForMatchFunc, correlation/cross_correlations.h:645-722, float input, non-census.  *
+ * Writes the processed float feature volume in place of `out` (same shape as feat).                  */
+static void processed_features(int func, const float *feat, int H, int W, int F, float *out) {
+    size_t npx = (size_t)H * W;
+    if (func_zero_mean(func) && func_normalized(func)) { /* :680-689, zeromeanNormalizedFeatureVolume :416-462 */
+        float *mean = (float *)malloc(npx * sizeof(float));
+        float *sigma = (float *)malloc(npx * sizeof(float));
+        channels_mean(feat, H, W, F, mean);
+        channels_zeromean_norm(feat, mean, H, W, F, sigma);
+#pragma omp parallel for
+        for (long p = 0; p < (long)npx; p++)
+            for (int c = 0; c < F; c++) out[p * F + c] = (feat[p * F + c] - mean[p]) / sigma[p];
+        free(mean);
+        free(sigma);
+    } else if (func_zero_mean(func)) { /* :691-699, zeromeanFeatureVolume :570-594 */
+        float *mean = (float *)malloc(npx * sizeof(float));
+        channels_mean(feat, H, W, F, mean);
+#pragma omp parallel for
+        for (long p = 0; p < (long)npx; p++)
+            for (int c = 0; c < F; c++) out[p * F + c] = feat[p * F + c] - mean[p];
+        free(mean);
+    } else if (func_normalized(func)) { /* :701-709, normalizedFeatureVolume :504-550 */
+        float *norm = (float *)malloc(npx * sizeof(float));
+        channels_norm(feat, H, W, F, norm);
+#pragma omp parallel for
+        for (long p = 0; p < (long)npx; p++)
+            for (int c = 0; c < F; c++) out[p * F + c] = feat[p * F + c] / norm[p];
+        free(norm);
+    } else { /* :716-720 cast only */
+        memcpy(out, feat, npx * F * sizeof(float));
+    }
+}
+
+/* ---- A4/A5: comparison kernels, correlation/matching_costs.h:59-156, :236-263 --------------- */
+static float cmp_float(int func, const float *s, const float *t, int F) {
+    float score = 0;
+    switch (func) {
+    case SO_CC: case SO_NCC: case SO_ZCC: case SO_ZNCC: /* dotProduct :59-78 */
+        for (int c = 0; c < F; c++) score += s[c] * t[c];
+        break;
+    case SO_SSD: case SO_ZSSD: /* SumSquareDiff :100-116 */
+        for (int c = 0; c < F; c++) {
+            float tmp = s[c] - t[c];
+            score += tmp * tmp;
+        }
+        break;
+    default: /* SumAbsDiff :136-156 */
+        for (int c = 0; c < F; c++) {
+            float tmp = s[c] - t[c];
+            score += fabsf(tmp);
+        }
+        break;
+    }
+    return score;
+}
+
+static float cmp_hamming(const uint32_t *s, const uint32_t *t, int nW) {
+    uint16_t score = 0; /* hamming_cv_t, :234 */
+    for (int w = 0; w < nW; w++) score += (uint16_t)__builtin_popcount(s[w] ^ t[w]);
+    return (float)score; /* traits return float, :664/:681 */
+}
+
+/* ---- A6: aggregateCost, correlation/cross_correlations.h:194-308 ---------------------------- *
+ * CV(i,j,d) = cmp(src(i,j,:), tgt(i, j + sign*(disp_lower + d), :)); the target vector is        *
+ * gathered element by element through a `float` temporary, 0 where the column is outside         *
+ * [0, Wt) (:234-237 / :293-296).  disp_lower = 0 is the disp_t overload, otherwise searchOffset. */
+static void aggregate_float(int func, const float *src, const float *tgt, int H, int Ws, int Wt, int F,
+                            int ddir, int disp_lower, int D, float *cv) {
+    int sign = (ddir == SO_RIGHT_TO_LEFT) ? 1 : -1;
+#pragma omp parallel
+    {
+        float *tv = (float *)malloc((size_t)F * sizeof(float));
+#pragma omp for
+        for (int i = 0; i < H; i++) {
+            for (int j = 0; j < Ws; j++) {
+                const float *sv = src + ((size_t)i * Ws + j) * F;
+                for (int d = 0; d < D; d++) {
+                    int jt = j + sign * (disp_lower + d);
+                    for (int c = 0; c < F; c++) {
+                        float t = (jt >= 0 && jt < Wt) ? tgt[((size_t)i * Wt + jt) * F + c] : 0.0f;
+                        tv[c] = t;
+                    }
+                    cv[((size_t)i * Ws + j) * D + d] = cmp_float(func, sv, tv, F);
+                }
+            }
+        }
+        free(tv);
+    }
+}
+
+static void aggregate_hamming(const uint32_t *src, const uint32_t *tgt, int H, int Ws, int Wt, int nW,
+                              int ddir, int disp_lower, int D, float *cv) {
+    int sign = (ddir == SO_RIGHT_TO_LEFT) ? 1 : -1;
+#pragma omp parallel
+    {
+        uint32_t *tv = (uint32_t *)malloc((size_t)nW * sizeof(uint32_t));
+#pragma omp for
+        for (int i = 0; i < H; i++) {
+            for (int j = 0; j < Ws; j++) {
+                const uint32_t *sv = src + ((size_t)i * Ws + j) * nW;
+                for (int d = 0; d < D; d++) {
+                    int jt = j + sign * (disp_lower + d);
+                    for (int w = 0; w < nW; w++) {
+                        /* float t = valueOrAlt(...); target(c) = t;  -> rule E2 */
+                        uint32_t raw = (jt >= 0 && jt < Wt) ? tgt[((size_t)i * Wt + jt) * nW + w] : 0u;
+                        tv[w] = so_round_word_through_float(raw);
+                    }
+                    cv[((size_t)i * Ws + j) * D + d] = cmp_hamming(sv, tv, nW);
+                }
+            }
+        }
+        free(tv);
+    }
+}
+
+/* featureVolume2CostVolume, correlation/cross_correlations.h:724-738.                           *
+ * feat_l [H][Wl][F], feat_r [H][Wr][F] float.  Source/target selection: condImgRef,             *
+ * correlation_base.h:829-878 (RightToLeft: source = right, target = left).                      *
+ * cv is [H][Ws][D] with Ws the source width.  Returns non-zero where the reference returns an    *
+ * empty array.                                                                                   */
+int so_feature_cost_volume(int func, const float *feat_l, const float *feat_r, int H, int Wl, int Wr, int F,
+                           int ddir, int disp_lower, int D, float *cv) {
+    if (!so_func_supported(func) || D <= 0) return 1;
+    const float *src = (ddir == SO_RIGHT_TO_LEFT) ? feat_r : feat_l;
+    const float *tgt = (ddir == SO_RIGHT_TO_LEFT) ? feat_l : feat_r;
+    int Ws = (ddir == SO_RIGHT_TO_LEFT) ? Wr : Wl;
+    int Wt = (ddir == SO_RIGHT_TO_LEFT) ? Wl : Wr;
+    if (func_census(func)) {
+        if (F <= 1) return 1;
+        int nW = so_census_words(F);
+        uint32_t *ws = (uint32_t *)malloc((size_t)H * Ws * nW * sizeof(uint32_t));
+        uint32_t *wt = (uint32_t *)malloc((size_t)H * Wt * nW * sizeof(uint32_t));
+        so_census_features(src, H, Ws, F, ws);
+        so_census_features(tgt, H, Wt, F, wt);
+        aggregate_hamming(ws, wt, H, Ws, Wt, nW, ddir, disp_lower, D, cv);
+        free(ws);
+        free(wt);
+    } else {
+        float *ps = (float *)malloc((size_t)H * Ws * F * sizeof(float));
+        float *pt = (float *)malloc((size_t)H * Wt * F * sizeof(float));
+        processed_features(func, src, H, Ws, F, ps);
+        processed_features(func, tgt, H, Wt, F, pt);
+        aggregate_float(func, ps, pt, H, Ws, Wt, F, ddir, disp_lower, D, cv);
+        free(ps);
+        free(pt);
+    }
+    return 0;
+}
+
+/* unfoldBasedCostVolume, correlation/cross_correlations.h:740-765: unfold both images with auto  *
+ * padding, then featureVolume2CostVolume.  Images [H][W*][C].                                    */
+int so_unfold_cost_volume(int func, const float *img_l, const float *img_r, int Hl, int Wl, int Hr, int Wr, int C,
+                          int h_r, int v_r, int ddir, int disp_lower, int D, float *cv) {
+    if (Hl != Hr) return 1; /* :751-753 */
+    int F = (2 * h_r + 1) * (2 * v_r + 1) * C;
+    float *fl = (float *)malloc((size_t)Hl * Wl * F * sizeof(float));
+    float *fr = (float *)malloc((size_t)Hr * Wr * F * sizeof(float));
+    if (!fl || !fr) { free(fl); free(fr); return 2; }
+    so_unfold(img_l, Hl, Wl, C, h_r, v_r, NULL, fl);
+    so_unfold(img_r, Hr, Wr, C, h_r, v_r, NULL, fr);
+    int rc = so_feature_cost_volume(func, fl, fr, Hl, Wl, Wr, F, ddir, disp_lower, D, cv);
+    free(fl);
+    free(fr);
+    return rc;
+}
+
+/* ---- A9: SGM, correlation/sgm.h ------------------------------------------------------------- */
+/* directionTraits, sgm.h:57-155, in the order of enum sgmDirections (:29-46) */
+static const int SGM_STEPS_V[16][2] = {{1, 1}, {-1, -1}, {0, 0}, {0, 0}, {1, 1}, {-1, -1}, {1, 1}, {-1, -1},
+                                       {0, 1}, {0, -1}, {0, 1}, {0, -1}, {1, 1}, {-1, -1}, {1, 1}, {-1, -1}};
+static const int SGM_STEPS_H[16][2] = {{0, 0}, {0, 0}, {1, 1}, {-1, -1}, {1, 1}, {-1, -1}, {-1, -1}, {1, 1},
+                                       {1, 1}, {-1, -1}, {-1, -1}, {1, 1}, {0, 1}, {0, -1}, {0, -1}, {0, 1}};
+enum { SGM_NOSTART = 0, SGM_ZEROPOS = 1, SGM_ENDPOS = 2 };
+/* startPostInfos, sgm.h:162-184 */
+static int start_pos(const int s[2]) {
+    if (s[0] == 0 && s[1] == 0) return SGM_NOSTART;
+    if (s[0] >= 0 && s[1] >= 0) return SGM_ZEROPOS;
+    return SGM_ENDPOS;
+}
+
+/* traverseLine, sgm.h:186-311, literal O(D^2) loops. */
+static void traverse_line_faithful(int dir, int strategy, long start_i, long start_j, const float *cv, float *sgm,
+                                   int H, int W, int D, float P1, float P2, const int m[4], float Pout) {
+    const int *sv = SGM_STEPS_V[dir], *sh = SGM_STEPS_H[dir];
+    int left = m[0], top = m[1], right = m[2], bottom = m[3];
+    float *previous_cost = (float *)malloc((size_t)D * sizeof(float));
+    float *actual_cost = (float *)malloc((size_t)D * sizeof(float));
+    for (int d = 0; d < D; d++) previous_cost[d] = 0.0f;
+    int c, i, j;
+    for (c = 0, i = (int)start_i, j = (int)start_j;
+         (i >= top && i < H - bottom) && (j >= left && j < W - right);
+         i += sv[c % 2], j += sh[c % 2], c++) {
+        const float *cvp = cv + ((size_t)i * W + j) * D;
+        if (strategy == SO_SCORE) { /* :218-255 */
+            float max_p_cost = -INFINITY;
+            for (int d = 0; d < D; d++) {
+                float p_score = previous_cost[d];
+                if (p_score > max_p_cost && isfinite(p_score)) max_p_cost = previous_cost[d];
+            }
+            for (int nd = 0; nd < D; nd++) {
+                float max_a_cost = -INFINITY;
+                float c_score = cvp[nd];
+                for (int od = 0; od < D; od++) {
+                    float p_score = previous_cost[od];
+                    if (abs(od - nd) == 1) p_score -= P1;
+                    if (abs(od - nd) > 1) p_score -= P2;
+                    if (p_score > max_a_cost && isfinite(p_score)) max_a_cost = p_score;
+                }
+                if (j + nd >= W) max_a_cost -= Pout;
+                actual_cost[nd] = c_score;
+                if (isfinite(max_a_cost) && isfinite(max_p_cost)) actual_cost[nd] += max_a_cost - max_p_cost;
+            }
+        } else { /* :257-296 */
+            float min_p_cost = INFINITY;
+            for (int d = 0; d < D; d++) {
+                float p_score = previous_cost[d];
+                if (p_score < min_p_cost && isfinite(p_score)) min_p_cost = previous_cost[d];
+            }
+            for (int nd = 0; nd < D; nd++) {
+                float min_a_cost = INFINITY;
+                float c_score = cvp[nd];
+                for (int od = 0; od < D; od++) {
+                    float p_score = previous_cost[od];
+                    if (abs(od - nd) == 1) p_score += P1;
+                    if (abs(od - nd) > 1) p_score += P2;
+                    if (p_score < min_a_cost && isfinite(p_score)) min_a_cost = c_score; /* sic, :281-283 */
+                }
+                if (j + nd >= W) min_a_cost += Pout;
+                actual_cost[nd] = c_score;
+                if (isfinite(min_a_cost) && isfinite(min_p_cost)) actual_cost[nd] += min_a_cost - min_p_cost;
+            }
+        }
+        float *sp = sgm + ((size_t)i * W + j) * D;
+        for (int d = 0; d < D; d++) sp[d] += actual_cost[d] - cvp[d]; /* :298-300 */
+        float *tmp = previous_cost;
+        previous_cost = actual_cost;
+        actual_cost = tmp;
+    }
+    free(previous_cost);
+    free(actual_cost);
+}
+
+/* Same recurrence in O(D) per pixel; must agree bitwise with traverse_line_faithful whenever      *
+ * prev[od] -/+ P stays finite for finite prev[od] (no float overflow).                            *
+ * Score: max over od of fl(prev[od] - pen(od,nd)) = fl(max prev[od] - pen) per penalty class       *
+ * because x -> fl(x - P) is monotone; the |od-nd|>1 class uses exclusive prefix/suffix maxima.     *
+ * Cost: min_a_cost is c_score as soon as one penalised prev is finite and smaller than the running *
+ * value -- reproduced with the same comparisons on the three penalty classes.                      */
+static void traverse_line_linear(int dir, int strategy, long start_i, long start_j, const float *cv, float *sgm,
+                                 int H, int W, int D, float P1, float P2, const int m[4], float Pout) {
+    const int *sv = SGM_STEPS_V[dir], *sh = SGM_STEPS_H[dir];
+    int left = m[0], top = m[1], right = m[2], bottom = m[3];
+    float *prev = (float *)malloc((size_t)D * sizeof(float));
+    float *act = (float *)malloc((size_t)D * sizeof(float));
+    float *pre = (float *)malloc((size_t)(D + 2) * sizeof(float)); /* pre[k] = ext over finite prev[0..k-1] */
+    float *suf = (float *)malloc((size_t)(D + 2) * sizeof(float)); /* suf[k] = ext over finite prev[k..D-1] */
+    for (int d = 0; d < D; d++) prev[d] = 0.0f;
+    int c, i, j;
+    for (c = 0, i = (int)start_i, j = (int)start_j;
+         (i >= top && i < H - bottom) && (j >= left && j < W - right);
+         i += sv[c % 2], j += sh[c % 2], c++) {
+        const float *cvp = cv + ((size_t)i * W + j) * D;
+        if (strategy == SO_SCORE) {
+            pre[0] = -INFINITY;
+            for (int d = 0; d < D; d++) pre[d + 1] = (isfinite(prev[d]) && prev[d] > pre[d]) ? prev[d] : pre[d];
+            suf[D] = -INFINITY;
+            suf[D + 1] = -INFINITY;
+            for (int d = D - 1; d >= 0; d--) suf[d] = (isfinite(prev[d]) && prev[d] > suf[d + 1]) ? prev[d] : suf[d + 1];
+            float max_p = pre[D];
+            for (int nd = 0; nd < D; nd++) {
+                float a = -INFINITY;
+                float far_l = (nd >= 2) ? pre[nd - 1] : -INFINITY; /* prev[0..nd-2] */
+                float far_r = suf[nd + 2 <= D ? nd + 2 : D];       /* prev[nd+2..] */
+                float far = far_l > far_r ? far_l : far_r;
+                float cand;
+                cand = prev[nd];
+                if (cand > a && isfinite(cand)) a = cand;
+                if (nd >= 1) { cand = prev[nd - 1] - P1; if (cand > a && isfinite(cand)) a = cand; }
+                if (nd + 1 < D) { cand = prev[nd + 1] - P1; if (cand > a && isfinite(cand)) a = cand; }
+                cand = far - P2;
+                if (cand > a && isfinite(cand)) a = cand;
+                if (j + nd >= W) a -= Pout;
+                act[nd] = cvp[nd];
+                if (isfinite(a) && isfinite(max_p)) act[nd] += a - max_p;
+            }
+        } else {
+            float min_p = INFINITY;
+            int nfinite = 0;
+            for (int d = 0; d < D; d++)
+                if (isfinite(prev[d])) { nfinite++; if (prev[d] < min_p) min_p = prev[d]; }
+            for (int nd = 0; nd < D; nd++) {
+                float c_score = cvp[nd];
+                /* min_a becomes c_score iff some penalised prev is finite (every finite value is < +inf) */
+                float a = nfinite > 0 ? c_score : INFINITY;
+                if (j + nd >= W) a += Pout;
+                act[nd] = c_score;
+                if (isfinite(a) && isfinite(min_p)) act[nd] += a - min_p;
+            }
+        }
+        float *sp = sgm + ((size_t)i * W + j) * D;
+        for (int d = 0; d < D; d++) sp[d] += act[d] - cvp[d];
+        float *tmp = prev;
+        prev = act;
+        act = tmp;
+    }
+    free(prev);
+    free(act);
+    free(pre);
+    free(suf);
+}
+
+typedef void (*line_fn)(int, int, long, long, const float *, float *, int, int, int, float, float, const int *, float);
+
+/* addDirectionalCost, sgm.h:313-356.  `serial` runs the lines of one start loop in index order      *
+ * (needed for the overlapping 16-direction lines, where the reference itself is a data race).       */
+static void add_directional_cost(line_fn fn, int dir, int strategy, const float *cv, float *sgm, int H, int W, int D,
+                                 float P1, float P2, const int m[4], float Pout, int serial) {
+    int colStart = start_pos(SGM_STEPS_V[dir]); /* from the vertical steps, sgm.h:167-173 */
+    int rowStart = start_pos(SGM_STEPS_H[dir]); /* from the horizontal steps, :175-181 */
+    int left = m[0], top = m[1], right = m[2], bottom = m[3];
+    if (rowStart != SGM_NOSTART) { /* :329-341 */
+        long start_j = (rowStart == SGM_ZEROPOS) ? left : W - right;
+        long bi = top, ei = H - bottom;
+#pragma omp parallel for if (!serial)
+        for (long start_i = bi; start_i < ei; start_i++) fn(dir, strategy, start_i, start_j, cv, sgm, H, W, D, P1, P2, m, Pout);
+    }
+    if (colStart != SGM_NOSTART) { /* :343-354 */
+        long start_i = (colStart == SGM_ZEROPOS) ? top : H - bottom;
+        long bj = left, ej = W - right;
+#pragma omp parallel for if (!serial)
+        for (long start_j = bj; start_j < ej; start_j++) fn(dir, strategy, start_i, start_j, cv, sgm, H, W, D, P1, P2, m, Pout);
+    }
+}
+
+/* sgmCostVolume, sgm.h:360-404.  margins = left, top, right, bottom.  variant 0 = literal O(D^2),    *
+ * 1 = O(D).                                                                                          */
+int so_sgm(int n_dir, int strategy, const float *cv, int H, int W, int D, float P1, float P2, const int margins[4],
+           float Pout, float *sgm, int variant) {
+    if (n_dir != 4 && n_dir != 8 && n_dir != 16) return 1;
+    line_fn fn = variant ? traverse_line_linear : traverse_line_faithful;
+    memcpy(sgm, cv, (size_t)H * W * D * sizeof(float)); /* :371-377 */
+    static const int order4[4] = {0, 1, 2, 3};          /* :379-382 */
+    static const int order8[4] = {4, 5, 6, 7};          /* :385-388 */
+    static const int order16[8] = {12, 13, 14, 15, 8, 9, 10, 11}; /* :392-400 */
+    for (int k = 0; k < 4; k++) add_directional_cost(fn, order4[k], strategy, cv, sgm, H, W, D, P1, P2, margins, Pout, 0);
+    if (n_dir >= 8)
+        for (int k = 0; k < 4; k++) add_directional_cost(fn, order8[k], strategy, cv, sgm, H, W, D, P1, P2, margins, Pout, 0);
+    if (n_dir >= 16)
+        for (int k = 0; k < 8; k++) add_directional_cost(fn, order16[k], strategy, cv, sgm, H, W, D, P1, P2, margins, Pout, 1);
+    return 0;
+}
+
+/* one direction alone, accumulated into a caller-initialised sgm volume (test helper) */
+int so_sgm_add_direction(int dir, int strategy, const float *cv, int H, int W, int D, float P1, float P2,
+                         const int margins[4], float Pout, float *sgm, int variant) {
+    if (dir < 0 || dir >= 16) return 1;
+    add_directional_cost(variant ? traverse_line_linear : traverse_line_faithful, dir, strategy, cv, sgm, H, W, D, P1, P2,
+                         margins, Pout, dir >= 8);
+    return 0;
+}
+
+/* ---- A10: extractSelectedIndex, correlation/correlation_base.h:427-464 ----------------------- */
+void so_extract_index(int strategy, const float *cv, int H, int W, int D, int32_t *idx) {
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const float *p = cv + ((size_t)i * W + j) * D;
+            float sel = p[0];
+            int32_t sd = 0;
+            for (int d = 1; d < D; d++) {
+                if (strategy == SO_COST) {
+                    if (p[d] <= sel) { sel = p[d]; sd = d; }
+                } else {
+                    if (p[d] >= sel) { sel = p[d]; sd = d; }
+                }
+            }
+            idx[(size_t)i * W + j] = sd;
+        }
+}
+
+/* selectedIndexToDisp, correlation_base.h:511-532 */
+void so_index_to_disp(int ddir, const int32_t *idx, int H, int W, int32_t offset, int32_t *disp) {
+    int32_t sign = (ddir == SO_RIGHT_TO_LEFT) ? 1 : -1;
+    for (size_t p = 0; p < (size_t)H * W; p++) disp[p] = sign * idx[p] + offset;
+}
+
+/* selectedCost, correlation_base.h:557-577 */
+void so_selected_cost(const float *cv, const int32_t *idx, int H, int W, int D, float *out) {
+    for (size_t p = 0; p < (size_t)H * W; p++) out[p] = cv[p * D + (uint32_t)idx[p]];
+}
+
+/* ---- A11: truncatedCostVolume, correlation_base.h:579-674 ------------------------------------ */
+int so_truncated_cv_depth(int sdir, int r) { return sdir == SO_TCV_BOTH ? 4 * r + 1 : 2 * r + 1; }
+
+void so_truncated_cost_volume(int sdir, int ddir, const float *cv, const int32_t *idx, int H, int W, int D, int h_r,
+                              int v_r, int r, float *tcv) {
+    int T = so_truncated_cv_depth(sdir, r);
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            float *o = tcv + ((size_t)i * W + j) * T;
+            int32_t sel = idx[(size_t)i * W + j];
+            for (int32_t d = 0; d <= 2 * r; d++) {
+                int32_t p = sel + d - r;
+                if (sdir == SO_TCV_SAME) { /* :601-613 */
+                    if (p < 0 || p >= D || j < h_r || j + p + h_r >= W || i < v_r || i + v_r >= H)
+                        o[d] = nanf("");
+                    else
+                        o[d] = cv[((size_t)i * W + j) * D + p];
+                } else if (sdir == SO_TCV_REVERSED) { /* :615-630 */
+                    int32_t sgn = (ddir == SO_RIGHT_TO_LEFT) ? -1 : 1;
+                    int32_t jp = j + sgn * (d - r);
+                    int32_t mn = jp < j ? jp : j, mx = jp > j ? jp : j;
+                    if (p < 0 || p >= D || mn < h_r || mx + h_r >= W || i < v_r || i + v_r >= H)
+                        o[d] = nanf("");
+                    else
+                        o[d] = cv[((size_t)i * W + jp) * D + p];
+                } else { /* Both, :632-667 */
+                    int32_t sgn = (ddir == SO_RIGHT_TO_LEFT) ? -1 : 1;
+                    int32_t jp = j + sgn * (d - r);
+                    int32_t d_d = 2 * d, d_r = 2 * d + 1;
+                    if (d == r) jp = -1;
+                    if (d > r) { d_d -= 1; d_r -= 1; }
+                    if (p < 0 || p >= D || j < h_r || j + p + h_r >= W || i < v_r || i + v_r >= H)
+                        o[d_d] = nanf("");
+                    else
+                        o[d_d] = cv[((size_t)i * W + j) * D + p];
+                    int32_t mn = jp < j ? jp : j, mx = jp > j ? jp : j;
+                    /* at d == r the reference writes tcv(i,j,d_r) with d_r == 2r+1 == slot of d=r+1's d_d;
+                       it is NaN there (jp = -1 < h_radius unless h_radius == 0 ... then value(i,-1,p)) and is
+                       overwritten by the next iteration's d_d store, so skip the out-of-bounds read. */
+                    if (d == r) continue;
+                    if (p < 0 || p >= D || mn < h_r || mx + h_r >= W || i < v_r || i + v_r >= H)
+                        o[d_r] = nanf("");
+                    else
+                        o[d_r] = cv[((size_t)i * W + jp) * D + p];
+                }
+            }
+        }
+}
+
+/* ---- A12: refineCostTriplet / refineDispCostInterpolation, cost_based_refinement.h:43-69, :128-163 */
+float so_refine_triplet(int kernel, float cm1, float c0, float c1) {
+    float val = 0;
+    switch (kernel) {
+    case SO_EQUIANGULAR: {
+        float alpha = copysignf(1.f, c0 - cm1);
+        alpha *= fmaxf(fabsf(c0 - cm1), fabsf(c1 - c0));
+        val = (c1 - cm1) / (2 * alpha);
+    } break;
+    case SO_PARABOLA:
+        val = (cm1 - c1) / (2 * (c1 - 2 * c0 + cm1));
+        break;
+    case SO_GAUSSIAN:
+        val = (logf(cm1) - logf(c1)) / (2 * (logf(c1) - 2 * logf(c0) + logf(cm1)));
+        break;
+    }
+    return val;
+}
+
+int so_refine_disp(int kernel, const float *tcv, const int32_t *raw, int H, int W, int T, float *refined) {
+    int cv_radius = (T - 1) / 2;
+    if (cv_radius < 1 || 2 * cv_radius + 1 != T) return 1; /* :141-143 */
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const float *t = tcv + ((size_t)i * W + j) * T;
+            float delta = so_refine_triplet(kernel, t[cv_radius - 1], t[cv_radius], t[cv_radius + 1]);
+            refined[(size_t)i * W + j] = (float)raw[(size_t)i * W + j] + delta;
+        }
+    return 0;
+}

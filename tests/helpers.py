@@ -1,0 +1,50 @@
+"""Shared test helpers: seeded synthetic stereo pairs and naive window formulas.
+
+The pair generator restates the recipe of the reference's generateParallaxSquareImage
+(test/test_correlation_utils.h:324-391) with a seeded numpy generator in place of
+std::random_device, as SURVEY.md section 8(d) prescribes.
+"""
+import numpy as np
+
+
+def parallax_pair(height, width, square, v_pos, h_pos, bg_parallax, sq_parallax, seed):
+    """Returns (source, target, gt_disp): float32 U(-1,1) images, background and a square
+    copied from source into target with the given parallaxes."""
+    rng = np.random.default_rng(seed)
+    height = max(height, square + v_pos)
+    width = max(width, square + h_pos + max(abs(bg_parallax), abs(sq_parallax)))
+    both = rng.uniform(-1.0, 1.0, size=(height, width, 2)).astype(np.float32)
+    source = np.ascontiguousarray(both[:, :, 0])
+    target = np.ascontiguousarray(both[:, :, 1])
+    gt = np.full((height, width), bg_parallax, np.int32)
+    jj = np.arange(width)
+    in_sq_rows = (np.arange(height) >= v_pos) & (np.arange(height) < v_pos + square)
+    in_sq_cols = (jj >= h_pos) & (jj < h_pos + square)
+    sq_mask = in_sq_rows[:, None] & in_sq_cols[None, :]
+    # background first, then the square (same write order as the reference)
+    for mask, par in ((~sq_mask, bg_parallax), (sq_mask, sq_parallax)):
+        ii, jj2 = np.nonzero(mask)
+        ok = (jj2 + par >= 0) & (jj2 + par < width)
+        target[ii[ok], jj2[ok] + par] = source[ii[ok], jj2[ok]]
+    gt[sq_mask] = sq_parallax
+    return source, target, gt
+
+
+def naive_window_cost(name, w1, w2):
+    """Formulas of the reference's in-test naive oracles (test/test_correlation_utils.h:9-310),
+    evaluated in float64 (the reference tests compare at 1e-3)."""
+    w1 = w1.astype(np.float64)
+    w2 = w2.astype(np.float64)
+    if name.startswith("Z"):
+        w1 = w1 - w1.mean()
+        w2 = w2 - w2.mean()
+        name = name[1:]
+    if name == "CC":
+        return float((w1 * w2).sum())
+    if name == "NCC":
+        return float((w1 * w2).sum() / (np.sqrt((w1 * w1).sum()) * np.sqrt((w2 * w2).sum())))
+    if name == "SSD":
+        return float(((w1 - w2) ** 2).sum())
+    if name == "SAD":
+        return float(np.abs(w1 - w2).sum())
+    raise ValueError(name)

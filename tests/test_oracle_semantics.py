@@ -1,0 +1,304 @@
+"""Hand-computed / first-principles checks for the oracle rows the reference never tests
+(census, Hamming, float round trip, SGM, argmin tie rule, truncated volume, refinement kernels).
+Pure-Python loops follow the cited reference lines literally on tiny inputs."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle as so
+
+
+def py_census(img, h_r, v_r):
+    """census.h:69-115 on top of unfold.h:247-291, literal loops."""
+    H, W = img.shape
+    h, v = 2 * h_r + 1, 2 * v_r + 1
+    F = h * v
+    nW = (F - 1) // 32 + 1
+    out = np.zeros((H, W, nW), np.uint32)
+    for i in range(H):
+        for j in range(W):
+            feat = []
+            for k in range(v):
+                for l in range(h):
+                    ii, jj = i - v_r + k, j - h_r + l
+                    feat.append(img[ii, jj] if 0 <= ii < H and 0 <= jj < W else np.float32(0))
+            ref, d, b, ch = feat[0], 0, 0, 0
+            for c in range(1, F):
+                d |= (1 if ref > feat[c] else 0) << b
+                b += 1
+                if b >= 32:
+                    out[i, j, ch] = d
+                    ch, d, b = ch + 1, 0, 0
+    return out
+
+
+@pytest.mark.parametrize("h_r,v_r", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 2), (4, 3)])
+def test_census_bits(rng, h_r, v_r):
+    img = rng.uniform(-1, 1, (9, 11)).astype(np.float32)
+    img[2, 3] = np.nan  # strict '>' makes every comparison with NaN false
+    got = so.census_transform(img, h_r, v_r)
+    assert np.array_equal(got, py_census(img, h_r, v_r))
+    F = (2 * h_r + 1) * (2 * v_r + 1)
+    # F6 / E1: words beyond floor((F-1)/32) are never written -> 0
+    assert np.all(got[:, :, (F - 1) // 32:] == 0)
+
+
+def test_census_reference_pixel_is_top_left():
+    """census.h:89 with unfold.h:180: the comparisons are against window element (k=0,l=0)."""
+    img = np.zeros((9, 9), np.float32)
+    img[0, 0] = 5.0  # top-left of the 9x9 window centred at (4,4)
+    w = so.census_transform(img, 4, 4)
+    assert w[4, 4, 0] == 0xFFFFFFFF and w[4, 4, 1] == 0xFFFFFFFF and w[4, 4, 2] == 0
+    assert w[3, 3, 0] == 0  # window top-left is outside the image -> ref = 0, nothing is smaller
+
+
+def test_census_needs_two_channels():
+    assert so.census_features(np.zeros((2, 2, 1), np.float32)).size == 0  # census.h:76-78
+
+
+@pytest.mark.parametrize("w,expected", [
+    (0, 0), (1, 1), (0x00FFFFFF, 0x00FFFFFF), (0x01000001, 0x01000000), (0x01000003, 0x01000004),
+    (0x7FFFFFFF, 0x80000000), (0xFFFFFF7F, 0xFFFFFF00), (0xFFFFFF80, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF),
+    (0x80000080, 0x80000000), (0x80000180, 0x80000200),
+])
+def test_round_word_through_float(w, expected):
+    """Rule E2: round-to-nearest-even to 24 significant bits, 2^32 saturates."""
+    assert so.round_word_through_float(w) == expected
+
+
+def test_hamming_volume_by_hand(rng):
+    """aggregateCost<CENSUS> (cross_correlations.h:194-249) with hammingDistance (matching_costs.h:236-263)."""
+    H, W, D = 5, 13, 6
+    left = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    right = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    cv = so.unfold_cost_volume(so.CENSUS, left, right, 4, 4, D)
+    wl, wr = py_census(left, 4, 4), py_census(right, 4, 4)
+    for i in range(H):
+        for j in range(W):
+            for d in range(D):
+                exp = 0
+                for k in range(3):
+                    t = so.round_word_through_float(int(wl[i, j + d, k])) if j + d < W else 0
+                    exp += bin(int(wr[i, j, k]) ^ t).count("1")
+                assert cv[i, j, d] == exp
+    assert np.array_equal(cv, so.unfold_cost_volume(so.HAMMING, left, right, 4, 4, D))
+
+
+def test_hamming_self_distance_not_zero_for_big_words(rng):
+    """F7: target words lose their low bits, so Hamming(x, x) > 0 when a word needs > 24 bits;
+    an all-ones word rounds to 2^32 and saturates back to itself (rule E2)."""
+    img = rng.uniform(-1, 1, (12, 12)).astype(np.float32)
+    cv = so.unfold_cost_volume(so.CENSUS, img, img, 4, 4, 1)
+    assert (cv[4:8, 4:8, 0] > 0).any()
+    ramp = np.tile(np.arange(12, 0, -1, dtype=np.float32), (12, 1)) + np.arange(12, 0, -1, dtype=np.float32)[:, None]
+    assert np.all(so.census_transform(ramp, 4, 4)[6, 6, :2] == 0xFFFFFFFF)
+    assert so.unfold_cost_volume(so.CENSUS, ramp, ramp, 4, 4, 1)[6, 6, 0] == 0
+
+
+def test_cost_volume_out_of_range_target_is_zero_vector(rng):
+    """cross_correlations.h:235: columns outside the target image contribute an all-zero vector."""
+    left = rng.uniform(-1, 1, (6, 8)).astype(np.float32)
+    right = rng.uniform(-1, 1, (6, 8)).astype(np.float32)
+    D = 12  # larger than the width
+    fr = so.unfold(right, 1, 1)
+    sad = so.unfold_cost_volume(so.SAD, left, right, 1, 1, D)
+    ssd = so.unfold_cost_volume(so.SSD, left, right, 1, 1, D)
+    ncc = so.unfold_cost_volume(so.NCC, left, right, 1, 1, D)
+    for j in range(8):
+        for d in range(D):
+            if j + d >= 8:
+                assert np.allclose(sad[:, j, d], np.abs(fr[:, j]).sum(-1), rtol=1e-6)
+                assert np.allclose(ssd[:, j, d], (fr[:, j] ** 2).sum(-1), rtol=1e-6)
+                assert np.all(ncc[:, j, d] == 0)
+    # LeftToRight looks at j - d
+    sad_l2r = so.unfold_cost_volume(so.SAD, left, right, 1, 1, D, ddir=so.LEFT_TO_RIGHT)
+    fl = so.unfold(left, 1, 1)
+    assert np.allclose(sad_l2r[:, 2, 5], np.abs(fl[:, 2]).sum(-1), rtol=1e-6)
+    assert np.allclose(sad_l2r[:, 5, 2], np.abs(fl[:, 5] - fr[:, 3]).sum(-1), rtol=1e-5)
+
+
+def test_cost_volume_shape_errors():
+    a = np.zeros((4, 6), np.float32)
+    b = np.zeros((5, 6), np.float32)
+    assert so.unfold_cost_volume(so.SAD, a, b, 1, 1, 3).size == 0  # cross_correlations.h:751-753
+    c = np.zeros((4, 9), np.float32)
+    assert so.unfold_cost_volume(so.SAD, a, c, 1, 1, 3).shape == (4, 9, 3)  # widths may differ; source = right
+
+
+def test_search_offset_range(rng):
+    """aggregateCost(searchOffset<1>) (cross_correlations.h:251-308): disp = lower + idx."""
+    left = rng.uniform(-1, 1, (5, 12)).astype(np.float32)
+    right = rng.uniform(-1, 1, (5, 12)).astype(np.float32)
+    full = so.unfold_cost_volume(so.SSD, left, right, 1, 1, 6)
+    off = so.unfold_cost_volume(so.SSD, left, right, 1, 1, 5, disp_lower=-2)
+    assert np.array_equal(off[:, :, 2:], full[:, :, :3])
+    fl, fr = so.unfold(left, 1, 1), so.unfold(right, 1, 1)
+    assert np.allclose(off[:, 2:, 0], ((fr[:, 2:] - fl[:, :-2]) ** 2).sum(-1), rtol=1e-5)
+    assert np.allclose(off[:, :2, 0], (fr[:, :2] ** 2).sum(-1), rtol=1e-5)  # j - 2 < 0 -> zero vector
+
+
+# ---------------------------------------------------------------- SGM ---------------------------------------
+def visits_8(H, W, margins):
+    """n(p) for the effective 8-direction set (F5)."""
+    l, t, r, b = margins
+    n = np.zeros((H, W), np.int32)
+    Hp, Wp = H - t - b, W - l - r
+    for i in range(t, H - b):
+        for j in range(l, W - r):
+            ip, jp = i - t, j - l
+            n[i, j] = 2 + 1 + (ip == jp) + (ip + jp < Wp) + (ip + jp < Hp)
+    return n
+
+
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+@pytest.mark.parametrize("margins", [(0, 0, 0, 0), (1, 2, 3, 1)])
+@pytest.mark.parametrize("integer", [True, False])
+@pytest.mark.parametrize("n_dir", [4, 8])
+def test_sgm_linear_equals_literal(rng, strategy, margins, integer, n_dir):
+    H, W, D = 11, 14, 9
+    cv = rng.integers(0, 64, (H, W, D)).astype(np.float32) if integer else rng.uniform(-1, 1, (H, W, D)).astype(np.float32)
+    for P1, P2, Pout in [(0.001, 0.01, 100.0), (2.0, 7.0, 3.0), (5.0, 1.0, 0.5)]:
+        a = so.sgm(cv, n_dir, strategy, P1, P2, margins, Pout, variant=0)
+        b = so.sgm(cv, n_dir, strategy, P1, P2, margins, Pout, variant=1)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_sgm_nonfinite_costs(rng):
+    cv = rng.uniform(-1, 1, (6, 7, 5)).astype(np.float32)
+    cv[2, 3, 1] = np.inf
+    cv[4, 1, :] = np.nan
+    cv[1, 5, 2] = -np.inf
+    for strategy in (so.COST, so.SCORE):
+        a = so.sgm(cv, 8, strategy, 0.5, 1.5, variant=0)
+        b = so.sgm(cv, 8, strategy, 0.5, 1.5, variant=1)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("margins", [(0, 0, 0, 0), (2, 1, 1, 3)])
+@pytest.mark.parametrize("shape", [(9, 13), (13, 9), (10, 10)])
+def test_sgm_coverage_and_cost_identity(rng, margins, shape):
+    """F4/F5: in the Cost branch with integer costs,
+    S = (1+n) C + n Pout [j+d>=W] - sum of per-pass minima, so argmin S = argmin of the first two terms."""
+    H, W = shape
+    D = 6
+    cv = rng.integers(0, 40, (H, W, D)).astype(np.float32)
+    Pout = 100.0
+    S = so.sgm(cv, 8, so.COST, 0.001, 0.01, margins, Pout)
+    n = visits_8(H, W, margins)
+    oob = (np.arange(W)[:, None] + np.arange(D)[None, :] >= W).astype(np.float32)
+    t = (1 + n)[:, :, None] * cv + n[:, :, None] * Pout * oob[None]
+    resid = S - t
+    # the residual is a per-pixel scalar (same for every d)
+    assert np.all(resid == resid[:, :, :1])
+    assert np.array_equal(so.extract_index(S, so.COST), so.extract_index(t, so.COST))
+    # pixels outside the margin box are untouched
+    assert np.array_equal(S[n == 0], cv[n == 0])
+
+
+def test_sgm_constant_cost_alternates():
+    """F4 verified by hand: constant cost 1, Pout unused -> contributions +1, -1, +1 ... along a line."""
+    cv = np.ones((1, 6, 3), np.float32)
+    S = so.sgm(cv, 4, so.COST, 0.5, 0.5, (0, 0, 0, 0), 0.0)
+    # Up2Down: every column is a 1-pixel line: contribution 2c - c = +1; Left2Right: +1,-1,+1,...
+    expect = 1 + 1 + np.array([1, -1, 1, -1, 1, -1], np.float32)
+    assert np.array_equal(S[0, :, 0], expect)
+
+
+def test_sgm_score_by_hand():
+    """Score branch, one line of 2 pixels, D=3 (sgm.h:218-255)."""
+    cv = np.array([[[1, 5, 2], [3, 0, 4]]], np.float32)  # H=1, W=2
+    P1, P2, Pout = np.float32(1), np.float32(3), np.float32(10)
+    S = so.sgm(cv, 4, so.SCORE, P1, P2, (0, 0, 0, 0), Pout)
+    # Up2Down (1-pixel lines): prev = 0 -> max_p = 0, max_a = 0 (prev[nd]); oob subtracts Pout
+    up = np.zeros((2, 3), np.float32)
+    for j in range(2):
+        for d in range(3):
+            up[j, d] = -Pout if j + d >= 2 else 0
+    # Left2Right pixel 0: same as above with actual = c + a ; pixel 1 uses prev = actual(pixel 0)
+    a0 = cv[0, 0] + up[0]
+    max_p = a0.max()
+    l2r1 = np.zeros(3, np.float32)
+    for nd in range(3):
+        cands = [a0[od] - (0 if od == nd else P1 if abs(od - nd) == 1 else P2) for od in range(3)]
+        a = max(cands) - (Pout if 1 + nd >= 2 else 0)
+        l2r1[nd] = (cv[0, 1, nd] + (a - max_p)) - cv[0, 1, nd]
+    assert np.allclose(S[0, 0], cv[0, 0] + up[0] + up[0])
+    assert np.allclose(S[0, 1], cv[0, 1] + up[1] + l2r1)
+
+
+def test_sgm_16_runs_and_extends_8(rng):
+    cv = rng.integers(0, 9, (7, 8, 4)).astype(np.float32)
+    s8 = so.sgm(cv, 8, so.COST, 1, 2)
+    s16 = so.sgm(cv, 16, so.COST, 1, 2)
+    assert s16.shape == s8.shape and np.all(np.isfinite(s16))
+    with pytest.raises(ValueError):
+        so.sgm(cv, 5, so.COST, 1, 2)
+
+
+# ------------------------------------------------------- winner / truncation / refinement --------------------
+def test_extract_index_rules():
+    """correlation_base.h:441-455: '<=' / '>=' scan -> last extremum wins; NaN never replaces the incumbent."""
+    cv = np.array([[[3, 1, 1, 2], [5, 5, 5, 5], [np.nan, 1, 0, 2], [2, np.nan, 2, 3], [0.0, -0.0, 1, 1]]], np.float32)
+    assert so.extract_index(cv, so.COST).tolist() == [[2, 3, 0, 2, 1]]
+    assert so.extract_index(cv, so.SCORE).tolist() == [[0, 3, 0, 3, 3]]
+
+
+def test_index_to_disp():
+    idx = np.array([[0, 3], [7, 1]], np.int32)
+    assert so.index_to_disp(idx, so.RIGHT_TO_LEFT, 2).tolist() == [[2, 5], [9, 3]]
+    assert so.index_to_disp(idx, so.LEFT_TO_RIGHT, 2).tolist() == [[2, -1], [-5, 1]]
+
+
+def test_truncated_cost_volume_borders(rng):
+    """correlation_base.h:601-613 (Same): NaN when p<0, p>=D, j<h_r, j+p+h_r>=W, i<v_r, i+v_r>=H."""
+    H, W, D, h_r, v_r, r = 7, 12, 5, 2, 1, 1
+    cv = rng.uniform(0, 1, (H, W, D)).astype(np.float32)
+    idx = rng.integers(0, D, (H, W)).astype(np.int32)
+    t = so.truncated_cost_volume(cv, idx, h_r, v_r, r)
+    assert t.shape == (H, W, 3)
+    for i in range(H):
+        for j in range(W):
+            for k in range(3):
+                p = idx[i, j] + k - r
+                bad = p < 0 or p >= D or j < h_r or j + p + h_r >= W or i < v_r or i + v_r >= H
+                if bad:
+                    assert math.isnan(t[i, j, k])
+                else:
+                    assert t[i, j, k] == cv[i, j, p]
+    both = so.truncated_cost_volume(cv, idx, h_r, v_r, r, sdir=so.TCV_BOTH)
+    assert both.shape == (H, W, 5)
+    same_slots = [0, 2, 3]  # d_d for d = 0, 1, 2 with r = 1
+    assert np.array_equal(np.isnan(both[:, :, same_slots]), np.isnan(t))
+    ok = ~np.isnan(t)
+    assert np.array_equal(both[:, :, same_slots][ok], t[ok])
+    rev = so.truncated_cost_volume(cv, idx, h_r, v_r, r, sdir=so.TCV_REVERSED)
+    for i in range(H):
+        for j in range(W):
+            for k in range(3):
+                p = idx[i, j] + k - r
+                jp = j - (k - r)  # RightToLeft -> sgn = -1 (correlation_base.h:618-621)
+                bad = p < 0 or p >= D or min(jp, j) < h_r or max(jp, j) + h_r >= W or i < v_r or i + v_r >= H
+                if bad:
+                    assert math.isnan(rev[i, j, k])
+                    if k != r:
+                        assert math.isnan(both[i, j, 2 * k + 1 - (k > r)])
+                else:
+                    assert rev[i, j, k] == cv[i, jp, p]
+                    if k != r:
+                        assert both[i, j, 2 * k + 1 - (k > r)] == cv[i, jp, p]
+
+
+def test_refine_kernels():
+    """cost_based_refinement.h:43-69."""
+    f = np.float32
+    cm1, c0, c1 = f(3.0), f(1.0), f(2.0)
+    assert so.refine_triplet(so.PARABOLA, cm1, c0, c1) == f((cm1 - c1) / (2 * (c1 - 2 * c0 + cm1)))
+    alpha = math.copysign(1.0, c0 - cm1) * max(abs(c0 - cm1), abs(c1 - c0))
+    assert so.refine_triplet(so.EQUIANGULAR, cm1, c0, c1) == f((c1 - cm1) / f(2 * alpha))
+    g = (math.log(3) - math.log(2)) / (2 * (math.log(2) - 2 * math.log(1) + math.log(3)))
+    assert abs(so.refine_triplet(so.GAUSSIAN, cm1, c0, c1) - g) < 1e-6
+    # no clamp, NaN propagates (cost_based_refinement.h:150-156)
+    tcv = np.array([[[np.nan, 1, 2], [1, 1, 1]]], np.float32)
+    out = so.refine_disp(tcv, np.array([[4, 2]], np.int32))
+    assert math.isnan(out[0, 0]) and math.isnan(out[0, 1])  # 0/0

@@ -1,0 +1,196 @@
+/*
+ * stevi_hip.h -- C ABI of libstevi_hip.so: the MI355X (gfx950) implementation of LibStevi's
+ * correlation/ hot path (cost-volume construction, SGM aggregation, winner extraction, cost-based
+ * sub-pixel refinement).
+ *
+ * The reference has no FFI layer: the path is a set of header-only function templates in
+ * namespace StereoVision::Correlation.  Each entry point below replaces one of those templates and
+ * cites it; libstevi_amd/include/ holds same-named C++ headers whose bodies marshal
+ * Multidim::Array arguments into these calls.
+ *
+ * Conventions
+ *   - every array argument is an svh_array: base pointer, dtype, memory space, shape and strides
+ *     (strides in ELEMENTS, may be any positive layout).  No ownership is ever taken.
+ *   - index order follows the reference: images (row, col[, channel]), feature volumes
+ *     (row, col, feature), cost volumes (row, col, disparity index), maps (row, col).
+ *   - SVH_HOST arrays are copied in/out synchronously; SVH_DEVICE arrays are used in place, the work
+ *     is enqueued on the context's stream and the call returns without synchronising.
+ *   - the kernels' native layout is "last index fastest, dense"; other layouts go through a
+ *     relayout kernel (device) or a strided copy (host).
+ *   - every function returns an svh_status.  SVH_EMPTY_RESULT marks the situations in which the
+ *     reference returns an empty Multidim::Array (shape mismatch etc.); outputs are untouched.
+ *   - there is no CPU fallback: without a usable HIP device every compute call fails with
+ *     SVH_ERR_NO_DEVICE / SVH_ERR_HIP.
+ */
+#ifndef STEVI_HIP_H
+#define STEVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVH_VERSION_MAJOR 0
+#define SVH_VERSION_MINOR 1
+
+typedef struct svh_context svh_context;
+
+typedef enum svh_status {
+    SVH_OK = 0,
+    SVH_EMPTY_RESULT = 1,        /* the reference would return an empty array */
+    SVH_ERR_INVALID_ARGUMENT = 2,
+    SVH_ERR_UNSUPPORTED = 3,     /* valid in the reference, not implemented on the GPU path */
+    SVH_ERR_NO_DEVICE = 4,
+    SVH_ERR_HIP = 5,
+    SVH_ERR_OUT_OF_MEMORY = 6
+} svh_status;
+
+typedef enum svh_memspace { SVH_HOST = 0, SVH_DEVICE = 1 } svh_memspace;
+
+typedef enum svh_dtype { SVH_F32 = 0, SVH_I32 = 1, SVH_U32 = 2, SVH_U8 = 3, SVH_U64 = 4 } svh_dtype;
+
+/* values of StereoVision::Correlation::matchingFunctions, correlation/matching_costs.h:38-53 */
+typedef enum svh_match_func {
+    SVH_CC = 0, SVH_NCC = 1, SVH_SSD = 2, SVH_SAD = 3, SVH_ZCC = 4, SVH_ZNCC = 5, SVH_ZSSD = 6, SVH_ZSAD = 7,
+    SVH_HAMMING = 10, SVH_CENSUS = 11
+} svh_match_func;
+
+/* dispExtractionStartegy / dispDirection / truncatedCostVolumeDirection, correlation/correlation_base.h:31-45 */
+typedef enum svh_strategy { SVH_COST = 0, SVH_SCORE = 1 } svh_strategy;
+typedef enum svh_disp_direction { SVH_LEFT_TO_RIGHT = 0, SVH_RIGHT_TO_LEFT = 1 } svh_disp_direction;
+typedef enum svh_tcv_direction { SVH_TCV_SAME = 0, SVH_TCV_REVERSED = 1, SVH_TCV_BOTH = 2 } svh_tcv_direction;
+
+/* InterpolationKernel, correlation/cost_based_refinement.h:30-35 */
+typedef enum svh_interp_kernel { SVH_EQUIANGULAR = 0, SVH_PARABOLA = 1, SVH_GAUSSIAN = 2 } svh_interp_kernel;
+
+#define SVH_MAX_DIMS 4
+
+typedef struct svh_array {
+    void *data;
+    int32_t ndim;
+    int32_t dtype;    /* svh_dtype */
+    int32_t memspace; /* svh_memspace */
+    int32_t reserved;
+    int64_t shape[SVH_MAX_DIMS];
+    int64_t strides[SVH_MAX_DIMS]; /* in elements */
+} svh_array;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+
+/* Creates a context bound to HIP device `device` (-1 = current device).  `stream` is a hipStream_t to
+ * enqueue on (e.g. the caller's / PyTorch's current stream), or NULL to let the context create its own. */
+int svh_context_create(svh_context **ctx, int device, void *stream);
+int svh_context_destroy(svh_context *ctx);
+int svh_context_set_stream(svh_context *ctx, void *stream);
+int svh_context_synchronize(svh_context *ctx);
+/* frees the cached device workspace (it is otherwise kept between calls to stay out of hipMalloc) */
+int svh_context_trim(svh_context *ctx);
+const char *svh_status_string(int status);
+/* message of the last failing call on this context ("" if none) */
+const char *svh_last_error(const svh_context *ctx);
+/* 1 when a HIP device is visible, 0 otherwise; never fails */
+int svh_device_available(void);
+
+/* Per-kernel timing with hipEvents on the context's stream.  While enabled, every kernel launch is
+ * bracketed by two events; svh_profile_collect() synchronises and folds them into per-kernel totals. */
+int svh_profile_enable(svh_context *ctx, int enable);
+int svh_profile_reset(svh_context *ctx);
+int svh_profile_collect(svh_context *ctx);
+int svh_profile_count(const svh_context *ctx);
+int svh_profile_get(const svh_context *ctx, int k, char *name, size_t name_len, double *total_ms, int64_t *launches);
+
+/* ---- A1  unfold<T_I,T_O>(h_radius, v_radius, img, padding)            correlation/unfold.h:247-344
+ * img (H,W) or (H,W,C) f32 -> out (Ho,Wo,F) f32, F=(2h_r+1)(2v_r+1)C, channel c = C(2h_r+1)k + C l + ch.
+ * pad = {left, top, right, bottom} or NULL for PaddingMargins() "auto" = (h_r, v_r). Rotate0 only. */
+int svh_unfold(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], svh_array *out);
+int svh_unfold_shape(const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], int64_t out_shape[3]);
+
+/* ---- A2  censusFeatures(features)                                      correlation/census.h:69-115
+ * feat (H,W,F) f32 -> words (H,W,nW) u32, nW=(F-1)/32+1; trailing partial word left 0.  F<=1 -> SVH_EMPTY_RESULT. */
+int svh_census_features(svh_context *ctx, const svh_array *feat, svh_array *words);
+
+/* ---- A3  censusTransform2D(img, h_radius, v_radius, padding)           correlation/census.h:117-131 */
+int svh_census_transform(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4],
+                         svh_array *words);
+
+/* ---- A6/A8  featureVolume2CostVolume<matchFunc,...,dDir,float>(feat_l, feat_r, range)
+ *                                                       correlation/cross_correlations.h:724-738 (+ :194-308, :645-722)
+ * feat_l (H,Wl,F), feat_r (H,Wr,F) f32 -> cv (H,Ws,D) f32, Ws = source width (right image for RightToLeft).
+ * disp_lower = 0 reproduces the disp_t overload; otherwise searchOffset<1>(disp_lower, disp_lower+D-1). */
+int svh_feature_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *feat_l,
+                            const svh_array *feat_r, int32_t disp_lower, int32_t disp_count, svh_array *cv);
+
+/* ---- A8  unfoldBasedCostVolume<matchFunc,...>(img_l, img_r, h_radius, v_radius, disp_width)
+ *                                                       correlation/cross_correlations.h:740-765
+ * Same result as unfold + featureVolume2CostVolume without materialising the unfolded volumes. */
+int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l,
+                           const svh_array *img_r, int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count,
+                           svh_array *cv);
+
+/* ---- A9  sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout)      correlation/sgm.h:360-404
+ * cv (H,W,D) f32 -> out (H,W,D) f32.  n_directions 4 or 8 (16 is a data race in the reference and unsupported).
+ * margins = {left, top, right, bottom}.  Reproduces the reference as written. */
+int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
+                        const int32_t margins[4], float Pout, svh_array *out);
+
+/* ---- A10 extractSelectedIndex<strategy>(cv)                         correlation/correlation_base.h:427-464
+ * cv (H,W,D) f32 -> idx (H,W) i32; ties go to the largest index, NaN never replaces the incumbent. */
+int svh_extract_selected_index(svh_context *ctx, int strategy, const svh_array *cv, svh_array *idx);
+
+/* ---- selectedIndexToDisp<disp_t,dDir>(idx, offset)                   correlation/correlation_base.h:511-532 */
+int svh_selected_index_to_disp(svh_context *ctx, int disp_direction, const svh_array *idx, int32_t disp_offset,
+                               svh_array *disp);
+
+/* ---- selectedCost(cv, idx)                                           correlation/correlation_base.h:557-577 */
+int svh_selected_cost(svh_context *ctx, const svh_array *cv, const svh_array *idx, svh_array *cost);
+
+/* ---- A11 truncatedCostVolume<float,dir,sdir>(cv, idx, h_radius, v_radius, cost_vol_radius)
+ *                                                                      correlation/correlation_base.h:579-674
+ * -> tcv (H,W,2r+1) f32 (4r+1 for SVH_TCV_BOTH), NaN outside the valid domain. */
+int svh_truncated_cost_volume(svh_context *ctx, int tcv_direction, int disp_direction, const svh_array *cv,
+                              const svh_array *idx, int h_radius, int v_radius, int cost_vol_radius, svh_array *tcv);
+
+/* ---- A12 refineDispCostInterpolation<kernel>(tcv, raw)            correlation/cost_based_refinement.h:128-163
+ * tcv (H,W,2r+1) f32, raw (H,W) i32 -> refined (H,W) f32 = raw + refineCostTriplet(...) (:43-69); no clamp.
+ * Depth not of the form 2r+1, r>=1 -> SVH_EMPTY_RESULT. */
+int svh_refine_disp_cost_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
+                                       svh_array *refined);
+
+/* ---- fused pipeline: the benchmark / stereo_refine_test call chain kept on the device ------------------
+ * unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp
+ *   (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294)
+ * -> [truncatedCostVolume -> refineDispCostInterpolation] (examples/stereo_refine_test/main.cpp:367-384).
+ * Produces bit-identical results to calling the entry points above one by one; volumes that are not
+ * requested as outputs are never written to HBM when the cost function allows it (census/Hamming). */
+typedef struct svh_stereo_params {
+    int32_t match_func;      /* svh_match_func */
+    int32_t disp_direction;  /* svh_disp_direction */
+    int32_t h_radius, v_radius;
+    int32_t disp_lower;      /* first searched offset (0 for the disp_t overload) */
+    int32_t disp_count;      /* D */
+    int32_t sgm_directions;  /* 0 = no SGM, 4 or 8 */
+    float P1, P2, Pout;
+    int32_t margins[4];      /* left, top, right, bottom */
+    int32_t refine_kernel;   /* -1 = no refinement, else svh_interp_kernel */
+    int32_t refine_h_radius, refine_v_radius; /* radii passed to truncatedCostVolume */
+    /* disparity shard for multi-GPU runs: this call handles indices [shard_begin, shard_begin+shard_count)
+     * of the D-wide range; shard_count = 0 means the whole range. */
+    int32_t shard_begin, shard_count;
+} svh_stereo_params;
+
+/* Optional outputs may be NULL.  disp (H,W) i32; refined (H,W) f32; cv / sgm_cv (H,W,D) f32;
+ * keys (H,W) u64 = order-preserving (value, index) keys of the local winner for a cross-GPU min-reduction
+ * (see svh_keys_to_index). */
+int svh_stereo_match(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
+                     svh_array *disp, svh_array *refined, svh_array *cv, svh_array *sgm_cv, svh_array *keys);
+
+/* decodes reduced keys back to selected indices / disparities (device or host arrays) */
+int svh_keys_to_index(svh_context *ctx, int strategy, const svh_array *keys, int32_t disp_count, svh_array *idx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* STEVI_HIP_H */

@@ -1,0 +1,442 @@
+"""Host-side mirror of the StereoVision::Correlation functions on the hot path.
+
+Same names, argument meaning and error behaviour as the reference templates (template parameters become
+leading keyword-free arguments).  Arrays are either numpy arrays (host memory: copied in and out by the C
+library) or torch CUDA tensors (used in place on the tensor's device, enqueued on torch's current stream);
+results come back as the same kind.  Where the reference returns an empty Multidim::Array (shape mismatch,
+bad truncated-volume depth, single-channel census) an empty array is returned.
+
+All compute goes through the C ABI of libstevi_hip.so (libstevi_amd/_capi.py); nothing here computes on the CPU.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _capi
+
+
+class matchingFunctions(enum.IntEnum):  # correlation/matching_costs.h:38-53
+    CC = 0
+    NCC = 1
+    SSD = 2
+    SAD = 3
+    ZCC = 4
+    ZNCC = 5
+    ZSSD = 6
+    ZSAD = 7
+    HAMMING = 10
+    CENSUS = 11
+
+
+class dispExtractionStartegy(enum.IntEnum):  # correlation/correlation_base.h:31-34 (spelling as in the reference)
+    Cost = 0
+    Score = 1
+
+
+class dispDirection(enum.IntEnum):  # correlation_base.h:36-39
+    LeftToRight = 0
+    RightToLeft = 1
+
+
+class truncatedCostVolumeDirection(enum.IntEnum):  # correlation_base.h:41-45
+    Same = 0
+    Reversed = 1
+    Both = 2
+
+
+class InterpolationKernel(enum.IntEnum):  # correlation/cost_based_refinement.h:30-35
+    Equiangular = 0
+    Parabola = 1
+    Gaussian = 2
+
+
+class Margins:  # utils/margins.h:24-92
+    def __init__(self, *a):
+        if len(a) == 0:
+            l = t = r = b = 0
+        elif len(a) == 1:
+            l = t = r = b = a[0]
+        elif len(a) == 2:
+            l = r = a[0]
+            t = b = a[1]
+        elif len(a) == 4:
+            l, t, r, b = a
+        else:
+            raise TypeError("Margins takes 0, 1, 2 or 4 integers")
+        self._v = (int(l), int(t), int(r), int(b))
+
+    def left(self): return self._v[0]
+    def top(self): return self._v[1]
+    def right(self): return self._v[2]
+    def bottom(self): return self._v[3]
+    def as_tuple(self): return self._v
+
+
+class PaddingMargins(Margins):  # utils/margins.h:95-163: no argument = automatic padding
+    def __init__(self, *a):
+        super().__init__(*a)
+        self._auto = len(a) == 0
+
+    def isAuto(self): return self._auto
+
+
+class searchOffset1:  # searchOffset<1>, correlation_base.h:288-409
+    def __init__(self, lower, upper):
+        self.lower, self.upper = int(lower), int(upper)
+
+    def dimRange(self): return self.upper - self.lower + 1
+
+
+def matchFuncStrategy(matchFunc):
+    """MatchingFunctionTraits<f>::extractionStrategy (matching_costs.h:419-685)."""
+    return dispExtractionStartegy.Score if int(matchFunc) in (0, 1, 4, 5) else dispExtractionStartegy.Cost
+
+
+# ------------------------------------------------------------------------------------------------ plumbing
+_NP_DTYPES = {np.dtype(np.float32): _capi.F32, np.dtype(np.int32): _capi.I32, np.dtype(np.uint32): _capi.U32,
+              np.dtype(np.uint8): _capi.U8, np.dtype(np.uint64): _capi.U64}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _torch_code(t):
+    import torch
+    table = {torch.float32: _capi.F32, torch.int32: _capi.I32, torch.uint8: _capi.U8}
+    for name, code in (("uint32", _capi.U32), ("uint64", _capi.U64)):
+        if hasattr(torch, name):
+            table[getattr(torch, name)] = code
+    if t.dtype == torch.int64:  # 8-byte keys travel as int64 tensors (torch.distributed has no uint64 reductions)
+        return _capi.U64
+    return table[t.dtype]
+
+
+class _Ctx:
+    """One svh_context per (device, stream)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, device_index=None):
+        lib = _capi.load()
+        stream = None
+        if device_index is None:
+            key = ("default",)
+        else:
+            import torch
+            stream = torch.cuda.current_stream(device_index).cuda_stream
+            key = (device_index, stream)
+        h = cls._cache.get(key)
+        if h is None:
+            h = C.c_void_p()
+            if device_index is not None:
+                import torch
+                with torch.cuda.device(device_index):
+                    st = lib.svh_context_create(C.byref(h), device_index, C.c_void_p(stream))
+            else:
+                st = lib.svh_context_create(C.byref(h), -1, None)
+            if st != _capi.OK:
+                raise _capi.SvhError(st, lib.svh_status_string(st).decode() + " (the HIP path has no CPU fallback)")
+            cls._cache[key] = h
+        return h
+
+
+def context_for(x=None):
+    """The svh_context handle used for array x (exposed for bench.py's profiling calls)."""
+    if x is not None and _is_torch(x):
+        if not x.is_cuda:
+            raise TypeError("torch tensors must live on a HIP device; pass numpy arrays for host memory")
+        return _Ctx.get(x.device.index if x.device.index is not None else 0)
+    return _Ctx.get(None)
+
+
+def _desc(x):
+    a = _capi.SvhArray()
+    if _is_torch(x):
+        a.data = x.data_ptr()
+        a.dtype = _torch_code(x)
+        a.memspace = _capi.DEVICE
+        shape, strides = tuple(x.shape), tuple(x.stride())
+    else:
+        if x.dtype not in _NP_DTYPES:
+            raise TypeError(f"unsupported dtype {x.dtype}")
+        a.data = x.ctypes.data
+        a.dtype = _NP_DTYPES[x.dtype]
+        a.memspace = _capi.HOST
+        shape = x.shape
+        strides = tuple(s // x.itemsize for s in x.strides)
+        if any(s % x.itemsize for s in x.strides):
+            raise ValueError("strides must be multiples of the item size")
+    a.ndim = len(shape)
+    for k in range(len(shape)):
+        a.shape[k] = shape[k]
+        a.strides[k] = strides[k]
+    return a
+
+
+def _like(x, shape, dtype):
+    """dtype: 'f32' | 'i32' | 'u32' | 'u64'"""
+    if _is_torch(x):
+        import torch
+        td = {"f32": torch.float32, "i32": torch.int32, "u32": getattr(torch, "uint32", torch.int32), "u64": torch.int64}[dtype]
+        return torch.empty(shape, dtype=td, device=x.device)
+    nd = {"f32": np.float32, "i32": np.int32, "u32": np.uint32, "u64": np.uint64}[dtype]
+    return np.empty(shape, nd)
+
+
+def _empty_like(x, ndim, dtype):
+    return _like(x, (0,) * ndim, dtype)
+
+
+def _prep(x, dtype=None):
+    """numpy: make sure the dtype is right; torch: must already be a CUDA tensor of the right dtype."""
+    if _is_torch(x):
+        return x
+    x = np.asarray(x)
+    if dtype is not None and x.dtype != dtype:
+        x = x.astype(dtype)
+    return x
+
+
+def _check(ctx, status):
+    if status in (_capi.OK, _capi.EMPTY_RESULT):
+        return status
+    lib = _capi.load()
+    msg = lib.svh_last_error(ctx).decode() or lib.svh_status_string(status).decode()
+    raise _capi.SvhError(status, msg)
+
+
+def _pad_arg(padding):
+    if padding is None or (isinstance(padding, PaddingMargins) and padding.isAuto()):
+        return None
+    v = padding.as_tuple() if isinstance(padding, Margins) else tuple(padding)
+    return (C.c_int32 * 4)(*v)
+
+
+def _search_range(r):
+    if isinstance(r, searchOffset1):
+        return r.lower, r.dimRange()
+    if isinstance(r, (tuple, list)):
+        return int(r[0]), int(r[1]) - int(r[0]) + 1
+    return 0, int(r)
+
+
+# ------------------------------------------------------------------------------------------------ functions
+def unfold(h_radius, v_radius, in_data, padding=None):
+    """unfold<T,T>(h_radius, v_radius, in_data, padding) -- correlation/unfold.h:247-344."""
+    lib = _capi.load()
+    x = _prep(in_data, np.float32)
+    ctx = context_for(x)
+    d = _desc(x)
+    shp = (C.c_int64 * 3)()
+    if lib.svh_unfold_shape(C.byref(d), h_radius, v_radius, _pad_arg(padding), shp) != _capi.OK:
+        raise ValueError("bad unfold arguments")
+    if shp[0] <= 0 or shp[1] <= 0:
+        return _empty_like(x, 3, "f32")
+    out = _like(x, (shp[0], shp[1], shp[2]), "f32")
+    _check(ctx, lib.svh_unfold(ctx, C.byref(d), h_radius, v_radius, _pad_arg(padding), C.byref(_desc(out))))
+    return out
+
+
+def censusFeatures(baseFeatures):
+    """censusFeatures -- correlation/census.h:69-115."""
+    lib = _capi.load()
+    x = _prep(baseFeatures, np.float32)
+    ctx = context_for(x)
+    H, W, F = x.shape
+    if F <= 1:
+        return _empty_like(x, 3, "u32")
+    out = _like(x, (H, W, (F - 1) // 32 + 1), "u32")
+    st = _check(ctx, lib.svh_census_features(ctx, C.byref(_desc(x)), C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(x, 3, "u32")
+
+
+def censusTransform2D(input, h_radius, v_radius, padding=None):
+    """censusTransform2D -- correlation/census.h:117-131."""
+    lib = _capi.load()
+    x = _prep(input, np.float32)
+    ctx = context_for(x)
+    d = _desc(x)
+    shp = (C.c_int64 * 3)()
+    if lib.svh_unfold_shape(C.byref(d), h_radius, v_radius, _pad_arg(padding), shp) != _capi.OK:
+        raise ValueError("bad census arguments")
+    if shp[0] <= 0 or shp[1] <= 0 or shp[2] <= 1:
+        return _empty_like(x, 3, "u32")
+    out = _like(x, (shp[0], shp[1], (shp[2] - 1) // 32 + 1), "u32")
+    st = _check(ctx, lib.svh_census_transform(ctx, C.byref(d), h_radius, v_radius, _pad_arg(padding), C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(x, 3, "u32")
+
+
+def featureVolume2CostVolume(matchFunc, feature_vol_l, feature_vol_r, searchRange, dDir=dispDirection.RightToLeft):
+    """featureVolume2CostVolume<matchFunc,...,dDir,float> -- correlation/cross_correlations.h:724-738."""
+    lib = _capi.load()
+    l, r = _prep(feature_vol_l, np.float32), _prep(feature_vol_r, np.float32)
+    ctx = context_for(l)
+    lower, D = _search_range(searchRange)
+    if l.shape[0] != r.shape[0]:
+        return _empty_like(l, 3, "f32")
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    out = _like(l, (src.shape[0], src.shape[1], D), "f32")
+    st = _check(ctx, lib.svh_feature_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), lower, D,
+                                                 C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(l, 3, "f32")
+
+
+def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft):
+    """unfoldBasedCostVolume<matchFunc,...> -- correlation/cross_correlations.h:740-765.
+    disp_width: an int (disp_t overload) or a searchOffset1 / (lower, upper) pair."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    lower, D = _search_range(disp_width)
+    if l.shape[0] != r.shape[0] or (l.ndim == 3 and l.shape[2] != r.shape[2]):
+        return _empty_like(l, 3, "f32")
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    out = _like(l, (src.shape[0], src.shape[1], D), "f32")
+    st = _check(ctx, lib.svh_unfold_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
+                                                lower, D, C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(l, 3, "f32")
+
+
+def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0):
+    """sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout) -- correlation/sgm.h:360-404."""
+    lib = _capi.load()
+    cv = _prep(cv_base, np.float32)
+    ctx = context_for(cv)
+    m = (margins or Margins()).as_tuple()
+    out = _like(cv, tuple(cv.shape), "f32")
+    _check(ctx, lib.svh_sgm_cost_volume(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), P1, P2, (C.c_int32 * 4)(*m), Pout,
+                                        C.byref(_desc(out))))
+    return out
+
+
+def extractSelectedIndex(strategy, costVolume):
+    """extractSelectedIndex<strategy> -- correlation/correlation_base.h:427-464."""
+    lib = _capi.load()
+    cv = _prep(costVolume, np.float32)
+    ctx = context_for(cv)
+    out = _like(cv, tuple(cv.shape[:2]), "i32")
+    _check(ctx, lib.svh_extract_selected_index(ctx, int(strategy), C.byref(_desc(cv)), C.byref(_desc(out))))
+    return out
+
+
+def selectedIndexToDisp(selectedIndex, disp_offset=0, dDir=dispDirection.RightToLeft):
+    """selectedIndexToDisp<disp_t,dDir> -- correlation_base.h:511-532."""
+    lib = _capi.load()
+    idx = _prep(selectedIndex, np.int32)
+    ctx = context_for(idx)
+    out = _like(idx, tuple(idx.shape), "i32")
+    _check(ctx, lib.svh_selected_index_to_disp(ctx, int(dDir), C.byref(_desc(idx)), int(disp_offset), C.byref(_desc(out))))
+    return out
+
+
+def selectedCost(costVolume, selectedIndex):
+    """selectedCost -- correlation_base.h:557-577."""
+    lib = _capi.load()
+    cv, idx = _prep(costVolume, np.float32), _prep(selectedIndex, np.int32)
+    ctx = context_for(cv)
+    out = _like(cv, tuple(cv.shape[:2]), "f32")
+    _check(ctx, lib.svh_selected_cost(ctx, C.byref(_desc(cv)), C.byref(_desc(idx)), C.byref(_desc(out))))
+    return out
+
+
+def truncatedCostVolume(costVolume, selectedIndex, h_radius, v_radius, cost_vol_radius, dir=dispDirection.RightToLeft,
+                        sdir=truncatedCostVolumeDirection.Same):
+    """truncatedCostVolume<T_CV,dir,sdir> -- correlation_base.h:579-674."""
+    lib = _capi.load()
+    cv, idx = _prep(costVolume, np.float32), _prep(selectedIndex, np.int32)
+    ctx = context_for(cv)
+    T = 4 * cost_vol_radius + 1 if int(sdir) == truncatedCostVolumeDirection.Both else 2 * cost_vol_radius + 1
+    out = _like(cv, (cv.shape[0], cv.shape[1], T), "f32")
+    _check(ctx, lib.svh_truncated_cost_volume(ctx, int(sdir), int(dir), C.byref(_desc(cv)), C.byref(_desc(idx)), h_radius, v_radius,
+                                              cost_vol_radius, C.byref(_desc(out))))
+    return out
+
+
+def refineDispCostInterpolation(kernel, truncatedCostVolume, rawDisparity):
+    """refineDispCostInterpolation<kernel> -- correlation/cost_based_refinement.h:128-163."""
+    lib = _capi.load()
+    tcv, raw = _prep(truncatedCostVolume, np.float32), _prep(rawDisparity, np.int32)
+    ctx = context_for(tcv)
+    out = _like(tcv, tuple(raw.shape), "f32")
+    st = _check(ctx, lib.svh_refine_disp_cost_interpolation(ctx, int(kernel), C.byref(_desc(tcv)), C.byref(_desc(raw)), C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(tcv, 2, "f32")
+
+
+def stereoMatch(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, sgmDirections=0, P1=0.001,
+                P2=0.01, Pout=100.0, margins=None, refineKernel=None, refine_h_radius=0, refine_v_radius=0, want_cv=False,
+                want_sgm_cv=False, want_keys=False, shard=None):
+    """Fused device pipeline (svh_stereo_match): unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex ->
+    selectedIndexToDisp -> [truncatedCostVolume(Same, radius 1) -> refineDispCostInterpolation].
+    Returns a dict with 'disp' and, when requested, 'refined', 'cv', 'sgm_cv', 'keys'."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    lower, D = _search_range(disp_width)
+    p = _capi.SvhStereoParams()
+    p.match_func, p.disp_direction = int(matchFunc), int(dDir)
+    p.h_radius, p.v_radius = int(h_radius), int(v_radius)
+    p.disp_lower, p.disp_count = lower, D
+    p.sgm_directions = int(sgmDirections)
+    p.P1, p.P2, p.Pout = P1, P2, Pout
+    for k, v in enumerate((margins or Margins()).as_tuple()):
+        p.margins[k] = v
+    p.refine_kernel = -1 if refineKernel is None else int(refineKernel)
+    p.refine_h_radius, p.refine_v_radius = int(refine_h_radius), int(refine_v_radius)
+    Dl = D
+    if shard is not None:
+        p.shard_begin, p.shard_count = int(shard[0]), int(shard[1])
+        Dl = int(shard[1])
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    H, W = src.shape[0], src.shape[1]
+    res = {"disp": _like(l, (H, W), "i32")}
+    if refineKernel is not None:
+        res["refined"] = _like(l, (H, W), "f32")
+    if want_cv:
+        res["cv"] = _like(l, (H, W, Dl), "f32")
+    if want_sgm_cv:
+        res["sgm_cv"] = _like(l, (H, W, Dl), "f32")
+    if want_keys:
+        res["keys"] = _like(l, (H, W), "u64")
+    descs = {k: _desc(v) for k, v in res.items()}
+
+    def ref(name):
+        return C.byref(descs[name]) if name in descs else None
+
+    st = _check(ctx, lib.svh_stereo_match(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), ref("disp"), ref("refined"), ref("cv"),
+                                          ref("sgm_cv"), ref("keys")))
+    if st != _capi.OK:
+        return {k: _empty_like(l, v.ndim, "f32") for k, v in res.items()}
+    return res
+
+
+def keysToIndex(strategy, keys, disp_count):
+    lib = _capi.load()
+    ctx = context_for(keys)
+    out = _like(keys, tuple(keys.shape), "i32")
+    _check(ctx, lib.svh_keys_to_index(ctx, int(strategy), C.byref(_desc(keys)), int(disp_count), C.byref(_desc(out))))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ profiling
+def profile_enable(x, on=True):
+    _capi.load().svh_profile_enable(context_for(x), 1 if on else 0)
+
+
+def profile_reset(x):
+    _capi.load().svh_profile_reset(context_for(x))
+
+
+def profile_collect(x):
+    """-> {kernel name: (total_ms, launches)} accumulated since the last reset."""
+    lib = _capi.load()
+    ctx = context_for(x)
+    _check(ctx, lib.svh_profile_collect(ctx))
+    out = {}
+    for k in range(lib.svh_profile_count(ctx)):
+        name = C.create_string_buffer(64)
+        ms, n = C.c_double(), C.c_int64()
+        lib.svh_profile_get(ctx, k, name, 64, C.byref(ms), C.byref(n))
+        out[name.value.decode()] = (ms.value, n.value)
+    return out

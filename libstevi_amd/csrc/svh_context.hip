@@ -1,0 +1,415 @@
+// Context, workspace pool, profiling and array marshalling for libstevi_hip.so.
+#include <cstdarg>
+
+#include "svh_internal.h"
+
+namespace svh {
+
+int fail(svh_context *ctx, int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->last_error = buf;
+    return status;
+}
+
+// ---- pool ------------------------------------------------------------------------------------------
+Scratch::~Scratch() {
+    for (size_t k : taken) ctx->pool[k].in_use = false;
+}
+
+void *Scratch::get(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~size_t(255);
+    // best fit among free blocks
+    size_t best = SIZE_MAX;
+    for (size_t k = 0; k < ctx->pool.size(); k++) {
+        const PoolBlock &b = ctx->pool[k];
+        if (!b.in_use && b.bytes >= bytes && (best == SIZE_MAX || b.bytes < ctx->pool[best].bytes)) best = k;
+    }
+    if (best != SIZE_MAX && ctx->pool[best].bytes <= 2 * bytes + (1 << 20)) {
+        ctx->pool[best].in_use = true;
+        taken.push_back(best);
+        return ctx->pool[best].ptr;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop every cached free block and retry once
+        for (auto &b : ctx->pool)
+            if (!b.in_use && b.ptr) {
+                (void)hipFree(b.ptr);
+                b.ptr = nullptr;
+                b.bytes = 0;
+            }
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            fail(ctx, SVH_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    ctx->pool.push_back({p, bytes, true});
+    taken.push_back(ctx->pool.size() - 1);
+    return p;
+}
+
+// ---- profiling -------------------------------------------------------------------------------------
+static hipEvent_t take_event(svh_context *ctx) {
+    if (!ctx->prof_free_events.empty()) {
+        hipEvent_t e = ctx->prof_free_events.back();
+        ctx->prof_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(svh_context *c, const char *n) : ctx(c), name(n) {
+    if (!ctx->profiling) return;
+    start = take_event(ctx);
+    stop = take_event(ctx);
+    if (!start || !stop) return;
+    active = true;
+    (void)hipEventRecord(start, ctx->stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(stop, ctx->stream);
+    ctx->prof_pending.push_back({name, start, stop});
+}
+
+// ---- arrays ----------------------------------------------------------------------------------------
+size_t dtype_size(int dtype) {
+    switch (dtype) {
+    case SVH_F32: case SVH_I32: case SVH_U32: return 4;
+    case SVH_U8: return 1;
+    case SVH_U64: return 8;
+    default: return 0;
+    }
+}
+
+int64_t num_elements(const svh_array &a) {
+    int64_t n = 1;
+    for (int k = 0; k < a.ndim; k++) n *= a.shape[k];
+    return n;
+}
+
+bool is_dense(const svh_array &a) {
+    int64_t expect = 1;
+    for (int k = a.ndim - 1; k >= 0; k--) {
+        if (a.shape[k] != 1 && a.strides[k] != expect) return false;
+        expect *= a.shape[k];
+    }
+    return true;
+}
+
+int validate(svh_context *ctx, const svh_array *a, const char *what, int dtype, int ndim_min, int ndim_max) {
+    if (!a) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: null array descriptor", what);
+    if (a->ndim < ndim_min || a->ndim > ndim_max || a->ndim > SVH_MAX_DIMS)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: ndim %d not in [%d,%d]", what, a->ndim, ndim_min, ndim_max);
+    if (a->dtype != dtype) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: dtype %d, expected %d", what, a->dtype, dtype);
+    if (a->memspace != SVH_HOST && a->memspace != SVH_DEVICE)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: bad memspace %d", what, a->memspace);
+    for (int k = 0; k < a->ndim; k++) {
+        if (a->shape[k] < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: negative extent", what);
+        if (a->shape[k] > 1 && a->strides[k] <= 0)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: strides must be positive", what);
+    }
+    if (num_elements(*a) > 0 && !a->data) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: null data pointer", what);
+    return SVH_OK;
+}
+
+bool any_host(std::initializer_list<const svh_array *> arrays) {
+    for (const svh_array *a : arrays)
+        if (a && a->memspace == SVH_HOST) return true;
+    return false;
+}
+
+struct Layout4 {
+    int64_t shape[4];
+    int64_t sstr[4];
+    int64_t dstr[4];
+};
+
+// element-size-generic strided copy; one thread per element, dense index order on the destination side
+template <class T>
+__global__ void relayout_kernel(const T *__restrict__ src, T *__restrict__ dst, Layout4 L, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = e;
+        int64_t i3 = r % L.shape[3];
+        r /= L.shape[3];
+        int64_t i2 = r % L.shape[2];
+        r /= L.shape[2];
+        int64_t i1 = r % L.shape[1];
+        int64_t i0 = r / L.shape[1];
+        dst[i0 * L.dstr[0] + i1 * L.dstr[1] + i2 * L.dstr[2] + i3 * L.dstr[3]] =
+            src[i0 * L.sstr[0] + i1 * L.sstr[1] + i2 * L.sstr[2] + i3 * L.sstr[3]];
+    }
+}
+
+static void dense_strides(const svh_array &a, int64_t out[4]) {
+    int64_t s = 1;
+    for (int k = 3; k >= 0; k--) {
+        int kk = k - (4 - a.ndim);
+        out[k] = s;
+        if (kk >= 0) s *= a.shape[kk];
+    }
+}
+
+static Layout4 make_layout(const svh_array &a, bool user_is_src) {
+    Layout4 L;
+    int64_t dense[4];
+    dense_strides(a, dense);
+    for (int k = 0; k < 4; k++) {
+        int kk = k - (4 - a.ndim);
+        L.shape[k] = kk >= 0 ? a.shape[kk] : 1;
+        int64_t us = kk >= 0 ? a.strides[kk] : 0;
+        L.sstr[k] = user_is_src ? us : dense[k];
+        L.dstr[k] = user_is_src ? dense[k] : us;
+    }
+    return L;
+}
+
+static int launch_relayout(svh_context *ctx, const void *src, void *dst, const Layout4 &L, int64_t n, size_t esize) {
+    if (n == 0) return SVH_OK;
+    int grid = grid_for(n, 256, 8192);
+    if (esize == 4)
+        SVH_LAUNCH(ctx, "relayout", relayout_kernel<uint32_t>, grid, 256, 0, (const uint32_t *)src, (uint32_t *)dst, L, n);
+    else if (esize == 8)
+        SVH_LAUNCH(ctx, "relayout", relayout_kernel<uint64_t>, grid, 256, 0, (const uint64_t *)src, (uint64_t *)dst, L, n);
+    else
+        SVH_LAUNCH(ctx, "relayout", relayout_kernel<uint8_t>, grid, 256, 0, (const uint8_t *)src, (uint8_t *)dst, L, n);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+template <class T> static void host_strided_copy(const T *src, T *dst, const Layout4 &L) {
+    for (int64_t i0 = 0; i0 < L.shape[0]; i0++)
+        for (int64_t i1 = 0; i1 < L.shape[1]; i1++)
+            for (int64_t i2 = 0; i2 < L.shape[2]; i2++)
+                for (int64_t i3 = 0; i3 < L.shape[3]; i3++)
+                    dst[i0 * L.dstr[0] + i1 * L.dstr[1] + i2 * L.dstr[2] + i3 * L.dstr[3]] =
+                        src[i0 * L.sstr[0] + i1 * L.sstr[1] + i2 * L.sstr[2] + i3 * L.sstr[3]];
+}
+
+static void host_copy(const void *src, void *dst, const Layout4 &L, size_t esize) {
+    if (esize == 4) host_strided_copy((const uint32_t *)src, (uint32_t *)dst, L);
+    else if (esize == 8) host_strided_copy((const uint64_t *)src, (uint64_t *)dst, L);
+    else host_strided_copy((const uint8_t *)src, (uint8_t *)dst, L);
+}
+
+int stage_in(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr) {
+    int64_t n = num_elements(a);
+    size_t es = dtype_size(a.dtype);
+    bool dense = is_dense(a);
+    if (a.memspace == SVH_DEVICE && dense) {
+        *dptr = a.data;
+        return SVH_OK;
+    }
+    void *buf = scr.get((size_t)n * es);
+    if (!buf) return SVH_ERR_OUT_OF_MEMORY;
+    *dptr = buf;
+    if (n == 0) return SVH_OK;
+    if (a.memspace == SVH_DEVICE) return launch_relayout(ctx, a.data, buf, make_layout(a, true), n, es);
+    if (dense) {
+        SVH_HIP_CHECK(ctx, hipMemcpyAsync(buf, a.data, (size_t)n * es, hipMemcpyHostToDevice, ctx->stream));
+        // the source may be pageable and reused by the caller right after we return
+        SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return SVH_OK;
+    }
+    std::vector<uint8_t> packed((size_t)n * es);
+    host_copy(a.data, packed.data(), make_layout(a, true), es);
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(buf, packed.data(), (size_t)n * es, hipMemcpyHostToDevice, ctx->stream));
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SVH_OK;
+}
+
+int stage_out(svh_context *ctx, Scratch &scr, const svh_array &a, OutStage *st) {
+    st->dst = &a;
+    if (a.memspace == SVH_DEVICE && is_dense(a)) {
+        st->dptr = a.data;
+        st->direct = true;
+        return SVH_OK;
+    }
+    st->direct = false;
+    st->dptr = scr.get((size_t)num_elements(a) * dtype_size(a.dtype));
+    if (!st->dptr) return SVH_ERR_OUT_OF_MEMORY;
+    (void)ctx;
+    return SVH_OK;
+}
+
+int finish_out(svh_context *ctx, const OutStage &st) {
+    if (st.direct || !st.dst) return SVH_OK;
+    const svh_array &a = *st.dst;
+    int64_t n = num_elements(a);
+    size_t es = dtype_size(a.dtype);
+    if (n == 0) return SVH_OK;
+    if (a.memspace == SVH_DEVICE) return launch_relayout(ctx, st.dptr, a.data, make_layout(a, false), n, es);
+    if (is_dense(a)) {
+        SVH_HIP_CHECK(ctx, hipMemcpyAsync(a.data, st.dptr, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
+        SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return SVH_OK;
+    }
+    std::vector<uint8_t> packed((size_t)n * es);
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(packed.data(), st.dptr, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    host_copy(packed.data(), a.data, make_layout(a, false), es);
+    return SVH_OK;
+}
+
+} // namespace svh
+
+using namespace svh;
+
+extern "C" {
+
+int svh_device_available(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? 1 : 0;
+}
+
+int svh_context_create(svh_context **out, int device, void *stream) {
+    if (!out) return SVH_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SVH_ERR_NO_DEVICE;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return SVH_ERR_HIP;
+    }
+    if (device >= n) return SVH_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device) != hipSuccess) return SVH_ERR_HIP;
+    svh_context *ctx = new svh_context();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return SVH_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return SVH_OK;
+}
+
+int svh_context_destroy(svh_context *ctx) {
+    if (!ctx) return SVH_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->pool)
+        if (b.ptr) (void)hipFree(b.ptr);
+    for (auto &p : ctx->prof_pending) {
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
+    }
+    for (auto e : ctx->prof_free_events) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SVH_OK;
+}
+
+int svh_context_set_stream(svh_context *ctx, void *stream) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) {
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        SVH_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return SVH_OK;
+}
+
+int svh_context_synchronize(svh_context *ctx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SVH_OK;
+}
+
+int svh_context_trim(svh_context *ctx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<PoolBlock> keep;
+    for (auto &b : ctx->pool) {
+        if (b.in_use) keep.push_back(b);
+        else if (b.ptr) (void)hipFree(b.ptr);
+    }
+    ctx->pool.swap(keep);
+    return SVH_OK;
+}
+
+const char *svh_status_string(int status) {
+    switch (status) {
+    case SVH_OK: return "ok";
+    case SVH_EMPTY_RESULT: return "empty result (the reference returns an empty array for these arguments)";
+    case SVH_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case SVH_ERR_UNSUPPORTED: return "unsupported on the GPU path";
+    case SVH_ERR_NO_DEVICE: return "no HIP device available";
+    case SVH_ERR_HIP: return "HIP runtime error";
+    case SVH_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+const char *svh_last_error(const svh_context *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int svh_profile_enable(svh_context *ctx, int enable) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    ctx->profiling = enable != 0;
+    return SVH_OK;
+}
+
+int svh_profile_collect(svh_context *ctx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            auto it = ctx->prof_stats.find(p.name);
+            if (it == ctx->prof_stats.end()) {
+                ctx->prof_order.push_back(p.name);
+                it = ctx->prof_stats.emplace(p.name, ProfStat()).first;
+            }
+            it->second.total_ms += ms;
+            it->second.launches += 1;
+        }
+        ctx->prof_free_events.push_back(p.start);
+        ctx->prof_free_events.push_back(p.stop);
+    }
+    ctx->prof_pending.clear();
+    return SVH_OK;
+}
+
+int svh_profile_reset(svh_context *ctx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    int s = svh_profile_collect(ctx);
+    ctx->prof_stats.clear();
+    ctx->prof_order.clear();
+    return s;
+}
+
+int svh_profile_count(const svh_context *ctx) { return ctx ? (int)ctx->prof_order.size() : 0; }
+
+int svh_profile_get(const svh_context *ctx, int k, char *name, size_t name_len, double *total_ms, int64_t *launches) {
+    if (!ctx || k < 0 || k >= (int)ctx->prof_order.size()) return SVH_ERR_INVALID_ARGUMENT;
+    const std::string &n = ctx->prof_order[k];
+    const ProfStat &s = ctx->prof_stats.at(n);
+    if (name && name_len) {
+        strncpy(name, n.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    return SVH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,325 @@
+// Cost-volume construction (A4-A8): aggregateCost over processed feature vectors.
+//
+// CV(i,j,d) = cmp(src(i,j,:), tgt(i, j + sign*(disp_lower+d), :)), with an all-zero target vector where the
+// target column falls outside the image (correlation/cross_correlations.h:235, :294).  The processed feature
+// (zero-mean / normalised, cross_correlations.h:416-594) is evaluated on the fly from per-pixel mean and
+// norm maps, with the same float operations and the same channel order as the reference, so no H x W x F
+// volume is ever written.  Volumes are stored (row, col, disparity) with the disparity fastest: one pixel's D
+// costs are contiguous, which is what the per-line SGM kernels and the winner scan want.
+#include "svh_internal.h"
+
+namespace svh {
+
+// ---- feature accessors ----------------------------------------------------------------------------
+struct FeatVolume { // dense (H, W, F)
+    const float *f;
+    int W, F;
+    __device__ __forceinline__ int count() const { return F; }
+};
+struct FeatImage { // unfold on the fly: (H, W, C) image, window (2v_r+1) x (2h_r+1), auto padding
+    const float *img;
+    int H, W, C, h_r, v_r;
+    __device__ __forceinline__ int count() const { return (2 * h_r + 1) * (2 * v_r + 1) * C; }
+};
+
+// sequential walk over the channels of pixel (i, j); `valid` false yields an all-zero raw vector
+struct VolumeCursor {
+    const float *p;
+    __device__ __forceinline__ VolumeCursor(const FeatVolume &a, int i, int j) : p(a.f + ((int64_t)i * a.W + j) * a.F) {}
+    __device__ __forceinline__ float next() { return *p++; }
+};
+struct ImageCursor {
+    const FeatImage &a;
+    int i0, j0, k = 0, l = 0, ch = 0;
+    __device__ __forceinline__ ImageCursor(const FeatImage &acc, int i, int j) : a(acc), i0(i - acc.v_r), j0(j - acc.h_r) {}
+    __device__ __forceinline__ float next() {
+        int ii = i0 + k, jj = j0 + l;
+        float v = (ii >= 0 && ii < a.H && jj >= 0 && jj < a.W) ? a.img[((int64_t)ii * a.W + jj) * a.C + ch] : 0.0f;
+        if (++ch == a.C) {
+            ch = 0;
+            if (++l == 2 * a.h_r + 1) {
+                l = 0;
+                ++k;
+            }
+        }
+        return v;
+    }
+};
+template <class A> struct CursorOf;
+template <> struct CursorOf<FeatVolume> { using type = VolumeCursor; };
+template <> struct CursorOf<FeatImage> { using type = ImageCursor; };
+
+// ---- per-pixel statistics (A7) ---------------------------------------------------------------------
+// mean: channelsMean, correlation_base.h:1100-1136 (sequential sum, then * float(1./F))
+// norm: channelsNorm cross_correlations.h:149-191 or channelsZeroMeanNorm :61-104 (sqrtf of sequential sum)
+template <class A>
+__global__ void stats_kernel(A acc, int H, int W, bool zero_mean, bool normalized, float *__restrict__ mean,
+                             float *__restrict__ norm) {
+    const int64_t npx = (int64_t)H * W;
+    const int F = acc.count();
+    const float scale = (float)(1. / (double)(float)F);
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        int j = (int)(p % W), i = (int)(p / W);
+        float m = 0.0f;
+        if (zero_mean) {
+            typename CursorOf<A>::type cur(acc, i, j);
+            for (int c = 0; c < F; c++) m += cur.next();
+            m *= scale;
+            mean[p] = m;
+        }
+        if (normalized) {
+            typename CursorOf<A>::type cur(acc, i, j);
+            float n = 0.0f;
+            for (int c = 0; c < F; c++) {
+                float tmp = cur.next() - m; // m == 0 without zero-mean: x - 0 is exact
+                n += tmp * tmp;
+            }
+            norm[p] = sqrtf(n);
+        }
+    }
+}
+
+enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
+
+// one thread per voxel, disparity fastest (coalesced stores; the source vector is wave-uniform for D >= 64)
+template <class A, int CMP, bool ZM, bool NORM>
+__global__ void cost_volume_kernel(A src, A tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
+                                   const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
+                                   int D, int sign, int disp_lower, float *__restrict__ cv) {
+    const int64_t n = (int64_t)H * Ws * D;
+    const int F = src.count();
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        int d = (int)(e % D);
+        int64_t p = e / D;
+        int j = (int)(p % Ws), i = (int)(p / Ws);
+        int jt = j + sign * (disp_lower + d);
+        bool t_in = jt >= 0 && jt < Wt;
+        float ms = ZM ? mean_s[p] : 0.0f;
+        float ns = NORM ? norm_s[p] : 1.0f;
+        float mt = 0.0f, nt = 1.0f;
+        if (t_in) {
+            int64_t pt = (int64_t)i * Wt + jt;
+            if (ZM) mt = mean_t[pt];
+            if (NORM) nt = norm_t[pt];
+        }
+        typename CursorOf<A>::type cs(src, i, j);
+        typename CursorOf<A>::type ct(tgt, i, t_in ? jt : 0);
+        float score = 0.0f;
+        for (int c = 0; c < F; c++) {
+            float s = cs.next();
+            float t = ct.next();
+            if (ZM) s = s - ms;
+            if (NORM) s = s / ns;
+            if (t_in) {
+                if (ZM) t = t - mt;
+                if (NORM) t = t / nt;
+            } else {
+                t = 0.0f;
+            }
+            if (CMP == CMP_DOT) {
+                score += s * t; // dotProduct, matching_costs.h:59-78
+            } else if (CMP == CMP_SSD) {
+                float tmp = s - t; // SumSquareDiff, :100-116
+                score += tmp * tmp;
+            } else {
+                float tmp = s - t; // SumAbsDiff, :136-156
+                score += fabsf(tmp);
+            }
+        }
+        cv[e] = score;
+    }
+}
+
+// Hamming volume from compact census words (only the fully written words are kept, the never-written trailing
+// word is 0 on both sides and contributes nothing).  hammingDistance, matching_costs.h:236-263: the sum is a
+// uint16_t returned as float.  Target words were rounded through float when they were produced (rule E2); a
+// target column outside the image is the zero vector, so the cost is popcount(source).
+__global__ void hamming_volume_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int nWw, int H, int Ws,
+                                      int Wt, int D, int sign, int disp_lower, float *__restrict__ cv) {
+    const int64_t n = (int64_t)H * Ws * D;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        int d = (int)(e % D);
+        int64_t p = e / D;
+        int j = (int)(p % Ws), i = (int)(p / Ws);
+        int jt = j + sign * (disp_lower + d);
+        bool t_in = jt >= 0 && jt < Wt;
+        const uint32_t *s = sw + p * nWw;
+        const uint32_t *t = tw + ((int64_t)i * Wt + (t_in ? jt : 0)) * nWw;
+        uint32_t score = 0;
+        for (int w = 0; w < nWw; w++) score += __popc(s[w] ^ (t_in ? t[w] : 0u));
+        cv[e] = (float)(uint16_t)score;
+    }
+}
+
+template <class A>
+static int launch_stats(svh_context *ctx, A acc, int H, int W, bool zm, bool nrm, float *mean, float *norm) {
+    int64_t npx = (int64_t)H * W;
+    if (npx == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "window_stats", (stats_kernel<A>), grid_for(npx, 256, 16384), 256, 0, acc, H, W, zm, nrm, mean, norm);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+template <class A, int CMP>
+static int launch_cv(svh_context *ctx, bool zm, bool nrm, A src, A tgt, const float *ms, const float *ns, const float *mt,
+                     const float *nt, const CostVolumeArgs &a, float *cv) {
+    int64_t n = (int64_t)a.H * a.Ws * a.D;
+    int grid = grid_for(n, 256, 65536);
+    int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+#define SVH_CV_LAUNCH(ZM, NORM)                                                                                          \
+    SVH_LAUNCH(ctx, "cost_volume", (cost_volume_kernel<A, CMP, ZM, NORM>), grid, 256, 0, src, tgt, ms, ns, mt, nt, a.H, a.Ws, \
+               a.Wt, a.D, sign, a.disp_lower, cv)
+    if (zm && nrm) SVH_CV_LAUNCH(true, true);
+    else if (zm) SVH_CV_LAUNCH(true, false);
+    else if (nrm) SVH_CV_LAUNCH(false, true);
+    else SVH_CV_LAUNCH(false, false);
+#undef SVH_CV_LAUNCH
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+template <class A>
+static int cost_volume_generic(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, A src, A tgt, float *cv) {
+    if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
+    bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
+    float *ms = nullptr, *ns = nullptr, *mt = nullptr, *nt = nullptr;
+    if (zm) {
+        ms = scr.get_n<float>((size_t)a.H * a.Ws);
+        mt = scr.get_n<float>((size_t)a.H * a.Wt);
+        if (!ms || !mt) return SVH_ERR_OUT_OF_MEMORY;
+    }
+    if (nrm) {
+        ns = scr.get_n<float>((size_t)a.H * a.Ws);
+        nt = scr.get_n<float>((size_t)a.H * a.Wt);
+        if (!ns || !nt) return SVH_ERR_OUT_OF_MEMORY;
+    }
+    if (zm || nrm) {
+        SVH_TRY(launch_stats(ctx, src, a.H, a.Ws, zm, nrm, ms, ns));
+        SVH_TRY(launch_stats(ctx, tgt, a.H, a.Wt, zm, nrm, mt, nt));
+    }
+    switch (a.func) {
+    case SVH_CC: case SVH_NCC: case SVH_ZCC: case SVH_ZNCC:
+        return launch_cv<A, CMP_DOT>(ctx, zm, nrm, src, tgt, ms, ns, mt, nt, a, cv);
+    case SVH_SSD: case SVH_ZSSD:
+        return launch_cv<A, CMP_SSD>(ctx, zm, nrm, src, tgt, ms, ns, mt, nt, a, cv);
+    case SVH_SAD: case SVH_ZSAD:
+        return launch_cv<A, CMP_SAD>(ctx, zm, nrm, src, tgt, ms, ns, mt, nt, a, cv);
+    default:
+        return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d is not available on the GPU path", a.func);
+    }
+}
+
+int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *src_words, const uint32_t *tgt_words, int nWw,
+                       float *cv) {
+    int64_t n = (int64_t)a.H * a.Ws * a.D;
+    if (n == 0) return SVH_OK;
+    int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+    SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_kernel, grid_for(n, 256, 65536), 256, 0, src_words, tgt_words, nWw, a.H, a.Ws,
+               a.Wt, a.D, sign, a.disp_lower, cv);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_cost_volume_from_features(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, const float *feat_src,
+                                  const float *feat_tgt, int F, float *cv) {
+    if (func_census(a.func)) {
+        int nWw = census_words_written(F);
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)a.H * a.Ws * (nWw ? nWw : 1));
+        uint32_t *tw = scr.get_n<uint32_t>((size_t)a.H * a.Wt * (nWw ? nWw : 1));
+        if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_from_features(ctx, feat_src, a.H, a.Ws, F, nWw, false, sw));
+        SVH_TRY(dev_census_from_features(ctx, feat_tgt, a.H, a.Wt, F, nWw, true, tw));
+        return dev_hamming_volume(ctx, a, sw, tw, nWw, cv);
+    }
+    return cost_volume_generic(ctx, scr, a, FeatVolume{feat_src, a.Ws, F}, FeatVolume{feat_tgt, a.Wt, F}, cv);
+}
+
+int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r,
+                                int v_r, float *cv) {
+    if (func_census(a.func)) {
+        int F = (2 * h_r + 1) * (2 * v_r + 1) * src.C;
+        int nWw = census_words_written(F);
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)a.H * a.Ws * (nWw ? nWw : 1));
+        uint32_t *tw = scr.get_n<uint32_t>((size_t)a.H * a.Wt * (nWw ? nWw : 1));
+        if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_from_image(ctx, src, h_r, v_r, h_r, v_r, a.H, a.Ws, nWw, false, sw));
+        SVH_TRY(dev_census_from_image(ctx, tgt, h_r, v_r, h_r, v_r, a.H, a.Wt, nWw, true, tw));
+        return dev_hamming_volume(ctx, a, sw, tw, nWw, cv);
+    }
+    return cost_volume_generic(ctx, scr, a, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r},
+                               FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, cv);
+}
+
+} // namespace svh
+
+using namespace svh;
+
+extern "C" {
+
+int svh_feature_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *feat_l,
+                            const svh_array *feat_r, int32_t disp_lower, int32_t disp_count, svh_array *cv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, feat_l, "feat_l", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, feat_r, "feat_r", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    // aggregateCost: cross_correlations.h:209-211
+    if (feat_l->shape[0] != feat_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ");
+    if (feat_l->shape[2] != feat_r->shape[2]) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "feature counts differ");
+    if (disp_count <= 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp_count must be positive");
+    int F = (int)feat_l->shape[2];
+    if (func_census(match_func) && F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    bool r2l = disp_direction == SVH_RIGHT_TO_LEFT;
+    const svh_array *src = r2l ? feat_r : feat_l, *tgt = r2l ? feat_l : feat_r; // condImgRef, correlation_base.h:829-878
+    CostVolumeArgs a{match_func, disp_direction, (int)src->shape[0], (int)src->shape[1], (int)tgt->shape[1], disp_lower, disp_count};
+    if (cv->shape[0] != a.H || cv->shape[1] != a.Ws || cv->shape[2] != a.D)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv must have shape (%d,%d,%d)", a.H, a.Ws, a.D);
+    Scratch scr(ctx);
+    void *ds, *dt;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *src, &ds));
+    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_out(ctx, scr, *cv, &os));
+    SVH_TRY(dev_cost_volume_from_features(ctx, scr, a, (const float *)ds, (const float *)dt, F, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l,
+                           const svh_array *img_r, int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count,
+                           svh_array *cv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (h_radius < 0 || v_radius < 0 || h_radius > 255 || v_radius > 255)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255] (uint8_t in the reference)");
+    if (img_l->ndim != img_r->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "image ranks differ");
+    // unfoldBasedCostVolume: cross_correlations.h:751-759
+    if (img_l->shape[0] != img_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ");
+    int C = img_l->ndim == 3 ? (int)img_l->shape[2] : 1;
+    if (img_l->ndim == 3 && img_l->shape[2] != img_r->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "channel counts differ");
+    if (disp_count <= 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp_count must be positive");
+    int F = (2 * h_radius + 1) * (2 * v_radius + 1) * C;
+    if (func_census(match_func) && F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    bool r2l = disp_direction == SVH_RIGHT_TO_LEFT;
+    const svh_array *src = r2l ? img_r : img_l, *tgt = r2l ? img_l : img_r;
+    CostVolumeArgs a{match_func, disp_direction, (int)src->shape[0], (int)src->shape[1], (int)tgt->shape[1], disp_lower, disp_count};
+    if (cv->shape[0] != a.H || cv->shape[1] != a.Ws || cv->shape[2] != a.D)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv must have shape (%d,%d,%d)", a.H, a.Ws, a.D);
+    Scratch scr(ctx);
+    void *ds, *dt;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *src, &ds));
+    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_out(ctx, scr, *cv, &os));
+    SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, {(const float *)ds, a.H, a.Ws, C}, {(const float *)dt, a.H, a.Wt, C}, h_radius,
+                                        v_radius, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+} // extern "C"

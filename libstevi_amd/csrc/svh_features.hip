@@ -1,0 +1,216 @@
+// unfold (A1), census features / transform (A2, A3).
+//
+// The image-based census never materialises the unfolded volume: one thread per output pixel walks the
+// window in channel order (c = C(2h_r+1)k + C l + ch, correlation/unfold.h:180) and packs comparisons
+// against channel 0 (the window's top-left sample, correlation/census.h:89) into 32-bit words, storing a
+// word only when it is full (census.h:103-108).  Images are a few MB and stay in L2; neighbouring threads
+// read overlapping windows, so the loads are L1/L2 hits.
+#include "svh_internal.h"
+
+namespace svh {
+
+__device__ __forceinline__ float image_or_zero(const float *__restrict__ img, int H, int W, int C, int i, int j, int ch) {
+    // valueOrAlt({i,j[,c]}, 0): correlation/unfold.h:284, :335
+    return (i >= 0 && i < H && j >= 0 && j < W) ? img[((int64_t)i * W + j) * C + ch] : 0.0f;
+}
+
+// rule E2: `float t = word; word' = t;` of cross_correlations.h:235-236.
+// v_cvt_f32_u32 rounds to nearest even, v_cvt_u32_f32 saturates 2^32 to 0xFFFFFFFF.
+__device__ __forceinline__ uint32_t round_word_through_float(uint32_t w) {
+    float t = (float)w;
+    return t >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+__global__ void unfold_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, int pl, int pt, int Ho,
+                              int Wo, float *__restrict__ out) {
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    const int F = h * v * C;
+    const int64_t n = (int64_t)Ho * Wo * F;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(e % F);
+        int64_t p = e / F;
+        int j = (int)(p % Wo), i = (int)(p / Wo);
+        int ch = c % C;
+        int l = (c / C) % h;
+        int k = c / (C * h);
+        out[e] = image_or_zero(img, H, W, C, i - pt + k, j - pl + l, ch);
+    }
+}
+
+__global__ void census_image_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, int pl, int pt,
+                                    int Ho, int Wo, int n_out, int n_written, bool round_target,
+                                    uint32_t *__restrict__ words) {
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    const int64_t npx = (int64_t)Ho * Wo;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        int j = (int)(p % Wo), i = (int)(p / Wo);
+        const float ref = image_or_zero(img, H, W, C, i - pt, j - pl, 0);
+        uint32_t *o = words + p * n_out;
+        uint32_t d = 0;
+        int b = 0, word = 0;
+        int c = 0;
+        for (int k = 0; k < v && word < n_written; k++) {
+            for (int l = 0; l < h && word < n_written; l++) {
+                for (int ch = 0; ch < C; ch++, c++) {
+                    if (c == 0) continue; // channel 0 is the reference sample itself
+                    if (word >= n_written) break;
+                    float val = image_or_zero(img, H, W, C, i - pt + k, j - pl + l, ch);
+                    d |= (ref > val ? 1u : 0u) << b;
+                    if (++b == 32) {
+                        o[word++] = round_target ? round_word_through_float(d) : d;
+                        d = 0;
+                        b = 0;
+                    }
+                }
+            }
+        }
+        for (int w = n_written; w < n_out; w++) o[w] = 0; // rule E1: never-written trailing word
+    }
+}
+
+__global__ void census_features_kernel(const float *__restrict__ feat, int64_t npx, int F, int n_out, int n_written,
+                                       bool round_target, uint32_t *__restrict__ words) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const float *f = feat + p * F;
+        uint32_t *o = words + p * n_out;
+        const float ref = f[0];
+        for (int w = 0; w < n_written; w++) {
+            uint32_t d = 0;
+            for (int b = 0; b < 32; b++) d |= (ref > f[1 + 32 * w + b] ? 1u : 0u) << b;
+            o[w] = round_target ? round_word_through_float(d) : d;
+        }
+        for (int w = n_written; w < n_out; w++) o[w] = 0;
+    }
+}
+
+int dev_unfold(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt, int Ho, int Wo, float *out) {
+    int64_t n = (int64_t)Ho * Wo * (2 * h_r + 1) * (2 * v_r + 1) * img.C;
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "unfold", unfold_kernel, grid_for(n, 256, 16384), 256, 0, img.data, img.H, img.W, img.C, h_r, v_r, pl, pt, Ho,
+               Wo, out);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt, int Ho, int Wo, int n_out,
+                          bool round_through_float, uint32_t *words) {
+    int64_t npx = (int64_t)Ho * Wo;
+    if (npx == 0 || n_out == 0) return SVH_OK;
+    int F = (2 * h_r + 1) * (2 * v_r + 1) * img.C;
+    SVH_LAUNCH(ctx, "census_transform", census_image_kernel, grid_for(npx, 256, 16384), 256, 0, img.data, img.H, img.W, img.C, h_r,
+               v_r, pl, pt, Ho, Wo, n_out, census_words_written(F), round_through_float, words);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, int F, int n_out, bool round_through_float,
+                             uint32_t *words) {
+    int64_t npx = (int64_t)H * W;
+    if (npx == 0 || n_out == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "census_features", census_features_kernel, grid_for(npx, 256, 16384), 256, 0, feat, npx, F, n_out,
+               census_words_written(F), round_through_float, words);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+} // namespace svh
+
+using namespace svh;
+
+static int image_desc(svh_context *ctx, const svh_array *img, const char *what, int *H, int *W, int *C) {
+    SVH_TRY(validate(ctx, img, what, SVH_F32, 2, 3));
+    *H = (int)img->shape[0];
+    *W = (int)img->shape[1];
+    *C = img->ndim == 3 ? (int)img->shape[2] : 1;
+    return SVH_OK;
+}
+
+static void unfold_geometry(int H, int W, int C, int h_r, int v_r, const int32_t pad[4], int *pl, int *pt, int *Ho, int *Wo,
+                            int *F) {
+    // correlation/unfold.h:256-270
+    int l = pad ? pad[0] : h_r, t = pad ? pad[1] : v_r, r = pad ? pad[2] : h_r, b = pad ? pad[3] : v_r;
+    int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    *pl = l;
+    *pt = t;
+    *Ho = H - v + t + b + 1;
+    *Wo = W - h + l + r + 1;
+    *F = h * v * C;
+}
+
+extern "C" {
+
+int svh_unfold_shape(const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], int64_t out_shape[3]) {
+    if (!img || !out_shape || img->ndim < 2 || img->ndim > 3 || h_radius < 0 || v_radius < 0) return SVH_ERR_INVALID_ARGUMENT;
+    int pl, pt, Ho, Wo, F;
+    unfold_geometry((int)img->shape[0], (int)img->shape[1], img->ndim == 3 ? (int)img->shape[2] : 1, h_radius, v_radius, pad, &pl,
+                    &pt, &Ho, &Wo, &F);
+    out_shape[0] = Ho;
+    out_shape[1] = Wo;
+    out_shape[2] = F;
+    return SVH_OK;
+}
+
+int svh_unfold(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], svh_array *out) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    int H, W, C;
+    SVH_TRY(image_desc(ctx, img, "img", &H, &W, &C));
+    SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
+    if (h_radius < 0 || v_radius < 0 || h_radius > 255 || v_radius > 255)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255] (uint8_t in the reference)");
+    int pl, pt, Ho, Wo, F;
+    unfold_geometry(H, W, C, h_radius, v_radius, pad, &pl, &pt, &Ho, &Wo, &F);
+    if (Ho <= 0 || Wo <= 0) return fail(ctx, SVH_EMPTY_RESULT, "unfold output is empty");
+    if (out->shape[0] != Ho || out->shape[1] != Wo || out->shape[2] != F)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have shape (%d,%d,%d)", Ho, Wo, F);
+    Scratch scr(ctx);
+    void *dimg;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img, &dimg));
+    SVH_TRY(stage_out(ctx, scr, *out, &os));
+    SVH_TRY(dev_unfold(ctx, {(const float *)dimg, H, W, C}, h_radius, v_radius, pl, pt, Ho, Wo, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_census_features(svh_context *ctx, const svh_array *feat, svh_array *words) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, feat, "feat", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, words, "words", SVH_U32, 3, 3));
+    int H = (int)feat->shape[0], W = (int)feat->shape[1], F = (int)feat->shape[2];
+    if (F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels (census.h:76-78)");
+    int nW = census_words(F);
+    if (words->shape[0] != H || words->shape[1] != W || words->shape[2] != nW)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "words must have shape (%d,%d,%d)", H, W, nW);
+    Scratch scr(ctx);
+    void *df;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *feat, &df));
+    SVH_TRY(stage_out(ctx, scr, *words, &os));
+    SVH_TRY(dev_census_from_features(ctx, (const float *)df, H, W, F, nW, false, (uint32_t *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_census_transform(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4],
+                         svh_array *words) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    int H, W, C;
+    SVH_TRY(image_desc(ctx, img, "img", &H, &W, &C));
+    SVH_TRY(validate(ctx, words, "words", SVH_U32, 3, 3));
+    if (h_radius < 0 || v_radius < 0 || h_radius > 127 || v_radius > 127)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,127] (int8_t in the reference)");
+    int pl, pt, Ho, Wo, F;
+    unfold_geometry(H, W, C, h_radius, v_radius, pad, &pl, &pt, &Ho, &Wo, &F);
+    if (Ho <= 0 || Wo <= 0 || F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census transform output is empty");
+    int nW = census_words(F);
+    if (words->shape[0] != Ho || words->shape[1] != Wo || words->shape[2] != nW)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "words must have shape (%d,%d,%d)", Ho, Wo, nW);
+    Scratch scr(ctx);
+    void *dimg;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img, &dimg));
+    SVH_TRY(stage_out(ctx, scr, *words, &os));
+    SVH_TRY(dev_census_from_image(ctx, {(const float *)dimg, H, W, C}, h_radius, v_radius, pl, pt, Ho, Wo, nW, false,
+                                  (uint32_t *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+} // extern "C"

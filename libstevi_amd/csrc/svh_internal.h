@@ -1,0 +1,198 @@
+// Internal declarations shared by the translation units of libstevi_hip.so.
+// Nothing here is part of the ABI (include/stevi_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/stevi_hip.h"
+
+namespace svh {
+
+// ---- device workspace: a small caching pool so steady-state calls never reach hipMalloc ----------
+struct PoolBlock {
+    void *ptr;
+    size_t bytes;
+    bool in_use;
+};
+
+struct ProfPending {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+struct ProfStat {
+    double total_ms = 0;
+    int64_t launches = 0;
+};
+
+} // namespace svh
+
+struct svh_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    std::vector<svh::PoolBlock> pool;
+    bool profiling = false;
+    std::vector<svh::ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_free_events;
+    std::map<std::string, svh::ProfStat> prof_stats;
+    std::vector<std::string> prof_order;
+};
+
+namespace svh {
+
+int fail(svh_context *ctx, int status, const char *fmt, ...);
+
+#define SVH_HIP_CHECK(ctx, expr)                                                                     \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return svh::fail(ctx, _e == hipErrorOutOfMemory ? SVH_ERR_OUT_OF_MEMORY : SVH_ERR_HIP,   \
+                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define SVH_TRY(expr)                 \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != SVH_OK) return _s;  \
+    } while (0)
+
+// RAII over pool blocks taken during one API call
+class Scratch {
+  public:
+    explicit Scratch(svh_context *c) : ctx(c) {}
+    ~Scratch();
+    // returns nullptr (and sets the context error) on failure
+    void *get(size_t bytes);
+    template <class T> T *get_n(size_t n) { return static_cast<T *>(get(n * sizeof(T))); }
+
+  private:
+    svh_context *ctx;
+    std::vector<size_t> taken;
+};
+
+// bracket a kernel launch with events when profiling is on
+class ProfScope {
+  public:
+    ProfScope(svh_context *c, const char *name);
+    ~ProfScope();
+
+  private:
+    svh_context *ctx;
+    bool active = false;
+    hipEvent_t start = nullptr, stop = nullptr;
+    const char *name;
+};
+
+#define SVH_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                              \
+    do {                                                                                    \
+        svh::ProfScope _prof(ctx, name);                                                    \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);         \
+    } while (0)
+
+#define SVH_CHECK_LAUNCH(ctx) SVH_HIP_CHECK(ctx, hipGetLastError())
+
+// ---- array marshalling ---------------------------------------------------------------------------
+size_t dtype_size(int dtype);
+int64_t num_elements(const svh_array &a);
+bool is_dense(const svh_array &a); // last index fastest, no gaps (size-1 dims ignored)
+int validate(svh_context *ctx, const svh_array *a, const char *what, int dtype, int ndim_min, int ndim_max);
+
+// Device-resident dense view of an input array: the array itself when it already is device+dense,
+// otherwise a scratch copy (H2D and/or relayout).
+int stage_in(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr);
+
+// Device-resident dense buffer to compute an output into; finish() moves it to the user's array when needed.
+struct OutStage {
+    void *dptr = nullptr;
+    bool direct = false;
+    const svh_array *dst = nullptr;
+};
+int stage_out(svh_context *ctx, Scratch &scr, const svh_array &a, OutStage *st);
+int finish_out(svh_context *ctx, const OutStage &st);
+// true when any host array took part (the call must synchronise before returning)
+bool any_host(std::initializer_list<const svh_array *> arrays);
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int grid_for(int64_t n, int block, int max_blocks = 1 << 20) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ---- trait helpers (correlation/matching_costs.h:419-685) -----------------------------------------
+inline bool func_supported(int f) { return (f >= SVH_CC && f <= SVH_ZSAD) || f == SVH_HAMMING || f == SVH_CENSUS; }
+inline bool func_zero_mean(int f) { return f == SVH_ZCC || f == SVH_ZNCC || f == SVH_ZSSD || f == SVH_ZSAD; }
+inline bool func_normalized(int f) { return f == SVH_NCC || f == SVH_ZNCC; }
+inline bool func_census(int f) { return f == SVH_HAMMING || f == SVH_CENSUS; }
+inline int func_strategy(int f) { return (f == SVH_CC || f == SVH_NCC || f == SVH_ZCC || f == SVH_ZNCC) ? SVH_SCORE : SVH_COST; }
+inline int census_words(int F) { return (F - 1) / 32 + 1; }
+inline int census_words_written(int F) { return (F - 1) / 32; }
+
+// ---- device-level building blocks (dense device pointers; shapes already validated) ---------------
+struct ImageDesc { // dense (H, W, C) float image on the device
+    const float *data;
+    int H, W, C;
+};
+
+int dev_unfold(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt, int Ho, int Wo, float *out);
+// words layout (H, W, n_out) with n_out = nW (API layout, trailing word zero) or nWw (compact);
+// round_through_float applies rule E2 (target side of aggregateCost) to every word.
+int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt, int Ho, int Wo, int n_out,
+                          bool round_through_float, uint32_t *words);
+int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, int F, int n_out, bool round_through_float,
+                             uint32_t *words);
+
+// cost volume (H, Ws, D) from feature volumes or images
+struct CostVolumeArgs {
+    int func, ddir;
+    int H, Ws, Wt;
+    int disp_lower, D;
+};
+int dev_cost_volume_from_features(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, const float *feat_src,
+                                  const float *feat_tgt, int F, float *cv);
+int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r,
+                                int v_r, float *cv);
+// Hamming volume from compact census words (src exact, tgt already rounded through float)
+int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *src_words, const uint32_t *tgt_words, int nWw,
+                       float *cv);
+
+// SGM
+struct SgmArgs {
+    int n_dir, strategy;
+    int H, W, D;
+    float P1, P2, Pout;
+    int left, top, right, bottom;
+};
+// cost source for the Cost-branch kernels: either a dense float volume or census words evaluated on the fly
+struct CostSource {
+    const float *cv = nullptr;       // (H, W, D) dense, or nullptr
+    const uint32_t *src_words = nullptr, *tgt_words = nullptr; // compact (H, W*, nWw)
+    int nWw = 0, Wt = 0, sign = 1, disp_lower = 0;
+};
+// out_sgm and out_idx may each be nullptr (but not both). out_keys optional (u64 per pixel).
+int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &src, float *out_sgm, int32_t *out_idx,
+                        float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
+                        int key_total_D);
+int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm);
+
+int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
+                      unsigned long long *keys, int key_index_offset, int key_total_D);
+int dev_index_to_disp(svh_context *ctx, int ddir, const int32_t *idx, int64_t n, int32_t offset, int32_t *disp);
+int dev_selected_cost(svh_context *ctx, const float *cv, const int32_t *idx, int64_t n, int D, float *out);
+int dev_truncated_cv(svh_context *ctx, int sdir, int ddir, const float *cv, const int32_t *idx, int H, int W, int D, int h_r,
+                     int v_r, int r, float *tcv);
+int dev_refine(svh_context *ctx, int kernel, const float *tcv, const int32_t *raw, int64_t n, int T, float *refined);
+int dev_keys_to_index(svh_context *ctx, int strategy, const unsigned long long *keys, int64_t n, int total_D, int32_t *idx);
+
+} // namespace svh

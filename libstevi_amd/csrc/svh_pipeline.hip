@@ -1,0 +1,156 @@
+// Fused stereo pipeline: the reference benchmark's call chain kept on the device.
+//   unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp
+//   (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294)
+//   -> [truncatedCostVolume -> refineDispCostInterpolation]   (examples/stereo_refine_test/main.cpp:367-384)
+// Every stage is the same kernel the stand-alone entry points use; what changes is what touches HBM:
+//   * census / Hamming: the cost volume is a pure function of two 8-byte-per-pixel word maps, so the SGM line
+//     kernels and the apply/winner kernel evaluate it on the fly and neither C nor S is written unless the
+//     caller asks for them;
+//   * float costs: C is materialised once (scratch or the caller's array); the Cost branch still writes S at
+//     most once, the Score branch sweeps S per pass.
+#include "svh_internal.h"
+
+using namespace svh;
+
+extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r,
+                                svh_array *disp, svh_array *refined, svh_array *cv, svh_array *sgm_cv, svh_array *keys) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (!prm) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
+    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    const int func = prm->match_func;
+    if (!func_supported(func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", func);
+    if (prm->disp_direction != SVH_LEFT_TO_RIGHT && prm->disp_direction != SVH_RIGHT_TO_LEFT)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (prm->h_radius < 0 || prm->v_radius < 0 || prm->h_radius > 255 || prm->v_radius > 255)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255]");
+    if (prm->disp_count <= 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp_count must be positive");
+    if (prm->sgm_directions != 0 && prm->sgm_directions != 4 && prm->sgm_directions != 8)
+        return fail(ctx, prm->sgm_directions == 16 ? SVH_ERR_UNSUPPORTED : SVH_ERR_INVALID_ARGUMENT, "sgm_directions must be 0, 4 or 8");
+    if (img_l->ndim != img_r->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "image ranks differ");
+    if (img_l->shape[0] != img_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ");
+    const int C = img_l->ndim == 3 ? (int)img_l->shape[2] : 1;
+    if (img_l->ndim == 3 && img_l->shape[2] != img_r->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "channel counts differ");
+    const int F = (2 * prm->h_radius + 1) * (2 * prm->v_radius + 1) * C;
+    if (func_census(func) && F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    const bool want_refine = prm->refine_kernel >= 0;
+    if (want_refine && prm->refine_kernel > SVH_GAUSSIAN) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad interpolation kernel");
+    if (want_refine && !refined) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "refinement requested without an output array");
+    if (!disp && !refined && !keys && !cv && !sgm_cv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "no output requested");
+
+    const bool r2l = prm->disp_direction == SVH_RIGHT_TO_LEFT;
+    const svh_array *src = r2l ? img_r : img_l, *tgt = r2l ? img_l : img_r;
+    const int H = (int)src->shape[0], Ws = (int)src->shape[1], Wt = (int)tgt->shape[1];
+    const int Dtot = prm->disp_count;
+    const int sb = prm->shard_count > 0 ? prm->shard_begin : 0;
+    const int D = prm->shard_count > 0 ? prm->shard_count : Dtot;
+    if (sb < 0 || sb + D > Dtot) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disparity shard outside [0, disp_count)");
+    const bool sharded = D != Dtot;
+    const int strategy = func_strategy(func);
+    const bool sgm = prm->sgm_directions != 0;
+    if (sharded && sgm)
+        return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM over a disparity shard needs the per-pixel minimum of every shard (see DESIGN.md, multi-GPU)");
+    if (sharded && want_refine) return fail(ctx, SVH_ERR_UNSUPPORTED, "refinement over a disparity shard");
+    for (int k = 0; k < 4; k++)
+        if (prm->margins[k] < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "margins must be non-negative");
+
+    if (disp) {
+        SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 2, 2));
+        if (disp->shape[0] != H || disp->shape[1] != Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d)", H, Ws);
+    }
+    if (refined) {
+        SVH_TRY(validate(ctx, refined, "refined", SVH_F32, 2, 2));
+        if (refined->shape[0] != H || refined->shape[1] != Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "refined must have shape (%d,%d)", H, Ws);
+        if (!want_refine) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "refined output given but refine_kernel < 0");
+    }
+    if (keys) {
+        SVH_TRY(validate(ctx, keys, "keys", SVH_U64, 2, 2));
+        if (keys->shape[0] != H || keys->shape[1] != Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "keys must have shape (%d,%d)", H, Ws);
+    }
+    for (svh_array *vol : {cv, sgm_cv}) {
+        if (!vol) continue;
+        SVH_TRY(validate(ctx, vol, "volume output", SVH_F32, 3, 3));
+        if (vol->shape[0] != H || vol->shape[1] != Ws || vol->shape[2] != D)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "volume outputs must have shape (%d,%d,%d)", H, Ws, D);
+    }
+    if (sgm_cv && !sgm) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_cv output given but sgm_directions == 0");
+
+    Scratch scr(ctx);
+    void *dsrc, *dtgt;
+    SVH_TRY(stage_in(ctx, scr, *src, &dsrc));
+    SVH_TRY(stage_in(ctx, scr, *tgt, &dtgt));
+    OutStage o_disp, o_ref, o_cv, o_sgm, o_keys;
+    if (disp) SVH_TRY(stage_out(ctx, scr, *disp, &o_disp));
+    if (refined) SVH_TRY(stage_out(ctx, scr, *refined, &o_ref));
+    if (cv) SVH_TRY(stage_out(ctx, scr, *cv, &o_cv));
+    if (sgm_cv) SVH_TRY(stage_out(ctx, scr, *sgm_cv, &o_sgm));
+    if (keys) SVH_TRY(stage_out(ctx, scr, *keys, &o_keys));
+
+    const int64_t npx = (int64_t)H * Ws;
+    const size_t nvox = (size_t)npx * D;
+    const bool need_idx = disp || want_refine;
+    int32_t *d_idx = need_idx ? scr.get_n<int32_t>((size_t)npx) : nullptr;
+    if (need_idx && !d_idx) return SVH_ERR_OUT_OF_MEMORY;
+    float *d_taps = want_refine ? scr.get_n<float>((size_t)npx * 3) : nullptr;
+    if (want_refine && !d_taps) return SVH_ERR_OUT_OF_MEMORY;
+    unsigned long long *d_keys = keys ? (unsigned long long *)o_keys.dptr : nullptr;
+
+    const CostVolumeArgs cva{func, prm->disp_direction, H, Ws, Wt, prm->disp_lower + sb, D};
+    const ImageDesc isrc{(const float *)dsrc, H, Ws, C}, itgt{(const float *)dtgt, H, Wt, C};
+    SgmArgs sa{prm->sgm_directions, strategy, H, Ws, D, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
+               prm->margins[3]};
+
+    if (func_census(func)) {
+        const int nWw = census_words_written(F);
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)H * Ws * (nWw ? nWw : 1));
+        uint32_t *tw = scr.get_n<uint32_t>((size_t)H * Wt * (nWw ? nWw : 1));
+        if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_from_image(ctx, isrc, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, H, Ws, nWw, false, sw));
+        SVH_TRY(dev_census_from_image(ctx, itgt, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, H, Wt, nWw, true, tw));
+        if (cv) SVH_TRY(dev_hamming_volume(ctx, cva, sw, tw, nWw, (float *)o_cv.dptr));
+        if (need_idx || keys || sgm_cv) {
+            // Cost branch with the Hamming cost evaluated on the fly; sgm_directions == 0 degenerates to S = C
+            CostSource cs;
+            cs.src_words = sw;
+            cs.tgt_words = tw;
+            cs.nWw = nWw;
+            cs.Wt = Wt;
+            cs.sign = r2l ? 1 : -1;
+            cs.disp_lower = cva.disp_lower;
+            SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, d_idx, d_taps, prm->refine_h_radius,
+                                        prm->refine_v_radius, d_keys, sb, Dtot));
+        }
+    } else {
+        float *d_cv = cv ? (float *)o_cv.dptr : scr.get_n<float>(nvox);
+        if (!d_cv) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_cost_volume_from_images(ctx, scr, cva, isrc, itgt, prm->h_radius, prm->v_radius, d_cv));
+        if (sgm && strategy == SVH_COST) {
+            CostSource cs;
+            cs.cv = d_cv;
+            SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, d_idx, d_taps, prm->refine_h_radius,
+                                        prm->refine_v_radius, d_keys, sb, Dtot));
+        } else {
+            const float *d_final = d_cv;
+            if (sgm) {
+                float *d_s = sgm_cv ? (float *)o_sgm.dptr : scr.get_n<float>(nvox);
+                if (!d_s) return SVH_ERR_OUT_OF_MEMORY;
+                SVH_TRY(dev_sgm_score_branch(ctx, scr, sa, d_cv, d_s));
+                d_final = d_s;
+            }
+            if (need_idx || keys) SVH_TRY(dev_extract_index(ctx, strategy, d_final, npx, D, d_idx, d_keys, sb, Dtot));
+            if (want_refine)
+                SVH_TRY(dev_truncated_cv(ctx, SVH_TCV_SAME, prm->disp_direction, d_final, d_idx, H, Ws, D, prm->refine_h_radius,
+                                         prm->refine_v_radius, 1, d_taps));
+        }
+    }
+    if (want_refine) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));
+    if (disp) // selectedIndexToDisp(idx, offset) with offset = first searched offset; a shard reports global indices
+        SVH_TRY(dev_index_to_disp(ctx, prm->disp_direction, d_idx, npx, (r2l ? 1 : -1) * (prm->disp_lower + sb), (int32_t *)o_disp.dptr));
+
+    if (disp) SVH_TRY(finish_out(ctx, o_disp));
+    if (refined) SVH_TRY(finish_out(ctx, o_ref));
+    if (cv) SVH_TRY(finish_out(ctx, o_cv));
+    if (sgm_cv) SVH_TRY(finish_out(ctx, o_sgm));
+    if (keys) SVH_TRY(finish_out(ctx, o_keys));
+    return SVH_OK;
+}

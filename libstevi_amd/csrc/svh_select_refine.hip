@@ -1,0 +1,330 @@
+// Winner extraction (A10), index -> disparity, selected cost, truncated volume (A11) and cost-based
+// sub-pixel refinement (A12).
+#include "svh_internal.h"
+
+namespace svh {
+
+__device__ __forceinline__ uint32_t order_key(float v) {
+    if (v == 0.0f) v = 0.0f; // fold -0 onto +0, they compare equal
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// extractSelectedIndex, correlation_base.h:427-464.  One wavefront per pixel; lane l scans disparities
+// l, l+64, ... in increasing order (256-byte coalesced reads of the pixel's contiguous costs), then the wave
+// combines with "extremum wins, ties to the larger index".  A NaN never replaces the incumbent, and a NaN at
+// index 0 is never replaced (every comparison with it is false).
+template <bool COST>
+__global__ void __launch_bounds__(256) extract_index_kernel(const float *__restrict__ cv, int64_t npx, int D, int32_t *__restrict__ idx,
+                                                           unsigned long long *__restrict__ keys, int key_offset, int key_total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t p = wave; p < npx; p += nwaves) {
+        const float *row = cv + p * D;
+        float bv = 0.0f;
+        int bd = -1;
+        for (int d = lane; d < D; d += 64) {
+            float v = row[d];
+            if (isnan(v)) continue;
+            bool take = bd < 0 || (COST ? v <= bv : v >= bv); // later index wins ties
+            if (take) {
+                bv = v;
+                bd = d;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(bv, off);
+            int od = __shfl_xor(bd, off);
+            bool take = od >= 0 && (bd < 0 || (COST ? (ov < bv || (ov == bv && od > bd)) : (ov > bv || (ov == bv && od > bd))));
+            if (take) {
+                bv = ov;
+                bd = od;
+            }
+        }
+        const bool first_nan = isnan(row[0]);
+        if (lane == 0) {
+            if (idx) idx[p] = (first_nan || bd < 0) ? 0 : bd;
+            if (keys) {
+                unsigned long long key;
+                if (key_offset == 0 && first_nan) key = COST ? (unsigned long long)(uint32_t)(key_total - 1) : (0xFFFFFFFFull << 32);
+                else if (bd < 0) key = COST ? ~0ull : 0ull;
+                else {
+                    uint32_t gd = (uint32_t)(key_offset + bd);
+                    key = ((unsigned long long)order_key(bv) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+                }
+                keys[p] = key;
+            }
+        }
+    }
+}
+
+__global__ void keys_to_index_kernel(const unsigned long long *__restrict__ keys, int64_t n, int total, bool cost,
+                                     int32_t *__restrict__ idx) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t low = (uint32_t)(keys[p] & 0xFFFFFFFFull);
+        int d = cost ? total - 1 - (int)low : (int)low;
+        if (d < 0 || d >= total) d = 0; // "nothing comparable anywhere": the reference stays on index 0
+        idx[p] = d;
+    }
+}
+
+// selectedIndexToDisp, correlation_base.h:511-532
+__global__ void index_to_disp_kernel(const int32_t *__restrict__ idx, int64_t n, int sign, int32_t offset, int32_t *__restrict__ disp) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        disp[p] = sign * idx[p] + offset;
+}
+
+// selectedCost, correlation_base.h:557-577
+__global__ void selected_cost_kernel(const float *__restrict__ cv, const int32_t *__restrict__ idx, int64_t n, int D,
+                                     float *__restrict__ out) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        out[p] = cv[p * D + (uint32_t)idx[p]];
+}
+
+// truncatedCostVolume, correlation_base.h:579-674.  One thread per output tap.
+__global__ void truncated_cv_kernel(int sdir, int ddir, const float *__restrict__ cv, const int32_t *__restrict__ idx, int H, int W,
+                                    int D, int h_r, int v_r, int r, float *__restrict__ tcv) {
+    const int T = sdir == SVH_TCV_BOTH ? 4 * r + 1 : 2 * r + 1;
+    const int64_t n = (int64_t)H * W * T;
+    const float nan = __uint_as_float(0x7FC00000u);
+    const int sgn = (ddir == SVH_RIGHT_TO_LEFT) ? -1 : 1; // :618, :635
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(e % T);
+        const int64_t px = e / T;
+        const int j = (int)(px % W), i = (int)(px / W);
+        // which tap d in [0, 2r] and which flavour (same-pixel or shifted-pixel) does this slot hold?
+        int d;
+        bool shifted;
+        if (sdir == SVH_TCV_SAME) {
+            d = slot;
+            shifted = false;
+        } else if (sdir == SVH_TCV_REVERSED) {
+            d = slot;
+            shifted = true;
+        } else { // Both: d<r -> (2d, 2d+1); d==r -> 2r; d>r -> (2d-1, 2d)   (:640-650)
+            if (slot < 2 * r) {
+                d = slot / 2;
+                shifted = slot & 1;
+            } else if (slot == 2 * r) {
+                d = r;
+                shifted = false;
+            } else {
+                d = (slot + 1) / 2;
+                shifted = !(slot & 1);
+            }
+        }
+        const int p = idx[px] + d - r;
+        const bool rows_bad = i < v_r || i + v_r >= H;
+        float val;
+        if (!shifted) {
+            bool bad = p < 0 || p >= D || j < h_r || j + p + h_r >= W || rows_bad; // :606-608
+            val = bad ? nan : cv[px * D + p];
+        } else {
+            int jp = j + sgn * (d - r);
+            int mn = min(jp, j), mx = max(jp, j);
+            bool bad = p < 0 || p >= D || mn < h_r || mx + h_r >= W || rows_bad; // :623-625
+            val = bad ? nan : cv[((int64_t)i * W + jp) * D + p];
+        }
+        tcv[e] = val;
+    }
+}
+
+// refineCostTriplet, cost_based_refinement.h:43-69
+__device__ __forceinline__ float refine_triplet(int kernel, float cm1, float c0, float c1) {
+    if (kernel == SVH_EQUIANGULAR) {
+        float alpha = copysignf(1.f, c0 - cm1);
+        alpha *= fmaxf(fabsf(c0 - cm1), fabsf(c1 - c0));
+        return (c1 - cm1) / (2 * alpha);
+    }
+    if (kernel == SVH_PARABOLA) return (cm1 - c1) / (2 * (c1 - 2 * c0 + cm1));
+    return (logf(cm1) - logf(c1)) / (2 * (logf(c1) - 2 * logf(c0) + logf(cm1)));
+}
+
+// refineDispCostInterpolation, cost_based_refinement.h:128-163
+__global__ void refine_kernel(int kernel, const float *__restrict__ tcv, const int32_t *__restrict__ raw, int64_t n, int T,
+                              float *__restrict__ refined) {
+    const int r = (T - 1) / 2;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const float *t = tcv + p * T;
+        refined[p] = (float)raw[p] + refine_triplet(kernel, t[r - 1], t[r], t[r + 1]);
+    }
+}
+
+int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
+                      unsigned long long *keys, int key_index_offset, int key_total_D) {
+    if (n_pixels == 0) return SVH_OK;
+    int grid = grid_for(n_pixels, 4, 256 * 8 * 4);
+    if (strategy == SVH_COST)
+        SVH_LAUNCH(ctx, "extract_index", extract_index_kernel<true>, grid, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D);
+    else
+        SVH_LAUNCH(ctx, "extract_index", extract_index_kernel<false>, grid, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_keys_to_index(svh_context *ctx, int strategy, const unsigned long long *keys, int64_t n, int total_D, int32_t *idx) {
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "keys_to_index", keys_to_index_kernel, grid_for(n, 256, 8192), 256, 0, keys, n, total_D, strategy == SVH_COST, idx);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_index_to_disp(svh_context *ctx, int ddir, const int32_t *idx, int64_t n, int32_t offset, int32_t *disp) {
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "index_to_disp", index_to_disp_kernel, grid_for(n, 256, 8192), 256, 0, idx, n, ddir == SVH_RIGHT_TO_LEFT ? 1 : -1,
+               offset, disp);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_selected_cost(svh_context *ctx, const float *cv, const int32_t *idx, int64_t n, int D, float *out) {
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "selected_cost", selected_cost_kernel, grid_for(n, 256, 8192), 256, 0, cv, idx, n, D, out);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_truncated_cv(svh_context *ctx, int sdir, int ddir, const float *cv, const int32_t *idx, int H, int W, int D, int h_r,
+                     int v_r, int r, float *tcv) {
+    int T = sdir == SVH_TCV_BOTH ? 4 * r + 1 : 2 * r + 1;
+    int64_t n = (int64_t)H * W * T;
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "truncated_cost_volume", truncated_cv_kernel, grid_for(n, 256, 16384), 256, 0, sdir, ddir, cv, idx, H, W, D, h_r, v_r,
+               r, tcv);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_refine(svh_context *ctx, int kernel, const float *tcv, const int32_t *raw, int64_t n, int T, float *refined) {
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "refine_disp", refine_kernel, grid_for(n, 256, 8192), 256, 0, kernel, tcv, raw, n, T, refined);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+} // namespace svh
+
+using namespace svh;
+
+static int same_map_shape(svh_context *ctx, const svh_array *vol, const svh_array *map, const char *what) {
+    if (map->shape[0] != vol->shape[0] || map->shape[1] != vol->shape[1])
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s must have shape (%lld,%lld)", what, (long long)vol->shape[0],
+                    (long long)vol->shape[1]);
+    return SVH_OK;
+}
+
+extern "C" {
+
+int svh_extract_selected_index(svh_context *ctx, int strategy, const svh_array *cv, svh_array *idx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 2, 2));
+    if (strategy != SVH_COST && strategy != SVH_SCORE) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad strategy");
+    SVH_TRY(same_map_shape(ctx, cv, idx, "idx"));
+    if (cv->shape[2] < 1) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cost volume has no disparity");
+    Scratch scr(ctx);
+    void *dcv;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_out(ctx, scr, *idx, &os));
+    SVH_TRY(dev_extract_index(ctx, strategy, (const float *)dcv, cv->shape[0] * cv->shape[1], (int)cv->shape[2], (int32_t *)os.dptr,
+                              nullptr, 0, 0));
+    return finish_out(ctx, os);
+}
+
+int svh_selected_index_to_disp(svh_context *ctx, int disp_direction, const svh_array *idx, int32_t disp_offset, svh_array *disp) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 2, 2));
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 2, 2));
+    SVH_TRY(same_map_shape(ctx, idx, disp, "disp"));
+    Scratch scr(ctx);
+    void *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *idx, &di));
+    SVH_TRY(stage_out(ctx, scr, *disp, &os));
+    SVH_TRY(dev_index_to_disp(ctx, disp_direction, (const int32_t *)di, num_elements(*idx), disp_offset, (int32_t *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_selected_cost(svh_context *ctx, const svh_array *cv, const svh_array *idx, svh_array *cost) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 2, 2));
+    SVH_TRY(validate(ctx, cost, "cost", SVH_F32, 2, 2));
+    SVH_TRY(same_map_shape(ctx, cv, idx, "idx"));
+    SVH_TRY(same_map_shape(ctx, cv, cost, "cost"));
+    Scratch scr(ctx);
+    void *dcv, *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_in(ctx, scr, *idx, &di));
+    SVH_TRY(stage_out(ctx, scr, *cost, &os));
+    SVH_TRY(dev_selected_cost(ctx, (const float *)dcv, (const int32_t *)di, num_elements(*idx), (int)cv->shape[2], (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_truncated_cost_volume(svh_context *ctx, int tcv_direction, int disp_direction, const svh_array *cv, const svh_array *idx,
+                              int h_radius, int v_radius, int cost_vol_radius, svh_array *tcv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 2, 2));
+    SVH_TRY(validate(ctx, tcv, "tcv", SVH_F32, 3, 3));
+    if (tcv_direction < SVH_TCV_SAME || tcv_direction > SVH_TCV_BOTH) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad truncation direction");
+    if (h_radius < 0 || v_radius < 0 || cost_vol_radius < 0 || h_radius > 255 || v_radius > 255 || cost_vol_radius > 255)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255] (uint8_t in the reference)");
+    SVH_TRY(same_map_shape(ctx, cv, idx, "idx"));
+    int T = tcv_direction == SVH_TCV_BOTH ? 4 * cost_vol_radius + 1 : 2 * cost_vol_radius + 1;
+    if (tcv->shape[0] != cv->shape[0] || tcv->shape[1] != cv->shape[1] || tcv->shape[2] != T)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "tcv must have shape (%lld,%lld,%d)", (long long)cv->shape[0], (long long)cv->shape[1], T);
+    Scratch scr(ctx);
+    void *dcv, *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_in(ctx, scr, *idx, &di));
+    SVH_TRY(stage_out(ctx, scr, *tcv, &os));
+    SVH_TRY(dev_truncated_cv(ctx, tcv_direction, disp_direction, (const float *)dcv, (const int32_t *)di, (int)cv->shape[0],
+                             (int)cv->shape[1], (int)cv->shape[2], h_radius, v_radius, cost_vol_radius, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_refine_disp_cost_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
+                                       svh_array *refined) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, tcv, "tcv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, raw, "raw", SVH_I32, 2, 2));
+    SVH_TRY(validate(ctx, refined, "refined", SVH_F32, 2, 2));
+    if (interp_kernel < SVH_EQUIANGULAR || interp_kernel > SVH_GAUSSIAN) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad interpolation kernel");
+    int T = (int)tcv->shape[2];
+    int r = (T - 1) / 2;
+    if (r < 1 || 2 * r + 1 != T) return fail(ctx, SVH_EMPTY_RESULT, "truncated volume depth must be 2r+1, r >= 1"); // :141-143
+    SVH_TRY(same_map_shape(ctx, raw, refined, "refined"));
+    if (tcv->shape[0] != raw->shape[0] || tcv->shape[1] != raw->shape[1])
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "tcv and raw disagree on the image size");
+    Scratch scr(ctx);
+    void *dt, *dr;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *tcv, &dt));
+    SVH_TRY(stage_in(ctx, scr, *raw, &dr));
+    SVH_TRY(stage_out(ctx, scr, *refined, &os));
+    SVH_TRY(dev_refine(ctx, interp_kernel, (const float *)dt, (const int32_t *)dr, num_elements(*raw), T, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+int svh_keys_to_index(svh_context *ctx, int strategy, const svh_array *keys, int32_t disp_count, svh_array *idx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, keys, "keys", SVH_U64, 2, 2));
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 2, 2));
+    SVH_TRY(same_map_shape(ctx, keys, idx, "idx"));
+    if (strategy != SVH_COST && strategy != SVH_SCORE) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad strategy");
+    Scratch scr(ctx);
+    void *dk;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *keys, &dk));
+    SVH_TRY(stage_out(ctx, scr, *idx, &os));
+    SVH_TRY(dev_keys_to_index(ctx, strategy, (const unsigned long long *)dk, num_elements(*keys), disp_count, (int32_t *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+} // extern "C"

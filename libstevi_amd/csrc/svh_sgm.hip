@@ -1,0 +1,534 @@
+// SGM path aggregation (A9), reproducing correlation/sgm.h as written.
+//
+// Effective passes of the reference for nDirections = 8, in accumulation order (sgm.h:379-388 with the start
+// rule of :329-354; Down2Up, Right2Left and DownRight2UpLeft start one past the last valid index and do
+// nothing):
+//   0 Up2Down            lines from (top, j)   step (+1, 0)
+//   1 Left2Right         lines from (i, left)  step ( 0,+1)
+//   2 UpLeft2DownRight   lines from (i, left)  step (+1,+1)   (row starts)
+//   3 UpLeft2DownRight   lines from (top, j)   step (+1,+1)   (column starts; the corner line runs twice)
+//   4 UpRight2DownLeft   lines from (top, j)   step (+1,-1)
+//   5 DownLeft2UpRight   lines from (i, left)  step (-1,+1)
+// nDirections = 4 keeps passes 0-1.  Lines of one pass are disjoint, so a launch per pass is race free and the
+// float accumulation order of the reference (pass after pass) is kept.
+//
+// Mapping: one wavefront per line, the 64 lanes span the disparity axis with R = ceil(D/64) consecutive
+// disparities per lane, so a pixel's D costs are one contiguous 4*D-byte read (volumes are (row, col, disparity)
+// with the disparity fastest).  No MFMA: there is no contraction here; the cross-lane work is a wave min / max
+// and prefix/suffix maxima done with lane shuffles.
+//
+// Cost branch (sgm.h:257-296).  Because of `min_a_cost = c_score` (:281-283, F4) the recurrence couples
+// disparities only through the per-pixel scalar min_p = min over finite previous costs:
+//     actual(d) = c(d) + ((c(d) [+ Pout if j+d >= W]) - min_p)     when both terms are finite, else c(d)
+// So a pass is fully described by the map pixel -> min_p.  The line kernel computes that map (the sequential
+// part, with exactly the reference's float operations), and one "apply" kernel then rebuilds
+//     S = C; S += actual_q - C for every pass q that visits the pixel, in pass order
+// per voxel, again with the reference's operations and order, so S is bit-identical while the volume is
+// written once instead of being read-modified-written per pass; the winner scan can be fused into it.
+//
+// Score branch (sgm.h:218-255) couples neighbouring disparities, so each pass is a read-modify-write sweep:
+//     a(nd) = max over finite { prev[nd], prev[nd-1]-P1, prev[nd+1]-P1, max_{|od-nd|>1} prev[od] - P2 }
+// The last term is evaluated exactly for any P1, P2 from exclusive prefix / suffix maxima (x -> fl(x - P2) is
+// monotone, so the max of the differences is the difference of the max).
+#include "svh_internal.h"
+
+namespace svh {
+
+struct LineSet {
+    int pass;   // 0..5 as listed above
+    int n_lines;
+    int top, left, Hp, Wp; // margin box origin and extent
+};
+
+struct Line {
+    int i0, j0, di, dj, len;
+};
+
+__device__ __forceinline__ Line line_of(const LineSet &ls, int l) {
+    Line L;
+    switch (ls.pass) {
+    case 0: L = {ls.top, ls.left + l, 1, 0, ls.Hp}; break;
+    case 1: L = {ls.top + l, ls.left, 0, 1, ls.Wp}; break;
+    case 2: L = {ls.top + l, ls.left, 1, 1, min(ls.Hp - l, ls.Wp)}; break;
+    case 3: L = {ls.top, ls.left + l, 1, 1, min(ls.Hp, ls.Wp - l)}; break;
+    case 4: L = {ls.top, ls.left + l, 1, -1, min(ls.Hp, l + 1)}; break;
+    default: L = {ls.top + l, ls.left, -1, 1, min(l + 1, ls.Wp)}; break;
+    }
+    return L;
+}
+
+// does pass q visit pixel (ip, jp) (coordinates relative to the margin box, already known to be inside it)?
+__device__ __forceinline__ bool pass_visits(int q, int ip, int jp, int Hp, int Wp) {
+    switch (q) {
+    case 0: case 1: return true;
+    case 2: return ip >= jp;
+    case 3: return jp >= ip;
+    case 4: return ip + jp < Wp;
+    default: return ip + jp < Hp;
+    }
+}
+
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; } // false for NaN and +-inf
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ---- cost sources -----------------------------------------------------------------------------------
+struct SrcVolume { // dense (H, W, D) floats
+    const float *cv;
+    int W, D;
+    bool vec; // 16-byte aligned rows, D % 4 == 0
+    template <int R> __device__ __forceinline__ void load(int i, int j, int lane, float (&c)[R]) const {
+        const float *p = cv + ((int64_t)i * W + j) * D + lane * R;
+        if constexpr (R % 4 == 0) {
+            if (vec && lane * R + R <= D) {
+#pragma unroll
+                for (int q = 0; q < R / 4; q++) {
+                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+                    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) c[k] = (lane * R + k < D) ? p[k] : 0.0f;
+    }
+};
+
+struct SrcCensus { // Hamming cost evaluated from compact census words (H, W*, nWw); target words pre-rounded (E2)
+    const uint32_t *sw, *tw;
+    int nWw, Ws, Wt, sign, disp_lower, D;
+    template <int R> __device__ __forceinline__ void load(int i, int j, int lane, float (&c)[R]) const {
+        const uint32_t *s = sw + ((int64_t)i * Ws + j) * nWw;
+        const uint32_t *trow = tw + (int64_t)i * Wt * nWw;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            int d = lane * R + k;
+            int jt = j + sign * (disp_lower + d);
+            bool in = d < D && jt >= 0 && jt < Wt;
+            uint32_t acc = 0;
+            for (int w = 0; w < nWw; w++) acc += __popc(s[w] ^ (in ? trow[(int64_t)jt * nWw + w] : 0u));
+            c[k] = (float)acc;
+        }
+    }
+};
+
+// ---- Cost branch: per-pass map pixel -> min_p ----------------------------------------------------------
+// One step of sgm.h:259-295 for the R disparities of this lane; returns the lane's min over finite actual costs.
+template <int R>
+__device__ __forceinline__ float cost_step_lane_min(const float (&c)[R], int lane, int D, int j, int W, float Pout, float mp) {
+    float lm = INFINITY;
+    const bool mp_fin = finite_f(mp);
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        int d = lane * R + k;
+        float t = (j + d >= W) ? c[k] + Pout : c[k]; // min_a_cost = c_score (+ Pout), :281-289
+        float act = c[k];
+        if (mp_fin && finite_f(t)) act = c[k] + (t - mp); // :291-294
+        if (d < D && finite_f(act)) lm = fminf(lm, act);  // next pixel's min over finite previous costs, :261-266
+    }
+    return lm;
+}
+
+template <class SRC, int R, int B>
+__global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, LineSet ls, int D, int W, float Pout,
+                                                             float *__restrict__ mmap) {
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (l >= ls.n_lines) return;
+    const Line L = line_of(ls, l);
+    float mp = 0.0f; // previous_cost[] = 0 -> min over finite = 0 (sgm.h:206-208)
+    int i = L.i0, j = L.j0;
+    for (int s0 = 0; s0 < L.len; s0 += B) {
+        float c[B][R];
+        const int nb = min(B, L.len - s0);
+        // the loads do not depend on the recurrence: issue a batch, then run the serial part
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (b < nb) src.template load<R>(i + b * L.di, j + b * L.dj, lane, c[b]);
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (b < nb) {
+                const int ii = i + b * L.di, jj = j + b * L.dj;
+                if (lane == 0) mmap[(int64_t)ii * W + jj] = mp;
+                mp = wave_min(cost_step_lane_min<R>(c[b], lane, D, jj, W, Pout, mp));
+            }
+        }
+        i += B * L.di;
+        j += B * L.dj;
+    }
+}
+
+// order-preserving key of a float for unsigned comparison; -0 is folded onto +0 (they compare equal)
+__device__ __forceinline__ uint32_t float_order_key(float v) {
+    if (v == 0.0f) v = 0.0f;
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct Winner {
+    float v;
+    int d; // -1: no candidate yet
+};
+
+// combine rule of extractSelectedIndex (correlation_base.h:441-455) for two partial scans over disjoint
+// disparity sets: the extremum wins, ties go to the larger index; NaN candidates never enter (handled by caller)
+template <bool COST> __device__ __forceinline__ Winner better(Winner a, Winner b) {
+    if (b.d < 0) return a;
+    if (a.d < 0) return b;
+    bool b_wins = COST ? (b.v < a.v || (b.v == a.v && b.d > a.d)) : (b.v > a.v || (b.v == a.v && b.d > a.d));
+    return b_wins ? b : a;
+}
+
+template <bool COST> __device__ __forceinline__ Winner wave_winner(Winner w) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Winner o;
+        o.v = __shfl_xor(w.v, off);
+        o.d = __shfl_xor(w.d, off);
+        w = better<COST>(w, o);
+    }
+    return w;
+}
+
+// Winner over the non-NaN values of the wave (d = -1 when there is none) and whether the value at local index 0
+// is NaN: the sequential scan of the reference starts from index 0 and never leaves it when that value is NaN.
+template <bool COST, int R>
+__device__ __forceinline__ Winner wave_select(const float (&s)[R], int lane, int D, bool *first_is_nan) {
+    Winner w{0.0f, -1};
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        int d = lane * R + k;
+        if (d < D && !isnan(s[k])) w = better<COST>(w, Winner{s[k], d});
+    }
+    w = wave_winner<COST>(w);
+    *first_is_nan = isnan(__shfl(s[0], 0));
+    return w;
+}
+
+// (ordered value, index) key for a cross-shard min (COST) / max (SCORE) reduction that reproduces the tie rule
+template <bool COST>
+__device__ __forceinline__ unsigned long long winner_key(Winner w, bool first_is_nan, int key_offset, int key_total) {
+    if (key_offset == 0 && first_is_nan) // global index 0 is NaN: it wins unconditionally
+        return COST ? (unsigned long long)(uint32_t)(key_total - 1) : (0xFFFFFFFFull << 32);
+    if (w.d < 0) return COST ? ~0ull : 0ull; // nothing comparable in this shard
+    const uint32_t gd = (uint32_t)(key_offset + w.d);
+    return ((unsigned long long)float_order_key(w.v) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+}
+
+struct ApplyOut {
+    float *sgm;               // (H, W, D) or nullptr
+    int32_t *idx;             // (H, W) or nullptr
+    float *taps;              // (H, W, 3) truncated volume around the winner (Same direction, radius 1) or nullptr
+    int taps_h_r, taps_v_r;
+    unsigned long long *keys; // (H, W) or nullptr
+    int key_offset, key_total;
+};
+
+template <class SRC, int R>
+__global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int W, int D, int top, int left, int Hp, int Wp,
+                                                            int n_pass, float Pout, const float *__restrict__ mmap,
+                                                            ApplyOut out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t npx = (int64_t)H * W;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t p = wave; p < npx; p += nwaves) {
+        const int j = (int)(p % W), i = (int)(p / W);
+        float c[R], s[R];
+        src.template load<R>(i, j, lane, c);
+#pragma unroll
+        for (int k = 0; k < R; k++) s[k] = c[k]; // sgm_cv := cv, sgm.h:371-377
+        const int ip = i - top, jp = j - left;
+        if (ip >= 0 && ip < Hp && jp >= 0 && jp < Wp) {
+            for (int q = 0; q < n_pass; q++) {
+                if (!pass_visits(q, ip, jp, Hp, Wp)) continue;
+                const float mp = mmap[(int64_t)q * npx + p];
+                const bool mp_fin = finite_f(mp);
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    int d = lane * R + k;
+                    float t = (j + d >= W) ? c[k] + Pout : c[k];
+                    float act = c[k];
+                    if (mp_fin && finite_f(t)) act = c[k] + (t - mp);
+                    s[k] += act - c[k]; // sgm.h:298-300
+                }
+            }
+        }
+        if (out.sgm) {
+            float *o = out.sgm + p * D + lane * R;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+                if (lane * R + k < D) o[k] = s[k];
+        }
+        if (out.idx || out.taps || out.keys) {
+            bool first_nan;
+            const Winner w = wave_select<true, R>(s, lane, D, &first_nan);
+            const int sel = (first_nan || w.d < 0) ? 0 : w.d;
+            if (out.idx && lane == 0) out.idx[p] = sel;
+            if (out.keys && lane == 0) out.keys[p] = winner_key<true>(w, first_nan, out.key_offset, out.key_total);
+            if (out.taps) {
+                // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613)
+                const bool px_bad = j < out.taps_h_r || i < out.taps_v_r || i + out.taps_v_r >= H;
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int pd = sel + t - 1;
+                    const bool bad = px_bad || pd < 0 || pd >= D || j + pd + out.taps_h_r >= W;
+                    if (bad) {
+                        if (lane == 0) out.taps[p * 3 + t] = __uint_as_float(0x7FC00000u);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < R; k++)
+                            if (lane * R + k == pd) out.taps[p * 3 + t] = s[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- Score branch: read-modify-write sweep per pass ----------------------------------------------------
+__device__ __forceinline__ float lane_shift_up(float v, int lane, float fill) { // value of lane-1
+    float t = __shfl_up(v, 1);
+    return lane == 0 ? fill : t;
+}
+__device__ __forceinline__ float lane_shift_down(float v, int lane, float fill) { // value of lane+1
+    float t = __shfl_down(v, 1);
+    return lane == 63 ? fill : t;
+}
+
+template <int R, int B, bool FIRST>
+__global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
+                                                            int D, int W, float P1, float P2, float Pout, bool vec) {
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (l >= ls.n_lines) return;
+    const Line L = line_of(ls, l);
+    const SrcVolume src{cv, W, D, vec};
+    const SrcVolume acc{sgm, W, D, vec};
+    float prev[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) prev[k] = 0.0f; // sgm.h:206-208
+    int i = L.i0, j = L.j0;
+    for (int s0 = 0; s0 < L.len; s0 += B) {
+        float c[B][R], s[B][R];
+        const int nb = min(B, L.len - s0);
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (b < nb) {
+                src.template load<R>(i + b * L.di, j + b * L.dj, lane, c[b]);
+                if (!FIRST) acc.template load<R>(i + b * L.di, j + b * L.dj, lane, s[b]);
+            }
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            if (b >= nb) continue;
+            const int ii = i + b * L.di, jj = j + b * L.dj;
+            // finite previous scores, -inf otherwise (isfinite filters of :224, :241)
+            float pf[R];
+            float A = -INFINITY, Ahead = -INFINITY, Atail = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                pf[k] = (lane * R + k < D && finite_f(prev[k])) ? prev[k] : -INFINITY;
+                A = fmaxf(A, pf[k]);
+                if (k < R - 1) Ahead = fmaxf(Ahead, pf[k]);
+                if (k > 0) Atail = fmaxf(Atail, pf[k]);
+            }
+            // inclusive prefix / suffix maxima of A over the lanes
+            float pin = A, sin_ = A;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                float t = __shfl_up(pin, off);
+                if (lane >= off) pin = fmaxf(pin, t);
+                float u = __shfl_down(sin_, off);
+                if (lane + off < 64) sin_ = fmaxf(sin_, u);
+            }
+            const float max_p = __shfl(pin, 63);                      // max over finite previous scores, :220-227
+            const float PM = lane_shift_up(pin, lane, -INFINITY);     // lanes < lane
+            const float SM = lane_shift_down(sin_, lane, -INFINITY);  // lanes > lane
+            const float far_l0 = lane_shift_up(fmaxf(PM, Ahead), lane, -INFINITY);   // disparities <= lane*R - 2
+            const float far_rl = lane_shift_down(fmaxf(SM, Atail), lane, -INFINITY); // disparities >= lane*R + R + 1
+            const float prevL = lane_shift_up(pf[R - 1], lane, -INFINITY);           // disparity lane*R - 1
+            const float prevR = lane_shift_down(pf[0], lane, -INFINITY);             // disparity lane*R + R
+            const bool maxp_fin = finite_f(max_p);
+            float act[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                float fl;
+                if (k == 0) fl = far_l0;
+                else {
+                    fl = PM;
+#pragma unroll
+                    for (int q = 0; q + 2 <= k; q++) fl = fmaxf(fl, pf[q]);
+                }
+                float fr;
+                if (k == R - 1) fr = far_rl;
+                else {
+                    fr = SM;
+#pragma unroll
+                    for (int q = k + 2; q < R; q++) fr = fmaxf(fr, pf[q]);
+                }
+                const float lo = (k > 0 ? pf[k - 1] : prevL) - P1;  // |od - nd| == 1, :238
+                const float hi = (k < R - 1 ? pf[k + 1] : prevR) - P1;
+                const float far = fmaxf(fl, fr) - P2;                // |od - nd| > 1, :239
+                float a = fmaxf(fmaxf(pf[k], far), fmaxf(lo, hi));
+                const int d = lane * R + k;
+                if (jj + d >= W) a -= Pout; // :247-249
+                act[k] = c[b][k];
+                if (maxp_fin && finite_f(a)) act[k] = c[b][k] + (a - max_p); // :251-254
+            }
+            float *o = sgm + ((int64_t)ii * W + jj) * D + lane * R;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const float base = FIRST ? c[b][k] : s[b][k];
+                if (lane * R + k < D) o[k] = base + (act[k] - c[b][k]); // :298-300
+                prev[k] = act[k];
+            }
+        }
+        i += B * L.di;
+        j += B * L.dj;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+static int pass_lines(int q, int Hp, int Wp) { return (q == 0 || q == 3 || q == 4) ? Wp : Hp; }
+
+static int pick_R(int D) {
+    int R = 1;
+    while (64 * R < D) R <<= 1;
+    return R;
+}
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+template <class SRC, int R>
+static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut &out) {
+    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+    const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
+    constexpr int B = (R <= 4) ? 8 : (R == 8 ? 4 : 2);
+    if (Hp > 0 && Wp > 0) {
+        for (int q = 0; q < n_pass; q++) {
+            LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
+            SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), ceil_div(ls.n_lines, 4), 256, 0, src, ls, a.D, a.W,
+                       a.Pout, mmap + (size_t)q * a.H * a.W);
+            SVH_CHECK_LAUNCH(ctx);
+        }
+    }
+    const int64_t npx = (int64_t)a.H * a.W;
+    int grid = grid_for(npx, 4, 256 * 8 * 4);
+    SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
+               Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, out);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+template <class SRC>
+static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut &out) {
+    switch (pick_R(a.D)) {
+    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out);
+    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out);
+    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out);
+    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out);
+    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out);
+    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
+    }
+}
+
+int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *out_sgm, int32_t *out_idx,
+                        float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
+                        int key_total_D) {
+    if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
+    float *mmap = scr.get_n<float>((size_t)6 * a.H * a.W);
+    if (!mmap) return SVH_ERR_OUT_OF_MEMORY;
+    ApplyOut out{out_sgm, out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D};
+    if (cs.cv) {
+        SrcVolume src{cs.cv, a.W, a.D, aligned16(cs.cv) && a.D % 4 == 0};
+        return dispatch_cost_branch(ctx, a, src, mmap, out);
+    }
+    SrcCensus src{cs.src_words, cs.tgt_words, cs.nWw, a.W, cs.Wt, cs.sign, cs.disp_lower, a.D};
+    return dispatch_cost_branch(ctx, a, src, mmap, out);
+}
+
+template <int R>
+static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm) {
+    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+    const int n_pass = a.n_dir >= 8 ? 6 : 2;
+    constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
+    const bool vec = aligned16(cv) && aligned16(sgm) && a.D % 4 == 0;
+    const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0;
+    if (!whole || Hp <= 0 || Wp <= 0) {
+        // pixels outside the margin box keep sgm = cv (sgm.h:371-377)
+        ProfScope prof(ctx, "sgm_copy");
+        SVH_HIP_CHECK(ctx, hipMemcpyAsync(sgm, cv, (size_t)a.H * a.W * a.D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (Hp <= 0 || Wp <= 0) return SVH_OK;
+    for (int q = 0; q < n_pass; q++) {
+        LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
+        int grid = ceil_div(ls.n_lines, 4);
+        if (q == 0 && whole)
+            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout,
+                       vec);
+        else
+            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout,
+                       vec);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return SVH_OK;
+}
+
+int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm) {
+    (void)scr;
+    if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
+    switch (pick_R(a.D)) {
+    case 1: return run_score_branch<1>(ctx, a, cv, out_sgm);
+    case 2: return run_score_branch<2>(ctx, a, cv, out_sgm);
+    case 4: return run_score_branch<4>(ctx, a, cv, out_sgm);
+    case 8: return run_score_branch<8>(ctx, a, cv, out_sgm);
+    case 16: return run_score_branch<16>(ctx, a, cv, out_sgm);
+    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
+    }
+}
+
+} // namespace svh
+
+using namespace svh;
+
+extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
+                                   const int32_t margins[4], float Pout, svh_array *out) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
+    if (n_directions == 16)
+        return fail(ctx, SVH_ERR_UNSUPPORTED,
+                    "16 directions: the reference's overlapping lines race on sgm_cv (sgm.h:299, :336), results are not defined");
+    if (n_directions != 4 && n_directions != 8) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "n_directions must be 4 or 8");
+    if (strategy != SVH_COST && strategy != SVH_SCORE) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad strategy");
+    for (int k = 0; k < 3; k++)
+        if (cv->shape[k] != out->shape[k]) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have the shape of cv");
+    static const int32_t zero[4] = {0, 0, 0, 0};
+    const int32_t *m = margins ? margins : zero;
+    for (int k = 0; k < 4; k++)
+        if (m[k] < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "margins must be non-negative");
+    SgmArgs a{n_directions, strategy, (int)cv->shape[0], (int)cv->shape[1], (int)cv->shape[2], P1, P2, Pout, m[0], m[1], m[2], m[3]};
+    Scratch scr(ctx);
+    void *dcv;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_out(ctx, scr, *out, &os));
+    if (strategy == SVH_COST) {
+        CostSource cs;
+        cs.cv = (const float *)dcv;
+        SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, nullptr, nullptr, 0, 0, nullptr, 0, 0));
+    } else {
+        if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
+        SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr));
+    }
+    return finish_out(ctx, os);
+}

@@ -1,0 +1,327 @@
+"""GPU parity tests: every entry point of the C ABI (through libstevi_amd's Python mirror) against the CPU
+oracle on the same seeded inputs.  Integer / index / bit-pattern outputs must match exactly; float cost
+volumes and refined disparities within 1e-4 (BASELINE.json north_star) with identical NaN masks.
+
+Host arrays (numpy) exercise the copy-in / copy-out path, torch CUDA tensors the in-place device path.
+"""
+import numpy as np
+import pytest
+
+import oracle as so
+from helpers import parallax_pair
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import libstevi_amd as sv  # noqa: E402
+from libstevi_amd import matchingFunctions as MF  # noqa: E402
+
+TOL = 1e-4  # north_star: float NCC costs and sub-pixel refinement within 1e-4
+DEV = torch.device("cuda:0")
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else x
+
+
+def assert_close(got, exp, tol=TOL):
+    got, exp = host(got), host(exp)
+    assert got.shape == exp.shape
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), "NaN masks differ"
+    both_inf = np.isinf(got) & np.isinf(exp) & (np.sign(got) == np.sign(exp))
+    ok = ~np.isnan(exp) & ~both_inf
+    err = np.abs(got[ok].astype(np.float64) - exp[ok].astype(np.float64))
+    lim = tol * np.maximum(1.0, np.abs(exp[ok].astype(np.float64)))
+    assert np.all(err <= lim), f"max err {err.max()} (tol {tol})"
+
+
+def assert_bits(got, exp):
+    got, exp = host(got), host(exp)
+    assert got.shape == exp.shape and got.dtype == exp.dtype
+    a = got.view(np.uint32) if got.dtype == np.float32 else got
+    b = exp.view(np.uint32) if exp.dtype == np.float32 else exp
+    nbad = int((a != b).sum())
+    assert nbad == 0, f"{nbad} of {a.size} elements differ"
+
+
+# ------------------------------------------------------------------------------------------------ A1-A3
+@pytest.mark.parametrize("h_r,v_r", [(0, 0), (1, 1), (2, 3), (4, 4), (5, 2)])
+@pytest.mark.parametrize("channels", [1, 3])
+def test_unfold(rng, h_r, v_r, channels):
+    img = rng.uniform(-1, 1, (9, 13, channels)).astype(np.float32)
+    if channels == 1:
+        img = img[:, :, 0]
+    assert_bits(sv.unfold(h_r, v_r, img), so.unfold(img, h_r, v_r))
+    assert_bits(sv.unfold(h_r, v_r, dev(img), sv.PaddingMargins(1, 0, 2, 1)), so.unfold(img, h_r, v_r, (1, 0, 2, 1)))
+    if 2 * v_r + 1 <= 9 and 2 * h_r + 1 <= 13:
+        assert_bits(sv.unfold(h_r, v_r, img, sv.PaddingMargins(0)), so.unfold(img, h_r, v_r, (0, 0, 0, 0)))
+
+
+@pytest.mark.parametrize("h_r,v_r", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 2), (4, 3), (7, 7)])
+def test_census_transform(rng, h_r, v_r):
+    img = rng.uniform(-1, 1, (17, 23)).astype(np.float32)
+    img[3, 5] = np.nan
+    exp = so.census_transform(img, h_r, v_r)
+    assert_bits(sv.censusTransform2D(img, h_r, v_r), exp)
+    assert_bits(sv.censusTransform2D(dev(img), h_r, v_r), exp)
+    # colour image and explicit padding
+    rgb = rng.uniform(-1, 1, (11, 12, 3)).astype(np.float32)
+    assert_bits(sv.censusTransform2D(rgb, h_r, v_r, sv.PaddingMargins(2, 1, 0, 3)), so.census_transform(rgb, h_r, v_r, (2, 1, 0, 3)))
+    # feature-volume entry point
+    feat = so.unfold(img, h_r, v_r)
+    assert_bits(sv.censusFeatures(feat), so.census_features(feat))
+
+
+def test_census_single_channel_is_empty():
+    assert sv.censusFeatures(np.zeros((3, 3, 1), np.float32)).size == 0
+    assert sv.censusTransform2D(np.zeros((3, 3), np.float32), 0, 0).size == 0
+
+
+# ------------------------------------------------------------------------------------------------ A4-A8
+ALL_FUNCS = [MF.CC, MF.NCC, MF.SSD, MF.SAD, MF.ZCC, MF.ZNCC, MF.ZSSD, MF.ZSAD, MF.HAMMING, MF.CENSUS]
+
+
+@pytest.mark.parametrize("func", ALL_FUNCS)
+@pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
+def test_unfold_cost_volume(rng, func, ddir):
+    left = rng.uniform(-1, 1, (12, 21)).astype(np.float32)
+    right = rng.uniform(-1, 1, (12, 17)).astype(np.float32)  # widths may differ (only rows are checked)
+    for (h_r, v_r, D, lower) in [(4, 4, 9, 0), (1, 2, 30, 0), (3, 3, 7, -3)]:
+        exp = so.unfold_cost_volume(int(func), left, right, h_r, v_r, D, int(ddir), lower)
+        rng_arg = D if lower == 0 else sv.searchOffset1(lower, lower + D - 1)
+        got = sv.unfoldBasedCostVolume(func, left, right, h_r, v_r, rng_arg, ddir)
+        if int(func) in (MF.HAMMING, MF.CENSUS):
+            assert_bits(got, exp)
+        else:
+            assert_close(got, exp)
+        got_d = sv.unfoldBasedCostVolume(func, dev(left), dev(right), h_r, v_r, rng_arg, ddir)
+        assert_bits(got_d, host(got))  # host and device paths run the same kernels
+
+
+def test_cost_volume_edge_cases(rng):
+    a = rng.uniform(-1, 1, (6, 8)).astype(np.float32)
+    b = rng.uniform(-1, 1, (7, 8)).astype(np.float32)
+    assert sv.unfoldBasedCostVolume(MF.SAD, a, b, 1, 1, 4).size == 0  # row mismatch -> empty (cross_correlations.h:751)
+    const = np.full((6, 8), 0.5, np.float32)
+    # zero norm -> NaN (rule E4), constant census -> all zero
+    exp = so.unfold_cost_volume(so.ZNCC, const, const, 1, 1, 3)
+    assert_close(sv.unfoldBasedCostVolume(MF.ZNCC, const, const, 1, 1, 3), exp)
+    assert_bits(sv.unfoldBasedCostVolume(MF.CENSUS, const, const, 4, 4, 3), so.unfold_cost_volume(so.CENSUS, const, const, 4, 4, 3))
+    # all-ones census words (monotone ramp) exercise the 2^32 saturation of rule E2
+    ramp = (np.arange(20, 0, -1, dtype=np.float32)[None, :] + np.arange(14, 0, -1, dtype=np.float32)[:, None])
+    assert_bits(sv.unfoldBasedCostVolume(MF.CENSUS, ramp, ramp, 4, 4, 6), so.unfold_cost_volume(so.CENSUS, ramp, ramp, 4, 4, 6))
+    # colour images
+    l3 = rng.uniform(-1, 1, (7, 9, 3)).astype(np.float32)
+    r3 = rng.uniform(-1, 1, (7, 9, 3)).astype(np.float32)
+    assert_close(sv.unfoldBasedCostVolume(MF.SSD, l3, r3, 1, 1, 4), so.unfold_cost_volume(so.SSD, l3, r3, 1, 1, 4))
+    assert_bits(sv.unfoldBasedCostVolume(MF.CENSUS, l3, r3, 2, 2, 4), so.unfold_cost_volume(so.CENSUS, l3, r3, 2, 2, 4))
+
+
+@pytest.mark.parametrize("func", [MF.NCC, MF.ZSAD, MF.SSD, MF.CENSUS])
+def test_feature_cost_volume(rng, func):
+    """featureVolume2CostVolume on caller-provided feature volumes (examples/stereo_refine_test/main.cpp:367-377)."""
+    fl = rng.uniform(-1, 1, (7, 12, 40)).astype(np.float32)
+    fr = rng.uniform(-1, 1, (7, 10, 40)).astype(np.float32)
+    exp = so.feature_cost_volume(int(func), fl, fr, 6)
+    got = sv.featureVolume2CostVolume(func, fl, fr, 6)
+    assert_bits(got, exp) if func == MF.CENSUS else assert_close(got, exp)
+    # non-dense device view (feature axis first in memory) goes through the relayout kernel
+    t = dev(np.ascontiguousarray(fl.transpose(2, 0, 1))).permute(1, 2, 0)
+    got2 = sv.featureVolume2CostVolume(func, t, dev(fr), 6)
+    assert_bits(got2, host(got))
+
+
+# ------------------------------------------------------------------------------------------------ A9
+SGM_PARAMS = [(0.001, 0.01, 100.0), (2.0, 7.0, 3.0), (5.0, 1.0, 0.5), (0.0, 0.0, 0.0)]
+
+
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+@pytest.mark.parametrize("D", [1, 5, 64, 70, 130, 256, 300])
+def test_sgm_bit_exact(rng, strategy, D):
+    H, W = 9, 12
+    for integer in (True, False):
+        cv = (rng.integers(0, 65, (H, W, D)) if integer else rng.uniform(-1, 1, (H, W, D))).astype(np.float32)
+        for n_dir, margins, (P1, P2, Pout) in [(8, (0, 0, 0, 0), SGM_PARAMS[0]), (8, (1, 2, 3, 1), SGM_PARAMS[1]),
+                                               (4, (0, 0, 0, 0), SGM_PARAMS[2]), (8, (2, 0, 0, 1), SGM_PARAMS[3])]:
+            exp = so.sgm(cv, n_dir, strategy, P1, P2, margins, Pout)
+            got = sv.sgmCostVolume(n_dir, strategy, cv, P1, P2, sv.Margins(*margins), Pout)
+            assert_bits(got, exp)
+    got_d = sv.sgmCostVolume(8, strategy, dev(cv), 0.5, 1.5, None, 10.0)
+    assert_bits(got_d, so.sgm(cv, 8, strategy, 0.5, 1.5, (0, 0, 0, 0), 10.0))
+
+
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+@pytest.mark.parametrize("shape", [(21, 33, 40), (33, 21, 40), (1, 17, 8), (17, 1, 8), (2, 2, 3)])
+def test_sgm_shapes_and_nonfinite(rng, strategy, shape):
+    cv = rng.uniform(0, 4, shape).astype(np.float32)
+    exp = so.sgm(cv, 8, strategy, 0.3, 0.9, (0, 0, 0, 0), 7.0)
+    assert_bits(sv.sgmCostVolume(8, strategy, cv, 0.3, 0.9, None, 7.0), exp)
+    if cv.size > 40:
+        cv[0, 0, 0] = np.nan
+        cv[-1, -1, :] = np.inf
+        cv[shape[0] // 2, shape[1] // 2, 1] = -np.inf
+        cv[0, shape[1] // 2, :] = np.nan
+        exp = so.sgm(cv, 8, strategy, 0.3, 0.9, (0, 0, 0, 0), 7.0)
+        got = host(sv.sgmCostVolume(8, strategy, cv, 0.3, 0.9, None, 7.0))
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+
+
+def test_sgm_margins_larger_than_image(rng):
+    cv = rng.uniform(0, 1, (5, 6, 4)).astype(np.float32)
+    for strategy in (so.COST, so.SCORE):
+        assert_bits(sv.sgmCostVolume(8, strategy, cv, 1, 2, sv.Margins(4, 4), 5.0), so.sgm(cv, 8, strategy, 1, 2, (4, 4, 4, 4), 5.0))
+
+
+def test_sgm_rejects_16_directions(rng):
+    from libstevi_amd._capi import SvhError, ERR_UNSUPPORTED
+    with pytest.raises(SvhError) as e:
+        sv.sgmCostVolume(16, so.COST, np.zeros((4, 4, 4), np.float32), 1, 2)
+    assert e.value.status == ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------ A10-A12
+@pytest.mark.parametrize("D", [1, 2, 63, 64, 65, 200, 513])
+def test_extract_index(rng, D):
+    cv = rng.integers(0, 6, (11, 14, D)).astype(np.float32)  # few levels -> many ties
+    cv[0, 0, 0] = np.nan
+    if D > 2:
+        cv[1, 1, 1] = np.nan
+        cv[2, 2, :] = np.nan
+        cv[3, 3, D - 1] = -0.0
+        cv[3, 3, 0] = 0.0
+    for strategy in (so.COST, so.SCORE):
+        exp = so.extract_index(cv, strategy)
+        assert_bits(sv.extractSelectedIndex(strategy, cv), exp)
+        assert_bits(sv.extractSelectedIndex(strategy, dev(cv)), exp)
+    const = np.ones((3, 4, D), np.float32)
+    assert np.all(host(sv.extractSelectedIndex(so.COST, const)) == D - 1)  # all ties -> largest index (F9)
+
+
+def test_index_to_disp_and_selected_cost(rng):
+    cv = rng.uniform(0, 1, (6, 7, 9)).astype(np.float32)
+    idx = rng.integers(0, 9, (6, 7)).astype(np.int32)
+    assert_bits(sv.selectedIndexToDisp(idx, 3), so.index_to_disp(idx, so.RIGHT_TO_LEFT, 3))
+    assert_bits(sv.selectedIndexToDisp(idx, -2, sv.dispDirection.LeftToRight), so.index_to_disp(idx, so.LEFT_TO_RIGHT, -2))
+    assert_bits(sv.selectedCost(cv, idx), np.take_along_axis(cv, idx[:, :, None].astype(np.int64), 2)[:, :, 0])
+
+
+@pytest.mark.parametrize("sdir", [so.TCV_SAME, so.TCV_REVERSED, so.TCV_BOTH])
+@pytest.mark.parametrize("r", [1, 2])
+def test_truncated_cost_volume(rng, sdir, r):
+    cv = rng.uniform(0, 1, (9, 15, 7)).astype(np.float32)
+    idx = rng.integers(0, 7, (9, 15)).astype(np.int32)
+    for ddir in (so.RIGHT_TO_LEFT, so.LEFT_TO_RIGHT):
+        for (h_r, v_r) in [(0, 0), (2, 1)]:
+            exp = so.truncated_cost_volume(cv, idx, h_r, v_r, r, sdir, ddir)
+            got = sv.truncatedCostVolume(cv, idx, h_r, v_r, r, ddir, sdir)
+            assert_close(got, exp, 0.0)
+
+
+@pytest.mark.parametrize("kernel", [so.EQUIANGULAR, so.PARABOLA, so.GAUSSIAN])
+def test_refine(rng, kernel):
+    tcv = rng.uniform(0.1, 2, (8, 9, 3)).astype(np.float32)
+    tcv[0, 0, 0] = np.nan
+    tcv[1, 1] = 1.0  # 0/0
+    raw = rng.integers(0, 50, (8, 9)).astype(np.int32)
+    assert_close(sv.refineDispCostInterpolation(kernel, tcv, raw), so.refine_disp(tcv, raw, kernel), 1e-5)
+    tcv5 = rng.uniform(0.1, 2, (4, 5, 5)).astype(np.float32)
+    raw5 = rng.integers(0, 9, (4, 5)).astype(np.int32)
+    assert_close(sv.refineDispCostInterpolation(kernel, tcv5, raw5), so.refine_disp(tcv5, raw5, kernel), 1e-5)
+    assert sv.refineDispCostInterpolation(kernel, np.zeros((2, 2, 4), np.float32), np.zeros((2, 2), np.int32)).size == 0
+
+
+# ------------------------------------------------------------------------------------------------ fused pipeline
+def oracle_chain(func, img_l, img_r, h_r, v_r, D, n_dir, P, margins, refine, rh, rv):
+    strategy = so.func_strategy(func)
+    cv = so.unfold_cost_volume(func, img_l, img_r, h_r, v_r, D)
+    vol = so.sgm(cv, n_dir, strategy, P[0], P[1], margins, P[2]) if n_dir else cv
+    idx = so.extract_index(vol, strategy)
+    out = {"cv": cv, "vol": vol, "idx": idx, "disp": so.index_to_disp(idx)}
+    if refine is not None:
+        out["refined"] = so.refine_disp(so.truncated_cost_volume(vol, idx, rh, rv, 1), idx, refine)
+    return out
+
+
+@pytest.mark.parametrize("func,h_r,v_r,D,n_dir,refine", [
+    (MF.SAD, 2, 2, 16, 0, None),            # config 1 shape family: SAD 5x5 + argmin
+    (MF.CENSUS, 4, 4, 24, 0, None),         # config 2: census 9x9 volume + argmin
+    (MF.CENSUS, 4, 4, 40, 8, None),         # config 3: census + SGM-8
+    (MF.CENSUS, 4, 4, 70, 4, so.PARABOLA),
+    (MF.NCC, 5, 5, 20, 8, so.PARABOLA),     # config 4: NCC 11x11 + SGM-8 + parabola
+    (MF.ZNCC, 2, 2, 12, 8, so.EQUIANGULAR),
+    (MF.SSD, 1, 1, 9, 8, so.PARABOLA),      # Cost branch on a float volume
+])
+def test_stereo_match_equals_chain(func, h_r, v_r, D, n_dir, refine):
+    src, tgt, _ = parallax_pair(30, 44, 10, 8, 12, 2, 6, seed=int(func) + D)
+    P = (0.001, 0.01, 100.0)
+    exp = oracle_chain(int(func), tgt, src, h_r, v_r, D, n_dir, P, (0, 0, 0, 0), refine, h_r, v_r)
+    for mk in (lambda x: x, dev):
+        res = sv.stereoMatch(func, mk(tgt), mk(src), h_r, v_r, D, sgmDirections=n_dir, P1=P[0], P2=P[1], Pout=P[2],
+                             refineKernel=refine, refine_h_radius=h_r, refine_v_radius=v_r, want_cv=True, want_sgm_cv=bool(n_dir))
+        census = int(func) in (MF.CENSUS, MF.HAMMING)
+        if census:
+            assert_bits(res["cv"], exp["cv"])
+            assert_bits(res["disp"], exp["disp"])
+            if n_dir:
+                assert_bits(res["sgm_cv"], exp["vol"])
+        else:
+            assert_close(res["cv"], exp["cv"])
+            # winners are compared on the GPU's own volume (float costs differ in the last bits from the CPU's)
+            gvol = host(res["sgm_cv"] if n_dir else res["cv"])
+            assert_bits(res["disp"], so.index_to_disp(so.extract_index(gvol, so.func_strategy(int(func)))))
+            assert (host(res["disp"]) == exp["disp"]).mean() > 0.99
+        if refine is not None:
+            gvol = host(res["sgm_cv"] if n_dir else res["cv"])
+            gidx = so.extract_index(gvol, so.func_strategy(int(func)))
+            assert_close(res["refined"], so.refine_disp(so.truncated_cost_volume(gvol, gidx, h_r, v_r, 1), gidx, refine), 1e-5)
+            if census:
+                assert_close(res["refined"], exp["refined"])
+    # the fused call without volume outputs gives the same map
+    lean = sv.stereoMatch(func, dev(tgt), dev(src), h_r, v_r, D, sgmDirections=n_dir, P1=P[0], P2=P[1], Pout=P[2])
+    assert_bits(lean["disp"], host(res["disp"]))
+
+
+def test_stereo_match_margins_and_direction(rng):
+    src, tgt, _ = parallax_pair(26, 40, 8, 6, 10, 1, 5, seed=11)
+    P = (0.5, 2.0, 9.0)
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, 33, so.LEFT_TO_RIGHT)
+    vol = so.sgm(cv, 8, so.COST, *P[:2], (2, 1, 3, 2), P[2])
+    idx = so.extract_index(vol, so.COST)
+    res = sv.stereoMatch(MF.CENSUS, dev(tgt), dev(src), 4, 4, 33, dDir=sv.dispDirection.LeftToRight, sgmDirections=8, P1=P[0], P2=P[1],
+                         Pout=P[2], margins=sv.Margins(2, 1, 3, 2), want_sgm_cv=True)
+    assert_bits(res["sgm_cv"], vol)
+    assert_bits(res["disp"], so.index_to_disp(idx, so.LEFT_TO_RIGHT))
+
+
+def test_disparity_shards_reduce_to_full_argmin(rng):
+    """Multi-GPU contract on one device: per-shard keys, element-wise min (what the RCCL all-reduce does), decode."""
+    src, tgt, _ = parallax_pair(24, 36, 8, 6, 10, 1, 5, seed=5)
+    D = 24
+    for func, red in ((MF.CENSUS, np.minimum), (MF.SAD, np.minimum), (MF.NCC, np.maximum)):
+        full = sv.stereoMatch(func, dev(tgt), dev(src), 4, 4, D, want_cv=True)
+        keys = None
+        for (b, n) in ((0, 7), (7, 9), (16, 8)):
+            part = sv.stereoMatch(func, dev(tgt), dev(src), 4, 4, D, want_keys=True, want_cv=True, shard=(b, n))
+            assert_bits(part["cv"], host(full["cv"])[:, :, b:b + n])
+            k = host(part["keys"]).view(np.uint64)
+            keys = k if keys is None else red(keys, k)
+        idx = sv.keysToIndex(sv.matchFuncStrategy(func), keys, D)
+        assert_bits(idx, host(full["disp"]))
+
+
+def test_non_dense_device_output(rng):
+    cv = rng.uniform(0, 1, (6, 8, 10)).astype(np.float32)
+    # cost volume stored (row, disparity, col) like the reference's aggregateCost (cross_correlations.h:220)
+    stored = dev(np.ascontiguousarray(cv.transpose(0, 2, 1))).permute(0, 2, 1)
+    assert not stored.is_contiguous()
+    assert_bits(sv.extractSelectedIndex(so.COST, stored), so.extract_index(cv, so.COST))
+    assert_bits(sv.sgmCostVolume(8, so.SCORE, stored, 0.1, 0.4, None, 3.0), so.sgm(cv, 8, so.SCORE, 0.1, 0.4, (0, 0, 0, 0), 3.0))

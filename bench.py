@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): census 9x9 + 8-path SGM, 1920x1080, D=256.
+
+One "step" = one pass of the fused device pipeline (svh_stereo_match) over one synthetic stereo pair that is
+already resident in HBM: census transform of both images -> Hamming cost (evaluated on the fly) -> the
+reference's five effective SGM passes -> winner -> disparity map (int32).  Output bit-exact vs the oracle
+(tests/test_gpu_parity.py, tests/test_gpu_fullsize.py).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Metric: Mdisparities/s = W*H*D*steps / seconds / 1e6 summed over ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# C3 of SURVEY.md section 8(d): 1920x1080, D=256, census 9x9, SGM-8 (P1=0.001, P2=0.01, Pout=100), seed 3
+WORKLOAD = dict(W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=3,
+                bg=8, sq=64, side=320, v=320, h=380)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def visited_voxels_per_pass(H, W, D, n_pass):
+    """voxels touched by each effective SGM pass, zero margins"""
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    masks = [np.ones((H, W), bool), np.ones((H, W), bool), ii >= jj, jj >= ii, ii + jj < W, ii + jj < H]
+    return [int(m.sum()) * D for m in masks[:n_pass]]
+
+
+def algorithmic_bytes(kernel, wl):
+    """Algorithmic bytes per launch of `kernel` under the model of SURVEY.md section 8(d) (DESIGN.md "Roofline"):
+    internal intermediates at the narrowest exact type (C u8, S i16), API outputs at their API size, each
+    effective SGM pass = one read of C + one read-modify-write of S = 5 B/voxel."""
+    H, W, D = wl["H"], wl["W"], wl["D"]
+    px, vox = H * W, H * W * D
+    if kernel == "sgm_cost_minmap":
+        v = visited_voxels_per_pass(H, W, D, 6)
+        return 5.0 * sum(v) / len(v)           # average over the six launches of one step
+    if kernel == "sgm_cost_apply":
+        return 2.0 * vox + 4.0 * px            # final read of S (i16) + int32 index write
+    if kernel == "census_transform":
+        return 4.0 * px + 3 * 4.0 * px         # image read + nW words written
+    if kernel == "index_to_disp":
+        return 8.0 * px
+    return None
+
+
+def cpu_baseline(wl, budget_s=18.0):
+    """Oracle (CPU restatement of the reference, literal O(D^2) SGM loops) on a bounded row band of the workload."""
+    import oracle as so
+    from helpers import parallax_pair
+    src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"])
+    D, hr, vr = wl["D"], wl["h_r"], wl["v_r"]
+
+    def run(rows, variant):
+        s, t = np.ascontiguousarray(src[:rows]), np.ascontiguousarray(tgt[:rows])
+        t0 = time.perf_counter()
+        cv = so.unfold_cost_volume(so.CENSUS, t, s, hr, vr, D)
+        vol = so.sgm(cv, wl["sgm"], so.COST, wl["P1"], wl["P2"], (0, 0, 0, 0), wl["Pout"], variant=variant)
+        so.index_to_disp(so.extract_index(vol, so.COST))
+        return time.perf_counter() - t0
+
+    out = {}
+    for variant, key in ((0, "literal"), (1, "linear")):
+        rows = 4
+        dt = run(rows, variant)
+        target = budget_s * (0.75 if variant == 0 else 0.25)
+        rows2 = int(min(wl["H"], max(rows, rows * target / max(dt, 1e-6))))
+        if rows2 > rows:
+            dt = run(rows2, variant)
+            rows = rows2
+        out[key] = (rows * wl["W"] * D / dt / 1e6, rows, dt)
+    cores = so.num_threads()
+    lit, lin = out["literal"], out["linear"]
+    return {
+        "value": round(lit[0], 3), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
+        "sample": f"top {lit[1]} rows of the same {wl['W']}x{wl['H']} pair, D={D}: census 9x9 volume + SGM-8 (literal O(D^2) loops of "
+                  f"sgm.h:269-295) + argmin, {lit[2]:.1f} s, OpenMP over rows/lines",
+        "linear_sgm_value": round(lin[0], 3),
+        "linear_sgm_sample": f"top {lin[1]} rows, O(D) SGM restatement (bitwise identical), {lin[2]:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--materialize", action="store_true", help="also write the cost volume and the SGM volume (float32) to HBM")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                             "--master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import libstevi_amd as sv
+    from helpers import parallax_pair
+
+    wl = dict(WORKLOAD)
+    src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"] + rank)
+    d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+
+    def step():
+        # (target, source) passed as (img_l, img_r) like benchmarkCrossCorrelationAlgorithms.cpp:93
+        return sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"],
+                              P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"], want_cv=args.materialize, want_sgm_cv=args.materialize)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sv.profile_reset(d_src)
+    sv.profile_enable(d_src, True)  # hipEvents around every kernel, on the stream the kernels run on
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    sv.profile_enable(d_src, False)
+    prof = sv.profile_collect(d_src)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    checksum = int(out["disp"].sum().item())
+
+    if rank == 0:
+        voxels = wl["W"] * wl["H"] * wl["D"]
+        value = voxels * args.steps * world / elapsed / 1e6
+        ms_per_step = elapsed / args.steps * 1e3
+        # dominant kernel by accumulated event time inside the timed region
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_ms, dom_n) = dom
+        avg_ms = dom_ms / max(dom_n, 1)
+        alg = algorithmic_bytes(dom_name, wl)
+        roof = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "traffic": None}
+        if alg is not None:
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(alg)})
+        else:
+            roof.update({"achieved": None, "frac": None})
+        pipeline_alg = 28.0 * voxels + 60.0 * wl["W"] * wl["H"]
+        kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+        line = {
+            "metric": "Mdisparities/s (W*H*D) for census+SGM, 1080p D=256", "value": round(value, 1), "unit": "Mdisparities/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1920x1080 synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
+                                   "D=256, argmin -> int32 disparity map (BASELINE.json configs[2])",
+                       "pipeline": "svh_stereo_match fused, inputs and outputs resident in HBM",
+                       "materialize_volumes": bool(args.materialize),
+                       "parallelism": "1 pair per GPU" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),
+                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                  "model": "SURVEY.md 8(d) C3: 28 B/voxel + 60 B/pixel"},
+            "kernel_ms_per_step": kernel_ms,
+            "disp_checksum": checksum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

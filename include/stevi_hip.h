@@ -79,8 +79,8 @@ typedef struct svh_array {
 
 /* ---- context ------------------------------------------------------------------------------------ */
 
-/* Creates a context bound to HIP device `device` (-1 = current device).  `stream` is a hipStream_t to
- * enqueue on (e.g. the caller's / PyTorch's current stream), or NULL to let the context create its own. */
+/* Creates a context bound to HIP device `device` (-1 = current device).  `stream` is the hipStream_t to
+ * enqueue on (e.g. the caller's / PyTorch's current stream); NULL is the device's default (null) stream. */
 int svh_context_create(svh_context **ctx, int device, void *stream);
 int svh_context_destroy(svh_context *ctx);
 int svh_context_set_stream(svh_context *ctx, void *stream);
@@ -90,6 +90,9 @@ int svh_context_trim(svh_context *ctx);
 const char *svh_status_string(int status);
 /* message of the last failing call on this context ("" if none) */
 const char *svh_last_error(const svh_context *ctx);
+/* Tuning / test switches.  "census_fast_path" (default 1): 0 forces the general wave-per-line SGM kernels
+ * for census costs too (same results, used by the parity tests to cross-check the two implementations). */
+int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);
 

@@ -7,4 +7,4 @@ correlation.py   Python mirror of the same functions over the C ABI (numpy = hos
 from . import _capi  # noqa: F401
 from .correlation import *  # noqa: F401,F403
 from .correlation import (Margins, PaddingMargins, searchOffset1, matchFuncStrategy, context_for, profile_enable,  # noqa: F401
-                          profile_reset, profile_collect)
+                          profile_reset, profile_collect, set_option)

@@ -20,7 +20,7 @@ F32, I32, U32, U8, U64 = 0, 1, 2, 3, 4
 
 # every symbol include/stevi_hip.h declares
 EXPORTS = [
-    "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_synchronize", "svh_context_trim",
+    "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_set_option", "svh_context_synchronize", "svh_context_trim",
     "svh_status_string", "svh_last_error", "svh_device_available",
     "svh_profile_enable", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
@@ -95,6 +95,7 @@ def load():
         "svh_context_create": (C.c_int, [P(C.c_void_p), C.c_int, C.c_void_p]),
         "svh_context_destroy": (C.c_int, [ctx]),
         "svh_context_set_stream": (C.c_int, [ctx, C.c_void_p]),
+        "svh_context_set_option": (C.c_int, [ctx, C.c_char_p, C.c_int]),
         "svh_context_synchronize": (C.c_int, [ctx]),
         "svh_context_trim": (C.c_int, [ctx]),
         "svh_status_string": (C.c_char_p, [C.c_int]),

@@ -419,6 +419,12 @@ def keysToIndex(strategy, keys, disp_count):
     return out
 
 
+def set_option(x, name, value):
+    """svh_context_set_option on the context used for array x (e.g. "census_fast_path", 0/1)."""
+    ctx = context_for(x)
+    _check(ctx, _capi.load().svh_context_set_option(ctx, name.encode(), int(value)))
+
+
 # ------------------------------------------------------------------------------------------------ profiling
 def profile_enable(x, on=True):
     _capi.load().svh_profile_enable(context_for(x), 1 if on else 0)

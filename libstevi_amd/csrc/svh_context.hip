@@ -285,15 +285,7 @@ int svh_context_create(svh_context **out, int device, void *stream) {
     if (hipSetDevice(device) != hipSuccess) return SVH_ERR_HIP;
     svh_context *ctx = new svh_context();
     ctx->device = device;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete ctx;
-            return SVH_ERR_HIP;
-        }
-        ctx->own_stream = true;
-    }
+    ctx->stream = (hipStream_t)stream; // NULL = the device's default (null) stream
     *out = ctx;
     return SVH_OK;
 }
@@ -316,17 +308,17 @@ int svh_context_destroy(svh_context *ctx) {
 int svh_context_set_stream(svh_context *ctx, void *stream) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->own_stream) {
-        (void)hipStreamDestroy(ctx->stream);
-        ctx->own_stream = false;
-    }
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
-        SVH_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    ctx->stream = (hipStream_t)stream;
     return SVH_OK;
+}
+
+int svh_context_set_option(svh_context *ctx, const char *name, int value) {
+    if (!ctx || !name) return SVH_ERR_INVALID_ARGUMENT;
+    if (strcmp(name, "census_fast_path") == 0) {
+        ctx->census_fast_path = value != 0;
+        return SVH_OK;
+    }
+    return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);
 }
 
 int svh_context_synchronize(svh_context *ctx) {

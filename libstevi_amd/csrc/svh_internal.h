@@ -42,6 +42,7 @@ struct svh_context {
     std::string last_error;
     std::vector<svh::PoolBlock> pool;
     bool profiling = false;
+    bool census_fast_path = true; // svh_context_set_option("census_fast_path")
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;
@@ -185,6 +186,13 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
                         float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
                         int key_total_D);
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm);
+// census specialisation of the Cost branch (svh_census_sgm.hip)
+bool census_lane_kernels_available(int nWw, int D);
+bool census_exact_regime(const SgmArgs &a, int nWw);
+int dev_census_minmaps_exact(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap);
+int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, int32_t *out_idx,
+                            float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
+                            int key_total_D);
 
 int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
                       unsigned long long *keys, int key_index_offset, int key_total_D);

@@ -408,12 +408,13 @@ static int pick_R(int D) {
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
+// phase 1: the per-pass min_p maps (the sequential part); phase 2: rebuild S / pick the winner per pixel
 template <class SRC, int R>
-static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut &out) {
+static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
     constexpr int B = (R <= 4) ? 8 : (R == 8 ? 4 : 2);
-    if (Hp > 0 && Wp > 0) {
+    if (do_minmaps && Hp > 0 && Wp > 0) {
         for (int q = 0; q < n_pass; q++) {
             LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
             SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), ceil_div(ls.n_lines, 4), 256, 0, src, ls, a.D, a.W,
@@ -421,22 +422,24 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
             SVH_CHECK_LAUNCH(ctx);
         }
     }
-    const int64_t npx = (int64_t)a.H * a.W;
-    int grid = grid_for(npx, 4, 256 * 8 * 4);
-    SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
-               Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, out);
-    SVH_CHECK_LAUNCH(ctx);
+    if (out) {
+        const int64_t npx = (int64_t)a.H * a.W;
+        int grid = grid_for(npx, 4, 256 * 8 * 4);
+        SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
+                   Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out);
+        SVH_CHECK_LAUNCH(ctx);
+    }
     return SVH_OK;
 }
 
 template <class SRC>
-static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut &out) {
+static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps) {
     switch (pick_R(a.D)) {
-    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out);
-    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out);
-    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out);
-    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out);
-    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out);
+    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps);
+    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps);
+    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps);
+    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps);
+    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps);
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
     }
 }
@@ -450,10 +453,19 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
     ApplyOut out{out_sgm, out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D};
     if (cs.cv) {
         SrcVolume src{cs.cv, a.W, a.D, aligned16(cs.cv) && a.D % 4 == 0};
-        return dispatch_cost_branch(ctx, a, src, mmap, out);
+        return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
     }
     SrcCensus src{cs.src_words, cs.tgt_words, cs.nWw, a.W, cs.Wt, cs.sign, cs.disp_lower, a.D};
-    return dispatch_cost_branch(ctx, a, src, mmap, out);
+    // census specialisation (svh_census_sgm.hip): pixel-per-lane kernels, and in the integer-exact regime the
+    // min_p maps from one parallel sweep + scalar line recurrences instead of six wave-per-line launches
+    const bool lanes = ctx->census_fast_path && census_lane_kernels_available(cs.nWw, a.D);
+    const bool exact = lanes && census_exact_regime(a, cs.nWw);
+    const bool lane_apply = lanes && !out_sgm;
+    if (exact) SVH_TRY(dev_census_minmaps_exact(ctx, scr, a, cs, mmap));
+    if (!exact || !lane_apply) SVH_TRY(dispatch_cost_branch(ctx, a, src, mmap, lane_apply ? nullptr : &out, !exact));
+    if (lane_apply)
+        SVH_TRY(dev_census_apply_select(ctx, a, cs, mmap, out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D));
+    return SVH_OK;
 }
 
 template <int R>

@@ -72,7 +72,7 @@ def test_census_transform(rng, h_r, v_r):
     assert_bits(sv.censusTransform2D(img, h_r, v_r), exp)
     assert_bits(sv.censusTransform2D(dev(img), h_r, v_r), exp)
     # colour image and explicit padding
-    rgb = rng.uniform(-1, 1, (11, 12, 3)).astype(np.float32)
+    rgb = rng.uniform(-1, 1, (19, 21, 3)).astype(np.float32)
     assert_bits(sv.censusTransform2D(rgb, h_r, v_r, sv.PaddingMargins(2, 1, 0, 3)), so.census_transform(rgb, h_r, v_r, (2, 1, 0, 3)))
     # feature-volume entry point
     feat = so.unfold(img, h_r, v_r)
@@ -325,3 +325,33 @@ def test_non_dense_device_output(rng):
     assert not stored.is_contiguous()
     assert_bits(sv.extractSelectedIndex(so.COST, stored), so.extract_index(cv, so.COST))
     assert_bits(sv.sgmCostVolume(8, so.SCORE, stored, 0.1, 0.4, None, 3.0), so.sgm(cv, 8, so.SCORE, 0.1, 0.4, (0, 0, 0, 0), 3.0))
+
+
+# ------------------------------------------------------------------------------------------------ census fast path
+@pytest.mark.parametrize("D", [1, 7, 70, 256, 300])
+@pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
+def test_census_fast_path_equals_general_and_oracle(D, ddir):
+    """The pixel-per-lane census kernels (integer-exact min_p recurrence) against the general wave-per-line kernels
+    and the oracle: disparity map, refined map and reduction keys."""
+    src, tgt, _ = parallax_pair(37, 300, 12, 8, 40, 3, 17, seed=D)
+    cases = [((0, 0, 0, 0), 100.0, 8, 4, 4), ((3, 2, 5, 1), 7.0, 8, 4, 4), ((0, 0, 0, 0), 100.0, 4, 3, 3), ((0, 0, 0, 0), 2.5, 8, 4, 4),
+             ((0, 0, 0, 0), 100.0, 0, 2, 2), ((0, 0, 0, 0), 1e6, 8, 4, 4)]
+    for margins, Pout, n_dir, h_r, v_r in cases:
+        kw = dict(dDir=ddir, sgmDirections=n_dir, P1=0.3, P2=0.9, Pout=Pout, margins=sv.Margins(*margins), refineKernel=so.PARABOLA,
+                  refine_h_radius=h_r, refine_v_radius=v_r, want_keys=True)
+        d_tgt, d_src = dev(tgt), dev(src)
+        try:
+            sv.set_option(d_tgt, "census_fast_path", 1)
+            fast = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
+            sv.set_option(d_tgt, "census_fast_path", 0)
+            gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
+        finally:
+            sv.set_option(d_tgt, "census_fast_path", 1)
+        for k in ("disp", "keys"):
+            assert_bits(fast[k], host(gen[k]))
+        assert_close(fast["refined"], host(gen["refined"]), 0.0)
+        cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, v_r, D, int(ddir))
+        vol = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, margins, Pout) if n_dir else cv
+        idx = so.extract_index(vol, so.COST)
+        assert_bits(fast["disp"], so.index_to_disp(idx, int(ddir)))
+        assert_close(fast["refined"], so.refine_disp(so.truncated_cost_volume(vol, idx, h_r, v_r, 1), idx, so.PARABOLA), 1e-6)

@@ -59,8 +59,17 @@ template <int NW> __device__ __forceinline__ float hamming_at(const Words<NW> &s
     return (float)acc;
 }
 
+template <int NW> __device__ __forceinline__ int hamming_int(const Words<NW> &s, const uint32_t *lds, int win, int x) {
+    int acc = 0;
+    if constexpr (NW > 0) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) acc += __popc(s.v[w] ^ lds[w * win + x]);
+    }
+    return acc;
+}
+
 // g(p) = min over d of the first-pixel actual cost c + (c [+ Pout]) (sgm.h:287-294 with min_p = 0)
-template <int NW>
+template <int NW, bool EXACT>
 __global__ void __launch_bounds__(TJ) census_gmin_kernel(CensusGeom g, float Pout, float *__restrict__ gmap) {
     extern __shared__ uint32_t lds[];
     const int i = blockIdx.y, j0 = blockIdx.x * TJ, tj = threadIdx.x, j = j0 + tj;
@@ -73,11 +82,23 @@ __global__ void __launch_bounds__(TJ) census_gmin_kernel(CensusGeom g, float Pou
 #pragma unroll
     for (int w = 0; w < NW; w++) s.v[w] = sp[w];
     float m = INFINITY;
-    for (int d = 0; d < g.D; d++) {
-        const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
-        const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
-        const float t = (j + d >= g.Ws) ? c + Pout : c;
-        m = fminf(m, c + t);
+    if (EXACT) {
+        // integer-exact regime: c + (c + Pout) = 2c + Pout with integer Pout, evaluated in int32
+        const int pout = (int)Pout;
+        int mi = 0x7FFFFFFF;
+        for (int d = 0; d < g.D; d++) {
+            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
+            const int c2 = 2 * hamming_int<NW>(s, lds, win, x);
+            mi = min(mi, (j + d >= g.Ws) ? c2 + pout : c2);
+        }
+        m = (float)mi;
+    } else {
+        for (int d = 0; d < g.D; d++) {
+            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
+            const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
+            const float t = (j + d >= g.Ws) ? c + Pout : c;
+            m = fminf(m, c + t);
+        }
     }
     gmap[(int64_t)i * g.Ws + j] = m;
 }
@@ -159,7 +180,7 @@ __device__ __forceinline__ float sgm_value(float c, float t, const PixelPasses &
 }
 
 // apply + extractSelectedIndex (+ truncated taps, + reduction keys) without writing any volume
-template <int NW>
+template <int NW, bool EXACT>
 __global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout,
                                                                  const float *__restrict__ mmap, SelectOut out) {
     extern __shared__ uint32_t lds[];
@@ -193,14 +214,40 @@ __global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, S
     // sequential scan of extractSelectedIndex (correlation_base.h:441-455): '<=' keeps the last minimum
     float best = 0.0f;
     int bd = 0;
-    for (int d = 0; d < g.D; d++) {
-        const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
-        const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
-        const float t = (j + d >= g.Ws) ? c + Pout : c;
-        const float v = sgm_value(c, t, pp, n_pass);
-        if (d == 0 || v <= best) {
-            best = v;
-            bd = d;
+    // integer-exact regime: every term (c + (t - mp)) - c equals t - mp exactly, so
+    // S = (1 + n) c + n Pout [oob] - sum(mp) in int32 carries the very same values as the float expression
+    int n_vis = 0, k0 = 0, k1 = 0;
+    if (EXACT) {
+        int msum = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if ((pp.vis >> q) & 1u) {
+                n_vis++;
+                msum += (int)pp.mp[q];
+            }
+        k0 = -msum;
+        k1 = n_vis * (int)Pout - msum;
+        int besti = 0;
+        const int mul = 1 + n_vis;
+        for (int d = 0; d < g.D; d++) {
+            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
+            const int v = mul * hamming_int<NW>(s, lds, win, x) + ((j + d >= g.Ws) ? k1 : k0);
+            if (d == 0 || v <= besti) {
+                besti = v;
+                bd = d;
+            }
+        }
+        best = (float)besti;
+    } else {
+        for (int d = 0; d < g.D; d++) {
+            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
+            const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
+            const float t = (j + d >= g.Ws) ? c + Pout : c;
+            const float v = sgm_value(c, t, pp, n_pass);
+            if (d == 0 || v <= best) {
+                best = v;
+                bd = d;
+            }
         }
     }
     if (out.idx) out.idx[p] = bd;
@@ -214,9 +261,13 @@ __global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, S
             float v = __uint_as_float(0x7FC00000u);
             if (!(px_bad || pd < 0 || pd >= g.D || j + pd + out.taps_h_r >= g.Ws)) {
                 const int x = tj + (g.sign > 0 ? pd : g.D - 1 - pd);
-                const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
-                const float t = (j + pd >= g.Ws) ? c + Pout : c;
-                v = sgm_value(c, t, pp, n_pass);
+                if (EXACT) {
+                    v = (float)((1 + n_vis) * hamming_int<NW>(s, lds, win, x) + ((j + pd >= g.Ws) ? k1 : k0));
+                } else {
+                    const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
+                    const float t = (j + pd >= g.Ws) ? c + Pout : c;
+                    v = sgm_value(c, t, pp, n_pass);
+                }
             }
             out.taps[p * 3 + tap] = v;
         }
@@ -227,17 +278,20 @@ template <int NW>
 int launch_gmin(svh_context *ctx, const CensusGeom &g, float Pout, float *gmap) {
     dim3 grid(ceil_div(g.Ws, TJ), g.H);
     size_t shmem = (size_t)(NW > 0 ? NW : 1) * (TJ + g.D - 1) * sizeof(uint32_t);
-    SVH_LAUNCH(ctx, "census_gmin", census_gmin_kernel<NW>, grid, TJ, shmem, g, Pout, gmap);
+    SVH_LAUNCH(ctx, "census_gmin", (census_gmin_kernel<NW, true>), grid, TJ, shmem, g, Pout, gmap);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
 template <int NW>
 int launch_apply_select(svh_context *ctx, const CensusGeom &g, const ScanGeom &sg, int n_pass, float Pout, const float *mmap,
-                        const SelectOut &out) {
+                        const SelectOut &out, bool exact) {
     dim3 grid(ceil_div(g.Ws, TJ), g.H);
     size_t shmem = (size_t)(NW > 0 ? NW : 1) * (TJ + g.D - 1) * sizeof(uint32_t);
-    SVH_LAUNCH(ctx, "census_apply_select", census_apply_select_kernel<NW>, grid, TJ, shmem, g, sg, n_pass, Pout, mmap, out);
+    if (exact)
+        SVH_LAUNCH(ctx, "census_apply_select", (census_apply_select_kernel<NW, true>), grid, TJ, shmem, g, sg, n_pass, Pout, mmap, out);
+    else
+        SVH_LAUNCH(ctx, "census_apply_select", (census_apply_select_kernel<NW, false>), grid, TJ, shmem, g, sg, n_pass, Pout, mmap, out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -285,12 +339,13 @@ int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource
     CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
     ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
     SelectOut out{out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D};
+    const bool exact = census_exact_regime(a, cs.nWw); // then the min_p maps hold integers too, whichever kernel made them
     switch (cs.nWw) {
-    case 0: return launch_apply_select<0>(ctx, g, sg, n_pass, a.Pout, mmap, out);
-    case 1: return launch_apply_select<1>(ctx, g, sg, n_pass, a.Pout, mmap, out);
-    case 2: return launch_apply_select<2>(ctx, g, sg, n_pass, a.Pout, mmap, out);
-    case 3: return launch_apply_select<3>(ctx, g, sg, n_pass, a.Pout, mmap, out);
-    default: return launch_apply_select<4>(ctx, g, sg, n_pass, a.Pout, mmap, out);
+    case 0: return launch_apply_select<0>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
+    case 1: return launch_apply_select<1>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
+    case 2: return launch_apply_select<2>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
+    case 3: return launch_apply_select<3>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
+    default: return launch_apply_select<4>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
     }
 }
 

@@ -3,18 +3,22 @@
 // For census costs the volume is a pure function of two small word maps, so nothing voxel-sized has to live in
 // HBM.  These kernels map one image pixel to one lane and walk the disparity axis sequentially inside the lane:
 //   * a block handles 256 consecutive pixels of one row and stages the (256 + D - 1)-pixel window of target
-//     census words in LDS (one plane per word: lanes read consecutive dwords, conflict free);
+//     census words in LDS as an array of NW-word records, stored so that lane tj reads record ybase(tj) + d:
+//     64 lanes read 64 consecutive records (ds_read_b32 / b64 / b128 with an immediate offset, conflict free);
 //   * the per-pixel reductions over d (minimum, winner with the reference's "<=" scan order) need no cross-lane
-//     traffic at all, and the d loop is literally the reference's loop order, ties included.
+//     traffic at all.
 //
 // Exactness argument used by the fast path (checked on the host before it is taken, see census_exact_regime):
 // Hamming costs are integers in [0, 32 nWw]; when Pout is an integer and 8 (2 cmax + |Pout|) (L + 2) < 2^24
 // (L = longest line), every intermediate of sgm.h:257-300 is an integer below 2^24 in magnitude, so each float
-// operation of the reference is exact.  Then the next pixel's min_p is
-//     min_d [ c + ((c [+Pout]) - mp) ]  =  g(p) - mp,      g(p) = min_d [ c + (c [+Pout]) ]
-// bit for bit, i.e. the sequential part of a pass collapses to the scalar recurrence mp' = g - mp along the line
-// (line_scan_kernel), fed by one fully parallel sweep (census_gmin_kernel).  The apply step still evaluates the
-// reference's expression per voxel.  Outside that regime the general wave-per-line kernels of svh_sgm.hip run.
+// operation of the reference is exact and integer arithmetic carries the very same values.  Then
+//   * the next pixel's min_p is  min_d [ c + ((c [+Pout]) - mp) ] = g(p) - mp,  g(p) = min_d [ 2c [+Pout] ]:
+//     the sequential part of a pass is the scalar recurrence mp' = g - mp along the line (scan kernels), fed by one
+//     fully parallel sweep (census_gmin_kernel);
+//   * S(p,d) = c + sum over visiting passes of ((c + (t - mp_q)) - c) = (1 + n) c + n Pout [j+d >= W] - sum mp_q,
+//     and the "<=" winner scan over d is a min over keys (value, D-1-d).
+// Outside that regime (non-integer or huge Pout) the float expressions of the reference are evaluated literally
+// (EXACT = false variants) on min_p maps produced by the general wave-per-line kernels of svh_sgm.hip.
 #include "svh_internal.h"
 
 namespace svh {
@@ -22,136 +26,239 @@ namespace svh {
 namespace {
 
 constexpr int TJ = 256; // pixels (= threads) per block
+constexpr int UNROLL = 8;
 
 struct CensusGeom {
     const uint32_t *sw, *tw; // compact words (H, Ws, nWw), (H, Wt, nWw); target pre-rounded through float (E2)
     int nWw, H, Ws, Wt, D, sign, disp_lower;
 };
 
-// Stage the target-word window of this block into LDS, planar: lds[w * win + x], x = column - x_base.
-// sign > 0: x = tj + d;  sign < 0: x = tj + (D - 1 - d).
-__device__ __forceinline__ void stage_target_window(const CensusGeom &g, int i, int j0, uint32_t *lds, int win) {
-    const int x_base = g.sign > 0 ? j0 + g.disp_lower : j0 - g.disp_lower - (g.D - 1);
-    const uint32_t *trow = g.tw + (int64_t)i * g.Wt * g.nWw;
-    for (int e = threadIdx.x; e < win * g.nWw; e += blockDim.x) {
-        int x = e / g.nWw, w = e - x * g.nWw; // consecutive threads read consecutive dwords of the row
-        int jt = x_base + x;
-        lds[w * win + x] = (jt >= 0 && jt < g.Wt) ? trow[(int64_t)jt * g.nWw + w] : 0u; // zero vector outside the image
-    }
-}
-
 template <int NW> struct Words {
     uint32_t v[NW > 0 ? NW : 1];
 };
 
-template <int NW> __device__ __forceinline__ float hamming_at(const Words<NW> &s, const uint32_t *lds, int win, int x, int nWw) {
-    uint32_t acc = 0;
+// Stage the target-word window of this block into LDS: record y of lane tj's disparity d is y = ybase(tj) + d with
+// ybase = tj for sign > 0 (target column j + lower + d) and TJ-1-tj for sign < 0 (target column j - lower - d, the
+// window is stored mirrored so that y still grows with d).  Columns outside the target image hold the zero vector
+// (cross_correlations.h:235).
+template <int NW> __device__ __forceinline__ void stage_target_window(const CensusGeom &g, int i, int j0, uint32_t *lds) {
     if constexpr (NW > 0) {
+        const int win = TJ + g.D - 1;
+        const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
+        for (int e = threadIdx.x; e < win * NW; e += TJ) {
+            const int y = e / NW, w = e - y * NW;
+            const int jt = g.sign > 0 ? j0 + g.disp_lower + y : j0 + (TJ - 1) - g.disp_lower - y;
+            lds[e] = (jt >= 0 && jt < g.Wt) ? trow[(int64_t)jt * NW + w] : 0u;
+        }
+    }
+}
+
+template <int NW> __device__ __forceinline__ Words<NW> load_source_words(const CensusGeom &g, int64_t p) {
+    Words<NW> s;
+    s.v[0] = 0;
+    if constexpr (NW > 0) {
+        const uint32_t *sp = g.sw + p * NW;
 #pragma unroll
-        for (int w = 0; w < NW; w++) acc += __popc(s.v[w] ^ lds[w * win + x]);
+        for (int w = 0; w < NW; w++) s.v[w] = sp[w];
+    }
+    return s;
+}
+
+// Hamming distance between the source words and LDS record `rec`
+template <int NW> __device__ __forceinline__ int hamming_rec(const Words<NW> &s, const uint32_t *rec) {
+    if constexpr (NW == 0) {
+        return 0;
+    } else if constexpr (NW == 2) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(rec);
+        return __popc(s.v[0] ^ t.x) + __popc(s.v[1] ^ t.y);
+    } else if constexpr (NW == 4) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(rec);
+        return __popc(s.v[0] ^ t.x) + __popc(s.v[1] ^ t.y) + __popc(s.v[2] ^ t.z) + __popc(s.v[3] ^ t.w);
     } else {
-        (void)s;
-        (void)lds;
-        (void)win;
-        (void)x;
-        (void)nWw;
-    }
-    return (float)acc;
-}
-
-template <int NW> __device__ __forceinline__ int hamming_int(const Words<NW> &s, const uint32_t *lds, int win, int x) {
-    int acc = 0;
-    if constexpr (NW > 0) {
+        int acc = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) acc += __popc(s.v[w] ^ lds[w * win + x]);
+        for (int w = 0; w < NW; w++) acc += __popc(s.v[w] ^ rec[w]);
+        return acc;
     }
-    return acc;
 }
 
-// g(p) = min over d of the first-pixel actual cost c + (c [+ Pout]) (sgm.h:287-294 with min_p = 0)
-template <int NW, bool EXACT>
-__global__ void __launch_bounds__(TJ) census_gmin_kernel(CensusGeom g, float Pout, float *__restrict__ gmap) {
-    extern __shared__ uint32_t lds[];
+// Calls f(d, c) for d = 0..D-1 in increasing order, c = Hamming cost of (pixel, d); LDS reads are issued UNROLL
+// records ahead of their use.
+template <int NW, class F> __device__ __forceinline__ void for_each_disparity(const Words<NW> &s, const uint32_t *base, int D, F f) {
+    int d0 = 0;
+    for (; d0 + UNROLL <= D; d0 += UNROLL) {
+        int c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) c[u] = hamming_rec<NW>(s, base + (d0 + u) * NW);
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) f(d0 + u, c[u]);
+    }
+    for (; d0 < D; d0++) f(d0, hamming_rec<NW>(s, base + d0 * NW));
+}
+
+// The one voxel sweep of the exact regime.  Per pixel it keeps, for the two disparity regions d < dsplit (no Pout)
+// and d >= dsplit (Pout applies, sgm.h:287-289), the minimum of the keys (c << 10 | 1023 - d): the regional minimum
+// cost with the reference's tie rule (last index) built in.  From them
+//   g(p) = min_d [ c + (c [+ Pout]) ] = min(2 c0, 2 c1 + Pout)          (first-pixel actual cost, min_p = 0)
+// feeds the line recurrences, and census_finalize_kernel picks the winner once the min_p maps exist.
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+
+template <int NW>
+__global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int i = blockIdx.y, j0 = blockIdx.x * TJ, tj = threadIdx.x, j = j0 + tj;
-    const int win = TJ + g.D - 1;
-    stage_target_window(g, i, j0, lds, win);
+    stage_target_window<NW>(g, i, j0, lds);
     __syncthreads();
     if (j >= g.Ws) return;
-    Words<NW> s;
-    const uint32_t *sp = g.sw + ((int64_t)i * g.Ws + j) * g.nWw;
-#pragma unroll
-    for (int w = 0; w < NW; w++) s.v[w] = sp[w];
-    float m = INFINITY;
-    if (EXACT) {
-        // integer-exact regime: c + (c + Pout) = 2c + Pout with integer Pout, evaluated in int32
-        const int pout = (int)Pout;
-        int mi = 0x7FFFFFFF;
-        for (int d = 0; d < g.D; d++) {
-            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
-            const int c2 = 2 * hamming_int<NW>(s, lds, win, x);
-            mi = min(mi, (j + d >= g.Ws) ? c2 + pout : c2);
-        }
-        m = (float)mi;
+    const int64_t p = (int64_t)i * g.Ws + j;
+    const Words<NW> s = load_source_words<NW>(g, p);
+    const uint32_t *base = lds + (g.sign > 0 ? tj : TJ - 1 - tj) * NW;
+    uint32_t key0 = KEY_NONE, key1 = KEY_NONE;
+    if (j0 + TJ - 1 + g.D - 1 < g.Ws) { // no lane of this block reaches j + d >= W
+        for_each_disparity<NW>(s, base, g.D, [&](int d, int c) { key0 = min(key0, ((uint32_t)c << 10) | (uint32_t)(1023 - d)); });
     } else {
-        for (int d = 0; d < g.D; d++) {
-            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
-            const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
-            const float t = (j + d >= g.Ws) ? c + Pout : c;
-            m = fminf(m, c + t);
-        }
+        const int dsplit = min(max(g.Ws - j, 0), g.D);
+        for_each_disparity<NW>(s, base, g.D, [&](int d, int c) {
+            const uint32_t k = ((uint32_t)c << 10) | (uint32_t)(1023 - d);
+            const bool oob = d >= dsplit;
+            key0 = min(key0, oob ? KEY_NONE : k);
+            key1 = min(key1, oob ? k : KEY_NONE);
+        });
     }
-    gmap[(int64_t)i * g.Ws + j] = m;
+    keys[p] = make_uint2(key0, key1);
+    const int pout = (int)Pout;
+    const int g0 = key0 == KEY_NONE ? (1 << 24) : 2 * (int)(key0 >> 10);
+    const int g1 = key1 == KEY_NONE ? (1 << 24) : 2 * (int)(key1 >> 10) + pout;
+    gmap[p] = (float)min(g0, g1);
 }
 
 struct ScanGeom {
     int top, left, Hp, Wp, W;
 };
 
-// mp' = g - mp along every line of every pass (blockIdx.y = pass); one thread per line, batched loads
-__global__ void __launch_bounds__(64) line_scan_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, float *__restrict__ mmap) {
-    const int q = blockIdx.y;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_lines = (q == 0 || q == 3 || q == 4) ? sg.Wp : sg.Hp;
-    if (l >= n_lines) return;
-    int i0, j0, di, dj, len;
+// ---- the recurrence mp' = g - mp in parallel form ------------------------------------------------------------
+// Over a run of n pixels mp' = g - mp is the affine map mp_out = A + (-1)^n mp_in (A = the run started from 0),
+// and such maps compose, so a line can be cut into segments that are summarised independently, chained, and
+// replayed.  All sums are of integers below 2^24 (exact regime), so the split does not change a single bit.
+//
+// scan_cols_kernel: passes whose lines cross the rows (0, 2, 3, 4, 5).  Lines are indexed by a "virtual column" v
+// with pixel column = v + s * row (s = 0 vertical, +1 diagonal, -1 anti-diagonal), so that at every row the 64
+// lanes of a wave (64 neighbouring lines) touch 64 consecutive pixels: every access is a coalesced 256-byte row
+// segment.  The rows are cut into SCAN_SEGS chunks handled by the threadIdx.y slices of the block.
+constexpr int SCAN_SEGS = 16;
+
+struct ColLines {
+    int s, v_lo, n_lines, dir;
+};
+
+__device__ __forceinline__ ColLines col_lines(int q, const ScanGeom &sg) {
     switch (q) {
-    case 0: i0 = sg.top; j0 = sg.left + l; di = 1; dj = 0; len = sg.Hp; break;
-    case 1: i0 = sg.top + l; j0 = sg.left; di = 0; dj = 1; len = sg.Wp; break;
-    case 2: i0 = sg.top + l; j0 = sg.left; di = 1; dj = 1; len = min(sg.Hp - l, sg.Wp); break;
-    case 3: i0 = sg.top; j0 = sg.left + l; di = 1; dj = 1; len = min(sg.Hp, sg.Wp - l); break;
-    case 4: i0 = sg.top; j0 = sg.left + l; di = 1; dj = -1; len = min(sg.Hp, l + 1); break;
-    default: i0 = sg.top + l; j0 = sg.left; di = -1; dj = 1; len = min(l + 1, sg.Wp); break;
-    }
-    float *out = mmap + (int64_t)q * npx;
-    const int64_t step = (int64_t)di * sg.W + dj;
-    int64_t p = (int64_t)i0 * sg.W + j0;
-    float mp = 0.0f;
-    constexpr int U = 8;
-    int k = 0;
-    for (; k + U <= len; k += U) {
-        float gv[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) gv[u] = gmap[p + u * step];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            out[p + u * step] = mp;
-            mp = gv[u] - mp;
-        }
-        p += U * step;
-    }
-    for (; k < len; k++, p += step) {
-        out[p] = mp;
-        mp = gmap[p] - mp;
+    case 0: return {0, 0, sg.Wp, 1};
+    case 2: return {1, -(sg.Hp - 1), sg.Hp, 1};
+    case 3: return {1, 0, sg.Wp, 1};
+    case 4: return {-1, 0, sg.Wp, 1};
+    default: return {-1, 0, sg.Hp, -1};
     }
 }
 
-struct SelectOut {
-    int32_t *idx;
-    float *taps;
-    int taps_h_r, taps_v_r;
-    unsigned long long *keys;
-    int key_offset, key_total;
-};
+// rows [r0, r1) (relative to the margin box) visited by line v of pass q
+__device__ __forceinline__ void col_line_rows(int q, int v, const ScanGeom &sg, int &r0, int &r1) {
+    switch (q) {
+    case 0: r0 = 0; r1 = sg.Hp; break;
+    case 2: r0 = -v; r1 = min(sg.Hp, sg.Wp - v); break;
+    case 3: r0 = 0; r1 = min(sg.Hp, sg.Wp - v); break;
+    case 4: r0 = 0; r1 = min(sg.Hp, v + 1); break;
+    default: r0 = max(0, v - sg.Wp + 1); r1 = v + 1; break;
+    }
+}
+
+__global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
+                                                                   float *__restrict__ mmap) {
+    __shared__ float seg_a[SCAN_SEGS][64];
+    __shared__ int seg_n[SCAN_SEGS][64];
+    const int q = (n_pass <= 2) ? 0 : (blockIdx.y == 0 ? 0 : blockIdx.y + 1); // blockIdx.y -> pass 0, 2, 3, 4, 5
+    const ColLines cl = col_lines(q, sg);
+    const int lane = threadIdx.x, seg = threadIdx.y;
+    const int v = cl.v_lo + blockIdx.x * 64 + lane;
+    if ((int)blockIdx.x * 64 >= cl.n_lines) return; // whole block out of range (uniform)
+    int r0 = 0, r1 = 0;
+    if (v < cl.v_lo + cl.n_lines) col_line_rows(q, v, sg, r0, r1);
+    const int chunk = (sg.Hp + SCAN_SEGS - 1) / SCAN_SEGS;
+    const int b = max(r0, seg * chunk), e = min(r1, (seg + 1) * chunk);
+    const int n = max(e - b, 0);
+    // pixel index of relative row r on this line: (top + r) * W + left + v + s r, advanced by dir * (W + s) per step
+    const int first = cl.dir > 0 ? b : e - 1;
+    const int64_t p0 = (int64_t)(sg.top + first) * sg.W + sg.left + v + cl.s * first;
+    const int64_t step = (int64_t)cl.dir * (sg.W + cl.s);
+    float mp = 0.0f;
+    {
+        int64_t p = p0;
+        int k = 0;
+        for (; k + 4 <= n; k += 4, p += 4 * step) {
+            const float g0 = gmap[p], g1 = gmap[p + step], g2 = gmap[p + 2 * step], g3 = gmap[p + 3 * step];
+            mp = g3 - (g2 - (g1 - (g0 - mp)));
+        }
+        for (; k < n; k++, p += step) mp = gmap[p] - mp;
+    }
+    seg_a[seg][lane] = mp;
+    seg_n[seg][lane] = n;
+    __syncthreads();
+    // chain the segments that come before this one in traversal order
+    mp = 0.0f;
+    if (cl.dir > 0) {
+        for (int t = 0; t < seg; t++) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
+    } else {
+        for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
+    }
+    float *out = mmap + (int64_t)q * npx;
+    {
+        int64_t p = p0;
+        int k = 0;
+        for (; k + 4 <= n; k += 4, p += 4 * step) {
+            const float g0 = gmap[p], g1 = gmap[p + step], g2 = gmap[p + 2 * step], g3 = gmap[p + 3 * step];
+            const float m1 = g0 - mp, m2 = g1 - m1, m3 = g2 - m2;
+            out[p] = mp;
+            out[p + step] = m1;
+            out[p + 2 * step] = m2;
+            out[p + 3 * step] = m3;
+            mp = g3 - m3;
+        }
+        for (; k < n; k++, p += step) {
+            out[p] = mp;
+            mp = gmap[p] - mp;
+        }
+    }
+}
+
+// scan_rows_kernel: pass 1 (Left2Right), one wavefront per image row; lane l owns a contiguous run of the row, the
+// run summaries are chained with a 6-step shuffle scan over the affine maps (A, sign).
+__global__ void __launch_bounds__(256) scan_rows_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, float *__restrict__ mmap) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= sg.Hp) return;
+    const int run = (sg.Wp + 63) / 64;
+    const int b = min(lane * run, sg.Wp), e = min(b + run, sg.Wp), n = e - b;
+    const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left + b;
+    float a = 0.0f;
+    for (int k = 0; k < n; k++) a = gmap[base + k] - a;
+    float sgn = (n & 1) ? -1.0f : 1.0f;
+    // inclusive scan of map composition: (earlier, then mine)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float ea = __shfl_up(a, off), es = __shfl_up(sgn, off);
+        if (lane >= off) {
+            a = a + sgn * ea;
+            sgn = sgn * es;
+        }
+    }
+    float mp = __shfl_up(a, 1); // everything before this lane, started from 0
+    if (lane == 0) mp = 0.0f;
+    float *out = mmap + npx; // pass 1
+    for (int k = 0; k < n; k++) {
+        out[base + k] = mp;
+        mp = gmap[base + k] - mp;
+    }
+}
 
 __device__ __forceinline__ uint32_t order_key_f(float v) {
     if (v == 0.0f) v = 0.0f;
@@ -159,41 +266,14 @@ __device__ __forceinline__ uint32_t order_key_f(float v) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// S(p, d) per sgm.h:298-300 from the per-pass min_p values of this pixel
+// per-pass min_p values of one pixel
 struct PixelPasses {
     float mp[6];
     unsigned vis; // bit q set: pass q visits the pixel and its min_p is finite
 };
 
-__device__ __forceinline__ float sgm_value(float c, float t, const PixelPasses &pp, int n_pass) {
-    float s = c;
-    const bool t_fin = fabsf(t) < INFINITY;
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-        if (q < n_pass) {
-            float act = c + (t - pp.mp[q]);
-            float ns = s + (act - c);
-            s = ((pp.vis >> q) & 1u) && t_fin ? ns : s;
-        }
-    }
-    return s;
-}
-
-// apply + extractSelectedIndex (+ truncated taps, + reduction keys) without writing any volume
-template <int NW, bool EXACT>
-__global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout,
-                                                                 const float *__restrict__ mmap, SelectOut out) {
-    extern __shared__ uint32_t lds[];
-    const int i = blockIdx.y, j0 = blockIdx.x * TJ, tj = threadIdx.x, j = j0 + tj;
-    const int win = TJ + g.D - 1;
-    stage_target_window(g, i, j0, lds, win);
-    __syncthreads();
-    if (j >= g.Ws) return;
-    const int64_t npx = (int64_t)g.H * g.Ws, p = (int64_t)i * g.Ws + j;
-    Words<NW> s;
-    const uint32_t *sp = g.sw + p * g.nWw;
-#pragma unroll
-    for (int w = 0; w < NW; w++) s.v[w] = sp[w];
+__device__ __forceinline__ PixelPasses load_pixel_passes(const ScanGeom &sg, int n_pass, int i, int j, const float *__restrict__ mmap,
+                                                         int64_t npx, int64_t p) {
     PixelPasses pp;
     pp.vis = 0;
     const int ip = i - sg.top, jp = j - sg.left;
@@ -211,97 +291,163 @@ __global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, S
             if (fabsf(pp.mp[q]) < INFINITY) pp.vis |= 1u << q;
         }
     }
-    // sequential scan of extractSelectedIndex (correlation_base.h:441-455): '<=' keeps the last minimum
-    float best = 0.0f;
-    int bd = 0;
-    // integer-exact regime: every term (c + (t - mp)) - c equals t - mp exactly, so
-    // S = (1 + n) c + n Pout [oob] - sum(mp) in int32 carries the very same values as the float expression
-    int n_vis = 0, k0 = 0, k1 = 0;
-    if (EXACT) {
-        int msum = 0;
+    return pp;
+}
+
+// S(p, d) per sgm.h:298-300, literal float form
+__device__ __forceinline__ float sgm_value(float c, float t, const PixelPasses &pp, int n_pass) {
+    float s = c;
+    const bool t_fin = fabsf(t) < INFINITY;
 #pragma unroll
-        for (int q = 0; q < 6; q++)
-            if ((pp.vis >> q) & 1u) {
-                n_vis++;
-                msum += (int)pp.mp[q];
-            }
-        k0 = -msum;
-        k1 = n_vis * (int)Pout - msum;
-        int besti = 0;
-        const int mul = 1 + n_vis;
-        for (int d = 0; d < g.D; d++) {
-            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
-            const int v = mul * hamming_int<NW>(s, lds, win, x) + ((j + d >= g.Ws) ? k1 : k0);
-            if (d == 0 || v <= besti) {
-                besti = v;
-                bd = d;
-            }
-        }
-        best = (float)besti;
-    } else {
-        for (int d = 0; d < g.D; d++) {
-            const int x = tj + (g.sign > 0 ? d : g.D - 1 - d);
-            const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
-            const float t = (j + d >= g.Ws) ? c + Pout : c;
-            const float v = sgm_value(c, t, pp, n_pass);
-            if (d == 0 || v <= best) {
-                best = v;
-                bd = d;
-            }
+    for (int q = 0; q < 6; q++) {
+        if (q < n_pass) {
+            float act = c + (t - pp.mp[q]);
+            float ns = s + (act - c);
+            s = ((pp.vis >> q) & 1u) && t_fin ? ns : s;
         }
     }
+    return s;
+}
+
+// Hamming cost of (pixel, d) straight from the word maps (used for the three refinement taps only)
+template <int NW> __device__ __forceinline__ int hamming_global(const CensusGeom &g, const Words<NW> &s, int i, int j, int d) {
+    if constexpr (NW == 0) {
+        return 0;
+    } else {
+        const int jt = j + g.sign * (g.disp_lower + d);
+        const bool in = jt >= 0 && jt < g.Wt;
+        const uint32_t *t = g.tw + ((int64_t)i * g.Wt + (in ? jt : 0)) * NW;
+        int acc = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) acc += __popc(s.v[w] ^ (in ? t[w] : 0u));
+        return acc;
+    }
+}
+
+// Exact regime, per pixel: S = (1 + n) c + n Pout [d >= dsplit] - sum of the visiting passes' min_p.  The winner is
+// the better of the two regional winners (the later region wins ties, as the reference's '<=' scan does).
+template <int NW>
+__global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout, const float *__restrict__ mmap,
+                                                              const uint2 *__restrict__ keys, WinnerOut out) {
+    const int64_t npx = (int64_t)g.H * g.Ws;
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= npx) return;
+    const int j = (int)(p % g.Ws), i = (int)(p / g.Ws);
+    const PixelPasses pp = load_pixel_passes(sg, n_pass, i, j, mmap, npx, p);
+    int msum = 0, n_vis = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        if ((pp.vis >> q) & 1u) {
+            n_vis++;
+            msum += (int)pp.mp[q];
+        }
+    const int mul = 1 + n_vis, k0 = -msum, k1 = n_vis * (int)Pout - msum;
+    const uint2 k = keys[p];
+    const int v0 = mul * (int)(k.x >> 10) + k0, d0 = 1023 - (int)(k.x & 1023u);
+    const int v1 = mul * (int)(k.y >> 10) + k1, d1 = 1023 - (int)(k.y & 1023u);
+    const bool take1 = k.y != KEY_NONE && (k.x == KEY_NONE || v1 <= v0);
+    const int best = take1 ? v1 : v0, bd = take1 ? d1 : d0;
     if (out.idx) out.idx[p] = bd;
-    if (out.keys) // census values are never NaN
-        out.keys[p] = ((unsigned long long)order_key_f(best) << 32) | (uint32_t)(out.key_total - 1 - (out.key_offset + bd));
-    if (out.taps) {
+    if (out.disp) out.disp[p] = out.disp_sign * bd + out.disp_offset;
+    if (out.keys) out.keys[p] = ((unsigned long long)order_key_f((float)best) << 32) | (uint32_t)(out.key_total - 1 - (out.key_offset + bd));
+    if (out.taps) { // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613)
+        const Words<NW> s = load_source_words<NW>(g, p);
+        const int dsplit = min(max(g.Ws - j, 0), g.D);
+        const bool px_bad = j < out.taps_h_r || i < out.taps_v_r || i + out.taps_v_r >= g.H;
+#pragma unroll
+        for (int tap = 0; tap < 3; tap++) {
+            const int pd = bd + tap - 1;
+            float v = __uint_as_float(0x7FC00000u);
+            if (!(px_bad || pd < 0 || pd >= g.D || j + pd + out.taps_h_r >= g.Ws))
+                v = (float)(mul * hamming_global<NW>(g, s, i, j, pd) + (pd >= dsplit ? k1 : k0));
+            out.taps[p * 3 + tap] = v;
+        }
+    }
+}
+
+// apply + extractSelectedIndex (+ truncated taps, + reduction keys) without writing any volume: literal float
+// evaluation of sgm.h:287-300 per voxel, for census costs outside the exact regime
+template <int NW>
+__global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout,
+                                                                 const float *__restrict__ mmap, WinnerOut out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int i = blockIdx.y, j0 = blockIdx.x * TJ, tj = threadIdx.x, j = j0 + tj;
+    stage_target_window<NW>(g, i, j0, lds);
+    __syncthreads();
+    if (j >= g.Ws) return;
+    const int64_t npx = (int64_t)g.H * g.Ws, p = (int64_t)i * g.Ws + j;
+    const Words<NW> s = load_source_words<NW>(g, p);
+    const uint32_t *base = lds + (g.sign > 0 ? tj : TJ - 1 - tj) * NW;
+    const PixelPasses pp = load_pixel_passes(sg, n_pass, i, j, mmap, npx, p);
+    const int dsplit = min(max(g.Ws - j, 0), g.D); // d >= dsplit pays Pout
+    float best = 0.0f; // S at the winner
+    int bd = 0;        // winner: sequential '<=' scan of extractSelectedIndex (correlation_base.h:441-455)
+    for_each_disparity<NW>(s, base, g.D, [&](int d, int ci) {
+        const float c = (float)ci;
+        const float t = (d >= dsplit) ? c + Pout : c;
+        const float v = sgm_value(c, t, pp, n_pass);
+        if (d == 0 || v <= best) {
+            best = v;
+            bd = d;
+        }
+    });
+    if (out.idx) out.idx[p] = bd;
+    if (out.disp) out.disp[p] = out.disp_sign * bd + out.disp_offset;
+    if (out.keys) { // (ordered value, total-1-global index): a min-reduction keeps ties on the largest index
+        unsigned long long key = ((unsigned long long)order_key_f(best) << 32) | (uint32_t)(out.key_total - 1 - (out.key_offset + bd));
+        if (isnan(best)) key = (out.key_offset == 0 && bd == 0) ? (unsigned long long)(uint32_t)(out.key_total - 1) : ~0ull;
+        out.keys[p] = key;
+    }
+    if (out.taps) { // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613)
         const bool px_bad = j < out.taps_h_r || i < out.taps_v_r || i + out.taps_v_r >= g.H;
 #pragma unroll
         for (int tap = 0; tap < 3; tap++) {
             const int pd = bd + tap - 1;
             float v = __uint_as_float(0x7FC00000u);
             if (!(px_bad || pd < 0 || pd >= g.D || j + pd + out.taps_h_r >= g.Ws)) {
-                const int x = tj + (g.sign > 0 ? pd : g.D - 1 - pd);
-                if (EXACT) {
-                    v = (float)((1 + n_vis) * hamming_int<NW>(s, lds, win, x) + ((j + pd >= g.Ws) ? k1 : k0));
-                } else {
-                    const float c = hamming_at<NW>(s, lds, win, x, g.nWw);
-                    const float t = (j + pd >= g.Ws) ? c + Pout : c;
-                    v = sgm_value(c, t, pp, n_pass);
-                }
+                const float c = (float)hamming_rec<NW>(s, base + pd * NW);
+                v = sgm_value(c, (pd >= dsplit) ? c + Pout : c, pp, n_pass);
             }
             out.taps[p * 3 + tap] = v;
         }
     }
 }
 
-template <int NW>
-int launch_gmin(svh_context *ctx, const CensusGeom &g, float Pout, float *gmap) {
+size_t lds_bytes(int nWw, int D) { return (size_t)(nWw ? nWw : 1) * (TJ + D - 1) * sizeof(uint32_t); }
+
+template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap) {
     dim3 grid(ceil_div(g.Ws, TJ), g.H);
-    size_t shmem = (size_t)(NW > 0 ? NW : 1) * (TJ + g.D - 1) * sizeof(uint32_t);
-    SVH_LAUNCH(ctx, "census_gmin", (census_gmin_kernel<NW, true>), grid, TJ, shmem, g, Pout, gmap);
+    SVH_LAUNCH(ctx, "census_sweep", census_sweep_kernel<NW>, grid, TJ, lds_bytes(NW, g.D), g, Pout, keys, gmap);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+template <int NW>
+int launch_finalize(svh_context *ctx, const CensusGeom &g, const ScanGeom &sg, int n_pass, float Pout, const float *mmap, const uint2 *keys,
+                    const WinnerOut &out) {
+    const int64_t npx = (int64_t)g.H * g.Ws;
+    SVH_LAUNCH(ctx, "census_finalize", census_finalize_kernel<NW>, grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
 template <int NW>
 int launch_apply_select(svh_context *ctx, const CensusGeom &g, const ScanGeom &sg, int n_pass, float Pout, const float *mmap,
-                        const SelectOut &out, bool exact) {
+                        const WinnerOut &out) {
     dim3 grid(ceil_div(g.Ws, TJ), g.H);
-    size_t shmem = (size_t)(NW > 0 ? NW : 1) * (TJ + g.D - 1) * sizeof(uint32_t);
-    if (exact)
-        SVH_LAUNCH(ctx, "census_apply_select", (census_apply_select_kernel<NW, true>), grid, TJ, shmem, g, sg, n_pass, Pout, mmap, out);
-    else
-        SVH_LAUNCH(ctx, "census_apply_select", (census_apply_select_kernel<NW, false>), grid, TJ, shmem, g, sg, n_pass, Pout, mmap, out);
+    SVH_LAUNCH(ctx, "census_apply_select", census_apply_select_kernel<NW>, grid, TJ, lds_bytes(NW, g.D), g, sg, n_pass, Pout, mmap, out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
 } // namespace
 
-// largest nWw the pixel-per-lane kernels are instantiated for (25x25 windows and smaller)
+// largest nWw the pixel-per-lane kernels are instantiated for (11x11 windows and smaller; 9x9 -> 2 words)
 static constexpr int kMaxWords = 4;
-// LDS budget: nWw planes of (256 + D - 1) dwords must fit the 64 KiB a block may take by default
-static bool census_lane_kernels_fit(int nWw, int D) { return nWw <= kMaxWords && (size_t)(nWw ? nWw : 1) * (TJ + D - 1) * 4 <= 60 * 1024; }
+
+// LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), D <= 1024 (10 index bits
+// in the winner key), costs <= 128 (22 value bits are plenty)
+bool census_lane_kernels_available(int nWw, int D) { return nWw <= kMaxWords && D <= 1024 && lds_bytes(nWw, D) <= 60 * 1024; }
 
 bool census_exact_regime(const SgmArgs &a, int nWw) {
     if (!std::isfinite(a.Pout) || a.Pout != std::nearbyint(a.Pout)) return false;
@@ -310,45 +456,60 @@ bool census_exact_regime(const SgmArgs &a, int nWw) {
     return 8.0 * gmax * (L + 2.0) < 16777216.0;
 }
 
-int dev_census_minmaps_exact(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap) {
-    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
-    const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0);
-    if (n_pass == 0 || Hp <= 0 || Wp <= 0) return SVH_OK;
-    float *gmap = scr.get_n<float>((size_t)a.H * a.W);
-    if (!gmap) return SVH_ERR_OUT_OF_MEMORY;
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
-    switch (cs.nWw) {
-    case 0: SVH_TRY(launch_gmin<0>(ctx, g, a.Pout, gmap)); break;
-    case 1: SVH_TRY(launch_gmin<1>(ctx, g, a.Pout, gmap)); break;
-    case 2: SVH_TRY(launch_gmin<2>(ctx, g, a.Pout, gmap)); break;
-    case 3: SVH_TRY(launch_gmin<3>(ctx, g, a.Pout, gmap)); break;
-    default: SVH_TRY(launch_gmin<4>(ctx, g, a.Pout, gmap)); break;
+#define SVH_NW_DISPATCH(nWw, CALL)                                                              \
+    switch (nWw) {                                                                              \
+    case 0: return CALL(0);                                                                     \
+    case 1: return CALL(1);                                                                     \
+    case 2: return CALL(2);                                                                     \
+    case 3: return CALL(3);                                                                     \
+    case 4: return CALL(4);                                                                     \
+    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "census lane kernels: %d words", nWw);       \
     }
+
+static int sweep_dispatch(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap) {
+#define CALL(N) launch_sweep<N>(ctx, g, Pout, keys, gmap)
+    SVH_NW_DISPATCH(g.nWw, CALL)
+#undef CALL
+}
+
+int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out) {
+    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+    const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
+    const int64_t npx = (int64_t)a.H * a.W;
+    uint2 *keys = scr.get_n<uint2>((size_t)npx);
+    float *gmap = scr.get_n<float>((size_t)npx);
+    if (!keys || !gmap) return SVH_ERR_OUT_OF_MEMORY;
+    *keys_out = keys;
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
+    SVH_TRY(sweep_dispatch(ctx, g, a.Pout, keys, gmap));
+    if (n_pass == 0) return SVH_OK;
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
-    dim3 grid(ceil_div(std::max(Hp, Wp), 64), n_pass);
-    SVH_LAUNCH(ctx, "sgm_line_scan", line_scan_kernel, grid, 64, 0, gmap, sg, (int64_t)a.H * a.W, mmap);
+    dim3 cgrid(ceil_div(std::max(Hp, Wp), 64), n_pass == 6 ? 5 : 1), cblock(64, SCAN_SEGS);
+    SVH_LAUNCH(ctx, "sgm_scan_cols", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap);
+    SVH_CHECK_LAUNCH(ctx);
+    SVH_LAUNCH(ctx, "sgm_scan_rows", scan_rows_kernel, ceil_div(Hp, 4), 256, 0, gmap, sg, npx, mmap);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
-int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, int32_t *out_idx,
-                            float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
-                            int key_total_D) {
+int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const uint2 *keys, const WinnerOut &win) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
     CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
     ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
-    SelectOut out{out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D};
-    const bool exact = census_exact_regime(a, cs.nWw); // then the min_p maps hold integers too, whichever kernel made them
-    switch (cs.nWw) {
-    case 0: return launch_apply_select<0>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
-    case 1: return launch_apply_select<1>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
-    case 2: return launch_apply_select<2>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
-    case 3: return launch_apply_select<3>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
-    default: return launch_apply_select<4>(ctx, g, sg, n_pass, a.Pout, mmap, out, exact);
-    }
+#define CALL(N) launch_finalize<N>(ctx, g, sg, n_pass, a.Pout, mmap, keys, win)
+    SVH_NW_DISPATCH(cs.nWw, CALL)
+#undef CALL
 }
 
-bool census_lane_kernels_available(int nWw, int D) { return census_lane_kernels_fit(nWw, D); }
+int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const WinnerOut &win) {
+    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+    const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
+    ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
+#define CALL(N) launch_apply_select<N>(ctx, g, sg, n_pass, a.Pout, mmap, win)
+    SVH_NW_DISPATCH(cs.nWw, CALL)
+#undef CALL
+}
 
 } // namespace svh

@@ -68,6 +68,54 @@ __global__ void census_image_kernel(const float *__restrict__ img, int H, int W,
     }
 }
 
+// LDS-tiled variant: a block produces 256 consecutive pixels of one output row from a staged
+// (2v_r+1) x (256 + 2h_r) x C tile (zero outside the image), so each input sample is fetched from memory once
+// per block instead of once per window.  Lanes read consecutive LDS dwords (conflict free for C == 1).
+constexpr int CENSUS_TJ = 256;
+
+__global__ void __launch_bounds__(CENSUS_TJ) census_image_tiled_kernel(const float *__restrict__ img, int H, int W, int C, int h_r,
+                                                                       int v_r, int pl, int pt, int Ho, int Wo, int n_out,
+                                                                       int n_written, bool round_target,
+                                                                       uint32_t *__restrict__ words) {
+    extern __shared__ float tile[];
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    const int i = blockIdx.y, j0 = blockIdx.x * CENSUS_TJ, tj = threadIdx.x, j = j0 + tj;
+    const int tw = (CENSUS_TJ + h - 1) * C; // floats per tile row
+    for (int k = 0; k < v; k++) {
+        const int ii = i - pt + k;
+        const bool row_in = ii >= 0 && ii < H;
+        const float *row = img + (int64_t)ii * W * C;
+        for (int e = tj; e < tw; e += CENSUS_TJ) {
+            const int jj = j0 - pl + e / C;
+            tile[k * tw + e] = (row_in && jj >= 0 && jj < W) ? row[(int64_t)(j0 - pl) * C + e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (j >= Wo) return;
+    const float ref = tile[tj * C];
+    uint32_t *o = words + ((int64_t)i * Wo + j) * n_out;
+    // walk the window in channel order c = (h C) k + (l C + ch), starting after channel 0 (the reference sample)
+    const int hc = h * C;
+    const float *tp = tile + tj * C; // + k * tw + rem
+    int rem = 1, row_off = 0;
+    if (rem == hc) {
+        rem = 0;
+        row_off = tw;
+    }
+    for (int word = 0; word < n_written; word++) {
+        uint32_t d = 0;
+        for (int b = 0; b < 32; b++) {
+            d |= (ref > tp[row_off + rem] ? 1u : 0u) << b;
+            if (++rem == hc) {
+                rem = 0;
+                row_off += tw;
+            }
+        }
+        o[word] = round_target ? round_word_through_float(d) : d;
+    }
+    for (int w = n_written; w < n_out; w++) o[w] = 0; // rule E1
+}
+
 __global__ void census_features_kernel(const float *__restrict__ feat, int64_t npx, int F, int n_out, int n_written,
                                        bool round_target, uint32_t *__restrict__ words) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
@@ -97,6 +145,14 @@ int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int
     int64_t npx = (int64_t)Ho * Wo;
     if (npx == 0 || n_out == 0) return SVH_OK;
     int F = (2 * h_r + 1) * (2 * v_r + 1) * img.C;
+    const size_t tile_bytes = (size_t)(2 * v_r + 1) * (CENSUS_TJ + 2 * h_r) * img.C * sizeof(float);
+    if (tile_bytes <= 60 * 1024 && census_words_written(F) > 0) {
+        dim3 grid(ceil_div(Wo, CENSUS_TJ), Ho);
+        SVH_LAUNCH(ctx, "census_transform", census_image_tiled_kernel, grid, CENSUS_TJ, tile_bytes, img.data, img.H, img.W, img.C, h_r, v_r,
+                   pl, pt, Ho, Wo, n_out, census_words_written(F), round_through_float, words);
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
     SVH_LAUNCH(ctx, "census_transform", census_image_kernel, grid_for(npx, 256, 16384), 256, 0, img.data, img.H, img.W, img.C, h_r,
                v_r, pl, pt, Ho, Wo, n_out, census_words_written(F), round_through_float, words);
     SVH_CHECK_LAUNCH(ctx);

@@ -181,18 +181,28 @@ struct CostSource {
     const uint32_t *src_words = nullptr, *tgt_words = nullptr; // compact (H, W*, nWw)
     int nWw = 0, Wt = 0, sign = 1, disp_lower = 0;
 };
-// out_sgm and out_idx may each be nullptr (but not both). out_keys optional (u64 per pixel).
-int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &src, float *out_sgm, int32_t *out_idx,
-                        float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
-                        int key_total_D);
+// per-pixel outputs of the winner stage; every pointer is optional
+struct WinnerOut {
+    int32_t *idx = nullptr;            // extractSelectedIndex
+    int32_t *disp = nullptr;           // selectedIndexToDisp: disp_sign * idx + disp_offset
+    int disp_sign = 1, disp_offset = 0;
+    float *taps = nullptr;             // (H, W, 3): truncatedCostVolume<Same>(S, idx, taps_h_r, taps_v_r, 1)
+    int taps_h_r = 0, taps_v_r = 0;
+    unsigned long long *keys = nullptr; // cross-shard reduction keys
+    int key_offset = 0, key_total = 0;
+    bool any() const { return idx || disp || taps || keys; }
+};
+// Cost branch on either source; out_sgm (H, W, D) optional
+int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &src, float *out_sgm, const WinnerOut &win);
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm);
 // census specialisation of the Cost branch (svh_census_sgm.hip)
 bool census_lane_kernels_available(int nWw, int D);
 bool census_exact_regime(const SgmArgs &a, int nWw);
-int dev_census_minmaps_exact(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap);
-int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, int32_t *out_idx,
-                            float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
-                            int key_total_D);
+// exact regime: one sweep (regional winner keys + g map), then the min_p maps by parallel line scans
+int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out);
+int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const uint2 *keys, const WinnerOut &win);
+// any regime: literal float evaluation per voxel from given min_p maps
+int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const WinnerOut &win);
 
 int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
                       unsigned long long *keys, int key_index_offset, int key_total_D);

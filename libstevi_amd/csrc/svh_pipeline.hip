@@ -88,12 +88,28 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
 
     const int64_t npx = (int64_t)H * Ws;
     const size_t nvox = (size_t)npx * D;
-    const bool need_idx = disp || want_refine;
+    // the Cost-branch winner kernels write the disparity map themselves; the index map is only materialised for the
+    // stages that read it back (refinement, the generic extract -> index_to_disp chain)
+    const bool cost_fused = func_census(func) || (sgm && strategy == SVH_COST);
+    const bool need_idx = want_refine || (disp && !cost_fused);
     int32_t *d_idx = need_idx ? scr.get_n<int32_t>((size_t)npx) : nullptr;
     if (need_idx && !d_idx) return SVH_ERR_OUT_OF_MEMORY;
+    const int disp_sign = r2l ? 1 : -1;
+    const int disp_offset = disp_sign * (prm->disp_lower + sb); // selectedIndexToDisp(idx, first searched offset); shards report global indices
+    WinnerOut win;
+    win.idx = d_idx;
+    win.disp = (disp && cost_fused) ? (int32_t *)o_disp.dptr : nullptr;
+    win.disp_sign = disp_sign;
+    win.disp_offset = disp_offset;
     float *d_taps = want_refine ? scr.get_n<float>((size_t)npx * 3) : nullptr;
     if (want_refine && !d_taps) return SVH_ERR_OUT_OF_MEMORY;
     unsigned long long *d_keys = keys ? (unsigned long long *)o_keys.dptr : nullptr;
+    win.taps = d_taps;
+    win.taps_h_r = prm->refine_h_radius;
+    win.taps_v_r = prm->refine_v_radius;
+    win.keys = d_keys;
+    win.key_offset = sb;
+    win.key_total = Dtot;
 
     const CostVolumeArgs cva{func, prm->disp_direction, H, Ws, Wt, prm->disp_lower + sb, D};
     const ImageDesc isrc{(const float *)dsrc, H, Ws, C}, itgt{(const float *)dtgt, H, Wt, C};
@@ -108,7 +124,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
         SVH_TRY(dev_census_from_image(ctx, isrc, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, H, Ws, nWw, false, sw));
         SVH_TRY(dev_census_from_image(ctx, itgt, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, H, Wt, nWw, true, tw));
         if (cv) SVH_TRY(dev_hamming_volume(ctx, cva, sw, tw, nWw, (float *)o_cv.dptr));
-        if (need_idx || keys || sgm_cv) {
+        if (win.any() || sgm_cv) {
             // Cost branch with the Hamming cost evaluated on the fly; sgm_directions == 0 degenerates to S = C
             CostSource cs;
             cs.src_words = sw;
@@ -117,8 +133,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             cs.Wt = Wt;
             cs.sign = r2l ? 1 : -1;
             cs.disp_lower = cva.disp_lower;
-            SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, d_idx, d_taps, prm->refine_h_radius,
-                                        prm->refine_v_radius, d_keys, sb, Dtot));
+            SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, win));
         }
     } else {
         float *d_cv = cv ? (float *)o_cv.dptr : scr.get_n<float>(nvox);
@@ -127,8 +142,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
         if (sgm && strategy == SVH_COST) {
             CostSource cs;
             cs.cv = d_cv;
-            SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, d_idx, d_taps, prm->refine_h_radius,
-                                        prm->refine_v_radius, d_keys, sb, Dtot));
+            SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, win));
         } else {
             const float *d_final = d_cv;
             if (sgm) {
@@ -144,8 +158,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
         }
     }
     if (want_refine) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));
-    if (disp) // selectedIndexToDisp(idx, offset) with offset = first searched offset; a shard reports global indices
-        SVH_TRY(dev_index_to_disp(ctx, prm->disp_direction, d_idx, npx, (r2l ? 1 : -1) * (prm->disp_lower + sb), (int32_t *)o_disp.dptr));
+    if (disp && !cost_fused) SVH_TRY(dev_index_to_disp(ctx, prm->disp_direction, d_idx, npx, disp_offset, (int32_t *)o_disp.dptr));
 
     if (disp) SVH_TRY(finish_out(ctx, o_disp));
     if (refined) SVH_TRY(finish_out(ctx, o_ref));

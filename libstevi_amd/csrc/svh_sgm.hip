@@ -225,12 +225,8 @@ __device__ __forceinline__ unsigned long long winner_key(Winner w, bool first_is
 }
 
 struct ApplyOut {
-    float *sgm;               // (H, W, D) or nullptr
-    int32_t *idx;             // (H, W) or nullptr
-    float *taps;              // (H, W, 3) truncated volume around the winner (Same direction, radius 1) or nullptr
-    int taps_h_r, taps_v_r;
-    unsigned long long *keys; // (H, W) or nullptr
-    int key_offset, key_total;
+    float *sgm; // (H, W, D) or nullptr
+    WinnerOut w;
 };
 
 template <class SRC, int R>
@@ -269,25 +265,27 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
             for (int k = 0; k < R; k++)
                 if (lane * R + k < D) o[k] = s[k];
         }
-        if (out.idx || out.taps || out.keys) {
+        const WinnerOut &wo = out.w;
+        if (wo.idx || wo.disp || wo.taps || wo.keys) {
             bool first_nan;
             const Winner w = wave_select<true, R>(s, lane, D, &first_nan);
             const int sel = (first_nan || w.d < 0) ? 0 : w.d;
-            if (out.idx && lane == 0) out.idx[p] = sel;
-            if (out.keys && lane == 0) out.keys[p] = winner_key<true>(w, first_nan, out.key_offset, out.key_total);
-            if (out.taps) {
+            if (wo.idx && lane == 0) wo.idx[p] = sel;
+            if (wo.disp && lane == 0) wo.disp[p] = wo.disp_sign * sel + wo.disp_offset;
+            if (wo.keys && lane == 0) wo.keys[p] = winner_key<true>(w, first_nan, wo.key_offset, wo.key_total);
+            if (wo.taps) {
                 // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613)
-                const bool px_bad = j < out.taps_h_r || i < out.taps_v_r || i + out.taps_v_r >= H;
+                const bool px_bad = j < wo.taps_h_r || i < wo.taps_v_r || i + wo.taps_v_r >= H;
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
                     const int pd = sel + t - 1;
-                    const bool bad = px_bad || pd < 0 || pd >= D || j + pd + out.taps_h_r >= W;
+                    const bool bad = px_bad || pd < 0 || pd >= D || j + pd + wo.taps_h_r >= W;
                     if (bad) {
-                        if (lane == 0) out.taps[p * 3 + t] = __uint_as_float(0x7FC00000u);
+                        if (lane == 0) wo.taps[p * 3 + t] = __uint_as_float(0x7FC00000u);
                     } else {
 #pragma unroll
                         for (int k = 0; k < R; k++)
-                            if (lane * R + k == pd) out.taps[p * 3 + t] = s[k];
+                            if (lane * R + k == pd) wo.taps[p * 3 + t] = s[k];
                     }
                 }
             }
@@ -444,27 +442,29 @@ static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &s
     }
 }
 
-int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *out_sgm, int32_t *out_idx,
-                        float *out_taps, int taps_h_r, int taps_v_r, unsigned long long *out_keys, int key_index_offset,
-                        int key_total_D) {
+int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *out_sgm, const WinnerOut &win) {
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
     float *mmap = scr.get_n<float>((size_t)6 * a.H * a.W);
     if (!mmap) return SVH_ERR_OUT_OF_MEMORY;
-    ApplyOut out{out_sgm, out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D};
+    ApplyOut out{out_sgm, win};
     if (cs.cv) {
         SrcVolume src{cs.cv, a.W, a.D, aligned16(cs.cv) && a.D % 4 == 0};
         return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
     }
     SrcCensus src{cs.src_words, cs.tgt_words, cs.nWw, a.W, cs.Wt, cs.sign, cs.disp_lower, a.D};
-    // census specialisation (svh_census_sgm.hip): pixel-per-lane kernels, and in the integer-exact regime the
-    // min_p maps from one parallel sweep + scalar line recurrences instead of six wave-per-line launches
+    // census specialisation (svh_census_sgm.hip): pixel-per-lane kernels.  In the integer-exact regime one sweep
+    // yields the regional winner keys and g, parallel line scans turn g into the min_p maps, and a per-pixel kernel
+    // finishes; otherwise the wave-per-line kernels make the min_p maps and the winner is evaluated in float.
     const bool lanes = ctx->census_fast_path && census_lane_kernels_available(cs.nWw, a.D);
     const bool exact = lanes && census_exact_regime(a, cs.nWw);
-    const bool lane_apply = lanes && !out_sgm;
-    if (exact) SVH_TRY(dev_census_minmaps_exact(ctx, scr, a, cs, mmap));
-    if (!exact || !lane_apply) SVH_TRY(dispatch_cost_branch(ctx, a, src, mmap, lane_apply ? nullptr : &out, !exact));
-    if (lane_apply)
-        SVH_TRY(dev_census_apply_select(ctx, a, cs, mmap, out_idx, out_taps, taps_h_r, taps_v_r, out_keys, key_index_offset, key_total_D));
+    const bool lane_winner = lanes && !out_sgm;
+    uint2 *keys = nullptr;
+    if (exact) SVH_TRY(dev_census_sweep_and_scans(ctx, scr, a, cs, mmap, &keys));
+    if (!exact || !lane_winner) SVH_TRY(dispatch_cost_branch(ctx, a, src, mmap, lane_winner ? nullptr : &out, !exact));
+    if (lane_winner && win.any()) {
+        if (exact) SVH_TRY(dev_census_finalize(ctx, a, cs, mmap, keys, win));
+        else SVH_TRY(dev_census_apply_select(ctx, a, cs, mmap, win));
+    }
     return SVH_OK;
 }
 
@@ -537,7 +537,7 @@ extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strat
     if (strategy == SVH_COST) {
         CostSource cs;
         cs.cv = (const float *)dcv;
-        SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, nullptr, nullptr, 0, 0, nullptr, 0, 0));
+        SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, WinnerOut()));
     } else {
         if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
         SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr));

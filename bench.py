@@ -38,21 +38,32 @@ def visited_voxels_per_pass(H, W, D, n_pass):
 
 
 def algorithmic_bytes(kernel, wl):
-    """Algorithmic bytes per launch of `kernel` under the model of SURVEY.md section 8(d) (DESIGN.md "Roofline"):
-    internal intermediates at the narrowest exact type (C u8, S i16), API outputs at their API size, each
-    effective SGM pass = one read of C + one read-modify-write of S = 5 B/voxel."""
+    """Algorithmic bytes per launch of `kernel` under the model of SURVEY.md section 8(d), row C3 (DESIGN.md "Roofline"):
+    C as u8, S as i16, each of the five effective SGM passes = one read of C + one read-modify-write of S:
+        28 B/voxel = 1 (C write) + 5 x (1 + 4) + 2 (final S read),   60 B/pixel = 8 (images) + 48 (census words) + 4 (disparity).
+    The fused pipeline has ONE voxel-sized kernel (census_sweep); all 28 B/voxel of the model are work it replaces.  The
+    per-pixel kernels carry the per-pixel bytes."""
     H, W, D = wl["H"], wl["W"], wl["D"]
     px, vox = H * W, H * W * D
-    if kernel == "sgm_cost_minmap":
-        v = visited_voxels_per_pass(H, W, D, 6)
-        return 5.0 * sum(v) / len(v)           # average over the six launches of one step
-    if kernel == "sgm_cost_apply":
-        return 2.0 * vox + 4.0 * px            # final read of S (i16) + int32 index write
-    if kernel == "census_transform":
-        return 4.0 * px + 3 * 4.0 * px         # image read + nW words written
-    if kernel == "index_to_disp":
-        return 8.0 * px
-    return None
+    table = {
+        "census_sweep": 28.0 * vox,
+        "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
+        "sgm_scan_cols": 4.0 * px + 5 * 4.0 * px,    # g read + five min_p maps written
+        "sgm_scan_rows": 4.0 * px + 4.0 * px,
+        "census_finalize": (8.0 + 24.0 + 4.0) * px,  # keys + six min_p maps + disparity
+    }
+    return table.get(kernel)
+
+
+def load_measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections
+    of MI355X_MICROARCH.md) on this workload; the summary is committed under profiles/ by the round that measured it."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(wl, budget_s=18.0):
@@ -122,10 +133,20 @@ def main():
     from helpers import parallax_pair
 
     wl = dict(WORKLOAD)
-    src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"] + rank)
+    # every rank holds the same pair: with N > 1 the ranks cooperate on ONE problem (disparity shards)
+    src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"])
     d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
 
+    if world > 1:
+        # north_star: the cost volume shards over the disparity axis, one RCCL all-reduce for the per-pixel argmin.
+        # Weak scaling: every GPU keeps the single-GPU slice (D=256), the searched range grows to 256 x N.
+        from libstevi_amd import sharded
+        wl["D"] = WORKLOAD["D"] * world
+
     def step():
+        if world > 1:
+            return sharded.stereoMatchSharded(d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"], P1=wl["P1"], P2=wl["P2"],
+                                              Pout=wl["Pout"])
         # (target, source) passed as (img_l, img_r) like benchmarkCrossCorrelationAlgorithms.cpp:93
         return sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"],
                               P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"], want_cv=args.materialize, want_sgm_cv=args.materialize)
@@ -155,14 +176,15 @@ def main():
     checksum = int(out["disp"].sum().item())
 
     if rank == 0:
-        voxels = wl["W"] * wl["H"] * wl["D"]
-        value = voxels * args.steps * world / elapsed / 1e6
+        voxels = wl["W"] * wl["H"] * wl["D"]  # D = 256 x N for N > 1: the whole job's voxels
+        value = voxels * args.steps / elapsed / 1e6
+        wl1 = dict(wl, D=WORKLOAD["D"])        # what one launch of a kernel processes on one GPU
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel by accumulated event time inside the timed region
         dom = max(prof.items(), key=lambda kv: kv[1][0])
         dom_name, (dom_ms, dom_n) = dom
         avg_ms = dom_ms / max(dom_n, 1)
-        alg = algorithmic_bytes(dom_name, wl)
+        alg = algorithmic_bytes(dom_name, wl1)
         roof = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "traffic": None}
         if alg is not None:
@@ -170,6 +192,9 @@ def main():
             roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(alg)})
         else:
             roof.update({"achieved": None, "frac": None})
+        traffic = load_measured_traffic(dom_name)
+        if traffic is not None:
+            roof["traffic"] = traffic
         pipeline_alg = 28.0 * voxels + 60.0 * wl["W"] * wl["H"]
         kernel_ms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
         line = {
@@ -180,7 +205,8 @@ def main():
                                    "D=256, argmin -> int32 disparity map (BASELINE.json configs[2])",
                        "pipeline": "svh_stereo_match fused, inputs and outputs resident in HBM",
                        "materialize_volumes": bool(args.materialize),
-                       "parallelism": "1 pair per GPU" if world > 1 else "single GPU"},
+                       "parallelism": (f"disparity axis sharded over {world} GPUs (D=256 per GPU, {wl['D']} in total), one RCCL int32 MIN "
+                                       "all-reduce of the regional winner keys (8 B/pixel) per step") if world > 1 else "single GPU"},
             "roofline": roof,
             "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

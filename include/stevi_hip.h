@@ -189,6 +189,19 @@ typedef struct svh_stereo_params {
 int svh_stereo_match(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                      svh_array *disp, svh_array *refined, svh_array *cv, svh_array *sgm_cv, svh_array *keys);
 
+/* ---- disparity-sharded census (+ SGM) across GPUs -------------------------------------------------------------
+ * Rank r handles the disparity indices [shard_begin, shard_begin + shard_count) of params->disp_count:
+ *   svh_census_shard_keys   -> keys (H,W,2) i32: the shard's regional winner keys (cost, global index), all positive
+ *   int32 MIN all-reduce of `keys` over the ranks (RCCL / torch.distributed): the only exchange
+ *   svh_census_shard_finish -> SGM line recurrences from the reduced keys + winner: disp (H,W) i32 [, refined (H,W) f32]
+ * The result is bit-identical to the single-GPU svh_stereo_match.  Census / Hamming costs in the integer-exact regime
+ * only (integer Pout, window <= 11x11, <= 1024 disparities per shard, <= 4096 in total); otherwise SVH_ERR_UNSUPPORTED:
+ * the Score branch and non-integer costs couple the disparities along every path step and do not shard. */
+int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
+                          svh_array *keys);
+int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
+                            const svh_array *keys, svh_array *disp, svh_array *refined);
+
 /* decodes reduced keys back to selected indices / disparities (device or host arrays) */
 int svh_keys_to_index(svh_context *ctx, int strategy, const svh_array *keys, int32_t disp_count, svh_array *idx);
 

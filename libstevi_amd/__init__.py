@@ -3,6 +3,7 @@
 csrc/            hand-written HIP kernels + the C ABI (include/stevi_hip.h) -> libstevi_hip.so
 include/         C++ drop-in headers with the reference's names (StereoVision::Correlation)
 correlation.py   Python mirror of the same functions over the C ABI (numpy = host arrays, torch = device arrays)
+sharded.py       disparity sharding over the GPUs of a node (torch.distributed / RCCL all-reduce of winner keys)
 """
 from . import _capi  # noqa: F401
 from .correlation import *  # noqa: F401,F403

@@ -26,7 +26,8 @@ EXPORTS = [
     "svh_unfold", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
-    "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index",
+    "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
+    "svh_census_shard_finish",
 ]
 
 
@@ -120,6 +121,8 @@ def load():
         "svh_refine_disp_cost_interpolation": (C.c_int, [ctx, C.c_int, A, A, A]),
         "svh_stereo_match": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A, A, A]),
         "svh_keys_to_index": (C.c_int, [ctx, C.c_int, A, i32, A]),
+        "svh_census_shard_keys": (C.c_int, [ctx, P(SvhStereoParams), A, A, A]),
+        "svh_census_shard_finish": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -364,15 +364,8 @@ def refineDispCostInterpolation(kernel, truncatedCostVolume, rawDisparity):
     return out if st == _capi.OK else _empty_like(tcv, 2, "f32")
 
 
-def stereoMatch(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, sgmDirections=0, P1=0.001,
-                P2=0.01, Pout=100.0, margins=None, refineKernel=None, refine_h_radius=0, refine_v_radius=0, want_cv=False,
-                want_sgm_cv=False, want_keys=False, shard=None):
-    """Fused device pipeline (svh_stereo_match): unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex ->
-    selectedIndexToDisp -> [truncatedCostVolume(Same, radius 1) -> refineDispCostInterpolation].
-    Returns a dict with 'disp' and, when requested, 'refined', 'cv', 'sgm_cv', 'keys'."""
-    lib = _capi.load()
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
-    ctx = context_for(l)
+def _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, refineKernel, refine_h_radius,
+                   refine_v_radius, shard):
     lower, D = _search_range(disp_width)
     p = _capi.SvhStereoParams()
     p.match_func, p.disp_direction = int(matchFunc), int(dDir)
@@ -384,10 +377,23 @@ def stereoMatch(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=di
         p.margins[k] = v
     p.refine_kernel = -1 if refineKernel is None else int(refineKernel)
     p.refine_h_radius, p.refine_v_radius = int(refine_h_radius), int(refine_v_radius)
-    Dl = D
     if shard is not None:
         p.shard_begin, p.shard_count = int(shard[0]), int(shard[1])
-        Dl = int(shard[1])
+    return p, D
+
+
+def stereoMatch(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, sgmDirections=0, P1=0.001,
+                P2=0.01, Pout=100.0, margins=None, refineKernel=None, refine_h_radius=0, refine_v_radius=0, want_cv=False,
+                want_sgm_cv=False, want_keys=False, shard=None):
+    """Fused device pipeline (svh_stereo_match): unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex ->
+    selectedIndexToDisp -> [truncatedCostVolume(Same, radius 1) -> refineDispCostInterpolation].
+    Returns a dict with 'disp' and, when requested, 'refined', 'cv', 'sgm_cv', 'keys'."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    p, D = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, refineKernel,
+                          refine_h_radius, refine_v_radius, shard)
+    Dl = D if shard is None else int(shard[1])
     src = r if int(dDir) == dispDirection.RightToLeft else l
     H, W = src.shape[0], src.shape[1]
     res = {"disp": _like(l, (H, W), "i32")}
@@ -408,6 +414,40 @@ def stereoMatch(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=di
                                           ref("sgm_cv"), ref("keys")))
     if st != _capi.OK:
         return {k: _empty_like(l, v.ndim, "f32") for k, v in res.items()}
+    return res
+
+
+def censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, dDir=dispDirection.RightToLeft, sgmDirections=8, P1=0.001,
+                    P2=0.01, Pout=100.0, margins=None, matchFunc=matchingFunctions.CENSUS):
+    """svh_census_shard_keys: (H, W, 2) int32 regional winner keys of the disparity shard (begin, count)."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    p, _ = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, None, 0, 0, shard)
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    keys = _like(l, (src.shape[0], src.shape[1], 2), "i32")
+    _check(ctx, lib.svh_census_shard_keys(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(keys))))
+    return keys
+
+
+def censusShardFinish(img_l, img_r, keys, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, sgmDirections=8, P1=0.001,
+                      P2=0.01, Pout=100.0, margins=None, refineKernel=None, refine_h_radius=0, refine_v_radius=0,
+                      matchFunc=matchingFunctions.CENSUS):
+    """svh_census_shard_finish on keys already MIN-reduced over all shards -> {'disp'[, 'refined']}."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    p, _ = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, refineKernel,
+                          refine_h_radius, refine_v_radius, None)
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    H, W = src.shape[0], src.shape[1]
+    res = {"disp": _like(l, (H, W), "i32")}
+    if refineKernel is not None:
+        res["refined"] = _like(l, (H, W), "f32")
+    dd = _desc(res["disp"])
+    dr = _desc(res["refined"]) if "refined" in res else None
+    _check(ctx, lib.svh_census_shard_finish(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(keys)), C.byref(dd),
+                                            C.byref(dr) if dr is not None else None))
     return res
 
 

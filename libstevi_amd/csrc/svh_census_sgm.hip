@@ -31,6 +31,7 @@ constexpr int UNROLL = 8;
 struct CensusGeom {
     const uint32_t *sw, *tw; // compact words (H, Ws, nWw), (H, Wt, nWw); target pre-rounded through float (E2)
     int nWw, H, Ws, Wt, D, sign, disp_lower;
+    int d_offset; // global index of local disparity 0 (disparity shards); disp_lower already includes it
 };
 
 template <int NW> struct Words {
@@ -97,11 +98,24 @@ template <int NW, class F> __device__ __forceinline__ void for_each_disparity(co
 }
 
 // The one voxel sweep of the exact regime.  Per pixel it keeps, for the two disparity regions d < dsplit (no Pout)
-// and d >= dsplit (Pout applies, sgm.h:287-289), the minimum of the keys (c << 10 | 1023 - d): the regional minimum
+// and d >= dsplit (Pout applies, sgm.h:287-289), the minimum of the keys (c << 12 | 4095 - d): the regional minimum
 // cost with the reference's tie rule (last index) built in.  From them
 //   g(p) = min_d [ c + (c [+ Pout]) ] = min(2 c0, 2 c1 + Pout)          (first-pixel actual cost, min_p = 0)
 // feeds the line recurrences, and census_finalize_kernel picks the winner once the min_p maps exist.
-constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+// Keys are positive int32 values (cost <= 128 needs 8 bits, the index 12), so an int32 MIN all-reduce across
+// disparity shards is the cross-GPU winner reduction.  The index part holds the GLOBAL disparity index.
+constexpr uint32_t KEY_NONE = 0x7FFFFFFFu;
+constexpr int KEY_IDX_BITS = 12;
+constexpr uint32_t KEY_IDX_MASK = (1u << KEY_IDX_BITS) - 1u;
+__device__ __forceinline__ uint32_t make_key(int c, int d_global) { return ((uint32_t)c << KEY_IDX_BITS) | (KEY_IDX_MASK - (uint32_t)d_global); }
+__device__ __forceinline__ int key_cost(uint32_t k) { return (int)(k >> KEY_IDX_BITS); }
+__device__ __forceinline__ int key_index(uint32_t k) { return (int)(KEY_IDX_MASK - (k & KEY_IDX_MASK)); }
+
+__device__ __forceinline__ float g_from_keys(uint32_t key0, uint32_t key1, int pout) {
+    const int g0 = key0 == KEY_NONE ? (1 << 24) : 2 * key_cost(key0);
+    const int g1 = key1 == KEY_NONE ? (1 << 24) : 2 * key_cost(key1) + pout;
+    return (float)min(g0, g1);
+}
 
 template <int NW>
 __global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap) {
@@ -114,22 +128,26 @@ __global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Po
     const Words<NW> s = load_source_words<NW>(g, p);
     const uint32_t *base = lds + (g.sign > 0 ? tj : TJ - 1 - tj) * NW;
     uint32_t key0 = KEY_NONE, key1 = KEY_NONE;
-    if (j0 + TJ - 1 + g.D - 1 < g.Ws) { // no lane of this block reaches j + d >= W
-        for_each_disparity<NW>(s, base, g.D, [&](int d, int c) { key0 = min(key0, ((uint32_t)c << 10) | (uint32_t)(1023 - d)); });
+    const int d_off = g.d_offset; // this call handles global indices d_off .. d_off + D - 1
+    if (j0 + TJ - 1 + d_off + g.D - 1 < g.Ws) { // no lane of this block reaches j + d >= W
+        for_each_disparity<NW>(s, base, g.D, [&](int d, int c) { key0 = min(key0, make_key(c, d_off + d)); });
     } else {
-        const int dsplit = min(max(g.Ws - j, 0), g.D);
+        const int dsplit = min(max(g.Ws - j - d_off, 0), g.D);
         for_each_disparity<NW>(s, base, g.D, [&](int d, int c) {
-            const uint32_t k = ((uint32_t)c << 10) | (uint32_t)(1023 - d);
+            const uint32_t k = make_key(c, d_off + d);
             const bool oob = d >= dsplit;
             key0 = min(key0, oob ? KEY_NONE : k);
             key1 = min(key1, oob ? k : KEY_NONE);
         });
     }
     keys[p] = make_uint2(key0, key1);
-    const int pout = (int)Pout;
-    const int g0 = key0 == KEY_NONE ? (1 << 24) : 2 * (int)(key0 >> 10);
-    const int g1 = key1 == KEY_NONE ? (1 << 24) : 2 * (int)(key1 >> 10) + pout;
-    gmap[p] = (float)min(g0, g1);
+    if (gmap) gmap[p] = g_from_keys(key0, key1, (int)Pout);
+}
+
+// the same g from already reduced keys (disparity-sharded runs)
+__global__ void gmap_from_keys_kernel(const uint2 *__restrict__ keys, int64_t npx, float Pout, float *__restrict__ gmap) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p < npx) gmap[p] = g_from_keys(keys[p].x, keys[p].y, (int)Pout);
 }
 
 struct ScanGeom {
@@ -343,8 +361,8 @@ __global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, Scan
         }
     const int mul = 1 + n_vis, k0 = -msum, k1 = n_vis * (int)Pout - msum;
     const uint2 k = keys[p];
-    const int v0 = mul * (int)(k.x >> 10) + k0, d0 = 1023 - (int)(k.x & 1023u);
-    const int v1 = mul * (int)(k.y >> 10) + k1, d1 = 1023 - (int)(k.y & 1023u);
+    const int v0 = mul * key_cost(k.x) + k0, d0 = key_index(k.x);
+    const int v1 = mul * key_cost(k.y) + k1, d1 = key_index(k.y);
     const bool take1 = k.y != KEY_NONE && (k.x == KEY_NONE || v1 <= v0);
     const int best = take1 ? v1 : v0, bd = take1 ? d1 : d0;
     if (out.idx) out.idx[p] = bd;
@@ -445,9 +463,10 @@ int launch_apply_select(svh_context *ctx, const CensusGeom &g, const ScanGeom &s
 // largest nWw the pixel-per-lane kernels are instantiated for (11x11 windows and smaller; 9x9 -> 2 words)
 static constexpr int kMaxWords = 4;
 
-// LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), D <= 1024 (10 index bits
-// in the winner key), costs <= 128 (22 value bits are plenty)
+// LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), at most 1024 disparities per
+// call, 4096 over all shards (12 index bits in the winner key), costs <= 128
 bool census_lane_kernels_available(int nWw, int D) { return nWw <= kMaxWords && D <= 1024 && lds_bytes(nWw, D) <= 60 * 1024; }
+int census_max_total_disparities() { return 1 << KEY_IDX_BITS; }
 
 bool census_exact_regime(const SgmArgs &a, int nWw) {
     if (!std::isfinite(a.Pout) || a.Pout != std::nearbyint(a.Pout)) return false;
@@ -472,17 +491,20 @@ static int sweep_dispatch(svh_context *ctx, const CensusGeom &g, float Pout, uin
 #undef CALL
 }
 
-int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out) {
+int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, uint2 *keys, float *gmap) {
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset};
+    return sweep_dispatch(ctx, g, a.Pout, keys, gmap);
+}
+
+int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, float *gmap, bool gmap_ready, float *mmap) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
-    const int64_t npx = (int64_t)a.H * a.W;
-    uint2 *keys = scr.get_n<uint2>((size_t)npx);
-    float *gmap = scr.get_n<float>((size_t)npx);
-    if (!keys || !gmap) return SVH_ERR_OUT_OF_MEMORY;
-    *keys_out = keys;
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
-    SVH_TRY(sweep_dispatch(ctx, g, a.Pout, keys, gmap));
     if (n_pass == 0) return SVH_OK;
+    const int64_t npx = (int64_t)a.H * a.W;
+    if (!gmap_ready) {
+        SVH_LAUNCH(ctx, "gmap_from_keys", gmap_from_keys_kernel, grid_for(npx, 256), 256, 0, keys, npx, a.Pout, gmap);
+        SVH_CHECK_LAUNCH(ctx);
+    }
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
     dim3 cgrid(ceil_div(std::max(Hp, Wp), 64), n_pass == 6 ? 5 : 1), cblock(64, SCAN_SEGS);
     SVH_LAUNCH(ctx, "sgm_scan_cols", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap);
@@ -492,10 +514,20 @@ int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a,
     return SVH_OK;
 }
 
+int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out) {
+    const int64_t npx = (int64_t)a.H * a.W;
+    uint2 *keys = scr.get_n<uint2>((size_t)npx);
+    float *gmap = scr.get_n<float>((size_t)npx);
+    if (!keys || !gmap) return SVH_ERR_OUT_OF_MEMORY;
+    *keys_out = keys;
+    SVH_TRY(dev_census_sweep(ctx, a, cs, keys, gmap));
+    return dev_census_scans(ctx, a, keys, gmap, true, mmap);
+}
+
 int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const uint2 *keys, const WinnerOut &win) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset};
     ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
 #define CALL(N) launch_finalize<N>(ctx, g, sg, n_pass, a.Pout, mmap, keys, win)
     SVH_NW_DISPATCH(cs.nWw, CALL)
@@ -505,7 +537,7 @@ int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs
 int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const WinnerOut &win) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower};
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset};
     ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
 #define CALL(N) launch_apply_select<N>(ctx, g, sg, n_pass, a.Pout, mmap, win)
     SVH_NW_DISPATCH(cs.nWw, CALL)

@@ -180,6 +180,7 @@ struct CostSource {
     const float *cv = nullptr;       // (H, W, D) dense, or nullptr
     const uint32_t *src_words = nullptr, *tgt_words = nullptr; // compact (H, W*, nWw)
     int nWw = 0, Wt = 0, sign = 1, disp_lower = 0;
+    int d_offset = 0; // disparity shards: global index of local disparity 0 (disp_lower already includes it)
 };
 // per-pixel outputs of the winner stage; every pointer is optional
 struct WinnerOut {
@@ -200,6 +201,9 @@ bool census_lane_kernels_available(int nWw, int D);
 bool census_exact_regime(const SgmArgs &a, int nWw);
 // exact regime: one sweep (regional winner keys + g map), then the min_p maps by parallel line scans
 int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out);
+int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, uint2 *keys, float *gmap /* may be null */);
+int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, float *gmap, bool gmap_ready, float *mmap);
+int census_max_total_disparities();
 int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const uint2 *keys, const WinnerOut &win);
 // any regime: literal float evaluation per voxel from given min_p maps
 int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const WinnerOut &win);

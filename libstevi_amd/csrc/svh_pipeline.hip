@@ -167,3 +167,167 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
     if (keys) SVH_TRY(finish_out(ctx, o_keys));
     return SVH_OK;
 }
+
+// ---- disparity-sharded census (+ SGM) across GPUs ---------------------------------------------------------------
+// Each rank owns the disparity indices [shard_begin, shard_begin + shard_count) of the D-wide range and calls
+//   1. svh_census_shard_keys   -> (H, W, 2) int32 regional winner keys of its shard (global indices inside)
+//   2. an int32 MIN all-reduce of the keys over the ranks (RCCL; the only exchange of the whole pipeline)
+//   3. svh_census_shard_finish -> the reduced keys give g = min_d [2c (+Pout)] over ALL disparities, hence the same
+//      min_p maps on every rank (line scans), and the finalize kernel emits the disparity map (replicated).
+// Valid in the integer-exact regime only (census / Hamming costs, integer Pout): there the Cost branch couples the
+// disparities through per-pixel scalars alone, which is what makes the disparity axis shardable.
+namespace {
+
+struct ShardSetup {
+    const svh_array *src, *tgt;
+    int H, Ws, Wt, C, F, nWw, Dtot, sb, D, sign;
+};
+
+int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r, ShardSetup *s) {
+    if (!prm) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
+    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    if (!func_census(prm->match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "disparity sharding with SGM needs census / Hamming costs");
+    if (prm->disp_direction != SVH_LEFT_TO_RIGHT && prm->disp_direction != SVH_RIGHT_TO_LEFT)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (prm->h_radius < 0 || prm->v_radius < 0 || prm->h_radius > 255 || prm->v_radius > 255)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255]");
+    if (prm->sgm_directions != 0 && prm->sgm_directions != 4 && prm->sgm_directions != 8)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_directions must be 0, 4 or 8");
+    if (img_l->ndim != img_r->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "image ranks differ");
+    if (img_l->shape[0] != img_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ");
+    s->C = img_l->ndim == 3 ? (int)img_l->shape[2] : 1;
+    if (img_l->ndim == 3 && img_l->shape[2] != img_r->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "channel counts differ");
+    s->F = (2 * prm->h_radius + 1) * (2 * prm->v_radius + 1) * s->C;
+    if (s->F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    s->nWw = census_words_written(s->F);
+    const bool r2l = prm->disp_direction == SVH_RIGHT_TO_LEFT;
+    s->sign = r2l ? 1 : -1;
+    s->src = r2l ? img_r : img_l;
+    s->tgt = r2l ? img_l : img_r;
+    s->H = (int)s->src->shape[0];
+    s->Ws = (int)s->src->shape[1];
+    s->Wt = (int)s->tgt->shape[1];
+    s->Dtot = prm->disp_count;
+    s->sb = prm->shard_count > 0 ? prm->shard_begin : 0;
+    s->D = prm->shard_count > 0 ? prm->shard_count : s->Dtot;
+    if (s->Dtot <= 0 || s->sb < 0 || s->sb + s->D > s->Dtot) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disparity shard outside [0, disp_count)");
+    if (s->Dtot > census_max_total_disparities()) return fail(ctx, SVH_ERR_UNSUPPORTED, "at most %d disparities over all shards", census_max_total_disparities());
+    for (int k = 0; k < 4; k++)
+        if (prm->margins[k] < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "margins must be non-negative");
+    SgmArgs sa{prm->sgm_directions, SVH_COST, s->H, s->Ws, s->D, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
+               prm->margins[3]};
+    if (!census_lane_kernels_available(s->nWw, s->D) || !census_exact_regime(sa, s->nWw))
+        return fail(ctx, SVH_ERR_UNSUPPORTED,
+                    "disparity sharding needs the integer-exact regime (integer Pout, window up to 11x11, <= 1024 disparities per shard)");
+    return SVH_OK;
+}
+
+} // namespace
+
+extern "C" int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r,
+                                     svh_array *keys) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    ShardSetup s;
+    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, &s));
+    SVH_TRY(validate(ctx, keys, "keys", SVH_I32, 3, 3));
+    if (keys->shape[0] != s.H || keys->shape[1] != s.Ws || keys->shape[2] != 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "keys must have shape (%d,%d,2)", s.H, s.Ws);
+    Scratch scr(ctx);
+    void *dsrc, *dtgt;
+    OutStage ok;
+    SVH_TRY(stage_in(ctx, scr, *s.src, &dsrc));
+    SVH_TRY(stage_in(ctx, scr, *s.tgt, &dtgt));
+    SVH_TRY(stage_out(ctx, scr, *keys, &ok));
+    uint32_t *sw = scr.get_n<uint32_t>((size_t)s.H * s.Ws * (s.nWw ? s.nWw : 1));
+    uint32_t *tw = scr.get_n<uint32_t>((size_t)s.H * s.Wt * (s.nWw ? s.nWw : 1));
+    if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(dev_census_from_image(ctx, {(const float *)dsrc, s.H, s.Ws, s.C}, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, s.H,
+                                  s.Ws, s.nWw, false, sw));
+    SVH_TRY(dev_census_from_image(ctx, {(const float *)dtgt, s.H, s.Wt, s.C}, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, s.H,
+                                  s.Wt, s.nWw, true, tw));
+    SgmArgs sa{prm->sgm_directions, SVH_COST, s.H, s.Ws, s.D, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
+               prm->margins[3]};
+    CostSource cs;
+    cs.src_words = sw;
+    cs.tgt_words = tw;
+    cs.nWw = s.nWw;
+    cs.Wt = s.Wt;
+    cs.sign = s.sign;
+    cs.disp_lower = prm->disp_lower + s.sb;
+    cs.d_offset = s.sb;
+    SVH_TRY(dev_census_sweep(ctx, sa, cs, (uint2 *)ok.dptr, nullptr));
+    return finish_out(ctx, ok);
+}
+
+extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r,
+                                       const svh_array *keys, svh_array *disp, svh_array *refined) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    ShardSetup s;
+    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, &s));
+    SVH_TRY(validate(ctx, keys, "keys", SVH_I32, 3, 3));
+    if (keys->shape[0] != s.H || keys->shape[1] != s.Ws || keys->shape[2] != 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "keys must have shape (%d,%d,2)", s.H, s.Ws);
+    const bool want_refine = prm->refine_kernel >= 0;
+    if (want_refine && (prm->refine_kernel > SVH_GAUSSIAN || !refined)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad refinement request");
+    if (!disp && !refined) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "no output requested");
+    if (disp) {
+        SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 2, 2));
+        if (disp->shape[0] != s.H || disp->shape[1] != s.Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d)", s.H, s.Ws);
+    }
+    if (refined) {
+        SVH_TRY(validate(ctx, refined, "refined", SVH_F32, 2, 2));
+        if (refined->shape[0] != s.H || refined->shape[1] != s.Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "refined must have shape (%d,%d)", s.H, s.Ws);
+        if (!want_refine) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "refined output given but refine_kernel < 0");
+    }
+    Scratch scr(ctx);
+    void *dkeys;
+    SVH_TRY(stage_in(ctx, scr, *keys, &dkeys));
+    OutStage o_disp, o_ref;
+    if (disp) SVH_TRY(stage_out(ctx, scr, *disp, &o_disp));
+    if (refined) SVH_TRY(stage_out(ctx, scr, *refined, &o_ref));
+    const int64_t npx = (int64_t)s.H * s.Ws;
+    // from here on everything is about the whole disparity range
+    SgmArgs sa{prm->sgm_directions, SVH_COST, s.H, s.Ws, s.Dtot, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
+               prm->margins[3]};
+    float *mmap = scr.get_n<float>((size_t)6 * npx);
+    float *gmap = scr.get_n<float>((size_t)npx);
+    if (!mmap || !gmap) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap));
+    CostSource cs;
+    cs.nWw = s.nWw;
+    cs.Wt = s.Wt;
+    cs.sign = s.sign;
+    cs.disp_lower = prm->disp_lower;
+    WinnerOut win;
+    win.disp = disp ? (int32_t *)o_disp.dptr : nullptr;
+    win.disp_sign = s.sign;
+    win.disp_offset = s.sign * prm->disp_lower;
+    int32_t *d_idx = nullptr;
+    float *d_taps = nullptr;
+    if (want_refine) { // the three taps are re-evaluated from the census words
+        void *dsrc, *dtgt;
+        SVH_TRY(stage_in(ctx, scr, *s.src, &dsrc));
+        SVH_TRY(stage_in(ctx, scr, *s.tgt, &dtgt));
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)s.H * s.Ws * (s.nWw ? s.nWw : 1));
+        uint32_t *tw = scr.get_n<uint32_t>((size_t)s.H * s.Wt * (s.nWw ? s.nWw : 1));
+        d_idx = scr.get_n<int32_t>((size_t)npx);
+        d_taps = scr.get_n<float>((size_t)npx * 3);
+        if (!sw || !tw || !d_idx || !d_taps) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_from_image(ctx, {(const float *)dsrc, s.H, s.Ws, s.C}, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, s.H,
+                                      s.Ws, s.nWw, false, sw));
+        SVH_TRY(dev_census_from_image(ctx, {(const float *)dtgt, s.H, s.Wt, s.C}, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, s.H,
+                                      s.Wt, s.nWw, true, tw));
+        cs.src_words = sw;
+        cs.tgt_words = tw;
+        win.idx = d_idx;
+        win.taps = d_taps;
+        win.taps_h_r = prm->refine_h_radius;
+        win.taps_v_r = prm->refine_v_radius;
+    }
+    SVH_TRY(dev_census_finalize(ctx, sa, cs, mmap, (const uint2 *)dkeys, win));
+    if (want_refine) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));
+    if (disp) SVH_TRY(finish_out(ctx, o_disp));
+    if (refined) SVH_TRY(finish_out(ctx, o_ref));
+    return SVH_OK;
+}

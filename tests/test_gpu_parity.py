@@ -355,3 +355,30 @@ def test_census_fast_path_equals_general_and_oracle(D, ddir):
         idx = so.extract_index(vol, so.COST)
         assert_bits(fast["disp"], so.index_to_disp(idx, int(ddir)))
         assert_close(fast["refined"], so.refine_disp(so.truncated_cost_volume(vol, idx, h_r, v_r, 1), idx, so.PARABOLA), 1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ disparity shards
+@pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
+def test_census_shards_equal_single_gpu(ddir):
+    """svh_census_shard_keys / _finish: three shards reduced with an element-wise min (what the RCCL all-reduce does)
+    give the single-call disparity and refined maps bit for bit; the keys match the numpy restatement."""
+    from shard_protocol import shard_keys
+    src, tgt, _ = parallax_pair(33, 290, 10, 8, 30, 3, 21, seed=42)
+    D = 300
+    for n_dir, Pout, margins in ((8, 100.0, (0, 0, 0, 0)), (8, 5.0, (3, 1, 2, 4)), (0, 100.0, (0, 0, 0, 0))):
+        kw = dict(dDir=ddir, sgmDirections=n_dir, P1=0.2, P2=0.7, Pout=Pout, margins=sv.Margins(*margins))
+        d_tgt, d_src = dev(tgt), dev(src)
+        full = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, refineKernel=so.PARABOLA, refine_h_radius=4, refine_v_radius=4, **kw)
+        cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D, int(ddir))
+        keys = None
+        for (b, n) in ((0, 101), (101, 64), (165, 135)):
+            k = sv.censusShardKeys(d_tgt, d_src, 4, 4, D, (b, n), **kw)
+            assert_bits(k, shard_keys(cv[:, :, b:b + n], b, cv.shape[1]))
+            keys = k if keys is None else torch.minimum(keys, k)
+        res = sv.censusShardFinish(d_tgt, d_src, keys, 4, 4, D, refineKernel=so.PARABOLA, refine_h_radius=4, refine_v_radius=4, **kw)
+        assert_bits(res["disp"], host(full["disp"]))
+        assert_close(res["refined"], host(full["refined"]), 0.0)
+    from libstevi_amd._capi import SvhError, ERR_UNSUPPORTED
+    with pytest.raises(SvhError) as e:  # non-integer Pout leaves the exact regime: the disparity axis no longer shards
+        sv.censusShardKeys(dev(tgt), dev(src), 4, 4, D, (0, 100), Pout=2.5)
+    assert e.value.status == ERR_UNSUPPORTED

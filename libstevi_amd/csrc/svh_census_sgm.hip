@@ -248,33 +248,38 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     }
 }
 
-// scan_rows_kernel: pass 1 (Left2Right), one wavefront per image row; lane l owns a contiguous run of the row, the
-// run summaries are chained with a 6-step shuffle scan over the affine maps (A, sign).
+// scan_rows_kernel: pass 1 (Left2Right), one wavefront per image row, 64 consecutive pixels per step (coalesced
+// 256-byte loads and stores).  Each pixel is the affine map x -> g - x; an inclusive 6-step shuffle scan composes
+// them inside the chunk and the carry of the previous chunks enters through lane 0.
 __global__ void __launch_bounds__(256) scan_rows_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, float *__restrict__ mmap) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= sg.Hp) return;
-    const int run = (sg.Wp + 63) / 64;
-    const int b = min(lane * run, sg.Wp), e = min(b + run, sg.Wp), n = e - b;
-    const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left + b;
-    float a = 0.0f;
-    for (int k = 0; k < n; k++) a = gmap[base + k] - a;
-    float sgn = (n & 1) ? -1.0f : 1.0f;
-    // inclusive scan of map composition: (earlier, then mine)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const float ea = __shfl_up(a, off), es = __shfl_up(sgn, off);
-        if (lane >= off) {
-            a = a + sgn * ea;
-            sgn = sgn * es;
-        }
-    }
-    float mp = __shfl_up(a, 1); // everything before this lane, started from 0
-    if (lane == 0) mp = 0.0f;
+    const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left;
     float *out = mmap + npx; // pass 1
-    for (int k = 0; k < n; k++) {
-        out[base + k] = mp;
-        mp = gmap[base + k] - mp;
+    float carry = 0.0f;      // min_p entering the chunk
+    for (int c0 = 0; c0 < sg.Wp; c0 += 64) {
+        const int k = c0 + lane;
+        const bool in = k < sg.Wp;
+        // map of this pixel (identity outside the row): mp_after = a + sgn * mp_before
+        float a = in ? gmap[base + k] : 0.0f;
+        float sgn = in ? -1.0f : 1.0f;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float ea = __shfl_up(a, off), es = __shfl_up(sgn, off);
+            if (lane >= off) {
+                a = a + sgn * ea;
+                sgn = sgn * es;
+            }
+        }
+        // min_p seen by this pixel = all earlier pixels of the chunk applied to the carry
+        float ea = __shfl_up(a, 1), es = __shfl_up(sgn, 1);
+        if (lane == 0) {
+            ea = 0.0f;
+            es = 1.0f;
+        }
+        if (in) out[base + k] = ea + es * carry;
+        carry = __shfl(a, 63) + __shfl(sgn, 63) * carry;
     }
 }
 

@@ -1,0 +1,105 @@
+// Drop-in for LibStevi's correlation/correlation_base.h (hot-path subset): same names and signatures, bodies
+// marshal to libstevi_hip.so.  Reference lines are cited per function.
+#ifndef STEREOVISION_CORRELATION_BASE_H
+#define STEREOVISION_CORRELATION_BASE_H
+
+#include <array>
+#include <cstdint>
+
+#include "./stevi_hip_bridge.h"
+
+namespace StereoVision {
+namespace Correlation {
+
+enum class dispExtractionStartegy { Cost = 0, Score = 1 };                       // correlation_base.h:31-34
+enum class dispDirection { LeftToRight = 0, RightToLeft = 1 };                   // :36-39
+enum class truncatedCostVolumeDirection { Same = 0, Reversed = 1, Both = 2 };    // :41-45
+typedef int32_t disp_t;                                                          // :47
+
+// searchOffset<nDim>, correlation_base.h:288-409 (the accessors the 1-D path uses)
+template <int nDim> class searchOffset {
+  public:
+    searchOffset() : _isValid(false) {
+        _upperOffsets.fill(0);
+        _lowerOffsets.fill(0);
+    }
+    template <typename... Ds> searchOffset(disp_t lowerOffset0, disp_t upperOffset0, Ds... nextOffsets) : _isValid(true) {
+        static_assert(sizeof...(nextOffsets) == 2 * (nDim - 1), "The number of offsets provided to the constructor should be twice the number of dimensions !");
+        std::array<disp_t, 2 * (nDim - 1) + 1> n{static_cast<disp_t>(nextOffsets)..., 0};
+        _lowerOffsets[0] = lowerOffset0;
+        _upperOffsets[0] = upperOffset0;
+        for (int i = 1; i < nDim; i++) {
+            _lowerOffsets[i] = n[2 * (i - 1)];
+            _upperOffsets[i] = n[2 * (i - 1) + 1];
+        }
+    }
+    bool isValid() const { return _isValid; }
+    template <int dim> int const &upperOffset() const { return _upperOffsets[dim]; }
+    template <int dim> int const &lowerOffset() const { return _lowerOffsets[dim]; }
+    int const &upperOffset(int dim) const { return _upperOffsets[dim]; }
+    int const &lowerOffset(int dim) const { return _lowerOffsets[dim]; }
+    int dimRange(int dim) const { return _upperOffsets[dim] - _lowerOffsets[dim] + 1; }
+    int idx2disp(int dim, int idx) const { return _lowerOffsets[dim] + idx; }
+    int disp2idx(int dim, int disp) const { return disp - _lowerOffsets[dim]; }
+
+  private:
+    std::array<disp_t, nDim> _upperOffsets, _lowerOffsets;
+    bool _isValid;
+};
+
+template <typename SearchRangeType> struct searchRangeTypeInfos {};
+template <> struct searchRangeTypeInfos<disp_t> { static const int CostVolumeDims = 3; };
+template <int nDim> struct searchRangeTypeInfos<searchOffset<nDim>> { static const int CostVolumeDims = 2 + nDim; };
+
+// extractSelectedIndex<strategy>, correlation_base.h:427-464
+template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 2> extractSelectedIndex(Multidim::Array<T_CV, 3> const &costVolume) {
+    auto s = costVolume.shape();
+    Multidim::Array<disp_t, 2> disp(s[0], s[1]);
+    if (disp.empty()) return disp;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
+    HipBridge::check(svh_extract_selected_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
+    return disp;
+}
+
+// selectedIndexToDisp<DT, dDir>, correlation_base.h:511-532
+template <typename DT, dispDirection dDir = dispDirection::RightToLeft>
+Multidim::Array<DT, 2> selectedIndexToDisp(Multidim::Array<DT, 2> const &selectedIndex, disp_t disp_offset = 0) {
+    auto s = selectedIndex.shape();
+    Multidim::Array<DT, 2> disp(s[0], s[1]);
+    if (disp.empty()) return disp;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
+    HipBridge::check(svh_selected_index_to_disp(HipBridge::context(), static_cast<int>(dDir), &in, disp_offset, &out));
+    return disp;
+}
+
+// selectedCost, correlation_base.h:557-577
+template <class T_CV> Multidim::Array<T_CV, 2> selectedCost(Multidim::Array<T_CV, 3> const &costVolume, Multidim::Array<disp_t, 2> const &selectedIndex) {
+    auto s = costVolume.shape();
+    Multidim::Array<T_CV, 2> tcv(s[0], s[1]);
+    if (tcv.empty()) return tcv;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
+    HipBridge::check(svh_selected_cost(HipBridge::context(), &cv, &idx, &out));
+    return tcv;
+}
+
+// truncatedCostVolume<T_CV, dir, sdir>, correlation_base.h:579-674
+template <class T_CV, dispDirection dir = dispDirection::RightToLeft, truncatedCostVolumeDirection sdir = truncatedCostVolumeDirection::Same>
+Multidim::Array<T_CV, 3> truncatedCostVolume(Multidim::Array<T_CV, 3> const &costVolume, Multidim::Array<disp_t, 2> const &selectedIndex,
+                                             uint8_t h_radius, uint8_t v_radius, uint8_t cost_vol_radius) {
+    auto s = costVolume.shape();
+    Multidim::Array<T_CV, 3> tcv(s[0], s[1], (sdir == truncatedCostVolumeDirection::Both) ? cost_vol_radius * 4 + 1 : cost_vol_radius * 2 + 1);
+    if (tcv.empty()) return tcv;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
+    HipBridge::check(svh_truncated_cost_volume(HipBridge::context(), static_cast<int>(sdir), static_cast<int>(dir), &cv, &idx, h_radius, v_radius,
+                                               cost_vol_radius, &out));
+    return tcv;
+}
+
+} // namespace Correlation
+} // namespace StereoVision
+
+#endif // STEREOVISION_CORRELATION_BASE_H

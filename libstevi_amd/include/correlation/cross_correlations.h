@@ -1,0 +1,67 @@
+// Drop-in for LibStevi's correlation/cross_correlations.h (1-D disparity path).
+#ifndef STEREOVISION_CROSS_CORRELATIONS_H
+#define STEREOVISION_CROSS_CORRELATIONS_H
+
+#include "./census.h"
+#include "./correlation_base.h"
+#include "./matching_costs.h"
+#include "./unfold.h"
+
+namespace StereoVision {
+namespace Correlation {
+
+namespace HipBridge {
+inline void rangeOf(disp_t width, int32_t &lower, int32_t &count) {
+    lower = 0;
+    count = width;
+}
+inline void rangeOf(searchOffset<1> const &r, int32_t &lower, int32_t &count) {
+    lower = r.lowerOffset(0);
+    count = r.dimRange(0);
+}
+} // namespace HipBridge
+
+// featureVolume2CostVolume<matchFunc, T_L, T_R, SearchRangeType, dDir, TCV>, cross_correlations.h:724-738
+template <matchingFunctions matchFunc, class T_L, class T_R, typename SearchRangeType, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
+inline Multidim::Array<TCV, 3> featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim::Array<T_R, 3> const &feature_vol_r,
+                                                        SearchRangeType searchRange) {
+    static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
+    static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(searchRangeTypeInfos<SearchRangeType>::CostVolumeDims == 3, "libstevi_hip: 1-D disparity ranges only (disp_t or searchOffset<1>)");
+    int32_t lower, count;
+    HipBridge::rangeOf(searchRange, lower, count);
+    if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || count <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :209-211
+    auto const &src = (dDir == dispDirection::RightToLeft) ? feature_vol_r.shape() : feature_vol_l.shape();
+    // aggregateCost's own layout (cross_correlations.h:220) is {w*D, 1, w}; the GPU's native one is dense (row, col, disparity)
+    Multidim::Array<TCV, 3> cv(src[0], src[1], count);
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
+    if (!HipBridge::check(svh_feature_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, lower, count, &out)))
+        return Multidim::Array<TCV, 3>(0, 0, 0);
+    return cv;
+}
+
+// unfoldBasedCostVolume<matchFunc, T_L, T_R, nImDim, dDir, TCV>(img_l, img_r, h_radius, v_radius, disp_width), cross_correlations.h:740-765
+template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
+Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const &img_l, Multidim::Array<T_R, nImDim> const &img_r, uint8_t h_radius,
+                                              uint8_t v_radius, disp_t disp_width) {
+    static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
+    static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
+    auto l_shape = img_l.shape();
+    auto r_shape = img_r.shape();
+    if (l_shape[0] != r_shape[0] || disp_width <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :751-753
+    if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 3>(0, 0, 0); // :755-759
+    auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
+    Multidim::Array<TCV, 3> cv(src[0], src[1], disp_width);
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
+    if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
+                                                 disp_width, &out)))
+        return Multidim::Array<TCV, 3>(0, 0, 0);
+    return cv;
+}
+
+} // namespace Correlation
+} // namespace StereoVision
+
+#endif // STEREOVISION_CROSS_CORRELATIONS_H

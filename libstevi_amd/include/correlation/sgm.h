@@ -1,0 +1,36 @@
+// Drop-in for LibStevi's correlation/sgm.h.
+#ifndef STEREOVISION_CORRELATION_SGM_H
+#define STEREOVISION_CORRELATION_SGM_H
+
+#include "../utils/margins.h"
+#include "./correlation_base.h"
+
+namespace StereoVision {
+namespace Correlation {
+
+enum class sgmDirections { // sgm.h:29-46
+    Up2Down, Down2Up, Left2Right, Right2Left, UpLeft2DownRight, DownRight2UpLeft, UpRight2DownLeft, DownLeft2UpRight,
+    UpLeft2Right, DownRight2Left, UpRight2Left, DownLeft2Right, UpLeft2Down, DownRight2Up, UpRight2Down, DownLeft2Up
+};
+
+// sgmCostVolume<nDirections, extractionStrategy, T_CV>(cv_base, P1, P2, margins, Pout), sgm.h:360-404.
+// Reproduces the reference as written (which passes really run, min_a_cost = c_score in the Cost branch).  16 directions
+// race on sgm_cv in the reference (sgm.h:299 under :336) and are rejected.
+template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV>
+Multidim::Array<float, 3> sgmCostVolume(Multidim::Array<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
+    static_assert(nDirections == 4 or nDirections == 8 or nDirections == 16, "SGM can only operate with 4, 8 or 16 directions");
+    static_assert(nDirections != 16, "libstevi_hip: the reference's 16-direction lines overlap inside one OpenMP loop; its result is not defined");
+    static_assert(std::is_same_v<T_CV, float>, "libstevi_hip: cost volumes are float");
+    Multidim::Array<float, 3> sgm_cv(cv_base.shape());
+    if (sgm_cv.empty()) return sgm_cv;
+    const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
+    HipBridge::check(svh_sgm_cost_volume(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
+    return sgm_cv;
+}
+
+} // namespace Correlation
+} // namespace StereoVision
+
+#endif // STEREOVISION_CORRELATION_SGM_H

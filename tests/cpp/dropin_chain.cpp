@@ -1,0 +1,71 @@
+// The reference benchmark's call chain written against the drop-in headers, with the reference's own names
+// (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294; examples/stereo_refine_test/main.cpp:367-384).
+// usage: dropin_chain <H> <W> <D> <left.f32> <right.f32> <out_prefix>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include <correlation/cost_based_refinement.h>
+#include <correlation/cross_correlations.h>
+#include <correlation/sgm.h>
+
+namespace SC = StereoVision::Correlation;
+
+template <class T> static void dump(std::string const &path, T const *p, size_t n) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f || fwrite(p, sizeof(T), n, f) != n) {
+        fprintf(stderr, "cannot write %s\n", path.c_str());
+        exit(2);
+    }
+    fclose(f);
+}
+
+static Multidim::Array<float, 2> load(const char *path, int H, int W) {
+    Multidim::Array<float, 2> img(H, W);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(img.data(), sizeof(float), (size_t)H * W, f) != (size_t)H * W) {
+        fprintf(stderr, "cannot read %s\n", path);
+        exit(2);
+    }
+    fclose(f);
+    return img;
+}
+
+int main(int argc, char **argv) {
+    if (argc != 7) return 1;
+    const int H = atoi(argv[1]), W = atoi(argv[2]), D = atoi(argv[3]);
+    Multidim::Array<float, 2> target = load(argv[4], H, W), source = load(argv[5], H, W);
+    const std::string out = argv[6];
+    const uint8_t h_r = 4, v_r = 4;
+    const float P1 = 0.001f, P2 = 0.01f, Pout = 100;
+
+    { // census + SGM-8 + argmin (Cost)
+        constexpr auto matchFunc = SC::matchingFunctions::CENSUS;
+        constexpr auto strat = SC::MatchingFunctionTraits<matchFunc>::extractionStrategy;
+        Multidim::Array<float, 3> CV = SC::unfoldBasedCostVolume<matchFunc>(target, source, h_r, v_r, D);
+        Multidim::Array<float, 3> SGM_CV = SC::sgmCostVolume<8, strat>(CV, P1, P2, StereoVision::Margins(), Pout);
+        Multidim::Array<SC::disp_t, 2> disp =
+            SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(SC::extractSelectedIndex<strat>(SGM_CV), 0);
+        dump(out + "_census_sgm.f32", SGM_CV.data(), SGM_CV.flatLenght());
+        dump(out + "_census_disp.i32", disp.data(), disp.flatLenght());
+    }
+    { // NCC + SGM-8 (Score) + parabola refinement
+        constexpr auto matchFunc = SC::matchingFunctions::NCC;
+        constexpr auto strat = SC::MatchingFunctionTraits<matchFunc>::extractionStrategy;
+        auto CV = SC::unfoldBasedCostVolume<matchFunc>(target, source, h_r, v_r, D);
+        auto SGM_CV = SC::sgmCostVolume<8, strat>(CV, P1, P2, StereoVision::Margins(), Pout);
+        auto rawDisp = SC::extractSelectedIndex<strat>(SGM_CV);
+        auto tcv = SC::truncatedCostVolume(SGM_CV, rawDisp, h_r, v_r, 1);
+        auto refined = SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(tcv, rawDisp);
+        dump(out + "_ncc_cv.f32", CV.data(), CV.flatLenght());
+        dump(out + "_ncc_idx.i32", rawDisp.data(), rawDisp.flatLenght());
+        dump(out + "_ncc_refined.f32", refined.data(), refined.flatLenght());
+    }
+    // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
+    Multidim::Array<float, 2> shorter(H - 1, W);
+    auto empty = SC::unfoldBasedCostVolume<SC::matchingFunctions::SAD>(target, shorter, h_r, v_r, D);
+    if (!empty.empty()) return 3;
+    printf("ok\n");
+    return 0;
+}

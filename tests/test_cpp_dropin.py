@@ -1,0 +1,55 @@
+"""The C++ drop-in headers (libstevi_amd/include): they compile and link against libstevi_hip.so on CPU, and on the
+GPU the reference benchmark's call chain written with the reference's names matches the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "dropin_chain.cpp")
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "dropin_chain")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "libstevi_amd", "include"), SRC, "-o", exe,
+           "-L", os.path.join(ROOT, "libstevi_amd"), "-lstevi_hip", "-Wl,-rpath," + os.path.join(ROOT, "libstevi_amd"),
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_headers_compile_and_link(tmp_path):
+    exe = build(tmp_path)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_reference_call_chain_matches_oracle(tmp_path):
+    import oracle as so
+    from helpers import parallax_pair
+    exe = build(tmp_path)
+    src, tgt, _ = parallax_pair(40, 64, 12, 10, 20, 2, 7, seed=21)
+    H, W, D = src.shape[0], src.shape[1], 24
+    tgt.tofile(tmp_path / "l.f32")
+    src.tofile(tmp_path / "r.f32")
+    out = subprocess.run([exe, str(H), str(W), str(D), str(tmp_path / "l.f32"), str(tmp_path / "r.f32"), str(tmp_path / "o")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+    vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    got_vol = np.fromfile(tmp_path / "o_census_sgm.f32", np.float32).reshape(H, W, D)
+    assert np.array_equal(got_vol.view(np.uint32), vol.view(np.uint32))
+    got_disp = np.fromfile(tmp_path / "o_census_disp.i32", np.int32).reshape(H, W)
+    assert np.array_equal(got_disp, so.index_to_disp(so.extract_index(vol, so.COST)))
+    ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
+    got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
+    assert np.max(np.abs(got_ncc - ncc)) <= 1e-4
+    svol = so.sgm(got_ncc, 8, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    idx = so.extract_index(svol, so.SCORE)
+    assert np.array_equal(np.fromfile(tmp_path / "o_ncc_idx.i32", np.int32).reshape(H, W), idx)
+    ref = so.refine_disp(so.truncated_cost_volume(svol, idx, 4, 4, 1), idx, so.PARABOLA)
+    got_ref = np.fromfile(tmp_path / "o_ncc_refined.f32", np.float32).reshape(H, W)
+    assert np.array_equal(np.isnan(got_ref), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.max(np.abs(got_ref[ok] - ref[ok])) <= 1e-4

@@ -117,31 +117,117 @@ __device__ __forceinline__ float g_from_keys(uint32_t key0, uint32_t key1, int p
     return (float)min(g0, g1);
 }
 
+// Two neighbouring pixels per lane.  With the records stored as 2-record pairs P_m = (rec 2m, rec 2m+1), the "even"
+// pixel E of a lane (record base 2 m0) and its "odd" neighbour O (base 2 m0 + 1) need, for the disparity pair (2e, 2e+1),
+//   E: P_{m0+e}.lo, P_{m0+e}.hi        O: P_{m0+e}.hi, P_{m0+e+1}.lo
+// i.e. ONE new 16-byte-aligned pair (ds_read_b128 for 2-word records) per four voxels.
+constexpr int PX = 2 * TJ; // pixels per block
+
+template <int NW> struct Rec {
+    uint32_t w[NW > 0 ? NW : 1];
+};
+
+template <int NW> __device__ __forceinline__ void load_pair(const uint32_t *lds, int m, Rec<NW> &lo, Rec<NW> &hi) {
+    if constexpr (NW == 2) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(lds + 4 * m);
+        lo.w[0] = t.x; lo.w[1] = t.y; hi.w[0] = t.z; hi.w[1] = t.w;
+    } else if constexpr (NW == 1) {
+        const uint2 t = *reinterpret_cast<const uint2 *>(lds + 2 * m);
+        lo.w[0] = t.x; hi.w[0] = t.y;
+    } else if constexpr (NW == 4) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(lds + 8 * m), b = *reinterpret_cast<const uint4 *>(lds + 8 * m + 4);
+        lo.w[0] = a.x; lo.w[1] = a.y; lo.w[2] = a.z; lo.w[3] = a.w; hi.w[0] = b.x; hi.w[1] = b.y; hi.w[2] = b.z; hi.w[3] = b.w;
+    } else if constexpr (NW == 3) {
+        const uint2 a = *reinterpret_cast<const uint2 *>(lds + 6 * m), b = *reinterpret_cast<const uint2 *>(lds + 6 * m + 2),
+                    c = *reinterpret_cast<const uint2 *>(lds + 6 * m + 4);
+        lo.w[0] = a.x; lo.w[1] = a.y; lo.w[2] = b.x; hi.w[0] = b.y; hi.w[1] = c.x; hi.w[2] = c.y;
+    } else {
+        lo.w[0] = 0; hi.w[0] = 0;
+    }
+}
+
+template <int NW> __device__ __forceinline__ int hamming_words(const Words<NW> &s, const Rec<NW> &r) {
+    int acc = 0;
+    if constexpr (NW > 0) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) acc += __popc(s.v[w] ^ r.w[w]);
+    }
+    return acc;
+}
+
+// window of PX + D - 1 records (+ padding to whole pairs), same record order as stage_target_window
+template <int NW> __device__ __forceinline__ void stage_target_window2(const CensusGeom &g, int i, int j0, uint32_t *lds, int n_rec) {
+    if constexpr (NW > 0) {
+        const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
+        for (int e = threadIdx.x; e < n_rec * NW; e += TJ) {
+            const int y = e / NW, w = e - y * NW;
+            const int jt = g.sign > 0 ? j0 + g.disp_lower + y : j0 + (PX - 1) - g.disp_lower - y;
+            lds[e] = (jt >= 0 && jt < g.Wt && y < PX + g.D - 1) ? trow[(int64_t)jt * NW + w] : 0u;
+        }
+    }
+}
+
+__host__ __device__ inline int sweep_records(int D) { return (PX + D - 1 + 3) & ~1; } // whole pairs, one spare pair for the look-ahead
+
 template <int NW>
 __global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int i = blockIdx.y, j0 = blockIdx.x * TJ, tj = threadIdx.x, j = j0 + tj;
-    stage_target_window<NW>(g, i, j0, lds);
+    const int i = blockIdx.y, j0 = blockIdx.x * PX, t = threadIdx.x;
+    stage_target_window2<NW>(g, i, j0, lds, sweep_records(g.D));
     __syncthreads();
-    if (j >= g.Ws) return;
-    const int64_t p = (int64_t)i * g.Ws + j;
-    const Words<NW> s = load_source_words<NW>(g, p);
-    const uint32_t *base = lds + (g.sign > 0 ? tj : TJ - 1 - tj) * NW;
-    uint32_t key0 = KEY_NONE, key1 = KEY_NONE;
-    const int d_off = g.d_offset; // this call handles global indices d_off .. d_off + D - 1
-    if (j0 + TJ - 1 + d_off + g.D - 1 < g.Ws) { // no lane of this block reaches j + d >= W
-        for_each_disparity<NW>(s, base, g.D, [&](int d, int c) { key0 = min(key0, make_key(c, d_off + d)); });
-    } else {
-        const int dsplit = min(max(g.Ws - j - d_off, 0), g.D);
-        for_each_disparity<NW>(s, base, g.D, [&](int d, int c) {
-            const uint32_t k = make_key(c, d_off + d);
-            const bool oob = d >= dsplit;
-            key0 = min(key0, oob ? KEY_NONE : k);
-            key1 = min(key1, oob ? k : KEY_NONE);
-        });
+    const bool fwd = g.sign > 0;
+    const int m0 = fwd ? t : TJ - 1 - t;                       // pair index of the even pixel at d = 0
+    const int jE = j0 + (fwd ? 2 * t : 2 * t + 1), jO = j0 + (fwd ? 2 * t + 1 : 2 * t);
+    const int64_t row = (int64_t)i * g.Ws;
+    Words<NW> sE = load_source_words<NW>(g, row + min(jE, g.Ws - 1)), sO = load_source_words<NW>(g, row + min(jO, g.Ws - 1));
+    const int d_off = g.d_offset, D = g.D;
+    // region limits: a pixel pays Pout for d >= dsplit = W - j - d_off.  Over the 128 pixels of this wave the split moves
+    // by 127, so d < lo is "nobody pays" and d >= hi "everybody pays", both wave uniform.
+    const int wave_j0 = j0 + 2 * (t & ~63);
+    const int lo = min(max(g.Ws - d_off - (wave_j0 + 127), 0), D), hi = min(max(g.Ws - d_off - wave_j0, 0), D);
+    const int splitE = min(max(g.Ws - d_off - jE, 0), D), splitO = min(max(g.Ws - d_off - jO, 0), D);
+    uint32_t kE0 = KEY_NONE, kE1 = KEY_NONE, kO0 = KEY_NONE, kO1 = KEY_NONE;
+    Rec<NW> cur_lo, cur_hi, nxt_lo, nxt_hi;
+    load_pair<NW>(lds, m0, cur_lo, cur_hi);
+    const int n_pairs = D >> 1;
+#pragma unroll 4
+    for (int e = 0; e < n_pairs; e++) {
+        load_pair<NW>(lds, m0 + e + 1, nxt_lo, nxt_hi);
+        const int d = 2 * e;
+        const uint32_t kEa = make_key(hamming_words<NW>(sE, cur_lo), d_off + d), kOa = make_key(hamming_words<NW>(sO, cur_hi), d_off + d);
+        const uint32_t kEb = make_key(hamming_words<NW>(sE, cur_hi), d_off + d + 1), kOb = make_key(hamming_words<NW>(sO, nxt_lo), d_off + d + 1);
+        if (d + 1 < lo) {
+            kE0 = min(kE0, min(kEa, kEb));
+            kO0 = min(kO0, min(kOa, kOb));
+        } else if (d >= hi) {
+            kE1 = min(kE1, min(kEa, kEb));
+            kO1 = min(kO1, min(kOa, kOb));
+        } else {
+            kE0 = min(kE0, min(d >= splitE ? KEY_NONE : kEa, d + 1 >= splitE ? KEY_NONE : kEb));
+            kE1 = min(kE1, min(d >= splitE ? kEa : KEY_NONE, d + 1 >= splitE ? kEb : KEY_NONE));
+            kO0 = min(kO0, min(d >= splitO ? KEY_NONE : kOa, d + 1 >= splitO ? KEY_NONE : kOb));
+            kO1 = min(kO1, min(d >= splitO ? kOa : KEY_NONE, d + 1 >= splitO ? kOb : KEY_NONE));
+        }
+        cur_lo = nxt_lo;
+        cur_hi = nxt_hi;
     }
-    keys[p] = make_uint2(key0, key1);
-    if (gmap) gmap[p] = g_from_keys(key0, key1, (int)Pout);
+    if (D & 1) { // last (even) disparity
+        const int d = D - 1;
+        const uint32_t kEa = make_key(hamming_words<NW>(sE, cur_lo), d_off + d), kOa = make_key(hamming_words<NW>(sO, cur_hi), d_off + d);
+        kE0 = min(kE0, d >= splitE ? KEY_NONE : kEa);
+        kE1 = min(kE1, d >= splitE ? kEa : KEY_NONE);
+        kO0 = min(kO0, d >= splitO ? KEY_NONE : kOa);
+        kO1 = min(kO1, d >= splitO ? kOa : KEY_NONE);
+    }
+    const int pout = (int)Pout;
+    if (jE < g.Ws) {
+        keys[row + jE] = make_uint2(kE0, kE1);
+        if (gmap) gmap[row + jE] = g_from_keys(kE0, kE1, pout);
+    }
+    if (jO < g.Ws) {
+        keys[row + jO] = make_uint2(kO0, kO1);
+        if (gmap) gmap[row + jO] = g_from_keys(kO0, kO1, pout);
+    }
 }
 
 // the same g from already reduced keys (disparity-sharded runs)
@@ -439,8 +525,9 @@ __global__ void __launch_bounds__(TJ) census_apply_select_kernel(CensusGeom g, S
 size_t lds_bytes(int nWw, int D) { return (size_t)(nWw ? nWw : 1) * (TJ + D - 1) * sizeof(uint32_t); }
 
 template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap) {
-    dim3 grid(ceil_div(g.Ws, TJ), g.H);
-    SVH_LAUNCH(ctx, "census_sweep", census_sweep_kernel<NW>, grid, TJ, lds_bytes(NW, g.D), g, Pout, keys, gmap);
+    dim3 grid(ceil_div(g.Ws, PX), g.H);
+    const size_t shmem = (size_t)(NW ? NW : 1) * sweep_records(g.D) * sizeof(uint32_t);
+    SVH_LAUNCH(ctx, "census_sweep", census_sweep_kernel<NW>, grid, TJ, shmem, g, Pout, keys, gmap);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -470,7 +557,9 @@ static constexpr int kMaxWords = 4;
 
 // LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), at most 1024 disparities per
 // call, 4096 over all shards (12 index bits in the winner key), costs <= 128
-bool census_lane_kernels_available(int nWw, int D) { return nWw <= kMaxWords && D <= 1024 && lds_bytes(nWw, D) <= 60 * 1024; }
+bool census_lane_kernels_available(int nWw, int D) {
+    return nWw <= kMaxWords && D <= 1024 && (size_t)(nWw ? nWw : 1) * sweep_records(D) * sizeof(uint32_t) <= 60 * 1024;
+}
 int census_max_total_disparities() { return 1 << KEY_IDX_BITS; }
 
 bool census_exact_regime(const SgmArgs &a, int nWw) {

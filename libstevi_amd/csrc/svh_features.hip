@@ -116,6 +116,51 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_image_tiled_kernel(const flo
     for (int w = n_written; w < n_out; w++) o[w] = 0; // rule E1
 }
 
+// Grey images with a compile-time window (the common 7x7 / 9x9 / 11x11 cases): the window walk is fully unrolled, every
+// LDS read has an immediate offset, and the word boundaries are known at compile time.
+template <int HR, int VR>
+__global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(const float *__restrict__ img, int H, int W, int pl, int pt, int Ho, int Wo,
+                                                                int n_out, bool round_target, uint32_t *__restrict__ words) {
+    constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TW = CENSUS_TJ + h - 1;
+    constexpr int NWRITTEN = (h * v - 1) / 32;
+    __shared__ float tile[v * TW];
+    const int i = blockIdx.y, j0 = blockIdx.x * CENSUS_TJ, tj = threadIdx.x, j = j0 + tj;
+#pragma unroll
+    for (int k = 0; k < v; k++) {
+        const int ii = i - pt + k;
+        const bool row_in = ii >= 0 && ii < H;
+        const float *row = img + (int64_t)ii * W;
+        for (int e = tj; e < TW; e += CENSUS_TJ) {
+            const int jj = j0 - pl + e;
+            tile[k * TW + e] = (row_in && jj >= 0 && jj < W) ? row[jj] : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (j >= Wo) return;
+    const float *tp = tile + tj;
+    const float ref = tp[0];
+    uint32_t *o = words + ((int64_t)i * Wo + j) * n_out;
+#pragma unroll
+    for (int word = 0; word < NWRITTEN; word++) {
+        uint32_t d = 0;
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const int c = 1 + 32 * word + b; // channel c = h * k + l (unfold.h:180)
+            const int k = c / h, l = c % h;
+            d |= (ref > tp[k * TW + l] ? 1u : 0u) << b;
+        }
+        o[word] = round_target ? round_word_through_float(d) : d;
+    }
+    for (int w = NWRITTEN; w < n_out; w++) o[w] = 0; // rule E1
+}
+
+template <int HR, int VR>
+static void launch_census_grey(svh_context *ctx, ImageDesc img, int pl, int pt, int Ho, int Wo, int n_out, bool round_target, uint32_t *words) {
+    dim3 grid(ceil_div(Wo, CENSUS_TJ), Ho);
+    SVH_LAUNCH(ctx, "census_transform", (census_grey_kernel<HR, VR>), grid, CENSUS_TJ, 0, img.data, img.H, img.W, pl, pt, Ho, Wo, n_out,
+               round_target, words);
+}
+
 __global__ void census_features_kernel(const float *__restrict__ feat, int64_t npx, int F, int n_out, int n_written,
                                        bool round_target, uint32_t *__restrict__ words) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
@@ -145,6 +190,13 @@ int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int
     int64_t npx = (int64_t)Ho * Wo;
     if (npx == 0 || n_out == 0) return SVH_OK;
     int F = (2 * h_r + 1) * (2 * v_r + 1) * img.C;
+    if (img.C == 1 && h_r == v_r && (h_r == 3 || h_r == 4 || h_r == 5)) {
+        if (h_r == 3) launch_census_grey<3, 3>(ctx, img, pl, pt, Ho, Wo, n_out, round_through_float, words);
+        else if (h_r == 4) launch_census_grey<4, 4>(ctx, img, pl, pt, Ho, Wo, n_out, round_through_float, words);
+        else launch_census_grey<5, 5>(ctx, img, pl, pt, Ho, Wo, n_out, round_through_float, words);
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
     const size_t tile_bytes = (size_t)(2 * v_r + 1) * (CENSUS_TJ + 2 * h_r) * img.C * sizeof(float);
     if (tile_bytes <= 60 * 1024 && census_words_written(F) > 0) {
         dim3 grid(ceil_div(Wo, CENSUS_TJ), Ho);

@@ -151,6 +151,49 @@ __global__ void hamming_volume_kernel(const uint32_t *__restrict__ sw, const uin
     }
 }
 
+// LDS-tiled form: a block owns HV_TP consecutive pixels of a row and stages their HV_TP + D - 1 target records once
+// (mirrored for LeftToRight so that the record index grows with d); a wave then writes one pixel's D costs at a time,
+// lane l taking d = l, l + 64, ...: 64 consecutive LDS records in, one coalesced 256-byte store out.  HBM-write bound
+// (4 B/voxel, the API's float volume).
+constexpr int HV_TP = 64;
+
+template <int NW>
+__global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int H,
+                                                                   int Ws, int Wt, int D, int sign, int disp_lower, float *__restrict__ cv) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
+    const int n_rec = HV_TP + D - 1;
+    const uint32_t *trow = tw + (int64_t)i * Wt * NW;
+    for (int e = threadIdx.x; e < n_rec * NW; e += blockDim.x) {
+        const int y = e / NW, w = e - y * NW;
+        const int jt = sign > 0 ? j0 + disp_lower + y : j0 + (HV_TP - 1) - disp_lower - y;
+        lds[e] = (jt >= 0 && jt < Wt) ? trow[(int64_t)jt * NW + w] : 0u;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = wave; u < HV_TP && j0 + u < Ws; u += 4) {
+        const int64_t p = (int64_t)i * Ws + j0 + u;
+        uint32_t s[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) s[w] = sw[p * NW + w];
+        const uint32_t *base = lds + (sign > 0 ? u : HV_TP - 1 - u) * NW;
+        float *out = cv + p * D;
+        for (int d = lane; d < D; d += 64) {
+            uint32_t score = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) score += __popc(s[w] ^ base[d * NW + w]);
+            out[d] = (float)score;
+        }
+    }
+}
+
+template <int NW>
+static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *sw, const uint32_t *tw, int sign, float *cv) {
+    dim3 grid(ceil_div(a.Ws, HV_TP), a.H);
+    const size_t shmem = (size_t)NW * (HV_TP + a.D - 1) * sizeof(uint32_t);
+    SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, cv);
+}
+
 template <class A>
 static int launch_stats(svh_context *ctx, A acc, int H, int W, bool zm, bool nrm, float *mean, float *norm) {
     int64_t npx = (int64_t)H * W;
@@ -214,6 +257,16 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
     int64_t n = (int64_t)a.H * a.Ws * a.D;
     if (n == 0) return SVH_OK;
     int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+    if (nWw >= 1 && nWw <= 4 && (size_t)nWw * (HV_TP + a.D - 1) * sizeof(uint32_t) <= 60 * 1024) {
+        switch (nWw) {
+        case 1: launch_hamming_tiled<1>(ctx, a, src_words, tgt_words, sign, cv); break;
+        case 2: launch_hamming_tiled<2>(ctx, a, src_words, tgt_words, sign, cv); break;
+        case 3: launch_hamming_tiled<3>(ctx, a, src_words, tgt_words, sign, cv); break;
+        default: launch_hamming_tiled<4>(ctx, a, src_words, tgt_words, sign, cv); break;
+        }
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_kernel, grid_for(n, 256, 65536), 256, 0, src_words, tgt_words, nWw, a.H, a.Ws,
                a.Wt, a.D, sign, a.disp_lower, cv);
     SVH_CHECK_LAUNCH(ctx);
@@ -246,6 +299,9 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
         SVH_TRY(dev_census_from_image(ctx, tgt, h_r, v_r, h_r, v_r, a.H, a.Wt, nWw, true, tw));
         return dev_hamming_volume(ctx, a, sw, tw, nWw, cv);
     }
+    // grey images with windows up to 11x11: LDS-tiled, register-blocked kernel (svh_cost_volume_tiled.hip)
+    const int st = dev_cost_volume_grey_tiled(ctx, scr, a, src, tgt, h_r, v_r, cv);
+    if (st != SVH_ERR_UNSUPPORTED) return st;
     return cost_volume_generic(ctx, scr, a, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r},
                                FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, cv);
 }

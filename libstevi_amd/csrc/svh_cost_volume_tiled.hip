@@ -1,0 +1,236 @@
+// LDS-tiled, register-blocked cost volumes for grey images (CC / NCC / SSD / SAD and their zero-mean variants).
+//
+// A block owns 32 consecutive pixels of one row (8 per wave) and every disparity.  The (2v_r+1)-row source and target
+// tiles are staged in LDS once; lanes span the disparity axis (64 per chunk) so that a wave stores one pixel's costs as
+// coalesced 256-byte runs into the (row, col, disparity) volume.  For one window row the 8 pixels x h window columns
+// of a wave touch only 8 + h - 1 distinct target samples per lane (pixel p, column l -> sample p + l), so each LDS read
+// feeds up to h multiply-adds; the source samples are wave-uniform and travel through SGPRs (v_readlane).  No MFMA:
+// there is no shared operand between the per-pixel dot products to contract over.
+//
+// Arithmetic relative to the reference (cross_correlations.h:416-594, matching_costs.h:59-156): the products /
+// differences are accumulated per pixel in the reference's channel order (rows outer, columns inner); the per-element
+// normalisations are applied algebraically after the sum,
+//     NCC   sum (s/ns)(t/nt)            = (sum s t) / (ns nt)
+//     ZCC   sum (s-ms)(t-mt)            = sum (s-c)(t-c) - F (ms-c)(mt-c)        (c: a block constant, keeps magnitudes small)
+//     ZSSD  sum ((s-ms)-(t-mt))^2       = sum (s-t)^2 - F (ms-mt)^2
+//     ZSAD  sum |(s-ms)-(t-mt)|         = sum |(s-t) - (ms-mt)|
+// which changes results by rounding only (a few 1e-7 relative; the north-star tolerance for float costs is 1e-4).
+// Means, norms and the all-zero-target cost (target column outside the image, cross_correlations.h:235) come from a
+// per-pixel statistics kernel that follows the reference literally.
+#include "svh_internal.h"
+
+namespace svh {
+
+namespace {
+
+enum { T_DOT = 0, T_SSD = 1, T_SAD = 2 };
+constexpr int CV_PB = 8;   // pixels per wave
+constexpr int CV_TPX = 32; // pixels per block
+
+__device__ __forceinline__ float image_or_zero1(const float *__restrict__ img, int H, int W, int i, int j) {
+    return (i >= 0 && i < H && j >= 0 && j < W) ? img[(int64_t)i * W + j] : 0.0f;
+}
+
+// per-pixel window statistics, literal order of the reference: mean (channelsMean, correlation_base.h:1100-1136), norm
+// (channelsNorm / channelsZeroMeanNorm, cross_correlations.h:61-191) and, for the source image, the cost against the
+// all-zero target vector
+template <int CMP>
+__global__ void tiled_stats_kernel(const float *__restrict__ img, int H, int W, int h_r, int v_r, bool zm, bool nrm, float *__restrict__ mean,
+                                   float *__restrict__ norm, float *__restrict__ zcost) {
+    const int64_t npx = (int64_t)H * W;
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1, F = h * v;
+    const float scale = (float)(1. / (double)(float)F);
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(p % W), i = (int)(p / W);
+        float m = 0.0f, n = 1.0f;
+        if (zm) {
+            for (int k = 0; k < v; k++)
+                for (int l = 0; l < h; l++) m += image_or_zero1(img, H, W, i - v_r + k, j - h_r + l);
+            m *= scale;
+            mean[p] = m;
+        }
+        if (nrm) {
+            float acc = 0.0f;
+            for (int k = 0; k < v; k++)
+                for (int l = 0; l < h; l++) {
+                    float tmp = image_or_zero1(img, H, W, i - v_r + k, j - h_r + l) - m;
+                    acc += tmp * tmp;
+                }
+            n = sqrtf(acc);
+            norm[p] = n;
+        }
+        if (zcost) {
+            float acc = 0.0f;
+            for (int k = 0; k < v; k++)
+                for (int l = 0; l < h; l++) {
+                    float s = image_or_zero1(img, H, W, i - v_r + k, j - h_r + l);
+                    if (zm) s = s - m;
+                    if (nrm) s = s / n;
+                    if (CMP == T_DOT) acc += s * 0.0f;
+                    else if (CMP == T_SSD) acc += s * s;
+                    else acc += fabsf(s);
+                }
+            zcost[p] = acc;
+        }
+    }
+}
+
+template <int CMP, bool ZM, int HR>
+__global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt,
+                                                                int v_r, int D, int sign, int disp_lower, const float *__restrict__ mean_s,
+                                                                const float *__restrict__ mean_t, const float *__restrict__ norm_s,
+                                                                const float *__restrict__ norm_t, const float *__restrict__ zcost,
+                                                                float *__restrict__ cv) {
+    constexpr int h = 2 * HR + 1, NV = CV_PB + h - 1;
+    extern __shared__ float lds[];
+    const int v = 2 * v_r + 1;
+    const int sw = CV_TPX + h - 1, tw = CV_TPX + h - 1 + D - 1;
+    float *stile = lds, *ttile = lds + v * sw;
+    const int i = blockIdx.y, j0 = blockIdx.x * CV_TPX;
+    // block constant that keeps the zero-mean dot products small (see the header comment)
+    const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(j0, Ws - 1)] : 0.0f;
+    for (int k = 0; k < v; k++) {
+        const int ii = i - v_r + k;
+        for (int x = threadIdx.x; x < sw; x += blockDim.x) stile[k * sw + x] = image_or_zero1(src, H, Ws, ii, j0 - HR + x) - c0;
+        for (int z = threadIdx.x; z < tw; z += blockDim.x) {
+            const int jt = sign > 0 ? j0 + disp_lower - HR + z : j0 + (CV_TPX - 1) - disp_lower + HR - z;
+            ttile[k * tw + z] = image_or_zero1(tgt, H, Wt, ii, jt) - c0;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int ub = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * CV_PB);
+    const int tbase = sign > 0 ? ub : CV_TPX - ub - CV_PB; // + d + m
+    const float Ff = (float)(h * v);
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        const int dd = min(d, D - 1); // lanes past D compute on the last valid disparity and do not store
+        float acc[CV_PB], delta[CV_PB];
+#pragma unroll
+        for (int p = 0; p < CV_PB; p++) {
+            acc[p] = 0.0f;
+            delta[p] = 0.0f;
+        }
+        if (ZM && CMP == T_SAD) {
+#pragma unroll
+            for (int p = 0; p < CV_PB; p++) {
+                const int j = j0 + ub + p, jt = j + sign * (disp_lower + dd);
+                if (j < Ws && jt >= 0 && jt < Wt) delta[p] = mean_s[(int64_t)i * Ws + j] - mean_t[(int64_t)i * Wt + jt];
+            }
+        }
+        for (int k = 0; k < v; k++) {
+            float tv[NV];
+            const float *trow = ttile + k * tw + tbase + dd;
+#pragma unroll
+            for (int m = 0; m < NV; m++) tv[m] = trow[m];
+            const float mine = stile[k * sw + ub + min(lane, NV - 1)]; // lane m holds source sample m of this wave's pixels
+#pragma unroll
+            for (int p = 0; p < CV_PB; p++) {
+#pragma unroll
+                for (int l = 0; l < h; l++) {
+                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), p + l));
+                    const float t = tv[sign > 0 ? p + l : (CV_PB - 1 - p) + (h - 1 - l)];
+                    if (CMP == T_DOT) {
+                        acc[p] = fmaf(s, t, acc[p]);
+                    } else if (CMP == T_SSD) {
+                        const float df = s - t;
+                        acc[p] = fmaf(df, df, acc[p]);
+                    } else {
+                        acc[p] += fabsf((s - t) - delta[p]);
+                    }
+                }
+            }
+        }
+        if (d < D) {
+#pragma unroll
+            for (int p = 0; p < CV_PB; p++) {
+                const int j = j0 + ub + p;
+                if (j >= Ws) continue;
+                const int64_t px = (int64_t)i * Ws + j;
+                const int jt = j + sign * (disp_lower + d);
+                float r = acc[p];
+                if (jt >= 0 && jt < Wt) {
+                    const int64_t pt = (int64_t)i * Wt + jt;
+                    if (ZM && CMP == T_DOT) r -= Ff * (mean_s[px] - c0) * (mean_t[pt] - c0);
+                    if (ZM && CMP == T_SSD) {
+                        const float dm = mean_s[px] - mean_t[pt];
+                        r -= Ff * dm * dm;
+                    }
+                    if (norm_s) r /= norm_s[px] * norm_t[pt];
+                } else {
+                    r = zcost[px];
+                }
+                cv[px * D + d] = r;
+            }
+        }
+    }
+}
+
+template <int CMP, bool ZM, int HR> void launch_tiled(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
+                                                      const float *ms, const float *mt, const float *ns, const float *nt, const float *zc,
+                                                      float *cv, size_t shmem) {
+    dim3 grid(ceil_div(a.Ws, CV_TPX), a.H);
+    SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_tiled_kernel<CMP, ZM, HR>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D, sign,
+               a.disp_lower, ms, mt, ns, nt, zc, cv);
+}
+
+template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
+                                             const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv,
+                                             size_t shmem) {
+    switch (h_r) {
+    case 1: launch_tiled<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 2: launch_tiled<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 3: launch_tiled<CMP, ZM, 3>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 4: launch_tiled<CMP, ZM, 4>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 5: launch_tiled<CMP, ZM, 5>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    default: return false;
+    }
+}
+
+} // namespace
+
+// Returns SVH_OK when the tiled kernel ran, SVH_ERR_UNSUPPORTED (without touching the context error) when the caller must
+// use the generic kernel (multi-channel images, windows wider than 11, tiles beyond the LDS budget).
+int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
+    if (src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func)) return SVH_ERR_UNSUPPORTED;
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    const size_t shmem = (size_t)v * ((CV_TPX + h - 1) + (CV_TPX + h - 1 + a.D - 1)) * sizeof(float);
+    if (shmem > 60 * 1024) return SVH_ERR_UNSUPPORTED;
+    if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
+    const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
+    const int cmp = (a.func == SVH_SSD || a.func == SVH_ZSSD) ? T_SSD : (a.func == SVH_SAD || a.func == SVH_ZSAD) ? T_SAD : T_DOT;
+    const size_t ns_px = (size_t)a.H * a.Ws, nt_px = (size_t)a.H * a.Wt;
+    float *ms = nullptr, *mt = nullptr, *ns = nullptr, *nt = nullptr;
+    float *zc = scr.get_n<float>(ns_px);
+    if (!zc) return SVH_ERR_OUT_OF_MEMORY;
+    if (zm) {
+        ms = scr.get_n<float>(ns_px);
+        mt = scr.get_n<float>(nt_px);
+        if (!ms || !mt) return SVH_ERR_OUT_OF_MEMORY;
+    }
+    if (nrm) {
+        ns = scr.get_n<float>(ns_px);
+        nt = scr.get_n<float>(nt_px);
+        if (!ns || !nt) return SVH_ERR_OUT_OF_MEMORY;
+    }
+    const int gs = grid_for((int64_t)ns_px, 256, 16384), gt = grid_for((int64_t)nt_px, 256, 16384);
+#define SVH_STATS(CMPV)                                                                                                                  \
+    SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gs, 256, 0, src.data, src.H, src.W, h_r, v_r, zm, nrm, ms, ns, zc);         \
+    if (zm || nrm) SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gt, 256, 0, tgt.data, tgt.H, tgt.W, h_r, v_r, zm, nrm, mt, nt, (float *)nullptr);
+    if (cmp == T_DOT) { SVH_STATS(T_DOT) } else if (cmp == T_SSD) { SVH_STATS(T_SSD) } else { SVH_STATS(T_SAD) }
+#undef SVH_STATS
+    SVH_CHECK_LAUNCH(ctx);
+    const int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+    bool ok;
+    if (cmp == T_DOT) ok = zm ? dispatch_hr<T_DOT, true>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem)
+                              : dispatch_hr<T_DOT, false>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
+    else if (cmp == T_SSD) ok = zm ? dispatch_hr<T_SSD, true>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem)
+                                   : dispatch_hr<T_SSD, false>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
+    else ok = zm ? dispatch_hr<T_SAD, true>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem)
+                 : dispatch_hr<T_SAD, false>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
+    if (!ok) return SVH_ERR_UNSUPPORTED;
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+} // namespace svh

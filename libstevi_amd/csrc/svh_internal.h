@@ -164,6 +164,7 @@ int dev_cost_volume_from_features(svh_context *ctx, Scratch &scr, const CostVolu
                                   const float *feat_tgt, int F, float *cv);
 int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r,
                                 int v_r, float *cv);
+int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv);
 // Hamming volume from compact census words (src exact, tgt already rounded through float)
 int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *src_words, const uint32_t *tgt_words, int nWw,
                        float *cv);

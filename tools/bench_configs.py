@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Times the other BASELINE.json configurations (parity-test cases, not the headline) with per-kernel breakdown.
+    python tools/bench_configs.py [c1 c2 c3 c4 c5slice ...]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+import libstevi_amd as sv  # noqa: E402
+from helpers import parallax_pair  # noqa: E402
+
+MF, IK = sv.matchingFunctions, sv.InterpolationKernel
+CONFIGS = {
+    # name: (W, H, D, func, h_r, v_r, sgm, refine, pair recipe (side, v, h, bg, sq, seed), extra kwargs)
+    "c1": (480, 360, 64, MF.SAD, 2, 2, 0, None, (120, 120, 120, 4, 24, 1), {}),
+    "c2": (1920, 1080, 128, MF.CENSUS, 4, 4, 0, None, (320, 320, 380, 8, 64, 2), {"want_cv": True}),
+    "c3": (1920, 1080, 256, MF.CENSUS, 4, 4, 8, None, (320, 320, 380, 8, 64, 3), {}),
+    "c3mat": (1920, 1080, 256, MF.CENSUS, 4, 4, 8, None, (320, 320, 380, 8, 64, 3), {"want_cv": True, "want_sgm_cv": True}),
+    "c4": (4096, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
+    "c4small": (1024, 540, 256, MF.NCC, 5, 5, 8, IK.Parabola, (160, 160, 190, 4, 32, 4), {}),
+    "c5slice": (8192, 4320, 64, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),
+}
+
+
+def main():
+    names = sys.argv[1:] or ["c1", "c2", "c3", "c4small"]
+    dev = torch.device("cuda:0")
+    for name in names:
+        W, H, D, func, hr, vr, sgm, refine, (side, v, h, bg, sq, seed), extra = CONFIGS[name]
+        src, tgt, _ = parallax_pair(H, W, side, v, h, bg, sq, seed)
+        d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+
+        def step():
+            return sv.stereoMatch(func, d_tgt, d_src, hr, vr, D, sgmDirections=sgm, refineKernel=refine, refine_h_radius=hr, refine_v_radius=vr,
+                                  **extra)
+
+        steps = 3 if W * H * D > 1e9 else 10
+        step()
+        torch.cuda.synchronize()
+        sv.profile_reset(d_src)
+        sv.profile_enable(d_src, True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        sv.profile_enable(d_src, False)
+        prof = sv.profile_collect(d_src)
+        print(json.dumps({"config": name, "shape": [W, H, D], "func": func.name, "sgm": sgm, "ms": round(dt * 1e3, 3),
+                          "Mdisp_per_s": round(W * H * D / dt / 1e6, 1), "kernel_ms": {k: round(v[0] / steps, 3) for k, v in prof.items()},
+                          "checksum": int(out["disp"].sum().item())}), flush=True)
+        del out
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

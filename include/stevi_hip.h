@@ -99,6 +99,9 @@ int svh_device_available(void);
 /* Per-kernel timing with hipEvents on the context's stream.  While enabled, every kernel launch is
  * bracketed by two events; svh_profile_collect() synchronises and folds them into per-kernel totals. */
 int svh_profile_enable(svh_context *ctx, int enable);
+/* restrict the event bracketing to launches of one kernel (NULL or "" = every kernel): two events per launch cost a few
+ * microseconds of stream time each, which matters for sub-millisecond steps */
+int svh_profile_filter(svh_context *ctx, const char *kernel_name);
 int svh_profile_reset(svh_context *ctx);
 int svh_profile_collect(svh_context *ctx);
 int svh_profile_count(const svh_context *ctx);

@@ -22,7 +22,7 @@ F32, I32, U32, U8, U64 = 0, 1, 2, 3, 4
 EXPORTS = [
     "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_set_option", "svh_context_synchronize", "svh_context_trim",
     "svh_status_string", "svh_last_error", "svh_device_available",
-    "svh_profile_enable", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
+    "svh_profile_enable", "svh_profile_filter", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
@@ -103,6 +103,7 @@ def load():
         "svh_last_error": (C.c_char_p, [ctx]),
         "svh_device_available": (C.c_int, []),
         "svh_profile_enable": (C.c_int, [ctx, C.c_int]),
+        "svh_profile_filter": (C.c_int, [ctx, C.c_char_p]),
         "svh_profile_reset": (C.c_int, [ctx]),
         "svh_profile_collect": (C.c_int, [ctx]),
         "svh_profile_count": (C.c_int, [ctx]),

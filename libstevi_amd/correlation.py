@@ -466,8 +466,11 @@ def set_option(x, name, value):
 
 
 # ------------------------------------------------------------------------------------------------ profiling
-def profile_enable(x, on=True):
-    _capi.load().svh_profile_enable(context_for(x), 1 if on else 0)
+def profile_enable(x, on=True, only=None):
+    """hipEvents around every kernel launch (only=None) or around launches of the kernel named `only`."""
+    lib = _capi.load()
+    lib.svh_profile_filter(context_for(x), only.encode() if only else None)
+    lib.svh_profile_enable(context_for(x), 1 if on else 0)
 
 
 def profile_reset(x):

@@ -68,7 +68,7 @@ static hipEvent_t take_event(svh_context *ctx) {
 }
 
 ProfScope::ProfScope(svh_context *c, const char *n) : ctx(c), name(n) {
-    if (!ctx->profiling) return;
+    if (!ctx->profiling || (!ctx->prof_filter.empty() && ctx->prof_filter != n)) return;
     start = take_event(ctx);
     stop = take_event(ctx);
     if (!start || !stop) return;
@@ -357,6 +357,12 @@ const char *svh_last_error(const svh_context *ctx) { return ctx ? ctx->last_erro
 int svh_profile_enable(svh_context *ctx, int enable) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     ctx->profiling = enable != 0;
+    return SVH_OK;
+}
+
+int svh_profile_filter(svh_context *ctx, const char *kernel_name) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    ctx->prof_filter = kernel_name ? kernel_name : "";
     return SVH_OK;
 }
 

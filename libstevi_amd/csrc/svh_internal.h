@@ -42,6 +42,7 @@ struct svh_context {
     std::string last_error;
     std::vector<svh::PoolBlock> pool;
     bool profiling = false;
+    std::string prof_filter; // when not empty only launches of this kernel are bracketed by events
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;

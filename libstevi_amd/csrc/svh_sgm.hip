@@ -70,10 +70,16 @@ __device__ __forceinline__ bool pass_visits(int q, int ip, int jp, int Hp, int W
 
 __device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; } // false for NaN and +-inf
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+__device__ __forceinline__ float wave_min(float v) { // DPP: row_shr 1,2,4,8, row_bcast:15, row_bcast:31, result in lane 63
+#define SVH_DPP_MIN(CTRL, RM) v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x7F800000, __builtin_bit_cast(int, v), CTRL, RM, 0xF, false)))
+    SVH_DPP_MIN(0x111, 0xF);
+    SVH_DPP_MIN(0x112, 0xF);
+    SVH_DPP_MIN(0x114, 0xF);
+    SVH_DPP_MIN(0x118, 0xF);
+    SVH_DPP_MIN(0x142, 0xA);
+    SVH_DPP_MIN(0x143, 0xC);
+#undef SVH_DPP_MIN
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -146,24 +152,30 @@ __global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, LineSet l
     if (l >= ls.n_lines) return;
     const Line L = line_of(ls, l);
     float mp = 0.0f; // previous_cost[] = 0 -> min over finite = 0 (sgm.h:206-208)
-    int i = L.i0, j = L.j0;
-    for (int s0 = 0; s0 < L.len; s0 += B) {
-        float c[B][R];
-        const int nb = min(B, L.len - s0);
-        // the loads do not depend on the recurrence: issue a batch, then run the serial part
+    // The loads do not depend on the recurrence.  Two register batches: while the serial part walks batch `cur`, the
+    // loads of batch `nxt` are already in flight (a line is one wave, so nothing else hides the HBM latency).
+    float cur[B][R], nxt[B][R];
+    auto load_batch = [&](float (&c)[B][R], int s0) {
 #pragma unroll
         for (int b = 0; b < B; b++)
-            if (b < nb) src.template load<R>(i + b * L.di, j + b * L.dj, lane, c[b]);
+            if (s0 + b < L.len) src.template load<R>(L.i0 + (s0 + b) * L.di, L.j0 + (s0 + b) * L.dj, lane, c[b]);
+    };
+    auto run_batch = [&](const float (&c)[B][R], int s0) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
-            if (b < nb) {
-                const int ii = i + b * L.di, jj = j + b * L.dj;
+            if (s0 + b < L.len) {
+                const int ii = L.i0 + (s0 + b) * L.di, jj = L.j0 + (s0 + b) * L.dj;
                 if (lane == 0) mmap[(int64_t)ii * W + jj] = mp;
                 mp = wave_min(cost_step_lane_min<R>(c[b], lane, D, jj, W, Pout, mp));
             }
         }
-        i += B * L.di;
-        j += B * L.dj;
+    };
+    load_batch(cur, 0);
+    for (int s0 = 0; s0 < L.len; s0 += 2 * B) {
+        load_batch(nxt, s0 + B);
+        run_batch(cur, s0);
+        load_batch(cur, s0 + 2 * B);
+        run_batch(nxt, s0 + B);
     }
 }
 
@@ -294,16 +306,31 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
 }
 
 // ---- Score branch: read-modify-write sweep per pass ----------------------------------------------------
-__device__ __forceinline__ float lane_shift_up(float v, int lane, float fill) { // value of lane-1
-    float t = __shfl_up(v, 1);
-    return lane == 0 ? fill : t;
+// cross-lane primitives on the DPP path (no LDS round trip): whole-wave shifts by one lane and a max reduction
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float lane_shift_down(float v, int lane, float fill) { // value of lane+1
-    float t = __shfl_down(v, 1);
-    return lane == 63 ? fill : t;
+__device__ __forceinline__ float lane_shift_up(float v, float fill) { return dpp_move<0x138>(fill, v); }   // wave_shr:1 -> value of lane-1
+__device__ __forceinline__ float lane_shift_down(float v, float fill) { return dpp_move<0x130>(fill, v); } // wave_shl:1 -> value of lane+1
+// inclusive prefix maximum over the lanes (lane 63 ends up with the wave maximum): row_shr 1,2,4,8 inside each row
+// of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ float wave_prefix_max(float v) {
+    v = fmaxf(v, dpp_move<0x111>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x112>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x114>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x118>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x142, 0xA>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x143, 0xC>(-INFINITY, v));
+    return v;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_prefix_max(v)), 63));
 }
 
-template <int R, int B, bool FIRST>
+// FAR_IS_GLOBAL: P2 >= P1 >= 0.  Then fl(prev[od] - P2) <= fl(prev[od] - P1) <= prev[od] for every od (x -> fl(x - P) is
+// monotone and P >= 0), so the three disparities excluded from the |od - nd| > 1 class are each dominated by a candidate
+// that is present anyway, and max_{|od-nd|>1} (prev[od] - P2) may be replaced by max_p - P2 without changing a(nd).
+template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL>
 __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
                                                             int D, int W, float P1, float P2, float Pout, bool vec) {
     const int lane = threadIdx.x & 63;
@@ -315,20 +342,8 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
     float prev[R];
 #pragma unroll
     for (int k = 0; k < R; k++) prev[k] = 0.0f; // sgm.h:206-208
-    int i = L.i0, j = L.j0;
-    for (int s0 = 0; s0 < L.len; s0 += B) {
-        float c[B][R], s[B][R];
-        const int nb = min(B, L.len - s0);
-#pragma unroll
-        for (int b = 0; b < B; b++)
-            if (b < nb) {
-                src.template load<R>(i + b * L.di, j + b * L.dj, lane, c[b]);
-                if (!FIRST) acc.template load<R>(i + b * L.di, j + b * L.dj, lane, s[b]);
-            }
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            if (b >= nb) continue;
-            const int ii = i + b * L.di, jj = j + b * L.dj;
+    // one pixel of the line: the reference's update of the R disparities of this lane
+    auto step = [&](const float (&c)[R], const float (&sacc)[R], int ii, int jj) {
             // finite previous scores, -inf otherwise (isfinite filters of :224, :241)
             float pf[R];
             float A = -INFINITY, Ahead = -INFINITY, Atail = -INFINITY;
@@ -339,59 +354,95 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
                 if (k < R - 1) Ahead = fmaxf(Ahead, pf[k]);
                 if (k > 0) Atail = fmaxf(Atail, pf[k]);
             }
-            // inclusive prefix / suffix maxima of A over the lanes
-            float pin = A, sin_ = A;
+            float max_p, PM = -INFINITY, SM = -INFINITY, far_l0 = -INFINITY, far_rl = -INFINITY;
+            if (FAR_IS_GLOBAL) {
+                max_p = wave_max_dpp(A); // max over finite previous scores, :220-227
+            } else {
+                // inclusive prefix / suffix maxima of A over the lanes
+                const float pin = wave_prefix_max(A);
+                float sin_ = A;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                float t = __shfl_up(pin, off);
-                if (lane >= off) pin = fmaxf(pin, t);
-                float u = __shfl_down(sin_, off);
-                if (lane + off < 64) sin_ = fmaxf(sin_, u);
+                for (int off = 1; off < 64; off <<= 1) {
+                    float u = __shfl_down(sin_, off);
+                    if (lane + off < 64) sin_ = fmaxf(sin_, u);
+                }
+                max_p = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pin), 63));
+                PM = lane_shift_up(pin, -INFINITY);                       // lanes < lane
+                SM = lane_shift_down(sin_, -INFINITY);                    // lanes > lane
+                far_l0 = lane_shift_up(fmaxf(PM, Ahead), -INFINITY);      // disparities <= lane*R - 2
+                far_rl = lane_shift_down(fmaxf(SM, Atail), -INFINITY);    // disparities >= lane*R + R + 1
             }
-            const float max_p = __shfl(pin, 63);                      // max over finite previous scores, :220-227
-            const float PM = lane_shift_up(pin, lane, -INFINITY);     // lanes < lane
-            const float SM = lane_shift_down(sin_, lane, -INFINITY);  // lanes > lane
-            const float far_l0 = lane_shift_up(fmaxf(PM, Ahead), lane, -INFINITY);   // disparities <= lane*R - 2
-            const float far_rl = lane_shift_down(fmaxf(SM, Atail), lane, -INFINITY); // disparities >= lane*R + R + 1
-            const float prevL = lane_shift_up(pf[R - 1], lane, -INFINITY);           // disparity lane*R - 1
-            const float prevR = lane_shift_down(pf[0], lane, -INFINITY);             // disparity lane*R + R
+            const float prevL = lane_shift_up(pf[R - 1], -INFINITY);      // disparity lane*R - 1
+            const float prevR = lane_shift_down(pf[0], -INFINITY);        // disparity lane*R + R
             const bool maxp_fin = finite_f(max_p);
-            float act[R];
+            const float far_global = max_p - P2;
+            float outv[R];
 #pragma unroll
             for (int k = 0; k < R; k++) {
-                float fl;
-                if (k == 0) fl = far_l0;
-                else {
-                    fl = PM;
+                float far;
+                if (FAR_IS_GLOBAL) {
+                    far = far_global;
+                } else {
+                    float fl;
+                    if (k == 0) fl = far_l0;
+                    else {
+                        fl = PM;
 #pragma unroll
-                    for (int q = 0; q + 2 <= k; q++) fl = fmaxf(fl, pf[q]);
-                }
-                float fr;
-                if (k == R - 1) fr = far_rl;
-                else {
-                    fr = SM;
+                        for (int q = 0; q + 2 <= k; q++) fl = fmaxf(fl, pf[q]);
+                    }
+                    float fr;
+                    if (k == R - 1) fr = far_rl;
+                    else {
+                        fr = SM;
 #pragma unroll
-                    for (int q = k + 2; q < R; q++) fr = fmaxf(fr, pf[q]);
+                        for (int q = k + 2; q < R; q++) fr = fmaxf(fr, pf[q]);
+                    }
+                    far = fmaxf(fl, fr) - P2; // |od - nd| > 1, :239
                 }
-                const float lo = (k > 0 ? pf[k - 1] : prevL) - P1;  // |od - nd| == 1, :238
+                const float lo = (k > 0 ? pf[k - 1] : prevL) - P1; // |od - nd| == 1, :238
                 const float hi = (k < R - 1 ? pf[k + 1] : prevR) - P1;
-                const float far = fmaxf(fl, fr) - P2;                // |od - nd| > 1, :239
                 float a = fmaxf(fmaxf(pf[k], far), fmaxf(lo, hi));
                 const int d = lane * R + k;
                 if (jj + d >= W) a -= Pout; // :247-249
-                act[k] = c[b][k];
-                if (maxp_fin && finite_f(a)) act[k] = c[b][k] + (a - max_p); // :251-254
+                float act = c[k];
+                if (maxp_fin && finite_f(a)) act = c[k] + (a - max_p); // :251-254
+                const float base = FIRST ? c[k] : sacc[k];
+                outv[k] = base + (act - c[k]); // :298-300
+                prev[k] = act;
             }
             float *o = sgm + ((int64_t)ii * W + jj) * D + lane * R;
+            if constexpr (R % 4 == 0) {
+                if (vec && lane * R + R <= D) {
 #pragma unroll
-            for (int k = 0; k < R; k++) {
-                const float base = FIRST ? c[b][k] : s[b][k];
-                if (lane * R + k < D) o[k] = base + (act[k] - c[b][k]); // :298-300
-                prev[k] = act[k];
+                    for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(outv[4 * q], outv[4 * q + 1], outv[4 * q + 2], outv[4 * q + 3]);
+                    return;
+                }
             }
-        }
-        i += B * L.di;
-        j += B * L.dj;
+#pragma unroll
+            for (int k = 0; k < R; k++)
+                if (lane * R + k < D) o[k] = outv[k];
+    };
+    // two register batches: the loads of the next batch are in flight while the serial part walks the current one
+    float c0[B][R], s0v[B][R], c1[B][R], s1v[B][R];
+    auto load_batch = [&](float (&c)[B][R], float (&sv)[B][R], int st) {
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (st + b < L.len) {
+                src.template load<R>(L.i0 + (st + b) * L.di, L.j0 + (st + b) * L.dj, lane, c[b]);
+                if (!FIRST) acc.template load<R>(L.i0 + (st + b) * L.di, L.j0 + (st + b) * L.dj, lane, sv[b]);
+            }
+    };
+    auto run_batch = [&](const float (&c)[B][R], const float (&sv)[B][R], int st) {
+#pragma unroll
+        for (int b = 0; b < B; b++)
+            if (st + b < L.len) step(c[b], sv[b], L.i0 + (st + b) * L.di, L.j0 + (st + b) * L.dj);
+    };
+    load_batch(c0, s0v, 0);
+    for (int st = 0; st < L.len; st += 2 * B) {
+        load_batch(c1, s1v, st + B);
+        run_batch(c0, s0v, st);
+        load_batch(c0, s0v, st + 2 * B);
+        run_batch(c1, s1v, st + B);
     }
 }
 
@@ -475,6 +526,7 @@ static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv,
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
     const bool vec = aligned16(cv) && aligned16(sgm) && a.D % 4 == 0;
     const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0;
+    const bool far_global = a.P2 >= a.P1 && a.P1 >= 0.0f; // also false for NaN penalties
     if (!whole || Hp <= 0 || Wp <= 0) {
         // pixels outside the margin box keep sgm = cv (sgm.h:371-377)
         ProfScope prof(ctx, "sgm_copy");
@@ -484,12 +536,15 @@ static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv,
     for (int q = 0; q < n_pass; q++) {
         LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
         int grid = ceil_div(ls.n_lines, 4);
-        if (q == 0 && whole)
-            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout,
-                       vec);
-        else
-            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout,
-                       vec);
+        const bool first = q == 0 && whole;
+#define SVH_SCORE(FIRSTV, FARV)                                                                                                          \
+    SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, FIRSTV, FARV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout, vec)
+        if (far_global) {
+            if (first) SVH_SCORE(true, true); else SVH_SCORE(false, true);
+        } else {
+            if (first) SVH_SCORE(true, false); else SVH_SCORE(false, false);
+        }
+#undef SVH_SCORE
         SVH_CHECK_LAUNCH(ctx);
     }
     return SVH_OK;

@@ -277,7 +277,8 @@ __device__ __forceinline__ void col_line_rows(int q, int v, const ScanGeom &sg, 
 }
 
 __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
-                                                                   float *__restrict__ mmap) {
+                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero) {
+    if (skip_if_nonzero && *skip_if_nonzero != 0) return; // the integer-volume probe failed: the line kernels make the maps
     __shared__ float seg_a[SCAN_SEGS][64];
     __shared__ int seg_n[SCAN_SEGS][64];
     const int q = (n_pass <= 2) ? 0 : (blockIdx.y == 0 ? 0 : blockIdx.y + 1); // blockIdx.y -> pass 0, 2, 3, 4, 5
@@ -337,7 +338,9 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
 // scan_rows_kernel: pass 1 (Left2Right), one wavefront per image row, 64 consecutive pixels per step (coalesced
 // 256-byte loads and stores).  Each pixel is the affine map x -> g - x; an inclusive 6-step shuffle scan composes
 // them inside the chunk and the carry of the previous chunks enters through lane 0.
-__global__ void __launch_bounds__(256) scan_rows_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, float *__restrict__ mmap) {
+__global__ void __launch_bounds__(256) scan_rows_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, float *__restrict__ mmap,
+                                                        const int *__restrict__ skip_if_nonzero) {
+    if (skip_if_nonzero && *skip_if_nonzero != 0) return;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= sg.Hp) return;
@@ -590,7 +593,7 @@ int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, u
     return sweep_dispatch(ctx, g, a.Pout, keys, gmap);
 }
 
-int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, float *gmap, bool gmap_ready, float *mmap) {
+int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, float *gmap, bool gmap_ready, float *mmap, const int *skip_if_nonzero) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
     if (n_pass == 0) return SVH_OK;
@@ -601,9 +604,9 @@ int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, floa
     }
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
     dim3 cgrid(ceil_div(std::max(Hp, Wp), 64), n_pass == 6 ? 5 : 1), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_scan_cols", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap);
+    SVH_LAUNCH(ctx, "sgm_scan_cols", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero);
     SVH_CHECK_LAUNCH(ctx);
-    SVH_LAUNCH(ctx, "sgm_scan_rows", scan_rows_kernel, ceil_div(Hp, 4), 256, 0, gmap, sg, npx, mmap);
+    SVH_LAUNCH(ctx, "sgm_scan_rows", scan_rows_kernel, ceil_div(Hp, 4), 256, 0, gmap, sg, npx, mmap, skip_if_nonzero);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -615,7 +618,7 @@ int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a,
     if (!keys || !gmap) return SVH_ERR_OUT_OF_MEMORY;
     *keys_out = keys;
     SVH_TRY(dev_census_sweep(ctx, a, cs, keys, gmap));
-    return dev_census_scans(ctx, a, keys, gmap, true, mmap);
+    return dev_census_scans(ctx, a, keys, gmap, true, mmap, nullptr);
 }
 
 int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const uint2 *keys, const WinnerOut &win) {

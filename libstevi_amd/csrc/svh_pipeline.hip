@@ -293,7 +293,7 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
     float *mmap = scr.get_n<float>((size_t)6 * npx);
     float *gmap = scr.get_n<float>((size_t)npx);
     if (!mmap || !gmap) return SVH_ERR_OUT_OF_MEMORY;
-    SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap));
+    SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap, nullptr));
     CostSource cs;
     cs.nWw = s.nWw;
     cs.Wt = s.Wt;

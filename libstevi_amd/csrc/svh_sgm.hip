@@ -146,7 +146,8 @@ __device__ __forceinline__ float cost_step_lane_min(const float (&c)[R], int lan
 
 template <class SRC, int R, int B>
 __global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, LineSet ls, int D, int W, float Pout,
-                                                             float *__restrict__ mmap) {
+                                                             float *__restrict__ mmap, const int *__restrict__ run_if_nonzero) {
+    if (run_if_nonzero && *run_if_nonzero == 0) return; // the exact-integer route already produced the maps
     const int lane = threadIdx.x & 63;
     const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (l >= ls.n_lines) return;
@@ -239,6 +240,7 @@ __device__ __forceinline__ unsigned long long winner_key(Winner w, bool first_is
 struct ApplyOut {
     float *sgm; // (H, W, D) or nullptr
     WinnerOut w;
+    bool vec_store; // sgm rows 16-byte aligned, D % 4 == 0
 };
 
 template <class SRC, int R>
@@ -273,9 +275,19 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
         }
         if (out.sgm) {
             float *o = out.sgm + p * D + lane * R;
+            bool stored = false;
+            if constexpr (R % 4 == 0) {
+                if (out.vec_store && lane * R + R <= D) {
 #pragma unroll
-            for (int k = 0; k < R; k++)
-                if (lane * R + k < D) o[k] = s[k];
+                    for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
+                    stored = true;
+                }
+            }
+            if (!stored) {
+#pragma unroll
+                for (int k = 0; k < R; k++)
+                    if (lane * R + k < D) o[k] = s[k];
+            }
         }
         const WinnerOut &wo = out.w;
         if (wo.idx || wo.disp || wo.taps || wo.keys) {
@@ -303,6 +315,39 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
             }
         }
     }
+}
+
+// Integer-volume probe.  A float cost volume whose values are all small integers (a Hamming volume handed to the
+// per-function API, say) is in the same exact regime as the census path: every operation of sgm.h:257-300 is exact,
+// the per-pass minima follow mp' = g - mp, and six wave-per-line sweeps of the volume collapse into this one read.
+// The kernel writes g(p) = min_d [c + (c [+ Pout])] and raises `flag` as soon as one value is not an integer in
+// [-limit, limit]; the scan kernels run only if the flag stayed 0 and the line kernels only if it was raised, so no host
+// round trip is needed.
+template <int R>
+__global__ void __launch_bounds__(256) volume_gmin_probe_kernel(SrcVolume src, int64_t npx, int D, int W, float Pout, float limit,
+                                                               float *__restrict__ gmap, int *__restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    bool bad = false;
+    for (int64_t p = wave; p < npx; p += nwaves) {
+        const int j = (int)(p % W), i = (int)(p / W);
+        float c[R];
+        src.template load<R>(i, j, lane, c);
+        float m = INFINITY;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int d = lane * R + k;
+            if (d < D) {
+                bad = bad || !(fabsf(c[k]) <= limit) || c[k] != rintf(c[k]);
+                const float t = (j + d >= W) ? c[k] + Pout : c[k];
+                m = fminf(m, c[k] + t);
+            }
+        }
+        m = wave_min(m);
+        if (lane == 0) gmap[p] = m;
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
 // ---- Score branch: read-modify-write sweep per pass ----------------------------------------------------
@@ -459,7 +504,8 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 // phase 1: the per-pass min_p maps (the sequential part); phase 2: rebuild S / pick the winner per pixel
 template <class SRC, int R>
-static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps) {
+static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
+                           const int *gate = nullptr) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
     constexpr int B = (R <= 4) ? 8 : (R == 8 ? 4 : 2);
@@ -467,7 +513,7 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
         for (int q = 0; q < n_pass; q++) {
             LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
             SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), ceil_div(ls.n_lines, 4), 256, 0, src, ls, a.D, a.W,
-                       a.Pout, mmap + (size_t)q * a.H * a.W);
+                       a.Pout, mmap + (size_t)q * a.H * a.W, gate);
             SVH_CHECK_LAUNCH(ctx);
         }
     }
@@ -482,13 +528,14 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
 }
 
 template <class SRC>
-static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps) {
+static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
+                                const int *gate = nullptr) {
     switch (pick_R(a.D)) {
-    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps);
-    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps);
-    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps);
-    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps);
-    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps);
+    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate);
+    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate);
+    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate);
+    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate);
+    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate);
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
     }
 }
@@ -497,10 +544,35 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
     float *mmap = scr.get_n<float>((size_t)6 * a.H * a.W);
     if (!mmap) return SVH_ERR_OUT_OF_MEMORY;
-    ApplyOut out{out_sgm, win};
+    ApplyOut out{out_sgm, win, out_sgm && aligned16(out_sgm) && a.D % 4 == 0};
     if (cs.cv) {
         SrcVolume src{cs.cv, a.W, a.D, aligned16(cs.cv) && a.D % 4 == 0};
-        return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
+        const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+        const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0);
+        // largest |c| for which 8 (2 |c| + |Pout|) (L + 2) stays below 2^24 (same bound as census_exact_regime)
+        const double L = (double)std::max(a.H, a.W);
+        const double limit = std::floor((16777216.0 / (8.0 * (L + 2.0)) - std::fabs((double)a.Pout)) / 2.0) - 1.0;
+        const bool try_exact = ctx->census_fast_path && n_pass > 0 && Hp > 0 && Wp > 0 && std::isfinite(a.Pout) &&
+                               a.Pout == std::nearbyint(a.Pout) && limit >= 1.0 && a.D <= 1024;
+        if (!try_exact) return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
+        const int64_t npx = (int64_t)a.H * a.W;
+        float *gmap = scr.get_n<float>((size_t)npx);
+        int *flag = scr.get_n<int>(64);
+        if (!gmap || !flag) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+        const int grid = grid_for(npx, 4, 256 * 8 * 4);
+#define SVH_PROBE(RV) SVH_LAUNCH(ctx, "sgm_volume_probe", volume_gmin_probe_kernel<RV>, grid, 256, 0, src, npx, a.D, a.W, a.Pout, (float)limit, gmap, flag)
+        switch (pick_R(a.D)) {
+        case 1: SVH_PROBE(1); break;
+        case 2: SVH_PROBE(2); break;
+        case 4: SVH_PROBE(4); break;
+        case 8: SVH_PROBE(8); break;
+        default: SVH_PROBE(16); break;
+        }
+#undef SVH_PROBE
+        SVH_CHECK_LAUNCH(ctx);
+        SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, flag)); // run only while the flag is 0
+        return dispatch_cost_branch(ctx, a, src, mmap, &out, true, flag);   // line kernels run only if it was raised
     }
     SrcCensus src{cs.src_words, cs.tgt_words, cs.nWw, a.W, cs.Wt, cs.sign, cs.disp_lower, a.D};
     // census specialisation (svh_census_sgm.hip): pixel-per-lane kernels.  In the integer-exact regime one sweep

@@ -382,3 +382,27 @@ def test_census_shards_equal_single_gpu(ddir):
     with pytest.raises(SvhError) as e:  # non-integer Pout leaves the exact regime: the disparity axis no longer shards
         sv.censusShardKeys(dev(tgt), dev(src), 4, 4, D, (0, 100), Pout=2.5)
     assert e.value.status == ERR_UNSUPPORTED
+
+
+def test_sgm_integer_volume_routes_agree(rng):
+    """svh_sgm_cost_volume on an integer-valued float volume takes the probe + scan route; it must equal the
+    wave-per-line route (option off) and the oracle bit for bit, also when a single voxel breaks integrality."""
+    cv = rng.integers(0, 65, (23, 31, 70)).astype(np.float32)
+    for breaker in (None, (5, 7, 3, 0.5), (0, 0, 0, np.inf), (22, 30, 69, 1e6)):
+        v = cv.copy()
+        if breaker is not None:
+            v[breaker[0], breaker[1], breaker[2]] = breaker[3]
+        d = dev(v)
+        for margins, Pout in (((0, 0, 0, 0), 100.0), ((2, 1, 0, 3), 7.0)):
+            exp = so.sgm(v, 8, so.COST, 0.3, 0.9, margins, Pout)
+            try:
+                sv.set_option(d, "census_fast_path", 1)
+                a = host(sv.sgmCostVolume(8, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout))
+                sv.set_option(d, "census_fast_path", 0)
+                b = host(sv.sgmCostVolume(8, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout))
+            finally:
+                sv.set_option(d, "census_fast_path", 1)
+            for got in (a, b):
+                assert np.array_equal(np.isnan(got), np.isnan(exp))
+                ok = ~np.isnan(exp)
+                assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))

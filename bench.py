@@ -156,7 +156,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up with hipEvents around EVERY kernel: per-kernel breakdown and the dominant kernel of the step
+    # one cold step (first-touch allocations), then warm-up with hipEvents around EVERY kernel: per-kernel breakdown
+    # and the dominant kernel of the step
+    step()
     sv.profile_reset(d_src)
     sv.profile_enable(d_src, True)
     for _ in range(max(args.warmup, 1)):

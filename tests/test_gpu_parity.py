@@ -406,3 +406,51 @@ def test_sgm_integer_volume_routes_agree(rng):
                 assert np.array_equal(np.isnan(got), np.isnan(exp))
                 ok = ~np.isnan(exp)
                 assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------------ randomised sweep
+def test_random_configurations_against_oracle():
+    """Seeded random shapes / windows / ranges / margins / penalties through the fused pipeline and the per-function
+    entry points: odd sizes, images narrower than a block, D > W, negative first offsets, both directions."""
+    r = np.random.default_rng(20260401)
+    funcs = [MF.CENSUS, MF.CENSUS, MF.CENSUS, MF.SAD, MF.ZNCC, MF.SSD, MF.NCC]
+    for case in range(28):
+        H, W = int(r.integers(1, 40)), int(r.integers(2, 300))
+        D = int(r.integers(1, 90)) if case % 3 else int(r.integers(90, 330))
+        func = funcs[case % len(funcs)]
+        h_r, v_r = (int(r.integers(3, 6)), int(r.integers(3, 6))) if func == MF.CENSUS else (int(r.integers(1, 4)), int(r.integers(0, 4)))
+        if func == MF.CENSUS and case % 5 == 0:
+            h_r, v_r = int(r.integers(0, 3)), int(r.integers(1, 3))  # windows with no fully written word at all
+            if (2 * h_r + 1) * (2 * v_r + 1) <= 1:
+                v_r = 1
+        n_dir = int(r.choice([0, 4, 8, 8]))
+        lower = int(r.integers(-5, 6)) if case % 4 == 0 else 0
+        ddir = int(r.integers(0, 2))
+        margins = tuple(int(x) for x in r.integers(0, 3, 4)) if case % 2 else (0, 0, 0, 0)
+        Pout = float(r.choice([100.0, 7.0, 0.0, 2.5, -3.0]))
+        P1, P2 = float(r.uniform(0, 2)), float(r.uniform(0, 4))
+        left = r.uniform(-1, 1, (H, W)).astype(np.float32)
+        right = r.uniform(-1, 1, (H, W)).astype(np.float32)
+        strategy = so.func_strategy(int(func))
+        cv = so.unfold_cost_volume(int(func), left, right, h_r, v_r, D, ddir, lower)
+        rng_arg = D if lower == 0 else sv.searchOffset1(lower, lower + D - 1)
+        res = sv.stereoMatch(func, dev(left), dev(right), h_r, v_r, rng_arg, dDir=ddir, sgmDirections=n_dir, P1=P1, P2=P2, Pout=Pout,
+                             margins=sv.Margins(*margins), want_cv=True, want_sgm_cv=bool(n_dir))
+        tag = f"case {case}: {func.name} {H}x{W}xD{D} win {h_r},{v_r} dirs {n_dir} lower {lower} ddir {ddir} margins {margins} Pout {Pout}"
+        gcv = host(res["cv"])
+        if func == MF.CENSUS:
+            assert np.array_equal(gcv, cv), tag
+        else:
+            assert_close(gcv, cv)
+        vol = so.sgm(gcv, n_dir, strategy, P1, P2, margins, Pout) if n_dir else gcv
+        if n_dir:
+            gvol = host(res["sgm_cv"])
+            assert np.array_equal(np.isnan(gvol), np.isnan(vol)), tag
+            ok = ~np.isnan(vol)
+            assert np.array_equal(gvol[ok].view(np.uint32), vol[ok].view(np.uint32)), tag
+        idx = so.extract_index(vol, strategy)
+        assert np.array_equal(host(res["disp"]), so.index_to_disp(idx, ddir, (1 if ddir == so.RIGHT_TO_LEFT else -1) * lower)), tag
+        # the lean call (no volumes) takes the pixel-per-lane kernels for census
+        lean = sv.stereoMatch(func, dev(left), dev(right), h_r, v_r, rng_arg, dDir=ddir, sgmDirections=n_dir, P1=P1, P2=P2, Pout=Pout,
+                              margins=sv.Margins(*margins))
+        assert np.array_equal(host(lean["disp"]), host(res["disp"])), tag

@@ -302,3 +302,107 @@ def test_refine_kernels():
     tcv = np.array([[[np.nan, 1, 2], [1, 1, 1]]], np.float32)
     out = so.refine_disp(tcv, np.array([[4, 2]], np.int32))
     assert math.isnan(out[0, 0]) and math.isnan(out[0, 1])  # 0/0
+
+
+# ------------------------------------------------- second, independent restatement of sgm.h in pure Python ---------------------
+def py_sgm(cv, n_dir, strategy, P1, P2, margins, Pout):
+    """sgm.h:186-404 line by line with numpy float32 scalars (no shortcuts: the O(D^2) double loop, the start-position
+    rule of :329-354 including the 'EndPos' starts that fall outside the loop guard)."""
+    f = np.float32
+    H, W, D = cv.shape
+    left, top, right, bottom = margins
+    P1, P2, Pout = f(P1), f(P2), f(Pout)
+    steps = {  # directionTraits, :61-155: (stepsVertical, stepsHorizontal)
+        "Up2Down": ((1, 1), (0, 0)), "Down2Up": ((-1, -1), (0, 0)), "Left2Right": ((0, 0), (1, 1)), "Right2Left": ((0, 0), (-1, -1)),
+        "UpLeft2DownRight": ((1, 1), (1, 1)), "DownRight2UpLeft": ((-1, -1), (-1, -1)), "UpRight2DownLeft": ((1, 1), (-1, -1)),
+        "DownLeft2UpRight": ((-1, -1), (1, 1)),
+    }
+
+    def start_pos(s):  # startPostInfos, :162-184
+        if s[0] == 0 and s[1] == 0:
+            return "NoStart"
+        if s[0] >= 0 and s[1] >= 0:
+            return "ZeroPos"
+        return "EndPos"
+
+    sgm = cv.copy()
+
+    def traverse(name, start_i, start_j):
+        sv_, sh_ = steps[name]
+        prev = np.zeros(D, np.float32)
+        c, i, j = 0, start_i, start_j
+        while top <= i < H - bottom and left <= j < W - right:
+            act = np.zeros(D, np.float32)
+            fin = np.isfinite(prev)
+            if strategy == so.SCORE:
+                max_p = prev[fin].max() if fin.any() else f(-np.inf)
+                for nd in range(D):
+                    max_a = f(-np.inf)
+                    for od in range(D):
+                        p = prev[od]
+                        if abs(od - nd) == 1:
+                            p = f(p - P1)
+                        if abs(od - nd) > 1:
+                            p = f(p - P2)
+                        if p > max_a and np.isfinite(p):
+                            max_a = p
+                    if j + nd >= W:
+                        max_a = f(max_a - Pout)
+                    act[nd] = cv[i, j, nd]
+                    if np.isfinite(max_a) and np.isfinite(max_p):
+                        act[nd] = f(act[nd] + f(max_a - max_p))
+            else:
+                min_p = prev[fin].min() if fin.any() else f(np.inf)
+                for nd in range(D):
+                    min_a = f(np.inf)
+                    c_score = cv[i, j, nd]
+                    for od in range(D):
+                        p = prev[od]
+                        if abs(od - nd) == 1:
+                            p = f(p + P1)
+                        if abs(od - nd) > 1:
+                            p = f(p + P2)
+                        if p < min_a and np.isfinite(p):
+                            min_a = c_score  # sic, sgm.h:281-283
+                    if j + nd >= W:
+                        min_a = f(min_a + Pout)
+                    act[nd] = c_score
+                    if np.isfinite(min_a) and np.isfinite(min_p):
+                        act[nd] = f(act[nd] + f(min_a - min_p))
+            sgm[i, j, :] = (sgm[i, j, :] + (act - cv[i, j, :])).astype(np.float32)
+            prev = act
+            i += sv_[c % 2]
+            j += sh_[c % 2]
+            c += 1
+
+    def add_direction(name):  # addDirectionalCost, :313-356
+        sv_, sh_ = steps[name]
+        col_start, row_start = start_pos(sv_), start_pos(sh_)
+        if row_start != "NoStart":
+            start_j = left if row_start == "ZeroPos" else W - right
+            for start_i in range(top, H - bottom):
+                traverse(name, start_i, start_j)
+        if col_start != "NoStart":
+            start_i = top if col_start == "ZeroPos" else H - bottom
+            for start_j in range(left, W - right):
+                traverse(name, start_i, start_j)
+
+    with np.errstate(invalid="ignore", over="ignore"):
+        for name in ("Up2Down", "Down2Up", "Left2Right", "Right2Left"):
+            add_direction(name)
+        if n_dir >= 8:
+            for name in ("UpLeft2DownRight", "DownRight2UpLeft", "UpRight2DownLeft", "DownLeft2UpRight"):
+                add_direction(name)
+    return sgm
+
+
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+@pytest.mark.parametrize("n_dir,margins", [(8, (0, 0, 0, 0)), (8, (1, 0, 2, 1)), (4, (0, 0, 0, 0))])
+def test_oracle_sgm_equals_python_restatement(rng, strategy, n_dir, margins):
+    for shape, integer in (((5, 7, 4), True), ((6, 5, 5), False), ((4, 4, 3), False)):
+        cv = (rng.integers(0, 20, shape) if integer else rng.uniform(-1, 1, shape)).astype(np.float32)
+        for P1, P2, Pout in ((0.001, 0.01, 100.0), (3.0, 1.0, 0.5)):
+            exp = py_sgm(cv, n_dir, strategy, P1, P2, margins, Pout)
+            for variant in (0, 1):
+                got = so.sgm(cv, n_dir, strategy, P1, P2, margins, Pout, variant=variant)
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))

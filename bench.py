@@ -48,8 +48,7 @@ def algorithmic_bytes(kernel, wl):
     table = {
         "census_sweep": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
-        "sgm_scan_cols": 4.0 * px + 5 * 4.0 * px,    # g read + five min_p maps written
-        "sgm_scan_rows": 4.0 * px + 4.0 * px,
+        "sgm_line_scans": 4.0 * px + 6 * 4.0 * px,   # g read + six min_p maps written
         "census_finalize": (8.0 + 24.0 + 4.0) * px,  # keys + six min_p maps + disparity
     }
     return table.get(kernel)

@@ -159,10 +159,22 @@ template <int NW> __device__ __forceinline__ int hamming_words(const Words<NW> &
 template <int NW> __device__ __forceinline__ void stage_target_window2(const CensusGeom &g, int i, int j0, uint32_t *lds, int n_rec) {
     if constexpr (NW > 0) {
         const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
-        for (int e = threadIdx.x; e < n_rec * NW; e += TJ) {
-            const int y = e / NW, w = e - y * NW;
-            const int jt = g.sign > 0 ? j0 + g.disp_lower + y : j0 + (PX - 1) - g.disp_lower - y;
-            lds[e] = (jt >= 0 && jt < g.Wt && y < PX + g.D - 1) ? trow[(int64_t)jt * NW + w] : 0u;
+        const int n = n_rec * NW;
+        constexpr int CH = 8; // loads in flight per thread before the first LDS write
+        for (int e0 = threadIdx.x; e0 < n; e0 += CH * TJ) {
+            uint32_t v[CH];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int e = e0 + c * TJ;
+                const int y = e / NW, w = e - y * NW;
+                const int jt = g.sign > 0 ? j0 + g.disp_lower + y : j0 + (PX - 1) - g.disp_lower - y;
+                v[c] = (e < n && jt >= 0 && jt < g.Wt && y < PX + g.D - 1) ? trow[(int64_t)jt * NW + w] : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int e = e0 + c * TJ;
+                if (e < n) lds[e] = v[c];
+            }
         }
     }
 }
@@ -276,9 +288,16 @@ __device__ __forceinline__ void col_line_rows(int q, int v, const ScanGeom &sg, 
     }
 }
 
+__device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
+                                             int lane);
+
 __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
                                                                    float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero) {
     if (skip_if_nonzero && *skip_if_nonzero != 0) return; // the integer-volume probe failed: the line kernels make the maps
+    if ((int)blockIdx.y == (n_pass <= 2 ? 1 : 5)) { // last slice of the grid: pass 1, one wave per row
+        scan_one_row(gmap, sg, npx, mmap, blockIdx.x * SCAN_SEGS + threadIdx.y, threadIdx.x);
+        return;
+    }
     __shared__ float seg_a[SCAN_SEGS][64];
     __shared__ int seg_n[SCAN_SEGS][64];
     const int q = (n_pass <= 2) ? 0 : (blockIdx.y == 0 ? 0 : blockIdx.y + 1); // blockIdx.y -> pass 0, 2, 3, 4, 5
@@ -335,14 +354,11 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     }
 }
 
-// scan_rows_kernel: pass 1 (Left2Right), one wavefront per image row, 64 consecutive pixels per step (coalesced
+// scan_one_row: pass 1 (Left2Right), run by the last grid slice of scan_cols_kernel; one wavefront per image row, 64 consecutive pixels per step (coalesced
 // 256-byte loads and stores).  Each pixel is the affine map x -> g - x; an inclusive 6-step shuffle scan composes
 // them inside the chunk and the carry of the previous chunks enters through lane 0.
-__global__ void __launch_bounds__(256) scan_rows_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, float *__restrict__ mmap,
-                                                        const int *__restrict__ skip_if_nonzero) {
-    if (skip_if_nonzero && *skip_if_nonzero != 0) return;
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+__device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
+                                             int lane) {
     if (row >= sg.Hp) return;
     const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left;
     float *out = mmap + npx; // pass 1
@@ -603,10 +619,9 @@ int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, floa
         SVH_CHECK_LAUNCH(ctx);
     }
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
-    dim3 cgrid(ceil_div(std::max(Hp, Wp), 64), n_pass == 6 ? 5 : 1), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_scan_cols", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero);
-    SVH_CHECK_LAUNCH(ctx);
-    SVH_LAUNCH(ctx, "sgm_scan_rows", scan_rows_kernel, ceil_div(Hp, 4), 256, 0, gmap, sg, npx, mmap, skip_if_nonzero);
+    // one launch: grid slices 0..4 (or 0) are the passes that cross the rows, the last slice is pass 1 (one wave per row)
+    dim3 cgrid(std::max(ceil_div(std::max(Hp, Wp), 64), ceil_div(Hp, SCAN_SEGS)), (n_pass == 6 ? 5 : 1) + 1), cblock(64, SCAN_SEGS);
+    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

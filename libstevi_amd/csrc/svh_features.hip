@@ -125,14 +125,26 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(const float *__r
     constexpr int NWRITTEN = (h * v - 1) / 32;
     __shared__ float tile[v * TW];
     const int i = blockIdx.y, j0 = blockIdx.x * CENSUS_TJ, tj = threadIdx.x, j = j0 + tj;
+    // stage the tile: every load of the thread is issued before the first LDS write, so a block pays one memory latency
+    constexpr int PER_ROW = (TW + CENSUS_TJ - 1) / CENSUS_TJ;
+    float r[v][PER_ROW];
 #pragma unroll
     for (int k = 0; k < v; k++) {
         const int ii = i - pt + k;
         const bool row_in = ii >= 0 && ii < H;
         const float *row = img + (int64_t)ii * W;
-        for (int e = tj; e < TW; e += CENSUS_TJ) {
-            const int jj = j0 - pl + e;
-            tile[k * TW + e] = (row_in && jj >= 0 && jj < W) ? row[jj] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < PER_ROW; q++) {
+            const int e = tj + q * CENSUS_TJ, jj = j0 - pl + e;
+            r[k][q] = (row_in && e < TW && jj >= 0 && jj < W) ? row[jj] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < v; k++) {
+#pragma unroll
+        for (int q = 0; q < PER_ROW; q++) {
+            const int e = tj + q * CENSUS_TJ;
+            if (e < TW) tile[k * TW + e] = r[k][q];
         }
     }
     __syncthreads();

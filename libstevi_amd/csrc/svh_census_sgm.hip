@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Po
     const int d_off = g.d_offset, D = g.D;
     // region limits: a pixel pays Pout for d >= dsplit = W - j - d_off.  Over the 128 pixels of this wave the split moves
     // by 127, so d < lo is "nobody pays" and d >= hi "everybody pays", both wave uniform.
-    const int wave_j0 = j0 + 2 * (t & ~63);
+    const int wave_j0 = __builtin_amdgcn_readfirstlane(j0 + 2 * (t & ~63)); // first pixel of this wave (SGPR: scalar branches below)
     const int lo = min(max(g.Ws - d_off - (wave_j0 + 127), 0), D), hi = min(max(g.Ws - d_off - wave_j0, 0), D);
     const int splitE = min(max(g.Ws - d_off - jE, 0), D), splitO = min(max(g.Ws - d_off - jO, 0), D);
     uint32_t kE0 = KEY_NONE, kE1 = KEY_NONE, kO0 = KEY_NONE, kO1 = KEY_NONE;

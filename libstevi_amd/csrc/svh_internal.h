@@ -71,7 +71,8 @@ int fail(svh_context *ctx, int status, const char *fmt, ...);
 // RAII over pool blocks taken during one API call
 class Scratch {
   public:
-    explicit Scratch(svh_context *c) : ctx(c) {}
+    // every API call builds one Scratch first: also the place where the context's device is made current
+    explicit Scratch(svh_context *c) : ctx(c) { (void)hipSetDevice(c->device); }
     ~Scratch();
     // returns nullptr (and sets the context error) on failure
     void *get(size_t bytes);

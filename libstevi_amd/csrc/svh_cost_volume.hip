@@ -295,8 +295,7 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
         uint32_t *sw = scr.get_n<uint32_t>((size_t)a.H * a.Ws * (nWw ? nWw : 1));
         uint32_t *tw = scr.get_n<uint32_t>((size_t)a.H * a.Wt * (nWw ? nWw : 1));
         if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
-        SVH_TRY(dev_census_from_image(ctx, src, h_r, v_r, h_r, v_r, a.H, a.Ws, nWw, false, sw));
-        SVH_TRY(dev_census_from_image(ctx, tgt, h_r, v_r, h_r, v_r, a.H, a.Wt, nWw, true, tw));
+        SVH_TRY(dev_census_pair_compact(ctx, src, tgt, h_r, v_r, nWw, sw, tw));
         return dev_hamming_volume(ctx, a, sw, tw, nWw, cv);
     }
     // grey images with windows up to 11x11: LDS-tiled, register-blocked kernel (svh_cost_volume_tiled.hip)

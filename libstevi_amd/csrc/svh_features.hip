@@ -118,9 +118,21 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_image_tiled_kernel(const flo
 
 // Grey images with a compile-time window (the common 7x7 / 9x9 / 11x11 cases): the window walk is fully unrolled, every
 // LDS read has an immediate offset, and the word boundaries are known at compile time.
+struct CensusJob { // one image of a launch (blockIdx.z selects): both images of a stereo pair go in one launch
+    const float *img;
+    int H, W, Ho, Wo;
+    bool round_target;
+    uint32_t *words;
+};
+
 template <int HR, int VR>
-__global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(const float *__restrict__ img, int H, int W, int pl, int pt, int Ho, int Wo,
-                                                                int n_out, bool round_target, uint32_t *__restrict__ words) {
+__global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(CensusJob job0, CensusJob job1, int pl, int pt, int n_out) {
+    const CensusJob &job = blockIdx.z == 0 ? job0 : job1;
+    const float *__restrict__ img = job.img;
+    uint32_t *__restrict__ words = job.words;
+    const int H = job.H, W = job.W, Ho = job.Ho, Wo = job.Wo;
+    const bool round_target = job.round_target;
+    if ((int)blockIdx.y >= Ho || (int)blockIdx.x * CENSUS_TJ >= Wo) return; // the grid covers the larger image
     constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TW = CENSUS_TJ + h - 1;
     constexpr int NWRITTEN = (h * v - 1) / 32;
     __shared__ float tile[v * TW];
@@ -167,10 +179,19 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(const float *__r
 }
 
 template <int HR, int VR>
-static void launch_census_grey(svh_context *ctx, ImageDesc img, int pl, int pt, int Ho, int Wo, int n_out, bool round_target, uint32_t *words) {
-    dim3 grid(ceil_div(Wo, CENSUS_TJ), Ho);
-    SVH_LAUNCH(ctx, "census_transform", (census_grey_kernel<HR, VR>), grid, CENSUS_TJ, 0, img.data, img.H, img.W, pl, pt, Ho, Wo, n_out,
-               round_target, words);
+static void launch_census_grey(svh_context *ctx, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {
+    dim3 grid(ceil_div(std::max(a.Wo, b ? b->Wo : 0), CENSUS_TJ), std::max(a.Ho, b ? b->Ho : 0), b ? 2 : 1);
+    SVH_LAUNCH(ctx, "census_transform", (census_grey_kernel<HR, VR>), grid, CENSUS_TJ, 0, a, b ? *b : a, pl, pt, n_out);
+}
+
+static bool census_grey_dispatch(svh_context *ctx, int h_r, int v_r, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {
+    if (h_r != v_r) return false;
+    switch (h_r) {
+    case 3: launch_census_grey<3, 3>(ctx, a, b, pl, pt, n_out); return true;
+    case 4: launch_census_grey<4, 4>(ctx, a, b, pl, pt, n_out); return true;
+    case 5: launch_census_grey<5, 5>(ctx, a, b, pl, pt, n_out); return true;
+    default: return false;
+    }
 }
 
 __global__ void census_features_kernel(const float *__restrict__ feat, int64_t npx, int F, int n_out, int n_written,
@@ -202,12 +223,12 @@ int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int
     int64_t npx = (int64_t)Ho * Wo;
     if (npx == 0 || n_out == 0) return SVH_OK;
     int F = (2 * h_r + 1) * (2 * v_r + 1) * img.C;
-    if (img.C == 1 && h_r == v_r && (h_r == 3 || h_r == 4 || h_r == 5)) {
-        if (h_r == 3) launch_census_grey<3, 3>(ctx, img, pl, pt, Ho, Wo, n_out, round_through_float, words);
-        else if (h_r == 4) launch_census_grey<4, 4>(ctx, img, pl, pt, Ho, Wo, n_out, round_through_float, words);
-        else launch_census_grey<5, 5>(ctx, img, pl, pt, Ho, Wo, n_out, round_through_float, words);
-        SVH_CHECK_LAUNCH(ctx);
-        return SVH_OK;
+    if (img.C == 1) {
+        CensusJob job{img.data, img.H, img.W, Ho, Wo, round_through_float, words};
+        if (census_grey_dispatch(ctx, h_r, v_r, job, nullptr, pl, pt, n_out)) {
+            SVH_CHECK_LAUNCH(ctx);
+            return SVH_OK;
+        }
     }
     const size_t tile_bytes = (size_t)(2 * v_r + 1) * (CENSUS_TJ + 2 * h_r) * img.C * sizeof(float);
     if (tile_bytes <= 60 * 1024 && census_words_written(F) > 0) {
@@ -221,6 +242,21 @@ int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int
                v_r, pl, pt, Ho, Wo, n_out, census_words_written(F), round_through_float, words);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
+}
+
+// compact words of both images of a pair (source exact, target rounded through float: rule E2), auto padding; one launch
+// for the common grey windows
+int dev_census_pair_compact(svh_context *ctx, ImageDesc src, ImageDesc tgt, int h_r, int v_r, int nWw, uint32_t *sw, uint32_t *tw) {
+    if (nWw == 0) return SVH_OK;
+    if (src.C == 1 && tgt.C == 1) {
+        CensusJob a{src.data, src.H, src.W, src.H, src.W, false, sw}, b{tgt.data, tgt.H, tgt.W, tgt.H, tgt.W, true, tw};
+        if (census_grey_dispatch(ctx, h_r, v_r, a, &b, h_r, v_r, nWw)) {
+            SVH_CHECK_LAUNCH(ctx);
+            return SVH_OK;
+        }
+    }
+    SVH_TRY(dev_census_from_image(ctx, src, h_r, v_r, h_r, v_r, src.H, src.W, nWw, false, sw));
+    return dev_census_from_image(ctx, tgt, h_r, v_r, h_r, v_r, tgt.H, tgt.W, nWw, true, tw);
 }
 
 int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, int F, int n_out, bool round_through_float,

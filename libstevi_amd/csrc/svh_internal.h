@@ -153,6 +153,7 @@ int dev_unfold(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt
 // round_through_float applies rule E2 (target side of aggregateCost) to every word.
 int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt, int Ho, int Wo, int n_out,
                           bool round_through_float, uint32_t *words);
+int dev_census_pair_compact(svh_context *ctx, ImageDesc src, ImageDesc tgt, int h_r, int v_r, int nWw, uint32_t *sw, uint32_t *tw);
 int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, int F, int n_out, bool round_through_float,
                              uint32_t *words);
 

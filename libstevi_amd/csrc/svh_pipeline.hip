@@ -121,8 +121,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
         uint32_t *sw = scr.get_n<uint32_t>((size_t)H * Ws * (nWw ? nWw : 1));
         uint32_t *tw = scr.get_n<uint32_t>((size_t)H * Wt * (nWw ? nWw : 1));
         if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
-        SVH_TRY(dev_census_from_image(ctx, isrc, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, H, Ws, nWw, false, sw));
-        SVH_TRY(dev_census_from_image(ctx, itgt, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, H, Wt, nWw, true, tw));
+        SVH_TRY(dev_census_pair_compact(ctx, isrc, itgt, prm->h_radius, prm->v_radius, nWw, sw, tw));
         if (cv) SVH_TRY(dev_hamming_volume(ctx, cva, sw, tw, nWw, (float *)o_cv.dptr));
         if (win.any() || sgm_cv) {
             // Cost branch with the Hamming cost evaluated on the fly; sgm_directions == 0 degenerates to S = C

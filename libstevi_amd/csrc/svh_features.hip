@@ -132,11 +132,12 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(CensusJob job0, 
     uint32_t *__restrict__ words = job.words;
     const int H = job.H, W = job.W, Ho = job.Ho, Wo = job.Wo;
     const bool round_target = job.round_target;
-    if ((int)blockIdx.y >= Ho || (int)blockIdx.x * CENSUS_TJ >= Wo) return; // the grid covers the larger image
-    constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TW = CENSUS_TJ + h - 1;
+    constexpr int PXB = 2 * CENSUS_TJ; // two neighbouring pixels per lane
+    if ((int)blockIdx.y >= Ho || (int)blockIdx.x * PXB >= Wo) return; // the grid covers the larger image
+    constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TW = PXB + h + 1; // row pitch even: float2 reads stay 8-byte aligned
     constexpr int NWRITTEN = (h * v - 1) / 32;
-    __shared__ float tile[v * TW];
-    const int i = blockIdx.y, j0 = blockIdx.x * CENSUS_TJ, tj = threadIdx.x, j = j0 + tj;
+    __shared__ __attribute__((aligned(16))) float tile[v * TW];
+    const int i = blockIdx.y, j0 = blockIdx.x * PXB, tj = threadIdx.x;
     // stage the tile: every load of the thread is issued before the first LDS write, so a block pays one memory latency
     constexpr int PER_ROW = (TW + CENSUS_TJ - 1) / CENSUS_TJ;
     float r[v][PER_ROW];
@@ -160,27 +161,47 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(CensusJob job0, 
         }
     }
     __syncthreads();
-    if (j >= Wo) return;
-    const float *tp = tile + tj;
-    const float ref = tp[0];
-    uint32_t *o = words + ((int64_t)i * Wo + j) * n_out;
+    // pixels A = j0 + 2 tj and B = A + 1 share the window columns 2 tj .. 2 tj + h: h + 1 samples per row, read as (h+1)/2
+    // 8-byte pairs (ds_read_b64); A compares against sample l, B against sample l + 1
+    const int jA = j0 + 2 * tj;
+    if (jA >= Wo) return;
+    const float *tp = tile + 2 * tj;
+    const float refA = tp[0], refB = tp[1];
+    uint32_t dA[NWRITTEN > 0 ? NWRITTEN : 1] = {}, dB[NWRITTEN > 0 ? NWRITTEN : 1] = {};
 #pragma unroll
-    for (int word = 0; word < NWRITTEN; word++) {
-        uint32_t d = 0;
+    for (int k = 0; k < v; k++) {
+        float smp[h + 1];
 #pragma unroll
-        for (int b = 0; b < 32; b++) {
-            const int c = 1 + 32 * word + b; // channel c = h * k + l (unfold.h:180)
-            const int k = c / h, l = c % h;
-            d |= (ref > tp[k * TW + l] ? 1u : 0u) << b;
+        for (int q = 0; q < (h + 1) / 2; q++) {
+            const float2 pr = *reinterpret_cast<const float2 *>(tp + k * TW + 2 * q);
+            smp[2 * q] = pr.x;
+            smp[2 * q + 1] = pr.y;
         }
-        o[word] = round_target ? round_word_through_float(d) : d;
+#pragma unroll
+        for (int l = 0; l < h; l++) {
+            const int c = h * k + l; // channel index (unfold.h:180); bit (c-1) % 32 of word (c-1) / 32 (census.h:98-108)
+            if (c >= 1 && (c - 1) / 32 < NWRITTEN) {
+                dA[(c - 1) / 32] |= (refA > smp[l] ? 1u : 0u) << ((c - 1) % 32);
+                dB[(c - 1) / 32] |= (refB > smp[l + 1] ? 1u : 0u) << ((c - 1) % 32);
+            }
+        }
     }
-    for (int w = NWRITTEN; w < n_out; w++) o[w] = 0; // rule E1
+    uint32_t *oA = words + ((int64_t)i * Wo + jA) * n_out;
+    const bool hasB = jA + 1 < Wo;
+#pragma unroll
+    for (int w = 0; w < NWRITTEN; w++) {
+        oA[w] = round_target ? round_word_through_float(dA[w]) : dA[w];
+        if (hasB) oA[n_out + w] = round_target ? round_word_through_float(dB[w]) : dB[w];
+    }
+    for (int w = NWRITTEN; w < n_out; w++) { // rule E1
+        oA[w] = 0;
+        if (hasB) oA[n_out + w] = 0;
+    }
 }
 
 template <int HR, int VR>
 static void launch_census_grey(svh_context *ctx, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {
-    dim3 grid(ceil_div(std::max(a.Wo, b ? b->Wo : 0), CENSUS_TJ), std::max(a.Ho, b ? b->Ho : 0), b ? 2 : 1);
+    dim3 grid(ceil_div(std::max(a.Wo, b ? b->Wo : 0), 2 * CENSUS_TJ), std::max(a.Ho, b ? b->Ho : 0), b ? 2 : 1);
     SVH_LAUNCH(ctx, "census_transform", (census_grey_kernel<HR, VR>), grid, CENSUS_TJ, 0, a, b ? *b : a, pl, pt, n_out);
 }
 

@@ -262,6 +262,7 @@ struct ScanGeom {
 // lanes of a wave (64 neighbouring lines) touch 64 consecutive pixels: every access is a coalesced 256-byte row
 // segment.  The rows are cut into SCAN_SEGS chunks handled by the threadIdx.y slices of the block.
 constexpr int SCAN_SEGS = 16;
+constexpr int SCAN_MAXSEG = 72; // segments up to this many rows are kept in registers (images up to 1152 rows)
 
 struct ColLines {
     int s, v_lo, n_lines, dir;
@@ -314,7 +315,33 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     const int first = cl.dir > 0 ? b : e - 1;
     const int64_t p0 = (int64_t)(sg.top + first) * sg.W + sg.left + v + cl.s * first;
     const int64_t step = (int64_t)cl.dir * (sg.W + cl.s);
+    float *out = mmap + (int64_t)q * npx;
     float mp = 0.0f;
+    if (chunk <= SCAN_MAXSEG) {
+        // the whole segment lives in registers: one round of loads (all in flight together), summary, chain, replay
+        float gv[SCAN_MAXSEG];
+#pragma unroll
+        for (int k = 0; k < SCAN_MAXSEG; k++) gv[k] = k < n ? gmap[p0 + k * step] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < SCAN_MAXSEG; k++)
+            if (k < n) mp = gv[k] - mp;
+        seg_a[seg][lane] = mp;
+        seg_n[seg][lane] = n;
+        __syncthreads();
+        mp = 0.0f;
+        if (cl.dir > 0) {
+            for (int t = 0; t < seg; t++) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
+        } else {
+            for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
+        }
+#pragma unroll
+        for (int k = 0; k < SCAN_MAXSEG; k++)
+            if (k < n) {
+                out[p0 + k * step] = mp;
+                mp = gv[k] - mp;
+            }
+        return;
+    }
     {
         int64_t p = p0;
         int k = 0;
@@ -334,7 +361,6 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     } else {
         for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
     }
-    float *out = mmap + (int64_t)q * npx;
     {
         int64_t p = p0;
         int k = 0;
@@ -354,37 +380,50 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     }
 }
 
-// scan_one_row: pass 1 (Left2Right), run by the last grid slice of scan_cols_kernel; one wavefront per image row, 64 consecutive pixels per step (coalesced
-// 256-byte loads and stores).  Each pixel is the affine map x -> g - x; an inclusive 6-step shuffle scan composes
-// them inside the chunk and the carry of the previous chunks enters through lane 0.
+// scan_one_row: pass 1 (Left2Right), run by the last grid slice of scan_cols_kernel; one wavefront per image row,
+// 64 consecutive pixels per step (coalesced 256-byte loads and stores).  Every pixel is the map x -> g - x, so the min_p seen
+// by pixel k is the alternating sum  g_{k-1} - g_{k-2} + ... :  with h_t = (-1)^t g_t and the inclusive prefix sum P of h,
+// min_p(k) = (-1)^(k-1) P_{k-1}.  The prefix sum inside a 64-pixel chunk is six DPP adds; exact (integers below 2^24).
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_add_from(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_prefix_sum(float v) {
+    v = dpp_add_from<0x111>(v);      // row_shr:1
+    v = dpp_add_from<0x112>(v);      // row_shr:2
+    v = dpp_add_from<0x114>(v);      // row_shr:4
+    v = dpp_add_from<0x118>(v);      // row_shr:8
+    v = dpp_add_from<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_add_from<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+constexpr int SCAN_ROW_CHUNKS = 32; // rows up to 2048 pixels are loaded in one go
+
 __device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
                                              int lane) {
     if (row >= sg.Hp) return;
     const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left;
     float *out = mmap + npx; // pass 1
-    float carry = 0.0f;      // min_p entering the chunk
-    for (int c0 = 0; c0 < sg.Wp; c0 += 64) {
-        const int k = c0 + lane;
-        const bool in = k < sg.Wp;
-        // map of this pixel (identity outside the row): mp_after = a + sgn * mp_before
-        float a = in ? gmap[base + k] : 0.0f;
-        float sgn = in ? -1.0f : 1.0f;
+    const float sgn = (lane & 1) ? -1.0f : 1.0f; // (-1)^lane; chunks start at even pixel indices
+    float carry = 0.0f;                            // prefix sum of h over the previous chunks
+    auto chunk = [&](float gval, int k) {
+        const float P = wave_prefix_sum(sgn * gval) + carry; // inclusive over pixels 0..k
+        // min_p(k) = (-1)^(k-1) P_{k-1}: take the neighbour's inclusive sum (lane 0: the carry)
+        float Pm1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, P), 0x138, 0xF, 0xF, false)); // wave_shr:1
+        if (lane == 0) Pm1 = carry;
+        const float mp = -sgn * Pm1;
+        if (k < sg.Wp) out[base + k] = mp == 0.0f ? 0.0f : mp; // the reference's first min_p is +0, never -0
+        carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, P), 63));
+    };
+    if (sg.Wp <= 64 * SCAN_ROW_CHUNKS) {
+        float gv[SCAN_ROW_CHUNKS];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float ea = __shfl_up(a, off), es = __shfl_up(sgn, off);
-            if (lane >= off) {
-                a = a + sgn * ea;
-                sgn = sgn * es;
-            }
-        }
-        // min_p seen by this pixel = all earlier pixels of the chunk applied to the carry
-        float ea = __shfl_up(a, 1), es = __shfl_up(sgn, 1);
-        if (lane == 0) {
-            ea = 0.0f;
-            es = 1.0f;
-        }
-        if (in) out[base + k] = ea + es * carry;
-        carry = __shfl(a, 63) + __shfl(sgn, 63) * carry;
+        for (int c = 0; c < SCAN_ROW_CHUNKS; c++) gv[c] = (c * 64 + lane < sg.Wp) ? gmap[base + c * 64 + lane] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < SCAN_ROW_CHUNKS; c++)
+            if (c * 64 < sg.Wp) chunk(gv[c], c * 64 + lane);
+    } else {
+        for (int c0 = 0; c0 < sg.Wp; c0 += 64) chunk((c0 + lane < sg.Wp) ? gmap[base + c0 + lane] : 0.0f, c0 + lane);
     }
 }
 

@@ -164,6 +164,21 @@ int svh_truncated_cost_volume(svh_context *ctx, int tcv_direction, int disp_dire
 int svh_refine_disp_cost_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
                                        svh_array *refined);
 
+/* ---- 2-D disparity (optical-flow style) volumes: SURVEY.md section 8(f) rank 2 --------------------------------------
+ * unfoldBased2dDisparityCostVolume<matchFunc,...>(img_l, img_r, h_radius, v_radius, searchOffset<2>(lower0, upper0, lower1, upper1))
+ *                                                                 correlation/cross_correlations.h:794-822 (+ :310-374)
+ * cv (H,W,Dh,Dw) f32, CV(i,j,dh,dw) = cmp(src(i,j,:), tgt(i+dh+lower0, j+dw+lower1,:)); image sizes must agree. */
+int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r,
+                              int h_radius, int v_radius, int32_t lower0, int32_t upper0, int32_t lower1, int32_t upper1, svh_array *cv);
+/* extractSelected2dIndex<strategy>(cv) -> idx (H,W,2) i32                          correlation/correlation_base.h:466-509 */
+int svh_extract_selected_2d_index(svh_context *ctx, int strategy, const svh_array *cv, svh_array *idx);
+/* selected2dIndexToDisp(idx, searchOffset<2>) -> disp (H,W,2) i32                  correlation/correlation_base.h:534-555 */
+int svh_selected_2d_index_to_disp(svh_context *ctx, const svh_array *idx, int32_t lower0, int32_t lower1, svh_array *disp);
+/* truncatedBidirectionaCostVolume(cv, idx, radius0, radius1) -> tcv (H,W,2r0+1,2r1+1), NaN outside the volume
+ *                                                                                  correlation/correlation_base.h:677-725 */
+int svh_truncated_bidirectional_cost_volume(svh_context *ctx, const svh_array *cv, const svh_array *idx, int radius0, int radius1,
+                                            svh_array *tcv);
+
 /* ---- fused pipeline: the benchmark / stereo_refine_test call chain kept on the device ------------------
  * unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp
  *   (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294)

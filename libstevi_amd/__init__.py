@@ -7,5 +7,5 @@ sharded.py       disparity sharding over the GPUs of a node (torch.distributed /
 """
 from . import _capi  # noqa: F401
 from .correlation import *  # noqa: F401,F403
-from .correlation import (Margins, PaddingMargins, searchOffset1, matchFuncStrategy, context_for, profile_enable,  # noqa: F401
+from .correlation import (Margins, PaddingMargins, searchOffset1, searchOffset2, matchFuncStrategy, context_for, profile_enable,  # noqa: F401
                           profile_reset, profile_collect, set_option)

@@ -459,6 +459,57 @@ def keysToIndex(strategy, keys, disp_count):
     return out
 
 
+class searchOffset2:  # searchOffset<2>, correlation_base.h:288-409
+    def __init__(self, lower0, upper0, lower1, upper1):
+        self.lower0, self.upper0, self.lower1, self.upper1 = int(lower0), int(upper0), int(lower1), int(upper1)
+
+
+def unfoldBased2dDisparityCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, searchWindows, dDir=dispDirection.RightToLeft):
+    """unfoldBased2dDisparityCostVolume -- correlation/cross_correlations.h:794-822; (H, W, Dh, Dw) or an empty array."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    sw = searchWindows
+    Dh, Dw = sw.upper0 - sw.lower0 + 1, sw.upper1 - sw.lower1 + 1
+    if l.shape[0] != r.shape[0] or l.shape[1] != r.shape[1] or (l.ndim == 3 and l.shape[2] != r.shape[2]) or Dh <= 0 or Dw <= 0:
+        return _empty_like(l, 4, "f32")
+    out = _like(l, (l.shape[0], l.shape[1], Dh, Dw), "f32")
+    st = _check(ctx, lib.svh_unfold_cost_volume_2d(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
+                                                   sw.lower0, sw.upper0, sw.lower1, sw.upper1, C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(l, 4, "f32")
+
+
+def extractSelected2dIndex(strategy, costVolume):
+    """extractSelected2dIndex<strategy> -- correlation_base.h:466-509."""
+    lib = _capi.load()
+    cv = _prep(costVolume, np.float32)
+    ctx = context_for(cv)
+    out = _like(cv, (cv.shape[0], cv.shape[1], 2), "i32")
+    _check(ctx, lib.svh_extract_selected_2d_index(ctx, int(strategy), C.byref(_desc(cv)), C.byref(_desc(out))))
+    return out
+
+
+def selected2dIndexToDisp(selectedIndex, offset):
+    """selected2dIndexToDisp(idx, searchOffset<2>) -- correlation_base.h:534-555."""
+    lib = _capi.load()
+    idx = _prep(selectedIndex, np.int32)
+    ctx = context_for(idx)
+    out = _like(idx, tuple(idx.shape), "i32")
+    _check(ctx, lib.svh_selected_2d_index_to_disp(ctx, C.byref(_desc(idx)), offset.lower0, offset.lower1, C.byref(_desc(out))))
+    return out
+
+
+def truncatedBidirectionaCostVolume(costVolume, selectedIndex, cost_vol_radius0, cost_vol_radius1):
+    """truncatedBidirectionaCostVolume -- correlation_base.h:677-725 (explicit radii)."""
+    lib = _capi.load()
+    cv, idx = _prep(costVolume, np.float32), _prep(selectedIndex, np.int32)
+    ctx = context_for(cv)
+    out = _like(cv, (cv.shape[0], cv.shape[1], 2 * cost_vol_radius0 + 1, 2 * cost_vol_radius1 + 1), "f32")
+    _check(ctx, lib.svh_truncated_bidirectional_cost_volume(ctx, C.byref(_desc(cv)), C.byref(_desc(idx)), cost_vol_radius0, cost_vol_radius1,
+                                                            C.byref(_desc(out))))
+    return out
+
+
 def set_option(x, name, value):
     """svh_context_set_option on the context used for array x (e.g. "census_fast_path", 0/1)."""
     ctx = context_for(x)

@@ -85,7 +85,8 @@ enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
 template <class A, int CMP, bool ZM, bool NORM>
 __global__ void cost_volume_kernel(A src, A tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
                                    const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
-                                   int D, int sign, int disp_lower, float *__restrict__ cv) {
+                                   int D, int sign, int disp_lower, int row_off, int64_t px_stride, int64_t out_off,
+                                   float *__restrict__ cv) {
     const int64_t n = (int64_t)H * Ws * D;
     const int F = src.count();
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -93,17 +94,18 @@ __global__ void cost_volume_kernel(A src, A tgt, const float *__restrict__ mean_
         int64_t p = e / D;
         int j = (int)(p % Ws), i = (int)(p / Ws);
         int jt = j + sign * (disp_lower + d);
-        bool t_in = jt >= 0 && jt < Wt;
+        const int it = i + row_off;
+        bool t_in = jt >= 0 && jt < Wt && it >= 0 && it < H;
         float ms = ZM ? mean_s[p] : 0.0f;
         float ns = NORM ? norm_s[p] : 1.0f;
         float mt = 0.0f, nt = 1.0f;
         if (t_in) {
-            int64_t pt = (int64_t)i * Wt + jt;
+            int64_t pt = (int64_t)it * Wt + jt;
             if (ZM) mt = mean_t[pt];
             if (NORM) nt = norm_t[pt];
         }
         typename CursorOf<A>::type cs(src, i, j);
-        typename CursorOf<A>::type ct(tgt, i, t_in ? jt : 0);
+        typename CursorOf<A>::type ct(tgt, t_in ? it : 0, t_in ? jt : 0);
         float score = 0.0f;
         for (int c = 0; c < F; c++) {
             float s = cs.next();
@@ -126,7 +128,7 @@ __global__ void cost_volume_kernel(A src, A tgt, const float *__restrict__ mean_
                 score += fabsf(tmp);
             }
         }
-        cv[e] = score;
+        cv[p * px_stride + out_off + d] = score;
     }
 }
 
@@ -135,19 +137,21 @@ __global__ void cost_volume_kernel(A src, A tgt, const float *__restrict__ mean_
 // uint16_t returned as float.  Target words were rounded through float when they were produced (rule E2); a
 // target column outside the image is the zero vector, so the cost is popcount(source).
 __global__ void hamming_volume_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int nWw, int H, int Ws,
-                                      int Wt, int D, int sign, int disp_lower, float *__restrict__ cv) {
+                                      int Wt, int D, int sign, int disp_lower, int row_off, int64_t px_stride, int64_t out_off,
+                                      float *__restrict__ cv) {
     const int64_t n = (int64_t)H * Ws * D;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         int d = (int)(e % D);
         int64_t p = e / D;
         int j = (int)(p % Ws), i = (int)(p / Ws);
         int jt = j + sign * (disp_lower + d);
-        bool t_in = jt >= 0 && jt < Wt;
+        const int it = i + row_off;
+        bool t_in = jt >= 0 && jt < Wt && it >= 0 && it < H;
         const uint32_t *s = sw + p * nWw;
-        const uint32_t *t = tw + ((int64_t)i * Wt + (t_in ? jt : 0)) * nWw;
+        const uint32_t *t = tw + ((int64_t)(t_in ? it : 0) * Wt + (t_in ? jt : 0)) * nWw;
         uint32_t score = 0;
         for (int w = 0; w < nWw; w++) score += __popc(s[w] ^ (t_in ? t[w] : 0u));
-        cv[e] = (float)(uint16_t)score;
+        cv[p * px_stride + out_off + d] = (float)(uint16_t)score;
     }
 }
 
@@ -159,15 +163,18 @@ constexpr int HV_TP = 64;
 
 template <int NW>
 __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int H,
-                                                                   int Ws, int Wt, int D, int sign, int disp_lower, float *__restrict__ cv) {
+                                                                   int Ws, int Wt, int D, int sign, int disp_lower, int row_off, int64_t px_stride,
+                                                                   int64_t out_off, float *__restrict__ cv) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
     const int n_rec = HV_TP + D - 1;
-    const uint32_t *trow = tw + (int64_t)i * Wt * NW;
+    const int it = i + row_off;
+    const bool row_in = it >= 0 && it < H; // a target row outside the image is the zero vector
+    const uint32_t *trow = tw + (int64_t)(row_in ? it : 0) * Wt * NW;
     for (int e = threadIdx.x; e < n_rec * NW; e += blockDim.x) {
         const int y = e / NW, w = e - y * NW;
         const int jt = sign > 0 ? j0 + disp_lower + y : j0 + (HV_TP - 1) - disp_lower - y;
-        lds[e] = (jt >= 0 && jt < Wt) ? trow[(int64_t)jt * NW + w] : 0u;
+        lds[e] = (row_in && jt >= 0 && jt < Wt) ? trow[(int64_t)jt * NW + w] : 0u;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -177,7 +184,7 @@ __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_
 #pragma unroll
         for (int w = 0; w < NW; w++) s[w] = sw[p * NW + w];
         const uint32_t *base = lds + (sign > 0 ? u : HV_TP - 1 - u) * NW;
-        float *out = cv + p * D;
+        float *out = cv + p * px_stride + out_off;
         for (int d = lane; d < D; d += 64) {
             uint32_t score = 0;
 #pragma unroll
@@ -191,7 +198,8 @@ template <int NW>
 static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *sw, const uint32_t *tw, int sign, float *cv) {
     dim3 grid(ceil_div(a.Ws, HV_TP), a.H);
     const size_t shmem = (size_t)NW * (HV_TP + a.D - 1) * sizeof(uint32_t);
-    SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, cv);
+    SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off,
+               a.px_stride(), a.out_off, cv);
 }
 
 template <class A>
@@ -208,10 +216,10 @@ static int launch_cv(svh_context *ctx, bool zm, bool nrm, A src, A tgt, const fl
                      const float *nt, const CostVolumeArgs &a, float *cv) {
     int64_t n = (int64_t)a.H * a.Ws * a.D;
     int grid = grid_for(n, 256, 65536);
-    int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+    int sign = a.sign();
 #define SVH_CV_LAUNCH(ZM, NORM)                                                                                          \
     SVH_LAUNCH(ctx, "cost_volume", (cost_volume_kernel<A, CMP, ZM, NORM>), grid, 256, 0, src, tgt, ms, ns, mt, nt, a.H, a.Ws, \
-               a.Wt, a.D, sign, a.disp_lower, cv)
+               a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off, a.px_stride(), a.out_off, cv)
     if (zm && nrm) SVH_CV_LAUNCH(true, true);
     else if (zm) SVH_CV_LAUNCH(true, false);
     else if (nrm) SVH_CV_LAUNCH(false, true);
@@ -256,7 +264,7 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
                        float *cv) {
     int64_t n = (int64_t)a.H * a.Ws * a.D;
     if (n == 0) return SVH_OK;
-    int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+    int sign = a.sign();
     if (nWw >= 1 && nWw <= 4 && (size_t)nWw * (HV_TP + a.D - 1) * sizeof(uint32_t) <= 60 * 1024) {
         switch (nWw) {
         case 1: launch_hamming_tiled<1>(ctx, a, src_words, tgt_words, sign, cv); break;
@@ -268,7 +276,7 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
         return SVH_OK;
     }
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_kernel, grid_for(n, 256, 65536), 256, 0, src_words, tgt_words, nWw, a.H, a.Ws,
-               a.Wt, a.D, sign, a.disp_lower, cv);
+               a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off, a.px_stride(), a.out_off, cv);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -378,3 +386,66 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
 }
 
 } // extern "C"
+
+// ---- 2-D disparity volumes ----------------------------------------------------------
+// unfoldBased2dDisparityCostVolume<matchFunc,...>(img_l, img_r, h_radius, v_radius, searchOffset<2>)
+//                                                                        correlation/cross_correlations.h:794-822, :310-374
+// cv (H, W, Dh, Dw): CV(i,j,dh,dw) = cmp(src(i,j,:), tgt(i + dh + lower0, j + dw + lower1, :)).  Built one vertical offset
+// at a time with the 1-D kernels (target row offset, +1 column sign, strided output).
+extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l,
+                                         const svh_array *img_r, int h_radius, int v_radius, int32_t lower0, int32_t upper0,
+                                         int32_t lower1, int32_t upper1, svh_array *cv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 4, 4));
+    if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (h_radius < 0 || v_radius < 0 || h_radius > 255 || v_radius > 255)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255] (uint8_t in the reference)");
+    if (img_l->ndim != img_r->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "image ranks differ");
+    // cross_correlations.h:801-816: rows, columns and channels must agree; :338-340: non-empty ranges
+    if (img_l->shape[0] != img_r->shape[0] || img_l->shape[1] != img_r->shape[1]) return fail(ctx, SVH_EMPTY_RESULT, "image sizes differ");
+    const int C = img_l->ndim == 3 ? (int)img_l->shape[2] : 1;
+    if (img_l->ndim == 3 && img_l->shape[2] != img_r->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "channel counts differ");
+    const int Dh = upper0 - lower0 + 1, Dw = upper1 - lower1 + 1;
+    if (Dh <= 0 || Dw <= 0) return fail(ctx, SVH_EMPTY_RESULT, "empty search range");
+    const int F = (2 * h_radius + 1) * (2 * v_radius + 1) * C;
+    if (func_census(match_func) && F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    const bool r2l = disp_direction == SVH_RIGHT_TO_LEFT;
+    const svh_array *src = r2l ? img_r : img_l, *tgt = r2l ? img_l : img_r;
+    const int H = (int)src->shape[0], W = (int)src->shape[1];
+    if (cv->shape[0] != H || cv->shape[1] != W || cv->shape[2] != Dh || cv->shape[3] != Dw)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv must have shape (%d,%d,%d,%d)", H, W, Dh, Dw);
+    Scratch scr(ctx);
+    void *ds, *dt;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *src, &ds));
+    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_out(ctx, scr, *cv, &os));
+    const ImageDesc isrc{(const float *)ds, H, W, C}, itgt{(const float *)dt, H, W, C};
+    CostVolumeArgs a{match_func, disp_direction, H, W, W, lower1, Dw};
+    a.force_sign = 1;
+    a.out_px_stride = (int64_t)Dh * Dw;
+    if (func_census(match_func)) { // census words once, one Hamming pass per vertical offset
+        const int nWw = census_words_written(F);
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)H * W * (nWw ? nWw : 1));
+        uint32_t *tw = scr.get_n<uint32_t>((size_t)H * W * (nWw ? nWw : 1));
+        if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_pair_compact(ctx, isrc, itgt, h_radius, v_radius, nWw, sw, tw));
+        for (int dh = 0; dh < Dh; dh++) {
+            a.tgt_row_off = lower0 + dh;
+            a.out_off = (int64_t)dh * Dw;
+            SVH_TRY(dev_hamming_volume(ctx, a, sw, tw, nWw, (float *)os.dptr));
+        }
+    } else {
+        for (int dh = 0; dh < Dh; dh++) {
+            a.tgt_row_off = lower0 + dh;
+            a.out_off = (int64_t)dh * Dw;
+            Scratch inner(ctx); // the per-offset statistics maps are released after each pass
+            SVH_TRY(dev_cost_volume_from_images(ctx, inner, a, isrc, itgt, h_radius, v_radius, (float *)os.dptr));
+        }
+    }
+    return finish_out(ctx, os);
+}

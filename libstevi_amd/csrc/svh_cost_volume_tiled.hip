@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__r
                                                                 int v_r, int D, int sign, int disp_lower, const float *__restrict__ mean_s,
                                                                 const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                 const float *__restrict__ norm_t, const float *__restrict__ zcost,
-                                                                float *__restrict__ cv) {
+                                                                int row_off, int64_t px_stride, int64_t out_off, float *__restrict__ cv) {
     constexpr int h = 2 * HR + 1, NV = CV_PB + h - 1;
     extern __shared__ float lds[];
     const int v = 2 * v_r + 1;
@@ -89,12 +89,14 @@ __global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__r
     const int i = blockIdx.y, j0 = blockIdx.x * CV_TPX;
     // block constant that keeps the zero-mean dot products small (see the header comment)
     const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(j0, Ws - 1)] : 0.0f;
+    const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
+    const bool trow_in = it >= 0 && it < H;
     for (int k = 0; k < v; k++) {
         const int ii = i - v_r + k;
         for (int x = threadIdx.x; x < sw; x += blockDim.x) stile[k * sw + x] = image_or_zero1(src, H, Ws, ii, j0 - HR + x) - c0;
         for (int z = threadIdx.x; z < tw; z += blockDim.x) {
             const int jt = sign > 0 ? j0 + disp_lower - HR + z : j0 + (CV_TPX - 1) - disp_lower + HR - z;
-            ttile[k * tw + z] = image_or_zero1(tgt, H, Wt, ii, jt) - c0;
+            ttile[k * tw + z] = image_or_zero1(tgt, H, Wt, it - v_r + k, jt) - c0;
         }
     }
     __syncthreads();
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__r
 #pragma unroll
             for (int p = 0; p < CV_PB; p++) {
                 const int j = j0 + ub + p, jt = j + sign * (disp_lower + dd);
-                if (j < Ws && jt >= 0 && jt < Wt) delta[p] = mean_s[(int64_t)i * Ws + j] - mean_t[(int64_t)i * Wt + jt];
+                if (j < Ws && trow_in && jt >= 0 && jt < Wt) delta[p] = mean_s[(int64_t)i * Ws + j] - mean_t[(int64_t)it * Wt + jt];
             }
         }
         for (int k = 0; k < v; k++) {
@@ -149,8 +151,8 @@ __global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__r
                 const int64_t px = (int64_t)i * Ws + j;
                 const int jt = j + sign * (disp_lower + d);
                 float r = acc[p];
-                if (jt >= 0 && jt < Wt) {
-                    const int64_t pt = (int64_t)i * Wt + jt;
+                if (trow_in && jt >= 0 && jt < Wt) {
+                    const int64_t pt = (int64_t)it * Wt + jt;
                     if (ZM && CMP == T_DOT) r -= Ff * (mean_s[px] - c0) * (mean_t[pt] - c0);
                     if (ZM && CMP == T_SSD) {
                         const float dm = mean_s[px] - mean_t[pt];
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__r
                 } else {
                     r = zcost[px];
                 }
-                cv[px * D + d] = r;
+                cv[px * px_stride + out_off + d] = r;
             }
         }
     }
@@ -171,7 +173,7 @@ template <int CMP, bool ZM, int HR> void launch_tiled(svh_context *ctx, const Co
                                                       float *cv, size_t shmem) {
     dim3 grid(ceil_div(a.Ws, CV_TPX), a.H);
     SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_tiled_kernel<CMP, ZM, HR>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D, sign,
-               a.disp_lower, ms, mt, ns, nt, zc, cv);
+               a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);
 }
 
 template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
@@ -220,7 +222,7 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
     if (cmp == T_DOT) { SVH_STATS(T_DOT) } else if (cmp == T_SSD) { SVH_STATS(T_SSD) } else { SVH_STATS(T_SAD) }
 #undef SVH_STATS
     SVH_CHECK_LAUNCH(ctx);
-    const int sign = a.ddir == SVH_RIGHT_TO_LEFT ? 1 : -1;
+    const int sign = a.sign();
     bool ok;
     if (cmp == T_DOT) ok = zm ? dispatch_hr<T_DOT, true>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem)
                               : dispatch_hr<T_DOT, false>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);

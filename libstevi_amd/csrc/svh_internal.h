@@ -162,6 +162,15 @@ struct CostVolumeArgs {
     int func, ddir;
     int H, Ws, Wt;
     int disp_lower, D;
+    // 2-D disparity volumes (aggregateCost(searchOffset<2>), cross_correlations.h:310-374) are built one vertical offset
+    // at a time: the target is read at row i + tgt_row_off, the column sign is +1 whatever dDir says, and the D costs of
+    // a pixel go to cv[pixel * out_px_stride + out_off + d].  Zero / default values give the 1-D behaviour.
+    int tgt_row_off = 0;
+    int force_sign = 0;          // 0: +1 for RightToLeft, -1 for LeftToRight
+    int64_t out_px_stride = 0;   // 0: D
+    int64_t out_off = 0;
+    int sign() const { return force_sign ? force_sign : (ddir == SVH_RIGHT_TO_LEFT ? 1 : -1); }
+    int64_t px_stride() const { return out_px_stride ? out_px_stride : D; }
 };
 int dev_cost_volume_from_features(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, const float *feat_src,
                                   const float *feat_tgt, int F, float *cv);

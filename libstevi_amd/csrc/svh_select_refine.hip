@@ -162,6 +162,37 @@ __global__ void refine_kernel(int kernel, const float *__restrict__ tcv, const i
     }
 }
 
+// flat index over (D1, D2) -> (d1, d2): the row-major '<=' scan of extractSelected2dIndex (correlation_base.h:466-509) is the
+// 1-D scan over the flattened axis
+__global__ void split_index_kernel(const int32_t *__restrict__ flat, int64_t n, int D2, int32_t *__restrict__ out2) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int f = flat[p];
+        out2[2 * p] = f / D2;
+        out2[2 * p + 1] = f % D2;
+    }
+}
+
+// selected2dIndexToDisp, correlation_base.h:534-555
+__global__ void index_2d_to_disp_kernel(const int32_t *__restrict__ idx, int64_t n, int lower0, int lower1, int32_t *__restrict__ disp) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        disp[2 * p] = idx[2 * p] + lower0;
+        disp[2 * p + 1] = idx[2 * p + 1] + lower1;
+    }
+}
+
+// truncatedBidirectionaCostVolume, correlation_base.h:677-725: valueOrAlt(..., NaN) around the selected 2-D index
+__global__ void truncated_bidirectional_kernel(const float *__restrict__ cv, const int32_t *__restrict__ idx, int64_t npx, int D1, int D2, int r0,
+                                               int r1, float *__restrict__ tcv) {
+    const int T0 = 2 * r0 + 1, T1 = 2 * r1 + 1;
+    const int64_t n = npx * T0 * T1;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int d1 = (int)(e % T1), d0 = (int)((e / T1) % T0);
+        const int64_t px = e / ((int64_t)T0 * T1);
+        const int p0 = idx[2 * px] + d0 - r0, p1 = idx[2 * px + 1] + d1 - r1;
+        tcv[e] = (p0 >= 0 && p0 < D1 && p1 >= 0 && p1 < D2) ? cv[(px * D1 + p0) * D2 + p1] : __uint_as_float(0x7FC00000u);
+    }
+}
+
 int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
                       unsigned long long *keys, int key_index_offset, int key_total_D) {
     if (n_pixels == 0) return SVH_OK;
@@ -342,3 +373,77 @@ int svh_keys_to_index(svh_context *ctx, int strategy, const svh_array *keys, int
 }
 
 } // extern "C"
+
+
+// ---- 2-D disparity volumes ----------------------------------------------------------
+extern "C" int svh_extract_selected_2d_index(svh_context *ctx, int strategy, const svh_array *cv, svh_array *idx) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 4, 4));
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 3, 3));
+    if (strategy != SVH_COST && strategy != SVH_SCORE) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad strategy");
+    if (idx->shape[0] != cv->shape[0] || idx->shape[1] != cv->shape[1] || idx->shape[2] != 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "idx must have shape (H, W, 2)");
+    const int64_t npx = cv->shape[0] * cv->shape[1];
+    const int64_t D = cv->shape[2] * cv->shape[3];
+    if (D < 1 || D > (1 << 30)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad search range");
+    Scratch scr(ctx);
+    void *dcv;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_out(ctx, scr, *idx, &os));
+    int32_t *flat = scr.get_n<int32_t>((size_t)npx);
+    if (!flat) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(dev_extract_index(ctx, strategy, (const float *)dcv, npx, (int)D, flat, nullptr, 0, 0));
+    if (npx) {
+        SVH_LAUNCH(ctx, "split_index", split_index_kernel, grid_for(npx, 256, 8192), 256, 0, flat, npx, (int)cv->shape[3], (int32_t *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return finish_out(ctx, os);
+}
+
+extern "C" int svh_selected_2d_index_to_disp(svh_context *ctx, const svh_array *idx, int32_t lower0, int32_t lower1, svh_array *disp) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 3, 3));
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 3, 3));
+    if (idx->shape[2] != 2 || disp->shape[0] != idx->shape[0] || disp->shape[1] != idx->shape[1] || disp->shape[2] != 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "idx and disp must have shape (H, W, 2)");
+    const int64_t npx = idx->shape[0] * idx->shape[1];
+    Scratch scr(ctx);
+    void *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *idx, &di));
+    SVH_TRY(stage_out(ctx, scr, *disp, &os));
+    if (npx) {
+        SVH_LAUNCH(ctx, "index_2d_to_disp", index_2d_to_disp_kernel, grid_for(npx, 256, 8192), 256, 0, (const int32_t *)di, npx, lower0, lower1,
+                   (int32_t *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return finish_out(ctx, os);
+}
+
+extern "C" int svh_truncated_bidirectional_cost_volume(svh_context *ctx, const svh_array *cv, const svh_array *idx, int radius0, int radius1,
+                                                       svh_array *tcv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 4, 4));
+    SVH_TRY(validate(ctx, idx, "idx", SVH_I32, 3, 3));
+    SVH_TRY(validate(ctx, tcv, "tcv", SVH_F32, 4, 4));
+    if (radius0 < 1 || radius1 < 1 || radius0 > 255 || radius1 > 255) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [1,255]");
+    if (idx->shape[0] != cv->shape[0] || idx->shape[1] != cv->shape[1] || idx->shape[2] != 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "idx must have shape (H, W, 2)");
+    if (tcv->shape[0] != cv->shape[0] || tcv->shape[1] != cv->shape[1] || tcv->shape[2] != 2 * radius0 + 1 || tcv->shape[3] != 2 * radius1 + 1)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "tcv must have shape (H, W, %d, %d)", 2 * radius0 + 1, 2 * radius1 + 1);
+    const int64_t npx = cv->shape[0] * cv->shape[1];
+    Scratch scr(ctx);
+    void *dcv, *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_in(ctx, scr, *idx, &di));
+    SVH_TRY(stage_out(ctx, scr, *tcv, &os));
+    const int64_t n = npx * (2 * radius0 + 1) * (2 * radius1 + 1);
+    if (n) {
+        SVH_LAUNCH(ctx, "truncated_bidirectional", truncated_bidirectional_kernel, grid_for(n, 256, 16384), 256, 0, (const float *)dcv,
+                   (const int32_t *)di, npx, (int)cv->shape[2], (int)cv->shape[3], radius0, radius1, (float *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return finish_out(ctx, os);
+}

@@ -99,6 +99,43 @@ Multidim::Array<T_CV, 3> truncatedCostVolume(Multidim::Array<T_CV, 3> const &cos
     return tcv;
 }
 
+// extractSelected2dIndex<strategy>, correlation_base.h:466-509
+template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 3> extractSelected2dIndex(Multidim::Array<T_CV, 4> const &costVolume) {
+    auto s = costVolume.shape();
+    Multidim::Array<disp_t, 3> disp(s[0], s[1], 2);
+    if (costVolume.empty()) return disp;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
+    HipBridge::check(svh_extract_selected_2d_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
+    return disp;
+}
+
+// selected2dIndexToDisp(selectedIndex, searchOffset<2>), correlation_base.h:534-555
+template <typename DT> Multidim::Array<DT, 3> selected2dIndexToDisp(Multidim::Array<DT, 3> const &selectedIndex, searchOffset<2> const &offset) {
+    auto s = selectedIndex.shape();
+    Multidim::Array<DT, 3> disp(s[0], s[1], 2);
+    if (selectedIndex.empty()) return disp;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
+    HipBridge::check(svh_selected_2d_index_to_disp(HipBridge::context(), &in, offset.lowerOffset(0), offset.lowerOffset(1), &out));
+    return disp;
+}
+
+// truncatedBidirectionaCostVolume<T_CV, dir>(costVolume, selectedIndex, radius0, radius1), correlation_base.h:677-725
+// (the reference's default radii are uint8_t(-1); pass them explicitly)
+template <class T_CV, dispDirection dir = dispDirection::RightToLeft>
+Multidim::Array<T_CV, 4> truncatedBidirectionaCostVolume(Multidim::Array<T_CV, 4> const &costVolume, Multidim::Array<disp_t, 3> const &selectedIndex,
+                                                         uint8_t cost_vol_radius0, uint8_t cost_vol_radius1) {
+    uint8_t r0 = cost_vol_radius0 < 1 ? 1 : cost_vol_radius0, r1 = cost_vol_radius1 < 1 ? r0 : cost_vol_radius1; // :690-696
+    auto s = costVolume.shape();
+    Multidim::Array<T_CV, 4> tcv(s[0], s[1], r0 * 2 + 1, r1 * 2 + 1);
+    if (costVolume.empty()) return tcv;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
+    HipBridge::check(svh_truncated_bidirectional_cost_volume(HipBridge::context(), &cv, &idx, r0, r1, &out));
+    return tcv;
+}
+
 } // namespace Correlation
 } // namespace StereoVision
 

@@ -61,6 +61,29 @@ Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const
     return cv;
 }
 
+// unfoldBased2dDisparityCostVolume<matchFunc, T_L, T_R, nImDim, dDir, TCV>(img_l, img_r, h_radius, v_radius, searchOffset<2>),
+// cross_correlations.h:794-822
+template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
+Multidim::Array<TCV, 4> unfoldBased2dDisparityCostVolume(Multidim::Array<T_L, nImDim> const &img_l, Multidim::Array<T_R, nImDim> const &img_r,
+                                                         uint8_t h_radius, uint8_t v_radius, searchOffset<2> const &searchWindows) {
+    static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
+    static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
+    auto l_shape = img_l.shape();
+    auto r_shape = img_r.shape();
+    if (l_shape[0] != r_shape[0] || l_shape[1] != r_shape[1]) return Multidim::Array<TCV, 4>(); // :804-810
+    if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 4>();
+    const int Dh = searchWindows.dimRange(0), Dw = searchWindows.dimRange(1);
+    if (Dh <= 0 || Dw <= 0) return Multidim::Array<TCV, 4>(); // :338-340
+    Multidim::Array<TCV, 4> cv(l_shape[0], l_shape[1], Dh, Dw);
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
+    if (!HipBridge::check(svh_unfold_cost_volume_2d(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius,
+                                                    searchWindows.lowerOffset(0), searchWindows.upperOffset(0), searchWindows.lowerOffset(1),
+                                                    searchWindows.upperOffset(1), &out)))
+        return Multidim::Array<TCV, 4>();
+    return cv;
+}
+
 } // namespace Correlation
 } // namespace StereoVision
 

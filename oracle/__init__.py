@@ -232,3 +232,41 @@ def refine_disp(tcv, raw, kernel=PARABOLA):
     if rc:
         return np.empty((0, 0), np.float32)
     return out
+
+
+# ---- 2-D disparity volumes ---------------------------------------------------------
+def unfold_cost_volume_2d(func, img_l, img_r, h_r, v_r, range0, range1, ddir=RIGHT_TO_LEFT):
+    """range0 = (lower, upper) vertical offsets, range1 = horizontal; returns (H, W, Dh, Dw) or an empty array."""
+    img_l, img_r = _img3(img_l), _img3(img_r)
+    Hl, Wl, Cc = img_l.shape
+    Hr, Wr, Cr = img_r.shape
+    Dh, Dw = range0[1] - range0[0] + 1, range1[1] - range1[0] + 1
+    if Hl != Hr or Wl != Wr or Cc != Cr or Dh <= 0 or Dw <= 0:
+        return np.empty((0, 0, 0, 0), np.float32)
+    cv = np.empty((Hl, Wl, Dh, Dw), np.float32)
+    rc = lib().so_unfold_cost_volume_2d(int(func), _p(img_l), _p(img_r), Hl, Wl, Hr, Wr, Cc, int(h_r), int(v_r), int(ddir),
+                                        int(range0[0]), int(range0[1]), int(range1[0]), int(range1[1]), _p(cv))
+    return cv if rc == 0 else np.empty((0, 0, 0, 0), np.float32)
+
+
+def extract_index_2d(cv, strategy):
+    cv = _f32(cv)
+    H, W, D1, D2 = cv.shape
+    idx = np.empty((H, W, 2), np.int32)
+    lib().so_extract_index_2d(int(strategy), _p(cv), H, W, D1, D2, _p(idx))
+    return idx
+
+
+def index_2d_to_disp(idx, lower0, lower1):
+    idx = _i32(idx)
+    out = np.empty_like(idx)
+    lib().so_index_2d_to_disp(_p(idx), idx.shape[0], idx.shape[1], int(lower0), int(lower1), _p(out))
+    return out
+
+
+def truncated_bidirectional_cv(cv, idx, r0, r1):
+    cv, idx = _f32(cv), _i32(idx)
+    H, W, D1, D2 = cv.shape
+    out = np.empty((H, W, 2 * r0 + 1, 2 * r1 + 1), np.float32)
+    lib().so_truncated_bidirectional_cv(_p(cv), _p(idx), H, W, D1, D2, int(r0), int(r1), _p(out))
+    return out

@@ -687,3 +687,132 @@ int so_refine_disp(int kernel, const float *tcv, const int32_t *raw, int H, int 
         }
     return 0;
 }
+
+/* ===== 2-D disparity (optical-flow style) volumes: SURVEY.md section 8(f) rank 2 ================================= */
+
+/* aggregateCost(searchOffset<2>), correlation/cross_correlations.h:310-374:
+ * CV(i,j,dh,dw) = cmp(src(i,j,:), tgt(i + dh + lower0, j + dw + lower1, :)), zero target vector outside the image
+ * (:359).  No direction sign here: dDir only selects which image is the source.  cv is [H][Ws][Dh][Dw]. */
+static void aggregate_float_2d(int func, const float *src, const float *tgt, int H, int Ws, int Wt, int F, int lower0, int Dh,
+                               int lower1, int Dw, float *cv) {
+#pragma omp parallel
+    {
+        float *tv = (float *)malloc((size_t)F * sizeof(float));
+#pragma omp for
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < Ws; j++) {
+                const float *sv = src + ((size_t)i * Ws + j) * F;
+                for (int dh = 0; dh < Dh; dh++)
+                    for (int dw = 0; dw < Dw; dw++) {
+                        int it = i + dh + lower0, jt = j + dw + lower1;
+                        int in = it >= 0 && it < H && jt >= 0 && jt < Wt;
+                        for (int c = 0; c < F; c++) tv[c] = in ? tgt[((size_t)it * Wt + jt) * F + c] : 0.0f;
+                        cv[(((size_t)i * Ws + j) * Dh + dh) * Dw + dw] = cmp_float(func, sv, tv, F);
+                    }
+            }
+        free(tv);
+    }
+}
+
+static void aggregate_hamming_2d(const uint32_t *src, const uint32_t *tgt, int H, int Ws, int Wt, int nW, int lower0, int Dh,
+                                 int lower1, int Dw, float *cv) {
+#pragma omp parallel
+    {
+        uint32_t *tv = (uint32_t *)malloc((size_t)nW * sizeof(uint32_t));
+#pragma omp for
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < Ws; j++) {
+                const uint32_t *sv = src + ((size_t)i * Ws + j) * nW;
+                for (int dh = 0; dh < Dh; dh++)
+                    for (int dw = 0; dw < Dw; dw++) {
+                        int it = i + dh + lower0, jt = j + dw + lower1;
+                        int in = it >= 0 && it < H && jt >= 0 && jt < Wt;
+                        for (int w = 0; w < nW; w++)
+                            tv[w] = so_round_word_through_float(in ? tgt[((size_t)it * Wt + jt) * nW + w] : 0u);
+                        cv[(((size_t)i * Ws + j) * Dh + dh) * Dw + dw] = cmp_hamming(sv, tv, nW);
+                    }
+            }
+        free(tv);
+    }
+}
+
+/* unfoldBased2dDisparityCostVolume, cross_correlations.h:794-822 (rows AND columns must agree, :801-810) */
+int so_unfold_cost_volume_2d(int func, const float *img_l, const float *img_r, int Hl, int Wl, int Hr, int Wr, int C, int h_r,
+                             int v_r, int ddir, int lower0, int upper0, int lower1, int upper1, float *cv) {
+    if (Hl != Hr || Wl != Wr) return 1;
+    int Dh = upper0 - lower0 + 1, Dw = upper1 - lower1 + 1;
+    if (Dh <= 0 || Dw <= 0 || !so_func_supported(func)) return 1; /* :338-340 */
+    int H = Hl, W = Wl, F = (2 * h_r + 1) * (2 * v_r + 1) * C;
+    float *fl = (float *)malloc((size_t)H * W * F * sizeof(float));
+    float *fr = (float *)malloc((size_t)H * W * F * sizeof(float));
+    if (!fl || !fr) { free(fl); free(fr); return 2; }
+    so_unfold(img_l, H, W, C, h_r, v_r, NULL, fl);
+    so_unfold(img_r, H, W, C, h_r, v_r, NULL, fr);
+    const float *src = (ddir == SO_RIGHT_TO_LEFT) ? fr : fl, *tgt = (ddir == SO_RIGHT_TO_LEFT) ? fl : fr;
+    if (func_census(func)) {
+        if (F <= 1) { free(fl); free(fr); return 1; }
+        int nW = so_census_words(F);
+        uint32_t *ws = (uint32_t *)malloc((size_t)H * W * nW * sizeof(uint32_t));
+        uint32_t *wt = (uint32_t *)malloc((size_t)H * W * nW * sizeof(uint32_t));
+        so_census_features(src, H, W, F, ws);
+        so_census_features(tgt, H, W, F, wt);
+        aggregate_hamming_2d(ws, wt, H, W, W, nW, lower0, Dh, lower1, Dw, cv);
+        free(ws);
+        free(wt);
+    } else {
+        float *ps = (float *)malloc((size_t)H * W * F * sizeof(float));
+        float *pt = (float *)malloc((size_t)H * W * F * sizeof(float));
+        processed_features(func, src, H, W, F, ps);
+        processed_features(func, tgt, H, W, F, pt);
+        aggregate_float_2d(func, ps, pt, H, W, W, F, lower0, Dh, lower1, Dw, cv);
+        free(ps);
+        free(pt);
+    }
+    free(fl);
+    free(fr);
+    return 0;
+}
+
+/* extractSelected2dIndex, correlation_base.h:466-509: scan (d1, d2) in row-major order with <= / >=, starting from
+ * cv(i,j,0,0): the last extremum wins.  idx is [H][W][2]. */
+void so_extract_index_2d(int strategy, const float *cv, int H, int W, int D1, int D2, int32_t *idx) {
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            const float *p = cv + ((size_t)i * W + j) * D1 * D2;
+            float sel = p[0];
+            int32_t s1 = 0, s2 = 0;
+            for (int d1 = 0; d1 < D1; d1++)
+                for (int d2 = 0; d2 < D2; d2++) {
+                    float v = p[d1 * D2 + d2];
+                    if (strategy == SO_COST ? (v <= sel) : (v >= sel)) { sel = v; s1 = d1; s2 = d2; }
+                }
+            idx[((size_t)i * W + j) * 2] = s1;
+            idx[((size_t)i * W + j) * 2 + 1] = s2;
+        }
+}
+
+/* selected2dIndexToDisp, correlation_base.h:534-555 */
+void so_index_2d_to_disp(const int32_t *idx, int H, int W, int lower0, int lower1, int32_t *disp) {
+    for (size_t p = 0; p < (size_t)H * W; p++) {
+        disp[2 * p] = idx[2 * p] + lower0;
+        disp[2 * p + 1] = idx[2 * p + 1] + lower1;
+    }
+}
+
+/* truncatedBidirectionaCostVolume, correlation_base.h:677-725 (explicit radii); tcv is [H][W][2r0+1][2r1+1] */
+void so_truncated_bidirectional_cv(const float *cv, const int32_t *idx, int H, int W, int D1, int D2, int r0, int r1, float *tcv) {
+    int T0 = 2 * r0 + 1, T1 = 2 * r1 + 1;
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            size_t px = (size_t)i * W + j;
+            for (int d0 = 0; d0 < T0; d0++) {
+                int p0 = idx[2 * px] + d0 - r0;
+                for (int d1 = 0; d1 < T1; d1++) {
+                    int p1 = idx[2 * px + 1] + d1 - r1;
+                    tcv[(px * T0 + d0) * T1 + d1] = (p0 >= 0 && p0 < D1 && p1 >= 0 && p1 < D2) ? cv[(px * D1 + p0) * D2 + p1] : nanf("");
+                }
+            }
+        }
+}

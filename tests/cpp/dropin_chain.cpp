@@ -62,6 +62,17 @@ int main(int argc, char **argv) {
         dump(out + "_ncc_idx.i32", rawDisp.data(), rawDisp.flatLenght());
         dump(out + "_ncc_refined.f32", refined.data(), refined.flatLenght());
     }
+    { // 2-D disparity volume + winner, as test/unittests/testCorrelation2d.cpp:166-175 chains them
+        constexpr auto matchFunc = SC::matchingFunctions::ZNCC;
+        constexpr auto strat = SC::MatchingFunctionTraits<matchFunc>::extractionStrategy;
+        SC::searchOffset<2> searchRange(-1, 2, -2, 3);
+        Multidim::Array<float, 4> CV2 = SC::unfoldBased2dDisparityCostVolume<matchFunc>(target, source, 2, 2, searchRange);
+        Multidim::Array<SC::disp_t, 3> disp2 = SC::selected2dIndexToDisp(SC::extractSelected2dIndex<strat>(CV2), searchRange);
+        auto tcv2 = SC::truncatedBidirectionaCostVolume(CV2, SC::extractSelected2dIndex<strat>(CV2), 1, 1);
+        dump(out + "_zncc2d_cv.f32", CV2.data(), CV2.flatLenght());
+        dump(out + "_zncc2d_disp.i32", disp2.data(), disp2.flatLenght());
+        if (tcv2.shape()[2] != 3 || tcv2.shape()[3] != 3) return 4;
+    }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);
     auto empty = SC::unfoldBasedCostVolume<SC::matchingFunctions::SAD>(target, shorter, h_r, v_r, D);

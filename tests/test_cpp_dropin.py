@@ -42,6 +42,11 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(got_vol.view(np.uint32), vol.view(np.uint32))
     got_disp = np.fromfile(tmp_path / "o_census_disp.i32", np.int32).reshape(H, W)
     assert np.array_equal(got_disp, so.index_to_disp(so.extract_index(vol, so.COST)))
+    cv2 = so.unfold_cost_volume_2d(so.ZNCC, tgt, src, 2, 2, (-1, 2), (-2, 3))
+    got2 = np.fromfile(tmp_path / "o_zncc2d_cv.f32", np.float32).reshape(cv2.shape)
+    assert np.array_equal(np.isnan(got2), np.isnan(cv2)) and np.nanmax(np.abs(got2 - cv2)) <= 1e-4
+    disp2 = np.fromfile(tmp_path / "o_zncc2d_disp.i32", np.int32).reshape(H, W, 2)
+    assert np.array_equal(disp2, so.index_2d_to_disp(so.extract_index_2d(got2, so.SCORE), -1, -2))
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

@@ -98,3 +98,46 @@ def test_planted_disparity_is_recovered():
         # census is weaker by construction: 32 of the 48 comparisons survive (census.h:103-108) and the target
         # word loses its low bits in the float round trip (cross_correlations.h:235-236)
         assert (disp[inner] == gt[inner]).mean() > (0.8 if f == so.CENSUS else 0.97)
+
+
+# ---- 2-D disparity volumes: testCorrelation2d.cpp ------------------------------------------------------------------
+SHAPES_2D = [(1, 1, 5, 5), (3, 3, 5, 5), (5, 1, 5, 3), (1, 5, 3, 5), (5, 5, 5, 5)]
+
+
+@pytest.mark.parametrize("h_r,v_r,disp_w,disp_h", SHAPES_2D)
+@pytest.mark.parametrize("name", ["NCC", "ZNCC", "SSD", "ZSSD", "SAD", "ZSAD"])
+def test_2d_matching(rng, name, h_r, v_r, disp_w, disp_h):
+    """test2dMatching (testCorrelation2d.cpp:75-127): CV(v_r, h_r, i, j) of unfoldBased2dDisparityCostVolume with
+    searchOffset<2>(0, disp_h, 0, disp_w) equals the naive formula on right[0:2v+1, 0:2h+1] vs left[i:.., j:..], 1e-3."""
+    h, w = 2 * v_r + disp_h + 1, 2 * h_r + disp_w + 1
+    left = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    right = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    cv = so.unfold_cost_volume_2d(FUNCS[name], left, right, h_r, v_r, (0, disp_h), (0, disp_w))
+    assert cv.shape == (h, w, disp_h + 1, disp_w + 1)
+    w1 = right[0:2 * v_r + 1, 0:2 * h_r + 1]
+    for i in range(disp_h):
+        for j in range(disp_w):
+            w2 = left[i:i + 2 * v_r + 1, j:j + 2 * h_r + 1]
+            assert abs(naive_window_cost(name, w1, w2) - cv[v_r, h_r, i, j]) < 1e-3
+
+
+@pytest.mark.parametrize("h_r,v_r", [(1, 1), (3, 3), (5, 1), (1, 5)])
+@pytest.mark.parametrize("name", ["NCC", "ZNCC", "SSD", "ZSSD", "SAD", "ZSAD"])
+def test_2d_disparity(rng, name, h_r, v_r):
+    """test2dDisparity (testCorrelation2d.cpp:131-191): a planted shift is recovered by extractSelected2dIndex +
+    selected2dIndexToDisp, for Score and Cost functions, at both ends of the search range."""
+    disp_w = disp_h = 3
+    h, w = 2 * v_r + disp_h + 1, 2 * h_r + disp_w + 1
+    source = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    target0 = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    targetmax = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    for i in range(2 * v_r + 1):
+        for j in range(2 * h_r + 1):
+            target0[i, j] = source[i + 1, j + 1]
+            targetmax[i + disp_h, j + disp_w] = source[i + 1, j + 1]
+    rng0, rng1 = (-1, disp_h - 1), (-1, disp_w - 1)
+    strat = so.func_strategy(FUNCS[name])
+    for target, expected in ((target0, (-1, -1)), (targetmax, (disp_h - 1, disp_w - 1))):
+        cv = so.unfold_cost_volume_2d(FUNCS[name], target, source, h_r, v_r, rng0, rng1)
+        disp = so.index_2d_to_disp(so.extract_index_2d(cv, strat), rng0[0], rng1[0])
+        assert tuple(disp[v_r + 1, h_r + 1]) == expected

@@ -179,6 +179,20 @@ int svh_selected_2d_index_to_disp(svh_context *ctx, const svh_array *idx, int32_
 int svh_truncated_bidirectional_cost_volume(svh_context *ctx, const svh_array *cv, const svh_array *idx, int radius0, int radius1,
                                             svh_array *tcv);
 
+/* ---- 2-D cost-based refinement: SURVEY.md section 8(f) rank 1 (the refinement examples/stereo-match --refine calls,
+ * examples/stereo-match/main.cpp:198-210) ------------------------------------------------------------------------------
+ * refineDisp2dCostInterpolation<kernel, isotropHypothesis>(tcv, raw)          correlation/cost_based_refinement.h:165-376
+ * tcv (H,W,2r0+1,2r1+1) f32, raw (H,W,2) i32 -> refined (H,W,2) f32 = raw + (delta0, delta1); both deltas are zeroed when
+ * either is NaN or larger than 1 in magnitude (:362-366).  Isotropic: one refineCostTriplet per axis through the centre;
+ * anisotropic: the two fitted extremum lines are intersected (:270-358).  Radii < 1 or even depths -> SVH_EMPTY_RESULT. */
+typedef enum svh_isotropy { SVH_ISOTROPIC = 0, SVH_ANISOTROPIC = 1 } svh_isotropy; /* IsotropyHypothesis, :37-41 */
+int svh_refine_disp_2d_cost_interpolation(svh_context *ctx, int interp_kernel, int isotropy, const svh_array *tcv, const svh_array *raw,
+                                          svh_array *refined);
+/* refineDisp2dCostPatchInterpolation<Parabola|Gaussian>(tcv, raw): least-squares quadric through the central 3x3 patch
+ * (refineCostPatch, :71-126) and its stationary point                              correlation/cost_based_refinement.h:378-436 */
+int svh_refine_disp_2d_cost_patch_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
+                                                svh_array *refined);
+
 /* ---- fused pipeline: the benchmark / stereo_refine_test call chain kept on the device ------------------
  * unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp
  *   (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294)

@@ -28,7 +28,7 @@ EXPORTS = [
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
-    "svh_truncated_bidirectional_cost_volume",
+    "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
 ]
 
 
@@ -127,6 +127,8 @@ def load():
         "svh_extract_selected_2d_index": (C.c_int, [ctx, C.c_int, A, A]),
         "svh_selected_2d_index_to_disp": (C.c_int, [ctx, A, i32, i32, A]),
         "svh_truncated_bidirectional_cost_volume": (C.c_int, [ctx, A, A, C.c_int, C.c_int, A]),
+        "svh_refine_disp_2d_cost_interpolation": (C.c_int, [ctx, C.c_int, C.c_int, A, A, A]),
+        "svh_refine_disp_2d_cost_patch_interpolation": (C.c_int, [ctx, C.c_int, A, A, A]),
         "svh_census_shard_keys": (C.c_int, [ctx, P(SvhStereoParams), A, A, A]),
         "svh_census_shard_finish": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A]),
     }

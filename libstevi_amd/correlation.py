@@ -51,6 +51,11 @@ class InterpolationKernel(enum.IntEnum):  # correlation/cost_based_refinement.h:
     Gaussian = 2
 
 
+class IsotropyHypothesis(enum.IntEnum):  # correlation/cost_based_refinement.h:37-41
+    Isotropic = 0
+    Anisotropic = 1
+
+
 class Margins:  # utils/margins.h:24-92
     def __init__(self, *a):
         if len(a) == 0:
@@ -508,6 +513,27 @@ def truncatedBidirectionaCostVolume(costVolume, selectedIndex, cost_vol_radius0,
     _check(ctx, lib.svh_truncated_bidirectional_cost_volume(ctx, C.byref(_desc(cv)), C.byref(_desc(idx)), cost_vol_radius0, cost_vol_radius1,
                                                             C.byref(_desc(out))))
     return out
+
+
+def refineDisp2dCostInterpolation(kernel, truncatedCostVolume, rawDisparity, isotropHypothesis=IsotropyHypothesis.Isotropic):
+    """refineDisp2dCostInterpolation<kernel, isotropHypothesis> -- correlation/cost_based_refinement.h:165-376."""
+    lib = _capi.load()
+    tcv, raw = _prep(truncatedCostVolume, np.float32), _prep(rawDisparity, np.int32)
+    ctx = context_for(tcv)
+    out = _like(tcv, tuple(raw.shape), "f32")
+    st = _check(ctx, lib.svh_refine_disp_2d_cost_interpolation(ctx, int(kernel), int(isotropHypothesis), C.byref(_desc(tcv)), C.byref(_desc(raw)),
+                                                               C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(tcv, 3, "f32")
+
+
+def refineDisp2dCostPatchInterpolation(kernel, truncatedCostVolume, rawDisparity):
+    """refineDisp2dCostPatchInterpolation<kernel> -- correlation/cost_based_refinement.h:378-436 (Parabola / Gaussian)."""
+    lib = _capi.load()
+    tcv, raw = _prep(truncatedCostVolume, np.float32), _prep(rawDisparity, np.int32)
+    ctx = context_for(tcv)
+    out = _like(tcv, tuple(raw.shape), "f32")
+    st = _check(ctx, lib.svh_refine_disp_2d_cost_patch_interpolation(ctx, int(kernel), C.byref(_desc(tcv)), C.byref(_desc(raw)), C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(tcv, 3, "f32")
 
 
 def set_option(x, name, value):

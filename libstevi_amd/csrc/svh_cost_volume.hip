@@ -171,18 +171,21 @@ __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_
     const int it = i + row_off;
     const bool row_in = it >= 0 && it < H; // a target row outside the image is the zero vector
     const uint32_t *trow = tw + (int64_t)(row_in ? it : 0) * Wt * NW;
+    uint32_t *lsrc = lds + n_rec * NW; // the tile's source records: no global load inside the store loop
     for (int e = threadIdx.x; e < n_rec * NW; e += blockDim.x) {
         const int y = e / NW, w = e - y * NW;
         const int jt = sign > 0 ? j0 + disp_lower + y : j0 + (HV_TP - 1) - disp_lower - y;
         lds[e] = (row_in && jt >= 0 && jt < Wt) ? trow[(int64_t)jt * NW + w] : 0u;
     }
+    const int n_src = min(HV_TP, Ws - j0) * NW;
+    for (int e = threadIdx.x; e < n_src; e += blockDim.x) lsrc[e] = sw[((int64_t)i * Ws + j0) * NW + e];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int u = wave; u < HV_TP && j0 + u < Ws; u += 4) {
         const int64_t p = (int64_t)i * Ws + j0 + u;
         uint32_t s[NW];
 #pragma unroll
-        for (int w = 0; w < NW; w++) s[w] = sw[p * NW + w];
+        for (int w = 0; w < NW; w++) s[w] = lsrc[u * NW + w];
         const uint32_t *base = lds + (sign > 0 ? u : HV_TP - 1 - u) * NW;
         float *out = cv + p * px_stride + out_off;
         for (int d = lane; d < D; d += 64) {
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_
 template <int NW>
 static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *sw, const uint32_t *tw, int sign, float *cv) {
     dim3 grid(ceil_div(a.Ws, HV_TP), a.H);
-    const size_t shmem = (size_t)NW * (HV_TP + a.D - 1) * sizeof(uint32_t);
+    const size_t shmem = (size_t)NW * (2 * HV_TP + a.D - 1) * sizeof(uint32_t);
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off,
                a.px_stride(), a.out_off, cv);
 }
@@ -265,7 +268,7 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
     int64_t n = (int64_t)a.H * a.Ws * a.D;
     if (n == 0) return SVH_OK;
     int sign = a.sign();
-    if (nWw >= 1 && nWw <= 4 && (size_t)nWw * (HV_TP + a.D - 1) * sizeof(uint32_t) <= 60 * 1024) {
+    if (nWw >= 1 && nWw <= 4 && (size_t)nWw * (2 * HV_TP + a.D - 1) * sizeof(uint32_t) <= 60 * 1024) {
         switch (nWw) {
         case 1: launch_hamming_tiled<1>(ctx, a, src_words, tgt_words, sign, cv); break;
         case 2: launch_hamming_tiled<2>(ctx, a, src_words, tgt_words, sign, cv); break;
@@ -440,6 +443,9 @@ extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int d
             SVH_TRY(dev_hamming_volume(ctx, a, sw, tw, nWw, (float *)os.dptr));
         }
     } else {
+        WindowStatsCache stats; // means / norms / zero-target costs do not depend on the offset: computed by the first pass
+        stats.scr = &scr;
+        a.stats = &stats;
         for (int dh = 0; dh < Dh; dh++) {
             a.tgt_row_off = lower0 + dh;
             a.out_off = (int64_t)dh * Dw;

@@ -202,26 +202,33 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
     const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
     const int cmp = (a.func == SVH_SSD || a.func == SVH_ZSSD) ? T_SSD : (a.func == SVH_SAD || a.func == SVH_ZSAD) ? T_SAD : T_DOT;
     const size_t ns_px = (size_t)a.H * a.Ws, nt_px = (size_t)a.H * a.Wt;
-    float *ms = nullptr, *mt = nullptr, *ns = nullptr, *nt = nullptr;
-    float *zc = scr.get_n<float>(ns_px);
-    if (!zc) return SVH_ERR_OUT_OF_MEMORY;
-    if (zm) {
-        ms = scr.get_n<float>(ns_px);
-        mt = scr.get_n<float>(nt_px);
-        if (!ms || !mt) return SVH_ERR_OUT_OF_MEMORY;
-    }
-    if (nrm) {
-        ns = scr.get_n<float>(ns_px);
-        nt = scr.get_n<float>(nt_px);
-        if (!ns || !nt) return SVH_ERR_OUT_OF_MEMORY;
-    }
-    const int gs = grid_for((int64_t)ns_px, 256, 16384), gt = grid_for((int64_t)nt_px, 256, 16384);
-#define SVH_STATS(CMPV)                                                                                                                  \
-    SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gs, 256, 0, src.data, src.H, src.W, h_r, v_r, zm, nrm, ms, ns, zc);         \
-    if (zm || nrm) SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gt, 256, 0, tgt.data, tgt.H, tgt.W, h_r, v_r, zm, nrm, mt, nt, (float *)nullptr);
-    if (cmp == T_DOT) { SVH_STATS(T_DOT) } else if (cmp == T_SSD) { SVH_STATS(T_SSD) } else { SVH_STATS(T_SAD) }
+    WindowStatsCache local;
+    WindowStatsCache &st = a.stats ? *a.stats : local;
+    if (!st.ready) {
+        Scratch &owner = st.scr ? *st.scr : scr;
+        st.zc = owner.get_n<float>(ns_px);
+        if (!st.zc) return SVH_ERR_OUT_OF_MEMORY;
+        if (zm) {
+            st.ms = owner.get_n<float>(ns_px);
+            st.mt = owner.get_n<float>(nt_px);
+            if (!st.ms || !st.mt) return SVH_ERR_OUT_OF_MEMORY;
+        }
+        if (nrm) {
+            st.ns = owner.get_n<float>(ns_px);
+            st.nt = owner.get_n<float>(nt_px);
+            if (!st.ns || !st.nt) return SVH_ERR_OUT_OF_MEMORY;
+        }
+        const int gs = grid_for((int64_t)ns_px, 256, 16384), gt = grid_for((int64_t)nt_px, 256, 16384);
+#define SVH_STATS(CMPV)                                                                                                                        \
+    SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gs, 256, 0, src.data, src.H, src.W, h_r, v_r, zm, nrm, st.ms, st.ns, st.zc);      \
+    if (zm || nrm)                                                                                                                             \
+        SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gt, 256, 0, tgt.data, tgt.H, tgt.W, h_r, v_r, zm, nrm, st.mt, st.nt, (float *)nullptr);
+        if (cmp == T_DOT) { SVH_STATS(T_DOT) } else if (cmp == T_SSD) { SVH_STATS(T_SSD) } else { SVH_STATS(T_SAD) }
 #undef SVH_STATS
-    SVH_CHECK_LAUNCH(ctx);
+        SVH_CHECK_LAUNCH(ctx);
+        st.ready = true;
+    }
+    float *ms = st.ms, *mt = st.mt, *ns = st.ns, *nt = st.nt, *zc = st.zc;
     const int sign = a.sign();
     bool ok;
     if (cmp == T_DOT) ok = zm ? dispatch_hr<T_DOT, true>(ctx, h_r, a, src.data, tgt.data, v_r, sign, ms, mt, ns, nt, zc, cv, shmem)

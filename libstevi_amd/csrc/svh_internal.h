@@ -158,6 +158,12 @@ int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, 
                              uint32_t *words);
 
 // cost volume (H, Ws, D) from feature volumes or images
+// per-pixel window statistics of an image pair, kept across the vertical offsets of a 2-D volume
+struct WindowStatsCache {
+    Scratch *scr = nullptr; // owner of the maps (must outlive the passes)
+    bool ready = false;
+    float *ms = nullptr, *mt = nullptr, *ns = nullptr, *nt = nullptr, *zc = nullptr;
+};
 struct CostVolumeArgs {
     int func, ddir;
     int H, Ws, Wt;
@@ -169,6 +175,7 @@ struct CostVolumeArgs {
     int force_sign = 0;          // 0: +1 for RightToLeft, -1 for LeftToRight
     int64_t out_px_stride = 0;   // 0: D
     int64_t out_off = 0;
+    WindowStatsCache *stats = nullptr; // optional: statistics maps shared by several passes over the same image pair
     int sign() const { return force_sign ? force_sign : (ddir == SVH_RIGHT_TO_LEFT ? 1 : -1); }
     int64_t px_stride() const { return out_px_stride ? out_px_stride : D; }
 };

@@ -193,6 +193,111 @@ __global__ void truncated_bidirectional_kernel(const float *__restrict__ cv, con
     }
 }
 
+// ---- 2-D cost-based refinement (what examples/stereo-match --refine calls) -------------
+// refineDisp2dCostInterpolation<kernel, isotropy>, cost_based_refinement.h:165-376.  One lane per pixel; tcv is
+// (pixel, T0, T1), raw / refined (pixel, 2).  The score / cost nature of the volume is probed at the centre pixel like the
+// reference does (:184-203; every comparison with a NaN is false).
+template <bool ANISO>
+__global__ void refine_2d_kernel(int kernel, const float *__restrict__ tcv, const int32_t *__restrict__ raw, int64_t npx, int64_t centre_px, int T0,
+                                 int T1, float *__restrict__ refined) {
+    const int r0 = (T0 - 1) / 2, r1 = (T1 - 1) / 2;
+    bool is_score = false;
+    if (ANISO) {
+        const float *c = tcv + centre_px * T0 * T1;
+        const float v0 = c[r0 * T1 + r1];
+        is_score = v0 > c[(r0 + 1) * T1 + r1] || v0 > c[(r0 - 1) * T1 + r1] || v0 > c[r0 * T1 + r1 + 1] || v0 > c[r0 * T1 + r1 - 1];
+    }
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const float *t = tcv + p * T0 * T1;
+        auto at = [&](int a, int b) { return t[a * T1 + b]; };
+        float delta0, delta1;
+        const float d0c = refine_triplet(kernel, at(r0 - 1, r1), at(r0, r1), at(r0 + 1, r1));
+        const float d1c = refine_triplet(kernel, at(r0, r1 - 1), at(r0, r1), at(r0, r1 + 1));
+        if (!ANISO) { // :257-268
+            delta0 = d0c;
+            delta1 = d1c;
+        } else {
+            // extremum along axis 0 inside columns r1 -+ 1 (argminForRow, :205-225) and along axis 1 inside rows r0 -+ 1
+            // (argminForCol, :227-247): '<=' / '>=' scans from +-inf, last extremum wins, NaN never selected, default 0
+            int am[4];
+#pragma unroll
+            for (int which = 0; which < 4; which++) {
+                const int fixed = which == 0 ? r1 - 1 : which == 1 ? r1 + 1 : which == 2 ? r0 - 1 : r0 + 1;
+                const int n = which < 2 ? T0 : T1;
+                float hat = is_score ? -INFINITY : INFINITY;
+                int arg = 0;
+                for (int a = 0; a < n; a++) {
+                    const float v = which < 2 ? at(a, fixed) : at(fixed, a);
+                    if (is_score ? (v >= hat) : (v <= hat)) {
+                        hat = v;
+                        arg = a;
+                    }
+                }
+                am[which] = arg;
+            }
+            float d0_0 = d0c, d0_2 = d0c, d1_0 = d1c, d1_2 = d1c;
+            if (am[0] > 0 && am[0] < T0 - 1) d0_0 = am[0] - r0 + refine_triplet(kernel, at(am[0] - 1, r1 - 1), at(am[0], r1 - 1), at(am[0] + 1, r1 - 1));
+            if (am[1] > 0 && am[1] < T0 - 1) d0_2 = am[1] - r0 + refine_triplet(kernel, at(am[1] - 1, r1 + 1), at(am[1], r1 + 1), at(am[1] + 1, r1 + 1));
+            if (am[2] > 0 && am[2] < T1 - 1) d1_0 = am[2] - r1 + refine_triplet(kernel, at(r0 - 1, am[2] - 1), at(r0 - 1, am[2]), at(r0 - 1, am[2] + 1));
+            if (am[3] > 0 && am[3] < T1 - 1) d1_2 = am[3] - r1 + refine_triplet(kernel, at(r0 + 1, am[3] - 1), at(r0 + 1, am[3]), at(r0 + 1, am[3] + 1));
+            // the two fitted lines delta0 = a0 delta1 + b0 and delta1 = a1 delta0 + b1, and their intersection (:310-358)
+            const float a0 = (d0_2 - d0_0) / 2, b0 = (d0_0 + d0c + d0_2) / 3;
+            const float a1 = (d1_2 - d1_0) / 2, b1 = (d1_0 + d1c + d1_2) / 3;
+            delta0 = (a0 * b1 + b0) / (1 - a0 * a1);
+            delta1 = (a1 * b0 + b1) / (1 - a0 * a1);
+        }
+        if (fabsf(delta0) > 1 || fabsf(delta1) > 1 || isnan(delta0) || isnan(delta1)) { // :362-366
+            delta0 = 0;
+            delta1 = 0;
+        }
+        refined[2 * p] = (float)raw[2 * p] + delta0;
+        refined[2 * p + 1] = (float)raw[2 * p + 1] + delta1;
+    }
+}
+
+// refineDisp2dCostPatchInterpolation<Parabola|Gaussian>, cost_based_refinement.h:378-436 with refineCostPatch (:71-126).
+// The reference solves the 9x6 least-squares system numerically for every pixel; the design matrix is constant, so the
+// normal equations have the closed form below (v, h in {-1,0,1}: S = sum L, Sv = sum v^2 L, Sh = sum h^2 L):
+//     f_vv = Sv/2 - S/3   f_vh = (sum v h L)/4   f_hh = Sh/2 - S/3   f_v = (sum v L)/6   f_h = (sum h L)/6
+// evaluated on L - L(0,0) (the five parameters do not depend on a constant offset; this keeps the cancellation small).
+// Stationary point: [2 f_vv, f_vh; f_vh, 2 f_hh]^-1 [-f_v, -f_h] as adjugate / determinant (:109-116).
+__global__ void refine_2d_patch_kernel(int kernel, const float *__restrict__ tcv, const int32_t *__restrict__ raw, int64_t npx, int T0, int T1,
+                                       float *__restrict__ refined) {
+    const int r0 = (T0 - 1) / 2, r1 = (T1 - 1) / 2;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const float *t = tcv + p * T0 * T1;
+        float L[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const float c = t[(r0 - 1 + a) * T1 + r1 - 1 + b];
+                L[a][b] = kernel == SVH_GAUSSIAN ? logf(c) : c; // :119-121
+            }
+        const float c00 = L[1][1];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) L[a][b] -= c00;
+        const float top = L[0][0] + L[0][1] + L[0][2], mid = L[1][0] + L[1][1] + L[1][2], bot = L[2][0] + L[2][1] + L[2][2];
+        const float lft = L[0][0] + L[1][0] + L[2][0], rgt = L[0][2] + L[1][2] + L[2][2];
+        const float S = top + mid + bot;
+        const float fvv = 0.5f * (top + bot) - S / 3.0f, fhh = 0.5f * (lft + rgt) - S / 3.0f;
+        const float fvh = 0.25f * ((L[0][0] + L[2][2]) - (L[0][2] + L[2][0]));
+        const float fv = (bot - top) / 6.0f, fh = (rgt - lft) / 6.0f;
+        const float m00 = 2 * fvv, m01 = fvh, m11 = 2 * fhh;
+        const float invdet = 1.0f / (m00 * m11 - m01 * m01);
+        float delta0 = (m11 * invdet) * (-fv) + (-m01 * invdet) * (-fh);
+        float delta1 = (-m01 * invdet) * (-fv) + (m00 * invdet) * (-fh);
+        if (fabsf(delta0) > 1 || fabsf(delta1) > 1 || isnan(delta0) || isnan(delta1)) { // :424-428
+            delta0 = 0;
+            delta1 = 0;
+        }
+        refined[2 * p] = (float)raw[2 * p] + delta0;
+        refined[2 * p + 1] = (float)raw[2 * p + 1] + delta1;
+    }
+}
+
 int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
                       unsigned long long *keys, int key_index_offset, int key_total_D) {
     if (n_pixels == 0) return SVH_OK;
@@ -443,6 +548,73 @@ extern "C" int svh_truncated_bidirectional_cost_volume(svh_context *ctx, const s
     if (n) {
         SVH_LAUNCH(ctx, "truncated_bidirectional", truncated_bidirectional_kernel, grid_for(n, 256, 16384), 256, 0, (const float *)dcv,
                    (const int32_t *)di, npx, (int)cv->shape[2], (int)cv->shape[3], radius0, radius1, (float *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return finish_out(ctx, os);
+}
+
+// ---- 2-D cost-based refinement -------------------------------------------------------
+static int refine_2d_common(svh_context *ctx, const svh_array *tcv, const svh_array *raw, svh_array *refined, int *T0, int *T1) {
+    SVH_TRY(validate(ctx, tcv, "tcv", SVH_F32, 4, 4));
+    SVH_TRY(validate(ctx, raw, "raw", SVH_I32, 3, 3));
+    SVH_TRY(validate(ctx, refined, "refined", SVH_F32, 3, 3));
+    *T0 = (int)tcv->shape[2];
+    *T1 = (int)tcv->shape[3];
+    const int r0 = (*T0 - 1) / 2, r1 = (*T1 - 1) / 2;
+    if (r0 < 1 || r1 < 1 || 2 * r0 + 1 != *T0 || 2 * r1 + 1 != *T1) // cost_based_refinement.h:180-182, :393-395
+        return fail(ctx, SVH_EMPTY_RESULT, "truncated volume must be (H, W, 2r0+1, 2r1+1) with r0, r1 >= 1");
+    if (raw->shape[2] != 2 || raw->shape[0] != tcv->shape[0] || raw->shape[1] != tcv->shape[1])
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "raw must have shape (H, W, 2)");
+    if (refined->shape[0] != raw->shape[0] || refined->shape[1] != raw->shape[1] || refined->shape[2] != 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "refined must have shape (H, W, 2)");
+    return SVH_OK;
+}
+
+extern "C" int svh_refine_disp_2d_cost_interpolation(svh_context *ctx, int interp_kernel, int isotropy, const svh_array *tcv, const svh_array *raw,
+                                                     svh_array *refined) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    int T0, T1;
+    SVH_TRY(refine_2d_common(ctx, tcv, raw, refined, &T0, &T1));
+    if (interp_kernel < SVH_EQUIANGULAR || interp_kernel > SVH_GAUSSIAN) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad interpolation kernel");
+    if (isotropy != SVH_ISOTROPIC && isotropy != SVH_ANISOTROPIC) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad isotropy hypothesis");
+    const int64_t H = tcv->shape[0], W = tcv->shape[1], npx = H * W;
+    Scratch scr(ctx);
+    void *dt, *dr;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *tcv, &dt));
+    SVH_TRY(stage_in(ctx, scr, *raw, &dr));
+    SVH_TRY(stage_out(ctx, scr, *refined, &os));
+    if (npx) {
+        const int64_t centre = (H / 2) * W + W / 2; // cv_shape[0]/2, cv_shape[1]/2 (:186-190)
+        const int grid = grid_for(npx, 256, 8192);
+        if (isotropy == SVH_ANISOTROPIC)
+            SVH_LAUNCH(ctx, "refine_disp_2d", refine_2d_kernel<true>, grid, 256, 0, interp_kernel, (const float *)dt, (const int32_t *)dr, npx, centre, T0,
+                       T1, (float *)os.dptr);
+        else
+            SVH_LAUNCH(ctx, "refine_disp_2d", refine_2d_kernel<false>, grid, 256, 0, interp_kernel, (const float *)dt, (const int32_t *)dr, npx, centre, T0,
+                       T1, (float *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return finish_out(ctx, os);
+}
+
+extern "C" int svh_refine_disp_2d_cost_patch_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
+                                                           svh_array *refined) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    int T0, T1;
+    SVH_TRY(refine_2d_common(ctx, tcv, raw, refined, &T0, &T1));
+    if (interp_kernel != SVH_PARABOLA && interp_kernel != SVH_GAUSSIAN) // static_assert, cost_based_refinement.h:83
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "patch refinement supports the Parabola and Gaussian kernels only");
+    const int64_t npx = tcv->shape[0] * tcv->shape[1];
+    Scratch scr(ctx);
+    void *dt, *dr;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *tcv, &dt));
+    SVH_TRY(stage_in(ctx, scr, *raw, &dr));
+    SVH_TRY(stage_out(ctx, scr, *refined, &os));
+    if (npx) {
+        SVH_LAUNCH(ctx, "refine_disp_2d_patch", refine_2d_patch_kernel, grid_for(npx, 256, 8192), 256, 0, interp_kernel, (const float *)dt,
+                   (const int32_t *)dr, npx, T0, T1, (float *)os.dptr);
         SVH_CHECK_LAUNCH(ctx);
     }
     return finish_out(ctx, os);

@@ -1,4 +1,5 @@
-// Drop-in for LibStevi's correlation/cost_based_refinement.h (1-D part; the 2-D Eigen-based variants are out of scope).
+// Drop-in for LibStevi's correlation/cost_based_refinement.h: the 1-D refinement and the three 2-D variants (no Eigen needed:
+// the 3x3 patch fit has a closed form on the device).
 #ifndef STEREOVISION_COST_BASED_REFINEMENT_H
 #define STEREOVISION_COST_BASED_REFINEMENT_H
 
@@ -25,6 +26,41 @@ Multidim::Array<float, 2> refineDispCostInterpolation(Multidim::Array<float, 3> 
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out)))
         return Multidim::Array<float, 2>();
+    return refined;
+}
+
+// refineDisp2dCostInterpolation<kernel, isotropHypothesis>(truncatedCostVolume, rawDisparity), cost_based_refinement.h:165-376
+template <InterpolationKernel kernel, IsotropyHypothesis isotropHypothesis = IsotropyHypothesis::Isotropic>
+Multidim::Array<float, 3> refineDisp2dCostInterpolation(Multidim::Array<float, 4> const &truncatedCostVolume, Multidim::Array<disp_t, 3> const &rawDisparity) {
+    auto cv_shape = truncatedCostVolume.shape();
+    int cv_radius0 = (cv_shape[2] - 1) / 2, cv_radius1 = (cv_shape[3] - 1) / 2;
+    if (cv_radius0 < 1 or cv_radius1 < 1 or 2 * cv_radius0 + 1 != cv_shape[2] or 2 * cv_radius1 + 1 != cv_shape[3])
+        return Multidim::Array<float, 3>(); // :180-182
+    Multidim::Array<float, 3> refined(rawDisparity.shape());
+    if (refined.empty()) return refined;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
+    if (!HipBridge::check(svh_refine_disp_2d_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), static_cast<int>(isotropHypothesis), &tcv,
+                                                                &raw, &out)))
+        return Multidim::Array<float, 3>();
+    return refined;
+}
+
+// refineDisp2dCostPatchInterpolation<kernel>(truncatedCostVolume, rawDisparity), cost_based_refinement.h:378-436
+template <InterpolationKernel kernel>
+Multidim::Array<float, 3> refineDisp2dCostPatchInterpolation(Multidim::Array<float, 4> const &truncatedCostVolume, Multidim::Array<disp_t, 3> const &rawDisparity) {
+    static_assert(kernel == InterpolationKernel::Parabola or kernel == InterpolationKernel::Gaussian,
+                  "Unsupported kernel used for patch cost refinement"); // :83
+    auto cv_shape = truncatedCostVolume.shape();
+    int cv_radius0 = (cv_shape[2] - 1) / 2, cv_radius1 = (cv_shape[3] - 1) / 2;
+    if (cv_radius0 < 1 or cv_radius1 < 1 or 2 * cv_radius0 + 1 != cv_shape[2] or 2 * cv_radius1 + 1 != cv_shape[3])
+        return Multidim::Array<float, 3>(); // :393-395
+    Multidim::Array<float, 3> refined(rawDisparity.shape());
+    if (refined.empty()) return refined;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
+    if (!HipBridge::check(svh_refine_disp_2d_cost_patch_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out)))
+        return Multidim::Array<float, 3>();
     return refined;
 }
 

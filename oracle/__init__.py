@@ -270,3 +270,25 @@ def truncated_bidirectional_cv(cv, idx, r0, r1):
     out = np.empty((H, W, 2 * r0 + 1, 2 * r1 + 1), np.float32)
     lib().so_truncated_bidirectional_cv(_p(cv), _p(idx), H, W, D1, D2, int(r0), int(r1), _p(out))
     return out
+
+
+# ---- 2-D cost-based refinement (what stereo-match --refine calls) ---------------------
+ISOTROPIC, ANISOTROPIC = 0, 1
+
+
+def refine_disp_2d(tcv, raw, kernel=PARABOLA, isotropy=ISOTROPIC):
+    tcv, raw = _f32(tcv), _i32(raw)
+    H, W, T0, T1 = tcv.shape
+    out = np.empty((H, W, 2), np.float32)
+    rc = lib().so_refine_disp_2d(int(kernel), int(isotropy), _p(tcv), _p(raw), H, W, T0, T1, _p(out))
+    return out if rc == 0 else np.empty((0, 0, 0), np.float32)
+
+
+def refine_disp_2d_patch(tcv, raw, kernel=PARABOLA):
+    tcv, raw = _f32(tcv), _i32(raw)
+    H, W, T0, T1 = tcv.shape
+    out = np.empty((H, W, 2), np.float32)
+    rc = lib().so_refine_disp_2d_patch(int(kernel), _p(tcv), _p(raw), H, W, T0, T1, _p(out))
+    if rc == 2:
+        raise ValueError("patch refinement supports the Parabola and Gaussian kernels only")
+    return out if rc == 0 else np.empty((0, 0, 0), np.float32)

@@ -816,3 +816,154 @@ void so_truncated_bidirectional_cv(const float *cv, const int32_t *idx, int H, i
             }
         }
 }
+
+/* ===== 2-D cost-based refinement: SURVEY.md section 8(f) rank 1 (the refinement stereo-match --refine calls) ========= */
+
+#define SO_ISOTROPIC 0
+#define SO_ANISOTROPIC 1
+
+/* refineCostPatch<Parabola|Gaussian>, cost_based_refinement.h:71-126: least-squares quadric through the 3x3 patch
+ * (parameters: v^2, v h, h^2, v, h, 1), fitted = ((A^T A)^-1 A^T) L in float, then the stationary point M^-1 v.
+ * The 6x6 inverse is a float Gauss-Jordan elimination with partial pivoting (Eigen's inverse() of a 6x6 goes through a
+ * partial-pivoting LU; A^T A holds small integers, so the two differ by rounding only); the 2x2 inverse is the
+ * adjugate times 1/det like Eigen's fixed-size 2x2 path. */
+static void so_refine_patch(int kernel, const float c[9], float delta[2]) {
+    float L[9];
+    for (int k = 0; k < 9; k++) L[k] = kernel == SO_GAUSSIAN ? logf(c[k]) : c[k]; /* :119-121 */
+    static const float vd[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, hd[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1}; /* :91-94 */
+    float A[9][6];
+    for (int i = 0; i < 9; i++) { /* :98-105 */
+        A[i][0] = vd[i] * vd[i];
+        A[i][1] = vd[i] * hd[i];
+        A[i][2] = hd[i] * hd[i];
+        A[i][3] = vd[i];
+        A[i][4] = hd[i];
+        A[i][5] = 1;
+    }
+    float N[6][12];
+    for (int r = 0; r < 6; r++)
+        for (int q = 0; q < 6; q++) {
+            float s = 0;
+            for (int i = 0; i < 9; i++) s += A[i][r] * A[i][q];
+            N[r][q] = s;
+            N[r][6 + q] = r == q ? 1.0f : 0.0f;
+        }
+    for (int col = 0; col < 6; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 6; r++)
+            if (fabsf(N[r][col]) > fabsf(N[piv][col])) piv = r;
+        if (piv != col)
+            for (int q = 0; q < 12; q++) { float t = N[col][q]; N[col][q] = N[piv][q]; N[piv][q] = t; }
+        float inv = 1.0f / N[col][col];
+        for (int q = 0; q < 12; q++) N[col][q] *= inv;
+        for (int r = 0; r < 6; r++) {
+            if (r == col) continue;
+            float f = N[r][col];
+            for (int q = 0; q < 12; q++) N[r][q] -= f * N[col][q];
+        }
+    }
+    float P[6][9]; /* (A^T A)^-1 A^T */
+    for (int r = 0; r < 6; r++)
+        for (int i = 0; i < 9; i++) {
+            float s = 0;
+            for (int q = 0; q < 6; q++) s += N[r][6 + q] * A[i][q];
+            P[r][i] = s;
+        }
+    float f[6];
+    for (int r = 0; r < 6; r++) {
+        float s = 0;
+        for (int i = 0; i < 9; i++) s += P[r][i] * L[i];
+        f[r] = s;
+    }
+    float m00 = 2 * f[0], m01 = f[1], m10 = f[1], m11 = 2 * f[2]; /* :109-111 */
+    float v0 = -f[3], v1 = -f[4];                                  /* :113-114 */
+    float invdet = 1.0f / (m00 * m11 - m10 * m01);
+    float i00 = m11 * invdet, i01 = -m01 * invdet, i10 = -m10 * invdet, i11 = m00 * invdet;
+    delta[0] = i00 * v0 + i01 * v1;
+    delta[1] = i10 * v0 + i11 * v1;
+}
+
+/* refineDisp2dCostInterpolation<kernel, isotropy>, cost_based_refinement.h:165-376.  tcv [H][W][T0][T1], raw and refined
+ * [H][W][2].  Returns 1 for the shapes the reference answers with an empty array (:180-182). */
+int so_refine_disp_2d(int kernel, int isotropy, const float *tcv, const int32_t *raw, int H, int W, int T0, int T1, float *refined) {
+    int r0 = (T0 - 1) / 2, r1 = (T1 - 1) / 2;
+    if (r0 < 1 || r1 < 1 || 2 * r0 + 1 != T0 || 2 * r1 + 1 != T1) return 1;
+#define TCV(i, j, a, b) tcv[(((size_t)(i) * W + (j)) * T0 + (a)) * T1 + (b)]
+    int is_score = 0; /* :184-203: probed once at the centre pixel; every comparison with a NaN is false */
+    if (H > 0 && W > 0) {
+        int ic = H / 2, jc = W / 2;
+        float v0 = TCV(ic, jc, r0, r1);
+        if (v0 > TCV(ic, jc, r0 + 1, r1)) is_score = 1;
+        if (v0 > TCV(ic, jc, r0 - 1, r1)) is_score = 1;
+        if (v0 > TCV(ic, jc, r0, r1 + 1)) is_score = 1;
+        if (v0 > TCV(ic, jc, r0, r1 - 1)) is_score = 1;
+    }
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            float delta0 = 0, delta1 = 0;
+            if (isotropy == SO_ISOTROPIC) { /* :257-268 */
+                delta0 = so_refine_triplet(kernel, TCV(i, j, r0 - 1, r1), TCV(i, j, r0, r1), TCV(i, j, r0 + 1, r1));
+                delta1 = so_refine_triplet(kernel, TCV(i, j, r0, r1 - 1), TCV(i, j, r0, r1), TCV(i, j, r0, r1 + 1));
+            } else {
+                /* extremum along axis 0 in column `col` of axis 1 (argminForRow, :205-225) and along axis 1 in row `row`
+                 * of axis 0 (argminForCol, :227-247); last extremum wins, NaN never selected, default 0 */
+                int am[4];
+                for (int which = 0; which < 4; which++) {
+                    int fixed = which == 0 ? r1 - 1 : which == 1 ? r1 + 1 : which == 2 ? r0 - 1 : r0 + 1;
+                    int n = which < 2 ? T0 : T1;
+                    float hat = is_score ? -INFINITY : INFINITY;
+                    int arg = 0;
+                    for (int a = 0; a < n; a++) {
+                        float v = which < 2 ? TCV(i, j, a, fixed) : TCV(i, j, fixed, a);
+                        if (is_score ? (v >= hat) : (v <= hat)) { hat = v; arg = a; }
+                    }
+                    am[which] = arg;
+                }
+                float delta0_1 = so_refine_triplet(kernel, TCV(i, j, r0 - 1, r1), TCV(i, j, r0, r1), TCV(i, j, r0 + 1, r1)); /* :274-278 */
+                float delta0_0 = delta0_1, delta0_2 = delta0_1;
+                if (am[0] > 0 && am[0] < T0 - 1) /* :285-293 */
+                    delta0_0 = am[0] - r0 + so_refine_triplet(kernel, TCV(i, j, am[0] - 1, r1 - 1), TCV(i, j, am[0], r1 - 1), TCV(i, j, am[0] + 1, r1 - 1));
+                if (am[1] > 0 && am[1] < T0 - 1) /* :300-308 */
+                    delta0_2 = am[1] - r0 + so_refine_triplet(kernel, TCV(i, j, am[1] - 1, r1 + 1), TCV(i, j, am[1], r1 + 1), TCV(i, j, am[1] + 1, r1 + 1));
+                float a0 = (delta0_2 - delta0_0) / 2; /* :311-312 */
+                float b0 = (delta0_0 + delta0_1 + delta0_2) / 3;
+                float delta1_1 = so_refine_triplet(kernel, TCV(i, j, r0, r1 - 1), TCV(i, j, r0, r1), TCV(i, j, r0, r1 + 1)); /* :316-320 */
+                float delta1_0 = delta1_1, delta1_2 = delta1_1;
+                if (am[2] > 0 && am[2] < T1 - 1) /* :327-335 */
+                    delta1_0 = am[2] - r1 + so_refine_triplet(kernel, TCV(i, j, r0 - 1, am[2] - 1), TCV(i, j, r0 - 1, am[2]), TCV(i, j, r0 - 1, am[2] + 1));
+                if (am[3] > 0 && am[3] < T1 - 1) /* :341-349 */
+                    delta1_2 = am[3] - r1 + so_refine_triplet(kernel, TCV(i, j, r0 + 1, am[3] - 1), TCV(i, j, r0 + 1, am[3]), TCV(i, j, r0 + 1, am[3] + 1));
+                float a1 = (delta1_2 - delta1_0) / 2; /* :352-353 */
+                float b1 = (delta1_0 + delta1_1 + delta1_2) / 3;
+                delta0 = (a0 * b1 + b0) / (1 - a0 * a1); /* :357-358 */
+                delta1 = (a1 * b0 + b1) / (1 - a0 * a1);
+            }
+            if (fabsf(delta0) > 1 || fabsf(delta1) > 1 || isnan(delta0) || isnan(delta1)) { delta0 = 0; delta1 = 0; } /* :362-366 */
+            size_t px = (size_t)i * W + j;
+            refined[2 * px] = (float)raw[2 * px] + delta0;
+            refined[2 * px + 1] = (float)raw[2 * px + 1] + delta1;
+        }
+    return 0;
+}
+
+/* refineDisp2dCostPatchInterpolation<Parabola|Gaussian>, cost_based_refinement.h:378-436 */
+int so_refine_disp_2d_patch(int kernel, const float *tcv, const int32_t *raw, int H, int W, int T0, int T1, float *refined) {
+    int r0 = (T0 - 1) / 2, r1 = (T1 - 1) / 2;
+    if (r0 < 1 || r1 < 1 || 2 * r0 + 1 != T0 || 2 * r1 + 1 != T1) return 1;
+    if (kernel != SO_PARABOLA && kernel != SO_GAUSSIAN) return 2; /* static_assert, :83 */
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            float c[9], d[2];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) c[3 * a + b] = TCV(i, j, r0 - 1 + a, r1 - 1 + b); /* :405-415 */
+            so_refine_patch(kernel, c, d);
+            if (fabsf(d[0]) > 1 || fabsf(d[1]) > 1 || isnan(d[0]) || isnan(d[1])) { d[0] = 0; d[1] = 0; } /* :424-428 */
+            size_t px = (size_t)i * W + j;
+            refined[2 * px] = (float)raw[2 * px] + d[0];
+            refined[2 * px + 1] = (float)raw[2 * px + 1] + d[1];
+        }
+    return 0;
+#undef TCV
+}

@@ -72,6 +72,13 @@ int main(int argc, char **argv) {
         dump(out + "_zncc2d_cv.f32", CV2.data(), CV2.flatLenght());
         dump(out + "_zncc2d_disp.i32", disp2.data(), disp2.flatLenght());
         if (tcv2.shape()[2] != 3 || tcv2.shape()[3] != 3) return 4;
+        // the refinement examples/stereo-match --refine applies (main.cpp:198-210), plus the two other 2-D variants
+        auto ref_iso = SC::refineDisp2dCostInterpolation<SC::InterpolationKernel::Equiangular>(tcv2, disp2);
+        auto ref_aniso = SC::refineDisp2dCostInterpolation<SC::InterpolationKernel::Parabola, SC::IsotropyHypothesis::Anisotropic>(tcv2, disp2);
+        auto ref_patch = SC::refineDisp2dCostPatchInterpolation<SC::InterpolationKernel::Parabola>(tcv2, disp2);
+        dump(out + "_zncc2d_ref_iso.f32", ref_iso.data(), ref_iso.flatLenght());
+        dump(out + "_zncc2d_ref_aniso.f32", ref_aniso.data(), ref_aniso.flatLenght());
+        dump(out + "_zncc2d_ref_patch.f32", ref_patch.data(), ref_patch.flatLenght());
     }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);

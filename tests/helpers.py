@@ -48,3 +48,42 @@ def naive_window_cost(name, w1, w2):
     if name == "SAD":
         return float(np.abs(w1 - w2).sum())
     raise ValueError(name)
+
+
+# ---- synthetic quadric cost patches, as testCostRefinement.cpp builds them ------------------------------------------
+def isotropic_patch(s, ex, ey, n=3):
+    """cost(dx, dy) = s ((dx - ex)^2 + (dy - ey)^2) on an n x n grid centred on 0 (testCostRefinement.cpp:82-100);
+    returns a (1, 1, n, n) float32 truncated volume, axis 2 = dx."""
+    r = n // 2
+    t = np.zeros((1, 1, n, n), np.float32)
+    for a in range(n):
+        for b in range(n):
+            cx, cy = np.float32(a - r) - np.float32(ex), np.float32(b - r) - np.float32(ey)
+            t[0, 0, a, b] = np.float32(s) * (cx * cx + cy * cy)
+    return t
+
+
+def rotated_quadric_patch(d1, d2, alpha, b, n):
+    """cost(dx, dy) = p^T A p with p = (dx - b0, dy - b1), A = R(alpha) diag(d1, d2) R(alpha)^T
+    (testCostRefinement.cpp:130-160, :176-208)."""
+    R = np.array([[np.cos(alpha), -np.sin(alpha)], [np.sin(alpha), np.cos(alpha)]], np.float32)
+    A = (R @ np.diag(np.array([d1, d2], np.float32)) @ R.T).astype(np.float32)
+    r = n // 2
+    t = np.zeros((1, 1, n, n), np.float32)
+    for i in range(n):
+        for j in range(n):
+            p = np.array([i - r - b[0], j - r - b[1]], np.float32)
+            t[0, 0, i, j] = np.float32(p @ (A @ p))
+    return t
+
+
+def refined_2d_mismatch(got, want, raw, tol=1e-4):
+    """Fraction of pixels whose refined 2-D disparities differ by more than tol, not counting the pixels where one side
+    zeroed its deltas (|delta| > 1 or NaN, cost_based_refinement.h:362-366) and the other did not: the rule is a hard
+    threshold on a float result, so two correctly rounded evaluations can fall on either side of it."""
+    got, want, raw = np.asarray(got), np.asarray(want), np.asarray(raw, np.float32)
+    bad = np.any(np.abs(got - want) > tol, axis=-1)
+    zero_g = np.all(got == raw, axis=-1)
+    zero_w = np.all(want == raw, axis=-1)
+    flipped = zero_g != zero_w
+    return float(np.mean(bad & ~flipped)), float(np.mean(flipped))

@@ -27,7 +27,7 @@ def test_headers_compile_and_link(tmp_path):
 @pytest.mark.gpu
 def test_reference_call_chain_matches_oracle(tmp_path):
     import oracle as so
-    from helpers import parallax_pair
+    from helpers import parallax_pair, refined_2d_mismatch
     exe = build(tmp_path)
     src, tgt, _ = parallax_pair(40, 64, 12, 10, 20, 2, 7, seed=21)
     H, W, D = src.shape[0], src.shape[1], 24
@@ -47,6 +47,13 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(np.isnan(got2), np.isnan(cv2)) and np.nanmax(np.abs(got2 - cv2)) <= 1e-4
     disp2 = np.fromfile(tmp_path / "o_zncc2d_disp.i32", np.int32).reshape(H, W, 2)
     assert np.array_equal(disp2, so.index_2d_to_disp(so.extract_index_2d(got2, so.SCORE), -1, -2))
+    idx2 = so.extract_index_2d(got2, so.SCORE)
+    tcv2 = so.truncated_bidirectional_cv(got2, idx2, 1, 1)
+    for name, exp in (("iso", so.refine_disp_2d(tcv2, disp2, so.EQUIANGULAR, so.ISOTROPIC)), ("aniso", so.refine_disp_2d(tcv2, disp2, so.PARABOLA, so.ANISOTROPIC)),
+                      ("patch", so.refine_disp_2d_patch(tcv2, disp2, so.PARABOLA))):
+        got = np.fromfile(tmp_path / f"o_zncc2d_ref_{name}.f32", np.float32).reshape(H, W, 2)
+        bad, flipped = refined_2d_mismatch(got, exp, disp2)
+        assert bad == 0.0 and flipped <= 0.01, (name, bad, flipped)
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

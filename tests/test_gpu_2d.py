@@ -93,3 +93,89 @@ def test_reference_test2dDisparity_on_gpu(rng, name, h_r, v_r):
         cv = sv.unfoldBased2dDisparityCostVolume(NAMES[name], dev(target), dev(source), h_r, v_r, off)
         disp = host(sv.selected2dIndexToDisp(sv.extractSelected2dIndex(strat, cv), off))
         assert tuple(disp[v_r + 1, h_r + 1]) == expected
+
+
+# ---- 2-D cost-based refinement (cost_based_refinement.h:165-436) --------------------------
+from helpers import isotropic_patch, rotated_quadric_patch, refined_2d_mismatch  # noqa: E402
+
+IK, ISO = sv.InterpolationKernel, sv.IsotropyHypothesis
+
+
+def _flow_chain(rng, func, r0, r1, shape=(37, 53)):
+    """a translated random image -> 2-D volume -> winner -> truncated volume (NaN where the winner sits on the range border)"""
+    H, W = shape
+    base = rng.uniform(-1, 1, (H + 8, W + 8)).astype(np.float32)
+    src = base[4:4 + H, 4:4 + W].copy()
+    tgt = (0.6 * base[5:5 + H, 2:2 + W] + 0.4 * base[6:6 + H, 3:3 + W]).astype(np.float32)  # sub-pixel mixture of two shifts
+    cv = so.unfold_cost_volume_2d(int(func), tgt, src, 2, 2, (-3, 3), (-3, 3))
+    strat = so.func_strategy(int(func))
+    idx = so.extract_index_2d(cv, strat)
+    tcv = so.truncated_bidirectional_cv(cv, idx, r0, r1)
+    return tcv, so.index_2d_to_disp(idx, -3, -3)
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SSD, MF.SAD])
+@pytest.mark.parametrize("kernel", [IK.Equiangular, IK.Parabola, IK.Gaussian])
+@pytest.mark.parametrize("iso", [ISO.Isotropic, ISO.Anisotropic])
+def test_refine_2d_matches_oracle(rng, func, kernel, iso):
+    """float tolerance 1e-4 on the refined disparities (the north-star tolerance for refinement outputs)"""
+    for (r0, r1) in [(1, 1), (2, 2), (1, 3)]:
+        tcv, raw = _flow_chain(rng, func, r0, r1)
+        if kernel == IK.Gaussian:
+            tcv = np.abs(tcv) + np.float32(0.05)  # log() of the costs
+        exp = so.refine_disp_2d(tcv, raw, int(kernel), int(iso))
+        for mk in (lambda x: x, dev):
+            got = host(sv.refineDisp2dCostInterpolation(kernel, mk(tcv), mk(raw), iso))
+            assert got.shape == exp.shape and not np.isnan(got).any()
+            bad, flipped = refined_2d_mismatch(got, exp, raw)
+            assert bad == 0.0 and flipped <= 0.002, (bad, flipped)
+        assert np.mean(np.any(exp != raw, axis=-1)) > 0.3  # the refinement does something on this data
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SSD])
+@pytest.mark.parametrize("kernel", [IK.Parabola, IK.Gaussian])
+def test_refine_2d_patch_matches_oracle(rng, func, kernel):
+    """closed-form normal equations on the device against the oracle's numerical 9x6 least squares"""
+    for (r0, r1) in [(1, 1), (2, 1)]:
+        tcv, raw = _flow_chain(rng, func, r0, r1)
+        if kernel == IK.Gaussian:
+            tcv = np.abs(tcv) + np.float32(0.05)
+        exp = so.refine_disp_2d_patch(tcv, raw, int(kernel))
+        for mk in (lambda x: x, dev):
+            got = host(sv.refineDisp2dCostPatchInterpolation(kernel, mk(tcv), mk(raw)))
+            bad, flipped = refined_2d_mismatch(got, exp, raw)
+            assert bad == 0.0 and flipped <= 0.002, (bad, flipped)
+        assert np.mean(np.any(exp != raw, axis=-1)) > 0.3
+
+
+def test_refine_2d_shape_and_argument_rules(rng):
+    raw = np.zeros((4, 5, 2), np.int32)
+    assert sv.refineDisp2dCostInterpolation(IK.Parabola, np.zeros((4, 5, 1, 3), np.float32), raw).size == 0  # :180-182
+    assert sv.refineDisp2dCostInterpolation(IK.Parabola, np.zeros((4, 5, 3, 4), np.float32), raw).size == 0
+    assert sv.refineDisp2dCostPatchInterpolation(IK.Parabola, np.zeros((4, 5, 2, 3), np.float32), raw).size == 0  # :393-395
+    with pytest.raises(Exception):
+        sv.refineDisp2dCostPatchInterpolation(IK.Equiangular, np.zeros((4, 5, 3, 3), np.float32), raw)  # static_assert :83
+    with pytest.raises(Exception):
+        sv.refineDisp2dCostInterpolation(IK.Parabola, np.zeros((4, 5, 3, 3), np.float32), np.zeros((4, 6, 2), np.int32))
+    flat = np.ones((4, 5, 3, 3), np.float32)  # 0/0 -> NaN -> both deltas zeroed (:362-366)
+    raw = rng.integers(-5, 5, (4, 5, 2)).astype(np.int32)
+    assert np.array_equal(host(sv.refineDisp2dCostInterpolation(IK.Parabola, dev(flat), dev(raw))), raw.astype(np.float32))
+    assert np.array_equal(host(sv.refineDisp2dCostPatchInterpolation(IK.Parabola, dev(flat), dev(raw))), raw.astype(np.float32))
+
+
+@pytest.mark.parametrize("trial", range(6))
+def test_reference_cost_refinement_tests_on_gpu(rng, trial):
+    """testCostRefinement.cpp:60-221 run against the HIP path: planted quadric minima are recovered."""
+    zero = np.zeros((1, 1, 2), np.int32)
+    s = rng.uniform(-1, 1)
+    s = 0.5 if abs(s) < 1e-4 else s
+    ex, ey = rng.uniform(-1, 1, 2)
+    ref = host(sv.refineDisp2dCostInterpolation(IK.Parabola, dev(isotropic_patch(s, ex, ey)), dev(zero), ISO.Isotropic))
+    assert ref[0, 0, 0] == pytest.approx(ex, rel=1e-5, abs=1e-6) and ref[0, 0, 1] == pytest.approx(ey, rel=1e-5, abs=1e-6)
+    s = np.copysign(max(abs(rng.uniform(-1, 1)), 0.5), rng.uniform(-1, 1))
+    d1, d2 = s * rng.uniform(0.7, 1, 2)
+    b = rng.uniform(-0.5, 0.5, 2)
+    ref = host(sv.refineDisp2dCostInterpolation(IK.Parabola, dev(rotated_quadric_patch(d1, d2, 0.1 * rng.uniform(-1, 1), b, 5)), dev(zero), ISO.Anisotropic))
+    assert abs(ref[0, 0, 0] - b[0]) < 2e-6 and abs(ref[0, 0, 1] - b[1]) < 2e-6
+    ref = host(sv.refineDisp2dCostPatchInterpolation(IK.Parabola, dev(rotated_quadric_patch(d1, d2, 3 * rng.uniform(-1, 1), b, 3)), dev(zero)))
+    assert ref[0, 0, 0] == pytest.approx(b[0], rel=1e-5, abs=2e-6) and ref[0, 0, 1] == pytest.approx(b[1], rel=1e-5, abs=2e-6)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle as so
-from helpers import naive_window_cost
+from helpers import isotropic_patch, rotated_quadric_patch, naive_window_cost
 
 SHAPES = [(3, 3, 1), (1, 1, 5), (3, 3, 5), (5, 1, 5), (1, 5, 5), (5, 5, 5)]  # testCorrelationFilters.cpp:270-275
 FUNCS = {"CC": so.CC, "NCC": so.NCC, "SSD": so.SSD, "SAD": so.SAD, "ZCC": so.ZCC, "ZNCC": so.ZNCC, "ZSSD": so.ZSSD,
@@ -141,3 +141,60 @@ def test_2d_disparity(rng, name, h_r, v_r):
         cv = so.unfold_cost_volume_2d(FUNCS[name], target, source, h_r, v_r, rng0, rng1)
         disp = so.index_2d_to_disp(so.extract_index_2d(cv, strat), rng0[0], rng1[0])
         assert tuple(disp[v_r + 1, h_r + 1]) == expected
+
+
+# ---- 2-D cost-based refinement: testCostRefinement.cpp -------------------------------------------------------------
+@pytest.mark.parametrize("trial", range(8))
+def test_2d_cost_isotropic_parabola(rng, trial):
+    """test2dCostIsotropicParabola (testCostRefinement.cpp:60-115): an isotropic paraboloid's minimum is recovered by
+    refineDisp2dCostInterpolation<Parabola, Isotropic>; QCOMPARE on floats is a 1e-5 relative comparison."""
+    s = rng.uniform(-1, 1)
+    s = 0.5 if abs(s) < 1e-4 else s
+    ex, ey = rng.uniform(-1, 1, 2)
+    ref = so.refine_disp_2d(isotropic_patch(s, ex, ey), np.zeros((1, 1, 2), np.int32), so.PARABOLA, so.ISOTROPIC)
+    assert ref[0, 0, 0] == pytest.approx(ex, rel=1e-5, abs=1e-6) and ref[0, 0, 1] == pytest.approx(ey, rel=1e-5, abs=1e-6)
+
+
+@pytest.mark.parametrize("trial", range(8))
+def test_2d_cost_anisotropic_parabola(rng, trial):
+    """test2dCostAnisotropicParabola (testCostRefinement.cpp:117-173): slightly rotated anisotropic quadric on a 5x5
+    truncated volume, recovered to 1e-6 by the Anisotropic hypothesis."""
+    s = rng.uniform(-1, 1)
+    s = np.copysign(max(abs(s), 0.5), s)
+    d1, d2 = s * rng.uniform(0.7, 1, 2)
+    b = rng.uniform(-0.5, 0.5, 2)
+    tcv = rotated_quadric_patch(d1, d2, 0.1 * rng.uniform(-1, 1), b, 5)
+    ref = so.refine_disp_2d(tcv, np.zeros((1, 1, 2), np.int32), so.PARABOLA, so.ANISOTROPIC)
+    assert abs(ref[0, 0, 0] - b[0]) < 2e-6 and abs(ref[0, 0, 1] - b[1]) < 2e-6  # float32 patch built here, 1e-6 in the reference
+
+
+@pytest.mark.parametrize("trial", range(8))
+def test_2d_cost_full_matching_parabola(rng, trial):
+    """test2dCostFullMatchingParabola (testCostRefinement.cpp:176-221): arbitrarily rotated quadric, recovered by the
+    3x3 patch fit refineDisp2dCostPatchInterpolation<Parabola>."""
+    s = rng.uniform(-1, 1)
+    s = np.copysign(max(abs(s), 0.5), s)
+    d1, d2 = s * rng.uniform(0.7, 1, 2)
+    b = rng.uniform(-0.5, 0.5, 2)
+    tcv = rotated_quadric_patch(d1, d2, 3 * rng.uniform(-1, 1), b, 3)
+    ref = so.refine_disp_2d_patch(tcv, np.zeros((1, 1, 2), np.int32), so.PARABOLA)
+    assert ref[0, 0, 0] == pytest.approx(b[0], rel=1e-5, abs=2e-6) and ref[0, 0, 1] == pytest.approx(b[1], rel=1e-5, abs=2e-6)
+
+
+def test_2d_refinement_rules():
+    """cost_based_refinement.h:180-182 (empty result for bad depths), :362-366 (deltas zeroed beyond 1 or NaN), :184-203 (the
+    score probe at the centre pixel only matters for the anisotropic extremum search)."""
+    raw = np.array([[[3, -2]]], np.int32)
+    assert so.refine_disp_2d(np.zeros((1, 1, 1, 3), np.float32), raw).size == 0
+    assert so.refine_disp_2d(np.zeros((1, 1, 4, 3), np.float32), raw).size == 0
+    flat = np.ones((1, 1, 3, 3), np.float32)  # 0/0 -> NaN -> zeroed
+    assert np.array_equal(so.refine_disp_2d(flat, raw, so.PARABOLA), raw.astype(np.float32))
+    far = isotropic_patch(1.0, 1.5, 0.0)  # minimum 1.5 away along axis 0 -> both deltas dropped
+    assert np.array_equal(so.refine_disp_2d(far, raw, so.PARABOLA), raw.astype(np.float32))
+    with pytest.raises(ValueError):
+        so.refine_disp_2d_patch(flat, raw, so.EQUIANGULAR)
+    # a score volume (maximum at the centre) is refined towards the same location as the mirrored cost volume
+    cost = isotropic_patch(0.8, 0.2, -0.3, 5)
+    a = so.refine_disp_2d(cost, raw, so.PARABOLA, so.ANISOTROPIC)
+    b = so.refine_disp_2d(-cost, raw, so.PARABOLA, so.ANISOTROPIC)
+    assert np.allclose(a, b, atol=1e-6) and np.allclose(a[0, 0], [3.2, -2.3], atol=1e-5)

@@ -91,7 +91,9 @@ const char *svh_status_string(int status);
 /* message of the last failing call on this context ("" if none) */
 const char *svh_last_error(const svh_context *ctx);
 /* Tuning / test switches.  "census_fast_path" (default 1): 0 forces the general wave-per-line SGM kernels
- * for census costs too (same results, used by the parity tests to cross-check the two implementations). */
+ * for census costs too (same results, used by the parity tests to cross-check the two implementations).
+ * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
+ * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);
@@ -192,6 +194,30 @@ int svh_refine_disp_2d_cost_interpolation(svh_context *ctx, int interp_kernel, i
  * (refineCostPatch, :71-126) and its stationary point                              correlation/cost_based_refinement.h:378-436 */
 int svh_refine_disp_2d_cost_patch_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
                                                 svh_array *refined);
+
+/* ---- hierarchical (coarse-to-fine) matching: SURVEY.md section 8(f) rank 3 -------------------------------------------
+ * Interpolation::averagePoolingDownsample(img, DownSampleWindows(h, v))                interpolation/downsampling.h:67-178
+ * img (H,W[,C]) f32 -> out (ceil(H/v), ceil(W/h)[,C]) f32: mean over the valid samples of each window, as written there. */
+int svh_average_pooling_downsample(svh_context *ctx, const svh_array *img, int win_horizontal, int win_vertical, svh_array *out);
+/* computeGuidedCV<matchFunc, ..., dDir>(feature_vol_l, feature_vol_r, disp_guide, upscale_disp_radius)
+ *                                                                                       correlation/hierarchical.h:74-229
+ * feat_l / feat_r: the volumes getFeatureVolumeForMatchFunc returns, (H,W*,F) f32 (already zero-mean / normalised) or
+ * (H,W*,nW) u32 census words; guide (Hg,Wg) i32, at least 2x2.  -> tcv (H,Ws,2r+1) f32 centred on the selected disparity,
+ * disp (H,Ws) i32 = OffsetedCostVolume::{truncated_cost_volume, disp_estimate}.  Row mismatch -> SVH_EMPTY_RESULT. */
+int svh_guided_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *feat_l, const svh_array *feat_r,
+                           const svh_array *guide, int32_t upscale_disp_radius, svh_array *tcv, svh_array *disp);
+/* hiearchicalTruncatedCostVolume<matchFunc, depth, ..., dDir>(img_l, img_r, h_radiuses, v_radiuses, disp_width, upscale_disp_radius)
+ *                                                                                       correlation/hierarchical.h:232-319
+ * h_radii / v_radii: depth + 1 entries, coarsest level first (the single-radius overload repeats one value, :296-315).
+ * depth 2x2 average poolings, full search over ceil(disp_width / 2^depth) disparities at the coarsest level
+ * (unfoldBasedCostVolume + extractSelectedIndex), one computeGuidedCV per level on the way up; nothing leaves the device
+ * in between.  Outputs as for svh_guided_cost_volume at the resolution of the source image.
+ * The coarsest volume uses the register-blocked kernels (results within rounding of the reference's; an exact tie broken
+ * differently changes that pixel's estimate) unless svh_context_set_option(ctx, "literal_cost_volumes", 1) selects the
+ * per-voxel kernel, which follows the reference operation by operation. */
+int svh_hierarchical_truncated_cost_volume(svh_context *ctx, int match_func, int disp_direction, int depth, const svh_array *img_l,
+                                           const svh_array *img_r, const int32_t *h_radii, const int32_t *v_radii, int32_t disp_width,
+                                           int32_t upscale_disp_radius, svh_array *tcv, svh_array *disp);
 
 /* ---- fused pipeline: the benchmark / stereo_refine_test call chain kept on the device ------------------
  * unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp

@@ -29,6 +29,7 @@ EXPORTS = [
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
+    "svh_average_pooling_downsample", "svh_guided_cost_volume", "svh_hierarchical_truncated_cost_volume",
 ]
 
 
@@ -129,6 +130,9 @@ def load():
         "svh_truncated_bidirectional_cost_volume": (C.c_int, [ctx, A, A, C.c_int, C.c_int, A]),
         "svh_refine_disp_2d_cost_interpolation": (C.c_int, [ctx, C.c_int, C.c_int, A, A, A]),
         "svh_refine_disp_2d_cost_patch_interpolation": (C.c_int, [ctx, C.c_int, A, A, A]),
+        "svh_average_pooling_downsample": (C.c_int, [ctx, A, C.c_int, C.c_int, A]),
+        "svh_guided_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, A, A, i32, A, A]),
+        "svh_hierarchical_truncated_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, C.c_int, A, A, P(i32), P(i32), i32, i32, A, A]),
         "svh_census_shard_keys": (C.c_int, [ctx, P(SvhStereoParams), A, A, A]),
         "svh_census_shard_finish": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A]),
     }

@@ -536,6 +536,65 @@ def refineDisp2dCostPatchInterpolation(kernel, truncatedCostVolume, rawDisparity
     return out if st == _capi.OK else _empty_like(tcv, 3, "f32")
 
 
+# ---- hierarchical matching ----------------------------------------------------------
+def averagePoolingDownsample(input, windows):
+    """Interpolation::averagePoolingDownsample(input, DownSampleWindows) -- interpolation/downsampling.h:67-178.
+    windows: int (square) or (horizontal, vertical)."""
+    lib = _capi.load()
+    x = _prep(input, np.float32)
+    ctx = context_for(x)
+    wh, wv = (int(windows), int(windows)) if np.isscalar(windows) else (int(windows[0]), int(windows[1]))
+    shp = ((x.shape[0] + wv - 1) // wv, (x.shape[1] + wh - 1) // wh) + tuple(x.shape[2:])
+    out = _like(x, shp, "f32")
+    _check(ctx, lib.svh_average_pooling_downsample(ctx, C.byref(_desc(x)), wh, wv, C.byref(_desc(out))))
+    return out
+
+
+class OffsetedCostVolume:  # correlation/hierarchical.h:33-37
+    def __init__(self, truncated_cost_volume, disp_estimate):
+        self.truncated_cost_volume = truncated_cost_volume
+        self.disp_estimate = disp_estimate
+
+
+def computeGuidedCV(matchFunc, feature_vol_l, feature_vol_r, disp_guide, upscale_disp_radius, dDir=dispDirection.RightToLeft):
+    """computeGuidedCV<matchFunc, ..., dDir> -- correlation/hierarchical.h:74-229, on the feature volumes
+    getFeatureVolumeForMatchFunc returns (float32, or uint32 census words)."""
+    lib = _capi.load()
+    ft = np.uint32 if int(matchFunc) in (matchingFunctions.CENSUS, matchingFunctions.HAMMING) else np.float32
+    l, r, g = _prep(feature_vol_l, ft), _prep(feature_vol_r, ft), _prep(disp_guide, np.int32)
+    ctx = context_for(l)
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    T = 2 * int(upscale_disp_radius) + 1
+    tcv, disp = _like(l, (src.shape[0], src.shape[1], T), "f32"), _like(l, (src.shape[0], src.shape[1]), "i32")
+    st = _check(ctx, lib.svh_guided_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(g)),
+                                                int(upscale_disp_radius), C.byref(_desc(tcv)), C.byref(_desc(disp))))
+    if st != _capi.OK:
+        return OffsetedCostVolume(_empty_like(l, 3, "f32"), _empty_like(l, 2, "i32"))
+    return OffsetedCostVolume(tcv, disp)
+
+
+def hiearchicalTruncatedCostVolume(matchFunc, depth, img_l, img_r, h_radiuses, v_radiuses, disp_width, upscale_disp_radius=2,
+                                   dDir=dispDirection.RightToLeft):
+    """hiearchicalTruncatedCostVolume<matchFunc, depth, ..., dDir> -- correlation/hierarchical.h:232-319.  h_radiuses /
+    v_radiuses: one radius for every level or depth + 1 radii, coarsest level first."""
+    lib = _capi.load()
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    ctx = context_for(l)
+    hr = [int(h_radiuses)] * (depth + 1) if np.isscalar(h_radiuses) else [int(v) for v in h_radiuses]
+    vr = [int(v_radiuses)] * (depth + 1) if np.isscalar(v_radiuses) else [int(v) for v in v_radiuses]
+    if len(hr) != depth + 1 or len(vr) != depth + 1:
+        raise ValueError("radii lists must hold depth + 1 entries")
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    T = 2 * int(upscale_disp_radius) + 1
+    tcv, disp = _like(l, (src.shape[0], src.shape[1], T), "f32"), _like(l, (src.shape[0], src.shape[1]), "i32")
+    st = _check(ctx, lib.svh_hierarchical_truncated_cost_volume(ctx, int(matchFunc), int(dDir), int(depth), C.byref(_desc(l)), C.byref(_desc(r)),
+                                                                (C.c_int32 * len(hr))(*hr), (C.c_int32 * len(vr))(*vr), int(disp_width),
+                                                                int(upscale_disp_radius), C.byref(_desc(tcv)), C.byref(_desc(disp))))
+    if st != _capi.OK:
+        return OffsetedCostVolume(_empty_like(l, 3, "f32"), _empty_like(l, 2, "i32"))
+    return OffsetedCostVolume(tcv, disp)
+
+
 def set_option(x, name, value):
     """svh_context_set_option on the context used for array x (e.g. "census_fast_path", 0/1)."""
     ctx = context_for(x)

@@ -1,0 +1,137 @@
+// Feature accessors and the literal per-voxel comparison shared by the generic cost-volume kernel (svh_cost_volume.hip) and the
+// guided cost volume of hierarchical matching (svh_hierarchical.hip).
+#ifndef SVH_COMPARE_H
+#define SVH_COMPARE_H
+
+#include "svh_internal.h"
+
+namespace svh {
+
+// ---- feature accessors ----------------------------------------------------------------------------
+struct FeatVolume { // dense (H, W, F)
+    const float *f;
+    int W, F;
+    __device__ __forceinline__ int count() const { return F; }
+};
+struct FeatImage { // unfold on the fly: (H, W, C) image, window (2v_r+1) x (2h_r+1), auto padding
+    const float *img;
+    int H, W, C, h_r, v_r;
+    __device__ __forceinline__ int count() const { return (2 * h_r + 1) * (2 * v_r + 1) * C; }
+};
+
+// sequential walk over the channels of pixel (i, j); `valid` false yields an all-zero raw vector
+struct VolumeCursor {
+    const float *p;
+    __device__ __forceinline__ VolumeCursor(const FeatVolume &a, int i, int j) : p(a.f + ((int64_t)i * a.W + j) * a.F) {}
+    __device__ __forceinline__ float next() { return *p++; }
+};
+struct ImageCursor {
+    const FeatImage &a;
+    int i0, j0, k = 0, l = 0, ch = 0;
+    __device__ __forceinline__ ImageCursor(const FeatImage &acc, int i, int j) : a(acc), i0(i - acc.v_r), j0(j - acc.h_r) {}
+    __device__ __forceinline__ float next() {
+        int ii = i0 + k, jj = j0 + l;
+        float v = (ii >= 0 && ii < a.H && jj >= 0 && jj < a.W) ? a.img[((int64_t)ii * a.W + jj) * a.C + ch] : 0.0f;
+        if (++ch == a.C) {
+            ch = 0;
+            if (++l == 2 * a.h_r + 1) {
+                l = 0;
+                ++k;
+            }
+        }
+        return v;
+    }
+};
+template <class A> struct CursorOf;
+template <> struct CursorOf<FeatVolume> { using type = VolumeCursor; };
+template <> struct CursorOf<FeatImage> { using type = ImageCursor; };
+
+// ---- per-pixel statistics (A7) ---------------------------------------------------------------------
+// mean: channelsMean, correlation_base.h:1100-1136 (sequential sum, then * float(1./F))
+// norm: channelsNorm cross_correlations.h:149-191 or channelsZeroMeanNorm :61-104 (sqrtf of sequential sum)
+template <class A>
+__global__ void stats_kernel(A acc, int H, int W, bool zero_mean, bool normalized, float *__restrict__ mean,
+                             float *__restrict__ norm) {
+    const int64_t npx = (int64_t)H * W;
+    const int F = acc.count();
+    const float scale = (float)(1. / (double)(float)F);
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        int j = (int)(p % W), i = (int)(p / W);
+        float m = 0.0f;
+        if (zero_mean) {
+            typename CursorOf<A>::type cur(acc, i, j);
+            for (int c = 0; c < F; c++) m += cur.next();
+            m *= scale;
+            mean[p] = m;
+        }
+        if (normalized) {
+            typename CursorOf<A>::type cur(acc, i, j);
+            float n = 0.0f;
+            for (int c = 0; c < F; c++) {
+                float tmp = cur.next() - m; // m == 0 without zero-mean: x - 0 is exact
+                n += tmp * tmp;
+            }
+            norm[p] = sqrtf(n);
+        }
+    }
+}
+
+template <class A>
+inline int launch_stats(svh_context *ctx, A acc, int H, int W, bool zm, bool nrm, float *mean, float *norm) {
+    int64_t npx = (int64_t)H * W;
+    if (npx == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "window_stats", (stats_kernel<A>), grid_for(npx, 256, 16384), 256, 0, acc, H, W, zm, nrm, mean, norm);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
+
+// cmp(src(i,j,:), tgt(it,jt,:)) on the processed features (zero-mean / normalised per element, cross_correlations.h:416-594), with
+// the reference's float operations in the reference's channel order; a target pixel outside the image is the zero vector
+// (cross_correlations.h:235, :294, :359; hierarchical.h:177).
+template <class A, int CMP, bool ZM, bool NORM>
+__device__ __forceinline__ float compare_features(const A &src, const A &tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
+                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt, int i,
+                                                  int j, int it, int jt) {
+    const int F = src.count();
+    const int64_t p = (int64_t)i * Ws + j;
+    bool t_in = jt >= 0 && jt < Wt && it >= 0 && it < H;
+    float ms = ZM ? mean_s[p] : 0.0f;
+    float ns = NORM ? norm_s[p] : 1.0f;
+    float mt = 0.0f, nt = 1.0f;
+    if (t_in) {
+        int64_t pt = (int64_t)it * Wt + jt;
+        if (ZM) mt = mean_t[pt];
+        if (NORM) nt = norm_t[pt];
+    }
+    typename CursorOf<A>::type cs(src, i, j);
+    typename CursorOf<A>::type ct(tgt, t_in ? it : 0, t_in ? jt : 0);
+    float score = 0.0f;
+    for (int c = 0; c < F; c++) {
+        float s = cs.next();
+        float t = ct.next();
+        if (ZM) s = s - ms;
+        if (NORM) s = s / ns;
+        if (t_in) {
+            if (ZM) t = t - mt;
+            if (NORM) t = t / nt;
+        } else {
+            t = 0.0f;
+        }
+        if (CMP == CMP_DOT) {
+            score += s * t; // dotProduct, matching_costs.h:59-78
+        } else if (CMP == CMP_SSD) {
+            float tmp = s - t; // SumSquareDiff, :100-116
+            score += tmp * tmp;
+        } else {
+            float tmp = s - t; // SumAbsDiff, :136-156
+            score += fabsf(tmp);
+        }
+    }
+    return score;
+}
+
+} // namespace svh
+
+#endif // SVH_COMPARE_H

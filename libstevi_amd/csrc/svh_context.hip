@@ -318,6 +318,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_fast_path = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "literal_cost_volumes") == 0) {
+        ctx->literal_cost_volumes = value != 0;
+        return SVH_OK;
+    }
     return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);
 }
 

@@ -7,79 +7,9 @@
 // volume is ever written.  Volumes are stored (row, col, disparity) with the disparity fastest: one pixel's D
 // costs are contiguous, which is what the per-line SGM kernels and the winner scan want.
 #include "svh_internal.h"
+#include "svh_compare.h"
 
 namespace svh {
-
-// ---- feature accessors ----------------------------------------------------------------------------
-struct FeatVolume { // dense (H, W, F)
-    const float *f;
-    int W, F;
-    __device__ __forceinline__ int count() const { return F; }
-};
-struct FeatImage { // unfold on the fly: (H, W, C) image, window (2v_r+1) x (2h_r+1), auto padding
-    const float *img;
-    int H, W, C, h_r, v_r;
-    __device__ __forceinline__ int count() const { return (2 * h_r + 1) * (2 * v_r + 1) * C; }
-};
-
-// sequential walk over the channels of pixel (i, j); `valid` false yields an all-zero raw vector
-struct VolumeCursor {
-    const float *p;
-    __device__ __forceinline__ VolumeCursor(const FeatVolume &a, int i, int j) : p(a.f + ((int64_t)i * a.W + j) * a.F) {}
-    __device__ __forceinline__ float next() { return *p++; }
-};
-struct ImageCursor {
-    const FeatImage &a;
-    int i0, j0, k = 0, l = 0, ch = 0;
-    __device__ __forceinline__ ImageCursor(const FeatImage &acc, int i, int j) : a(acc), i0(i - acc.v_r), j0(j - acc.h_r) {}
-    __device__ __forceinline__ float next() {
-        int ii = i0 + k, jj = j0 + l;
-        float v = (ii >= 0 && ii < a.H && jj >= 0 && jj < a.W) ? a.img[((int64_t)ii * a.W + jj) * a.C + ch] : 0.0f;
-        if (++ch == a.C) {
-            ch = 0;
-            if (++l == 2 * a.h_r + 1) {
-                l = 0;
-                ++k;
-            }
-        }
-        return v;
-    }
-};
-template <class A> struct CursorOf;
-template <> struct CursorOf<FeatVolume> { using type = VolumeCursor; };
-template <> struct CursorOf<FeatImage> { using type = ImageCursor; };
-
-// ---- per-pixel statistics (A7) ---------------------------------------------------------------------
-// mean: channelsMean, correlation_base.h:1100-1136 (sequential sum, then * float(1./F))
-// norm: channelsNorm cross_correlations.h:149-191 or channelsZeroMeanNorm :61-104 (sqrtf of sequential sum)
-template <class A>
-__global__ void stats_kernel(A acc, int H, int W, bool zero_mean, bool normalized, float *__restrict__ mean,
-                             float *__restrict__ norm) {
-    const int64_t npx = (int64_t)H * W;
-    const int F = acc.count();
-    const float scale = (float)(1. / (double)(float)F);
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
-        int j = (int)(p % W), i = (int)(p / W);
-        float m = 0.0f;
-        if (zero_mean) {
-            typename CursorOf<A>::type cur(acc, i, j);
-            for (int c = 0; c < F; c++) m += cur.next();
-            m *= scale;
-            mean[p] = m;
-        }
-        if (normalized) {
-            typename CursorOf<A>::type cur(acc, i, j);
-            float n = 0.0f;
-            for (int c = 0; c < F; c++) {
-                float tmp = cur.next() - m; // m == 0 without zero-mean: x - 0 is exact
-                n += tmp * tmp;
-            }
-            norm[p] = sqrtf(n);
-        }
-    }
-}
-
-enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
 
 // one thread per voxel, disparity fastest (coalesced stores; the source vector is wave-uniform for D >= 64)
 template <class A, int CMP, bool ZM, bool NORM>
@@ -88,47 +18,13 @@ __global__ void cost_volume_kernel(A src, A tgt, const float *__restrict__ mean_
                                    int D, int sign, int disp_lower, int row_off, int64_t px_stride, int64_t out_off,
                                    float *__restrict__ cv) {
     const int64_t n = (int64_t)H * Ws * D;
-    const int F = src.count();
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         int d = (int)(e % D);
         int64_t p = e / D;
         int j = (int)(p % Ws), i = (int)(p / Ws);
         int jt = j + sign * (disp_lower + d);
         const int it = i + row_off;
-        bool t_in = jt >= 0 && jt < Wt && it >= 0 && it < H;
-        float ms = ZM ? mean_s[p] : 0.0f;
-        float ns = NORM ? norm_s[p] : 1.0f;
-        float mt = 0.0f, nt = 1.0f;
-        if (t_in) {
-            int64_t pt = (int64_t)it * Wt + jt;
-            if (ZM) mt = mean_t[pt];
-            if (NORM) nt = norm_t[pt];
-        }
-        typename CursorOf<A>::type cs(src, i, j);
-        typename CursorOf<A>::type ct(tgt, t_in ? it : 0, t_in ? jt : 0);
-        float score = 0.0f;
-        for (int c = 0; c < F; c++) {
-            float s = cs.next();
-            float t = ct.next();
-            if (ZM) s = s - ms;
-            if (NORM) s = s / ns;
-            if (t_in) {
-                if (ZM) t = t - mt;
-                if (NORM) t = t / nt;
-            } else {
-                t = 0.0f;
-            }
-            if (CMP == CMP_DOT) {
-                score += s * t; // dotProduct, matching_costs.h:59-78
-            } else if (CMP == CMP_SSD) {
-                float tmp = s - t; // SumSquareDiff, :100-116
-                score += tmp * tmp;
-            } else {
-                float tmp = s - t; // SumAbsDiff, :136-156
-                score += fabsf(tmp);
-            }
-        }
-        cv[p * px_stride + out_off + d] = score;
+        cv[p * px_stride + out_off + d] = compare_features<A, CMP, ZM, NORM>(src, tgt, mean_s, norm_s, mean_t, norm_t, H, Ws, Wt, i, j, it, jt);
     }
 }
 
@@ -203,15 +99,6 @@ static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, cons
     const size_t shmem = (size_t)NW * (2 * HV_TP + a.D - 1) * sizeof(uint32_t);
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off,
                a.px_stride(), a.out_off, cv);
-}
-
-template <class A>
-static int launch_stats(svh_context *ctx, A acc, int H, int W, bool zm, bool nrm, float *mean, float *norm) {
-    int64_t npx = (int64_t)H * W;
-    if (npx == 0) return SVH_OK;
-    SVH_LAUNCH(ctx, "window_stats", (stats_kernel<A>), grid_for(npx, 256, 16384), 256, 0, acc, H, W, zm, nrm, mean, norm);
-    SVH_CHECK_LAUNCH(ctx);
-    return SVH_OK;
 }
 
 template <class A, int CMP>
@@ -310,7 +197,7 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
         return dev_hamming_volume(ctx, a, sw, tw, nWw, cv);
     }
     // grey images with windows up to 11x11: LDS-tiled, register-blocked kernel (svh_cost_volume_tiled.hip)
-    const int st = dev_cost_volume_grey_tiled(ctx, scr, a, src, tgt, h_r, v_r, cv);
+    const int st = a.literal ? SVH_ERR_UNSUPPORTED : dev_cost_volume_grey_tiled(ctx, scr, a, src, tgt, h_r, v_r, cv);
     if (st != SVH_ERR_UNSUPPORTED) return st;
     return cost_volume_generic(ctx, scr, a, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r},
                                FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, cv);

@@ -1,0 +1,377 @@
+// Hierarchical (coarse-to-fine) matching: SURVEY.md section 8(f) rank 3.
+//
+//   averagePoolingDownsample                                   interpolation/downsampling.h:67-178
+//   computeGuidedCV<matchFunc>(feat_l, feat_r, guide, r)        correlation/hierarchical.h:74-229
+//   hiearchicalTruncatedCostVolume<matchFunc, depth>            correlation/hierarchical.h:232-319
+//
+// computeGuidedCV searches 2r+1 disparities around twice the bilinearly upsampled coarse estimate, keeps the first strict
+// extremum d_r, and re-centres the truncated volume on it (:194-227).  After the re-centring every entry is
+//     tcv(i, j, dd) = cmp(src(i,j,:), tgt(i, j + d_r + dirSign (dd - r), :)),
+// a pure function of d_r, so the device runs two passes: a lane per pixel picks d_r (`guided_select`), then a lane per
+// (pixel, dd) fills the volume (`guided_volume`).  Both call the literal comparison of svh_compare.h, so equal inputs give
+// bit-equal costs in the two passes and the strict '<' / '>' winner rule sees exactly the values the volume holds.
+#include "svh_compare.h"
+#include "svh_internal.h"
+
+namespace svh {
+
+namespace {
+
+// averagePoolingDownsample as written (downsampling.h:78-114, :131-176): the row loop of the window runs over the
+// HORIZONTAL window size, the column offset is derived from the ROW remainder and vice versa; mean over the valid samples.
+__global__ void downsample_kernel(const float *__restrict__ img, int H, int W, int C, int win_h, int win_v, int Ho, int Wo, float *__restrict__ out) {
+    const int64_t n = (int64_t)Ho * Wo * C;
+    const int hRem = Ho * win_v - H, vRem = Wo * win_h - W;
+    const int initialHOffset = hRem / 2, initialVOffset = vRem / 2;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(e % C);
+        const int j = (int)((e / C) % Wo), i = (int)(e / ((int64_t)C * Wo));
+        float val = 0.0f;
+        int count = 0;
+        for (int dv = 0; dv < win_h; dv++) {
+            const int p_i = i * win_v - initialVOffset + dv;
+            for (int dh = 0; dh < win_h; dh++) {
+                const int p_j = j * win_h - initialHOffset + dh;
+                if (p_i >= 0 && p_i < H && p_j >= 0 && p_j < W) {
+                    val += img[((int64_t)p_i * W + p_j) * C + f];
+                    count += 1;
+                }
+            }
+        }
+        out[e] = val / (float)count;
+    }
+}
+
+// hierarchical.h:106-150: bilinear upsampling of the integer guide (taps clamped as written), times two, rounded half away
+// from zero; float operations in the reference's order
+__device__ __forceinline__ int guided_base_disp(const int32_t *__restrict__ guide, int Hg, int Wg, int h, int w, int i, int j, int dirSign) {
+    const float v_pos = (float)(i * (Hg - 1)) / (float)(h - 1);
+    int v0 = (int)floorf(v_pos), v1 = (int)ceilf(v_pos);
+    if (v0 == v1) v1 += 1;
+    if (v1 == Hg) {
+        v0 -= 1;
+        v1 -= 1;
+    }
+    const float h_pos = (float)(j * (Wg - 1)) / (float)(w - 1);
+    int h0 = (int)floorf(h_pos), h1 = (int)ceilf(h_pos);
+    if (h0 == h1) h1 += 1;
+    if (h1 == Wg) {
+        h0 -= 1;
+        h1 -= 1;
+    }
+    float interp = 0.0f;
+    interp += (v_pos - (float)v0) * (h_pos - (float)h0) * (float)guide[(int64_t)v1 * Wg + h1];
+    interp += ((float)v1 - v_pos) * (h_pos - (float)h0) * (float)guide[(int64_t)v0 * Wg + h1];
+    interp += (v_pos - (float)v0) * ((float)h1 - h_pos) * (float)guide[(int64_t)v1 * Wg + h0];
+    interp += ((float)v1 - v_pos) * ((float)h1 - h_pos) * (float)guide[(int64_t)v0 * Wg + h0];
+    interp *= 2.0f;
+    return dirSign * (int)roundf(interp);
+}
+
+// Hamming distance between exact words (the target is gathered as uint32 here, no float round trip: hierarchical.h:175-178)
+struct WordVolume {
+    const uint32_t *w;
+    int W, nW;
+};
+__device__ __forceinline__ float compare_words(const WordVolume &src, const WordVolume &tgt, int i, int j, int jt) {
+    const uint32_t *s = src.w + ((int64_t)i * src.W + j) * src.nW;
+    const bool t_in = jt >= 0 && jt < tgt.W;
+    const uint32_t *t = tgt.w + ((int64_t)i * tgt.W + (t_in ? jt : 0)) * tgt.nW;
+    uint32_t score = 0;
+    for (int k = 0; k < src.nW; k++) score += __popc(s[k] ^ (t_in ? t[k] : 0u));
+    return (float)(uint16_t)score; // hamming_cv_t, matching_costs.h:234
+}
+
+struct GuideArgs {
+    const int32_t *guide;
+    int Hg, Wg, radius, dirSign;
+    bool cost;
+};
+
+template <class CmpFn>
+__device__ __forceinline__ void guided_select_body(CmpFn cmp, int H, int Ws, const GuideArgs &g, int32_t *__restrict__ disp) {
+    const int64_t npx = (int64_t)H * Ws;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(p % Ws), i = (int)(p / Ws);
+        const int d0 = guided_base_disp(g.guide, g.Hg, g.Wg, H, Ws, i, j, g.dirSign);
+        float score = g.cost ? INFINITY : -INFINITY;
+        int d_r = d0;
+        for (int delta_d = -g.radius; delta_d <= g.radius; delta_d++) { // :157-190: strict comparison, the first extremum wins
+            const float c = cmp(i, j, j + d0 + delta_d);
+            if (g.cost ? (c < score) : (c > score)) {
+                score = c;
+                d_r = d0 + delta_d;
+            }
+        }
+        disp[p] = g.dirSign * d_r; // :192
+    }
+}
+
+template <class CmpFn>
+__device__ __forceinline__ void guided_volume_body(CmpFn cmp, int H, int Ws, const GuideArgs &g, const int32_t *__restrict__ disp,
+                                                   float *__restrict__ tcv) {
+    const int T = 2 * g.radius + 1;
+    const int64_t n = (int64_t)H * Ws * T;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int dd = (int)(e % T);
+        const int64_t p = e / T;
+        const int j = (int)(p % Ws), i = (int)(p / Ws);
+        const int d_r = g.dirSign * disp[p];
+        tcv[e] = cmp(i, j, j + d_r + g.dirSign * (dd - g.radius));
+    }
+}
+
+template <class A, int CMP, bool ZM, bool NORM>
+__global__ void guided_select_kernel(A src, A tgt, const float *__restrict__ ms, const float *__restrict__ ns, const float *__restrict__ mt,
+                                     const float *__restrict__ nt, int H, int Ws, int Wt, GuideArgs g, int32_t *__restrict__ disp) {
+    guided_select_body([&](int i, int j, int jt) { return compare_features<A, CMP, ZM, NORM>(src, tgt, ms, ns, mt, nt, H, Ws, Wt, i, j, i, jt); }, H, Ws, g,
+                       disp);
+}
+template <class A, int CMP, bool ZM, bool NORM>
+__global__ void guided_volume_kernel(A src, A tgt, const float *__restrict__ ms, const float *__restrict__ ns, const float *__restrict__ mt,
+                                     const float *__restrict__ nt, int H, int Ws, int Wt, GuideArgs g, const int32_t *__restrict__ disp,
+                                     float *__restrict__ tcv) {
+    guided_volume_body([&](int i, int j, int jt) { return compare_features<A, CMP, ZM, NORM>(src, tgt, ms, ns, mt, nt, H, Ws, Wt, i, j, i, jt); }, H, Ws, g,
+                       disp, tcv);
+}
+__global__ void guided_select_words_kernel(WordVolume src, WordVolume tgt, int H, int Ws, GuideArgs g, int32_t *__restrict__ disp) {
+    guided_select_body([&](int i, int j, int jt) { return compare_words(src, tgt, i, j, jt); }, H, Ws, g, disp);
+}
+__global__ void guided_volume_words_kernel(WordVolume src, WordVolume tgt, int H, int Ws, GuideArgs g, const int32_t *__restrict__ disp,
+                                           float *__restrict__ tcv) {
+    guided_volume_body([&](int i, int j, int jt) { return compare_words(src, tgt, i, j, jt); }, H, Ws, g, disp, tcv);
+}
+
+template <class A, int CMP, bool ZM, bool NORM>
+int launch_guided(svh_context *ctx, A src, A tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws, int Wt,
+                  const GuideArgs &g, int32_t *disp, float *tcv) {
+    const int64_t npx = (int64_t)H * Ws;
+    SVH_LAUNCH(ctx, "guided_select", (guided_select_kernel<A, CMP, ZM, NORM>), grid_for(npx, 256, 16384), 256, 0, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g,
+               disp);
+    SVH_LAUNCH(ctx, "guided_volume", (guided_volume_kernel<A, CMP, ZM, NORM>), grid_for(npx * (2 * g.radius + 1), 256, 65536), 256, 0, src, tgt, ms, ns, mt,
+               nt, H, Ws, Wt, g, disp, tcv);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+template <class A>
+int guided_float(svh_context *ctx, Scratch &scr, int func, bool processed, A src, A tgt, int H, int Ws, int Wt, const GuideArgs &g, int32_t *disp,
+                 float *tcv) {
+    // `processed`: the features already went through getFeatureVolumeForMatchFunc (feature-volume entry point), the raw
+    // comparison is all that is left; otherwise means / norms are applied on the fly like in the cost-volume kernels
+    const bool zm = !processed && func_zero_mean(func), nrm = !processed && func_normalized(func);
+    float *ms = nullptr, *ns = nullptr, *mt = nullptr, *nt = nullptr;
+    if (zm) {
+        ms = scr.get_n<float>((size_t)H * Ws);
+        mt = scr.get_n<float>((size_t)H * Wt);
+        if (!ms || !mt) return SVH_ERR_OUT_OF_MEMORY;
+    }
+    if (nrm) {
+        ns = scr.get_n<float>((size_t)H * Ws);
+        nt = scr.get_n<float>((size_t)H * Wt);
+        if (!ns || !nt) return SVH_ERR_OUT_OF_MEMORY;
+    }
+    if (zm || nrm) {
+        SVH_TRY(launch_stats(ctx, src, H, Ws, zm, nrm, ms, ns));
+        SVH_TRY(launch_stats(ctx, tgt, H, Wt, zm, nrm, mt, nt));
+    }
+#define SVH_GUIDED(CMPV)                                                                                                     \
+    do {                                                                                                                     \
+        if (zm && nrm) return launch_guided<A, CMPV, true, true>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);    \
+        if (zm) return launch_guided<A, CMPV, true, false>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);          \
+        if (nrm) return launch_guided<A, CMPV, false, true>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);         \
+        return launch_guided<A, CMPV, false, false>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);                 \
+    } while (0)
+    switch (func) {
+    case SVH_CC: case SVH_NCC: case SVH_ZCC: case SVH_ZNCC: SVH_GUIDED(CMP_DOT);
+    case SVH_SSD: case SVH_ZSSD: SVH_GUIDED(CMP_SSD);
+    case SVH_SAD: case SVH_ZSAD: SVH_GUIDED(CMP_SAD);
+    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d is not available on the GPU path", func);
+    }
+#undef SVH_GUIDED
+}
+
+int guided_words(svh_context *ctx, WordVolume src, WordVolume tgt, int H, int Ws, const GuideArgs &g, int32_t *disp, float *tcv) {
+    const int64_t npx = (int64_t)H * Ws;
+    SVH_LAUNCH(ctx, "guided_select", guided_select_words_kernel, grid_for(npx, 256, 16384), 256, 0, src, tgt, H, Ws, g, disp);
+    SVH_LAUNCH(ctx, "guided_volume", guided_volume_words_kernel, grid_for(npx * (2 * g.radius + 1), 256, 65536), 256, 0, src, tgt, H, Ws, g, disp, tcv);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_downsample(svh_context *ctx, const float *img, int H, int W, int C, int win_h, int win_v, float *out) {
+    const int Ho = (H + win_v - 1) / win_v, Wo = (W + win_h - 1) / win_h;
+    const int64_t n = (int64_t)Ho * Wo * C;
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "average_pooling_downsample", downsample_kernel, grid_for(n, 256, 16384), 256, 0, img, H, W, C, win_h, win_v, Ho, Wo, out);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+// computeGuidedCV on the feature volumes of two images (unfold + getFeatureVolumeForMatchFunc evaluated on the fly)
+int dev_guided_from_images(svh_context *ctx, Scratch &scr, int func, int ddir, ImageDesc img_l, ImageDesc img_r, int h_r, int v_r, const int32_t *guide,
+                           int Hg, int Wg, int radius, float *tcv, int32_t *disp) {
+    const bool r2l = ddir == SVH_RIGHT_TO_LEFT;
+    const ImageDesc src = r2l ? img_r : img_l, tgt = r2l ? img_l : img_r;
+    const GuideArgs g{guide, Hg, Wg, radius, r2l ? 1 : -1, func_strategy(func) == SVH_COST};
+    if ((int64_t)src.H * src.W == 0) return SVH_OK;
+    if (func_census(func)) {
+        const int F = (2 * h_r + 1) * (2 * v_r + 1) * src.C;
+        const int nWw = census_words_written(F); // the never-written trailing word is 0 on both sides (rule E1): it adds nothing
+        if (nWw == 0) { // 3x3 and 5x5 grey windows: every distance is 0
+            WordVolume none{nullptr, src.W, 0}, nonet{nullptr, tgt.W, 0};
+            return guided_words(ctx, none, nonet, src.H, src.W, g, disp, tcv);
+        }
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)src.H * src.W * nWw), *tw = scr.get_n<uint32_t>((size_t)tgt.H * tgt.W * nWw);
+        if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_from_image(ctx, src, h_r, v_r, h_r, v_r, src.H, src.W, nWw, false, sw));
+        SVH_TRY(dev_census_from_image(ctx, tgt, h_r, v_r, h_r, v_r, tgt.H, tgt.W, nWw, false, tw));
+        return guided_words(ctx, WordVolume{sw, src.W, nWw}, WordVolume{tw, tgt.W, nWw}, src.H, src.W, g, disp, tcv);
+    }
+    return guided_float(ctx, scr, func, false, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r}, FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, src.H,
+                        src.W, tgt.W, g, disp, tcv);
+}
+
+// hiearchicalTruncatedCostVolume, hierarchical.h:232-294; radii arrays hold depth + 1 entries, coarsest level first
+int dev_hierarchical(svh_context *ctx, Scratch &scr, int func, int ddir, int depth, ImageDesc img_l, ImageDesc img_r, const int32_t *h_radii,
+                     const int32_t *v_radii, int disp_width, int radius, float *tcv, int32_t *disp) {
+    const bool r2l = ddir == SVH_RIGHT_TO_LEFT;
+    const int Hd = (img_l.H + 1) / 2, Wld = (img_l.W + 1) / 2, Wrd = (img_r.W + 1) / 2, C = img_l.C;
+    float *dl = scr.get_n<float>((size_t)Hd * Wld * C), *dr = scr.get_n<float>((size_t)Hd * Wrd * C);
+    if (!dl || !dr) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(dev_downsample(ctx, img_l.data, img_l.H, img_l.W, C, 2, 2, dl)); // :248-249
+    SVH_TRY(dev_downsample(ctx, img_r.data, img_r.H, img_r.W, C, 2, 2, dr));
+    const ImageDesc sl{dl, Hd, Wld, C}, sr{dr, Hd, Wrd, C};
+    const int Wsd = r2l ? Wrd : Wld;
+    int32_t *guide = scr.get_n<int32_t>((size_t)Hd * Wsd);
+    if (!guide) return SVH_ERR_OUT_OF_MEMORY;
+    if (depth == 1) { // full search at the coarsest level, :253-260
+        const int D0 = (disp_width + 1) / 2;
+        float *cv = scr.get_n<float>((size_t)Hd * Wsd * D0);
+        if (!cv) return SVH_ERR_OUT_OF_MEMORY;
+        CostVolumeArgs a{func, ddir, Hd, Wsd, r2l ? Wld : Wrd, 0, D0};
+        a.literal = ctx->literal_cost_volumes;
+        SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, r2l ? sr : sl, r2l ? sl : sr, h_radii[0], v_radii[0], cv));
+        SVH_TRY(dev_extract_index(ctx, func_strategy(func), cv, (int64_t)Hd * Wsd, D0, guide, nullptr, 0, 0));
+    } else { // :268-286: the radii of the coarser levels are the leading entries
+        float *tprev = scr.get_n<float>((size_t)Hd * Wsd * (2 * radius + 1));
+        if (!tprev) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_hierarchical(ctx, scr, func, ddir, depth - 1, sl, sr, h_radii, v_radii, (disp_width + 1) / 2, radius, tprev, guide));
+    }
+    return dev_guided_from_images(ctx, scr, func, ddir, img_l, img_r, h_radii[depth], v_radii[depth], guide, Hd, Wsd, radius, tcv, disp);
+}
+
+} // namespace
+
+} // namespace svh
+
+using namespace svh;
+
+extern "C" int svh_average_pooling_downsample(svh_context *ctx, const svh_array *img, int win_horizontal, int win_vertical, svh_array *out) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, img, "img", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, out, "out", SVH_F32, 2, 3));
+    if (win_horizontal < 1 || win_vertical < 1) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "window sizes must be positive");
+    if (out->ndim != img->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have the rank of img");
+    const int H = (int)img->shape[0], W = (int)img->shape[1], C = img->ndim == 3 ? (int)img->shape[2] : 1;
+    const int Ho = (H + win_vertical - 1) / win_vertical, Wo = (W + win_horizontal - 1) / win_horizontal; // downsampling.h:79-80
+    if (out->shape[0] != Ho || out->shape[1] != Wo || (img->ndim == 3 && out->shape[2] != C))
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have shape (%d,%d[,%d])", Ho, Wo, C);
+    Scratch scr(ctx);
+    void *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img, &di));
+    SVH_TRY(stage_out(ctx, scr, *out, &os));
+    SVH_TRY(dev_downsample(ctx, (const float *)di, H, W, C, win_horizontal, win_vertical, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+static int check_guided_outputs(svh_context *ctx, int H, int Ws, int radius, const svh_array *tcv, const svh_array *disp) {
+    SVH_TRY(validate(ctx, tcv, "tcv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 2, 2));
+    if (tcv->shape[0] != H || tcv->shape[1] != Ws || tcv->shape[2] != 2 * radius + 1)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "tcv must have shape (%d,%d,%d)", H, Ws, 2 * radius + 1);
+    if (disp->shape[0] != H || disp->shape[1] != Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d)", H, Ws);
+    return SVH_OK;
+}
+
+extern "C" int svh_guided_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *feat_l, const svh_array *feat_r,
+                                      const svh_array *guide, int32_t upscale_disp_radius, svh_array *tcv, svh_array *disp) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    const int ft = func_census(match_func) ? SVH_U32 : SVH_F32; // FeatureType, matching_costs.h:742-788
+    SVH_TRY(validate(ctx, feat_l, "feat_l", ft, 3, 3));
+    SVH_TRY(validate(ctx, feat_r, "feat_r", ft, 3, 3));
+    SVH_TRY(validate(ctx, guide, "guide", SVH_I32, 2, 2));
+    if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (upscale_disp_radius < 0 || upscale_disp_radius > 1024) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad search radius");
+    if (feat_l->shape[0] != feat_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ"); // hierarchical.h:90-92
+    if (feat_l->shape[2] != feat_r->shape[2]) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "feature counts differ");
+    if (guide->shape[0] < 2 || guide->shape[1] < 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "the guide must be at least 2x2 (bilinear taps, :108-137)");
+    const bool r2l = disp_direction == SVH_RIGHT_TO_LEFT;
+    const svh_array *src = r2l ? feat_r : feat_l, *tgt = r2l ? feat_l : feat_r;
+    const int H = (int)src->shape[0], Ws = (int)src->shape[1], Wt = (int)tgt->shape[1], F = (int)src->shape[2];
+    SVH_TRY(check_guided_outputs(ctx, H, Ws, upscale_disp_radius, tcv, disp));
+    Scratch scr(ctx);
+    void *ds, *dt, *dg;
+    OutStage ot, od;
+    SVH_TRY(stage_in(ctx, scr, *src, &ds));
+    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_in(ctx, scr, *guide, &dg));
+    SVH_TRY(stage_out(ctx, scr, *tcv, &ot));
+    SVH_TRY(stage_out(ctx, scr, *disp, &od));
+    const GuideArgs g{(const int32_t *)dg, (int)guide->shape[0], (int)guide->shape[1], upscale_disp_radius, r2l ? 1 : -1,
+                      func_strategy(match_func) == SVH_COST};
+    if ((int64_t)H * Ws > 0) {
+        if (func_census(match_func))
+            SVH_TRY(guided_words(ctx, WordVolume{(const uint32_t *)ds, Ws, F}, WordVolume{(const uint32_t *)dt, Wt, F}, H, Ws, g, (int32_t *)od.dptr,
+                                 (float *)ot.dptr));
+        else
+            SVH_TRY(guided_float(ctx, scr, match_func, true, FeatVolume{(const float *)ds, Ws, F}, FeatVolume{(const float *)dt, Wt, F}, H, Ws, Wt, g,
+                                 (int32_t *)od.dptr, (float *)ot.dptr));
+    }
+    SVH_TRY(finish_out(ctx, ot));
+    return finish_out(ctx, od);
+}
+
+extern "C" int svh_hierarchical_truncated_cost_volume(svh_context *ctx, int match_func, int disp_direction, int depth, const svh_array *img_l,
+                                                      const svh_array *img_r, const int32_t *h_radii, const int32_t *v_radii, int32_t disp_width,
+                                                      int32_t upscale_disp_radius, svh_array *tcv, svh_array *disp) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (depth < 1 || depth > 16) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "depth must be in [1,16] (static_assert depth > 0, hierarchical.h:243)");
+    if (!h_radii || !v_radii) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii arrays must hold depth + 1 entries");
+    for (int k = 0; k <= depth; k++)
+        if (h_radii[k] < 0 || v_radii[k] < 0 || h_radii[k] > 255 || v_radii[k] > 255)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "radii must be in [0,255] (uint8_t in the reference)");
+    if (disp_width < 1) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp_width must be positive");
+    if (upscale_disp_radius < 0 || upscale_disp_radius > 1024) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad search radius");
+    if (img_l->ndim != img_r->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "image ranks differ");
+    if (img_l->shape[0] != img_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ"); // cross_correlations.h:751-753 at the coarsest level
+    const int C = img_l->ndim == 3 ? (int)img_l->shape[2] : 1;
+    if (img_l->ndim == 3 && img_l->shape[2] != img_r->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "channel counts differ");
+    const bool r2l = disp_direction == SVH_RIGHT_TO_LEFT;
+    const int H = (int)img_l->shape[0], Wl = (int)img_l->shape[1], Wr = (int)img_r->shape[1], Ws = r2l ? Wr : Wl;
+    // every level must leave the bilinear guide at least 2x2 (hierarchical.h:108-137 reads outside it otherwise)
+    if ((H >> depth) < 2 || (Wl >> depth) < 2 || (Wr >> depth) < 2)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "images too small for %d levels", depth);
+    for (int k = 0; k <= depth; k++) {
+        const int F = (2 * h_radii[k] + 1) * (2 * v_radii[k] + 1) * C;
+        if (func_census(match_func) && F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    }
+    SVH_TRY(check_guided_outputs(ctx, H, Ws, upscale_disp_radius, tcv, disp));
+    Scratch scr(ctx);
+    void *dl, *dr;
+    OutStage ot, od;
+    SVH_TRY(stage_in(ctx, scr, *img_l, &dl));
+    SVH_TRY(stage_in(ctx, scr, *img_r, &dr));
+    SVH_TRY(stage_out(ctx, scr, *tcv, &ot));
+    SVH_TRY(stage_out(ctx, scr, *disp, &od));
+    SVH_TRY(dev_hierarchical(ctx, scr, match_func, disp_direction, depth, ImageDesc{(const float *)dl, H, Wl, C}, ImageDesc{(const float *)dr, H, Wr, C},
+                             h_radii, v_radii, disp_width, upscale_disp_radius, (float *)ot.dptr, (int32_t *)od.dptr));
+    SVH_TRY(finish_out(ctx, ot));
+    return finish_out(ctx, od);
+}

@@ -44,6 +44,7 @@ struct svh_context {
     bool profiling = false;
     std::string prof_filter; // when not empty only launches of this kernel are bracketed by events
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
+    bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;
@@ -175,6 +176,7 @@ struct CostVolumeArgs {
     int force_sign = 0;          // 0: +1 for RightToLeft, -1 for LeftToRight
     int64_t out_px_stride = 0;   // 0: D
     int64_t out_off = 0;
+    bool literal = false;        // skip the register-blocked kernel: the reference's operations in the reference's order
     WindowStatsCache *stats = nullptr; // optional: statistics maps shared by several passes over the same image pair
     int sign() const { return force_sign ? force_sign : (ddir == SVH_RIGHT_TO_LEFT ? 1 : -1); }
     int64_t px_stride() const { return out_px_stride ? out_px_stride : D; }

@@ -292,3 +292,65 @@ def refine_disp_2d_patch(tcv, raw, kernel=PARABOLA):
     if rc == 2:
         raise ValueError("patch refinement supports the Parabola and Gaussian kernels only")
     return out if rc == 0 else np.empty((0, 0, 0), np.float32)
+
+
+# ---- hierarchical matching ----------------------------------------------------------
+def average_pooling_downsample(img, win_h=2, win_v=None):
+    """Interpolation::averagePoolingDownsample (interpolation/downsampling.h:67-178); 2-D or 3-D float image."""
+    win_v = win_h if win_v is None else win_v
+    x = _img3(img)
+    H, W, Cc = x.shape
+    Ho, Wo = C.c_int(), C.c_int()
+    lib().so_downsample_shape(H, W, int(win_h), int(win_v), C.byref(Ho), C.byref(Wo))
+    out = np.empty((Ho.value, Wo.value, Cc), np.float32)
+    lib().so_average_pooling_downsample(_p(x), H, W, Cc, int(win_h), int(win_v), _p(out))
+    return out if np.ndim(img) == 3 else out[:, :, 0]
+
+
+def match_features(func, img, h_r, v_r):
+    """unfold + getFeatureVolumeForMatchFunc: float (H,W,F) or uint32 census words (H,W,nW)."""
+    x = _img3(img)
+    H, W, Cc = x.shape
+    F = (2 * h_r + 1) * (2 * v_r + 1) * Cc
+    census = int(func) in (HAMMING, CENSUS)
+    n = census_words(F) if census else F
+    out = np.empty((H, W, n), np.uint32 if census else np.float32)
+    lib().so_match_features(int(func), _p(x), H, W, Cc, int(h_r), int(v_r), _p(out))
+    return out
+
+
+def guided_cv(func, feat_l, feat_r, guide, radius, ddir=RIGHT_TO_LEFT):
+    """computeGuidedCV (hierarchical.h:74-229) on feature volumes; returns (tcv (H,Ws,2r+1), disp_estimate (H,Ws))."""
+    census = int(func) in (HAMMING, CENSUS)
+    dt = np.uint32 if census else np.float32
+    feat_l, feat_r = np.ascontiguousarray(feat_l, dt), np.ascontiguousarray(feat_r, dt)
+    guide = _i32(guide)
+    H, Wl, F = feat_l.shape
+    Wr = feat_r.shape[1]
+    Ws = Wr if ddir == RIGHT_TO_LEFT else Wl
+    tcv = np.empty((H, Ws, 2 * radius + 1), np.float32)
+    disp = np.empty((H, Ws), np.int32)
+    rc = lib().so_guided_cv(int(func), int(census), _p(feat_l), _p(feat_r), H, Wl, Wr, F, int(ddir), _p(guide), guide.shape[0], guide.shape[1],
+                            int(radius), _p(tcv), _p(disp))
+    if rc:
+        raise ValueError("guide must be at least 2x2")
+    return tcv, disp
+
+
+def hierarchical_truncated_cv(func, depth, img_l, img_r, h_radii, v_radii, disp_width, radius=2, ddir=RIGHT_TO_LEFT):
+    """hiearchicalTruncatedCostVolume<matchFunc, depth> (hierarchical.h:232-319); h_radii / v_radii: int or depth+1 ints."""
+    img_l, img_r = _img3(img_l), _img3(img_r)
+    H, Wl, Cc = img_l.shape
+    Wr = img_r.shape[1]
+    if img_r.shape[0] != H or img_r.shape[2] != Cc:
+        return np.empty((0, 0, 0), np.float32), np.empty((0, 0), np.int32)
+    hr = [int(h_radii)] * (depth + 1) if np.isscalar(h_radii) else [int(x) for x in h_radii]
+    vr = [int(v_radii)] * (depth + 1) if np.isscalar(v_radii) else [int(x) for x in v_radii]
+    Ws = Wr if ddir == RIGHT_TO_LEFT else Wl
+    tcv = np.empty((H, Ws, 2 * radius + 1), np.float32)
+    disp = np.empty((H, Ws), np.int32)
+    rc = lib().so_hierarchical_truncated_cv(int(func), int(depth), _p(img_l), _p(img_r), H, Wl, Wr, Cc, (C.c_int * len(hr))(*hr), (C.c_int * len(vr))(*vr),
+                                            int(disp_width), int(radius), int(ddir), _p(tcv), _p(disp))
+    if rc:
+        return np.empty((0, 0, 0), np.float32), np.empty((0, 0), np.int32)
+    return tcv, disp

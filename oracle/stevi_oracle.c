@@ -967,3 +967,189 @@ int so_refine_disp_2d_patch(int kernel, const float *tcv, const int32_t *raw, in
     return 0;
 #undef TCV
 }
+
+/* ===== hierarchical matching: SURVEY.md section 8(f) rank 3 ========================================================= */
+
+/* Interpolation::averagePoolingDownsample, interpolation/downsampling.h:67-178, as written: the inner row loop runs over
+ * windows.horizontal() (:92, :147), and the column offset is derived from the ROW remainder and vice versa (:82-86,
+ * :136-140).  With the 2x2 windows hierarchical.h uses, both offsets are 0 and odd sizes give a last window of one valid
+ * row / column whose mean is taken over the valid samples only.  img [H][W][C] -> out [Ho][Wo][C], float accumulation. */
+void so_downsample_shape(int H, int W, int win_h, int win_v, int *Ho, int *Wo) {
+    *Ho = (H + (win_v - 1)) / win_v;
+    *Wo = (W + (win_h - 1)) / win_h;
+}
+
+void so_average_pooling_downsample(const float *img, int H, int W, int C, int win_h, int win_v, float *out) {
+    int Ho, Wo;
+    so_downsample_shape(H, W, win_h, win_v, &Ho, &Wo);
+    int hRem = Ho * win_v - H, vRem = Wo * win_h - W;
+    int initialHOffset = hRem / 2, initialVOffset = vRem / 2;
+#pragma omp parallel for
+    for (int i = 0; i < Ho; i++)
+        for (int j = 0; j < Wo; j++)
+            for (int f = 0; f < C; f++) {
+                float val = 0;
+                int count = 0;
+                for (int dv = 0; dv < win_h; dv++) {
+                    int p_i = i * win_v - initialVOffset + dv;
+                    for (int dh = 0; dh < win_h; dh++) {
+                        int p_j = j * win_h - initialHOffset + dh;
+                        if (p_i >= 0 && p_i < H && p_j >= 0 && p_j < W) {
+                            val += img[((size_t)p_i * W + p_j) * C + f];
+                            count += 1;
+                        }
+                    }
+                }
+                val /= count;
+                out[((size_t)i * Wo + j) * C + f] = val;
+            }
+}
+
+/* computeGuidedCV<matchFunc>, correlation/hierarchical.h:74-229.  feat_l / feat_r are the feature volumes
+ * getFeatureVolumeForMatchFunc returns: float [H][W*][F] (is_census = 0) or uint32 words [H][W*][nW] (is_census = 1; the
+ * target words are gathered as uint32, NOT through a float: :175-178).  guide [Hg][Wg] int32, Hg, Wg >= 2 (the bilinear
+ * taps of :108-137 read outside the array otherwise).  Outputs: tcv [H][Ws][2r+1], disp [H][Ws].
+ * After the re-centring of :200-228, tcv(i,j,dd) = cmp(src(i,j), tgt(i, j + d_r + dirSign (dd - r))) for every dd, computed
+ * here exactly as the reference does (first pass around d0, shift, fill the uncovered entries). */
+int so_guided_cv(int func, int is_census, const void *feat_l, const void *feat_r, int H, int Wl, int Wr, int F, int ddir, const int32_t *guide,
+                 int Hg, int Wg, int radius, float *tcv, int32_t *disp) {
+    if (Hg < 2 || Wg < 2 || radius < 0) return 1;
+    const int dirSign = ddir == SO_RIGHT_TO_LEFT ? 1 : -1;
+    const void *src = ddir == SO_RIGHT_TO_LEFT ? feat_r : feat_l, *tgt = ddir == SO_RIGHT_TO_LEFT ? feat_l : feat_r;
+    const int w = ddir == SO_RIGHT_TO_LEFT ? Wr : Wl, wt = ddir == SO_RIGHT_TO_LEFT ? Wl : Wr, h = H;
+    const int depth = 2 * radius + 1;
+    const int cost = so_func_strategy(func) == SO_COST;
+#pragma omp parallel
+    {
+        void *tv = malloc((size_t)F * 4);
+#define GUIDED_CMP(col, res)                                                                                                       \
+    do {                                                                                                                           \
+        int c_ = (col);                                                                                                            \
+        if (is_census) {                                                                                                           \
+            for (int c = 0; c < F; c++) ((uint32_t *)tv)[c] = (c_ >= 0 && c_ < wt) ? ((const uint32_t *)tgt)[((size_t)i * wt + c_) * F + c] : 0u; \
+            res = cmp_hamming((const uint32_t *)src + ((size_t)i * w + j) * F, (const uint32_t *)tv, F);                           \
+        } else {                                                                                                                   \
+            for (int c = 0; c < F; c++) ((float *)tv)[c] = (c_ >= 0 && c_ < wt) ? ((const float *)tgt)[((size_t)i * wt + c_) * F + c] : 0.0f; \
+            res = cmp_float(func, (const float *)src + ((size_t)i * w + j) * F, (const float *)tv, F);                             \
+        }                                                                                                                          \
+    } while (0)
+#pragma omp for
+        for (int i = 0; i < h; i++) {
+            float v_pos = (float)(i * (Hg - 1)) / (h - 1); /* :108 */
+            int v0 = (int)floorf(v_pos), v1 = (int)ceilf(v_pos);
+            if (v0 == v1) v1 += 1;
+            if (v1 == Hg) { v0 -= 1; v1 -= 1; }
+            for (int j = 0; j < w; j++) {
+                float h_pos = (float)(j * (Wg - 1)) / (w - 1); /* :124 */
+                int h0 = (int)floorf(h_pos), h1 = (int)ceilf(h_pos);
+                if (h0 == h1) h1 += 1;
+                if (h1 == Wg) { h0 -= 1; h1 -= 1; }
+                float interp = 0; /* :138-147 */
+                interp += (v_pos - v0) * (h_pos - h0) * guide[(size_t)v1 * Wg + h1];
+                interp += (v1 - v_pos) * (h_pos - h0) * guide[(size_t)v0 * Wg + h1];
+                interp += (v_pos - v0) * (h1 - h_pos) * guide[(size_t)v1 * Wg + h0];
+                interp += (v1 - v_pos) * (h1 - h_pos) * guide[(size_t)v0 * Wg + h0];
+                interp *= 2;
+                int32_t d0 = dirSign * (int32_t)roundf(interp); /* :150 */
+                float *o = tcv + ((size_t)i * w + j) * depth;
+                float score = cost ? INFINITY : -INFINITY;
+                int32_t d_r = d0;
+                for (int delta_d = -radius; delta_d <= radius; delta_d++) { /* :157-190 */
+                    float cmp;
+                    GUIDED_CMP(j + d0 + delta_d, cmp);
+                    o[dirSign * delta_d + radius] = cmp;
+                    if (cost ? (cmp < score) : (cmp > score)) { score = cmp; d_r = d0 + delta_d; }
+                }
+                disp[(size_t)i * w + j] = dirSign * d_r; /* :192 */
+                if (d_r != d0) {                         /* :194-227 */
+                    int delta = dirSign * (d0 - d_r), startempty, endempty;
+                    if (delta > 0) {
+                        for (int dd = depth - 1; dd >= delta; dd--) o[dd] = o[dd - delta];
+                        startempty = 0;
+                        endempty = delta;
+                    } else {
+                        for (int dd = 0; dd < depth + delta; dd++) o[dd] = o[dd - delta];
+                        startempty = depth + delta;
+                        endempty = depth;
+                    }
+                    for (int dd = startempty; dd < endempty; dd++) GUIDED_CMP(j + d_r + dirSign * (dd - radius), o[dd]);
+                }
+            }
+        }
+        free(tv);
+    }
+#undef GUIDED_CMP
+    return 0;
+}
+
+/* feature volume of one image for a matching function: unfold (auto padding) + getFeatureVolumeForMatchFunc
+ * (cross_correlations.h:645-722); returns a malloc'ed float [H][W][F] or uint32 [H][W][nW] volume and the channel count */
+static void *match_features(int func, const float *img, int H, int W, int C, int h_r, int v_r, int *nchan) {
+    int F = (2 * h_r + 1) * (2 * v_r + 1) * C;
+    float *raw = (float *)malloc((size_t)H * W * F * sizeof(float));
+    so_unfold(img, H, W, C, h_r, v_r, NULL, raw);
+    if (func_census(func)) {
+        int nW = so_census_words(F);
+        uint32_t *words = (uint32_t *)malloc((size_t)H * W * nW * sizeof(uint32_t));
+        so_census_features(raw, H, W, F, words);
+        free(raw);
+        *nchan = nW;
+        return words;
+    }
+    float *out = (float *)malloc((size_t)H * W * F * sizeof(float));
+    processed_features(func, raw, H, W, F, out);
+    free(raw);
+    *nchan = F;
+    return out;
+}
+
+/* hiearchicalTruncatedCostVolume<matchFunc, depth>, correlation/hierarchical.h:232-294: recursion over 2x2 average-pooled
+ * images down to `depth` levels, full search with ceil(disp_width / 2^depth) disparities at the coarsest level
+ * (unfoldBasedCostVolume + extractSelectedIndex, :253-260), then one computeGuidedCV per level on the way up.
+ * h_radii / v_radii have depth + 1 entries, coarsest first (:256, :262 use [0] and [1]; :289 uses back()).
+ * Outputs at the resolution of the source image: tcv [H][Ws][2r+1], disp [H][Ws]. */
+int so_hierarchical_truncated_cv(int func, int depth, const float *img_l, const float *img_r, int H, int Wl, int Wr, int C,
+                                 const int *h_radii, const int *v_radii, int disp_width, int radius, int ddir, float *tcv, int32_t *disp) {
+    if (depth < 1 || !so_func_supported(func)) return 1;
+    int Hd, Wld, Wrd;
+    so_downsample_shape(H, Wl, 2, 2, &Hd, &Wld);
+    so_downsample_shape(H, Wr, 2, 2, &Hd, &Wrd);
+    float *dl = (float *)malloc((size_t)Hd * Wld * C * sizeof(float)), *dr = (float *)malloc((size_t)Hd * Wrd * C * sizeof(float));
+    so_average_pooling_downsample(img_l, H, Wl, C, 2, 2, dl);
+    so_average_pooling_downsample(img_r, H, Wr, C, 2, 2, dr);
+    int Wsd = ddir == SO_RIGHT_TO_LEFT ? Wrd : Wld;
+    int32_t *guide = (int32_t *)malloc((size_t)Hd * Wsd * sizeof(int32_t));
+    int rc = 0;
+    if (depth == 1) {
+        int D0 = (disp_width + 1) / 2;
+        float *cv = (float *)malloc((size_t)Hd * Wsd * D0 * sizeof(float));
+        rc = so_unfold_cost_volume(func, dl, dr, Hd, Wld, Hd, Wrd, C, h_radii[0], v_radii[0], ddir, 0, D0, cv);
+        if (rc == 0) so_extract_index(so_func_strategy(func), cv, Hd, Wsd, D0, guide);
+        free(cv);
+    } else {
+        float *tprev = (float *)malloc((size_t)Hd * Wsd * (2 * radius + 1) * sizeof(float));
+        rc = so_hierarchical_truncated_cv(func, depth - 1, dl, dr, Hd, Wld, Wrd, C, h_radii, v_radii, (disp_width + 1) / 2, radius, ddir, tprev, guide);
+        free(tprev);
+    }
+    if (rc == 0) {
+        int nl, nr;
+        void *fl = match_features(func, img_l, H, Wl, C, h_radii[depth], v_radii[depth], &nl);
+        void *fr = match_features(func, img_r, H, Wr, C, h_radii[depth], v_radii[depth], &nr);
+        rc = so_guided_cv(func, func_census(func), fl, fr, H, Wl, Wr, nl, ddir, guide, Hd, Wsd, radius, tcv, disp);
+        free(fl);
+        free(fr);
+    }
+    free(dl);
+    free(dr);
+    free(guide);
+    return rc;
+}
+
+/* the feature volumes computeGuidedCV is given in hierarchical.h:262-265 / :288-291, exposed for the tests */
+int so_match_features(int func, const float *img, int H, int W, int C, int h_r, int v_r, void *out) {
+    int n;
+    void *f = match_features(func, img, H, W, C, h_r, v_r, &n);
+    memcpy(out, f, (size_t)H * W * n * 4);
+    free(f);
+    return n;
+}

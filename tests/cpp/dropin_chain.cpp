@@ -8,6 +8,7 @@
 
 #include <correlation/cost_based_refinement.h>
 #include <correlation/cross_correlations.h>
+#include <correlation/hierarchical.h>
 #include <correlation/sgm.h>
 
 namespace SC = StereoVision::Correlation;
@@ -79,6 +80,15 @@ int main(int argc, char **argv) {
         dump(out + "_zncc2d_ref_iso.f32", ref_iso.data(), ref_iso.flatLenght());
         dump(out + "_zncc2d_ref_aniso.f32", ref_aniso.data(), ref_aniso.flatLenght());
         dump(out + "_zncc2d_ref_patch.f32", ref_patch.data(), ref_patch.flatLenght());
+    }
+    { // benchmarkCrossCorrelationAlgorithms.cpp:198-233: hiearchicalTruncatedCostVolume<matchFunc, depth>(target, source, h_r, v_r, disp_w)
+        constexpr auto matchFunc = SC::matchingFunctions::ZNCC;
+        SC::OffsetedCostVolume<float> result = SC::hiearchicalTruncatedCostVolume<matchFunc, 2>(target, source, uint8_t(2), uint8_t(2), D);
+        if (result.disp_estimate.shape()[0] != H || result.disp_estimate.shape()[1] != W) return 5;
+        dump(out + "_hier_disp.i32", result.disp_estimate.data(), result.disp_estimate.flatLenght());
+        dump(out + "_hier_tcv.f32", result.truncated_cost_volume.data(), result.truncated_cost_volume.flatLenght());
+        Multidim::Array<float, 2> half = StereoVision::Interpolation::averagePoolingDownsample(source, StereoVision::Interpolation::DownSampleWindows(2));
+        dump(out + "_half.f32", half.data(), half.flatLenght());
     }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);

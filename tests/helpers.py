@@ -87,3 +87,31 @@ def refined_2d_mismatch(got, want, raw, tol=1e-4):
     zero_w = np.all(want == raw, axis=-1)
     flipped = zero_g != zero_w
     return float(np.mean(bad & ~flipped)), float(np.mean(flipped))
+
+
+# ---- hierarchical matching: the scene and the acceptance rule of testCorrelationHierarchical.cpp:27-132 -------------
+def hierarchical_scene(depth, img_height=48, img_width=64, h_radius=2, v_radius=2, disp_w=16, seed=0):
+    disp_square = (disp_w & ~7) // 2
+    disp_bg = disp_square // 2
+    square_size = max(h_radius, v_radius) * (2 << max(3, depth)) + 1
+    v_pos, h_pos = img_height // 2 - square_size // 2, img_width // 2 - square_size // 2
+    src, tgt, _ = parallax_pair(img_height, img_width, square_size, v_pos, h_pos, disp_bg, disp_square, seed)
+    return dict(source=src, target=tgt, disp_square=disp_square, square=(v_pos, h_pos, square_size), disp_w=disp_w, h_radius=h_radius, v_radius=v_radius)
+
+
+def hierarchical_acceptance(scene, depth, disp, disp_rev, upscale_disp_radius=2):
+    """range check on both directions (:84-113) and >= 95 % exact matches inside the square (:115-140)"""
+    H, W = disp.shape
+    mo = 0
+    for _ in range(depth):
+        mo = mo * 2 + upscale_disp_radius
+    mo *= 2
+    assert disp.min() >= -mo and disp.max() <= scene["disp_w"] + mo
+    assert disp_rev.min() >= -mo and disp_rev.max() <= scene["disp_w"] + mo
+    v_pos, h_pos, size = scene["square"]
+    vr, hr = scene["v_radius"], scene["h_radius"]
+    rows = range(v_pos + 2 * depth * vr, min(v_pos + size - 3 * depth * vr, H - 2 * depth * vr))
+    cols = range(h_pos + 2 * depth * hr, min(h_pos + size - 3 * depth * hr, W - 2 * depth * hr))
+    expected = len(rows) * len(cols)
+    count = sum(int(disp[i, j] == scene["disp_square"]) for i in rows for j in cols)
+    assert expected > 0 and expected - count < 0.05 * expected, (count, expected)

@@ -54,6 +54,13 @@ def test_reference_call_chain_matches_oracle(tmp_path):
         got = np.fromfile(tmp_path / f"o_zncc2d_ref_{name}.f32", np.float32).reshape(H, W, 2)
         bad, flipped = refined_2d_mismatch(got, exp, disp2)
         assert bad == 0.0 and flipped <= 0.01, (name, bad, flipped)
+    etcv, edisp = so.hierarchical_truncated_cv(so.ZNCC, 2, tgt, src, 2, 2, D, 2)
+    hdisp = np.fromfile(tmp_path / "o_hier_disp.i32", np.int32).reshape(H, W)
+    same = hdisp == edisp
+    assert same.mean() >= 0.995  # default (register-blocked) coarsest volume: see tests/test_gpu_hierarchical.py
+    assert np.max(np.abs(np.fromfile(tmp_path / "o_hier_tcv.f32", np.float32).reshape(H, W, 5)[same] - etcv[same])) <= 1e-4
+    half = so.average_pooling_downsample(src, 2)
+    assert np.array_equal(np.fromfile(tmp_path / "o_half.f32", np.float32).reshape(half.shape), half)
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

@@ -1,0 +1,133 @@
+"""Hierarchical matching on the GPU: averagePoolingDownsample, computeGuidedCV and
+hiearchicalTruncatedCostVolume against the oracle, and the reference's own test (testCorrelationHierarchical.cpp) run
+directly against the HIP path."""
+import numpy as np
+import pytest
+
+import oracle as so
+from helpers import hierarchical_acceptance, hierarchical_scene, parallax_pair
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import libstevi_amd as sv  # noqa: E402
+from libstevi_amd import matchingFunctions as MF  # noqa: E402
+
+DEV = torch.device("cuda:0")
+R2L, L2R = sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight
+FLOAT_FUNCS = [MF.CC, MF.NCC, MF.SSD, MF.SAD, MF.ZCC, MF.ZNCC, MF.ZSSD, MF.ZSAD]
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else x
+
+
+@pytest.mark.parametrize("shape", [(7, 10), (8, 8), (33, 17), (6, 5, 3), (1, 9)])
+def test_downsample_is_bit_exact(rng, shape):
+    img = rng.uniform(-1, 1, shape).astype(np.float32)
+    for win in (2, 3, (2, 3), (3, 2)):
+        wh, wv = (win, win) if np.isscalar(win) else win
+        exp = so.average_pooling_downsample(img, wh, wv)
+        for mk in (lambda x: x, dev):
+            got = host(sv.averagePoolingDownsample(mk(img), win))
+            assert got.shape == exp.shape
+            assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))  # NaN (empty windows of the as-written offsets) included
+
+
+@pytest.mark.parametrize("func", FLOAT_FUNCS + [MF.CENSUS])
+@pytest.mark.parametrize("ddir", [R2L, L2R])
+def test_guided_cv_matches_oracle(rng, func, ddir):
+    """feature-volume entry point: integer estimates bit-exact, costs bit-exact (same float operations in the same order)"""
+    H, Wl, Wr, r = 21, 45, 41, 2
+    left = rng.uniform(-1, 1, (H, Wl)).astype(np.float32)
+    right = rng.uniform(-1, 1, (H, Wr)).astype(np.float32)
+    fl, fr = so.match_features(int(func), left, 2, 1), so.match_features(int(func), right, 2, 1)
+    ws = Wr if ddir == R2L else Wl
+    guide = rng.integers(-3, 9, (H // 2 + 1, ws // 2 + 1)).astype(np.int32)
+    for radius in (0, 1, r, 4):
+        etcv, edisp = so.guided_cv(int(func), fl, fr, guide, radius, int(ddir))
+        for mk in (lambda x: x, dev):
+            res = sv.computeGuidedCV(func, mk(fl), mk(fr), mk(guide), radius, ddir)
+            assert np.array_equal(host(res.disp_estimate), edisp)
+            got = host(res.truncated_cost_volume)
+            assert got.shape == etcv.shape
+            assert np.array_equal(got.view(np.uint32), etcv.view(np.uint32))
+
+
+def test_guided_cv_argument_rules(rng):
+    f = rng.uniform(-1, 1, (6, 9, 4)).astype(np.float32)
+    g = np.zeros((3, 5), np.int32)
+    assert sv.computeGuidedCV(MF.SAD, f, f[:5], g, 2).disp_estimate.size == 0  # row mismatch, hierarchical.h:90-92
+    with pytest.raises(Exception):
+        sv.computeGuidedCV(MF.SAD, f, f, np.zeros((1, 5), np.int32), 2)  # bilinear taps need a 2x2 guide
+    with pytest.raises(Exception):
+        sv.computeGuidedCV(MF.CENSUS, dev(f), dev(f), dev(g), 2)  # census features are uint32 words
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.SAD, MF.ZSSD, MF.CENSUS])
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_hierarchical_matches_oracle_literal(rng, func, depth):
+    """with the per-voxel coarsest volume the whole chain follows the reference operation by operation: estimates and
+    truncated costs must be bit-identical to the oracle, both directions, equal and per-level radii"""
+    src, tgt, _ = parallax_pair(52, 75, 24, 14, 22, 3, 9, seed=100 + depth)
+    x = dev(src)
+    sv.set_option(x, "literal_cost_volumes", 1)
+    try:
+        for ddir in (R2L, L2R):
+            for radii in (3, list(range(1, depth + 2))):
+                etcv, edisp = so.hierarchical_truncated_cv(int(func), depth, tgt, src, radii, radii, 20, 2, int(ddir))
+                res = sv.hiearchicalTruncatedCostVolume(func, depth, dev(tgt), x, radii, radii, 20, 2, ddir)
+                assert np.array_equal(host(res.disp_estimate), edisp)
+                assert np.array_equal(host(res.truncated_cost_volume).view(np.uint32), etcv.view(np.uint32))
+    finally:
+        sv.set_option(x, "literal_cost_volumes", 0)
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SAD])
+def test_hierarchical_default_kernels_agree_with_literal(rng, func):
+    """default (register-blocked coarsest volume): costs within rounding; an estimate may only differ where the coarsest
+    winner was a near tie, so at least 99.5 % of the pixels carry identical estimates and costs within 1e-4"""
+    src, tgt, _ = parallax_pair(120, 200, 60, 30, 70, 4, 12, seed=7)
+    for mk in (lambda a: a, dev):
+        res = sv.hiearchicalTruncatedCostVolume(func, 2, mk(tgt), mk(src), 2, 2, 32, 2)
+        etcv, edisp = so.hierarchical_truncated_cv(int(func), 2, tgt, src, 2, 2, 32, 2)
+        same = host(res.disp_estimate) == edisp
+        assert same.mean() >= 0.995
+        assert np.max(np.abs(host(res.truncated_cost_volume)[same] - etcv[same])) <= 1e-4
+
+
+def test_hierarchical_multichannel_and_shape_rules(rng):
+    rgb_l = rng.uniform(-1, 1, (40, 56, 3)).astype(np.float32)
+    rgb_r = rng.uniform(-1, 1, (40, 56, 3)).astype(np.float32)
+    x = dev(rgb_l)
+    sv.set_option(x, "literal_cost_volumes", 1)
+    try:
+        etcv, edisp = so.hierarchical_truncated_cv(so.ZSAD, 2, rgb_l, rgb_r, 1, 1, 12, 1)
+        res = sv.hiearchicalTruncatedCostVolume(MF.ZSAD, 2, x, dev(rgb_r), 1, 1, 12, 1)
+        assert np.array_equal(host(res.disp_estimate), edisp)
+        assert np.array_equal(host(res.truncated_cost_volume).view(np.uint32), etcv.view(np.uint32))
+    finally:
+        sv.set_option(x, "literal_cost_volumes", 0)
+    assert sv.hiearchicalTruncatedCostVolume(MF.SAD, 1, rgb_l, rgb_r[:39], 1, 1, 12).disp_estimate.size == 0  # row mismatch
+    with pytest.raises(Exception):
+        sv.hiearchicalTruncatedCostVolume(MF.SAD, 5, rgb_l, rgb_r, 1, 1, 12)  # 40 rows do not leave a 2x2 guide after 5 levels
+    with pytest.raises(ValueError):
+        sv.hiearchicalTruncatedCostVolume(MF.SAD, 2, rgb_l, rgb_r, [1, 1], [1, 1], 12)  # needs depth + 1 radii
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_reference_testMatchingFilter_on_gpu(depth):
+    """testCorrelationHierarchical.cpp:27-170 (rows small_lvl{1,2,3}_zncc) against the HIP path with its default kernels."""
+    sc = hierarchical_scene(depth, seed=20 + depth)
+    res = sv.hiearchicalTruncatedCostVolume(MF.ZNCC, depth, dev(sc["target"]), dev(sc["source"]), 2, 2, 16, 2)
+    rev = sv.hiearchicalTruncatedCostVolume(MF.ZNCC, depth, dev(sc["target"]), dev(sc["source"]), 2, 2, 16, 2, L2R)
+    disp = host(res.disp_estimate)
+    assert disp.shape == sc["source"].shape and tuple(res.truncated_cost_volume.shape) == sc["source"].shape + (5,)
+    hierarchical_acceptance(sc, depth, disp, host(rev.disp_estimate))

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle as so
-from helpers import isotropic_patch, rotated_quadric_patch, naive_window_cost
+from helpers import hierarchical_acceptance, hierarchical_scene, isotropic_patch, rotated_quadric_patch, naive_window_cost
 
 SHAPES = [(3, 3, 1), (1, 1, 5), (3, 3, 5), (5, 1, 5), (1, 5, 5), (5, 5, 5)]  # testCorrelationFilters.cpp:270-275
 FUNCS = {"CC": so.CC, "NCC": so.NCC, "SSD": so.SSD, "SAD": so.SAD, "ZCC": so.ZCC, "ZNCC": so.ZNCC, "ZSSD": so.ZSSD,
@@ -198,3 +198,70 @@ def test_2d_refinement_rules():
     a = so.refine_disp_2d(cost, raw, so.PARABOLA, so.ANISOTROPIC)
     b = so.refine_disp_2d(-cost, raw, so.PARABOLA, so.ANISOTROPIC)
     assert np.allclose(a, b, atol=1e-6) and np.allclose(a[0, 0], [3.2, -2.3], atol=1e-5)
+
+
+# ---- hierarchical matching: testCorrelationHierarchical.cpp ---------------------------------------------------------
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_hierarchical_matching_filter(depth):
+    """testMatchingFilter rows small_lvl{1,2,3}_zncc (testCorrelationHierarchical.cpp:158-170): 48x64 pair, 5x5 windows,
+    disp_w 16, upscale radius 2, both directions; shapes, range bound and >= 95 % exact matches inside the square."""
+    sc = hierarchical_scene(depth, seed=10 + depth)
+    tcv, disp = so.hierarchical_truncated_cv(so.ZNCC, depth, sc["target"], sc["source"], 2, 2, 16, 2)
+    _, disp_rev = so.hierarchical_truncated_cv(so.ZNCC, depth, sc["target"], sc["source"], 2, 2, 16, 2, so.LEFT_TO_RIGHT)
+    assert disp.shape == sc["source"].shape and tcv.shape == sc["source"].shape + (5,)
+    hierarchical_acceptance(sc, depth, disp, disp_rev)
+
+
+def test_average_pooling_downsample_rules(rng):
+    """interpolation/downsampling.h:67-114: output size ceil(n / window); even sizes are plain 2x2 means, an odd last row /
+    column averages the valid samples only (count, :101-106)."""
+    img = rng.uniform(-1, 1, (7, 10)).astype(np.float32)
+    out = so.average_pooling_downsample(img, 2)
+    assert out.shape == (4, 5)
+    assert np.allclose(out[:3], img[:6].reshape(3, 2, 5, 2).mean(axis=(1, 3)), atol=1e-6)
+    assert np.allclose(out[3], img[6].reshape(5, 2).mean(axis=1), atol=1e-6)
+    rgb = rng.uniform(-1, 1, (6, 5, 3)).astype(np.float32)
+    out3 = so.average_pooling_downsample(rgb, 2)
+    assert out3.shape == (3, 3, 3) and np.allclose(out3[:, 2], rgb[:, 4].reshape(3, 2, 3).mean(axis=1), atol=1e-6)
+
+
+def test_guided_cv_recentres_on_the_winner(rng):
+    """computeGuidedCV (hierarchical.h:74-229): whatever the guide, the truncated volume ends up centred on the selected
+    disparity: tcv(i,j,dd) = cmp(src(i,j), tgt(i, j + d_r + dirSign (dd - r))); checked against a direct evaluation."""
+    H, W, r = 9, 23, 2
+    left = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    right = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    guide = rng.integers(0, 4, (5, 12)).astype(np.int32)
+    for func, ddir in ((so.SAD, so.RIGHT_TO_LEFT), (so.ZNCC, so.LEFT_TO_RIGHT), (so.CENSUS, so.RIGHT_TO_LEFT)):
+        fl, fr = so.match_features(func, left, 3, 3), so.match_features(func, right, 3, 3)
+        tcv, disp = so.guided_cv(func, fl, fr, guide, r, ddir)
+        sign = 1 if ddir == so.RIGHT_TO_LEFT else -1
+        src, tgt = (fr, fl) if ddir == so.RIGHT_TO_LEFT else (fl, fr)
+        cost = so.func_strategy(func) == so.COST
+        for i in range(H):
+            for j in range(W):
+                d_r = sign * disp[i, j]
+                for dd in range(2 * r + 1):
+                    col = j + d_r + sign * (dd - r)
+                    t = tgt[i, col] if 0 <= col < W else np.zeros_like(tgt[0, 0])
+                    if func == so.CENSUS:
+                        exp = sum(bin(int(a) ^ int(b)).count("1") for a, b in zip(src[i, j], t))
+                    elif func == so.SAD:
+                        exp = np.abs(src[i, j].astype(np.float64) - t).sum()
+                    else:
+                        exp = float(src[i, j].astype(np.float64) @ t)
+                    assert abs(tcv[i, j, dd] - exp) < 1e-4
+    # with a constant guide g the search window is centred on d0 = dirSign * 2g everywhere: the estimate is the first strict
+    # extremum of cmp(src(i,j), tgt(i, j + d0 + delta)), delta = -r..r (:157-190)
+    fl, fr = so.match_features(so.SAD, left, 1, 1), so.match_features(so.SAD, right, 1, 1)
+    tcv, disp = so.guided_cv(so.SAD, fl, fr, np.full((4, 4), 3, np.int32), r, so.RIGHT_TO_LEFT)
+    for i in range(H):
+        for j in range(W):
+            best, arg = np.inf, 6
+            for delta in range(-r, r + 1):
+                col = j + 6 + delta
+                t = fl[i, col] if 0 <= col < W else np.zeros_like(fl[0, 0])
+                c = np.float32(np.abs(fr[i, j] - t).astype(np.float32).sum(dtype=np.float32))
+                if c < best - 1e-5:
+                    best, arg = c, 6 + delta
+            assert disp[i, j] == arg

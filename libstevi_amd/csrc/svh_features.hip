@@ -125,39 +125,49 @@ struct CensusJob { // one image of a launch (blockIdx.z selects): both images of
     uint32_t *words;
 };
 
-template <int HR, int VR>
-__global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(CensusJob job0, CensusJob job1, int pl, int pt, int n_out) {
+// word = 2 * word + (ref > sample): the compare writes VCC, the add-with-carry consumes it
+__device__ __forceinline__ void shift_in_greater(uint32_t &word, float ref, float sample) {
+    asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(ref), "v"(sample) : "vcc");
+}
+
+// ROWS output rows per block: the (2 VR + ROWS) x (512 + 2 HR) tile is staged once and every lane keeps its
+// (2 VR + ROWS) x (2 HR + 2) samples in registers, so an output row costs a staged row and (2 HR + 2) / 2 LDS reads
+// instead of a whole window of each
+template <int HR, int VR, int ROWS, int TJN>
+__global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, CensusJob job1, int pl, int pt, int n_out) {
     const CensusJob &job = blockIdx.z == 0 ? job0 : job1;
     const float *__restrict__ img = job.img;
     uint32_t *__restrict__ words = job.words;
     const int H = job.H, W = job.W, Ho = job.Ho, Wo = job.Wo;
     const bool round_target = job.round_target;
-    constexpr int PXB = 2 * CENSUS_TJ; // two neighbouring pixels per lane
-    if ((int)blockIdx.y >= Ho || (int)blockIdx.x * PXB >= Wo) return; // the grid covers the larger image
-    constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TW = PXB + h + 1; // row pitch even: float2 reads stay 8-byte aligned
+    constexpr int PXB = 2 * TJN; // two neighbouring pixels per lane
+    if ((int)blockIdx.y * ROWS >= Ho || (int)blockIdx.x * PXB >= Wo) return; // the grid covers the larger image
+    constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TR = v + ROWS - 1, TW = PXB + h + 1; // row pitch even: float2 reads stay 8-byte aligned
     constexpr int NWRITTEN = (h * v - 1) / 32;
-    __shared__ __attribute__((aligned(16))) float tile[v * TW];
-    const int i = blockIdx.y, j0 = blockIdx.x * PXB, tj = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float tile[TR * TW];
+    const int i0 = blockIdx.y * ROWS, j0 = blockIdx.x * PXB, tj = threadIdx.x;
     // stage the tile: every load of the thread is issued before the first LDS write, so a block pays one memory latency
-    constexpr int PER_ROW = (TW + CENSUS_TJ - 1) / CENSUS_TJ;
-    float r[v][PER_ROW];
+    constexpr int PER_ROW = (TW + TJN - 1) / TJN;
+    {
+        float r[TR][PER_ROW];
 #pragma unroll
-    for (int k = 0; k < v; k++) {
-        const int ii = i - pt + k;
-        const bool row_in = ii >= 0 && ii < H;
-        const float *row = img + (int64_t)ii * W;
+        for (int k = 0; k < TR; k++) {
+            const int ii = i0 - pt + k;
+            const bool row_in = ii >= 0 && ii < H;
+            const float *row = img + (int64_t)ii * W;
 #pragma unroll
-        for (int q = 0; q < PER_ROW; q++) {
-            const int e = tj + q * CENSUS_TJ, jj = j0 - pl + e;
-            r[k][q] = (row_in && e < TW && jj >= 0 && jj < W) ? row[jj] : 0.0f;
+            for (int q = 0; q < PER_ROW; q++) {
+                const int e = tj + q * TJN, jj = j0 - pl + e;
+                r[k][q] = (row_in && e < TW && jj >= 0 && jj < W) ? row[jj] : 0.0f;
+            }
         }
-    }
 #pragma unroll
-    for (int k = 0; k < v; k++) {
+        for (int k = 0; k < TR; k++) {
 #pragma unroll
-        for (int q = 0; q < PER_ROW; q++) {
-            const int e = tj + q * CENSUS_TJ;
-            if (e < TW) tile[k * TW + e] = r[k][q];
+            for (int q = 0; q < PER_ROW; q++) {
+                const int e = tj + q * TJN;
+                if (e < TW) tile[k * TW + e] = r[k][q];
+            }
         }
     }
     __syncthreads();
@@ -166,43 +176,58 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_grey_kernel(CensusJob job0, 
     const int jA = j0 + 2 * tj;
     if (jA >= Wo) return;
     const float *tp = tile + 2 * tj;
-    const float refA = tp[0], refB = tp[1];
-    uint32_t dA[NWRITTEN > 0 ? NWRITTEN : 1] = {}, dB[NWRITTEN > 0 ? NWRITTEN : 1] = {};
+    float smp[TR][h + 1];
 #pragma unroll
-    for (int k = 0; k < v; k++) {
-        float smp[h + 1];
+    for (int k = 0; k < TR; k++) {
 #pragma unroll
         for (int q = 0; q < (h + 1) / 2; q++) {
             const float2 pr = *reinterpret_cast<const float2 *>(tp + k * TW + 2 * q);
-            smp[2 * q] = pr.x;
-            smp[2 * q + 1] = pr.y;
-        }
-#pragma unroll
-        for (int l = 0; l < h; l++) {
-            const int c = h * k + l; // channel index (unfold.h:180); bit (c-1) % 32 of word (c-1) / 32 (census.h:98-108)
-            if (c >= 1 && (c - 1) / 32 < NWRITTEN) {
-                dA[(c - 1) / 32] |= (refA > smp[l] ? 1u : 0u) << ((c - 1) % 32);
-                dB[(c - 1) / 32] |= (refB > smp[l + 1] ? 1u : 0u) << ((c - 1) % 32);
-            }
+            smp[k][2 * q] = pr.x;
+            smp[k][2 * q + 1] = pr.y;
         }
     }
-    uint32_t *oA = words + ((int64_t)i * Wo + jA) * n_out;
     const bool hasB = jA + 1 < Wo;
 #pragma unroll
-    for (int w = 0; w < NWRITTEN; w++) {
-        oA[w] = round_target ? round_word_through_float(dA[w]) : dA[w];
-        if (hasB) oA[n_out + w] = round_target ? round_word_through_float(dB[w]) : dB[w];
-    }
-    for (int w = NWRITTEN; w < n_out; w++) { // rule E1
-        oA[w] = 0;
-        if (hasB) oA[n_out + w] = 0;
+    for (int rr = 0; rr < ROWS; rr++) {
+        const int i = i0 + rr;
+        if (i >= Ho) break;
+        // the bits of each word from the highest channel down: word = 2 word + (ref > sample) is one v_cmp (-> VCC) and one
+        // v_addc (carry-in = VCC) per bit; the reference pixel is the window's top-left sample (finding F6)
+        const float refA = smp[rr][0], refB = smp[rr][1];
+        uint32_t dA[NWRITTEN > 0 ? NWRITTEN : 1] = {}, dB[NWRITTEN > 0 ? NWRITTEN : 1] = {};
+#pragma unroll
+        for (int w = 0; w < NWRITTEN; w++) {
+#pragma unroll
+            for (int b = 31; b >= 0; b--) {
+                const int c = 32 * w + b + 1; // channel index (unfold.h:180) behind bit b of word w (census.h:98-108)
+                const int k = c / h, l = c % h;
+                shift_in_greater(dA[w], refA, smp[rr + k][l]);
+                shift_in_greater(dB[w], refB, smp[rr + k][l + 1]);
+            }
+        }
+        uint32_t *oA = words + ((int64_t)i * Wo + jA) * n_out;
+#pragma unroll
+        for (int w = 0; w < NWRITTEN; w++) {
+            oA[w] = round_target ? round_word_through_float(dA[w]) : dA[w];
+            if (hasB) oA[n_out + w] = round_target ? round_word_through_float(dB[w]) : dB[w];
+        }
+        for (int w = NWRITTEN; w < n_out; w++) { // rule E1
+            oA[w] = 0;
+            if (hasB) oA[n_out + w] = 0;
+        }
     }
 }
-
+template <int HR, int VR, int ROWS, int TJN>
+static void launch_census_grey_as(svh_context *ctx, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {
+    dim3 grid(ceil_div(std::max(a.Wo, b ? b->Wo : 0), 2 * TJN), ceil_div(std::max(a.Ho, b ? b->Ho : 0), ROWS), b ? 2 : 1);
+    SVH_LAUNCH(ctx, "census_transform", (census_grey_kernel<HR, VR, ROWS, TJN>), grid, TJN, 0, a, b ? *b : a, pl, pt, n_out);
+}
 template <int HR, int VR>
 static void launch_census_grey(svh_context *ctx, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {
-    dim3 grid(ceil_div(std::max(a.Wo, b ? b->Wo : 0), 2 * CENSUS_TJ), std::max(a.Ho, b ? b->Ho : 0), b ? 2 : 1);
-    SVH_LAUNCH(ctx, "census_transform", (census_grey_kernel<HR, VR>), grid, CENSUS_TJ, 0, a, b ? *b : a, pl, pt, n_out);
+    // measured at 1080p, 9x9 (MI355X): 1 / 2 / 3 / 4 rows x 128 / 256 lanes all land within 31-34 us; 4 rows x 128 lanes was the
+    // fastest.  11x11 windows keep two rows (register budget: (2 VR + ROWS) x (2 HR + 2) samples per lane)
+    if (HR <= 4) launch_census_grey_as<HR, VR, 4, 128>(ctx, a, b, pl, pt, n_out);
+    else launch_census_grey_as<HR, VR, 2, 128>(ctx, a, b, pl, pt, n_out);
 }
 
 static bool census_grey_dispatch(svh_context *ctx, int h_r, int v_r, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {

@@ -172,6 +172,11 @@ int svh_refine_disp_cost_interpolation(svh_context *ctx, int interp_kernel, cons
  * cv (H,W,Dh,Dw) f32, CV(i,j,dh,dw) = cmp(src(i,j,:), tgt(i+dh+lower0, j+dw+lower1,:)); image sizes must agree. */
 int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r,
                               int h_radius, int v_radius, int32_t lower0, int32_t upper0, int32_t lower1, int32_t upper1, svh_array *cv);
+/* featureVolume2CostVolume<matchFunc, ..., searchOffset<2>, dDir>(feature_vol_l, feature_vol_r, searchRange)
+ *                                                              correlation/cross_correlations.h:724-738 (+ :310-374)
+ * raw feature volumes (H,W*,F) f32 -> cv (H,Ws,Dh,Dw) f32; only the row counts must agree (:324-326). */
+int svh_feature_cost_volume_2d(svh_context *ctx, int match_func, int disp_direction, const svh_array *feat_l, const svh_array *feat_r,
+                               int32_t lower0, int32_t upper0, int32_t lower1, int32_t upper1, svh_array *cv);
 /* extractSelected2dIndex<strategy>(cv) -> idx (H,W,2) i32                          correlation/correlation_base.h:466-509 */
 int svh_extract_selected_2d_index(svh_context *ctx, int strategy, const svh_array *cv, svh_array *idx);
 /* selected2dIndexToDisp(idx, searchOffset<2>) -> disp (H,W,2) i32                  correlation/correlation_base.h:534-555 */

@@ -29,7 +29,7 @@ EXPORTS = [
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
-    "svh_average_pooling_downsample", "svh_guided_cost_volume", "svh_hierarchical_truncated_cost_volume",
+    "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_guided_cost_volume", "svh_hierarchical_truncated_cost_volume",
 ]
 
 
@@ -125,6 +125,7 @@ def load():
         "svh_stereo_match": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A, A, A]),
         "svh_keys_to_index": (C.c_int, [ctx, C.c_int, A, i32, A]),
         "svh_unfold_cost_volume_2d": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_int, i32, i32, i32, i32, A]),
+        "svh_feature_cost_volume_2d": (C.c_int, [ctx, C.c_int, C.c_int, A, A, i32, i32, i32, i32, A]),
         "svh_extract_selected_2d_index": (C.c_int, [ctx, C.c_int, A, A]),
         "svh_selected_2d_index_to_disp": (C.c_int, [ctx, A, i32, i32, A]),
         "svh_truncated_bidirectional_cost_volume": (C.c_int, [ctx, A, A, C.c_int, C.c_int, A]),

@@ -274,14 +274,24 @@ def censusTransform2D(input, h_radius, v_radius, padding=None):
 
 
 def featureVolume2CostVolume(matchFunc, feature_vol_l, feature_vol_r, searchRange, dDir=dispDirection.RightToLeft):
-    """featureVolume2CostVolume<matchFunc,...,dDir,float> -- correlation/cross_correlations.h:724-738."""
+    """featureVolume2CostVolume<matchFunc,...,dDir,float> -- correlation/cross_correlations.h:724-738.
+    searchRange: int / searchOffset1 -> (H,W,D) volume; searchOffset2 -> (H,W,Dh,Dw) volume (aggregateCost :310-374)."""
     lib = _capi.load()
     l, r = _prep(feature_vol_l, np.float32), _prep(feature_vol_r, np.float32)
     ctx = context_for(l)
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    if isinstance(searchRange, searchOffset2):
+        o = searchRange
+        Dh, Dw = o.upper0 - o.lower0 + 1, o.upper1 - o.lower1 + 1
+        if l.shape[0] != r.shape[0] or Dh <= 0 or Dw <= 0:
+            return _empty_like(l, 4, "f32")
+        out = _like(l, (src.shape[0], src.shape[1], Dh, Dw), "f32")
+        st = _check(ctx, lib.svh_feature_cost_volume_2d(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), o.lower0, o.upper0,
+                                                        o.lower1, o.upper1, C.byref(_desc(out))))
+        return out if st == _capi.OK else _empty_like(l, 4, "f32")
     lower, D = _search_range(searchRange)
     if l.shape[0] != r.shape[0]:
         return _empty_like(l, 3, "f32")
-    src = r if int(dDir) == dispDirection.RightToLeft else l
     out = _like(l, (src.shape[0], src.shape[1], D), "f32")
     st = _check(ctx, lib.svh_feature_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), lower, D,
                                                  C.byref(_desc(out))))

@@ -342,3 +342,59 @@ extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int d
     }
     return finish_out(ctx, os);
 }
+
+// featureVolume2CostVolume<matchFunc, ..., searchOffset<2>, dDir>(feature_vol_l, feature_vol_r, searchRange)
+//                                                       correlation/cross_correlations.h:724-738 over aggregateCost :310-374
+// Raw (H,W*,F) float feature volumes in, getFeatureVolumeForMatchFunc applied on the fly; only the row counts must agree
+// (:324-326), the target may be narrower or wider than the source.
+extern "C" int svh_feature_cost_volume_2d(svh_context *ctx, int match_func, int disp_direction, const svh_array *feat_l, const svh_array *feat_r,
+                                          int32_t lower0, int32_t upper0, int32_t lower1, int32_t upper1, svh_array *cv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, feat_l, "feat_l", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, feat_r, "feat_r", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 4, 4));
+    if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
+    if (feat_l->shape[0] != feat_r->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ");
+    if (feat_l->shape[2] != feat_r->shape[2]) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "feature counts differ");
+    const int Dh = upper0 - lower0 + 1, Dw = upper1 - lower1 + 1;
+    if (Dh <= 0 || Dw <= 0) return fail(ctx, SVH_EMPTY_RESULT, "empty search range"); // :338-340
+    const int F = (int)feat_l->shape[2];
+    if (func_census(match_func) && F <= 1) return fail(ctx, SVH_EMPTY_RESULT, "census needs at least two feature channels");
+    const bool r2l = disp_direction == SVH_RIGHT_TO_LEFT;
+    const svh_array *src = r2l ? feat_r : feat_l, *tgt = r2l ? feat_l : feat_r;
+    const int H = (int)src->shape[0], Ws = (int)src->shape[1], Wt = (int)tgt->shape[1];
+    if (cv->shape[0] != H || cv->shape[1] != Ws || cv->shape[2] != Dh || cv->shape[3] != Dw)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv must have shape (%d,%d,%d,%d)", H, Ws, Dh, Dw);
+    Scratch scr(ctx);
+    void *ds, *dt;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *src, &ds));
+    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_out(ctx, scr, *cv, &os));
+    CostVolumeArgs a{match_func, disp_direction, H, Ws, Wt, lower1, Dw};
+    a.force_sign = 1;
+    a.out_px_stride = (int64_t)Dh * Dw;
+    if (func_census(match_func)) { // census words once (target side rounded through float, rule E2), one Hamming pass per vertical offset
+        const int nWw = census_words_written(F);
+        uint32_t *sw = scr.get_n<uint32_t>((size_t)H * Ws * (nWw ? nWw : 1));
+        uint32_t *tw = scr.get_n<uint32_t>((size_t)H * Wt * (nWw ? nWw : 1));
+        if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_from_features(ctx, (const float *)ds, H, Ws, F, nWw, false, sw));
+        SVH_TRY(dev_census_from_features(ctx, (const float *)dt, H, Wt, F, nWw, true, tw));
+        for (int dh = 0; dh < Dh; dh++) {
+            a.tgt_row_off = lower0 + dh;
+            a.out_off = (int64_t)dh * Dw;
+            SVH_TRY(dev_hamming_volume(ctx, a, sw, tw, nWw, (float *)os.dptr));
+        }
+    } else {
+        for (int dh = 0; dh < Dh; dh++) {
+            a.tgt_row_off = lower0 + dh;
+            a.out_off = (int64_t)dh * Dw;
+            Scratch inner(ctx); // per-pass mean / norm maps
+            SVH_TRY(dev_cost_volume_from_features(ctx, inner, a, (const float *)ds, (const float *)dt, F, (float *)os.dptr));
+        }
+    }
+    return finish_out(ctx, os);
+}

@@ -21,24 +21,39 @@ inline void rangeOf(searchOffset<1> const &r, int32_t &lower, int32_t &count) {
 }
 } // namespace HipBridge
 
-// featureVolume2CostVolume<matchFunc, T_L, T_R, SearchRangeType, dDir, TCV>, cross_correlations.h:724-738
+// featureVolume2CostVolume<matchFunc, T_L, T_R, SearchRangeType, dDir, TCV>, cross_correlations.h:724-738: disp_t / searchOffset<1>
+// give a (row, col, disparity) volume (aggregateCost :194-308), searchOffset<2> a (row, col, dh, dw) one (:310-374)
 template <matchingFunctions matchFunc, class T_L, class T_R, typename SearchRangeType, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
-inline Multidim::Array<TCV, 3> featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim::Array<T_R, 3> const &feature_vol_r,
-                                                        SearchRangeType searchRange) {
+inline Multidim::Array<TCV, searchRangeTypeInfos<SearchRangeType>::CostVolumeDims>
+featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim::Array<T_R, 3> const &feature_vol_r, SearchRangeType searchRange) {
     static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
     static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
-    static_assert(searchRangeTypeInfos<SearchRangeType>::CostVolumeDims == 3, "libstevi_hip: 1-D disparity ranges only (disp_t or searchOffset<1>)");
-    int32_t lower, count;
-    HipBridge::rangeOf(searchRange, lower, count);
-    if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || count <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :209-211
+    constexpr int nCvDims = searchRangeTypeInfos<SearchRangeType>::CostVolumeDims;
     auto const &src = (dDir == dispDirection::RightToLeft) ? feature_vol_r.shape() : feature_vol_l.shape();
-    // aggregateCost's own layout (cross_correlations.h:220) is {w*D, 1, w}; the GPU's native one is dense (row, col, disparity)
-    Multidim::Array<TCV, 3> cv(src[0], src[1], count);
-    std::lock_guard<std::mutex> g(HipBridge::lock());
-    svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
-    if (!HipBridge::check(svh_feature_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, lower, count, &out)))
-        return Multidim::Array<TCV, 3>(0, 0, 0);
-    return cv;
+    if constexpr (nCvDims == 3) {
+        int32_t lower, count;
+        HipBridge::rangeOf(searchRange, lower, count);
+        if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || count <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :209-211
+        // aggregateCost's own layout (cross_correlations.h:220) is {w*D, 1, w}; the GPU's native one is dense (row, col, disparity)
+        Multidim::Array<TCV, 3> cv(src[0], src[1], count);
+        std::lock_guard<std::mutex> g(HipBridge::lock());
+        svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
+        if (!HipBridge::check(svh_feature_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, lower, count, &out)))
+            return Multidim::Array<TCV, 3>(0, 0, 0);
+        return cv;
+    } else {
+        static_assert(nCvDims == 4, "libstevi_hip: disp_t, searchOffset<1> or searchOffset<2>");
+        const int Dh = searchRange.dimRange(0), Dw = searchRange.dimRange(1);
+        if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || Dh <= 0 || Dw <= 0) return Multidim::Array<TCV, 4>(); // :324-326, :338-340
+        Multidim::Array<TCV, 4> cv(src[0], src[1], Dh, Dw);
+        std::lock_guard<std::mutex> g(HipBridge::lock());
+        svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
+        if (!HipBridge::check(svh_feature_cost_volume_2d(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r,
+                                                         searchRange.template lowerOffset<0>(), searchRange.template upperOffset<0>(),
+                                                         searchRange.template lowerOffset<1>(), searchRange.template upperOffset<1>(), &out)))
+            return Multidim::Array<TCV, 4>();
+        return cv;
+    }
 }
 
 // unfoldBasedCostVolume<matchFunc, T_L, T_R, nImDim, dDir, TCV>(img_l, img_r, h_radius, v_radius, disp_width), cross_correlations.h:740-765

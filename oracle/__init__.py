@@ -354,3 +354,17 @@ def hierarchical_truncated_cv(func, depth, img_l, img_r, h_radii, v_radii, disp_
     if rc:
         return np.empty((0, 0, 0), np.float32), np.empty((0, 0), np.int32)
     return tcv, disp
+
+
+def feature_cost_volume_2d(func, feat_l, feat_r, range0, range1, ddir=RIGHT_TO_LEFT):
+    """featureVolume2CostVolume with a searchOffset<2> on raw feature volumes; (H, Ws, Dh, Dw) or an empty array."""
+    feat_l, feat_r = _f32(feat_l), _f32(feat_r)
+    H, Wl, F = feat_l.shape
+    Dh, Dw = range0[1] - range0[0] + 1, range1[1] - range1[0] + 1
+    if feat_r.shape[0] != H or feat_r.shape[2] != F or Dh <= 0 or Dw <= 0:
+        return np.empty((0, 0, 0, 0), np.float32)
+    Wr = feat_r.shape[1]
+    cv = np.empty((H, Wr if ddir == RIGHT_TO_LEFT else Wl, Dh, Dw), np.float32)
+    rc = lib().so_feature_cost_volume_2d(int(func), _p(feat_l), _p(feat_r), H, Wl, Wr, F, int(ddir), int(range0[0]), int(range0[1]), int(range1[0]),
+                                         int(range1[1]), _p(cv))
+    return cv if rc == 0 else np.empty((0, 0, 0, 0), np.float32)

@@ -1153,3 +1153,31 @@ int so_match_features(int func, const float *img, int H, int W, int C, int h_r, 
     free(f);
     return n;
 }
+
+/* featureVolume2CostVolume<matchFunc, ..., searchOffset<2>> on raw feature volumes, cross_correlations.h:724-738 over
+ * aggregateCost :310-374: only the row counts must agree (:324-326).  cv [H][Ws][Dh][Dw]. */
+int so_feature_cost_volume_2d(int func, const float *feat_l, const float *feat_r, int H, int Wl, int Wr, int F, int ddir, int lower0, int upper0,
+                              int lower1, int upper1, float *cv) {
+    int Dh = upper0 - lower0 + 1, Dw = upper1 - lower1 + 1;
+    if (Dh <= 0 || Dw <= 0 || !so_func_supported(func)) return 1;
+    const float *src = ddir == SO_RIGHT_TO_LEFT ? feat_r : feat_l, *tgt = ddir == SO_RIGHT_TO_LEFT ? feat_l : feat_r;
+    int Ws = ddir == SO_RIGHT_TO_LEFT ? Wr : Wl, Wt = ddir == SO_RIGHT_TO_LEFT ? Wl : Wr;
+    if (func_census(func)) {
+        if (F <= 1) return 1;
+        int nW = so_census_words(F);
+        uint32_t *ws = (uint32_t *)malloc((size_t)H * Ws * nW * sizeof(uint32_t)), *wt = (uint32_t *)malloc((size_t)H * Wt * nW * sizeof(uint32_t));
+        so_census_features(src, H, Ws, F, ws);
+        so_census_features(tgt, H, Wt, F, wt);
+        aggregate_hamming_2d(ws, wt, H, Ws, Wt, nW, lower0, Dh, lower1, Dw, cv);
+        free(ws);
+        free(wt);
+    } else {
+        float *ps = (float *)malloc((size_t)H * Ws * F * sizeof(float)), *pt = (float *)malloc((size_t)H * Wt * F * sizeof(float));
+        processed_features(func, src, H, Ws, F, ps);
+        processed_features(func, tgt, H, Wt, F, pt);
+        aggregate_float_2d(func, ps, pt, H, Ws, Wt, F, lower0, Dh, lower1, Dw, cv);
+        free(ps);
+        free(pt);
+    }
+    return 0;
+}

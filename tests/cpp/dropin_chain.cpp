@@ -73,6 +73,11 @@ int main(int argc, char **argv) {
         dump(out + "_zncc2d_cv.f32", CV2.data(), CV2.flatLenght());
         dump(out + "_zncc2d_disp.i32", disp2.data(), disp2.flatLenght());
         if (tcv2.shape()[2] != 3 || tcv2.shape()[3] != 3) return 4;
+        // feature-volume form, as testOnDemandCostVolume.cpp:139 calls it
+        auto fl = SC::unfold<float, float>(2, 2, target), fr = SC::unfold<float, float>(2, 2, source);
+        Multidim::Array<float, 4> CV2f = SC::featureVolume2CostVolume<matchFunc, float, float, SC::searchOffset<2>, SC::dispDirection::RightToLeft, float>(fl, fr, searchRange);
+        if (CV2f.shape()[2] != CV2.shape()[2] || CV2f.shape()[3] != CV2.shape()[3]) return 6;
+        dump(out + "_zncc2d_cv_feat.f32", CV2f.data(), CV2f.flatLenght());
         // the refinement examples/stereo-match --refine applies (main.cpp:198-210), plus the two other 2-D variants
         auto ref_iso = SC::refineDisp2dCostInterpolation<SC::InterpolationKernel::Equiangular>(tcv2, disp2);
         auto ref_aniso = SC::refineDisp2dCostInterpolation<SC::InterpolationKernel::Parabola, SC::IsotropyHypothesis::Anisotropic>(tcv2, disp2);

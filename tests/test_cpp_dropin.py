@@ -45,6 +45,8 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     cv2 = so.unfold_cost_volume_2d(so.ZNCC, tgt, src, 2, 2, (-1, 2), (-2, 3))
     got2 = np.fromfile(tmp_path / "o_zncc2d_cv.f32", np.float32).reshape(cv2.shape)
     assert np.array_equal(np.isnan(got2), np.isnan(cv2)) and np.nanmax(np.abs(got2 - cv2)) <= 1e-4
+    got2f = np.fromfile(tmp_path / "o_zncc2d_cv_feat.f32", np.float32).reshape(cv2.shape)
+    assert np.nanmax(np.abs(got2f - cv2)) <= 1e-4  # same volume through unfold + featureVolume2CostVolume(searchOffset<2>)
     disp2 = np.fromfile(tmp_path / "o_zncc2d_disp.i32", np.int32).reshape(H, W, 2)
     assert np.array_equal(disp2, so.index_2d_to_disp(so.extract_index_2d(got2, so.SCORE), -1, -2))
     idx2 = so.extract_index_2d(got2, so.SCORE)

@@ -179,3 +179,25 @@ def test_reference_cost_refinement_tests_on_gpu(rng, trial):
     assert abs(ref[0, 0, 0] - b[0]) < 2e-6 and abs(ref[0, 0, 1] - b[1]) < 2e-6
     ref = host(sv.refineDisp2dCostPatchInterpolation(IK.Parabola, dev(rotated_quadric_patch(d1, d2, 3 * rng.uniform(-1, 1), b, 3)), dev(zero)))
     assert ref[0, 0, 0] == pytest.approx(b[0], rel=1e-5, abs=2e-6) and ref[0, 0, 1] == pytest.approx(b[1], rel=1e-5, abs=2e-6)
+
+
+@pytest.mark.parametrize("func", list(NAMES.values()) + [MF.CENSUS])
+def test_feature_volume_2d_matches_oracle(rng, func):
+    """featureVolume2CostVolume with a searchOffset<2> on raw feature volumes (cross_correlations.h:310-374): widths may differ"""
+    fl = rng.uniform(-10, 10, (11, 17, 7)).astype(np.float32)
+    fr = rng.uniform(-10, 10, (11, 14, 7)).astype(np.float32)
+    if func == MF.CENSUS:
+        fl, fr = np.repeat(fl, 6, axis=2)[:, :, :40], np.repeat(fr, 6, axis=2)[:, :, :40]  # at least one full census word
+        fl = (fl + rng.uniform(-3, 3, fl.shape)).astype(np.float32)
+        fr = (fr + rng.uniform(-3, 3, fr.shape)).astype(np.float32)
+    for ddir in (sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight):
+        for r0, r1 in (((-2, 2), (-3, 1)), ((1, 1), (0, 5))):
+            exp = so.feature_cost_volume_2d(int(func), fl, fr, r0, r1, int(ddir))
+            for mk in (lambda x: x, dev):
+                got = host(sv.featureVolume2CostVolume(func, mk(fl), mk(fr), sv.searchOffset2(r0[0], r0[1], r1[0], r1[1]), ddir))
+                assert got.shape == exp.shape
+                if func == MF.CENSUS:
+                    assert np.array_equal(got, exp)
+                else:
+                    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))  # the per-voxel kernel follows the reference's operation order
+    assert sv.featureVolume2CostVolume(MF.SAD, fl, fr[:10], sv.searchOffset2(0, 1, 0, 1)).size == 0

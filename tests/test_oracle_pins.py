@@ -265,3 +265,23 @@ def test_guided_cv_recentres_on_the_winner(rng):
                 if c < best - 1e-5:
                     best, arg = c, 6 + delta
             assert disp[i, j] == arg
+
+
+# ---- on-demand cost volume tests that pin the dense feature-volume paths: testOnDemandCostVolume.cpp ------------------
+@pytest.mark.parametrize("name", ["NCC", "ZNCC", "SSD", "SAD"])
+def test_feature_volume_2d_equals_per_offset_1d(rng, name):
+    """testOnDemandCVOpticalFlow (testOnDemandCostVolume.cpp:117-170) compares every in-range entry of
+    featureVolume2CostVolume(searchOffset<2>) with the pairwise feature comparison; restated here against the 1-D volume of
+    row-shifted targets, which the stereo variant of the same test (:66-115) pins entry by entry."""
+    H, W, F, r = 7, 9, 6, 2
+    src = rng.uniform(-10, 10, (H, W, F)).astype(np.float32)
+    tgt = rng.uniform(-10, 10, (H, W, F)).astype(np.float32)
+    cv = so.feature_cost_volume_2d(FUNCS[name], tgt, src, (-r, r), (-r, r))
+    assert cv.shape == (H, W, 2 * r + 1, 2 * r + 1)
+    for dh in range(-r, r + 1):
+        shifted = np.zeros_like(tgt)
+        lo, hi = max(0, -dh), min(H, H - dh)
+        shifted[lo:hi] = tgt[lo + dh:hi + dh]
+        one = so.feature_cost_volume(FUNCS[name], shifted, src, 2 * r + 1, so.RIGHT_TO_LEFT, -r)
+        rows = slice(lo, hi)  # rows whose shifted target exists; elsewhere the target vector is zero, not a processed zero row
+        assert np.allclose(cv[rows, :, dh + r, :], one[rows], rtol=1e-5, atol=1e-5)

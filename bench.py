@@ -202,6 +202,16 @@ def main():
         traffic = load_measured_traffic(dom_name)
         if traffic is not None:
             roof["traffic"] = traffic
+        # The HBM model above prices traffic this design never generates; the roof that physically binds census_sweep is VALU
+        # issue.  Per 64 voxels a SIMD issues 2 v_xor (full rate, 2 cycles each) + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3 (half rate,
+        # 4 cycles each on gfx950: tools/ubench_valu.hip) = 18 cycles; 256 CUs x 4 SIMDs at 2.4 GHz.
+        issue = None
+        if dom_name == "census_sweep":
+            vox_launch = wl1["W"] * wl1["H"] * wl1["D"]
+            peak_vox = 1024 * 2.4e9 / 18.0 * 64.0
+            ach_vox = vox_launch / (avg_ms * 1e-3)
+            issue = {"bound": "valu_issue", "kernel": dom_name, "cycles_per_64_voxels_per_simd": 18, "peak": round(peak_vox / 1e9, 1),
+                     "achieved": round(ach_vox / 1e9, 1), "unit": "Gvoxels/s", "frac": round(ach_vox / peak_vox, 4)}
         pipeline_alg = 28.0 * voxels + 60.0 * wl["W"] * wl["H"]
         kernel_ms = {k: round(v[0] / n_warm, 4) for k, v in prof_all.items()}  # from the warm-up steps (all kernels bracketed)
         line = {
@@ -218,6 +228,7 @@ def main():
             "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                   "model": "SURVEY.md 8(d) C3: 28 B/voxel + 60 B/pixel"},
+            "issue_roofline": issue,
             "kernel_ms_per_step_warmup": kernel_ms,
             "disp_checksum": checksum,
         }

@@ -166,6 +166,25 @@ int svh_truncated_cost_volume(svh_context *ctx, int tcv_direction, int disp_dire
 int svh_refine_disp_cost_interpolation(svh_context *ctx, int interp_kernel, const svh_array *tcv, const svh_array *raw,
                                        svh_array *refined);
 
+/* ---- A7 / A8 per-pixel statistics and feature-volume transforms as stand-alone functions -----------------------------------
+ * (the cost-volume entry points evaluate them on the fly; examples/stereo_refine_test/main.cpp:386-398 calls them directly)
+ * feat (H,W,F) f32; maps (H,W) f32; transformed volumes (H,W,F) f32.
+ * channelsMean                                                                   correlation/correlation_base.h:1100-1136 */
+int svh_channels_mean(svh_context *ctx, const svh_array *feat, svh_array *mean);
+/* channelsNorm: sqrtf(sum v^2)                                                    correlation/cross_correlations.h:149-191 */
+int svh_channels_norm(svh_context *ctx, const svh_array *feat, svh_array *norm);
+/* channelsZeroMeanNorm: sqrtf(sum (v - mean)^2); mean == NULL -> channelsMean first (the one-argument overload)   :61-122 */
+int svh_channels_zero_mean_norm(svh_context *ctx, const svh_array *feat, const svh_array *mean, svh_array *norm);
+/* zeromeanFeatureVolume: v - mean                                                                                 :570-594 */
+int svh_zeromean_feature_volume(svh_context *ctx, const svh_array *feat, const svh_array *mean, svh_array *out);
+/* normalizedFeatureVolume: v / norm (true division, norm 0 -> NaN / inf)                                          :504-550 */
+int svh_normalized_feature_volume(svh_context *ctx, const svh_array *feat, const svh_array *norm, svh_array *out);
+/* zeromeanNormalizedFeatureVolume: (v - mean) / norm                                                              :416-462 */
+int svh_zeromean_normalized_feature_volume(svh_context *ctx, const svh_array *feat, const svh_array *mean, const svh_array *norm, svh_array *out);
+/* getFeatureVolumeForMatchFunc<matchFunc>(feature_vol): the volume aggregateCost / computeGuidedCV consume          :645-722
+ * out (H,W,F) f32, or (H,W,nW) u32 census words for CENSUS / HAMMING (single-channel input -> SVH_EMPTY_RESULT). */
+int svh_feature_volume_for_match_func(svh_context *ctx, int match_func, const svh_array *feat, svh_array *out);
+
 /* ---- 2-D disparity (optical-flow style) volumes: SURVEY.md section 8(f) rank 2 --------------------------------------
  * unfoldBased2dDisparityCostVolume<matchFunc,...>(img_l, img_r, h_radius, v_radius, searchOffset<2>(lower0, upper0, lower1, upper1))
  *                                                                 correlation/cross_correlations.h:794-822 (+ :310-374)

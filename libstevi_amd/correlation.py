@@ -546,6 +546,71 @@ def refineDisp2dCostPatchInterpolation(kernel, truncatedCostVolume, rawDisparity
     return out if st == _capi.OK else _empty_like(tcv, 3, "f32")
 
 
+# ---- A7 / A8: per-pixel statistics and feature-volume transforms as stand-alone functions -------------------------------
+def _map_call(fn, feat, *maps):
+    lib = _capi.load()
+    f = _prep(feat, np.float32)
+    ms = [None if m is None else _prep(m, np.float32) for m in maps]
+    ctx = context_for(f)
+    out = _like(f, (f.shape[0], f.shape[1]), "f32")
+    _check(ctx, getattr(lib, fn)(ctx, C.byref(_desc(f)), *[None if m is None else C.byref(_desc(m)) for m in ms], C.byref(_desc(out))))
+    return out
+
+
+def _volume_call(fn, feat, *maps):
+    lib = _capi.load()
+    f = _prep(feat, np.float32)
+    ms = [_prep(m, np.float32) for m in maps]
+    ctx = context_for(f)
+    out = _like(f, tuple(f.shape), "f32")
+    _check(ctx, getattr(lib, fn)(ctx, C.byref(_desc(f)), *[C.byref(_desc(m)) for m in ms], C.byref(_desc(out))))
+    return out
+
+
+def channelsMean(in_data):
+    """channelsMean -- correlation/correlation_base.h:1100-1136."""
+    return _map_call("svh_channels_mean", in_data)
+
+
+def channelsNorm(in_data):
+    """channelsNorm -- correlation/cross_correlations.h:149-191."""
+    return _map_call("svh_channels_norm", in_data)
+
+
+def channelsZeroMeanNorm(in_data, mean=None):
+    """channelsZeroMeanNorm(in_data[, mean]) -- correlation/cross_correlations.h:61-122."""
+    return _map_call("svh_channels_zero_mean_norm", in_data, mean)
+
+
+def zeromeanFeatureVolume(feature_vol, mean):
+    """zeromeanFeatureVolume -- correlation/cross_correlations.h:570-594."""
+    return _volume_call("svh_zeromean_feature_volume", feature_vol, mean)
+
+
+def normalizedFeatureVolume(feature_vol, norm):
+    """normalizedFeatureVolume -- correlation/cross_correlations.h:504-550."""
+    return _volume_call("svh_normalized_feature_volume", feature_vol, norm)
+
+
+def zeromeanNormalizedFeatureVolume(feature_vol, mean, norm):
+    """zeromeanNormalizedFeatureVolume -- correlation/cross_correlations.h:416-462."""
+    return _volume_call("svh_zeromean_normalized_feature_volume", feature_vol, mean, norm)
+
+
+def getFeatureVolumeForMatchFunc(matchFunc, feature_vol):
+    """getFeatureVolumeForMatchFunc<matchFunc> -- correlation/cross_correlations.h:645-722: float32 volume, or uint32 census words."""
+    lib = _capi.load()
+    f = _prep(feature_vol, np.float32)
+    ctx = context_for(f)
+    census = int(matchFunc) in (matchingFunctions.CENSUS, matchingFunctions.HAMMING)
+    H, W, F = f.shape
+    if census and F <= 1:
+        return _empty_like(f, 3, "u32")
+    out = _like(f, (H, W, (F - 1) // 32 + 1), "u32") if census else _like(f, (H, W, F), "f32")
+    st = _check(ctx, lib.svh_feature_volume_for_match_func(ctx, int(matchFunc), C.byref(_desc(f)), C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(f, 3, "u32" if census else "f32")
+
+
 # ---- hierarchical matching (SURVEY.md section 8f rank 3) ----------------------------------------------------------
 def averagePoolingDownsample(input, windows):
     """Interpolation::averagePoolingDownsample(input, DownSampleWindows) -- interpolation/downsampling.h:67-178.

@@ -136,6 +136,18 @@ Multidim::Array<T_CV, 4> truncatedBidirectionaCostVolume(Multidim::Array<T_CV, 4
     return tcv;
 }
 
+// channelsMean<T_I, T_O>(in_data), correlation_base.h:1100-1136
+template <class T_I, class T_O = float, Multidim::ArrayDataAccessConstness C>
+inline Multidim::Array<T_O, 2> channelsMean(Multidim::Array<T_I, 3, C> const &in_data) {
+    static_assert(std::is_same_v<std::remove_const_t<T_I>, float> && std::is_same_v<T_O, float>, "libstevi_hip: float feature volumes only");
+    Multidim::Array<T_O, 2> mean(in_data.shape()[0], in_data.shape()[1]);
+    if (mean.empty()) return mean;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array in = HipBridge::describe(in_data), out = HipBridge::describe(mean);
+    HipBridge::check(svh_channels_mean(HipBridge::context(), &in, &out));
+    return mean;
+}
+
 } // namespace Correlation
 } // namespace StereoVision
 

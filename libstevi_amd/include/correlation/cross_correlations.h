@@ -21,6 +21,86 @@ inline void rangeOf(searchOffset<1> const &r, int32_t &lower, int32_t &count) {
 }
 } // namespace HipBridge
 
+// ---- per-pixel statistics and feature-volume transforms (rows A7 / A8), float volumes ------------------------------------
+namespace HipBridge {
+template <class Fn, class... Maps> inline Multidim::Array<float, 2> mapOf(Fn fn, svh_array in, int h, int w, Maps... maps) {
+    Multidim::Array<float, 2> out(h, w);
+    if (out.empty()) return out;
+    std::lock_guard<std::mutex> g(lock());
+    svh_array o = describe(out);
+    check(fn(context(), &in, maps..., &o));
+    return out;
+}
+template <class Fn, class... Maps> inline Multidim::Array<float, 3> volumeOf(Fn fn, svh_array in, int h, int w, int f, Maps... maps) {
+    Multidim::Array<float, 3> out(h, w, f);
+    if (out.empty()) return out;
+    std::lock_guard<std::mutex> g(lock());
+    svh_array o = describe(out);
+    check(fn(context(), &in, maps..., &o));
+    return out;
+}
+} // namespace HipBridge
+
+// channelsZeroMeanNorm(in_data, mean) and channelsZeroMeanNorm(in_data), cross_correlations.h:61-122
+template <class T_I, class T_M, class T_O = float, Multidim::ArrayDataAccessConstness Cd, Multidim::ArrayDataAccessConstness Cm>
+Multidim::Array<T_O, 2> channelsZeroMeanNorm(Multidim::Array<T_I, 3, Cd> const &in_data, Multidim::Array<T_M, 2, Cm> const &mean) {
+    static_assert(std::is_same_v<T_O, float>, "libstevi_hip: float statistics");
+    svh_array m = HipBridge::describe(mean);
+    return HipBridge::mapOf(svh_channels_zero_mean_norm, HipBridge::describe(in_data), in_data.shape()[0], in_data.shape()[1], (const svh_array *)&m);
+}
+template <class T_I, class T_M = float, class T_O = float, Multidim::ArrayDataAccessConstness C>
+Multidim::Array<T_O, 2> channelsZeroMeanNorm(Multidim::Array<T_I, 3, C> const &in_data) {
+    static_assert(std::is_same_v<T_O, float>, "libstevi_hip: float statistics");
+    return HipBridge::mapOf(svh_channels_zero_mean_norm, HipBridge::describe(in_data), in_data.shape()[0], in_data.shape()[1], (const svh_array *)nullptr);
+}
+// channelsNorm(in_data), cross_correlations.h:149-191
+template <class T_I, class T_O = float, Multidim::ArrayDataAccessConstness C> Multidim::Array<T_O, 2> channelsNorm(Multidim::Array<T_I, 3, C> const &in_data) {
+    static_assert(std::is_same_v<T_O, float>, "libstevi_hip: float statistics");
+    return HipBridge::mapOf(svh_channels_norm, HipBridge::describe(in_data), in_data.shape()[0], in_data.shape()[1]);
+}
+// zeromeanNormalizedFeatureVolume(feature_vol, mean, norm), cross_correlations.h:416-462
+template <class T_I, class T_M, class T_N, class T_O = float, Multidim::ArrayDataAccessConstness Cf, Multidim::ArrayDataAccessConstness Cm,
+          Multidim::ArrayDataAccessConstness Cn>
+inline Multidim::Array<T_O, 3> zeromeanNormalizedFeatureVolume(Multidim::Array<T_I, 3, Cf> const &feature_vol, Multidim::Array<T_M, 2, Cm> const &mean,
+                                                               Multidim::Array<T_N, 2, Cn> const &norm) {
+    static_assert(std::is_same_v<T_O, float>, "libstevi_hip: float feature volumes");
+    svh_array m = HipBridge::describe(mean), n = HipBridge::describe(norm);
+    auto shp = feature_vol.shape();
+    return HipBridge::volumeOf(svh_zeromean_normalized_feature_volume, HipBridge::describe(feature_vol), shp[0], shp[1], shp[2], (const svh_array *)&m,
+                               (const svh_array *)&n);
+}
+// normalizedFeatureVolume(feature_vol, norm), cross_correlations.h:504-550
+template <class T_I, class T_N, class T_O = float, Multidim::ArrayDataAccessConstness Cf, Multidim::ArrayDataAccessConstness Cn>
+inline Multidim::Array<T_O, 3> normalizedFeatureVolume(Multidim::Array<T_I, 3, Cf> const &feature_vol, Multidim::Array<T_N, 2, Cn> const &norm) {
+    static_assert(std::is_same_v<T_O, float>, "libstevi_hip: float feature volumes");
+    svh_array n = HipBridge::describe(norm);
+    auto shp = feature_vol.shape();
+    return HipBridge::volumeOf(svh_normalized_feature_volume, HipBridge::describe(feature_vol), shp[0], shp[1], shp[2], (const svh_array *)&n);
+}
+// zeromeanFeatureVolume(feature_vol, mean), cross_correlations.h:570-594
+template <class T_I, class T_M, class T_O = float, Multidim::ArrayDataAccessConstness Cf, Multidim::ArrayDataAccessConstness Cm>
+inline Multidim::Array<T_O, 3> zeromeanFeatureVolume(Multidim::Array<T_I, 3, Cf> const &feature_vol, Multidim::Array<T_M, 2, Cm> const &mean) {
+    static_assert(std::is_same_v<T_O, float>, "libstevi_hip: float feature volumes");
+    svh_array m = HipBridge::describe(mean);
+    auto shp = feature_vol.shape();
+    return HipBridge::volumeOf(svh_zeromean_feature_volume, HipBridge::describe(feature_vol), shp[0], shp[1], shp[2], (const svh_array *)&m);
+}
+// getFeatureVolumeForMatchFunc<matchFunc>(feature_vol), cross_correlations.h:645-722: float features, uint32 census words for CENSUS / HAMMING
+template <matchingFunctions matchFunc, class T_I, Multidim::ArrayDataAccessConstness C,
+          class FType = std::conditional_t<MatchingFunctionTraits<matchFunc>::isCensusBased, census_data_t, float>>
+Multidim::Array<FType, 3> getFeatureVolumeForMatchFunc(Multidim::Array<T_I, 3, C> const &feature_vol) {
+    static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
+    auto shp = feature_vol.shape();
+    constexpr bool census = MatchingFunctionTraits<matchFunc>::isCensusBased;
+    if (census && shp[2] <= 1) return Multidim::Array<FType, 3>(); // census.h:76-78
+    Multidim::Array<FType, 3> out(shp[0], shp[1], census ? (shp[2] - 1) / 32 + 1 : shp[2]);
+    if (out.empty()) return out;
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array in = HipBridge::describe(feature_vol), o = HipBridge::describe(out);
+    if (!HipBridge::check(svh_feature_volume_for_match_func(HipBridge::context(), static_cast<int>(matchFunc), &in, &o))) return Multidim::Array<FType, 3>();
+    return out;
+}
+
 // featureVolume2CostVolume<matchFunc, T_L, T_R, SearchRangeType, dDir, TCV>, cross_correlations.h:724-738: disp_t / searchOffset<1>
 // give a (row, col, disparity) volume (aggregateCost :194-308), searchOffset<2> a (row, col, dh, dw) one (:310-374)
 template <matchingFunctions matchFunc, class T_L, class T_R, typename SearchRangeType, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>

@@ -368,3 +368,32 @@ def feature_cost_volume_2d(func, feat_l, feat_r, range0, range1, ddir=RIGHT_TO_L
     rc = lib().so_feature_cost_volume_2d(int(func), _p(feat_l), _p(feat_r), H, Wl, Wr, F, int(ddir), int(range0[0]), int(range0[1]), int(range1[0]),
                                          int(range1[1]), _p(cv))
     return cv if rc == 0 else np.empty((0, 0, 0, 0), np.float32)
+
+
+# ---- A7 / A8 as stand-alone functions ----------------------------------------------------------------------------
+def channels_zeromean_norm_given(feat, mean):
+    feat, mean = _f32(feat), _f32(mean)
+    H, W, F = feat.shape
+    out = np.empty((H, W), np.float32)
+    lib().so_channels_zeromean_norm_given(_p(feat), _p(mean), H, W, F, _p(out))
+    return out
+
+
+def affine_feature_volume(feat, mean=None, norm=None):
+    """zeromeanFeatureVolume (mean only), normalizedFeatureVolume (norm only), zeromeanNormalizedFeatureVolume (both)."""
+    feat = _f32(feat)
+    H, W, F = feat.shape
+    mean = None if mean is None else _f32(mean)
+    norm = None if norm is None else _f32(norm)
+    out = np.empty_like(feat)
+    lib().so_affine_feature_volume(_p(feat), None if mean is None else _p(mean), None if norm is None else _p(norm), H, W, F, _p(out))
+    return out
+
+
+def feature_volume_for_match_func(func, feat):
+    feat = _f32(feat)
+    H, W, F = feat.shape
+    census = int(func) in (HAMMING, CENSUS)
+    out = np.empty((H, W, census_words(F) if census else F), np.uint32 if census else np.float32)
+    lib().so_feature_volume_for_match_func(int(func), _p(feat), H, W, F, _p(out))
+    return out

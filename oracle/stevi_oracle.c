@@ -1181,3 +1181,31 @@ int so_feature_cost_volume_2d(int func, const float *feat_l, const float *feat_r
     }
     return 0;
 }
+
+/* ---- A7 / A8 as stand-alone functions (callers such as examples/stereo_refine_test/main.cpp:386-398 use them directly) ---- */
+/* channelsZeroMeanNorm with an explicit mean map, cross_correlations.h:61-104 */
+void so_channels_zeromean_norm_given(const float *feat, const float *mean, int H, int W, int F, float *norm) {
+    channels_zeromean_norm(feat, mean, H, W, F, norm);
+}
+/* zeromeanFeatureVolume :570-594 (norm == NULL), normalizedFeatureVolume :504-550 (mean == NULL),
+ * zeromeanNormalizedFeatureVolume :416-462 (both): (v - mean) / norm with exactly those operations */
+void so_affine_feature_volume(const float *feat, const float *mean, const float *norm, int H, int W, int F, float *out) {
+#pragma omp parallel for
+    for (long p = 0; p < (long)H * W; p++)
+        for (int c = 0; c < F; c++) {
+            float v = feat[p * F + c];
+            if (mean) v = v - mean[p];
+            if (norm) v = v / norm[p];
+            out[p * F + c] = v;
+        }
+}
+/* getFeatureVolumeForMatchFunc on a feature volume, :645-722: float [H][W][F] or census words [H][W][nW]; returns the
+ * channel count of the result */
+int so_feature_volume_for_match_func(int func, const float *feat, int H, int W, int F, void *out) {
+    if (func_census(func)) {
+        so_census_features(feat, H, W, F, (uint32_t *)out);
+        return so_census_words(F);
+    }
+    processed_features(func, feat, H, W, F, (float *)out);
+    return F;
+}

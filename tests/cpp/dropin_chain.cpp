@@ -95,6 +95,19 @@ int main(int argc, char **argv) {
         Multidim::Array<float, 2> half = StereoVision::Interpolation::averagePoolingDownsample(source, StereoVision::Interpolation::DownSampleWindows(2));
         dump(out + "_half.f32", half.data(), half.flatLenght());
     }
+    { // examples/stereo_refine_test/main.cpp:386-398: statistics and feature transforms called directly
+        auto feats = SC::unfold<float, float>(1, 1, source);
+        Multidim::Array<float, 2> mean = SC::channelsMean<float, float>(feats);
+        Multidim::Array<float, 3> zm = SC::zeromeanFeatureVolume<float, float, float>(feats, mean);
+        Multidim::Array<float, 3> proc = SC::getFeatureVolumeForMatchFunc<SC::matchingFunctions::ZNCC>(feats);
+        Multidim::Array<uint32_t, 3> words = SC::getFeatureVolumeForMatchFunc<SC::matchingFunctions::CENSUS>(SC::unfold<float, float>(3, 3, source));
+        Multidim::Array<float, 2> sigma = SC::channelsZeroMeanNorm<float, float, float>(feats, mean);
+        if (words.shape()[2] != 2 || sigma.shape()[0] != H) return 7;
+        dump(out + "_mean.f32", mean.data(), mean.flatLenght());
+        dump(out + "_zm.f32", zm.data(), zm.flatLenght());
+        dump(out + "_zncc_feat.f32", proc.data(), proc.flatLenght());
+        dump(out + "_words.u32", words.data(), words.flatLenght());
+    }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);
     auto empty = SC::unfoldBasedCostVolume<SC::matchingFunctions::SAD>(target, shorter, h_r, v_r, D);

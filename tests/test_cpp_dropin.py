@@ -63,6 +63,11 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.max(np.abs(np.fromfile(tmp_path / "o_hier_tcv.f32", np.float32).reshape(H, W, 5)[same] - etcv[same])) <= 1e-4
     half = so.average_pooling_downsample(src, 2)
     assert np.array_equal(np.fromfile(tmp_path / "o_half.f32", np.float32).reshape(half.shape), half)
+    feats = so.unfold(src, 1, 1)
+    assert np.array_equal(np.fromfile(tmp_path / "o_mean.f32", np.float32).reshape(H, W), so.channels_mean(feats))
+    assert np.array_equal(np.fromfile(tmp_path / "o_zm.f32", np.float32).reshape(feats.shape), so.affine_feature_volume(feats, so.channels_mean(feats)))
+    assert np.array_equal(np.fromfile(tmp_path / "o_zncc_feat.f32", np.float32).reshape(feats.shape), so.feature_volume_for_match_func(so.ZNCC, feats))
+    assert np.array_equal(np.fromfile(tmp_path / "o_words.u32", np.uint32).reshape(H, W, 2), so.census_transform(src, 3, 3))
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

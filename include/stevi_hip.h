@@ -115,6 +115,17 @@ int svh_profile_get(const svh_context *ctx, int k, char *name, size_t name_len, 
 int svh_unfold(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], svh_array *out);
 int svh_unfold_shape(const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], int64_t out_shape[3]);
 
+/* ---- UnFoldCompressor features: SURVEY.md section 8(f) rank 4 -----------------------------------------------------------
+ * unfold(UnFoldCompressor(mask), img, padding)                             correlation/unfold.h:47-121, :346-471
+ * mask: HOST array of mask_h x mask_w int labels (row-major); every positive label is a superpixel of the window, feature f is
+ * the mean of the image over the f-th smallest label's pixels.  img (H,W[,C]) f32 -> out (Ho,Wo,C*nFeatures) f32 with the
+ * channel-major feature index in_c * nFeatures + f (:455); pad = {left, top, right, bottom} or NULL for the compressor's own
+ * margins.  Feed the result to svh_feature_cost_volume[_2d] for the compressor overloads of unfoldBasedCostVolume /
+ * unfoldBased2dDisparityCostVolume (cross_correlations.h:767-791, :824-851). */
+int svh_unfold_compressed(svh_context *ctx, const svh_array *img, const int32_t *mask, int mask_h, int mask_w, const int32_t pad[4],
+                          svh_array *out);
+int svh_unfold_compressed_shape(const svh_array *img, const int32_t *mask, int mask_h, int mask_w, const int32_t pad[4], int64_t out_shape[3]);
+
 /* ---- A2  censusFeatures(features)                                      correlation/census.h:69-115
  * feat (H,W,F) f32 -> words (H,W,nW) u32, nW=(F-1)/32+1; trailing partial word left 0.  F<=1 -> SVH_EMPTY_RESULT. */
 int svh_census_features(svh_context *ctx, const svh_array *feat, svh_array *words);

@@ -29,7 +29,7 @@ EXPORTS = [
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
-    "svh_feature_cost_volume_2d", "svh_average_pooling_downsample",
+    "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_unfold_compressed", "svh_unfold_compressed_shape",
     "svh_channels_mean", "svh_channels_norm", "svh_channels_zero_mean_norm", "svh_zeromean_feature_volume", "svh_normalized_feature_volume",
     "svh_zeromean_normalized_feature_volume", "svh_feature_volume_for_match_func", "svh_guided_cost_volume", "svh_hierarchical_truncated_cost_volume",
 ]
@@ -134,6 +134,8 @@ def load():
         "svh_refine_disp_2d_cost_interpolation": (C.c_int, [ctx, C.c_int, C.c_int, A, A, A]),
         "svh_refine_disp_2d_cost_patch_interpolation": (C.c_int, [ctx, C.c_int, A, A, A]),
         "svh_average_pooling_downsample": (C.c_int, [ctx, A, C.c_int, C.c_int, A]),
+        "svh_unfold_compressed": (C.c_int, [ctx, A, P(i32), C.c_int, C.c_int, P(i32), A]),
+        "svh_unfold_compressed_shape": (C.c_int, [A, P(i32), C.c_int, C.c_int, P(i32), P(C.c_int64)]),
         "svh_channels_mean": (C.c_int, [ctx, A, A]),
         "svh_channels_norm": (C.c_int, [ctx, A, A]),
         "svh_channels_zero_mean_norm": (C.c_int, [ctx, A, A, A]),

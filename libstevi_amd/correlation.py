@@ -546,6 +546,91 @@ def refineDisp2dCostPatchInterpolation(kernel, truncatedCostVolume, rawDisparity
     return out if st == _capi.OK else _empty_like(tcv, 3, "f32")
 
 
+# ---- UnFoldCompressor features ---------------------------------------------------------
+class UnFoldCompressor:
+    """UnFoldCompressor(mask) -- correlation/unfold.h:36-137.  mask: 2-D int array, positive labels = superpixels of the window."""
+
+    class pixelIndex:
+        def __init__(self, verticalShift, horizontalShift, featureIndex, weight):
+            self.verticalShift, self.horizontalShift, self.featureIndex, self.weight = verticalShift, horizontalShift, featureIndex, weight
+
+    def __init__(self, mask):
+        self.mask = np.ascontiguousarray(np.asarray(mask), dtype=np.int32)
+        if self.mask.ndim != 2:
+            raise ValueError("the mask is a 2-D array of labels")
+        mh, mw = self.mask.shape
+        ii, jj = np.nonzero(self.mask > 0)
+        dv, dh = ii - mh // 2, jj - mw // 2
+        self._minH, self._maxH = min(0, int(dv.min(initial=0))), max(0, int(dv.max(initial=0)))  # the box always holds the centre (:57-60)
+        self._minW, self._maxW = min(0, int(dh.min(initial=0))), max(0, int(dh.max(initial=0)))
+        labels, counts = np.unique(self.mask[self.mask > 0], return_counts=True)
+        self._nFeatures = int(labels.size)
+        self._indices = []
+        for f, (lab, cnt) in enumerate(zip(labels, counts)):  # features in increasing label order, entries row-major (:103-120)
+            for i, j in zip(*np.nonzero(self.mask == lab)):
+                self._indices.append(UnFoldCompressor.pixelIndex(int(i) - mh // 2, int(j) - mw // 2, f, float(np.float32(1.0 / cnt))))
+
+    def nFeatures(self): return self._nFeatures
+    def width(self): return self._maxW - self._minW + 1
+    def height(self): return self._maxH - self._minH + 1
+    def margins(self): return PaddingMargins(-self._minW, -self._minH, self._maxW, self._maxH)
+    def indices(self): return list(self._indices)
+
+
+class CompressorGenerators:
+    """correlation/unfold.h:475-693: the two 17-superpixel masks the reference ships (radius 3 and 4 windows)."""
+
+    @staticmethod
+    def GrPix17R3Filter():
+        return np.array([[14, 14, 10, 10, 10, 16, 16],
+                         [14, 14, 6, 4, 7, 16, 16],
+                         [11, 6, 6, 4, 7, 7, 13],
+                         [11, 2, 2, 1, 3, 3, 13],
+                         [11, 8, 8, 5, 9, 9, 13],
+                         [15, 15, 8, 5, 9, 17, 17],
+                         [15, 15, 12, 12, 12, 17, 17]], np.int32)
+
+    @staticmethod
+    def GrPix17R4Filter():
+        return np.array([[14, 14, 14, 10, 10, 10, 16, 16, 16],
+                         [14, 14, 14, 10, 10, 10, 16, 16, 16],
+                         [14, 14, 6, 6, 4, 7, 7, 16, 16],
+                         [11, 11, 6, 6, 4, 7, 7, 13, 13],
+                         [11, 11, 2, 2, 1, 3, 3, 13, 13],
+                         [11, 11, 8, 8, 5, 9, 9, 13, 13],
+                         [15, 15, 8, 8, 5, 9, 9, 17, 17],
+                         [15, 15, 15, 12, 12, 12, 17, 17, 17],
+                         [15, 15, 15, 12, 12, 12, 17, 17, 17]], np.int32)
+
+
+def unfoldCompressed(compressor, in_data, padding=None):
+    """unfold(compressor, in_data, padding) -- correlation/unfold.h:346-471."""
+    lib = _capi.load()
+    x = _prep(in_data, np.float32)
+    ctx = context_for(x)
+    d = _desc(x)
+    m = compressor.mask
+    mp = m.ctypes.data_as(C.POINTER(C.c_int32))
+    shp = (C.c_int64 * 3)()
+    if lib.svh_unfold_compressed_shape(C.byref(d), mp, m.shape[0], m.shape[1], _pad_arg(padding), shp) != _capi.OK:
+        raise ValueError("bad unfold arguments")
+    if shp[0] <= 0 or shp[1] <= 0 or shp[2] <= 0:
+        return _empty_like(x, 3, "f32")
+    out = _like(x, (shp[0], shp[1], shp[2]), "f32")
+    _check(ctx, lib.svh_unfold_compressed(ctx, C.byref(d), mp, m.shape[0], m.shape[1], _pad_arg(padding), C.byref(_desc(out))))
+    return out
+
+
+def unfoldBasedCostVolumeCompressed(matchFunc, img_l, img_r, compressor, disp_width, dDir=dispDirection.RightToLeft):
+    """unfoldBasedCostVolume(img_l, img_r, compressor, disp_width) / unfoldBased2dDisparityCostVolume(img_l, img_r, compressor,
+    searchOffset<2>) -- correlation/cross_correlations.h:767-791, :824-851: compressed unfold, then featureVolume2CostVolume."""
+    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    two_d = isinstance(disp_width, searchOffset2)
+    if l.shape[0] != r.shape[0] or (two_d and l.shape[1] != r.shape[1]) or (l.ndim == 3 and l.shape[2] != r.shape[2]):
+        return _empty_like(l, 4 if two_d else 3, "f32")
+    return featureVolume2CostVolume(matchFunc, unfoldCompressed(compressor, l), unfoldCompressed(compressor, r), disp_width, dDir)
+
+
 # ---- A7 / A8: per-pixel statistics and feature-volume transforms as stand-alone functions -------------------------------
 def _map_call(fn, feat, *maps):
     lib = _capi.load()

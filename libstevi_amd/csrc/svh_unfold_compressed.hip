@@ -1,0 +1,143 @@
+// UnFoldCompressor features (second half): superpixel means over a window mask.
+//
+//   UnFoldCompressor(mask)                       correlation/unfold.h:47-121
+//   unfold(compressor, img2D | img3D, padding)   correlation/unfold.h:346-471
+//
+// The mask is a small host-side parameter (7x7 / 9x9 in the reference's generators): the index list is built on the host
+// exactly as the constructor does (positive labels, features in increasing label order, entries ordered by feature then
+// row-major, weight = float(1. / pixel count), bounding box always containing the centre) and uploaded as a few hundred
+// bytes.  One lane per output feature accumulates `weight * sample` over its entries in list order: the products are
+// rounded before the add, as in the reference's `out += static_cast<T_O>(weight * value)`.
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "svh_internal.h"
+
+namespace svh {
+
+namespace {
+
+struct PixelIndex {
+    int32_t v, h;
+    float w;
+};
+
+struct Compressor {
+    int n_features = 0, minH = 0, maxH = 0, minW = 0, maxW = 0;
+    std::vector<PixelIndex> entries;   // ordered by feature
+    std::vector<int32_t> first;        // entries of feature f: [first[f], first[f + 1])
+    int height() const { return maxH - minH + 1; }
+    int width() const { return maxW - minW + 1; }
+};
+
+Compressor build_compressor(const int32_t *mask, int mh, int mw) {
+    Compressor c;
+    const int v_off = mh / 2, h_off = mw / 2;
+    std::map<int32_t, int> count;
+    for (int i = 0; i < mh; i++)
+        for (int j = 0; j < mw; j++) {
+            const int32_t feat = mask[i * mw + j];
+            if (feat <= 0) continue;
+            c.minH = std::min(c.minH, i - v_off);
+            c.maxH = std::max(c.maxH, i - v_off);
+            c.minW = std::min(c.minW, j - h_off);
+            c.maxW = std::max(c.maxW, j - h_off);
+            count[feat]++;
+        }
+    c.n_features = (int)count.size();
+    for (auto const &kv : count) { // std::map iterates in increasing label order (= the sorted feats of unfold.h:103)
+        c.first.push_back((int32_t)c.entries.size());
+        for (int i = 0; i < mh; i++)
+            for (int j = 0; j < mw; j++)
+                if (mask[i * mw + j] == kv.first) c.entries.push_back({i - v_off, j - h_off, (float)(1. / kv.second)});
+    }
+    c.first.push_back((int32_t)c.entries.size());
+    return c;
+}
+
+void compressed_geometry(const Compressor &c, int H, int W, const int32_t pad[4], int *pl, int *pt, int *Ho, int *Wo) {
+    const int left = -c.minW, top = -c.minH; // compressor.margins(), unfold.h:98
+    *pl = pad ? pad[0] : left;
+    *pt = pad ? pad[1] : top;
+    const int pr = pad ? pad[2] : c.maxW, pb = pad ? pad[3] : c.maxH;
+    *Ho = H - c.height() + *pt + pb + 1;
+    *Wo = W - c.width() + *pl + pr + 1;
+}
+
+// out(i, j, in_c * nF + f) = sum over the entries of feature f, in order, of fl(weight * img(i + v + top - pad_top, j + h + left - pad_left, in_c))
+__global__ void unfold_compressed_kernel(const float *__restrict__ img, int H, int W, int C, const PixelIndex *__restrict__ entries,
+                                         const int32_t *__restrict__ first, int nF, int di, int dj, int Ho, int Wo, float *__restrict__ out) {
+    const int F = C * nF;
+    const int64_t n = (int64_t)Ho * Wo * F;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int fo = (int)(e % F);
+        const int64_t p = e / F;
+        const int j = (int)(p % Wo), i = (int)(p / Wo);
+        const int in_c = fo / nF, f = fo - in_c * nF;
+        float acc = 0.0f;
+        for (int k = first[f]; k < first[f + 1]; k++) {
+            const int in_i = i + entries[k].v + di, in_j = j + entries[k].h + dj;
+            const float v = (in_i >= 0 && in_i < H && in_j >= 0 && in_j < W) ? img[((int64_t)in_i * W + in_j) * C + in_c] : 0.0f;
+            acc += entries[k].w * v;
+        }
+        out[e] = acc;
+    }
+}
+
+int check_mask(svh_context *ctx, const int32_t *mask, int mh, int mw) {
+    if (!mask || mh < 1 || mw < 1 || mh > 255 || mw > 255) {
+        if (ctx) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "mask must be a host array of 1..255 x 1..255 labels");
+        return SVH_ERR_INVALID_ARGUMENT;
+    }
+    return SVH_OK;
+}
+
+} // namespace
+
+} // namespace svh
+
+using namespace svh;
+
+extern "C" int svh_unfold_compressed_shape(const svh_array *img, const int32_t *mask, int mask_h, int mask_w, const int32_t pad[4], int64_t out_shape[3]) {
+    if (!img || !out_shape || img->ndim < 2 || img->ndim > 3 || check_mask(nullptr, mask, mask_h, mask_w) != SVH_OK) return SVH_ERR_INVALID_ARGUMENT;
+    const Compressor c = build_compressor(mask, mask_h, mask_w);
+    int pl, pt, Ho, Wo;
+    compressed_geometry(c, (int)img->shape[0], (int)img->shape[1], pad, &pl, &pt, &Ho, &Wo);
+    out_shape[0] = Ho;
+    out_shape[1] = Wo;
+    out_shape[2] = (img->ndim == 3 ? img->shape[2] : 1) * c.n_features;
+    return SVH_OK;
+}
+
+extern "C" int svh_unfold_compressed(svh_context *ctx, const svh_array *img, const int32_t *mask, int mask_h, int mask_w, const int32_t pad[4],
+                                     svh_array *out) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, img, "img", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
+    SVH_TRY(check_mask(ctx, mask, mask_h, mask_w));
+    const int H = (int)img->shape[0], W = (int)img->shape[1], C = img->ndim == 3 ? (int)img->shape[2] : 1;
+    const Compressor c = build_compressor(mask, mask_h, mask_w);
+    if (c.n_features == 0) return fail(ctx, SVH_EMPTY_RESULT, "the mask holds no positive label");
+    int pl, pt, Ho, Wo;
+    compressed_geometry(c, H, W, pad, &pl, &pt, &Ho, &Wo);
+    if (Ho <= 0 || Wo <= 0) return fail(ctx, SVH_EMPTY_RESULT, "unfold output is empty");
+    const int F = C * c.n_features;
+    if (out->shape[0] != Ho || out->shape[1] != Wo || out->shape[2] != F) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have shape (%d,%d,%d)", Ho, Wo, F);
+    Scratch scr(ctx);
+    void *dimg;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img, &dimg));
+    SVH_TRY(stage_out(ctx, scr, *out, &os));
+    PixelIndex *d_entries = scr.get_n<PixelIndex>(c.entries.size());
+    int32_t *d_first = scr.get_n<int32_t>(c.first.size());
+    if (!d_entries || !d_first) return SVH_ERR_OUT_OF_MEMORY;
+    // pageable sources: the copies have left the host buffers when the calls return, the vectors may go out of scope afterwards
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(d_entries, c.entries.data(), c.entries.size() * sizeof(PixelIndex), hipMemcpyHostToDevice, ctx->stream));
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(d_first, c.first.data(), c.first.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const int64_t n = (int64_t)Ho * Wo * F;
+    SVH_LAUNCH(ctx, "unfold_compressed", unfold_compressed_kernel, grid_for(n, 256, 65536), 256, 0, (const float *)dimg, H, W, C, d_entries, d_first,
+               c.n_features, -c.minH - pt, -c.minW - pl, Ho, Wo, (float *)os.dptr);
+    SVH_CHECK_LAUNCH(ctx);
+    return finish_out(ctx, os);
+}

@@ -156,6 +156,32 @@ Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const
     return cv;
 }
 
+// unfoldBasedCostVolume(img_l, img_r, compressor, disp_width), cross_correlations.h:767-791
+template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
+Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const &img_l, Multidim::Array<T_R, nImDim> const &img_r,
+                                              UnFoldCompressor const &compressor, disp_t disp_width) {
+    auto l_shape = img_l.shape();
+    auto r_shape = img_r.shape();
+    if (l_shape[0] != r_shape[0]) return Multidim::Array<TCV, 3>(0, 0, 0);
+    if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 3>(0, 0, 0);
+    Multidim::Array<float, 3> left_feature_volume = unfold(compressor, img_l);
+    Multidim::Array<float, 3> right_feature_volume = unfold(compressor, img_r);
+    return featureVolume2CostVolume<matchFunc, float, float, disp_t, dDir, TCV>(left_feature_volume, right_feature_volume, disp_width);
+}
+
+// unfoldBased2dDisparityCostVolume(img_l, img_r, compressor, searchOffset<2>), cross_correlations.h:824-851
+template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
+Multidim::Array<TCV, 4> unfoldBased2dDisparityCostVolume(Multidim::Array<T_L, nImDim> const &img_l, Multidim::Array<T_R, nImDim> const &img_r,
+                                                         UnFoldCompressor const &compressor, searchOffset<2> const &searchWindows) {
+    auto l_shape = img_l.shape();
+    auto r_shape = img_r.shape();
+    if (l_shape[0] != r_shape[0] || l_shape[1] != r_shape[1]) return Multidim::Array<TCV, 4>();
+    if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 4>();
+    Multidim::Array<float, 3> left_feature_volume = unfold(compressor, img_l);
+    Multidim::Array<float, 3> right_feature_volume = unfold(compressor, img_r);
+    return featureVolume2CostVolume<matchFunc, float, float, searchOffset<2>, dDir, TCV>(left_feature_volume, right_feature_volume, searchWindows);
+}
+
 // unfoldBased2dDisparityCostVolume<matchFunc, T_L, T_R, nImDim, dDir, TCV>(img_l, img_r, h_radius, v_radius, searchOffset<2>),
 // cross_correlations.h:794-822
 template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>

@@ -397,3 +397,17 @@ def feature_volume_for_match_func(func, feat):
     out = np.empty((H, W, census_words(F) if census else F), np.uint32 if census else np.float32)
     lib().so_feature_volume_for_match_func(int(func), _p(feat), H, W, F, _p(out))
     return out
+
+
+# ---- UnFoldCompressor ---------------------------------------------------------------
+def unfold_compressed(img, mask, pad=None):
+    """unfold(UnFoldCompressor(mask), img, padding) -- correlation/unfold.h:47-121, :346-471."""
+    x = _img3(img)
+    H, W, Cc = x.shape
+    mask = _i32(mask)
+    Ho, Wo, F = C.c_int(), C.c_int(), C.c_int()
+    lib().so_unfold_compressed_shape(H, W, Cc, _p(mask), mask.shape[0], mask.shape[1], _pad(pad), C.byref(Ho), C.byref(Wo), C.byref(F))
+    out = np.empty((max(Ho.value, 0), max(Wo.value, 0), F.value), np.float32)
+    if out.size:
+        lib().so_unfold_compressed(_p(x), H, W, Cc, _p(mask), mask.shape[0], mask.shape[1], _pad(pad), _p(out))
+    return out

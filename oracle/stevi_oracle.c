@@ -1209,3 +1209,82 @@ int so_feature_volume_for_match_func(int func, const float *feat, int H, int W, 
     processed_features(func, feat, H, W, F, (float *)out);
     return F;
 }
+
+/* ===== UnFoldCompressor: SURVEY.md section 8(f) rank 4 (second half) ================================================ */
+
+/* UnFoldCompressor(mask), correlation/unfold.h:47-121: positive labels of an odd- or even-sized int mask are superpixels;
+ * offsets are relative to (height/2, width/2); features are numbered in increasing label order; the index list is ordered by
+ * feature, then row-major inside the mask; weight = float(1. / pixels of the superpixel); the bounding box always contains the
+ * centre (min / max start at 0, :57-60).  Fills at most mh*mw entries; returns the entry count. */
+typedef struct { int v, h, f; float w; } so_pix_index;
+static int compressor_build(const int32_t *mask, int mh, int mw, so_pix_index *idx, int *n_features, int *box /* minH,maxH,minW,maxW */) {
+    int v_off = mh / 2, h_off = mw / 2, minH = 0, maxH = 0, minW = 0, maxW = 0, nf = 0, n = 0;
+    int32_t *labels = (int32_t *)malloc((size_t)mh * mw * sizeof(int32_t));
+    int *counts = (int *)malloc((size_t)mh * mw * sizeof(int));
+    for (int i = 0; i < mh; i++)
+        for (int j = 0; j < mw; j++) {
+            int32_t feat = mask[i * mw + j];
+            if (feat <= 0) continue;
+            if (i - v_off < minH) minH = i - v_off;
+            if (i - v_off > maxH) maxH = i - v_off;
+            if (j - h_off < minW) minW = j - h_off;
+            if (j - h_off > maxW) maxW = j - h_off;
+            int k = 0;
+            while (k < nf && labels[k] != feat) k++;
+            if (k == nf) { labels[nf] = feat; counts[nf] = 0; nf++; }
+            counts[k]++;
+        }
+    for (int a = 0; a < nf; a++) /* std::sort of the labels, :103 */
+        for (int b = a + 1; b < nf; b++)
+            if (labels[b] < labels[a]) { int32_t t = labels[a]; labels[a] = labels[b]; labels[b] = t; int c = counts[a]; counts[a] = counts[b]; counts[b] = c; }
+    for (int f = 0; f < nf; f++)
+        for (int i = 0; i < mh; i++)
+            for (int j = 0; j < mw; j++)
+                if (mask[i * mw + j] == labels[f]) {
+                    idx[n].v = i - v_off; idx[n].h = j - h_off; idx[n].f = f; idx[n].w = (float)(1. / counts[f]);
+                    n++;
+                }
+    *n_features = nf;
+    box[0] = minH; box[1] = maxH; box[2] = minW; box[3] = maxW;
+    free(labels);
+    free(counts);
+    return n;
+}
+
+/* unfold(compressor, img, padding), unfold.h:346-471; pad = {left, top, right, bottom} or NULL for auto (= compressor.margins()).
+ * img [H][W][C] -> out [Ho][Wo][C * nFeatures], channel-major feature index in_c * nFeatures + f (:455). */
+void so_unfold_compressed_shape(int H, int W, int C, const int32_t *mask, int mh, int mw, const int *pad, int *Ho, int *Wo, int *F) {
+    so_pix_index *idx = (so_pix_index *)malloc((size_t)mh * mw * sizeof(so_pix_index));
+    int nf, box[4];
+    compressor_build(mask, mh, mw, idx, &nf, box);
+    int pl = pad ? pad[0] : -box[2], pt = pad ? pad[1] : -box[0], pr = pad ? pad[2] : box[3], pb = pad ? pad[3] : box[1];
+    *Ho = H - (box[1] - box[0] + 1) + pt + pb + 1;
+    *Wo = W - (box[3] - box[2] + 1) + pl + pr + 1;
+    *F = C * nf;
+    free(idx);
+}
+
+void so_unfold_compressed(const float *img, int H, int W, int C, const int32_t *mask, int mh, int mw, const int *pad, float *out) {
+    so_pix_index *idx = (so_pix_index *)malloc((size_t)mh * mw * sizeof(so_pix_index));
+    int nf, box[4];
+    int n = compressor_build(mask, mh, mw, idx, &nf, box);
+    int top = -box[0], left = -box[2];
+    int pl = pad ? pad[0] : left, pt = pad ? pad[1] : top, pr = pad ? pad[2] : box[3], pb = pad ? pad[3] : box[1];
+    int Ho = H - (box[1] - box[0] + 1) + pt + pb + 1, Wo = W - (box[3] - box[2] + 1) + pl + pr + 1, F = C * nf;
+    if (Ho > 0 && Wo > 0) {
+        memset(out, 0, (size_t)Ho * Wo * F * sizeof(float));
+        for (int e = 0; e < n; e++) /* :395-411 / :444-464: one pass over the output per index entry (and channel) */
+            for (int c = 0; c < C; c++) {
+#pragma omp parallel for
+                for (int i = 0; i < Ho; i++) {
+                    int in_i = i + idx[e].v + top - pt;
+                    for (int j = 0; j < Wo; j++) {
+                        int in_j = j + idx[e].h + left - pl;
+                        float v = (in_i >= 0 && in_i < H && in_j >= 0 && in_j < W) ? img[((size_t)in_i * W + in_j) * C + c] : 0.0f;
+                        out[((size_t)i * Wo + j) * F + c * nf + idx[e].f] += idx[e].w * v;
+                    }
+                }
+            }
+    }
+    free(idx);
+}

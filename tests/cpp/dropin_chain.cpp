@@ -108,6 +108,13 @@ int main(int argc, char **argv) {
         dump(out + "_zncc_feat.f32", proc.data(), proc.flatLenght());
         dump(out + "_words.u32", words.data(), words.flatLenght());
     }
+    { // benchmarkCrossCorrelationAlgorithms.cpp:140-160: the compressor overload with one of the shipped masks
+        SC::UnFoldCompressor compressor(SC::CompressorGenerators::GrPix17R3Filter());
+        if (compressor.nFeatures() != 17 || compressor.width() != 7 || compressor.height() != 7) return 8;
+        Multidim::Array<float, 3> CVc = SC::unfoldBasedCostVolume<SC::matchingFunctions::ZNCC>(target, source, compressor, D);
+        if (CVc.shape()[0] != H || CVc.shape()[1] != W || CVc.shape()[2] != D) return 9;
+        dump(out + "_compressed_cv.f32", CVc.data(), CVc.flatLenght());
+    }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);
     auto empty = SC::unfoldBasedCostVolume<SC::matchingFunctions::SAD>(target, shorter, h_r, v_r, D);

@@ -68,6 +68,11 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "o_zm.f32", np.float32).reshape(feats.shape), so.affine_feature_volume(feats, so.channels_mean(feats)))
     assert np.array_equal(np.fromfile(tmp_path / "o_zncc_feat.f32", np.float32).reshape(feats.shape), so.feature_volume_for_match_func(so.ZNCC, feats))
     assert np.array_equal(np.fromfile(tmp_path / "o_words.u32", np.uint32).reshape(H, W, 2), so.census_transform(src, 3, 3))
+    import libstevi_amd as sv
+    mask = sv.CompressorGenerators.GrPix17R3Filter()
+    ccv = so.feature_cost_volume(so.ZNCC, so.unfold_compressed(tgt, mask), so.unfold_compressed(src, mask), D)
+    got_c = np.fromfile(tmp_path / "o_compressed_cv.f32", np.float32).reshape(H, W, D)
+    assert np.array_equal(np.isnan(got_c), np.isnan(ccv)) and np.nanmax(np.abs(got_c - ccv)) <= 1e-4
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

@@ -74,3 +74,60 @@ def test_reference_channel_mean_and_sigma_on_gpu(rng, n):
     assert abs(mean - host(sv.channelsMean(dev(v)))[0, 0]) < 1e-3
     sigma = np.sqrt(((v.astype(np.float64) - mean) ** 2).sum())
     assert abs(sigma - host(sv.channelsZeroMeanNorm(dev(v)))[0, 0]) < 1e-3
+
+
+# ---- UnFoldCompressor (unfold.h:36-137, :346-471) ------------------------------------------
+@pytest.mark.parametrize("shape", [(23, 31), (9, 12, 3), (7, 7)])
+def test_unfold_compressed_bit_exact(rng, shape):
+    img = rng.uniform(-1, 1, shape).astype(np.float32)
+    odd = rng.integers(-1, 6, (5, 4)).astype(np.int32)  # even-sized mask, labels <= 0 ignored, label gaps
+    for mask in (sv.CompressorGenerators.GrPix17R3Filter(), sv.CompressorGenerators.GrPix17R4Filter(), odd):
+        comp = sv.UnFoldCompressor(mask)
+        for pad in (None, sv.PaddingMargins(0), sv.PaddingMargins(2, 1, 0, 3)):
+            opad = None if pad is None else pad.as_tuple()
+            exp = so.unfold_compressed(img, mask, opad)
+            for mk in (lambda x: x, dev):
+                got = host(sv.unfoldCompressed(comp, mk(img), pad))
+                if exp.size == 0:  # window larger than the padded image: the reference returns an empty array
+                    assert got.size == 0
+                    continue
+                assert got.shape == exp.shape
+                assert np.array_equal(bits(got), bits(exp))
+
+
+def test_compressor_accessors_match_the_reference_rules():
+    comp = sv.UnFoldCompressor(sv.CompressorGenerators.GrPix17R3Filter())
+    assert (comp.nFeatures(), comp.width(), comp.height()) == (17, 7, 7) and comp.margins().as_tuple() == (3, 3, 3, 3)
+    idx = comp.indices()
+    assert len(idx) == 49 and [e.featureIndex for e in idx] == sorted(e.featureIndex for e in idx)
+    assert (idx[0].verticalShift, idx[0].horizontalShift, idx[0].weight) == (0, 0, 1.0)  # superpixel 1 is the centre pixel alone
+    off = sv.UnFoldCompressor(np.array([[0, 0, 0], [0, 0, 5], [0, 0, 5]], np.int32))  # off-centre labels: the box still holds the centre
+    assert (off.width(), off.height()) == (2, 2) and off.margins().as_tuple() == (0, 0, 1, 1)
+
+
+@pytest.mark.parametrize("h_radius,v_radius", [(1, 1), (3, 3), (5, 1), (1, 5), (5, 5)])
+def test_reference_testUnfoldCompressor_on_gpu(rng, h_radius, v_radius):
+    """testCorrelationFilters.cpp:502-577 against the HIP path."""
+    h, w = 2 * v_radius + 1, 2 * h_radius + 1
+    img = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    labels = (np.arange(h * w) % h) + 1
+    rng.shuffle(labels)
+    mask = labels.reshape(h, w).astype(np.int32)
+    out = host(sv.unfoldCompressed(sv.UnFoldCompressor(mask), dev(img), sv.PaddingMargins(0)))
+    assert out.shape == (1, 1, h)
+    check = np.sort([img[mask == f].astype(np.float64).mean() for f in range(1, h + 1)])
+    assert np.max(np.abs(np.sort(out[0, 0]) - check)) < 1e-4
+
+
+def test_compressed_cost_volume_matches_oracle(rng):
+    """unfoldBasedCostVolume / unfoldBased2dDisparityCostVolume with a compressor (cross_correlations.h:767-791, :824-851)"""
+    left = rng.uniform(-1, 1, (21, 33)).astype(np.float32)
+    right = rng.uniform(-1, 1, (21, 33)).astype(np.float32)
+    mask = sv.CompressorGenerators.GrPix17R4Filter()
+    comp = sv.UnFoldCompressor(mask)
+    fl, fr = so.unfold_compressed(left, mask), so.unfold_compressed(right, mask)
+    for func in (MF.ZNCC, MF.SAD, MF.NCC):
+        got = host(sv.unfoldBasedCostVolumeCompressed(func, dev(left), dev(right), comp, 12))
+        assert np.array_equal(bits(got), bits(so.feature_cost_volume(int(func), fl, fr, 12)))
+        got2 = host(sv.unfoldBasedCostVolumeCompressed(func, dev(left), dev(right), comp, sv.searchOffset2(-1, 1, -2, 2)))
+        assert np.array_equal(bits(got2), bits(so.feature_cost_volume_2d(int(func), fl, fr, (-1, 1), (-2, 2))))

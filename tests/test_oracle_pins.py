@@ -285,3 +285,37 @@ def test_feature_volume_2d_equals_per_offset_1d(rng, name):
         one = so.feature_cost_volume(FUNCS[name], shifted, src, 2 * r + 1, so.RIGHT_TO_LEFT, -r)
         rows = slice(lo, hi)  # rows whose shifted target exists; elsewhere the target vector is zero, not a processed zero row
         assert np.allclose(cv[rows, :, dh + r, :], one[rows], rtol=1e-5, atol=1e-5)
+
+
+# ---- UnFoldCompressor: testCorrelationFilters.cpp:502-577 -----------------------------------------------------------
+@pytest.mark.parametrize("h_radius,v_radius", [(1, 1), (3, 3), (5, 1), (1, 5), (5, 5)])
+def test_unfold_compressor(rng, h_radius, v_radius):
+    """testUnfoldCompressor: a random partition of the window into h superpixels; with PaddingMargins(0) the single output
+    pixel holds the superpixel means (compared as sorted multisets at 1e-4, like the reference)."""
+    h, w = 2 * v_radius + 1, 2 * h_radius + 1
+    img = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    labels = (np.arange(h * w) % h) + 1
+    rng.shuffle(labels)
+    mask = labels.reshape(h, w).astype(np.int32)
+    out = so.unfold_compressed(img, mask, (0, 0, 0, 0))
+    assert out.shape == (1, 1, h)
+    check = np.sort([img[mask == f].astype(np.float64).mean() for f in range(1, h + 1)])
+    assert np.max(np.abs(np.sort(out[0, 0]) - check)) < 1e-4
+
+
+def test_unfold_compressor_layout_rules(rng):
+    """unfold.h:47-121, :346-471: features in increasing label order whatever the labels are; labels <= 0 are ignored; auto padding
+    keeps the image size; multi-channel images give the channel-major index in_c * nFeatures + f; zero outside the image."""
+    img = rng.uniform(-1, 1, (6, 7)).astype(np.float32)
+    mask = np.array([[0, 7, 7], [3, 3, -2], [0, 40, 0]], np.int32)  # labels 3, 7, 40 -> features 0, 1, 2
+    out = so.unfold_compressed(img, mask)
+    assert out.shape == (6, 7, 3)
+    pad = np.pad(img, 1)
+    i, j = 2, 3
+    win = pad[i:i + 3, j:j + 3]
+    assert np.allclose(out[i, j], [(win[1, 0] + win[1, 1]) / 2, (win[0, 1] + win[0, 2]) / 2, win[2, 1]], atol=1e-6)
+    assert np.allclose(out[0, 0, 1], 0.0)  # the row above the image
+    rgb = rng.uniform(-1, 1, (5, 4, 2)).astype(np.float32)
+    out3 = so.unfold_compressed(rgb, mask)
+    assert out3.shape == (5, 4, 6)
+    assert np.array_equal(out3[:, :, 0:3], so.unfold_compressed(rgb[:, :, 0], mask)) and np.array_equal(out3[:, :, 3:6], so.unfold_compressed(rgb[:, :, 1], mask))

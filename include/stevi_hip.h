@@ -111,8 +111,12 @@ int svh_profile_get(const svh_context *ctx, int k, char *name, size_t name_len, 
 
 /* ---- A1  unfold<T_I,T_O>(h_radius, v_radius, img, padding)            correlation/unfold.h:247-344
  * img (H,W) or (H,W,C) f32 -> out (Ho,Wo,F) f32, F=(2h_r+1)(2v_r+1)C, channel c = C(2h_r+1)k + C l + ch.
- * pad = {left, top, right, bottom} or NULL for PaddingMargins() "auto" = (h_r, v_r). Rotate0 only. */
+ * pad = {left, top, right, bottom} or NULL for PaddingMargins() "auto" = (h_r, v_r).  svh_unfold is Rotate0; svh_unfold_oriented
+ * places sample (k, l, ch) at channelFromCord(k, l, ch, h, v, C, orientation) (unfold.h:139-191: the patch rotated by 0 / 90 /
+ * 180 / 270 degrees). */
+typedef enum svh_patch_orientation { SVH_ROTATE0 = 0, SVH_ROTATE90 = 1, SVH_ROTATE180 = 2, SVH_ROTATE270 = 3 } svh_patch_orientation;
 int svh_unfold(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], svh_array *out);
+int svh_unfold_oriented(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], int orientation, svh_array *out);
 int svh_unfold_shape(const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], int64_t out_shape[3]);
 
 /* ---- UnFoldCompressor features: SURVEY.md section 8(f) rank 4 -----------------------------------------------------------

@@ -23,7 +23,7 @@ EXPORTS = [
     "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_set_option", "svh_context_synchronize", "svh_context_trim",
     "svh_status_string", "svh_last_error", "svh_device_available",
     "svh_profile_enable", "svh_profile_filter", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
-    "svh_unfold", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
+    "svh_unfold", "svh_unfold_oriented", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
@@ -114,6 +114,7 @@ def load():
         "svh_profile_get": (C.c_int, [ctx, C.c_int, C.c_char_p, C.c_size_t, P(C.c_double), P(C.c_int64)]),
         "svh_unfold": (C.c_int, [ctx, A, C.c_int, C.c_int, P(i32), A]),
         "svh_unfold_shape": (C.c_int, [A, C.c_int, C.c_int, P(i32), P(C.c_int64)]),
+        "svh_unfold_oriented": (C.c_int, [ctx, A, C.c_int, C.c_int, P(i32), C.c_int, A]),
         "svh_census_features": (C.c_int, [ctx, A, A]),
         "svh_census_transform": (C.c_int, [ctx, A, C.c_int, C.c_int, P(i32), A]),
         "svh_feature_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, A, i32, i32, A]),

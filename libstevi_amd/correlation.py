@@ -228,8 +228,18 @@ def _search_range(r):
 
 
 # ------------------------------------------------------------------------------------------------ functions
-def unfold(h_radius, v_radius, in_data, padding=None):
-    """unfold<T,T>(h_radius, v_radius, in_data, padding) -- correlation/unfold.h:247-344."""
+class UnfoldPatchOrientation(enum.IntEnum):  # correlation/unfold.h:139-144
+    Rotate0 = 0
+    Rotate90 = 1
+    Rotate180 = 2
+    Rotate270 = 3
+
+
+def unfold(h_radius, v_radius, in_data, padding=None, orientation=UnfoldPatchOrientation.Rotate0):
+    """unfold<T,T>(h_radius, v_radius, in_data, padding, orientation) -- correlation/unfold.h:247-344; with an UnFoldCompressor
+    as first argument (unfold(compressor, in_data, padding), :346-471) it forwards to unfoldCompressed."""
+    if isinstance(h_radius, UnFoldCompressor):
+        return unfoldCompressed(h_radius, v_radius, in_data)
     lib = _capi.load()
     x = _prep(in_data, np.float32)
     ctx = context_for(x)
@@ -240,7 +250,7 @@ def unfold(h_radius, v_radius, in_data, padding=None):
     if shp[0] <= 0 or shp[1] <= 0:
         return _empty_like(x, 3, "f32")
     out = _like(x, (shp[0], shp[1], shp[2]), "f32")
-    _check(ctx, lib.svh_unfold(ctx, C.byref(d), h_radius, v_radius, _pad_arg(padding), C.byref(_desc(out))))
+    _check(ctx, lib.svh_unfold_oriented(ctx, C.byref(d), h_radius, v_radius, _pad_arg(padding), int(orientation), C.byref(_desc(out))))
     return out
 
 

@@ -37,6 +37,26 @@ __global__ void unfold_kernel(const float *__restrict__ img, int H, int W, int C
     }
 }
 
+// unfold with a patch orientation: sample (k, l, ch) goes to channelFromCord(k, l, ch, h, v, C, orientation) (unfold.h:171-191)
+__global__ void unfold_oriented_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, int pl, int pt, int Ho, int Wo,
+                                       int orientation, float *__restrict__ out) {
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1;
+    const int F = h * v * C;
+    const int64_t n = (int64_t)Ho * Wo * F;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(e % F); // source-ordered sample index (k, l, ch)
+        const int64_t p = e / F;
+        const int j = (int)(p % Wo), i = (int)(p / Wo);
+        const int ch = s % C, l = (s / C) % h, k = s / (C * h);
+        int c;
+        if (orientation == 1) c = C * v * (h - l - 1) + C * k + ch;
+        else if (orientation == 2) c = C * h * (v - k - 1) + C * (h - l - 1) + ch;
+        else if (orientation == 3) c = C * v * l + C * (v - k - 1) + ch;
+        else c = s;
+        out[p * F + c] = image_or_zero(img, H, W, C, i - pt + k, j - pl + l, ch);
+    }
+}
+
 __global__ void census_image_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, int pl, int pt,
                                     int Ho, int Wo, int n_out, int n_written, bool round_target,
                                     uint32_t *__restrict__ words) {
@@ -353,7 +373,12 @@ int svh_unfold_shape(const svh_array *img, int h_radius, int v_radius, const int
 }
 
 int svh_unfold(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], svh_array *out) {
+    return svh_unfold_oriented(ctx, img, h_radius, v_radius, pad, SVH_ROTATE0, out);
+}
+
+int svh_unfold_oriented(svh_context *ctx, const svh_array *img, int h_radius, int v_radius, const int32_t pad[4], int orientation, svh_array *out) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (orientation < SVH_ROTATE0 || orientation > SVH_ROTATE270) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad patch orientation");
     int H, W, C;
     SVH_TRY(image_desc(ctx, img, "img", &H, &W, &C));
     SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
@@ -369,7 +394,13 @@ int svh_unfold(svh_context *ctx, const svh_array *img, int h_radius, int v_radiu
     OutStage os;
     SVH_TRY(stage_in(ctx, scr, *img, &dimg));
     SVH_TRY(stage_out(ctx, scr, *out, &os));
-    SVH_TRY(dev_unfold(ctx, {(const float *)dimg, H, W, C}, h_radius, v_radius, pl, pt, Ho, Wo, (float *)os.dptr));
+    if (orientation == SVH_ROTATE0) {
+        SVH_TRY(dev_unfold(ctx, {(const float *)dimg, H, W, C}, h_radius, v_radius, pl, pt, Ho, Wo, (float *)os.dptr));
+    } else {
+        SVH_LAUNCH(ctx, "unfold", unfold_oriented_kernel, grid_for((int64_t)Ho * Wo * F, 256, 16384), 256, 0, (const float *)dimg, H, W, C, h_radius, v_radius,
+                   pl, pt, Ho, Wo, orientation, (float *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
     return finish_out(ctx, os);
 }
 

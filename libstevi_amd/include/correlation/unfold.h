@@ -1,4 +1,4 @@
-// Drop-in for LibStevi's correlation/unfold.h: plain unfold (Rotate0) and the UnFoldCompressor variant with its two generators.
+// Drop-in for LibStevi's correlation/unfold.h: plain unfold (all four patch orientations) and the UnFoldCompressor variant with its two generators.
 #ifndef STEREOVISION_CORRELATION_UNFOLD_H
 #define STEREOVISION_CORRELATION_UNFOLD_H
 
@@ -78,7 +78,6 @@ Multidim::Array<T_O, 3> unfold(uint8_t h_radius, uint8_t v_radius, Multidim::Arr
                                PaddingMargins const &padding = PaddingMargins(), UnfoldPatchOrientation orientation = Rotate0) {
     static_assert(nImDim == 2 || nImDim == 3, "unfold takes grey (2-D) or multi-channel (3-D) images");
     static_assert(std::is_same_v<T_I, float> && std::is_same_v<T_O, float>, "libstevi_hip: unfold is implemented for float images");
-    if (orientation != Rotate0) throw std::runtime_error("libstevi_hip: only Rotate0 unfold is implemented");
     const int32_t pad[4] = {padding.left(), padding.top(), padding.right(), padding.bottom()};
     const int32_t *pp = padding.isAuto() ? nullptr : pad;
     svh_array in = HipBridge::describe(in_data);
@@ -87,7 +86,8 @@ Multidim::Array<T_O, 3> unfold(uint8_t h_radius, uint8_t v_radius, Multidim::Arr
     Multidim::Array<T_O, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2]));
     std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array o = HipBridge::describe(out);
-    if (!HipBridge::check(svh_unfold(HipBridge::context(), &in, h_radius, v_radius, pp, &o))) return Multidim::Array<T_O, 3>();
+    if (!HipBridge::check(svh_unfold_oriented(HipBridge::context(), &in, h_radius, v_radius, pp, static_cast<int>(orientation), &o)))
+        return Multidim::Array<T_O, 3>();
     return out;
 }
 

@@ -88,7 +88,10 @@ def census_words(F):
     return (F - 1) // 32 + 1
 
 
-def unfold(img, h_r, v_r, pad=None):
+ROTATE0, ROTATE90, ROTATE180, ROTATE270 = 0, 1, 2, 3
+
+
+def unfold(img, h_r, v_r, pad=None, orientation=ROTATE0):
     """pad = (left, top, right, bottom) or None for the reference's auto padding."""
     img = _img3(img)
     H, W, Cc = img.shape
@@ -96,7 +99,10 @@ def unfold(img, h_r, v_r, pad=None):
     lib().so_unfold_shape(H, W, Cc, h_r, v_r, _pad(pad), C.byref(Ho), C.byref(Wo), C.byref(F))
     out = np.empty((max(Ho.value, 0), max(Wo.value, 0), F.value), np.float32)
     if out.size:
-        lib().so_unfold(_p(img), H, W, Cc, h_r, v_r, _pad(pad), _p(out))
+        if orientation == ROTATE0:
+            lib().so_unfold(_p(img), H, W, Cc, h_r, v_r, _pad(pad), _p(out))
+        else:
+            lib().so_unfold_oriented(_p(img), H, W, Cc, h_r, v_r, _pad(pad), int(orientation), _p(out))
     return out
 
 

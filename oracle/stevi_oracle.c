@@ -1288,3 +1288,34 @@ void so_unfold_compressed(const float *img, int H, int W, int C, const int32_t *
     }
     free(idx);
 }
+
+/* ---- unfold with a patch orientation, correlation/unfold.h:139-191, :247-344 ---------------------------------------------
+ * channelFromCord(k, l, ch, hSize, vSize, channels, orientation) places window sample (k, l, ch) at the position it has after
+ * rotating the patch by 0 / 90 / 180 / 270 degrees; the samples themselves are read exactly as for Rotate0. */
+static int channel_from_cord(int vertical, int horizontal, int channel, int hSize, int vSize, int channels, int orientation) {
+    switch (orientation) {
+    case 0: return channels * hSize * vertical + channels * horizontal + channel;
+    case 1: return channels * vSize * (hSize - horizontal - 1) + channels * vertical + channel;
+    case 2: return channels * hSize * (vSize - vertical - 1) + channels * (hSize - horizontal - 1) + channel;
+    case 3: return channels * vSize * horizontal + channels * (vSize - vertical - 1) + channel;
+    }
+    return -1;
+}
+
+void so_unfold_oriented(const float *img, int H, int W, int C, int h_r, int v_r, const int *pad, int orientation, float *out) {
+    int pl = pad ? pad[0] : h_r, pt = pad ? pad[1] : v_r;
+    int Ho, Wo, F;
+    so_unfold_shape(H, W, C, h_r, v_r, pad, &Ho, &Wo, &F);
+    int h = 2 * h_r + 1, v = 2 * v_r + 1;
+#pragma omp parallel for
+    for (int i = 0; i < Ho; i++)
+        for (int j = 0; j < Wo; j++) {
+            float *o = out + ((size_t)i * Wo + j) * F;
+            for (int k = 0; k < v; k++)
+                for (int l = 0; l < h; l++)
+                    for (int ch = 0; ch < C; ch++) {
+                        int ii = i - pt + k, jj = j - pl + l;
+                        o[channel_from_cord(k, l, ch, h, v, C, orientation)] = (ii >= 0 && ii < H && jj >= 0 && jj < W) ? img[((size_t)ii * W + jj) * C + ch] : 0.0f;
+                    }
+        }
+}

@@ -131,3 +131,22 @@ def test_compressed_cost_volume_matches_oracle(rng):
         assert np.array_equal(bits(got), bits(so.feature_cost_volume(int(func), fl, fr, 12)))
         got2 = host(sv.unfoldBasedCostVolumeCompressed(func, dev(left), dev(right), comp, sv.searchOffset2(-1, 1, -2, 2)))
         assert np.array_equal(bits(got2), bits(so.feature_cost_volume_2d(int(func), fl, fr, (-1, 1), (-2, 2))))
+
+
+# ---- unfold with a patch orientation (unfold.h:139-191, :247-344) --------------------------------------------------------
+@pytest.mark.parametrize("shape,h_r,v_r", [((9, 11), 1, 2), ((8, 8, 3), 2, 1), ((6, 7), 3, 3)])
+def test_unfold_orientations(rng, shape, h_r, v_r):
+    img = rng.uniform(-1, 1, shape).astype(np.float32)
+    h, v, Cc = 2 * h_r + 1, 2 * v_r + 1, (shape[2] if len(shape) == 3 else 1)
+    base = so.unfold(img, h_r, v_r)
+    for orient in sv.UnfoldPatchOrientation:
+        exp = so.unfold(img, h_r, v_r, None, int(orient))
+        for mk in (lambda x: x, dev):
+            got = host(sv.unfold(h_r, v_r, mk(img), None, orient))
+            assert np.array_equal(bits(got), bits(exp))
+        # every orientation holds the same samples, permuted: rotating the (v, h) patch by 0 / 90 / 180 / 270 degrees
+        patch = base.reshape(base.shape[0], base.shape[1], v, h, Cc)
+        rot = np.rot90(patch, k=int(orient), axes=(2, 3))
+        assert np.array_equal(exp, np.ascontiguousarray(rot).reshape(exp.shape))
+    exp = so.unfold(img, h_r, v_r, (1, 0, 2, 1), so.ROTATE270)
+    assert np.array_equal(bits(host(sv.unfold(h_r, v_r, dev(img), sv.PaddingMargins(1, 0, 2, 1), sv.UnfoldPatchOrientation.Rotate270))), bits(exp))

@@ -14,57 +14,88 @@ __device__ __forceinline__ uint32_t order_key(float v) {
 // l, l+64, ... in increasing order (256-byte coalesced reads of the pixel's contiguous costs), then the wave
 // combines with "extremum wins, ties to the larger index".  A NaN never replaces the incumbent, and a NaN at
 // index 0 is never replaced (every comparison with it is false).
+// EXTRACT_PB pixels per wave iteration: their first chunks are loaded before any of them is reduced, so a wave keeps
+// EXTRACT_PB loads in flight instead of one (the kernel is latency-bound otherwise: one 1 KiB load per wave and round trip)
+constexpr int EXTRACT_PB = 4;
+
 template <bool COST, bool VEC>
 __global__ void __launch_bounds__(256) extract_index_kernel(const float *__restrict__ cv, int64_t npx, int D, int32_t *__restrict__ idx,
                                                            unsigned long long *__restrict__ keys, int key_offset, int key_total) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t p = wave; p < npx; p += nwaves) {
-        const float *row = cv + p * D;
-        float bv = 0.0f;
-        int bd = -1;
-        auto consider = [&](float v, int d) {
-            if (isnan(v)) return;
-            const bool take = bd < 0 || (COST ? v <= bv : v >= bv); // later index wins ties
-            if (take) {
-                bv = v;
-                bd = d;
+    constexpr int STEP = VEC ? 256 : 64; // disparities a wave covers per chunk
+    for (int64_t p0 = wave * EXTRACT_PB; p0 < npx; p0 += nwaves * EXTRACT_PB) {
+        float4 first[EXTRACT_PB];
+        float head[EXTRACT_PB];
+#pragma unroll
+        for (int q = 0; q < EXTRACT_PB; q++) {
+            const int64_t p = min(p0 + q, npx - 1);
+            const float *row = cv + p * D;
+            first[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC) { // D % 4 == 0 and 16-byte aligned rows: 1 KiB per wave access
+                if (4 * lane < D) first[q] = *reinterpret_cast<const float4 *>(row + 4 * lane);
+            } else if (lane < D) {
+                first[q].x = row[lane];
             }
-        };
-        if (VEC) { // D % 4 == 0 and 16-byte aligned rows: 1 KiB per wave access
-            for (int d = 4 * lane; d < D; d += 256) {
-                const float4 v = *reinterpret_cast<const float4 *>(row + d);
-                consider(v.x, d);
-                consider(v.y, d + 1);
-                consider(v.z, d + 2);
-                consider(v.w, d + 3);
-            }
-        } else {
-            for (int d = lane; d < D; d += 64) consider(row[d], d);
+            head[q] = row[0];
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            float ov = __shfl_xor(bv, off);
-            int od = __shfl_xor(bd, off);
-            bool take = od >= 0 && (bd < 0 || (COST ? (ov < bv || (ov == bv && od > bd)) : (ov > bv || (ov == bv && od > bd))));
-            if (take) {
-                bv = ov;
-                bd = od;
-            }
-        }
-        const bool first_nan = isnan(row[0]);
-        if (lane == 0) {
-            if (idx) idx[p] = (first_nan || bd < 0) ? 0 : bd;
-            if (keys) {
-                unsigned long long key;
-                if (key_offset == 0 && first_nan) key = COST ? (unsigned long long)(uint32_t)(key_total - 1) : (0xFFFFFFFFull << 32);
-                else if (bd < 0) key = COST ? ~0ull : 0ull;
-                else {
-                    uint32_t gd = (uint32_t)(key_offset + bd);
-                    key = ((unsigned long long)order_key(bv) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+        for (int q = 0; q < EXTRACT_PB; q++) {
+            const int64_t p = p0 + q;
+            if (p >= npx) break;
+            const float *row = cv + p * D;
+            float bv = 0.0f;
+            int bd = -1;
+            auto consider = [&](float v, int d) {
+                if (isnan(v)) return;
+                const bool take = bd < 0 || (COST ? v <= bv : v >= bv); // later index wins ties
+                if (take) {
+                    bv = v;
+                    bd = d;
                 }
-                keys[p] = key;
+            };
+            if (VEC) {
+                if (4 * lane < D) {
+                    consider(first[q].x, 4 * lane);
+                    consider(first[q].y, 4 * lane + 1);
+                    consider(first[q].z, 4 * lane + 2);
+                    consider(first[q].w, 4 * lane + 3);
+                }
+                for (int d = 4 * lane + STEP; d < D; d += STEP) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row + d);
+                    consider(v.x, d);
+                    consider(v.y, d + 1);
+                    consider(v.z, d + 2);
+                    consider(v.w, d + 3);
+                }
+            } else {
+                if (lane < D) consider(first[q].x, lane);
+                for (int d = lane + STEP; d < D; d += STEP) consider(row[d], d);
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                float ov = __shfl_xor(bv, off);
+                int od = __shfl_xor(bd, off);
+                bool take = od >= 0 && (bd < 0 || (COST ? (ov < bv || (ov == bv && od > bd)) : (ov > bv || (ov == bv && od > bd))));
+                if (take) {
+                    bv = ov;
+                    bd = od;
+                }
+            }
+            const bool first_nan = isnan(head[q]);
+            if (lane == 0) {
+                if (idx) idx[p] = (first_nan || bd < 0) ? 0 : bd;
+                if (keys) {
+                    unsigned long long key;
+                    if (key_offset == 0 && first_nan) key = COST ? (unsigned long long)(uint32_t)(key_total - 1) : (0xFFFFFFFFull << 32);
+                    else if (bd < 0) key = COST ? ~0ull : 0ull;
+                    else {
+                        uint32_t gd = (uint32_t)(key_offset + bd);
+                        key = ((unsigned long long)order_key(bv) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+                    }
+                    keys[p] = key;
+                }
             }
         }
     }
@@ -301,7 +332,7 @@ __global__ void refine_2d_patch_kernel(int kernel, const float *__restrict__ tcv
 int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
                       unsigned long long *keys, int key_index_offset, int key_total_D) {
     if (n_pixels == 0) return SVH_OK;
-    int grid = grid_for(n_pixels, 4, 256 * 8 * 4);
+    int grid = grid_for(ceil_div(n_pixels, EXTRACT_PB), 4, 256 * 8 * 4);
     const bool vec = D % 4 == 0 && ((uintptr_t)cv & 15) == 0;
 #define SVH_EXTRACT(C, V) SVH_LAUNCH(ctx, "extract_index", (extract_index_kernel<C, V>), grid, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D)
     if (strategy == SVH_COST) {

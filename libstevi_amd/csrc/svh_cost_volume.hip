@@ -101,6 +101,59 @@ static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, cons
                a.px_stride(), a.out_off, cv);
 }
 
+// 2-D search ranges (aggregateCost(searchOffset<2>), cross_correlations.h:310-374): every vertical offset's target records are
+// staged together and the lanes run over the flattened (dh, dw) axis, so a pixel's Dh x Dw costs leave as one contiguous run
+// with every lane busy (one launch per vertical offset writes 4 Dw-byte pieces into 4 Dh Dw-byte pixels and idles the lanes
+// beyond Dw).
+template <int NW>
+__global__ void __launch_bounds__(256) hamming_volume_2d_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int H, int Ws, int Wt,
+                                                                int Dh, int Dw, int lower0, int lower1, float *__restrict__ cv) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
+    const int n_rec = HV_TP + Dw - 1, DD = Dh * Dw;
+    uint32_t *lsrc = lds + (size_t)Dh * n_rec * NW;
+    uint16_t *lut = reinterpret_cast<uint16_t *>(lsrc + HV_TP * NW); // q = dh Dw + dw -> record offset dh n_rec + dw
+    for (int e = threadIdx.x; e < Dh * n_rec * NW; e += blockDim.x) {
+        const int w = e % NW, y = (e / NW) % n_rec, dh = e / (NW * n_rec);
+        const int it = i + lower0 + dh, jt = j0 + lower1 + y;
+        lds[e] = (it >= 0 && it < H && jt >= 0 && jt < Wt) ? tw[((int64_t)it * Wt + jt) * NW + w] : 0u; // zero vector outside the image (:359)
+    }
+    const int n_src = min(HV_TP, Ws - j0) * NW;
+    for (int e = threadIdx.x; e < n_src; e += blockDim.x) lsrc[e] = sw[((int64_t)i * Ws + j0) * NW + e];
+    for (int q = threadIdx.x; q < DD; q += blockDim.x) lut[q] = (uint16_t)((q / Dw) * n_rec + q % Dw);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = wave; u < HV_TP && j0 + u < Ws; u += 4) {
+        uint32_t s[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) s[w] = lsrc[u * NW + w];
+        float *out = cv + ((int64_t)i * Ws + j0 + u) * DD;
+        for (int q = lane; q < DD; q += 64) {
+            const uint32_t *rec = lds + ((int)lut[q] + u) * NW;
+            uint32_t score = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) score += __popc(s[w] ^ rec[w]);
+            out[q] = (float)score;
+        }
+    }
+}
+
+// true when the 2-D kernel took the job (compact words of 1..4 words, tile within the LDS budget, offsets addressable by the LUT)
+bool dev_hamming_volume_2d(svh_context *ctx, const uint32_t *sw, const uint32_t *tw, int nWw, int H, int Ws, int Wt, int Dh, int Dw, int lower0, int lower1,
+                           float *cv) {
+    const size_t shmem = ((size_t)Dh * (HV_TP + Dw - 1) + HV_TP) * nWw * sizeof(uint32_t) + (size_t)Dh * Dw * sizeof(uint16_t);
+    if (nWw < 1 || nWw > 4 || shmem > 60 * 1024 || (size_t)Dh * (HV_TP + Dw - 1) > 65535) return false;
+    if ((int64_t)H * Ws == 0) return true;
+    dim3 grid(ceil_div(Ws, HV_TP), H);
+    switch (nWw) {
+    case 1: SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_2d_kernel<1>, grid, 256, shmem, sw, tw, H, Ws, Wt, Dh, Dw, lower0, lower1, cv); break;
+    case 2: SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_2d_kernel<2>, grid, 256, shmem, sw, tw, H, Ws, Wt, Dh, Dw, lower0, lower1, cv); break;
+    case 3: SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_2d_kernel<3>, grid, 256, shmem, sw, tw, H, Ws, Wt, Dh, Dw, lower0, lower1, cv); break;
+    default: SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_2d_kernel<4>, grid, 256, shmem, sw, tw, H, Ws, Wt, Dh, Dw, lower0, lower1, cv); break;
+    }
+    return true;
+}
+
 template <class A, int CMP>
 static int launch_cv(svh_context *ctx, bool zm, bool nrm, A src, A tgt, const float *ms, const float *ns, const float *mt,
                      const float *nt, const CostVolumeArgs &a, float *cv) {
@@ -324,6 +377,10 @@ extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int d
         uint32_t *tw = scr.get_n<uint32_t>((size_t)H * W * (nWw ? nWw : 1));
         if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
         SVH_TRY(dev_census_pair_compact(ctx, isrc, itgt, h_radius, v_radius, nWw, sw, tw));
+        if (dev_hamming_volume_2d(ctx, sw, tw, nWw, H, W, W, Dh, Dw, lower0, lower1, (float *)os.dptr)) {
+            SVH_CHECK_LAUNCH(ctx);
+            return finish_out(ctx, os);
+        }
         for (int dh = 0; dh < Dh; dh++) {
             a.tgt_row_off = lower0 + dh;
             a.out_off = (int64_t)dh * Dw;
@@ -383,6 +440,10 @@ extern "C" int svh_feature_cost_volume_2d(svh_context *ctx, int match_func, int 
         if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
         SVH_TRY(dev_census_from_features(ctx, (const float *)ds, H, Ws, F, nWw, false, sw));
         SVH_TRY(dev_census_from_features(ctx, (const float *)dt, H, Wt, F, nWw, true, tw));
+        if (dev_hamming_volume_2d(ctx, sw, tw, nWw, H, Ws, Wt, Dh, Dw, lower0, lower1, (float *)os.dptr)) {
+            SVH_CHECK_LAUNCH(ctx);
+            return finish_out(ctx, os);
+        }
         for (int dh = 0; dh < Dh; dh++) {
             a.tgt_row_off = lower0 + dh;
             a.out_off = (int64_t)dh * Dw;

@@ -18,26 +18,29 @@ __device__ __forceinline__ uint32_t order_key(float v) {
 // EXTRACT_PB loads in flight instead of one (the kernel is latency-bound otherwise: one 1 KiB load per wave and round trip)
 constexpr int EXTRACT_PB = 4;
 
-template <bool COST, bool VEC>
+// four consecutive costs with only the 4-byte alignment every cost has: global_load_dwordx4 does not need more on gfx950,
+// so rows of any length (2-D volumes flatten to odd lengths) are read 16 bytes per lane
+struct __attribute__((packed, aligned(4))) Costs4 {
+    float x, y, z, w;
+};
+
+template <bool COST>
 __global__ void __launch_bounds__(256) extract_index_kernel(const float *__restrict__ cv, int64_t npx, int D, int32_t *__restrict__ idx,
                                                            unsigned long long *__restrict__ keys, int key_offset, int key_total) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    constexpr int STEP = VEC ? 256 : 64; // disparities a wave covers per chunk
+    const int D4 = D & ~3; // the last D - D4 costs are read one per lane
     for (int64_t p0 = wave * EXTRACT_PB; p0 < npx; p0 += nwaves * EXTRACT_PB) {
-        float4 first[EXTRACT_PB];
-        float head[EXTRACT_PB];
+        Costs4 first[EXTRACT_PB];
+        float head[EXTRACT_PB], tail[EXTRACT_PB];
 #pragma unroll
         for (int q = 0; q < EXTRACT_PB; q++) {
             const int64_t p = min(p0 + q, npx - 1);
             const float *row = cv + p * D;
-            first[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (VEC) { // D % 4 == 0 and 16-byte aligned rows: 1 KiB per wave access
-                if (4 * lane < D) first[q] = *reinterpret_cast<const float4 *>(row + 4 * lane);
-            } else if (lane < D) {
-                first[q].x = row[lane];
-            }
+            first[q] = Costs4{0.f, 0.f, 0.f, 0.f};
+            if (4 * lane < D4) first[q] = *reinterpret_cast<const Costs4 *>(row + 4 * lane);
+            tail[q] = D4 + lane < D ? row[D4 + lane] : 0.0f;
             head[q] = row[0];
         }
 #pragma unroll
@@ -55,24 +58,20 @@ __global__ void __launch_bounds__(256) extract_index_kernel(const float *__restr
                     bd = d;
                 }
             };
-            if (VEC) {
-                if (4 * lane < D) {
-                    consider(first[q].x, 4 * lane);
-                    consider(first[q].y, 4 * lane + 1);
-                    consider(first[q].z, 4 * lane + 2);
-                    consider(first[q].w, 4 * lane + 3);
-                }
-                for (int d = 4 * lane + STEP; d < D; d += STEP) {
-                    const float4 v = *reinterpret_cast<const float4 *>(row + d);
-                    consider(v.x, d);
-                    consider(v.y, d + 1);
-                    consider(v.z, d + 2);
-                    consider(v.w, d + 3);
-                }
-            } else {
-                if (lane < D) consider(first[q].x, lane);
-                for (int d = lane + STEP; d < D; d += STEP) consider(row[d], d);
+            if (4 * lane < D4) {
+                consider(first[q].x, 4 * lane);
+                consider(first[q].y, 4 * lane + 1);
+                consider(first[q].z, 4 * lane + 2);
+                consider(first[q].w, 4 * lane + 3);
             }
+            for (int d = 4 * lane + 256; d < D4; d += 256) {
+                const Costs4 v = *reinterpret_cast<const Costs4 *>(row + d);
+                consider(v.x, d);
+                consider(v.y, d + 1);
+                consider(v.z, d + 2);
+                consider(v.w, d + 3);
+            }
+            if (D4 + lane < D) consider(tail[q], D4 + lane);
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 float ov = __shfl_xor(bv, off);
@@ -333,13 +332,9 @@ int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n
                       unsigned long long *keys, int key_index_offset, int key_total_D) {
     if (n_pixels == 0) return SVH_OK;
     int grid = grid_for(ceil_div(n_pixels, EXTRACT_PB), 4, 256 * 8 * 4);
-    const bool vec = D % 4 == 0 && ((uintptr_t)cv & 15) == 0;
-#define SVH_EXTRACT(C, V) SVH_LAUNCH(ctx, "extract_index", (extract_index_kernel<C, V>), grid, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D)
-    if (strategy == SVH_COST) {
-        if (vec) SVH_EXTRACT(true, true); else SVH_EXTRACT(true, false);
-    } else {
-        if (vec) SVH_EXTRACT(false, true); else SVH_EXTRACT(false, false);
-    }
+#define SVH_EXTRACT(C) SVH_LAUNCH(ctx, "extract_index", (extract_index_kernel<C>), grid, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D)
+    if (strategy == SVH_COST) SVH_EXTRACT(true);
+    else SVH_EXTRACT(false);
 #undef SVH_EXTRACT
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;

@@ -251,17 +251,32 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
     const int64_t npx = (int64_t)H * W;
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t p = wave; p < npx; p += nwaves) {
+    // APPLY_PB pixels per wave iteration: their cost rows and min_p values are all requested before the first one is used
+    // (one pixel at a time leaves a single 1 KiB load in flight per wave and the kernel latency-bound)
+    constexpr int APPLY_PB = 4, MAX_PASS = 6;
+    for (int64_t p0 = wave * APPLY_PB; p0 < npx; p0 += nwaves * APPLY_PB) {
+      float cb[APPLY_PB][R], mpb[APPLY_PB][MAX_PASS];
+#pragma unroll
+      for (int u = 0; u < APPLY_PB; u++) {
+          const int64_t pu = min(p0 + u, npx - 1);
+          src.template load<R>((int)(pu / W), (int)(pu % W), lane, cb[u]);
+#pragma unroll
+          for (int q = 0; q < MAX_PASS; q++) mpb[u][q] = q < n_pass ? mmap[(int64_t)q * npx + pu] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < APPLY_PB; u++) {
+        const int64_t p = p0 + u;
+        if (p >= npx) break;
         const int j = (int)(p % W), i = (int)(p / W);
         float c[R], s[R];
-        src.template load<R>(i, j, lane, c);
 #pragma unroll
-        for (int k = 0; k < R; k++) s[k] = c[k]; // sgm_cv := cv, sgm.h:371-377
+        for (int k = 0; k < R; k++) s[k] = c[k] = cb[u][k]; // sgm_cv := cv, sgm.h:371-377
         const int ip = i - top, jp = j - left;
         if (ip >= 0 && ip < Hp && jp >= 0 && jp < Wp) {
-            for (int q = 0; q < n_pass; q++) {
-                if (!pass_visits(q, ip, jp, Hp, Wp)) continue;
-                const float mp = mmap[(int64_t)q * npx + p];
+#pragma unroll
+            for (int q = 0; q < MAX_PASS; q++) {
+                if (q >= n_pass || !pass_visits(q, ip, jp, Hp, Wp)) continue;
+                const float mp = mpb[u][q];
                 const bool mp_fin = finite_f(mp);
 #pragma unroll
                 for (int k = 0; k < R; k++) {
@@ -314,6 +329,7 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
                 }
             }
         }
+      }
     }
 }
 
@@ -330,22 +346,33 @@ __global__ void __launch_bounds__(256) volume_gmin_probe_kernel(SrcVolume src, i
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     bool bad = false;
-    for (int64_t p = wave; p < npx; p += nwaves) {
-        const int j = (int)(p % W), i = (int)(p / W);
-        float c[R];
-        src.template load<R>(i, j, lane, c);
-        float m = INFINITY;
+    constexpr int PROBE_PB = 4; // pixels per wave iteration, loads issued together
+    for (int64_t p0 = wave * PROBE_PB; p0 < npx; p0 += nwaves * PROBE_PB) {
+        float cb[PROBE_PB][R];
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            const int d = lane * R + k;
-            if (d < D) {
-                bad = bad || !(fabsf(c[k]) <= limit) || c[k] != rintf(c[k]);
-                const float t = (j + d >= W) ? c[k] + Pout : c[k];
-                m = fminf(m, c[k] + t);
-            }
+        for (int u = 0; u < PROBE_PB; u++) {
+            const int64_t pu = min(p0 + u, npx - 1);
+            src.template load<R>((int)(pu / W), (int)(pu % W), lane, cb[u]);
         }
-        m = wave_min(m);
-        if (lane == 0) gmap[p] = m;
+#pragma unroll
+        for (int u = 0; u < PROBE_PB; u++) {
+            const int64_t p = p0 + u;
+            if (p >= npx) break;
+            const int j = (int)(p % W);
+            float m = INFINITY;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const int d = lane * R + k;
+                if (d < D) {
+                    const float c = cb[u][k];
+                    bad = bad || !(fabsf(c) <= limit) || c != rintf(c);
+                    const float t = (j + d >= W) ? c + Pout : c;
+                    m = fminf(m, c + t);
+                }
+            }
+            m = wave_min(m);
+            if (lane == 0) gmap[p] = m;
+        }
     }
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }

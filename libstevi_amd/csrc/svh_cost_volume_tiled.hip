@@ -1,11 +1,8 @@
 // LDS-tiled, register-blocked cost volumes for grey images (CC / NCC / SSD / SAD and their zero-mean variants).
 //
-// A block owns 32 consecutive pixels of one row (8 per wave) and every disparity.  The (2v_r+1)-row source and target
-// tiles are staged in LDS once; lanes span the disparity axis (64 per chunk) so that a wave stores one pixel's costs as
-// coalesced 256-byte runs into the (row, col, disparity) volume.  For one window row the 8 pixels x h window columns
-// of a wave touch only 8 + h - 1 distinct target samples per lane (pixel p, column l -> sample p + l), so each LDS read
-// feeds up to h multiply-adds; the source samples are wave-uniform and travel through SGPRs (v_readlane).  No MFMA:
-// there is no shared operand between the per-pixel dot products to contract over.
+// A block owns 64 consecutive pixels of one row and every disparity.  The (2v_r+1)-row source and target tiles are staged in
+// LDS once; a lane is a pixel and keeps a block of 16 or 32 consecutive disparities in registers (see the kernel comment).
+// No MFMA: there is no shared operand between the per-pixel dot products to contract over.
 //
 // Arithmetic relative to the reference (cross_correlations.h:416-594, matching_costs.h:59-156): the products /
 // differences are accumulated per pixel in the reference's channel order (rows outer, columns inner); the per-element
@@ -24,8 +21,6 @@ namespace svh {
 namespace {
 
 enum { T_DOT = 0, T_SSD = 1, T_SAD = 2 };
-constexpr int CV_PB = 8;   // pixels per wave
-constexpr int CV_TPX = 32; // pixels per block
 
 __device__ __forceinline__ float image_or_zero1(const float *__restrict__ img, int H, int W, int i, int j) {
     return (i >= 0 && i < H && j >= 0 && j < W) ? img[(int64_t)i * W + j] : 0.0f;
@@ -75,116 +70,158 @@ __global__ void tiled_stats_kernel(const float *__restrict__ img, int H, int W, 
     }
 }
 
-template <int CMP, bool ZM, int HR>
-__global__ void __launch_bounds__(256) cost_volume_tiled_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt,
-                                                                int v_r, int D, int sign, int disp_lower, const float *__restrict__ mean_s,
-                                                                const float *__restrict__ mean_t, const float *__restrict__ norm_s,
-                                                                const float *__restrict__ norm_t, const float *__restrict__ zcost,
-                                                                int row_off, int64_t px_stride, int64_t out_off, float *__restrict__ cv) {
-    constexpr int h = 2 * HR + 1, NV = CV_PB + h - 1;
+// A block owns PL_TPX = 64 consecutive pixels of a row: lane u of every wave is pixel j0 + u, and each wave walks blocks of DB
+// consecutive disparities held in registers (wave w takes blocks w, w + 4, ...).  For one window row a lane reads its h source
+// samples and the h + DB - 1 target samples its DB windows cover (both stride-1 across the lanes: conflict-free LDS reads) and
+// issues h DB multiply-adds on register operands only (v_pk_fma_f32): no cross-lane traffic, about h DB / (2 h + DB - 1)
+// multiply-adds per LDS read, and no idle lanes when the disparity range is short (2-D volumes, the coarse levels of
+// hierarchical matching).  A lane stores its DB costs as 16-byte pieces of its pixel's run.  The direction sign is a template
+// parameter: as a runtime value it turns the operand selection into indirect register indexing.
+// (The first version of this file put the disparities on the lanes and eight pixels per wave in registers, with the source
+// samples broadcast by v_readlane: 2.45 ms for 1080p x 256 NCC 11x11 against 1.79 ms for this form.)
+constexpr int PL_TPX = 64;
+
+template <int CMP, bool ZM, int HR, int DB, int SIGN>
+__global__ void __launch_bounds__(256) cost_volume_pxlane_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
+                                                                 int D, int disp_lower, const float *__restrict__ mean_s,
+                                                                 const float *__restrict__ mean_t, const float *__restrict__ norm_s,
+                                                                 const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv) {
+    constexpr int h = 2 * HR + 1, NT = h + DB - 1;
     extern __shared__ float lds[];
     const int v = 2 * v_r + 1;
-    const int sw = CV_TPX + h - 1, tw = CV_TPX + h - 1 + D - 1;
+    const int n_blocks = (D + DB - 1) / DB;
+    const int sw = PL_TPX + h - 1, tw = PL_TPX + h - 1 + n_blocks * DB - 1;
     float *stile = lds, *ttile = lds + v * sw;
-    const int i = blockIdx.y, j0 = blockIdx.x * CV_TPX;
-    // block constant that keeps the zero-mean dot products small (see the header comment)
-    const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(j0, Ws - 1)] : 0.0f;
+    const int i = blockIdx.y, j0 = blockIdx.x * PL_TPX;
+    const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(j0, Ws - 1)] : 0.0f; // keeps the zero-mean dot products small
     const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
     const bool trow_in = it >= 0 && it < H;
     for (int k = 0; k < v; k++) {
         const int ii = i - v_r + k;
         for (int x = threadIdx.x; x < sw; x += blockDim.x) stile[k * sw + x] = image_or_zero1(src, H, Ws, ii, j0 - HR + x) - c0;
         for (int z = threadIdx.x; z < tw; z += blockDim.x) {
-            const int jt = sign > 0 ? j0 + disp_lower - HR + z : j0 + (CV_TPX - 1) - disp_lower + HR - z;
+            // forward: tile index = column offset; LeftToRight: mirrored, so that the index still grows with d
+            const int jt = SIGN > 0 ? j0 + disp_lower - HR + z : j0 + (PL_TPX - 1) - disp_lower + HR - z;
             ttile[k * tw + z] = image_or_zero1(tgt, H, Wt, it - v_r + k, jt) - c0;
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int ub = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * CV_PB);
-    const int tbase = sign > 0 ? ub : CV_TPX - ub - CV_PB; // + d + m
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = j0 + lane;
+    const bool px_in = j < Ws;
+    const int64_t px = (int64_t)i * Ws + min(j, Ws - 1);
+    const int tlane = SIGN > 0 ? lane : PL_TPX - 1 - lane;
     const float Ff = (float)(h * v);
-    for (int d0 = 0; d0 < D; d0 += 64) {
-        const int d = d0 + lane;
-        const int dd = min(d, D - 1); // lanes past D compute on the last valid disparity and do not store
-        float acc[CV_PB], delta[CV_PB];
+    const float ms = ZM ? mean_s[px] : 0.0f;
+    for (int db = wave; db < n_blocks; db += 4) {
+        const int d0 = db * DB;
+        float acc[DB], delta[DB];
 #pragma unroll
-        for (int p = 0; p < CV_PB; p++) {
-            acc[p] = 0.0f;
-            delta[p] = 0.0f;
+        for (int q = 0; q < DB; q++) {
+            acc[q] = 0.0f;
+            delta[q] = 0.0f;
         }
         if (ZM && CMP == T_SAD) {
 #pragma unroll
-            for (int p = 0; p < CV_PB; p++) {
-                const int j = j0 + ub + p, jt = j + sign * (disp_lower + dd);
-                if (j < Ws && trow_in && jt >= 0 && jt < Wt) delta[p] = mean_s[(int64_t)i * Ws + j] - mean_t[(int64_t)it * Wt + jt];
+            for (int q = 0; q < DB; q++) {
+                const int jt = j + SIGN * (disp_lower + d0 + q);
+                if (px_in && d0 + q < D && trow_in && jt >= 0 && jt < Wt) delta[q] = ms - mean_t[(int64_t)it * Wt + jt];
             }
         }
         for (int k = 0; k < v; k++) {
-            float tv[NV];
-            const float *trow = ttile + k * tw + tbase + dd;
+            float sv[h], tv[NT];
+            const float *srow = stile + k * sw + lane, *trow = ttile + k * tw + tlane + d0;
 #pragma unroll
-            for (int m = 0; m < NV; m++) tv[m] = trow[m];
-            const float mine = stile[k * sw + ub + min(lane, NV - 1)]; // lane m holds source sample m of this wave's pixels
+            for (int l = 0; l < h; l++) sv[l] = srow[l];
 #pragma unroll
-            for (int p = 0; p < CV_PB; p++) {
+            for (int m = 0; m < NT; m++) tv[m] = trow[m];
 #pragma unroll
-                for (int l = 0; l < h; l++) {
-                    const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), p + l));
-                    const float t = tv[sign > 0 ? p + l : (CV_PB - 1 - p) + (h - 1 - l)];
+            for (int l = 0; l < h; l++) {
+#pragma unroll
+                for (int q = 0; q < DB; q++) {
+                    const float s = sv[l], t = tv[SIGN > 0 ? l + q : (h - 1 - l) + q];
                     if (CMP == T_DOT) {
-                        acc[p] = fmaf(s, t, acc[p]);
+                        acc[q] = fmaf(s, t, acc[q]);
                     } else if (CMP == T_SSD) {
                         const float df = s - t;
-                        acc[p] = fmaf(df, df, acc[p]);
+                        acc[q] = fmaf(df, df, acc[q]);
                     } else {
-                        acc[p] += fabsf((s - t) - delta[p]);
+                        acc[q] += fabsf((s - t) - delta[q]);
                     }
                 }
             }
         }
-        if (d < D) {
+        if (!px_in) continue;
+        const float nsv = norm_s ? norm_s[px] : 1.0f, zc = zcost[px];
+        float r[DB];
 #pragma unroll
-            for (int p = 0; p < CV_PB; p++) {
-                const int j = j0 + ub + p;
-                if (j >= Ws) continue;
-                const int64_t px = (int64_t)i * Ws + j;
-                const int jt = j + sign * (disp_lower + d);
-                float r = acc[p];
-                if (trow_in && jt >= 0 && jt < Wt) {
-                    const int64_t pt = (int64_t)it * Wt + jt;
-                    if (ZM && CMP == T_DOT) r -= Ff * (mean_s[px] - c0) * (mean_t[pt] - c0);
-                    if (ZM && CMP == T_SSD) {
-                        const float dm = mean_s[px] - mean_t[pt];
-                        r -= Ff * dm * dm;
-                    }
-                    if (norm_s) r /= norm_s[px] * norm_t[pt];
-                } else {
-                    r = zcost[px];
+        for (int q = 0; q < DB; q++) {
+            const int d = d0 + q;
+            const int jt = j + SIGN * (disp_lower + d);
+            r[q] = acc[q];
+            if (d < D && trow_in && jt >= 0 && jt < Wt) {
+                const int64_t pt = (int64_t)it * Wt + jt;
+                if (ZM && CMP == T_DOT) r[q] -= Ff * (ms - c0) * (mean_t[pt] - c0);
+                if (ZM && CMP == T_SSD) {
+                    const float dm = ms - mean_t[pt];
+                    r[q] -= Ff * dm * dm;
                 }
-                cv[px * px_stride + out_off + d] = r;
+                if (norm_s) r[q] /= nsv * norm_t[pt];
+            } else {
+                r[q] = zc;
             }
+        }
+        float *o = cv + px * px_stride + out_off + d0;
+        if (d0 + DB <= D && (((px * px_stride + out_off + d0) & 3) == 0)) {
+#pragma unroll
+            for (int q = 0; q < DB; q += 4) *reinterpret_cast<float4 *>(o + q) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < DB; q++)
+                if (d0 + q < D) o[q] = r[q];
         }
     }
 }
 
-template <int CMP, bool ZM, int HR> void launch_tiled(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
-                                                      const float *ms, const float *mt, const float *ns, const float *nt, const float *zc,
-                                                      float *cv, size_t shmem) {
-    dim3 grid(ceil_div(a.Ws, CV_TPX), a.H);
-    SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_tiled_kernel<CMP, ZM, HR>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D, sign,
-               a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);
+template <int CMP, bool ZM, int HR, int DB> void launch_pxlane_db(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
+                                                                  const float *ms, const float *mt, const float *ns, const float *nt, const float *zc,
+                                                                  float *cv, size_t shmem) {
+    dim3 grid(ceil_div(a.Ws, PL_TPX), a.H);
+    if (sign > 0)
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_pxlane_kernel<CMP, ZM, HR, DB, 1>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D,
+                   a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);
+    else
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_pxlane_kernel<CMP, ZM, HR, DB, -1>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D,
+                   a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);
+}
+
+// disparities per lane and block: 32 for wide windows over long ranges (fewer LDS reads per multiply-add: measured 5 % faster
+// for 11x11 at D = 256, slower for 5x5), else 16
+inline int pxlane_db(int h_r, int D) { return (D >= 128 && h_r >= 4) ? 32 : 16; }
+inline size_t pxlane_shmem(int h_r, int v_r, int D) {
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1, db = pxlane_db(h_r, D), nb = (D + db - 1) / db;
+    return (size_t)v * ((PL_TPX + h - 1) + (PL_TPX + h - 1 + nb * db - 1)) * sizeof(float);
+}
+
+template <int CMP, bool ZM, int HR> void launch_pxlane(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
+                                                       const float *ms, const float *mt, const float *ns, const float *nt, const float *zc,
+                                                       float *cv, size_t shmem) {
+    if constexpr (HR >= 4) {
+        if (pxlane_db(HR, a.D) == 32) return launch_pxlane_db<CMP, ZM, HR, 32>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
+    }
+    launch_pxlane_db<CMP, ZM, HR, 16>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
 }
 
 template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                              const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv,
                                              size_t shmem) {
     switch (h_r) {
-    case 1: launch_tiled<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
-    case 2: launch_tiled<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
-    case 3: launch_tiled<CMP, ZM, 3>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
-    case 4: launch_tiled<CMP, ZM, 4>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
-    case 5: launch_tiled<CMP, ZM, 5>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 1: launch_pxlane<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 2: launch_pxlane<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 3: launch_pxlane<CMP, ZM, 3>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 4: launch_pxlane<CMP, ZM, 4>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 5: launch_pxlane<CMP, ZM, 5>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
     default: return false;
     }
 }
@@ -196,7 +233,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
     if (src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func)) return SVH_ERR_UNSUPPORTED;
     const int h = 2 * h_r + 1, v = 2 * v_r + 1;
-    const size_t shmem = (size_t)v * ((CV_TPX + h - 1) + (CV_TPX + h - 1 + a.D - 1)) * sizeof(float);
+    const size_t shmem = pxlane_shmem(h_r, v_r, a.D);
     if (shmem > 60 * 1024) return SVH_ERR_UNSUPPORTED;
     if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
     const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);

@@ -25,6 +25,7 @@ CONFIGS = {
     "c4": (4096, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
     "c4small": (1024, 540, 256, MF.NCC, 5, 5, 8, IK.Parabola, (160, 160, 190, 4, 32, 4), {}),
     "c5slice": (8192, 4320, 64, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),
+    "c5": (8192, 4320, 512, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),  # the whole range on one GPU
 }
 
 

@@ -10,6 +10,8 @@
 // a pure function of d_r, so the device runs two passes: a lane per pixel picks d_r (`guided_select`), then a lane per
 // (pixel, dd) fills the volume (`guided_volume`).  Both call the literal comparison of svh_compare.h, so equal inputs give
 // bit-equal costs in the two passes and the strict '<' / '>' winner rule sees exactly the values the volume holds.
+#include <type_traits>
+
 #include "svh_compare.h"
 #include "svh_internal.h"
 
@@ -142,10 +144,107 @@ __global__ void guided_volume_words_kernel(WordVolume src, WordVolume tgt, int H
     guided_volume_body([&](int i, int j, int jt) { return compare_words(src, tgt, i, j, jt); }, H, Ws, g, disp, tcv);
 }
 
+// One-pass form for images (the pyramid levels of hiearchicalTruncatedCostVolume) and radii up to 3: a lane evaluates the
+// 4R + 1 offsets d0 - 2R .. d0 + 2R of its pixel in one walk over the window, sharing the processed source sample between them;
+// the winner is searched over the middle 2R + 1 (strict comparison in increasing offset, as the reference does), and the
+// re-centred volume d_r - R .. d_r + R always lies inside the evaluated span.  The per-offset sums see exactly the terms, in
+// exactly the order, of compare_features, so the result equals the two-pass form bit for bit.
+template <int CMP, bool ZM, bool NORM, int R>
+__global__ void __launch_bounds__(256) guided_fused_kernel(FeatImage src, FeatImage tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
+                                                           const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
+                                                           GuideArgs g, int32_t *__restrict__ disp, float *__restrict__ tcv) {
+    constexpr int NC = 4 * R + 1, T = 2 * R + 1;
+    const int64_t npx = (int64_t)H * Ws;
+    const int C = src.C, h = 2 * src.h_r + 1, v = 2 * src.v_r + 1;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(p % Ws), i = (int)(p / Ws);
+        const int d0 = guided_base_disp(g.guide, g.Hg, g.Wg, H, Ws, i, j, g.dirSign);
+        const float ms = ZM ? mean_s[p] : 0.0f, ns = NORM ? norm_s[p] : 1.0f;
+        float mt[NC], nt[NC], acc[NC];
+        bool tin[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int jt = j + d0 + c - 2 * R;
+            tin[c] = jt >= 0 && jt < Wt;
+            const int64_t pt = (int64_t)i * Wt + (tin[c] ? jt : 0);
+            mt[c] = (ZM && tin[c]) ? mean_t[pt] : 0.0f;
+            nt[c] = (NORM && tin[c]) ? norm_t[pt] : 1.0f;
+            acc[c] = 0.0f;
+        }
+        for (int k = 0; k < v; k++) {
+            const int ii = i - src.v_r + k;
+            const bool row_in = ii >= 0 && ii < H;
+            for (int l = 0; l < h; l++) {
+                const int jj = j - src.h_r + l;
+                for (int ch = 0; ch < C; ch++) {
+                    float s = (row_in && jj >= 0 && jj < Ws) ? src.img[((int64_t)ii * Ws + jj) * C + ch] : 0.0f;
+                    if (ZM) s = s - ms;
+                    if (NORM) s = s / ns;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const int jc = jj + d0 + c - 2 * R;
+                        float t = 0.0f;
+                        if (tin[c]) {
+                            t = (row_in && jc >= 0 && jc < Wt) ? tgt.img[((int64_t)ii * Wt + jc) * C + ch] : 0.0f;
+                            if (ZM) t = t - mt[c];
+                            if (NORM) t = t / nt[c];
+                        }
+                        if (CMP == CMP_DOT) {
+                            acc[c] += s * t;
+                        } else if (CMP == CMP_SSD) {
+                            const float tmp = s - t;
+                            acc[c] += tmp * tmp;
+                        } else {
+                            acc[c] += fabsf(s - t);
+                        }
+                    }
+                }
+            }
+        }
+        float score = g.cost ? INFINITY : -INFINITY;
+        int best = 0; // offset of the winner relative to d0
+#pragma unroll
+        for (int c = R; c <= 3 * R; c++) {
+            if (g.cost ? (acc[c] < score) : (acc[c] > score)) {
+                score = acc[c];
+                best = c - 2 * R;
+            }
+        }
+        disp[p] = g.dirSign * (d0 + best);
+#pragma unroll
+        for (int dd = 0; dd < T; dd++) {
+            const int want = best + g.dirSign * (dd - R) + 2 * R;
+            float val = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (c == want) val = acc[c];
+            tcv[p * T + dd] = val;
+        }
+    }
+}
+
+template <int CMP, bool ZM, bool NORM>
+bool launch_guided_fused(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws,
+                         int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
+    const int grid = grid_for((int64_t)H * Ws, 256, 16384);
+    switch (g.radius) {
+    case 1: SVH_LAUNCH(ctx, "guided_fused", (guided_fused_kernel<CMP, ZM, NORM, 1>), grid, 256, 0, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
+    case 2: SVH_LAUNCH(ctx, "guided_fused", (guided_fused_kernel<CMP, ZM, NORM, 2>), grid, 256, 0, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
+    case 3: SVH_LAUNCH(ctx, "guided_fused", (guided_fused_kernel<CMP, ZM, NORM, 3>), grid, 256, 0, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
+    default: return false;
+    }
+}
+
 template <class A, int CMP, bool ZM, bool NORM>
 int launch_guided(svh_context *ctx, A src, A tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws, int Wt,
                   const GuideArgs &g, int32_t *disp, float *tcv) {
     const int64_t npx = (int64_t)H * Ws;
+    if constexpr (std::is_same_v<A, FeatImage>) {
+        if (launch_guided_fused<CMP, ZM, NORM>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv)) {
+            SVH_CHECK_LAUNCH(ctx);
+            return SVH_OK;
+        }
+    }
     SVH_LAUNCH(ctx, "guided_select", (guided_select_kernel<A, CMP, ZM, NORM>), grid_for(npx, 256, 16384), 256, 0, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g,
                disp);
     SVH_LAUNCH(ctx, "guided_volume", (guided_volume_kernel<A, CMP, ZM, NORM>), grid_for(npx * (2 * g.radius + 1), 256, 65536), 256, 0, src, tgt, ms, ns, mt,

@@ -203,15 +203,19 @@ def main():
         if traffic is not None:
             roof["traffic"] = traffic
         # The HBM model above prices traffic this design never generates; the roof that physically binds census_sweep is VALU
-        # issue.  Per 64 voxels a SIMD issues 2 v_xor (full rate, 2 cycles each) + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3 (half rate,
-        # 4 cycles each on gfx950: tools/ubench_valu.hip) = 18 cycles; 256 CUs x 4 SIMDs at 2.4 GHz.
+        # issue.  Per 64 voxels a SIMD issues 2 v_xor + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3; tools/ubench_valu.hip measures
+        # 2.76 / 4.58 / 4.46 / 4.55 cycles per wave-instruction and SIMD for them (in 2.4 GHz cycles, i.e. at the clock the chip
+        # actually holds under an all-VALU load): 21.4 cycles per 64 voxels; 256 CUs x 4 SIMDs.  The same mix issued from
+        # registers only (no LDS, ubench "sweep mix") reaches 6.2 Tvoxels/s including its loop overhead.
         issue = None
         if dom_name == "census_sweep":
             vox_launch = wl1["W"] * wl1["H"] * wl1["D"]
-            peak_vox = 1024 * 2.4e9 / 18.0 * 64.0
+            cyc = 2 * 2.76 + 2 * 4.58 + 4.46 + 0.5 * 4.55
+            peak_vox = 1024 * 2.4e9 / cyc * 64.0
             ach_vox = vox_launch / (avg_ms * 1e-3)
-            issue = {"bound": "valu_issue", "kernel": dom_name, "cycles_per_64_voxels_per_simd": 18, "peak": round(peak_vox / 1e9, 1),
-                     "achieved": round(ach_vox / 1e9, 1), "unit": "Gvoxels/s", "frac": round(ach_vox / peak_vox, 4)}
+            issue = {"bound": "valu_issue", "kernel": dom_name, "cycles_per_64_voxels_per_simd": round(cyc, 2), "peak": round(peak_vox / 1e9, 1),
+                     "achieved": round(ach_vox / 1e9, 1), "unit": "Gvoxels/s", "frac": round(ach_vox / peak_vox, 4),
+                     "rates": "measured per-instruction issue rates, tools/ubench_valu.hip"}
         pipeline_alg = 28.0 * voxels + 60.0 * wl["W"] * wl["H"]
         kernel_ms = {k: round(v[0] / n_warm, 4) for k, v in prof_all.items()}  # from the warm-up steps (all kernels bracketed)
         line = {

@@ -19,6 +19,8 @@
 //     and the "<=" winner scan over d is a min over keys (value, D-1-d).
 // Outside that regime (non-integer or huge Pout) the float expressions of the reference are evaluated literally
 // (EXACT = false variants) on min_p maps produced by the general wave-per-line kernels of svh_sgm.hip.
+#include <type_traits>
+
 #include "svh_internal.h"
 
 namespace svh {
@@ -202,16 +204,20 @@ __global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Po
     Rec<NW> cur_lo, cur_hi, nxt_lo, nxt_hi;
     load_pair<NW>(lds, m0, cur_lo, cur_hi);
     const int n_pairs = D >> 1;
-#pragma unroll 4
-    for (int e = 0; e < n_pairs; e++) {
+    // three branch-free loops instead of a three-way test per iteration: pairs entirely below `lo` (nobody pays Pout), the
+    // at most 64 pairs between `lo` and `hi` (per-lane split), pairs entirely from `hi` on (everybody pays).  The limits are
+    // wave uniform: 2e + 1 < lo <=> e < lo >> 1, and 2e >= hi <=> e >= (hi + 1) >> 1.
+    const int e_lo = min(lo >> 1, n_pairs), e_hi = min((hi + 1) >> 1, n_pairs);
+    auto step = [&](int e, auto mode) {
+        constexpr int MODE = decltype(mode)::value;
         load_pair<NW>(lds, m0 + e + 1, nxt_lo, nxt_hi);
         const int d = 2 * e;
         const uint32_t kEa = make_key(hamming_words<NW>(sE, cur_lo), d_off + d), kOa = make_key(hamming_words<NW>(sO, cur_hi), d_off + d);
         const uint32_t kEb = make_key(hamming_words<NW>(sE, cur_hi), d_off + d + 1), kOb = make_key(hamming_words<NW>(sO, nxt_lo), d_off + d + 1);
-        if (d + 1 < lo) {
+        if constexpr (MODE == 0) {
             kE0 = min(kE0, min(kEa, kEb));
             kO0 = min(kO0, min(kOa, kOb));
-        } else if (d >= hi) {
+        } else if constexpr (MODE == 2) {
             kE1 = min(kE1, min(kEa, kEb));
             kO1 = min(kO1, min(kOa, kOb));
         } else {
@@ -222,7 +228,15 @@ __global__ void __launch_bounds__(TJ) census_sweep_kernel(CensusGeom g, float Po
         }
         cur_lo = nxt_lo;
         cur_hi = nxt_hi;
-    }
+    };
+    // (the min-reductions are associative, so the loop vectoriser would otherwise interleave 16 iterations and spill the
+    // register file: 256 VGPRs instead of 40)
+#pragma clang loop vectorize(disable) interleave(disable) unroll_count(4)
+    for (int e = 0; e < e_lo; e++) step(e, std::integral_constant<int, 0>{});
+#pragma clang loop vectorize(disable) interleave(disable) unroll_count(2)
+    for (int e = e_lo; e < e_hi; e++) step(e, std::integral_constant<int, 1>{});
+#pragma clang loop vectorize(disable) interleave(disable) unroll_count(4)
+    for (int e = e_hi; e < n_pairs; e++) step(e, std::integral_constant<int, 2>{});
     if (D & 1) { // last (even) disparity
         const int d = D - 1;
         const uint32_t kEa = make_key(hamming_words<NW>(sE, cur_lo), d_off + d), kOa = make_key(hamming_words<NW>(sO, cur_hi), d_off + d);

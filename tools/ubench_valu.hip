@@ -22,6 +22,40 @@ template <int OP> __global__ void k(uint32_t *out, uint32_t seed, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// the instruction mix of one census_sweep voxel pair, on registers only (no LDS): 4 v_xor, 4 v_bcnt (two with a running sum),
+// 2 v_lshl_or, 1 v_min3 -- what the sweep could reach if nothing but VALU issue limited it
+__global__ void sweep_mix(uint32_t *out, uint32_t seed, int iters) {
+    uint32_t s0 = seed + threadIdx.x, s1 = s0 * 3, t0 = s0 * 5, t1 = s0 * 7, t2 = s0 * 11, t3 = s0 * 13, k = 0x7FFFFFFFu, c0, c1;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            asm volatile("v_xor_b32 %0, %2, %4\n\tv_xor_b32 %1, %3, %5\n\tv_bcnt_u32_b32 %0, %0, 0\n\tv_bcnt_u32_b32 %0, %1, %0\n\tv_lshl_or_b32 %0, %0, 12, %6"
+                         : "=&v"(c0), "=&v"(c1) : "v"(s0), "v"(s1), "v"(t0), "v"(t1), "s"(i + u));
+            asm volatile("v_xor_b32 %0, %2, %4\n\tv_xor_b32 %1, %3, %5\n\tv_bcnt_u32_b32 %0, %0, 0\n\tv_bcnt_u32_b32 %0, %1, %0\n\tv_lshl_or_b32 %0, %0, 12, %6"
+                         : "=&v"(c1), "=&v"(t2) : "v"(s0), "v"(s1), "v"(t1), "v"(t3), "s"(i + u + 1));
+            asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(k) : "v"(c0), "v"(c1));
+            t0 += k & 1; // keeps the chain alive without a memory access
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = k ^ t0 ^ t2;
+}
+
+void run_mix(uint32_t *d) {
+    const int blocks = 256 * 8, threads = 256, iters = 2048;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    sweep_mix<<<blocks, threads>>>(d, 1, 16);
+    hipEventRecord(e0);
+    sweep_mix<<<blocks, threads>>>(d, 1, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double voxels = (double)blocks * threads * iters * 8 * 2;
+    printf("sweep mix        %8.3f ms  %.1f Gvoxels/s  (1080p x 256 = 530.8 Mvoxels in %.1f us at this rate)\n", ms, voxels / ms / 1e6, 530.8e6 / (voxels / ms) * 1e3);
+}
+
 template <int OP> void run(const char *name, uint32_t *d) {
     const int blocks = 256 * 8, threads = 256, iters = 4096;
     hipEvent_t e0, e1;
@@ -50,5 +84,6 @@ int main() {
     run<5>("v_lshl_or_b32", d);
     run<6>("v_cndmask_b32", d);
     run<7>("v_min_u32", d);
+    run_mix(d);
     return 0;
 }

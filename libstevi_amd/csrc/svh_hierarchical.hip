@@ -7,9 +7,11 @@
 // computeGuidedCV searches 2r+1 disparities around twice the bilinearly upsampled coarse estimate, keeps the first strict
 // extremum d_r, and re-centres the truncated volume on it (:194-227).  After the re-centring every entry is
 //     tcv(i, j, dd) = cmp(src(i,j,:), tgt(i, j + d_r + dirSign (dd - r), :)),
-// a pure function of d_r, so the device runs two passes: a lane per pixel picks d_r (`guided_select`), then a lane per
-// (pixel, dd) fills the volume (`guided_volume`).  Both call the literal comparison of svh_compare.h, so equal inputs give
-// bit-equal costs in the two passes and the strict '<' / '>' winner rule sees exactly the values the volume holds.
+// a pure function of d_r.  Image inputs with r <= 3 take one pass (`guided_fused`: a lane per pixel evaluates the offsets
+// d0 - 2r .. d0 + 2r once, picks d_r among the middle ones and copies the re-centred window out); feature volumes, census
+// words and larger radii take two: a lane per pixel picks d_r (`guided_select`), then a lane per (pixel, dd) fills the volume
+// (`guided_volume`).  All of them accumulate the terms of the literal comparison of svh_compare.h in the same order, so equal
+// inputs give bit-equal costs and the strict '<' / '>' winner rule sees exactly the values the volume holds.
 #include <type_traits>
 
 #include "svh_compare.h"

@@ -87,6 +87,89 @@ inline int launch_stats(svh_context *ctx, A acc, int H, int W, bool zm, bool nrm
 
 enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
 
+// Window statistics of an image (unfold on the fly, auto padding) from an LDS tile: a block owns WS_TP consecutive pixels of a
+// row and stages the (2 v_r + 1) x (WS_TP + 2 h_r) x C samples its windows cover once; every lane then walks its own window two
+// or three times exactly as stats_kernel does (same values, same order, same operations), reading LDS instead of issuing
+// (2 h_r + 1)(2 v_r + 1) C bounds-checked global loads per walk.  zcost (optional): the cost of the pixel against the all-zero
+// target vector, which aggregateCost uses where the target column leaves the image (cross_correlations.h:235).
+constexpr int WS_TP = 256;
+
+template <int CMP>
+__global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, bool zero_mean, bool normalized, float *__restrict__ mean,
+                                                                   float *__restrict__ norm, float *__restrict__ zcost) {
+    extern __shared__ float ws_tile[];
+    const int h = 2 * a.h_r + 1, v = 2 * a.v_r + 1, C = a.C, F = h * v * C;
+    const int tw = (WS_TP + h - 1) * C; // floats per tile row
+    const int i = blockIdx.y, j0 = blockIdx.x * WS_TP;
+    for (int k = 0; k < v; k++) {
+        const int ii = i - a.v_r + k;
+        const bool row_in = ii >= 0 && ii < a.H;
+        for (int e = threadIdx.x; e < tw; e += WS_TP) {
+            const int jj = j0 - a.h_r + e / C;
+            ws_tile[k * tw + e] = (row_in && jj >= 0 && jj < a.W) ? a.img[((int64_t)ii * a.W + j0 - a.h_r) * C + e] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= a.W) return;
+    const int64_t p = (int64_t)i * a.W + j;
+    const float *win = ws_tile + threadIdx.x * C; // window sample (k, l, ch) at win[k * tw + l * C + ch]
+    const int hc = h * C;
+    const float scale = (float)(1. / (double)(float)F);
+    float m = 0.0f, n = 1.0f;
+    if (zero_mean) {
+        for (int k = 0; k < v; k++)
+            for (int q = 0; q < hc; q++) m += win[k * tw + q];
+        m *= scale;
+        mean[p] = m;
+    }
+    if (normalized) {
+        float acc = 0.0f;
+        for (int k = 0; k < v; k++)
+            for (int q = 0; q < hc; q++) {
+                const float tmp = win[k * tw + q] - m; // m == 0 without zero-mean: x - 0 is exact
+                acc += tmp * tmp;
+            }
+        n = sqrtf(acc);
+        norm[p] = n;
+    }
+    if (zcost) {
+        float acc = 0.0f;
+        for (int k = 0; k < v; k++)
+            for (int q = 0; q < hc; q++) {
+                float s = win[k * tw + q];
+                if (zero_mean) s = s - m;
+                if (normalized) s = s / n;
+                if (CMP == CMP_DOT) acc += s * 0.0f;
+                else if (CMP == CMP_SSD) acc += s * s;
+                else acc += fabsf(s);
+            }
+        zcost[p] = acc;
+    }
+}
+
+// image statistics: the LDS-tiled kernel when the tile fits, the per-lane global walk otherwise; cmp only matters for zcost
+inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm, float *mean, float *norm, float *zcost, int cmp) {
+    if ((int64_t)a.H * a.W == 0 || (!zm && !nrm && !zcost)) return SVH_OK;
+    const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
+    if (shmem <= 60 * 1024) {
+        dim3 grid(ceil_div(a.W, WS_TP), a.H);
+        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SSD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost);
+        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SAD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost);
+        else SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_DOT>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost);
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
+    if (zcost) return SVH_ERR_UNSUPPORTED; // callers that need zcost only take windows that fit (the register-blocked cost volumes)
+    return launch_stats<FeatImage>(ctx, a, a.H, a.W, zm, nrm, mean, norm);
+}
+inline int launch_stats(svh_context *ctx, FeatImage acc, int H, int W, bool zm, bool nrm, float *mean, float *norm) {
+    (void)H;
+    (void)W;
+    if (!zm && !nrm) return SVH_OK;
+    return launch_window_stats(ctx, acc, zm, nrm, mean, norm, nullptr, CMP_DOT);
+}
+
 // cmp(src(i,j,:), tgt(it,jt,:)) on the processed features (zero-mean / normalised per element, cross_correlations.h:416-594), with
 // the reference's float operations in the reference's channel order; a target pixel outside the image is the zero vector
 // (cross_correlations.h:235, :294, :359; hierarchical.h:177).

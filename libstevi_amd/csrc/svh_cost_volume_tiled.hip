@@ -14,6 +14,7 @@
 // which changes results by rounding only (a few 1e-7 relative; the north-star tolerance for float costs is 1e-4).
 // Means, norms and the all-zero-target cost (target column outside the image, cross_correlations.h:235) come from a
 // per-pixel statistics kernel that follows the reference literally.
+#include "svh_compare.h"
 #include "svh_internal.h"
 
 namespace svh {
@@ -24,50 +25,6 @@ enum { T_DOT = 0, T_SSD = 1, T_SAD = 2 };
 
 __device__ __forceinline__ float image_or_zero1(const float *__restrict__ img, int H, int W, int i, int j) {
     return (i >= 0 && i < H && j >= 0 && j < W) ? img[(int64_t)i * W + j] : 0.0f;
-}
-
-// per-pixel window statistics, literal order of the reference: mean (channelsMean, correlation_base.h:1100-1136), norm
-// (channelsNorm / channelsZeroMeanNorm, cross_correlations.h:61-191) and, for the source image, the cost against the
-// all-zero target vector
-template <int CMP>
-__global__ void tiled_stats_kernel(const float *__restrict__ img, int H, int W, int h_r, int v_r, bool zm, bool nrm, float *__restrict__ mean,
-                                   float *__restrict__ norm, float *__restrict__ zcost) {
-    const int64_t npx = (int64_t)H * W;
-    const int h = 2 * h_r + 1, v = 2 * v_r + 1, F = h * v;
-    const float scale = (float)(1. / (double)(float)F);
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(p % W), i = (int)(p / W);
-        float m = 0.0f, n = 1.0f;
-        if (zm) {
-            for (int k = 0; k < v; k++)
-                for (int l = 0; l < h; l++) m += image_or_zero1(img, H, W, i - v_r + k, j - h_r + l);
-            m *= scale;
-            mean[p] = m;
-        }
-        if (nrm) {
-            float acc = 0.0f;
-            for (int k = 0; k < v; k++)
-                for (int l = 0; l < h; l++) {
-                    float tmp = image_or_zero1(img, H, W, i - v_r + k, j - h_r + l) - m;
-                    acc += tmp * tmp;
-                }
-            n = sqrtf(acc);
-            norm[p] = n;
-        }
-        if (zcost) {
-            float acc = 0.0f;
-            for (int k = 0; k < v; k++)
-                for (int l = 0; l < h; l++) {
-                    float s = image_or_zero1(img, H, W, i - v_r + k, j - h_r + l);
-                    if (zm) s = s - m;
-                    if (nrm) s = s / n;
-                    if (CMP == T_DOT) acc += s * 0.0f;
-                    else if (CMP == T_SSD) acc += s * s;
-                    else acc += fabsf(s);
-                }
-            zcost[p] = acc;
-        }
-    }
 }
 
 // A block owns PL_TPX = 64 consecutive pixels of a row: lane u of every wave is pixel j0 + u, and each wave walks blocks of DB
@@ -255,14 +212,11 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
             st.nt = owner.get_n<float>(nt_px);
             if (!st.ns || !st.nt) return SVH_ERR_OUT_OF_MEMORY;
         }
-        const int gs = grid_for((int64_t)ns_px, 256, 16384), gt = grid_for((int64_t)nt_px, 256, 16384);
-#define SVH_STATS(CMPV)                                                                                                                        \
-    SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gs, 256, 0, src.data, src.H, src.W, h_r, v_r, zm, nrm, st.ms, st.ns, st.zc);      \
-    if (zm || nrm)                                                                                                                             \
-        SVH_LAUNCH(ctx, "window_stats", tiled_stats_kernel<CMPV>, gt, 256, 0, tgt.data, tgt.H, tgt.W, h_r, v_r, zm, nrm, st.mt, st.nt, (float *)nullptr);
-        if (cmp == T_DOT) { SVH_STATS(T_DOT) } else if (cmp == T_SSD) { SVH_STATS(T_SSD) } else { SVH_STATS(T_SAD) }
-#undef SVH_STATS
-        SVH_CHECK_LAUNCH(ctx);
+        // means / norms follow the reference literally (channelsMean, channelsNorm, channelsZeroMeanNorm); zc = cost of the source
+        // window against the all-zero target vector
+        const int cmpk = cmp == T_DOT ? CMP_DOT : cmp == T_SSD ? CMP_SSD : CMP_SAD;
+        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, 1, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk));
+        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, 1, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk));
         st.ready = true;
     }
     float *ms = st.ms, *mt = st.mt, *ns = st.ns, *nt = st.nt, *zc = st.zc;

@@ -158,6 +158,13 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
 int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
                         const int32_t margins[4], float Pout, svh_array *out);
 
+/* "Textbook" semi-global matching -- NOT the reference's behaviour, an explicit second mode:
+ * every one of the 4 / 8 directions traverses every line of the margin box once (the reference skips three directions and half of
+ * two more), and the Cost strategy penalises the neighbouring disparities (the reference adds the pixel's own cost there).  The
+ * Score strategy uses the reference's Score recurrence.  Defined by oracle/stevi_oracle.c so_sgm_textbook. */
+int svh_sgm_cost_volume_textbook(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
+                                 const int32_t margins[4], float Pout, svh_array *out);
+
 /* ---- A10 extractSelectedIndex<strategy>(cv)                         correlation/correlation_base.h:427-464
  * cv (H,W,D) f32 -> idx (H,W) i32; ties go to the largest index, NaN never replaces the incumbent. */
 int svh_extract_selected_index(svh_context *ctx, int strategy, const svh_array *cv, svh_array *idx);

@@ -24,7 +24,7 @@ EXPORTS = [
     "svh_status_string", "svh_last_error", "svh_device_available",
     "svh_profile_enable", "svh_profile_filter", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_oriented", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
-    "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume",
+    "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume", "svh_sgm_cost_volume_textbook",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
@@ -120,6 +120,7 @@ def load():
         "svh_feature_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, A, i32, i32, A]),
         "svh_unfold_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_int, i32, i32, A]),
         "svh_sgm_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, C.c_float, C.c_float, P(i32), C.c_float, A]),
+        "svh_sgm_cost_volume_textbook": (C.c_int, [ctx, C.c_int, C.c_int, A, C.c_float, C.c_float, P(i32), C.c_float, A]),
         "svh_extract_selected_index": (C.c_int, [ctx, C.c_int, A, A]),
         "svh_selected_index_to_disp": (C.c_int, [ctx, C.c_int, A, i32, A]),
         "svh_selected_cost": (C.c_int, [ctx, A, A, A]),

@@ -324,15 +324,19 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
     return out if st == _capi.OK else _empty_like(l, 3, "f32")
 
 
-def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0):
-    """sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout) -- correlation/sgm.h:360-404."""
+def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0, semantics="reference"):
+    """sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout) -- correlation/sgm.h:360-404, as written.
+    semantics="textbook" selects the explicit second mode (every direction fully traversed, neighbour penalties in the Cost
+    strategy): NOT the reference's result, see svh_sgm_cost_volume_textbook in include/stevi_hip.h."""
     lib = _capi.load()
     cv = _prep(cv_base, np.float32)
     ctx = context_for(cv)
     m = (margins or Margins()).as_tuple()
     out = _like(cv, tuple(cv.shape), "f32")
-    _check(ctx, lib.svh_sgm_cost_volume(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), P1, P2, (C.c_int32 * 4)(*m), Pout,
-                                        C.byref(_desc(out))))
+    if semantics not in ("reference", "textbook"):
+        raise ValueError("semantics is 'reference' or 'textbook'")
+    fn = lib.svh_sgm_cost_volume if semantics == "reference" else lib.svh_sgm_cost_volume_textbook
+    _check(ctx, fn(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), P1, P2, (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out))))
     return out
 
 

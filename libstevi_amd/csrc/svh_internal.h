@@ -217,7 +217,7 @@ struct WinnerOut {
 };
 // Cost branch on either source; out_sgm (H, W, D) optional
 int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &src, float *out_sgm, const WinnerOut &win);
-int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm);
+int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook = false);
 // census specialisation of the Cost branch (svh_census_sgm.hip)
 bool census_lane_kernels_available(int nWw, int D);
 bool census_exact_regime(const SgmArgs &a, int nWw);

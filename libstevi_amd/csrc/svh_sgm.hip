@@ -52,7 +52,22 @@ __device__ __forceinline__ Line line_of(const LineSet &ls, int l) {
     case 2: L = {ls.top + l, ls.left, 1, 1, min(ls.Hp - l, ls.Wp)}; break;
     case 3: L = {ls.top, ls.left + l, 1, 1, min(ls.Hp, ls.Wp - l)}; break;
     case 4: L = {ls.top, ls.left + l, 1, -1, min(ls.Hp, l + 1)}; break;
-    default: L = {ls.top + l, ls.left, -1, 1, min(l + 1, ls.Wp)}; break;
+    case 5: L = {ls.top + l, ls.left, -1, 1, min(l + 1, ls.Wp)}; break;
+    // "textbook" line sets (svh_sgm_cost_volume_textbook): the eight directions, every line of the margin box exactly once
+    case 6: L = {ls.top, ls.left + l, 1, 0, ls.Hp}; break;                  // Up2Down
+    case 7: L = {ls.top + ls.Hp - 1, ls.left + l, -1, 0, ls.Hp}; break;     // Down2Up
+    case 8: L = {ls.top + l, ls.left, 0, 1, ls.Wp}; break;                  // Left2Right
+    case 9: L = {ls.top + l, ls.left + ls.Wp - 1, 0, -1, ls.Wp}; break;     // Right2Left
+    case 10: case 11: {                                                    // diagonal j - i = l - (Hp - 1), forwards / backwards
+        const int k = l - (ls.Hp - 1), i0 = k <= 0 ? -k : 0, j0 = k <= 0 ? 0 : k, len = min(ls.Hp - i0, ls.Wp - j0);
+        if (ls.pass == 10) L = {ls.top + i0, ls.left + j0, 1, 1, len};
+        else L = {ls.top + i0 + len - 1, ls.left + j0 + len - 1, -1, -1, len};
+    } break;
+    default: {                                                             // anti-diagonal i + j = l, downwards / upwards
+        const int i0 = l < ls.Wp ? 0 : l - (ls.Wp - 1), j0 = l < ls.Wp ? l : ls.Wp - 1, len = min(ls.Hp - i0, j0 + 1);
+        if (ls.pass == 12) L = {ls.top + i0, ls.left + j0, 1, -1, len};
+        else L = {ls.top + i0 + len - 1, ls.left + j0 - (len - 1), -1, 1, len};
+    } break;
     }
     return L;
 }
@@ -402,7 +417,10 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // FAR_IS_GLOBAL: P2 >= P1 >= 0.  Then fl(prev[od] - P2) <= fl(prev[od] - P1) <= prev[od] for every od (x -> fl(x - P) is
 // monotone and P >= 0), so the three disparities excluded from the |od - nd| > 1 class are each dominated by a candidate
 // that is present anyway, and max_{|od-nd|>1} (prev[od] - P2) may be replaced by max_p - P2 without changing a(nd).
-template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL>
+// NEG: the pass runs on the negated costs and subtracts its contribution, which turns the max / -P recurrence into the
+// textbook min / +P one bit for bit (negation is exact, max(-x) = -min(x), fl(-p - P) = -fl(p + P)); only used by the
+// textbook mode: the reference's own Cost branch is the scalar recurrence of the kernels above (finding F4).
+template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG>
 __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
                                                             int D, int W, float P1, float P2, float Pout, bool vec) {
     const int lane = threadIdx.x & 63;
@@ -415,7 +433,10 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
 #pragma unroll
     for (int k = 0; k < R; k++) prev[k] = 0.0f; // sgm.h:206-208
     // one pixel of the line: the reference's update of the R disparities of this lane
-    auto step = [&](const float (&c)[R], const float (&sacc)[R], int ii, int jj) {
+    auto step = [&](const float (&c_in)[R], const float (&sacc)[R], int ii, int jj) {
+            float c[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) c[k] = NEG ? -c_in[k] : c_in[k];
             // finite previous scores, -inf otherwise (isfinite filters of :224, :241)
             float pf[R];
             float A = -INFINITY, Ahead = -INFINITY, Atail = -INFINITY;
@@ -478,8 +499,8 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
                 if (jj + d >= W) a -= Pout; // :247-249
                 float act = c[k];
                 if (maxp_fin && finite_f(a)) act = c[k] + (a - max_p); // :251-254
-                const float base = FIRST ? c[k] : sacc[k];
-                outv[k] = base + (act - c[k]); // :298-300
+                const float base = FIRST ? c_in[k] : sacc[k];
+                outv[k] = NEG ? base - (act - c[k]) : base + (act - c[k]); // :298-300
                 prev[k] = act;
             }
             float *o = sgm + ((int64_t)ii * W + jj) * D + lane * R;
@@ -519,7 +540,11 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-static int pass_lines(int q, int Hp, int Wp) { return (q == 0 || q == 3 || q == 4) ? Wp : Hp; }
+static int pass_lines(int q, int Hp, int Wp) {
+    if (q >= 10) return Hp + Wp - 1;
+    if (q >= 6) return q < 8 ? Wp : Hp;
+    return (q == 0 || q == 3 || q == 4) ? Wp : Hp;
+}
 
 static int pick_R(int D) {
     int R = 1;
@@ -619,9 +644,11 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
 }
 
 template <int R>
-static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm) {
+static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, bool textbook = false) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
-    const int n_pass = a.n_dir >= 8 ? 6 : 2;
+    const int n_pass = textbook ? (a.n_dir >= 8 ? 8 : 4) : (a.n_dir >= 8 ? 6 : 2);
+    const int pass0 = textbook ? 6 : 0;
+    const bool neg = textbook && a.strategy == SVH_COST;
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
     const bool vec = aligned16(cv) && aligned16(sgm) && a.D % 4 == 0;
     const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0;
@@ -633,15 +660,22 @@ static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv,
     }
     if (Hp <= 0 || Wp <= 0) return SVH_OK;
     for (int q = 0; q < n_pass; q++) {
-        LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
+        LineSet ls{pass0 + q, pass_lines(pass0 + q, Hp, Wp), a.top, a.left, Hp, Wp};
         int grid = ceil_div(ls.n_lines, 4);
         const bool first = q == 0 && whole;
-#define SVH_SCORE(FIRSTV, FARV)                                                                                                          \
-    SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, FIRSTV, FARV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout, vec)
-        if (far_global) {
-            if (first) SVH_SCORE(true, true); else SVH_SCORE(false, true);
+#define SVH_SCORE(FIRSTV, FARV, NEGV)                                                                                                    \
+    SVH_LAUNCH(ctx, NEGV ? "sgm_textbook_pass" : "sgm_score_pass", (sgm_score_pass_kernel<R, B, FIRSTV, FARV, NEGV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, \
+               a.P1, a.P2, a.Pout, vec)
+        if (neg) {
+            if (far_global) {
+                if (first) SVH_SCORE(true, true, true); else SVH_SCORE(false, true, true);
+            } else {
+                if (first) SVH_SCORE(true, false, true); else SVH_SCORE(false, false, true);
+            }
+        } else if (far_global) {
+            if (first) SVH_SCORE(true, true, false); else SVH_SCORE(false, true, false);
         } else {
-            if (first) SVH_SCORE(true, false); else SVH_SCORE(false, false);
+            if (first) SVH_SCORE(true, false, false); else SVH_SCORE(false, false, false);
         }
 #undef SVH_SCORE
         SVH_CHECK_LAUNCH(ctx);
@@ -649,15 +683,15 @@ static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv,
     return SVH_OK;
 }
 
-int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm) {
+int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook) {
     (void)scr;
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
     switch (pick_R(a.D)) {
-    case 1: return run_score_branch<1>(ctx, a, cv, out_sgm);
-    case 2: return run_score_branch<2>(ctx, a, cv, out_sgm);
-    case 4: return run_score_branch<4>(ctx, a, cv, out_sgm);
-    case 8: return run_score_branch<8>(ctx, a, cv, out_sgm);
-    case 16: return run_score_branch<16>(ctx, a, cv, out_sgm);
+    case 1: return run_score_branch<1>(ctx, a, cv, out_sgm, textbook);
+    case 2: return run_score_branch<2>(ctx, a, cv, out_sgm, textbook);
+    case 4: return run_score_branch<4>(ctx, a, cv, out_sgm, textbook);
+    case 8: return run_score_branch<8>(ctx, a, cv, out_sgm, textbook);
+    case 16: return run_score_branch<16>(ctx, a, cv, out_sgm, textbook);
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
     }
 }
@@ -694,7 +728,36 @@ extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strat
         SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, WinnerOut()));
     } else {
         if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
-        SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr));
+        SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr, false));
     }
+    return finish_out(ctx, os);
+}
+
+// "Textbook" semi-global matching: NOT the reference's behaviour -- what correlation/sgm.h
+// evidently intends.  All 4 / 8 directions, every line of the margin box once (the reference skips three directions and half of
+// two more: finding F5); Cost strategy a(nd) = min{prev[nd], prev[nd +- 1] + P1, min_far prev + P2} (the reference assigns the
+// pixel's own cost there: finding F4); Score strategy as the reference's Score branch.  Defined by oracle/stevi_oracle.c
+// so_sgm_textbook; same kernels as the Score branch (the Cost form runs on negated costs).
+extern "C" int svh_sgm_cost_volume_textbook(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
+                                            const int32_t margins[4], float Pout, svh_array *out) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
+    if (n_directions != 4 && n_directions != 8) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "n_directions must be 4 or 8");
+    if (strategy != SVH_COST && strategy != SVH_SCORE) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad strategy");
+    for (int k = 0; k < 3; k++)
+        if (cv->shape[k] != out->shape[k]) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have the shape of cv");
+    static const int32_t zero[4] = {0, 0, 0, 0};
+    const int32_t *m = margins ? margins : zero;
+    for (int k = 0; k < 4; k++)
+        if (m[k] < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "margins must be non-negative");
+    SgmArgs a{n_directions, strategy, (int)cv->shape[0], (int)cv->shape[1], (int)cv->shape[2], P1, P2, Pout, m[0], m[1], m[2], m[3]};
+    Scratch scr(ctx);
+    void *dcv;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_out(ctx, scr, *out, &os));
+    if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
+    SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr, true));
     return finish_out(ctx, os);
 }

@@ -30,6 +30,21 @@ Multidim::Array<float, 3> sgmCostVolume(Multidim::Array<T_CV, 3> const &cv_base,
     return sgm_cv;
 }
 
+// Extension, not in the reference: the "textbook" mode (all directions fully traversed, neighbour penalties in the Cost strategy);
+// see svh_sgm_cost_volume_textbook in include/stevi_hip.h.  sgmCostVolume above stays the reference as written.
+template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV>
+Multidim::Array<float, 3> sgmCostVolumeTextbook(Multidim::Array<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
+    static_assert(nDirections == 4 or nDirections == 8, "the textbook mode operates with 4 or 8 directions");
+    static_assert(std::is_same_v<T_CV, float>, "libstevi_hip: cost volumes are float");
+    Multidim::Array<float, 3> sgm_cv(cv_base.shape());
+    if (sgm_cv.empty()) return sgm_cv;
+    const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
+    std::lock_guard<std::mutex> g(HipBridge::lock());
+    svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
+    HipBridge::check(svh_sgm_cost_volume_textbook(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
+    return sgm_cv;
+}
+
 } // namespace Correlation
 } // namespace StereoVision
 

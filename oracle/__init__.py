@@ -417,3 +417,15 @@ def unfold_compressed(img, mask, pad=None):
     if out.size:
         lib().so_unfold_compressed(_p(x), H, W, Cc, _p(mask), mask.shape[0], mask.shape[1], _pad(pad), _p(out))
     return out
+
+
+# ---- "textbook" SGM: NOT the reference's behaviour, see the C comment ------------------
+def sgm_textbook(cv, n_dir, strategy, P1, P2, margins=(0, 0, 0, 0), Pout=100.0):
+    cv = _f32(cv)
+    H, W, D = cv.shape
+    out = np.empty_like(cv)
+    m = (C.c_int * 4)(*[int(x) for x in margins])
+    rc = lib().so_sgm_textbook(int(n_dir), int(strategy), _p(cv), H, W, D, C.c_float(P1), C.c_float(P2), m, C.c_float(Pout), _p(out))
+    if rc:
+        raise ValueError("unsupported number of directions")
+    return out

@@ -1319,3 +1319,89 @@ void so_unfold_oriented(const float *img, int H, int W, int C, int h_r, int v_r,
                     }
         }
 }
+
+/* ===== "textbook" SGM: SURVEY.md section 8(f) rank 4 (first half) ===================================================
+ * NOT the reference's behaviour (that is so_sgm, findings F4 / F5): what correlation/sgm.h evidently intends.
+ *   - all 8 (or 4) directions are traversed, every line exactly once, in the call order of sgmCostVolume (sgm.h:379-388):
+ *     Up2Down, Down2Up, Left2Right, Right2Left, UpLeft2DownRight, DownRight2UpLeft, UpRight2DownLeft, DownLeft2UpRight;
+ *   - Cost strategy:  a(nd) = min over finite { prev[nd], prev[nd-1] + P1, prev[nd+1] + P1, min_{|od-nd|>1} prev[od] + P2 }
+ *     (the penalised neighbour, not the pixel's own cost: the fix of sgm.h:281-283), + Pout where j + nd >= W;
+ *     Score strategy: the mirror image with max and -P (sgm.h:230-255 as written, it has no such slip);
+ *   - act(nd) = c(nd) + (a(nd) - ext) when a and ext = min / max over finite prev are finite, else c(nd); S += act - c;
+ *     prev = 0 at the start of every line; pixels outside the margin box keep S = C.
+ * This function is the definition the device mode is checked against (there is nothing in the reference to pin it to). */
+static void textbook_line(int strategy, long i0, long j0, int di, int dj, int len, const float *cv, float *sgm, int W, int D, float P1, float P2,
+                          float Pout, float *prev, float *act, float *pre, float *suf) {
+    const int cost = strategy == SO_COST;
+    const float worst = cost ? INFINITY : -INFINITY;
+    for (int d = 0; d < D; d++) prev[d] = 0.0f;
+    for (int s = 0; s < len; s++) {
+        long i = i0 + (long)s * di, j = j0 + (long)s * dj;
+        const float *c = cv + ((size_t)i * W + j) * D;
+        float *S = sgm + ((size_t)i * W + j) * D;
+        /* exclusive prefix / suffix extrema over the finite previous values: pre[d] covers od < d, suf[d] covers od > d */
+        float run = worst;
+        for (int d = 0; d < D; d++) { pre[d] = run; if (isfinite(prev[d])) run = cost ? fminf(run, prev[d]) : fmaxf(run, prev[d]); }
+        float ext = run;
+        run = worst;
+        for (int d = D - 1; d >= 0; d--) { suf[d] = run; if (isfinite(prev[d])) run = cost ? fminf(run, prev[d]) : fmaxf(run, prev[d]); }
+        for (int nd = 0; nd < D; nd++) {
+            float a = worst;
+#define TB_TAKE(v) do { float v_ = (v); if (isfinite(v_)) a = cost ? fminf(a, v_) : fmaxf(a, v_); } while (0)
+            TB_TAKE(prev[nd]);
+            if (nd > 0) TB_TAKE(cost ? prev[nd - 1] + P1 : prev[nd - 1] - P1);
+            if (nd + 1 < D) TB_TAKE(cost ? prev[nd + 1] + P1 : prev[nd + 1] - P1);
+            float far = worst; /* |od - nd| > 1: od <= nd - 2 or od >= nd + 2 */
+            if (nd >= 1) far = cost ? fminf(far, pre[nd - 1]) : fmaxf(far, pre[nd - 1]);
+            if (nd + 1 < D) far = cost ? fminf(far, suf[nd + 1]) : fmaxf(far, suf[nd + 1]);
+            TB_TAKE(cost ? far + P2 : far - P2);
+#undef TB_TAKE
+            if (j + nd >= W) a = cost ? a + Pout : a - Pout;
+            act[nd] = c[nd];
+            if (isfinite(a) && isfinite(ext)) act[nd] = c[nd] + (a - ext);
+        }
+        for (int d = 0; d < D; d++) { S[d] += act[d] - c[d]; prev[d] = act[d]; }
+    }
+}
+
+int so_sgm_textbook(int n_dir, int strategy, const float *cv, int H, int W, int D, float P1, float P2, const int margins[4], float Pout, float *out) {
+    if (n_dir != 4 && n_dir != 8) return 1;
+    memcpy(out, cv, (size_t)H * W * D * sizeof(float));
+    int left = margins[0], top = margins[1], Hp = H - margins[1] - margins[3], Wp = W - margins[0] - margins[2];
+    if (Hp <= 0 || Wp <= 0 || D <= 0) return 0;
+    int n_pass = n_dir == 8 ? 8 : 4;
+    for (int q = 0; q < n_pass; q++) {
+        int n_lines = q < 2 ? Wp : q < 4 ? Hp : Hp + Wp - 1;
+#pragma omp parallel
+        {
+            float *buf = (float *)malloc((size_t)4 * D * sizeof(float));
+#pragma omp for schedule(dynamic, 4)
+            for (int l = 0; l < n_lines; l++) {
+                long i0, j0;
+                int di, dj, len;
+                switch (q) {
+                case 0: i0 = 0; j0 = l; di = 1; dj = 0; len = Hp; break;
+                case 1: i0 = Hp - 1; j0 = l; di = -1; dj = 0; len = Hp; break;
+                case 2: i0 = l; j0 = 0; di = 0; dj = 1; len = Wp; break;
+                case 3: i0 = l; j0 = Wp - 1; di = 0; dj = -1; len = Wp; break;
+                case 4: case 5: { /* diagonal k = j - i = l - (Hp - 1) */
+                    int k = l - (Hp - 1);
+                    i0 = k <= 0 ? -k : 0; j0 = k <= 0 ? 0 : k;
+                    len = (Hp - i0) < (Wp - j0) ? (int)(Hp - i0) : (int)(Wp - j0);
+                    di = 1; dj = 1;
+                    if (q == 5) { i0 += len - 1; j0 += len - 1; di = -1; dj = -1; }
+                } break;
+                default: { /* anti-diagonal s = i + j = l */
+                    i0 = l < Wp ? 0 : l - (Wp - 1); j0 = l < Wp ? l : Wp - 1;
+                    len = (Hp - i0) < (j0 + 1) ? (int)(Hp - i0) : (int)(j0 + 1);
+                    di = 1; dj = -1;
+                    if (q == 7) { i0 += len - 1; j0 -= len - 1; di = -1; dj = 1; }
+                } break;
+                }
+                textbook_line(strategy, top + i0, left + j0, di, dj, len, cv, out, W, D, P1, P2, Pout, buf, buf + D, buf + 2 * D, buf + 3 * D);
+            }
+            free(buf);
+        }
+    }
+    return 0;
+}

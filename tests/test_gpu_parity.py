@@ -454,3 +454,32 @@ def test_random_configurations_against_oracle():
         lean = sv.stereoMatch(func, dev(left), dev(right), h_r, v_r, rng_arg, dDir=ddir, sgmDirections=n_dir, P1=P1, P2=P2, Pout=Pout,
                               margins=sv.Margins(*margins))
         assert np.array_equal(host(lean["disp"]), host(res["disp"])), tag
+
+
+# ------------------------------------------------------------------------------------------------ textbook SGM (explicit second mode)
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+@pytest.mark.parametrize("D", [1, 5, 64, 70, 130, 256, 300])
+def test_textbook_sgm_matches_its_definition(rng, strategy, D):
+    """svh_sgm_cost_volume_textbook against so_sgm_textbook (oracle/stevi_oracle.c): not the reference's behaviour, an extra mode
+    (SURVEY.md section 8f rank 4).  Same float operations in the same order: equal values (the Cost form runs on negated costs,
+    so a zero may come out with the other sign)."""
+    H, W = (9, 21) if D > 100 else (13, 17)
+    cv = rng.uniform(0, 8, (H, W, D)).astype(np.float32)
+    if D > 2:
+        cv[1, 2, 1] = np.inf
+        cv[3, 4, 0] = np.nan
+    for n_dir, margins, (P1, P2), Pout in ((8, (0, 0, 0, 0), (0.001, 0.01), 100.0), (4, (0, 0, 0, 0), (1.5, 0.5), 7.0), (8, (2, 1, 0, 3), (0.25, 3.0), -2.5)):
+        exp = so.sgm_textbook(cv, n_dir, strategy, P1, P2, margins, Pout)
+        for mk in (lambda x: x, dev):
+            got = host(sv.sgmCostVolume(n_dir, strategy, mk(cv), P1, P2, sv.Margins(*margins), Pout, semantics="textbook"))
+            assert np.array_equal(np.isnan(got), np.isnan(exp))
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok], exp[ok])
+
+
+def test_textbook_sgm_differs_from_the_reference_mode(rng):
+    cv = rng.uniform(0, 8, (12, 16, 20)).astype(np.float32)
+    ref = host(sv.sgmCostVolume(8, so.COST, dev(cv), 0.5, 2.0, sv.Margins(), 100.0))
+    tb = host(sv.sgmCostVolume(8, so.COST, dev(cv), 0.5, 2.0, sv.Margins(), 100.0, semantics="textbook"))
+    assert np.array_equal(ref, so.sgm(cv, 8, so.COST, 0.5, 2.0, (0, 0, 0, 0), 100.0))  # the default stays the reference as written
+    assert not np.array_equal(ref, tb)

@@ -406,3 +406,81 @@ def test_oracle_sgm_equals_python_restatement(rng, strategy, n_dir, margins):
             for variant in (0, 1):
                 got = so.sgm(cv, n_dir, strategy, P1, P2, margins, Pout, variant=variant)
                 assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+# ---- "textbook" SGM: an explicit second mode, not the reference's behaviour --------------
+def py_sgm_textbook(cv, n_dir, strategy, P1, P2, margins, Pout):
+    """Literal loops of the definition in oracle/stevi_oracle.c (so_sgm_textbook): O(D^2) candidate scan per pixel, float32
+    arithmetic, the eight directions in the call order of sgm.h:379-388, every line of the margin box once."""
+    f = np.float32
+    H, W, D = cv.shape
+    out = cv.copy()
+    left, top, right, bottom = margins
+    Hp, Wp = H - top - bottom, W - left - right
+    if Hp <= 0 or Wp <= 0:
+        return out
+    cost = strategy == so.COST
+    worst = f(np.inf) if cost else f(-np.inf)
+    better = (lambda a, b: a if a < b else b) if cost else (lambda a, b: a if a > b else b)
+    steps = [(1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, -1), (1, -1), (-1, 1)][:n_dir]
+    for di, dj in steps:
+        starts = [(i, j) for i in range(Hp) for j in range(Wp) if not (0 <= i - di < Hp and 0 <= j - dj < Wp)]
+        for (i, j) in starts:
+            prev = np.zeros(D, f)
+            while 0 <= i < Hp and 0 <= j < Wp:
+                ii, jj = top + i, left + j
+                c = cv[ii, jj]
+                fin = [p for p in prev if np.isfinite(p)]
+                ext = worst
+                for p in fin:
+                    ext = better(ext, p)
+                act = c.copy()
+                for nd in range(D):
+                    a = worst
+                    for od in range(D):
+                        if not np.isfinite(prev[od]):
+                            continue
+                        pen = f(0) if od == nd else (f(P1) if abs(od - nd) == 1 else f(P2))
+                        v = f(prev[od] + pen) if cost else f(prev[od] - pen)
+                        if np.isfinite(v):
+                            a = better(a, v)
+                    if jj + nd >= W:
+                        a = f(a + f(Pout)) if cost else f(a - f(Pout))
+                    if np.isfinite(a) and np.isfinite(ext):
+                        act[nd] = f(c[nd] + f(a - ext))
+                out[ii, jj] += act - c
+                prev = act
+                i, j = i + di, j + dj
+    return out
+
+
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+@pytest.mark.parametrize("n_dir", [4, 8])
+def test_textbook_sgm_oracle_equals_literal_loops(rng, strategy, n_dir):
+    for shape, margins, Pout in (((5, 7, 6), (0, 0, 0, 0), 100.0), ((6, 4, 9), (1, 0, 0, 2), 3.5), ((1, 5, 3), (0, 0, 0, 0), 0.0)):
+        cv = rng.uniform(0, 4, shape).astype(np.float32)
+        cv[0, 0, 1] = np.inf
+        if shape[0] > 2:
+            cv[2, 1, 0] = np.nan
+        got = so.sgm_textbook(cv, n_dir, strategy, 0.75, 2.5, margins, Pout)
+        exp = py_sgm_textbook(cv, n_dir, strategy, 0.75, 2.5, margins, Pout)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.array_equal(got[ok], exp[ok])
+
+
+def test_textbook_sgm_properties(rng):
+    cv = rng.uniform(0, 10, (9, 11, 7)).astype(np.float32)
+    # Cost and Score modes are mirror images
+    assert np.array_equal(so.sgm_textbook(cv, 8, so.COST, 0.5, 2.0), -so.sgm_textbook(-cv, 8, so.SCORE, 0.5, 2.0))
+    # a constant volume has nothing to propagate (Pout 0)
+    one = np.ones((4, 5, 3), np.float32)
+    assert np.array_equal(so.sgm_textbook(one, 8, so.COST, 1.0, 2.0, Pout=0.0), one)
+    # unlike the reference as written (finding F4), the penalties matter in Cost mode ...
+    assert not np.array_equal(so.sgm_textbook(cv, 8, so.COST, 0.5, 2.0), so.sgm_textbook(cv, 8, so.COST, 1.5, 2.0))
+    assert np.array_equal(so.sgm(cv, 8, so.COST, 0.5, 2.0), so.sgm(cv, 8, so.COST, 1.5, 2.0))
+    # ... and the result is invariant under a 180 degree rotation of the problem (the reference's direction set is not, F5); only
+    # compare where Pout cannot act (Pout = 0) and up to float summation order
+    a = so.sgm_textbook(cv, 8, so.COST, 0.5, 2.0, Pout=0.0)
+    b = so.sgm_textbook(cv[::-1, ::-1].copy(), 8, so.COST, 0.5, 2.0, Pout=0.0)[::-1, ::-1]
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-4)

@@ -265,6 +265,35 @@ int svh_hierarchical_truncated_cost_volume(svh_context *ctx, int match_func, int
                                            const svh_array *img_r, const int32_t *h_radii, const int32_t *v_radii, int32_t disp_width,
                                            int32_t upscale_disp_radius, svh_array *tcv, svh_array *disp);
 
+/* ---- on-demand (cacheless) cost volumes and PatchMatch: SURVEY.md section 8(f) rank 1 -- what examples/stereo-match runs
+ * (main.cpp:166-210).  Float matching functions only (CC ... ZSAD).  Images (H,W[,C]) f32.
+ * Features: OnDemandDecoratedFeaturesVolume<ZNFeaturesVolumeDecorator<ZeroMean, Normalized>, ...> over the full window
+ * (di, dj) in [-v_radius, v_radius] x [-h_radius, h_radius], channels innermost (main.cpp:150-164): samples CLAMPED to the image
+ * border, mean = sum / nF, norm = sqrt(sum of squares / nF)              correlation/on_demand_features_volume.h:34-214 */
+typedef struct svh_on_demand_params {
+    int32_t match_func;   /* svh_match_func, not CENSUS / HAMMING */
+    int32_t search_dims;  /* 1: CachelessOnDemandStereoCostVolume (columns only), 2: CachelessOnDemandImageFlowVolume (rows, columns) */
+    int32_t h_radius, v_radius;
+    int32_t lower0, upper0; /* searched row offsets (search_dims == 2 only) */
+    int32_t lower1, upper1; /* searched column offsets */
+} svh_on_demand_params;
+/* getFeatureVec of every pixel -> out (H,W,nF) f32, nF = (2 v_radius + 1)(2 h_radius + 1) C */
+int svh_on_demand_features(svh_context *ctx, int match_func, const svh_array *img, int h_radius, int v_radius, svh_array *out);
+/* CachelessOnDemandCostVolume::truncatedCostVolume(disp, radius)                 correlation/on_demand_cost_volume.h:474-596
+ * disp (H,W,search_dims) i32 -> tcv (H,W,2r+1[,2r+1]) f32, AS WRITTEN: the window is centred on disparity - lowerOffset (an index is
+ * handed to costValue where it expects a disparity, :513-514), entries without a value hold defaultCvValForMatchFunc (FLT_MAX for
+ * costs, FLT_MIN for scores, matching_costs.h:706-713).  disp with another component count -> SVH_EMPTY_RESULT (:478-480). */
+int svh_on_demand_truncated_cost_volume(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source,
+                                        const svh_array *img_target, const svh_array *disp, int radius, svh_array *tcv);
+/* cachelessPatchMatch<matchFunc, searchSpaceDim>(features_source, features_target, searchOffset, nIter, nRandomSearch)
+ *                                                                                 correlation/patchmatch.h:560-621
+ * -> disp (H,W,search_dims) i32; *iterations_run (optional) = iterations executed before "no change" stopped the loop.
+ * The reference draws from std::default_random_engine seeded by std::random_device per thread (not reproducible); here every
+ * draw is a pure function of (seed, iteration, pixel, draw, dimension) mapped into the range like the reference's NumbersCache
+ * branch (|v % range| + lower), so equal seeds give equal results, bit-identical to oracle/stevi_oracle.c. */
+int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
+                              int n_iter, int n_random_search, uint64_t seed, svh_array *disp, int32_t *iterations_run);
+
 /* ---- fused pipeline: the benchmark / stereo_refine_test call chain kept on the device ------------------
  * unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp
  *   (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294)

@@ -29,10 +29,15 @@ EXPORTS = [
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
+    "svh_on_demand_features", "svh_on_demand_truncated_cost_volume", "svh_cacheless_patch_match",
     "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_unfold_compressed", "svh_unfold_compressed_shape",
     "svh_channels_mean", "svh_channels_norm", "svh_channels_zero_mean_norm", "svh_zeromean_feature_volume", "svh_normalized_feature_volume",
     "svh_zeromean_normalized_feature_volume", "svh_feature_volume_for_match_func", "svh_guided_cost_volume", "svh_hierarchical_truncated_cost_volume",
 ]
+
+
+class SvhOnDemandParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("match_func", "search_dims", "h_radius", "v_radius", "lower0", "upper0", "lower1", "upper1")]
 
 
 class SvhArray(C.Structure):
@@ -136,6 +141,9 @@ def load():
         "svh_refine_disp_2d_cost_interpolation": (C.c_int, [ctx, C.c_int, C.c_int, A, A, A]),
         "svh_refine_disp_2d_cost_patch_interpolation": (C.c_int, [ctx, C.c_int, A, A, A]),
         "svh_average_pooling_downsample": (C.c_int, [ctx, A, C.c_int, C.c_int, A]),
+        "svh_on_demand_features": (C.c_int, [ctx, C.c_int, A, C.c_int, C.c_int, A]),
+        "svh_on_demand_truncated_cost_volume": (C.c_int, [ctx, P(SvhOnDemandParams), A, A, A, C.c_int, A]),
+        "svh_cacheless_patch_match": (C.c_int, [ctx, P(SvhOnDemandParams), A, A, C.c_int, C.c_int, C.c_uint64, A, P(i32)]),
         "svh_unfold_compressed": (C.c_int, [ctx, A, P(i32), C.c_int, C.c_int, P(i32), A]),
         "svh_unfold_compressed_shape": (C.c_int, [A, P(i32), C.c_int, C.c_int, P(i32), P(C.c_int64)]),
         "svh_channels_mean": (C.c_int, [ctx, A, A]),

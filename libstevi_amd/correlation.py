@@ -769,6 +769,66 @@ def hiearchicalTruncatedCostVolume(matchFunc, depth, img_l, img_r, h_radiuses, v
     return OffsetedCostVolume(tcv, disp)
 
 
+# ---- on-demand (cacheless) cost volumes and PatchMatch (what examples/stereo-match runs) --------
+def _on_demand_params(matchFunc, radius, searchRange):
+    p = _capi.SvhOnDemandParams()
+    p.match_func = int(matchFunc)
+    p.h_radius, p.v_radius = (int(radius), int(radius)) if np.isscalar(radius) else (int(radius[0]), int(radius[1]))
+    if isinstance(searchRange, searchOffset2):
+        p.search_dims = 2
+        p.lower0, p.upper0, p.lower1, p.upper1 = searchRange.lower0, searchRange.upper0, searchRange.lower1, searchRange.upper1
+    else:
+        lo, hi = (searchRange.lower, searchRange.upper) if isinstance(searchRange, searchOffset1) else (int(searchRange[0]), int(searchRange[1]))
+        p.search_dims = 1
+        p.lower0 = p.upper0 = 0
+        p.lower1, p.upper1 = lo, hi
+    return p
+
+
+def onDemandFeatures(matchFunc, img, radius):
+    """getFeatureVec of OnDemandDecoratedFeaturesVolume<ZNFeaturesVolumeDecorator<ZeroMean, Normalized>, ...> at every pixel, over
+    the full (2r+1)^2 x C window of examples/stereo-match/main.cpp:150-164 -- correlation/on_demand_features_volume.h:34-214."""
+    lib = _capi.load()
+    x = _prep(img, np.float32)
+    ctx = context_for(x)
+    hr, vr = (int(radius), int(radius)) if np.isscalar(radius) else (int(radius[0]), int(radius[1]))
+    Cc = x.shape[2] if x.ndim == 3 else 1
+    out = _like(x, (x.shape[0], x.shape[1], (2 * hr + 1) * (2 * vr + 1) * Cc), "f32")
+    _check(ctx, lib.svh_on_demand_features(ctx, int(matchFunc), C.byref(_desc(x)), hr, vr, C.byref(_desc(out))))
+    return out
+
+
+def cachelessPatchMatch(matchFunc, img_source, img_target, radius, searchOffset, nIter=5, nRandomSearch=4, seed=0, return_iterations=False):
+    """cachelessPatchMatch<matchFunc, searchSpaceDim>(OnDemand features of img_source / img_target, searchOffset, nIter, nRandomSearch)
+    -- correlation/patchmatch.h:560-621.  searchOffset: searchOffset2 (flow, disp (H,W,2)) or searchOffset1 / (lower, upper)
+    (stereo, disp (H,W,1)).  The random stream is a function of `seed` (the reference's is not reproducible)."""
+    lib = _capi.load()
+    s, t = _prep(img_source, np.float32), _prep(img_target, np.float32)
+    ctx = context_for(s)
+    p = _on_demand_params(matchFunc, radius, searchOffset)
+    out = _like(s, (s.shape[0], s.shape[1], p.search_dims), "i32")
+    its = C.c_int32(0)
+    st = _check(ctx, lib.svh_cacheless_patch_match(ctx, C.byref(p), C.byref(_desc(s)), C.byref(_desc(t)), int(nIter), int(nRandomSearch), C.c_uint64(seed),
+                                                   C.byref(_desc(out)), C.byref(its)))
+    if st != _capi.OK:
+        out = _empty_like(s, 3, "i32")
+    return (out, its.value) if return_iterations else out
+
+
+def onDemandTruncatedCostVolume(matchFunc, img_source, img_target, radius, searchOffset, disp, cv_radius=1):
+    """CachelessOnDemand{ImageFlow,Stereo}CostVolume(features_source, features_target, searchSpace).truncatedCostVolume(disp, radius)
+    -- correlation/on_demand_cost_volume.h:474-596, as written (window centred on disparity - lowerOffset)."""
+    lib = _capi.load()
+    s, t, d = _prep(img_source, np.float32), _prep(img_target, np.float32), _prep(disp, np.int32)
+    ctx = context_for(s)
+    p = _on_demand_params(matchFunc, radius, searchOffset)
+    T = 2 * int(cv_radius) + 1
+    out = _like(s, (s.shape[0], s.shape[1]) + (T,) * p.search_dims, "f32")
+    st = _check(ctx, lib.svh_on_demand_truncated_cost_volume(ctx, C.byref(p), C.byref(_desc(s)), C.byref(_desc(t)), C.byref(_desc(d)), int(cv_radius),
+                                                             C.byref(_desc(out))))
+    return out if st == _capi.OK else _empty_like(s, 2 + p.search_dims, "f32")
+
+
 def set_option(x, name, value):
     """svh_context_set_option on the context used for array x (e.g. "census_fast_path", 0/1)."""
     ctx = context_for(x)

@@ -1,0 +1,460 @@
+// On-demand (cacheless) cost volumes and PatchMatch: SURVEY.md section 8(f) rank 1 -- what examples/stereo-match runs
+// (main.cpp:166-210): ZNCC cachelessPatchMatch on on-demand zero-mean-normalised features, then, with --refine, the truncated
+// on-demand cost volume around the result (fed to refineDisp2dCostInterpolation, svh_select_refine.hip).
+//
+//   OnDemandDecoratedFeaturesVolume<ZNFeaturesVolumeDecorator<ZM, N>, ...>     correlation/on_demand_features_volume.h:34-214
+//   CachelessOnDemandCostVolume::costValue / truncatedCostVolume               correlation/on_demand_cost_volume.h:345-612
+//   cachelessPatchMatch / patchMatchImpl / patchMatchPropagate / patchMatchSearch / patchMatchTestCost
+//                                                                              correlation/patchmatch.h:61-621
+//
+// These are NOT the features of the dense path: window samples outside the image are clamped to the border instead of being
+// zero, and the decorator divides by the feature count (mean = sum / nF, norm = sqrt(sum of squares / nF)).  "Cacheless" in the
+// reference means every cost is recomputed from the two images; here the decorated feature vectors of both images are formed
+// once per call (H W nF floats each, in HBM) and a cost is the reference's featureComparison of two of them -- same values,
+// same order, without redoing the decoration for every candidate.
+//
+// PatchMatch follows the reference statement by statement: a propagation pass is a row sweep (rows independent, a row
+// sequential: one lane per row) followed by a column sweep (one lane per column), then the random search (one lane per pixel);
+// the std::optional comparisons of patchmatch.h:203-211 are reproduced (a candidate without a value is dropped; with a score
+// function a candidate beats a current solution that has no value, with a cost function it never does); going left / up the
+// sweeps stop before index 0 (`j != final`, propagation_direction.h:40-55).  The one thing that cannot be reproduced is the random
+// stream: the reference seeds a std::default_random_engine per OpenMP thread from std::random_device (patchmatch.h:76-92,
+// :243-258), so its own output differs from run to run.  Here every draw is a pure function of (seed, iteration, pixel, draw,
+// dimension), mapped into the range as the reference's NumbersCache branch does: |v % range| + lower (correlation_base.h:377-384).
+#include <algorithm>
+#include <cfloat>
+
+#include "svh_internal.h"
+
+namespace svh {
+
+namespace {
+
+struct OdVolume {
+    const float *fs, *ft; // decorated features (H, W, nF)
+    int func, nd;         // matching function, number of search dimensions
+    int lower[2], upper[2];
+    int Hs, Ws, Ht, Wt, nF;
+    bool score;
+};
+
+__global__ void on_demand_features_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, bool zm, bool nrm,
+                                          float *__restrict__ out) {
+    const int64_t npx = (int64_t)H * W;
+    const int nF = (2 * v_r + 1) * (2 * h_r + 1) * C;
+    auto sample = [&](int i, int j, int f) {
+        const int c = f % C, dj = (f / C) % (2 * h_r + 1) - h_r, di = f / (C * (2 * h_r + 1)) - v_r;
+        const int ii = min(H - 1, max(0, i + di)), jj = min(W - 1, max(0, j + dj)); // constant border condition, features_volume.h:128-133
+        return img[((int64_t)ii * W + jj) * C + c];
+    };
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(p % W), i = (int)(p / W);
+        float mean = 0.0f, norm = 1.0f;
+        if (zm) { // :183-192
+            for (int f = 0; f < nF; f++) mean += sample(i, j, f);
+            mean /= (float)nF;
+        }
+        if (nrm) { // :194-207
+            float acc = 0.0f;
+            for (int f = 0; f < nF; f++) {
+                float v = sample(i, j, f);
+                if (zm) v -= mean;
+                acc += v * v;
+            }
+            acc /= (float)nF;
+            norm = sqrtf(acc);
+        }
+        float *o = out + p * nF;
+        for (int f = 0; f < nF; f++) {
+            float v = sample(i, j, f);
+            if (zm) v -= mean;
+            if (nrm) v /= norm;
+            o[f] = v;
+        }
+    }
+}
+
+// costValue, on_demand_cost_volume.h:409-468.  disp[0] = rows, disp[1] = columns (flow); disp[0] = columns (stereo).
+__device__ __forceinline__ bool od_cost(const OdVolume &o, int i, int j, int d0, int d1, float *cost) {
+    int ti = i, tj = j;
+    if (o.nd == 2) {
+        if (d0 < o.lower[0] || d0 > o.upper[0] || d1 < o.lower[1] || d1 > o.upper[1]) return false;
+        ti += d0;
+        tj += d1;
+    } else {
+        if (d0 < o.lower[0] || d0 > o.upper[0]) return false;
+        tj += d0;
+    }
+    if (ti < 0 || ti >= o.Ht || tj < 0 || tj >= o.Wt) return false;
+    const float *s = o.fs + ((int64_t)i * o.Ws + j) * o.nF, *t = o.ft + ((int64_t)ti * o.Wt + tj) * o.nF;
+    float acc = 0.0f;
+    if (o.func == SVH_SSD || o.func == SVH_ZSSD) {
+        for (int f = 0; f < o.nF; f++) {
+            const float tmp = s[f] - t[f];
+            acc += tmp * tmp;
+        }
+    } else if (o.func == SVH_SAD || o.func == SVH_ZSAD) {
+        for (int f = 0; f < o.nF; f++) acc += fabsf(s[f] - t[f]);
+    } else {
+        for (int f = 0; f < o.nF; f++) acc += s[f] * t[f];
+    }
+    *cost = acc;
+    return true;
+}
+
+// truncatedCostVolume as written (on_demand_cost_volume.h:474-596): the value handed to costValue as a disparity is
+// tap - radius + disp2idx(disparity), i.e. the window is centred on disparity - lowerOffset
+__global__ void od_truncated_kernel(OdVolume o, const int32_t *__restrict__ disp, int radius, float def, float *__restrict__ tcv) {
+    const int T = 2 * radius + 1, TT = o.nd == 2 ? T * T : T;
+    const int64_t n = (int64_t)o.Hs * o.Ws * TT;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(e % TT);
+        const int64_t p = e / TT;
+        const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+        const int32_t *d = disp + p * o.nd;
+        float c;
+        bool ok;
+        if (o.nd == 2) ok = od_cost(o, i, j, tap / T - radius + (d[0] - o.lower[0]), tap % T - radius + (d[1] - o.lower[1]), &c);
+        else ok = od_cost(o, i, j, tap - radius + (d[0] - o.lower[0]), 0, &c);
+        tcv[e] = ok ? c : def;
+    }
+}
+
+// ---- PatchMatch ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t pm_random(uint64_t seed, uint32_t iter, uint32_t i, uint32_t j, uint32_t k, uint32_t dim) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (((uint64_t)iter << 40) ^ ((uint64_t)i << 20) ^ (uint64_t)j ^ ((uint64_t)k << 56) ^ ((uint64_t)dim << 60) ^ 0x632BE59BD9B4E019ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; // splitmix64 finaliser
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (int32_t)(uint32_t)(z >> 32);
+}
+__device__ __forceinline__ int32_t pm_in_range(int32_t v, int lower, int upper) { // setValueInRange, correlation_base.h:377-384
+    const int range = upper - lower + 1;
+    const int m = v % range;
+    return (m < 0 ? -m : m) + lower;
+}
+
+// One wavefront evaluates one cost: the lanes fetch the two feature vectors coalesced (64 consecutive floats per access) and form
+// the per-feature terms in parallel -- exactly the products / differences featureComparison forms -- park them in LDS, and the
+// running sum is then taken in the reference's order (f = 0, 1, 2, ...) by every lane redundantly, so all lanes hold the same,
+// bit-identical value.  (A lane per cost, as the truncated-volume kernel does, leaves the sweeps waiting on one dependent load
+// after the other: 45 us per pixel step at 1080p RGB 7x7; this form takes well under one.)  Blocks are single waves.
+__device__ __forceinline__ bool wave_cost(const OdVolume &o, int i, int j, int d0, int d1, float *buf, float *cost) {
+    int ti = i, tj = j;
+    if (o.nd == 2) {
+        if (d0 < o.lower[0] || d0 > o.upper[0] || d1 < o.lower[1] || d1 > o.upper[1]) return false;
+        ti += d0;
+        tj += d1;
+    } else {
+        if (d0 < o.lower[0] || d0 > o.upper[0]) return false;
+        tj += d0;
+    }
+    if (ti < 0 || ti >= o.Ht || tj < 0 || tj >= o.Wt) return false;
+    const float *s = o.fs + ((int64_t)i * o.Ws + j) * o.nF, *t = o.ft + ((int64_t)ti * o.Wt + tj) * o.nF;
+    const int lane = threadIdx.x;
+    __syncthreads(); // the previous cost's readers are done with buf
+    for (int f = lane; f < o.nF; f += 64) {
+        const float a = s[f], b = t[f];
+        float term;
+        if (o.func == SVH_SSD || o.func == SVH_ZSSD) {
+            const float tmp = a - b;
+            term = tmp * tmp;
+        } else if (o.func == SVH_SAD || o.func == SVH_ZSAD) {
+            term = fabsf(a - b);
+        } else {
+            term = a * b;
+        }
+        buf[f] = term;
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    int f = 0;
+    for (; f + 4 <= o.nF; f += 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(buf + f);
+        acc += q.x;
+        acc += q.y;
+        acc += q.z;
+        acc += q.w;
+    }
+    for (; f < o.nF; f++) acc += buf[f];
+    *cost = acc;
+    return true;
+}
+
+// The cost of the current solution of every pixel is kept next to it (value + "has a value"), updated whenever the solution
+// changes: the reference recomputes it for every test (it is "cacheless"), which gives the same number each time.
+struct PmState {
+    int32_t *sol;
+    float *cost;
+    uint8_t *valid;
+};
+
+// patchMatchTestCost, patchmatch.h:162-224, for the whole wave (uniform control flow); returns 1 when the candidate was kept
+__device__ __forceinline__ int pm_test(const OdVolume &o, const PmState &st, int i, int j, int c0, int c1, float *buf) {
+    const int64_t p = (int64_t)i * o.Ws + j;
+    float c_new;
+    if (!wave_cost(o, i, j, c0, c1, buf, &c_new)) return 0;
+    const bool has_old = st.valid[p] != 0;
+    const float c_old = st.cost[p];
+    bool keep;
+    if (o.score) keep = has_old ? (c_new >= c_old) : true;  // `v >= nullopt` is true
+    else keep = has_old ? (c_new <= c_old) : false;         // `v <= nullopt` is false
+    if (keep && threadIdx.x == 0) {
+        st.sol[p * o.nd] = c0;
+        if (o.nd == 2) st.sol[p * o.nd + 1] = c1;
+        st.cost[p] = c_new;
+        st.valid[p] = 1;
+    }
+    return keep ? 1 : 0;
+}
+
+// randomDispInit, :61-160 (NumbersCache branch), plus the cost of the initial solution; a wave per pixel
+__global__ void __launch_bounds__(64) pm_init_kernel(OdVolume o, uint64_t seed, PmState st) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int64_t npx = (int64_t)o.Hs * o.Ws;
+    for (int64_t p = blockIdx.x; p < npx; p += gridDim.x) {
+        const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+        int d[2] = {0, 0};
+        for (int s = 0; s < o.nd; s++) d[s] = pm_in_range(pm_random(seed, 0xFFFFFFFFu, i, j, 0, s), o.lower[s], o.upper[s]);
+        float c = 0.0f;
+        const bool ok = wave_cost(o, i, j, d[0], d[1], pm_buf, &c);
+        if (threadIdx.x == 0) {
+            for (int s = 0; s < o.nd; s++) st.sol[p * o.nd + s] = d[s];
+            st.cost[p] = c;
+            st.valid[p] = ok ? 1 : 0;
+        }
+    }
+}
+
+// row sweep of patchMatchPropagate (:387-410): a wave per row, the row is sequential; the candidate is the (possibly just
+// updated) solution of the previous pixel, carried in registers
+__global__ void __launch_bounds__(64) pm_rows_kernel(OdVolume o, int inc, PmState st, int *__restrict__ changes) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int i = blockIdx.x;
+    int n = 0;
+    const int jfirst = inc > 0 ? 0 : o.Ws - 1;
+    int64_t pp = (int64_t)i * o.Ws + jfirst;
+    int p0 = st.sol[pp * o.nd], p1 = o.nd == 2 ? st.sol[pp * o.nd + 1] : 0; // solution of the sweep's first pixel (it has no predecessor)
+    for (int j = jfirst + inc; inc > 0 ? j < o.Ws : j > 0; j += inc) { // `j != final`: going left stops before column 0
+        const int kept = pm_test(o, st, i, j, p0, p1, pm_buf);
+        n += kept;
+        if (!kept) { // the next pixel's candidate is this pixel's solution
+            const int64_t p = (int64_t)i * o.Ws + j;
+            p0 = st.sol[p * o.nd];
+            p1 = o.nd == 2 ? st.sol[p * o.nd + 1] : 0;
+        }
+    }
+    if (n && threadIdx.x == 0) atomicAdd(changes, n);
+}
+
+// column sweep (:412-437): a wave per column
+__global__ void __launch_bounds__(64) pm_cols_kernel(OdVolume o, int inc, PmState st, int *__restrict__ changes) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int j = blockIdx.x;
+    int n = 0;
+    const int ifirst = inc > 0 ? 0 : o.Hs - 1;
+    int64_t pp = (int64_t)ifirst * o.Ws + j;
+    int p0 = st.sol[pp * o.nd], p1 = o.nd == 2 ? st.sol[pp * o.nd + 1] : 0;
+    for (int i = ifirst + inc; inc > 0 ? i < o.Hs : i > 0; i += inc) {
+        const int kept = pm_test(o, st, i, j, p0, p1, pm_buf);
+        n += kept;
+        if (!kept) {
+            const int64_t p = (int64_t)i * o.Ws + j;
+            p0 = st.sol[p * o.nd];
+            p1 = o.nd == 2 ? st.sol[p * o.nd + 1] : 0;
+        }
+    }
+    if (n && threadIdx.x == 0) atomicAdd(changes, n);
+}
+
+// patchMatchSearch, :226-363: a wave per pixel
+__global__ void __launch_bounds__(64) pm_search_kernel(OdVolume o, uint64_t seed, uint32_t iter, int n_random, PmState st, int *__restrict__ changes) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int64_t npx = (int64_t)o.Hs * o.Ws;
+    int total = 0;
+    for (int64_t p = blockIdx.x; p < npx; p += gridDim.x) {
+        const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+        const int base_i = o.nd == 2 ? st.sol[p * o.nd] : 0, base_j = o.nd == 2 ? st.sol[p * o.nd + 1] : st.sol[p * o.nd];
+        int n_chang = 0;
+        for (int k = 0; k < n_random; k++) {
+            int disp_i = 0, disp_j;
+            if (o.nd == 1) {
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+            } else {
+                disp_i = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 1), o.lower[1], o.upper[1]);
+            }
+            int delta_i = disp_i - base_i, delta_j = disp_j - base_j; // :320-331: exploration shrunk towards the current solution
+            delta_j *= k + 1;
+            delta_j /= n_random + 1;
+            if (o.nd == 2) {
+                delta_i *= k + 1;
+                delta_i /= n_random + 1;
+            }
+            disp_i = base_i + delta_i;
+            disp_j = base_j + delta_j;
+            if (o.nd == 1) {
+                if (disp_j == base_j) disp_j = base_j + 1;
+            } else if (disp_i == base_i && disp_j == base_j) {
+                disp_i = base_i + 1;
+                disp_j = base_j + 1;
+            }
+            n_chang = pm_test(o, st, i, j, o.nd == 2 ? disp_i : disp_j, disp_j, pm_buf); // `=`, not `+=` (:345)
+        }
+        total += n_chang;
+    }
+    if (total && threadIdx.x == 0) atomicAdd(changes, total);
+}
+
+struct OdInputs {
+    int func, nd, h_r, v_r, H, Ws, Ht, Wt, C;
+};
+
+int check_params(svh_context *ctx, const svh_on_demand_params *p, const svh_array *src, const svh_array *tgt, OdInputs *in) {
+    if (!p) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
+    SVH_TRY(validate(ctx, src, "img_source", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, tgt, "img_target", SVH_F32, 2, 3));
+    if (!func_supported(p->match_func) || func_census(p->match_func))
+        return fail(ctx, SVH_ERR_UNSUPPORTED, "on-demand volumes take the float matching functions (CC ... ZSAD), not %d", p->match_func);
+    if (p->search_dims != 1 && p->search_dims != 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "search_dims must be 1 (stereo) or 2 (flow)");
+    if (p->h_radius < 0 || p->v_radius < 0 || p->h_radius > 64 || p->v_radius > 64) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad window radius");
+    if (src->ndim != tgt->ndim) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "image ranks differ");
+    const int C = src->ndim == 3 ? (int)src->shape[2] : 1;
+    if (src->ndim == 3 && src->shape[2] != tgt->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "channel counts differ"); // patchmatch.h:583-585
+    if (p->search_dims == 1 && src->shape[0] != tgt->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ"); // :587-591
+    if (p->upper1 < p->lower1 || (p->search_dims == 2 && p->upper0 < p->lower0)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "empty search range");
+    *in = OdInputs{p->match_func, p->search_dims, p->h_radius, p->v_radius, (int)src->shape[0], (int)src->shape[1], (int)tgt->shape[0], (int)tgt->shape[1], C};
+    return SVH_OK;
+}
+
+int dev_on_demand_features(svh_context *ctx, int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out) {
+    const int64_t npx = (int64_t)H * W;
+    if (npx == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_kernel, grid_for(npx, 256, 16384), 256, 0, img, H, W, C, h_r, v_r, func_zero_mean(func),
+               func_normalized(func), out);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int make_volume(svh_context *ctx, Scratch &scr, const svh_on_demand_params *p, const OdInputs &in, const float *d_src, const float *d_tgt, OdVolume *o) {
+    const int nF = (2 * in.v_r + 1) * (2 * in.h_r + 1) * in.C;
+    float *fs = scr.get_n<float>((size_t)in.H * in.Ws * nF), *ft = scr.get_n<float>((size_t)in.Ht * in.Wt * nF);
+    if (!fs || !ft) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(dev_on_demand_features(ctx, in.func, d_src, in.H, in.Ws, in.C, in.h_r, in.v_r, fs));
+    SVH_TRY(dev_on_demand_features(ctx, in.func, d_tgt, in.Ht, in.Wt, in.C, in.h_r, in.v_r, ft));
+    o->fs = fs;
+    o->ft = ft;
+    o->func = in.func;
+    o->nd = in.nd;
+    if (in.nd == 2) {
+        o->lower[0] = p->lower0; o->upper[0] = p->upper0; o->lower[1] = p->lower1; o->upper[1] = p->upper1;
+    } else { // stereo: the only search dimension is the column axis
+        o->lower[0] = p->lower1; o->upper[0] = p->upper1; o->lower[1] = 0; o->upper[1] = 0;
+    }
+    o->Hs = in.H; o->Ws = in.Ws; o->Ht = in.Ht; o->Wt = in.Wt; o->nF = nF;
+    o->score = func_strategy(in.func) == SVH_SCORE;
+    return SVH_OK;
+}
+
+} // namespace
+
+} // namespace svh
+
+using namespace svh;
+
+extern "C" int svh_on_demand_features(svh_context *ctx, int match_func, const svh_array *img, int h_radius, int v_radius, svh_array *out) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    SVH_TRY(validate(ctx, img, "img", SVH_F32, 2, 3));
+    SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
+    if (!func_supported(match_func) || func_census(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
+    if (h_radius < 0 || v_radius < 0 || h_radius > 64 || v_radius > 64) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad window radius");
+    const int H = (int)img->shape[0], W = (int)img->shape[1], C = img->ndim == 3 ? (int)img->shape[2] : 1;
+    const int nF = (2 * v_radius + 1) * (2 * h_radius + 1) * C;
+    if (out->shape[0] != H || out->shape[1] != W || out->shape[2] != nF) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "out must have shape (%d,%d,%d)", H, W, nF);
+    Scratch scr(ctx);
+    void *di;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img, &di));
+    SVH_TRY(stage_out(ctx, scr, *out, &os));
+    SVH_TRY(dev_on_demand_features(ctx, match_func, (const float *)di, H, W, C, h_radius, v_radius, (float *)os.dptr));
+    return finish_out(ctx, os);
+}
+
+extern "C" int svh_on_demand_truncated_cost_volume(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source,
+                                                   const svh_array *img_target, const svh_array *disp, int radius, svh_array *tcv) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    OdInputs in;
+    SVH_TRY(check_params(ctx, params, img_source, img_target, &in));
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 3, 3));
+    if (radius < 0 || radius > 64) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad radius");
+    if (disp->shape[0] != in.H || disp->shape[1] != in.Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
+    if (disp->shape[2] != in.nd) return fail(ctx, SVH_EMPTY_RESULT, "disp holds %lld components, the volume searches %d dimensions", (long long)disp->shape[2], in.nd); // :478-480
+    const int T = 2 * radius + 1;
+    SVH_TRY(validate(ctx, tcv, "tcv", SVH_F32, 2 + in.nd, 2 + in.nd));
+    if (tcv->shape[0] != in.H || tcv->shape[1] != in.Ws || tcv->shape[2] != T || (in.nd == 2 && tcv->shape[3] != T))
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "tcv must have shape (H, W, %d%s)", T, in.nd == 2 ? ", same" : "");
+    Scratch scr(ctx);
+    void *ds, *dt, *dd;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img_source, &ds));
+    SVH_TRY(stage_in(ctx, scr, *img_target, &dt));
+    SVH_TRY(stage_in(ctx, scr, *disp, &dd));
+    SVH_TRY(stage_out(ctx, scr, *tcv, &os));
+    OdVolume o;
+    SVH_TRY(make_volume(ctx, scr, params, in, (const float *)ds, (const float *)dt, &o));
+    const int64_t n = (int64_t)in.H * in.Ws * (in.nd == 2 ? T * T : T);
+    if (n) {
+        // defaultCvValForMatchFunc, matching_costs.h:706-713: max() for costs, min() (the smallest positive normal) for scores
+        SVH_LAUNCH(ctx, "on_demand_truncated", od_truncated_kernel, grid_for(n, 256, 16384), 256, 0, o, (const int32_t *)dd, radius, o.score ? FLT_MIN : FLT_MAX,
+                   (float *)os.dptr);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    return finish_out(ctx, os);
+}
+
+extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
+                                         int n_iter, int n_random_search, uint64_t seed, svh_array *disp, int32_t *iterations_run) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    OdInputs in;
+    SVH_TRY(check_params(ctx, params, img_source, img_target, &in));
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 3, 3));
+    if (n_iter < 0 || n_random_search < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "iteration counts must be non-negative");
+    if (disp->shape[0] != in.H || disp->shape[1] != in.Ws || disp->shape[2] != in.nd)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
+    Scratch scr(ctx);
+    void *ds, *dt;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img_source, &ds));
+    SVH_TRY(stage_in(ctx, scr, *img_target, &dt));
+    SVH_TRY(stage_out(ctx, scr, *disp, &os));
+    int32_t *sol = (int32_t *)os.dptr;
+    int it = 0;
+    const int64_t npx = (int64_t)in.H * in.Ws;
+    if (npx > 0) {
+        OdVolume o;
+        SVH_TRY(make_volume(ctx, scr, params, in, (const float *)ds, (const float *)dt, &o));
+        int *changes = scr.get_n<int>(1);
+        PmState st{sol, scr.get_n<float>((size_t)npx), scr.get_n<uint8_t>((size_t)npx)};
+        if (!changes || !st.cost || !st.valid) return SVH_ERR_OUT_OF_MEMORY;
+        const size_t shmem = (size_t)((o.nF + 3) & ~3) * sizeof(float);
+        const int px_grid = (int)std::min<int64_t>(npx, 256 * 64); // a wave per pixel, grid-stride
+        SVH_LAUNCH(ctx, "patchmatch_init", pm_init_kernel, px_grid, 64, shmem, o, seed, st);
+        for (; it < n_iter; it++) {
+            SVH_HIP_CHECK(ctx, hipMemsetAsync(changes, 0, sizeof(int), ctx->stream));
+            const int inc0 = (it % 4) < 2 ? 1 : -1, inc1 = (it % 2) == 0 ? 1 : -1; // propagation_direction.h:64-86, patchmatch.h:462-479
+            SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
+            SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);
+            SVH_LAUNCH(ctx, "patchmatch_search", pm_search_kernel, px_grid, 64, shmem, o, seed, (uint32_t)it, n_random_search, st, changes);
+            SVH_CHECK_LAUNCH(ctx);
+            int h_changes = 0;
+            SVH_HIP_CHECK(ctx, hipMemcpyAsync(&h_changes, changes, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (h_changes == 0) { // patchmatch.h:486-488
+                it++;
+                break;
+            }
+        }
+    }
+    if (iterations_run) *iterations_run = it;
+    return finish_out(ctx, os);
+}

@@ -429,3 +429,48 @@ def sgm_textbook(cv, n_dir, strategy, P1, P2, margins=(0, 0, 0, 0), Pout=100.0):
     if rc:
         raise ValueError("unsupported number of directions")
     return out
+
+
+# ---- on-demand (cacheless) cost volumes and PatchMatch (what examples/stereo-match runs) -----
+def on_demand_features(func, img, h_r, v_r):
+    x = _img3(img)
+    H, W, Cc = x.shape
+    out = np.empty((H, W, (2 * h_r + 1) * (2 * v_r + 1) * Cc), np.float32)
+    lib().so_on_demand_features(int(func), _p(x), H, W, Cc, int(h_r), int(v_r), _p(out))
+    return out
+
+
+def _od_range(search_dims, search_range):
+    """search_range: (lower, upper) for stereo, ((lower0, upper0), (lower1, upper1)) for flow -> C array lower0, upper0, lower1, upper1"""
+    if search_dims == 1:
+        return (C.c_int * 4)(0, 0, int(search_range[0]), int(search_range[1]))
+    return (C.c_int * 4)(int(search_range[0][0]), int(search_range[0][1]), int(search_range[1][0]), int(search_range[1][1]))
+
+
+def on_demand_truncated_cv(func, img_s, img_t, h_r, v_r, search_range, disp, radius=1):
+    s, t = _img3(img_s), _img3(img_t)
+    disp = _i32(disp)
+    nd = disp.shape[2]
+    T = 2 * radius + 1
+    out = np.empty(s.shape[:2] + (T,) * nd, np.float32)
+    rc = lib().so_on_demand_truncated_cv(int(func), nd, _p(s), s.shape[0], s.shape[1], _p(t), t.shape[0], t.shape[1], s.shape[2], int(h_r), int(v_r),
+                                         _od_range(nd, search_range), _p(disp), int(radius), _p(out))
+    if rc:
+        raise ValueError("unsupported on-demand configuration")
+    return out
+
+
+def pm_random(seed, it, i, j, k, dim):
+    lib().so_pm_random.restype = C.c_int32
+    return int(lib().so_pm_random(C.c_uint64(seed), C.c_uint32(it & 0xFFFFFFFF), C.c_uint32(i), C.c_uint32(j), C.c_uint32(k), C.c_uint32(dim)))
+
+
+def cacheless_patch_match(func, search_dims, img_s, img_t, h_r, v_r, search_range, n_iter=5, n_random=4, seed=0):
+    s, t = _img3(img_s), _img3(img_t)
+    sol = np.empty(s.shape[:2] + (search_dims,), np.int32)
+    its = C.c_int(0)
+    rc = lib().so_cacheless_patch_match(int(func), int(search_dims), _p(s), s.shape[0], s.shape[1], _p(t), t.shape[0], t.shape[1], s.shape[2], int(h_r),
+                                        int(v_r), _od_range(search_dims, search_range), int(n_iter), int(n_random), C.c_uint64(seed), _p(sol), C.byref(its))
+    if rc:
+        return np.empty((0, 0, 0), np.int32), 0
+    return sol, its.value

@@ -22,6 +22,7 @@
  *   cost volumes [H][W][D]  index / disparity maps [H][W]
  * Each function cites the reference file:line it restates (paths relative to the LibStevi tree).
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1403,5 +1404,228 @@ int so_sgm_textbook(int n_dir, int strategy, const float *cv, int H, int W, int 
             free(buf);
         }
     }
+    return 0;
+}
+
+/* ===== on-demand (cacheless) cost volumes and PatchMatch: SURVEY.md section 8(f) rank 1, what examples/stereo-match runs ==========
+ *
+ * Features: OnDemandDecoratedFeaturesVolume<ZNFeaturesVolumeDecorator<ZeroMean, Normalized>, float, 3, ..., 2>
+ * (correlation/on_demand_features_volume.h:34-214) over the window list examples/stereo-match/main.cpp:150-164 builds: offsets
+ * (di, dj) in [-r, r]^2 row-major, channels innermost.  Samples outside the image are CLAMPED to the border (:128-133), not
+ * zero; the decorator divides by the feature count: mean = (sum v) / nF, v -= mean, norm = sqrt((sum v^2) / nF), v /= norm
+ * (:168-214).  So these are not the features of the dense path (zero padding, sqrt of the plain sum).
+ * Cost: CachelessOnDemandCostVolume::costValue (correlation/on_demand_cost_volume.h:409-468): no value when a disparity is
+ * outside the search range or the target position is outside the target image, else featureComparison of the two vectors. */
+typedef struct {
+    int func, search_dims, h_r, v_r, lower[2], upper[2];
+    int Hs, Ws, Ht, Wt, C, nF;
+    const float *fs, *ft; /* decorated feature volumes [H][W][nF] */
+} od_volume;
+
+static void on_demand_features(int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out) {
+    const int nF = (2 * v_r + 1) * (2 * h_r + 1) * C;
+    const int zm = func_zero_mean(func), nrm = func_normalized(func);
+#pragma omp parallel for
+    for (int i = 0; i < H; i++)
+        for (int j = 0; j < W; j++) {
+            float *v = out + ((size_t)i * W + j) * nF;
+            int f = 0;
+            for (int di = -v_r; di <= v_r; di++)
+                for (int dj = -h_r; dj <= h_r; dj++)
+                    for (int c = 0; c < C; c++) {
+                        int ii = i + di, jj = j + dj; /* constant border condition, :128-133 */
+                        ii = ii < 0 ? 0 : (ii > H - 1 ? H - 1 : ii);
+                        jj = jj < 0 ? 0 : (jj > W - 1 ? W - 1 : jj);
+                        v[f++] = img[((size_t)ii * W + jj) * C + c];
+                    }
+            if (zm) { /* :183-192 */
+                float mean = 0;
+                for (int k = 0; k < nF; k++) mean += v[k];
+                mean /= nF;
+                for (int k = 0; k < nF; k++) v[k] -= mean;
+            }
+            if (nrm) { /* :194-207 */
+                float norm = 0;
+                for (int k = 0; k < nF; k++) norm += v[k] * v[k];
+                norm /= nF;
+                norm = sqrtf(norm);
+                for (int k = 0; k < nF; k++) v[k] /= norm;
+            }
+        }
+}
+
+/* costValue, on_demand_cost_volume.h:409-468; returns 0 when there is no value.  disp[0] = rows, disp[1] = columns for the flow
+ * volume; disp[0] = columns for the stereo volume. */
+static int od_cost(const od_volume *o, int i, int j, const int *disp, float *cost) {
+    int ti = i, tj = j;
+    if (i < 0 || i >= o->Hs || j < 0 || j >= o->Ws) return 0;
+    for (int s = 0; s < o->search_dims; s++) {
+        if (disp[s] < o->lower[s] || disp[s] > o->upper[s]) return 0;
+    }
+    if (o->search_dims == 2) { ti += disp[0]; tj += disp[1]; } else tj += disp[0];
+    if (ti < 0 || ti >= o->Ht || tj < 0 || tj >= o->Wt) return 0;
+    *cost = cmp_float(o->func, o->fs + ((size_t)i * o->Ws + j) * o->nF, o->ft + ((size_t)ti * o->Wt + tj) * o->nF, o->nF);
+    return 1;
+}
+
+static int od_setup(od_volume *o, int func, int search_dims, const float *img_s, int Hs, int Ws, const float *img_t, int Ht, int Wt, int C, int h_r,
+                    int v_r, const int *range /* lower0, upper0, lower1, upper1 */) {
+    if (!so_func_supported(func) || func_census(func) || (search_dims != 1 && search_dims != 2)) return 1;
+    if (search_dims == 1 && Hs != Ht) return 1; /* patchmatch.h:587-591 */
+    o->func = func; o->search_dims = search_dims; o->h_r = h_r; o->v_r = v_r;
+    o->lower[0] = range[0]; o->upper[0] = range[1]; o->lower[1] = range[2]; o->upper[1] = range[3];
+    o->Hs = Hs; o->Ws = Ws; o->Ht = Ht; o->Wt = Wt; o->C = C; o->nF = (2 * v_r + 1) * (2 * h_r + 1) * C;
+    float *fs = (float *)malloc((size_t)Hs * Ws * o->nF * sizeof(float)), *ft = (float *)malloc((size_t)Ht * Wt * o->nF * sizeof(float));
+    if (!fs || !ft) { free(fs); free(ft); return 2; }
+    on_demand_features(func, img_s, Hs, Ws, C, h_r, v_r, fs);
+    on_demand_features(func, img_t, Ht, Wt, C, h_r, v_r, ft);
+    o->fs = fs; o->ft = ft;
+    return 0;
+}
+static void od_free(od_volume *o) { free((void *)o->fs); free((void *)o->ft); }
+
+/* the decorated features themselves, for the tests */
+void so_on_demand_features(int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out) { on_demand_features(func, img, H, W, C, h_r, v_r, out); }
+
+/* CachelessOnDemandCostVolume::truncatedCostVolume(disp, radius, defaultVal), on_demand_cost_volume.h:474-596, AS WRITTEN: the
+ * value handed to costValue as a disparity is `tap - radius + disp2idx(disparity)`, an INDEX (:513-514, :285-286), so the window
+ * is centred on disparity - lowerOffset, which is the disparity only when the range starts at 0.  Entries without a value hold
+ * defaultCvValForMatchFunc (matching_costs.h:706-713): FLT_MAX for costs, numeric_limits<float>::min() = FLT_MIN for scores.
+ * range = {lower0, upper0, lower1, upper1}; for search_dims == 1 only lower1 / upper1 (columns) are used.
+ * disp [H][W][search_dims] -> tcv [H][W][(2 radius + 1)^search_dims]. */
+int so_on_demand_truncated_cv(int func, int search_dims, const float *img_s, int Hs, int Ws, const float *img_t, int Ht, int Wt, int C, int h_r,
+                              int v_r, const int *range, const int32_t *disp, int radius, float *tcv) {
+    od_volume o;
+    int r2[4] = {range[0], range[1], range[2], range[3]};
+    if (search_dims == 1) { r2[0] = range[2]; r2[1] = range[3]; }
+    int rc = od_setup(&o, func, search_dims, img_s, Hs, Ws, img_t, Ht, Wt, C, h_r, v_r, r2);
+    if (rc) return rc;
+    const int T = 2 * radius + 1;
+    const float def = so_func_strategy(func) == SO_COST ? FLT_MAX : FLT_MIN;
+#pragma omp parallel for
+    for (int i = 0; i < Hs; i++)
+        for (int j = 0; j < Ws; j++) {
+            const int32_t *d = disp + ((size_t)i * Ws + j) * search_dims;
+            if (search_dims == 2) {
+                for (int a = 0; a < T; a++)
+                    for (int b = 0; b < T; b++) {
+                        int arg[2] = {a - radius + (d[0] - o.lower[0]), b - radius + (d[1] - o.lower[1])};
+                        float c;
+                        tcv[(((size_t)i * Ws + j) * T + a) * T + b] = od_cost(&o, i, j, arg, &c) ? c : def;
+                    }
+            } else {
+                for (int a = 0; a < T; a++) {
+                    int arg[1] = {a - radius + (d[0] - o.lower[0])};
+                    float c;
+                    tcv[((size_t)i * Ws + j) * T + a] = od_cost(&o, i, j, arg, &c) ? c : def;
+                }
+            }
+        }
+    od_free(&o);
+    return 0;
+}
+
+/* ---- cachelessPatchMatch, correlation/patchmatch.h:61-160 (init), :162-224 (test), :226-363 (search), :365-445 (propagate),
+ * :447-493 (iterations), :560-621 (entry).  The reference seeds one std::default_random_engine per OpenMP thread from
+ * std::random_device (:76-92, :243-258), so its output is not reproducible even by itself; here every draw is a pure function
+ * of (seed, iteration, pixel, draw index, dimension) -- a counter-based stream in the role of the reference's NumbersCache
+ * branch, mapped into the range exactly as that branch does: setValueInRange(v) = |v % range| + lower (correlation_base.h:377-384).
+ * Everything else follows the reference statement by statement, including the std::optional comparisons of :203-211:
+ * a candidate without a value is dropped; with a score function a candidate beats a current solution that has no value
+ * (`v >= nullopt` is true), with a cost function it never does (`v <= nullopt` is false). */
+static inline int32_t pm_random(uint64_t seed, uint32_t iter, uint32_t i, uint32_t j, uint32_t k, uint32_t dim) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (((uint64_t)iter << 40) ^ ((uint64_t)i << 20) ^ (uint64_t)j ^ ((uint64_t)k << 56) ^ ((uint64_t)dim << 60) ^ 0x632BE59BD9B4E019ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; /* splitmix64 finaliser */
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (int32_t)(uint32_t)(z >> 32);
+}
+int32_t so_pm_random(uint64_t seed, uint32_t iter, uint32_t i, uint32_t j, uint32_t k, uint32_t dim) { return pm_random(seed, iter, i, j, k, dim); }
+static inline int32_t pm_in_range(int32_t v, int lower, int upper) {
+    int range = upper - lower + 1;
+    int m = v % range;
+    return (m < 0 ? -m : m) + lower;
+}
+
+static int pm_test(const od_volume *o, int32_t *sol, int i, int j, const int *cand) { /* patchMatchTestCost, :162-224 */
+    const int nd = o->search_dims;
+    int32_t *cur = sol + ((size_t)i * o->Ws + j) * nd;
+    int dc[2] = {cand[0], nd == 2 ? cand[1] : 0}, da[2] = {cur[0], nd == 2 ? cur[1] : 0};
+    float c_new, c_old;
+    if (!od_cost(o, i, j, dc, &c_new)) return 0;
+    int has_old = od_cost(o, i, j, da, &c_old);
+    int keep;
+    if (so_func_strategy(o->func) == SO_SCORE) keep = has_old ? (c_new >= c_old) : 1;
+    else keep = has_old ? (c_new <= c_old) : 0;
+    if (keep) { cur[0] = cand[0]; if (nd == 2) cur[1] = cand[1]; }
+    return keep;
+}
+
+int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int Hs, int Ws, const float *img_t, int Ht, int Wt, int C, int h_r,
+                             int v_r, const int *range, int n_iter, int n_random, uint64_t seed, int32_t *sol, int *iterations_run) {
+    od_volume o;
+    int r2[4] = {range[0], range[1], range[2], range[3]};
+    if (search_dims == 1) { r2[0] = range[2]; r2[1] = range[3]; }
+    int rc = od_setup(&o, func, search_dims, img_s, Hs, Ws, img_t, Ht, Wt, C, h_r, v_r, r2);
+    if (rc) return rc;
+    const int nd = search_dims;
+    for (int i = 0; i < Hs; i++) /* randomDispInit, the NumbersCache branch with a search offset: :110-118 */
+        for (int j = 0; j < Ws; j++)
+            for (int s = 0; s < nd; s++) sol[((size_t)i * Ws + j) * nd + s] = pm_in_range(pm_random(seed, 0xFFFFFFFFu, i, j, 0, s), o.lower[s], o.upper[s]);
+    int it = 0;
+    for (; it < n_iter; it++) {
+        long changes = 0;
+        const int inc0 = (it % 4) < 2 ? 1 : -1, inc1 = (it % 2) == 0 ? 1 : -1; /* propagation_direction.h:64-86, patchmatch.h:462-479 */
+        /* line scans, :387-410: rows are independent, a row is sequential */
+#pragma omp parallel for reduction(+ : changes)
+        for (int i = 0; i < Hs; i++)
+            for (int j = inc1 > 0 ? 0 : Ws - 1; inc1 > 0 ? j < Ws : j > 0; j += inc1) { /* `j != final` with final = Ws or 0: the last column is skipped going left */
+                int pj = j - inc1;
+                if (pj < 0 || pj >= Ws) continue;
+                const int32_t *pv = sol + ((size_t)i * Ws + pj) * nd;
+                int cand[2] = {pv[0], nd == 2 ? pv[1] : 0};
+                changes += pm_test(&o, sol, i, j, cand);
+            }
+        /* column scans, :412-437 */
+#pragma omp parallel for reduction(+ : changes)
+        for (int j = 0; j < Ws; j++)
+            for (int i = inc0 > 0 ? 0 : Hs - 1; inc0 > 0 ? i < Hs : i > 0; i += inc0) {
+                int pi = i - inc0;
+                if (pi < 0 || pi >= Hs) continue;
+                const int32_t *pv = sol + ((size_t)pi * Ws + j) * nd;
+                int cand[2] = {pv[0], nd == 2 ? pv[1] : 0};
+                changes += pm_test(&o, sol, i, j, cand);
+            }
+        /* random search, :226-363 */
+#pragma omp parallel for reduction(+ : changes)
+        for (int i = 0; i < Hs; i++)
+            for (int j = 0; j < Ws; j++) {
+                const int32_t *cur = sol + ((size_t)i * Ws + j) * nd;
+                const int base_i = nd == 2 ? cur[0] : 0, base_j = nd == 2 ? cur[1] : cur[0];
+                int n_chang = 0;
+                for (int k = 0; k < n_random; k++) {
+                    int disp_i = 0, disp_j;
+                    if (nd == 1) disp_j = pm_in_range(pm_random(seed, it, i, j, k, 0), o.lower[0], o.upper[0]);
+                    else {
+                        disp_i = pm_in_range(pm_random(seed, it, i, j, k, 0), o.lower[0], o.upper[0]);
+                        disp_j = pm_in_range(pm_random(seed, it, i, j, k, 1), o.lower[1], o.upper[1]);
+                    }
+                    int delta_i = disp_i - base_i, delta_j = disp_j - base_j; /* :320-331: exploration shrunk towards the solution */
+                    delta_j *= k + 1;
+                    delta_j /= n_random + 1;
+                    if (nd == 2) { delta_i *= k + 1; delta_i /= n_random + 1; }
+                    disp_i = base_i + delta_i;
+                    disp_j = base_j + delta_j;
+                    if (nd == 1) { if (disp_j == base_j) disp_j = base_j + 1; }
+                    else if (disp_i == base_i && disp_j == base_j) { disp_i = base_i + 1; disp_j = base_j + 1; }
+                    int cand[2] = {nd == 2 ? disp_i : disp_j, disp_j};
+                    n_chang = pm_test(&o, sol, i, j, cand); /* `=`, not `+=` (:345): only the last draw's outcome is counted */
+                }
+                changes += n_chang;
+            }
+        if (changes == 0) { it++; break; } /* :486-488 */
+    }
+    if (iterations_run) *iterations_run = it;
+    od_free(&o);
     return 0;
 }

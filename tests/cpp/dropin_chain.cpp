@@ -9,6 +9,7 @@
 #include <correlation/cost_based_refinement.h>
 #include <correlation/cross_correlations.h>
 #include <correlation/hierarchical.h>
+#include <correlation/patchmatch.h>
 #include <correlation/sgm.h>
 
 namespace SC = StereoVision::Correlation;
@@ -114,6 +115,42 @@ int main(int argc, char **argv) {
         Multidim::Array<float, 3> CVc = SC::unfoldBasedCostVolume<SC::matchingFunctions::ZNCC>(target, source, compressor, D);
         if (CVc.shape()[0] != H || CVc.shape()[1] != W || CVc.shape()[2] != D) return 9;
         dump(out + "_compressed_cv.f32", CVc.data(), CVc.flatLenght());
+    }
+    { // examples/stereo-match/main.cpp:140-210 with its own types: on-demand ZN features, cachelessPatchMatch, --refine chain
+        using namespace StereoVision::Correlation;
+        Multidim::Array<float, 3> img_source(H, W, 1), img_target(H, W, 1);
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++) {
+                img_source.atUnchecked(i, j, 0) = source.valueUnchecked(i, j);
+                img_target.atUnchecked(i, j, 0) = target.valueUnchecked(i, j);
+            }
+        const int searchWindowRadius = 2, nChannels = 1;
+        std::vector<std::array<int, 3>> featuresWindow;
+        for (int i = -searchWindowRadius; i <= searchWindowRadius; i++)
+            for (int j = -searchWindowRadius; j <= searchWindowRadius; j++)
+                for (int c = 0; c < nChannels; c++) featuresWindow.push_back({i, j, c});
+        constexpr matchingFunctions matchFunc = matchingFunctions::ZNCC;
+        constexpr bool ZeroMean = MatchingFunctionTraits<matchFunc>::ZeroMean;
+        constexpr bool Normalized = MatchingFunctionTraits<matchFunc>::Normalized;
+        constexpr Multidim::ArrayDataAccessConstness constness = Multidim::ArrayDataAccessConstness::NonConstView;
+        using OnDemandFeaturesT = OnDemandDecoratedFeaturesVolume<ZNFeaturesVolumeDecorator<ZeroMean, Normalized>, float, 3, constness, 2>;
+        static_assert(OnDemandFeaturesT::nOutDim == 2);
+        searchOffset<2> searchRegion(-2, 2, 0, 12);
+        OnDemandFeaturesT features_source(featuresWindow, img_source);
+        OnDemandFeaturesT features_target(featuresWindow, img_target);
+        HipBridge::patchMatchSeed() = 99; // reproducible run for the checker
+        Multidim::Array<disp_t, 3> pm = cachelessPatchMatch<matchFunc, 2>(features_source, features_target, searchRegion, 6, 4, std::nullopt);
+        if (pm.shape()[0] != H || pm.shape()[1] != W || pm.shape()[2] != 2) return 10;
+        using CostVolT = CachelessOnDemandImageFlowVolume<matchFunc, float, OnDemandFeaturesT, OnDemandFeaturesT>;
+        using SearchSpaceT = typename CostVolT::SearchSpaceType;
+        SearchSpaceT searchSpace(SearchSpaceBase::SearchDim(searchRegion.template lowerOffset<0>(), searchRegion.template upperOffset<0>()),
+                                 SearchSpaceBase::SearchDim(searchRegion.template lowerOffset<1>(), searchRegion.template upperOffset<1>()),
+                                 SearchSpaceBase::FeatureDim());
+        CostVolT onDemandCV(features_source, features_target, searchSpace);
+        Multidim::Array<float, 3> refinedDisp = refineDisp2dCostInterpolation<InterpolationKernel::Equiangular>(onDemandCV.truncatedCostVolume(pm), pm);
+        if (refinedDisp.shape()[2] != 2) return 11;
+        dump(out + "_pm_disp.i32", pm.data(), pm.flatLenght());
+        dump(out + "_pm_refined.f32", refinedDisp.data(), refinedDisp.flatLenght());
     }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);

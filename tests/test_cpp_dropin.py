@@ -73,6 +73,13 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     ccv = so.feature_cost_volume(so.ZNCC, so.unfold_compressed(tgt, mask), so.unfold_compressed(src, mask), D)
     got_c = np.fromfile(tmp_path / "o_compressed_cv.f32", np.float32).reshape(H, W, D)
     assert np.array_equal(np.isnan(got_c), np.isnan(ccv)) and np.nanmax(np.abs(got_c - ccv)) <= 1e-4
+    pm, _ = so.cacheless_patch_match(so.ZNCC, 2, src[:, :, None], tgt[:, :, None], 2, 2, ((-2, 2), (0, 12)), 6, 4, seed=99)
+    got_pm = np.fromfile(tmp_path / "o_pm_disp.i32", np.int32).reshape(H, W, 2)
+    assert np.array_equal(got_pm, pm)
+    pm_tcv = so.on_demand_truncated_cv(so.ZNCC, src[:, :, None], tgt[:, :, None], 2, 2, ((-2, 2), (0, 12)), pm, 1)
+    pm_ref = so.refine_disp_2d(pm_tcv, pm, so.EQUIANGULAR, so.ISOTROPIC)
+    bad, flipped = refined_2d_mismatch(np.fromfile(tmp_path / "o_pm_refined.f32", np.float32).reshape(H, W, 2), pm_ref, pm)
+    assert bad == 0.0 and flipped <= 0.01
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

@@ -1,0 +1,115 @@
+"""On-demand (cacheless) cost volumes and PatchMatch (what examples/stereo-match runs) on the GPU.
+The reference's PatchMatch is not reproducible (random_device seeds per thread); with the counter-based stream both sides
+use, the device result is bit-identical to the oracle's statement-by-statement restatement."""
+import numpy as np
+import pytest
+
+import oracle as so
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import libstevi_amd as sv  # noqa: E402
+from libstevi_amd import matchingFunctions as MF  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(x):
+    return x.cpu().numpy() if hasattr(x, "cpu") else x
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def shifted_pair(rng, H, W, C, dv, dh):
+    """source(i, j) == target(i + dv, j + dh): a pure translation, smooth enough for window matching to be informative"""
+    base = rng.uniform(0, 1, (H + 24, W + 24, C)).astype(np.float32)
+    base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(base, (1, 1), (0, 1))) / np.float32(4)
+    src = base[12:12 + H, 12:12 + W].copy()
+    tgt = base[12 - dv:12 - dv + H, 12 - dh:12 - dh + W].copy()
+    return np.ascontiguousarray(src), np.ascontiguousarray(tgt)
+
+
+@pytest.mark.parametrize("func", [MF.CC, MF.NCC, MF.SSD, MF.SAD, MF.ZCC, MF.ZNCC, MF.ZSSD, MF.ZSAD])
+def test_on_demand_features_bit_exact(rng, func):
+    for shape, r in (((9, 13, 3), 2), ((7, 8), (1, 3)), ((5, 5, 1), 0)):
+        img = rng.uniform(-1, 1, shape).astype(np.float32)
+        hr, vr = (r, r) if np.isscalar(r) else r
+        exp = so.on_demand_features(int(func), img, hr, vr)
+        for mk in (lambda x: x, dev):
+            got = host(sv.onDemandFeatures(func, mk(img), r))
+            assert got.shape == exp.shape and np.array_equal(bits(got), bits(exp))
+    # not the dense path's features: clamped borders and the RMS norm (on_demand_features_volume.h:128-133, :194-207)
+    img = rng.uniform(-1, 1, (6, 6)).astype(np.float32)
+    dense = so.feature_volume_for_match_func(int(func), so.unfold(img, 1, 1))
+    assert not np.allclose(host(sv.onDemandFeatures(func, img, 1)), dense)
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SAD, MF.NCC])
+def test_on_demand_truncated_volume_matches_oracle(rng, func):
+    src, tgt = shifted_pair(rng, 21, 27, 2, 1, -2)
+    for rng2, nd in ((((0, 5), (0, 6)), 2), (((-3, 3), (-4, 2)), 2), ((-5, 5), 1), ((0, 7), 1)):
+        off = sv.searchOffset2(rng2[0][0], rng2[0][1], rng2[1][0], rng2[1][1]) if nd == 2 else sv.searchOffset1(*rng2)
+        lo = np.array([rng2[0][0], rng2[1][0]] if nd == 2 else [rng2[0]])
+        hi = np.array([rng2[0][1], rng2[1][1]] if nd == 2 else [rng2[1]])
+        disp = rng.integers(lo, hi + 1, (21, 27, nd)).astype(np.int32)
+        for radius in (1, 2):
+            exp = so.on_demand_truncated_cv(int(func), src, tgt, 2, 2, rng2, disp, radius)
+            for mk in (lambda x: x, dev):
+                got = host(sv.onDemandTruncatedCostVolume(func, mk(src), mk(tgt), 2, off, mk(disp), radius))
+                assert got.shape == exp.shape and np.array_equal(bits(got), bits(exp))
+    # with a range starting at 0 the centre tap is the cost at the given disparity; entries without a value hold FLT_MAX / FLT_MIN
+    disp = np.zeros((21, 27, 1), np.int32)
+    tcv = host(sv.onDemandTruncatedCostVolume(func, src, tgt, 2, sv.searchOffset1(0, 7), disp, 1))
+    default = np.float32(np.finfo(np.float32).max if so.func_strategy(int(func)) == so.COST else np.finfo(np.float32).tiny)
+    assert np.all(tcv[:, :, 0] == default)  # disparity -1 is outside the range
+    fs, ft = so.on_demand_features(int(func), src, 2, 2), so.on_demand_features(int(func), tgt, 2, 2)
+    i, j = 10, 11
+    direct = {MF.ZNCC: float(fs[i, j].astype(np.float64) @ ft[i, j]), MF.NCC: float(fs[i, j].astype(np.float64) @ ft[i, j]),
+              MF.SAD: float(np.abs(fs[i, j].astype(np.float64) - ft[i, j]).sum())}[func]
+    assert abs(tcv[i, j, 1] - direct) < 1e-4
+    assert sv.onDemandTruncatedCostVolume(func, src, tgt, 2, sv.searchOffset1(0, 7), np.zeros((21, 27, 2), np.int32), 1).size == 0  # :478-480
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.ZSAD, MF.SSD])
+@pytest.mark.parametrize("nd", [1, 2])
+def test_patch_match_bit_identical_to_oracle(rng, func, nd):
+    src, tgt = shifted_pair(rng, 30, 41, 3, 0 if nd == 1 else 2, -3)
+    search = ((-4, 4), (-5, 5)) if nd == 2 else (-5, 5)
+    off = sv.searchOffset2(-4, 4, -5, 5) if nd == 2 else sv.searchOffset1(-5, 5)
+    for seed, n_iter, n_random in ((1, 6, 4), (987654321, 3, 2), (7, 1, 0)):
+        exp, its = so.cacheless_patch_match(int(func), nd, src, tgt, 2, 2, search, n_iter, n_random, seed)
+        for mk in (lambda x: x, dev):
+            got, gits = sv.cachelessPatchMatch(func, mk(src), mk(tgt), 2, off, n_iter, n_random, seed, return_iterations=True)
+            assert np.array_equal(host(got), exp) and gits == its
+
+
+def test_patch_match_recovers_a_planted_flow(rng):
+    """the acceptance the reference's own benchmark applies to PatchMatch (benchmarkStereoMatchingModels.cpp: proportion of correct
+    pixels) on a synthetic translation: ZNCC 5x5 windows, 13 x 13 offsets, 10 iterations as examples/stereo-match defaults"""
+    src, tgt = shifted_pair(rng, 96, 128, 3, -2, 3)
+    disp = host(sv.cachelessPatchMatch(MF.ZNCC, dev(src), dev(tgt), 2, sv.searchOffset2(-6, 6, -6, 6), 10, 4, seed=2024))
+    inner = disp[8:-8, 8:-8]
+    assert np.mean((inner[..., 0] == -2) & (inner[..., 1] == 3)) > 0.97
+    # the --refine chain of examples/stereo-match (main.cpp:198-210): truncated on-demand volume + equiangular 2-D refinement
+    tcv = sv.onDemandTruncatedCostVolume(MF.ZNCC, dev(src), dev(tgt), 2, sv.searchOffset2(-6, 6, -6, 6), dev(disp), 1)
+    refined = host(sv.refineDisp2dCostInterpolation(sv.InterpolationKernel.Equiangular, tcv, dev(disp)))
+    assert refined.shape == disp.shape and np.isfinite(refined).all()
+
+
+def test_patch_match_argument_rules(rng):
+    a = rng.uniform(0, 1, (8, 9, 3)).astype(np.float32)
+    assert sv.cachelessPatchMatch(MF.ZNCC, a, a[:, :, :2].copy(), 1, sv.searchOffset2(-1, 1, -1, 1)).size == 0  # channel mismatch, patchmatch.h:583-585
+    assert sv.cachelessPatchMatch(MF.ZNCC, a, a[:7].copy(), 1, sv.searchOffset1(-1, 1)).size == 0  # stereo needs equal row counts, :587-591
+    assert sv.cachelessPatchMatch(MF.ZNCC, a, a[:7].copy(), 1, sv.searchOffset2(-1, 1, -1, 1)).shape == (8, 9, 2)  # flow does not
+    with pytest.raises(Exception):
+        sv.cachelessPatchMatch(MF.CENSUS, a, a, 1, sv.searchOffset1(-1, 1))

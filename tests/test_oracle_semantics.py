@@ -485,3 +485,152 @@ def test_textbook_sgm_properties(rng):
     a = so.sgm_textbook(cv, 8, so.COST, 0.5, 2.0, Pout=0.0)
     b = so.sgm_textbook(cv[::-1, ::-1].copy(), 8, so.COST, 0.5, 2.0, Pout=0.0)[::-1, ::-1]
     assert np.allclose(a, b, rtol=1e-5, atol=1e-4)
+
+
+# ---- on-demand cost volumes and PatchMatch: literal Python restatements ------------------
+def py_on_demand_features(func, img, h_r, v_r):
+    """on_demand_features_volume.h:115-214 in plain loops: clamped window gather, then mean = sum / nF, v -= mean,
+    norm = sqrt(sum v^2 / nF), v /= norm, all in float32 in the reference's order"""
+    f = np.float32
+    H, W, C = img.shape
+    zm = func in (so.ZCC, so.ZNCC, so.ZSSD, so.ZSAD)
+    nrm = func in (so.NCC, so.ZNCC)
+    nF = (2 * v_r + 1) * (2 * h_r + 1) * C
+    out = np.empty((H, W, nF), f)
+    for i in range(H):
+        for j in range(W):
+            v = [img[min(H - 1, max(0, i + di)), min(W - 1, max(0, j + dj)), c] for di in range(-v_r, v_r + 1) for dj in range(-h_r, h_r + 1) for c in range(C)]
+            if zm:
+                mean = f(0)
+                for x in v:
+                    mean = f(mean + x)
+                mean = f(mean / f(nF))
+                v = [f(x - mean) for x in v]
+            if nrm:
+                norm = f(0)
+                for x in v:
+                    norm = f(norm + f(x * x))
+                norm = f(np.sqrt(f(norm / f(nF))))
+                v = [f(x / norm) for x in v]
+            out[i, j] = v
+    return out
+
+
+def py_cost(func, fs, ft, i, j, disp, lower, upper):
+    """costValue, on_demand_cost_volume.h:409-468; None when there is no value"""
+    f = np.float32
+    nd = len(disp)
+    if any(d < lo or d > hi for d, lo, hi in zip(disp, lower, upper)):
+        return None
+    ti, tj = (i + disp[0], j + disp[1]) if nd == 2 else (i, j + disp[0])
+    if not (0 <= ti < ft.shape[0] and 0 <= tj < ft.shape[1]):
+        return None
+    acc = f(0)
+    for a, b in zip(fs[i, j], ft[ti, tj]):
+        if func in (so.SSD, so.ZSSD):
+            acc = f(acc + f(f(a - b) * f(a - b)))
+        elif func in (so.SAD, so.ZSAD):
+            acc = f(acc + abs(f(a - b)))
+        else:
+            acc = f(acc + f(a * b))
+    return acc
+
+
+@pytest.mark.parametrize("func", [so.ZNCC, so.NCC, so.ZSAD, so.SSD])
+def test_on_demand_features_and_truncated_volume_literal(rng, func):
+    img = rng.uniform(-1, 1, (5, 6, 2)).astype(np.float32)
+    other = rng.uniform(-1, 1, (5, 6, 2)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        fs, ft = py_on_demand_features(func, img, 1, 2), py_on_demand_features(func, other, 1, 2)
+    assert np.array_equal(so.on_demand_features(func, img, 1, 2).view(np.uint32), fs.view(np.uint32))
+    cost = so.func_strategy(func) == so.COST
+    default = np.float32(np.finfo(np.float32).max if cost else np.finfo(np.float32).tiny)
+    for (lower, upper) in (((0, 0), (2, 3)), ((-1, -2), (1, 2))):
+        disp = np.stack([rng.integers(lower[0], upper[0] + 1, (5, 6)), rng.integers(lower[1], upper[1] + 1, (5, 6))], axis=-1).astype(np.int32)
+        tcv = so.on_demand_truncated_cv(func, img, other, 1, 2, ((lower[0], upper[0]), (lower[1], upper[1])), disp, 1)
+        for i in range(5):
+            for j in range(6):
+                for a in range(3):
+                    for b in range(3):
+                        # as written (:513-514): the argument of costValue is tap - radius + (disparity - lowerOffset)
+                        arg = (a - 1 + disp[i, j, 0] - lower[0], b - 1 + disp[i, j, 1] - lower[1])
+                        c = py_cost(func, fs, ft, i, j, arg, lower, upper)
+                        exp = default if c is None else c
+                        assert tcv[i, j, a, b].view(np.uint32) == np.float32(exp).view(np.uint32)
+
+
+def py_pm_random(seed, it, i, j, k, dim):
+    M = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15 * (((it << 40) ^ (i << 20) ^ j ^ (k << 56) ^ (dim << 60) ^ 0x632BE59BD9B4E019) & M)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z = z ^ (z >> 31)
+    v = z >> 32
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
+def py_in_range(v, lower, upper):
+    rng_ = upper - lower + 1
+    m = abs(v) % rng_  # |v % range| with C's truncating %: the remainder's magnitude is |v| mod range
+    return m + lower
+
+
+def py_patch_match(func, nd, img_s, img_t, h_r, v_r, lower, upper, n_iter, n_random, seed):
+    """patchmatch.h:61-493 in plain loops (see the comment of so_cacheless_patch_match for the random stream)"""
+    with np.errstate(all="ignore"):
+        fs, ft = py_on_demand_features(func, img_s, h_r, v_r), py_on_demand_features(func, img_t, h_r, v_r)
+    H, W = img_s.shape[:2]
+    score = so.func_strategy(func) == so.SCORE
+    sol = [[[py_in_range(py_pm_random(seed, 0xFFFFFFFF, i, j, 0, s), lower[s], upper[s]) for s in range(nd)] for j in range(W)] for i in range(H)]
+
+    def test(i, j, cand):
+        c_new = py_cost(func, fs, ft, i, j, cand, lower, upper)
+        if c_new is None:
+            return 0
+        c_old = py_cost(func, fs, ft, i, j, sol[i][j], lower, upper)
+        keep = (c_old is None or c_new >= c_old) if score else (c_old is not None and c_new <= c_old)
+        if keep:
+            sol[i][j] = list(cand)
+        return int(keep)
+
+    iterations = 0
+    for it in range(n_iter):
+        iterations += 1
+        changes = 0
+        inc0, inc1 = (1 if it % 4 < 2 else -1), (1 if it % 2 == 0 else -1)
+        for i in range(H):
+            for j in (range(0, W) if inc1 > 0 else range(W - 1, 0, -1)):
+                if 0 <= j - inc1 < W:
+                    changes += test(i, j, sol[i][j - inc1])
+        for j in range(W):
+            for i in (range(0, H) if inc0 > 0 else range(H - 1, 0, -1)):
+                if 0 <= i - inc0 < H:
+                    changes += test(i, j, sol[i - inc0][j])
+        for i in range(H):
+            for j in range(W):
+                base = list(sol[i][j])
+                n_chang = 0
+                for k in range(n_random):
+                    draw = [py_in_range(py_pm_random(seed, it, i, j, k, s), lower[s], upper[s]) for s in range(nd)]
+                    delta = [int((draw[s] - base[s]) * (k + 1) / (n_random + 1)) for s in range(nd)]  # C division truncates towards zero
+                    cand = [base[s] + delta[s] for s in range(nd)]
+                    if cand == base:
+                        cand = [b + 1 for b in base]
+                    n_chang = test(i, j, cand)
+                changes += n_chang
+        if changes == 0:
+            break
+    return np.array(sol, np.int32), iterations
+
+
+@pytest.mark.parametrize("func,nd", [(so.ZNCC, 2), (so.SAD, 1), (so.ZSSD, 2)])
+def test_patch_match_oracle_equals_literal_loops(rng, func, nd):
+    src = rng.uniform(0, 1, (7, 9, 2)).astype(np.float32)
+    tgt = np.roll(src, (1, -2), (0, 1)) + rng.uniform(0, 0.01, src.shape).astype(np.float32)
+    lower, upper = ((-2, -3), (2, 3)) if nd == 2 else ((-3,), (3,))
+    search = ((lower[0], upper[0]), (lower[1], upper[1])) if nd == 2 else (lower[0], upper[0])
+    for seed, n_iter, n_random in ((3, 4, 3), (2 ** 40 + 17, 2, 1)):
+        assert so.pm_random(seed, 1, 2, 3, 1, 1) == py_pm_random(seed, 1, 2, 3, 1, 1)
+        got, its = so.cacheless_patch_match(func, nd, src, tgt, 1, 1, search, n_iter, n_random, seed)
+        exp, eits = py_patch_match(func, nd, src, tgt, 1, 1, lower, upper, n_iter, n_random, seed)
+        assert np.array_equal(got, exp) and its == eits

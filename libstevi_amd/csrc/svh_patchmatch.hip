@@ -306,6 +306,188 @@ __global__ void __launch_bounds__(64) pm_search_kernel(OdVolume o, uint64_t seed
     if (total && threadIdx.x == 0) atomicAdd(changes, total);
 }
 
+struct __attribute__((packed, aligned(4))) Feat4 { // four consecutive features; global_load_dwordx4 only needs 4-byte alignment
+    float x, y, z, w;
+};
+
+// patchMatchSearch for up to 64 candidates per wave at a time: the n_random candidates of a pixel are all derived from the
+// solution the pixel had when its loop started (patchmatch.h:287-340), so their costs do not depend on one another -- only the
+// accept / reject decisions do.  A wave takes P = E / n_random pixels, lane e owns candidate e % n_random of pixel e / n_random:
+//   0. every lane draws its candidate and checks that it has a value;
+//   A. candidate by candidate, the 64 lanes fetch the two feature vectors coalesced and write the per-feature terms to row e of
+//      an LDS table (row pitch odd: the column walk of phase B is conflict free);
+//   B. lane e takes the running sum of row e in the reference's order: 64 ordered sums side by side instead of one sum done 64
+//      times over;
+//   C. the first lane of every pixel replays the reference's loop over its candidates with those costs (same comparisons, same
+//      order, `n_chang =` keeping only the last outcome).
+// Bit-identical to the wave-per-cost form, 64x fewer additions.
+__global__ void __launch_bounds__(64) pm_search_batched_kernel(OdVolume o, uint64_t seed, uint32_t iter, int n_random, int E, int pitch, PmState st,
+                                                              int *__restrict__ changes) {
+    extern __shared__ __attribute__((aligned(16))) float pm_tab[];
+    __shared__ int64_t pm_src[64], pm_tgt[64]; // per candidate: offsets of the two feature vectors (-1: no value)
+    const int64_t npx = (int64_t)o.Hs * o.Ws;
+    const int lane = threadIdx.x, P = E / n_random;
+    int total = 0;
+    for (int64_t g0 = (int64_t)blockIdx.x * P; g0 < npx; g0 += (int64_t)gridDim.x * P) {
+        // phase 0
+        const int slot = lane / n_random, k = lane - slot * n_random;
+        const int64_t p = g0 + slot;
+        const bool mine = lane < P * n_random && p < npx;
+        int c0 = 0, c1 = 0, ti = 0, tj = 0;
+        bool has = false;
+        if (mine) {
+            const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+            const int base_i = o.nd == 2 ? st.sol[p * o.nd] : 0, base_j = o.nd == 2 ? st.sol[p * o.nd + 1] : st.sol[p * o.nd];
+            int disp_i = 0, disp_j;
+            if (o.nd == 1) {
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+            } else {
+                disp_i = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 1), o.lower[1], o.upper[1]);
+            }
+            int delta_i = disp_i - base_i, delta_j = disp_j - base_j;
+            delta_j *= k + 1;
+            delta_j /= n_random + 1;
+            if (o.nd == 2) {
+                delta_i *= k + 1;
+                delta_i /= n_random + 1;
+            }
+            disp_i = base_i + delta_i;
+            disp_j = base_j + delta_j;
+            if (o.nd == 1) {
+                if (disp_j == base_j) disp_j = base_j + 1;
+            } else if (disp_i == base_i && disp_j == base_j) {
+                disp_i = base_i + 1;
+                disp_j = base_j + 1;
+            }
+            c0 = o.nd == 2 ? disp_i : disp_j;
+            c1 = disp_j;
+            ti = i;
+            tj = j;
+            if (o.nd == 2) {
+                has = c0 >= o.lower[0] && c0 <= o.upper[0] && c1 >= o.lower[1] && c1 <= o.upper[1];
+                ti += c0;
+                tj += c1;
+            } else {
+                has = c0 >= o.lower[0] && c0 <= o.upper[0];
+                tj += c0;
+            }
+            has = has && ti >= 0 && ti < o.Ht && tj >= 0 && tj < o.Wt;
+        }
+        // phase A: the E x nF terms as one flat loop (independent loads, several in flight per lane)
+        __syncthreads(); // the previous round's readers are done with the table and the descriptors
+        if (lane < E) {
+            pm_src[lane] = (g0 + slot) * o.nF;
+            pm_tgt[lane] = has ? ((int64_t)ti * o.Wt + tj) * o.nF : -1;
+        }
+        __syncthreads();
+        const int n_cand = P * n_random, nq = o.nF >> 2;
+        auto term_of = [&](float a, float b) {
+            if (o.func == SVH_SSD || o.func == SVH_ZSSD) {
+                const float tmp = a - b;
+                return tmp * tmp;
+            }
+            if (o.func == SVH_SAD || o.func == SVH_ZSAD) return fabsf(a - b);
+            return a * b;
+        };
+        if (o.nF < 128) {
+            // short vectors: one flat loop over the E x nF terms (independent loads, four in flight per lane)
+            const int n_terms = n_cand * o.nF;
+#pragma unroll 4
+            for (int idx = lane; idx < n_terms; idx += 64) {
+                const int e = idx / o.nF, f = idx - e * o.nF;
+                const int64_t tb = pm_tgt[e];
+                if (tb >= 0) pm_tab[e * pitch + f] = term_of(o.fs[pm_src[e] + f], o.ft[tb + f]);
+            }
+        } else {
+            // long vectors: eight candidates at a time, four features per lane and load (16 bytes, 4-byte aligned), so that 16
+            // loads of up to 1 KiB per wave are in flight together -- the targets of the random search are scattered over HBM
+            // and the kernel lives on memory-level parallelism
+            for (int e0 = 0; e0 < n_cand; e0 += 8) {
+                for (int q0 = 0; q0 < nq; q0 += 64) {
+                    const int q = q0 + lane;
+                    Feat4 sa[8], ta[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u;
+                        const int64_t tb = e < n_cand ? pm_tgt[e] : -1;
+                        sa[u] = ta[u] = Feat4{0.f, 0.f, 0.f, 0.f};
+                        if (tb >= 0 && q < nq) {
+                            sa[u] = *reinterpret_cast<const Feat4 *>(o.fs + pm_src[e] + 4 * q);
+                            ta[u] = *reinterpret_cast<const Feat4 *>(o.ft + tb + 4 * q);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u;
+                        if (e < n_cand && q < nq && pm_tgt[e] >= 0) {
+                            float *row = pm_tab + e * pitch + 4 * q;
+                            row[0] = term_of(sa[u].x, ta[u].x);
+                            row[1] = term_of(sa[u].y, ta[u].y);
+                            row[2] = term_of(sa[u].z, ta[u].z);
+                            row[3] = term_of(sa[u].w, ta[u].w);
+                        }
+                    }
+                }
+            }
+            for (int idx = lane; idx < n_cand * (o.nF & 3); idx += 64) { // the nF % 4 trailing features of every candidate
+                const int e = idx / (o.nF & 3), f = 4 * nq + idx % (o.nF & 3);
+                const int64_t tb = pm_tgt[e];
+                if (tb >= 0) pm_tab[e * pitch + f] = term_of(o.fs[pm_src[e] + f], o.ft[tb + f]);
+            }
+        }
+        __syncthreads();
+        // phase B
+        float c_new = 0.0f;
+        if (has) {
+            const float *row = pm_tab + (int64_t)lane * pitch;
+            for (int f = 0; f < o.nF; f++) c_new += row[f];
+        }
+        // phase C: every lane of a pixel replays the loop (the shuffles need all lanes), its first lane writes the outcome
+        {
+            const int leader = lane - k;
+            bool has_old = mine ? st.valid[p] != 0 : false;
+            float c_old = mine ? st.cost[p] : 0.0f;
+            int s0 = 0, s1 = 0, n_chang = 0;
+            bool changed = false;
+            for (int q = 0; q < n_random; q++) {
+                const int srcl = min(leader + q, 63);
+                const int hq = __shfl((int)has, srcl);
+                const float cq = __shfl(c_new, srcl);
+                const int q0 = __shfl(c0, srcl), q1 = __shfl(c1, srcl);
+                if (!hq) { // no value: patchMatchTestCost returns 0 (:197-199)
+                    n_chang = 0;
+                    continue;
+                }
+                bool keep;
+                if (o.score) keep = has_old ? (cq >= c_old) : true;
+                else keep = has_old ? (cq <= c_old) : false;
+                if (keep) {
+                    s0 = q0;
+                    s1 = q1;
+                    c_old = cq;
+                    has_old = true;
+                    changed = true;
+                }
+                n_chang = keep ? 1 : 0;
+            }
+            if (mine && k == 0) {
+                if (changed) {
+                    st.sol[p * o.nd] = s0;
+                    if (o.nd == 2) st.sol[p * o.nd + 1] = s1;
+                    st.cost[p] = c_old;
+                    st.valid[p] = 1;
+                }
+                total += n_chang;
+            }
+        }
+    }
+    // every pixel's first lane holds a partial count
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+    if (total && lane == 0) atomicAdd(changes, total);
+}
+
 struct OdInputs {
     int func, nd, h_r, v_r, H, Ws, Ht, Wt, C;
 };
@@ -442,9 +624,22 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
         for (; it < n_iter; it++) {
             SVH_HIP_CHECK(ctx, hipMemsetAsync(changes, 0, sizeof(int), ctx->stream));
             const int inc0 = (it % 4) < 2 ? 1 : -1, inc1 = (it % 2) == 0 ? 1 : -1; // propagation_direction.h:64-86, patchmatch.h:462-479
+            // (prefetching the next pixel's vectors under both outcomes of the current test was tried: no gain -- with one wave per
+            // SIMD a step is bound by its ~150 dependent additions and the instructions around them, not by the loads)
             SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
             SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);
-            SVH_LAUNCH(ctx, "patchmatch_search", pm_search_kernel, px_grid, 64, shmem, o, seed, (uint32_t)it, n_random_search, st, changes);
+            // batched search when at least one pixel's candidates fit a wave and an LDS table of 60 KB
+            const int pitch = o.nF | 1;
+            int E = std::min<int>(64, (int)(16 * 1024 / (pitch * sizeof(float)))); // table of at most 16 KB: ten waves per CU keep loads in flight
+            if (n_random_search > 0 && E >= n_random_search) {
+                E = (E / n_random_search) * n_random_search;
+                const int P = E / n_random_search;
+                const int groups = (int)std::min<int64_t>((npx + P - 1) / P, 256 * 16);
+                SVH_LAUNCH(ctx, "patchmatch_search", pm_search_batched_kernel, groups, 64, (size_t)E * pitch * sizeof(float), o, seed, (uint32_t)it,
+                           n_random_search, E, pitch, st, changes);
+            } else {
+                SVH_LAUNCH(ctx, "patchmatch_search", pm_search_kernel, px_grid, 64, shmem, o, seed, (uint32_t)it, n_random_search, st, changes);
+            }
             SVH_CHECK_LAUNCH(ctx);
             int h_changes = 0;
             SVH_HIP_CHECK(ctx, hipMemcpyAsync(&h_changes, changes, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libstevi_oracle.so")
+_LIB_PATH = os.environ.get("STEVI_ORACLE_LIB") or os.path.join(_HERE, "libstevi_oracle.so")  # STEVI_ORACLE_LIB: e.g. the sanitizer build
 
 # enum values (reference: correlation/matching_costs.h:38-53, correlation_base.h:31-45,
 # cost_based_refinement.h:30-35)
@@ -25,6 +25,8 @@ EQUIANGULAR, PARABOLA, GAUSSIAN = 0, 1, 2
 
 
 def build(force=False):
+    if os.environ.get("STEVI_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "stevi_oracle.c"))
     ):

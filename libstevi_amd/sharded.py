@@ -8,6 +8,9 @@
 Why one int32 MIN all-reduce is enough: in the Cost branch as the reference computes it a pass couples
 the disparities of a pixel only through min_d [c + (c [+Pout])]; with integer census costs that minimum and the winner
 are both functions of the two regional minima (cost, last index) the keys carry.
+
+Streams of frames (video, a survey's image pairs): ShardedStereoPipeline keeps one exchange in flight, so that the
+all-reduce of frame k (RCCL's own stream, xGMI) runs under the key kernels of frame k + 1 on the compute stream.
 """
 import torch.distributed as dist
 
@@ -36,3 +39,51 @@ def stereoMatchSharded(img_l, img_r, h_radius, v_radius, disp_width, group=None,
     if world > 1:
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
     return _c.censusShardFinish(img_l, img_r, keys, h_radius, v_radius, disp_width, **kw)
+
+
+class ShardedStereoPipeline:
+    """stereoMatchSharded over a stream of frames with the exchange of one frame overlapped with the compute of the
+    next:
+
+        submit(frame k):  keys_k = censusShardKeys(...)                 compute stream
+                          work_k = all_reduce(keys_k, MIN, async_op)    RCCL stream, starts when keys_k are written
+                          return finish(frame k - 1)                    waits for work_{k-1} only
+
+    Results are the ones stereoMatchSharded returns, one submit late; flush() returns the last one.  The keys of a frame
+    are a fresh tensor per submit, so the frame in flight is never overwritten."""
+
+    def __init__(self, h_radius, v_radius, disp_width, group=None, **kw):
+        self.h_radius, self.v_radius, self.disp_width, self.group, self.kw = h_radius, v_radius, disp_width, group, kw
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        _, D = _c._search_range(disp_width)
+        self.shard = shard_range(D, self.rank, self.world)
+        if self.shard[1] == 0:
+            raise ValueError("more ranks than disparities")
+        self._in_flight = None
+
+    # the two device stages (overridable: the CPU tests drive the pipeline with the numpy restatement of the protocol)
+    def _keys(self, img_l, img_r):
+        keys_kw = {k: v for k, v in self.kw.items() if k in ("dDir", "sgmDirections", "P1", "P2", "Pout", "margins", "matchFunc")}
+        return _c.censusShardKeys(img_l, img_r, self.h_radius, self.v_radius, self.disp_width, self.shard, **keys_kw)
+
+    def _finish(self, img_l, img_r, keys):
+        return _c.censusShardFinish(img_l, img_r, keys, self.h_radius, self.v_radius, self.disp_width, **self.kw)
+
+    def _complete(self, frame):
+        img_l, img_r, keys, work = frame
+        if work is not None:
+            work.wait()  # RCCL: the compute stream waits for the exchange; gloo: the host does
+        return self._finish(img_l, img_r, keys)
+
+    def submit(self, img_l, img_r):
+        """Start frame k; returns the result of frame k - 1 (None for the first frame)."""
+        keys = self._keys(img_l, img_r)
+        work = dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group, async_op=True) if self.world > 1 else None
+        previous, self._in_flight = self._in_flight, (img_l, img_r, keys, work)
+        return self._complete(previous) if previous is not None else None
+
+    def flush(self):
+        """Result of the last submitted frame (None when nothing is in flight)."""
+        previous, self._in_flight = self._in_flight, None
+        return self._complete(previous) if previous is not None else None

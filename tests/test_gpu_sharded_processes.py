@@ -43,6 +43,18 @@ def _worker(rank, world, port, out_dir):
         assert torch.equal(res["disp"], full["disp"])
         a, b = res["refined"].cpu().numpy(), full["refined"].cpu().numpy()
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+        # the same frames through the pipelined exchange: results one submit late, identical
+        pipe = sharded.ShardedStereoPipeline(4, 4, D, sgmDirections=8, Pout=100.0)
+        frames = []
+        for k in range(3):
+            s_k, t_k, _ = parallax_pair(64, 320, 20, 10, 30 + 5 * k, 3, 19, seed=20 + k)
+            frames.append((torch.from_numpy(t_k).to(dev), torch.from_numpy(s_k).to(dev)))
+        got = [pipe.submit(t_k, s_k) for t_k, s_k in frames]
+        assert got[0] is None
+        got = got[1:] + [pipe.flush()]
+        for (t_k, s_k), r in zip(frames, got):
+            ref = sv.stereoMatch(sv.matchingFunctions.CENSUS, t_k, s_k, 4, 4, D, sgmDirections=8, Pout=100.0)
+            assert torch.equal(r["disp"], ref["disp"])
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -52,6 +52,55 @@ def test_disparity_shards_over_gloo(tmp_path):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
+def _pipeline_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import oracle as so
+    from helpers import parallax_pair
+    from libstevi_amd.sharded import ShardedStereoPipeline
+    from shard_protocol import finish, shard_keys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D, n_dir, Pout, margins = 23, 8, 100.0, (0, 0, 0, 0)
+
+        class NumpyStages(ShardedStereoPipeline):  # the pipeline's ordering and exchange, with the protocol restated in numpy
+            def _keys(self, img_l, img_r):
+                cv = so.unfold_cost_volume(so.CENSUS, img_l, img_r, 4, 4, D)
+                begin, count = self.shard
+                return torch.from_numpy(shard_keys(cv[:, :, begin:begin + count], begin, cv.shape[1]))
+
+            def _finish(self, img_l, img_r, keys):
+                return finish(keys.numpy(), n_dir, Pout, margins)
+
+        pipe = NumpyStages(4, 4, D)
+        frames = [parallax_pair(17, 28, 6, 5, 3 + k, 1, 4, seed=300 + k) for k in range(4)]
+        results = [pipe.submit(tgt, src) for src, tgt, _ in frames]
+        assert results[0] is None and pipe.flush.__self__._in_flight is not None
+        results = results[1:] + [pipe.flush()]
+        assert pipe.flush() is None
+        for k, ((src, tgt, _), idx) in enumerate(zip(frames, results)):
+            cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+            exp = so.extract_index(so.sgm(cv, n_dir, so.COST, 0.001, 0.01, margins, Pout), so.COST)
+            assert np.array_equal(idx, exp), f"rank {rank} frame {k}: {(idx != exp).sum()} pixels differ"
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_exchange_over_gloo(tmp_path):
+    """ShardedStereoPipeline: async all-reduce of frame k in flight while frame k + 1 is submitted; results arrive one
+    submit late, in order, each equal to the unsharded oracle chain."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 def test_shard_range_partitions():
     from libstevi_amd.sharded import shard_range
     for total in (1, 7, 256, 257, 2048):

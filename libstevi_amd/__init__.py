@@ -4,8 +4,10 @@ csrc/            hand-written HIP kernels + the C ABI (include/stevi_hip.h) -> l
 include/         C++ drop-in headers with the reference's names (StereoVision::Correlation)
 correlation.py   Python mirror of the same functions over the C ABI (numpy = host arrays, torch = device arrays)
 sharded.py       disparity sharding over the GPUs of a node (torch.distributed / RCCL all-reduce of winner keys)
+stevimg.py       the reference's .stevimg array files (io/image_io.h), the data format either side of the path
 """
 from . import _capi  # noqa: F401
 from .correlation import *  # noqa: F401,F403
 from .correlation import (Margins, PaddingMargins, searchOffset1, searchOffset2, matchFuncStrategy, context_for, profile_enable,  # noqa: F401
                           profile_reset, profile_collect, set_option)
+from .stevimg import read_stevimg, write_stevimg  # noqa: F401,E402

@@ -9,6 +9,10 @@ the reference are in hand_computed.json: the cases SURVEY.md section 8(c) record
 correlation_base.h / sgm.h during the survey, and cases worked out by hand from the cited lines.
 
     python tests/golden/make_golden.py        # rewrites oracle_regression.npz (inputs are derived from the fixed seed)
+
+It also writes stereo_pair/*.stevimg: one small image pair with the frozen results of the census + SGM-8 chain, in the
+reference's own array file format (io/image_io.h:48-168; the cost volume in the layout {W*D, 1, W} of
+cross_correlations.h:220), so that the fixtures are readable by the reference's readStevimg as well.
 """
 import os
 import sys
@@ -73,7 +77,28 @@ def build():
     return out
 
 
+def build_stereo_pair():
+    """(target, source) as (img_l, img_r), like benchmarkCrossCorrelationAlgorithms.cpp:93; census 9x9, D = 16, SGM-8."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import parallax_pair
+    src, tgt, _ = parallax_pair(24, 40, 8, 6, 12, 2, 7, seed=SEED % 1000)
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, 16)
+    sg = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    idx = so.extract_index(sg, so.COST)
+    tcv = so.truncated_cost_volume(sg, idx, 4, 4, 1, so.TCV_SAME)
+    H, W, D = cv.shape
+    cv_ref_layout = np.ascontiguousarray(cv.transpose(0, 2, 1)).transpose(0, 2, 1)  # strides {W*D, 1, W}
+    return {"img_l": tgt, "img_r": src, "cost_volume_census": cv_ref_layout, "sgm8_cost_volume": sg, "disp_index": idx,
+            "refined_parabola": so.refine_disp(tcv, idx, so.PARABOLA)}
+
+
 if __name__ == "__main__":
+    from libstevi_amd.stevimg import write_stevimg
+    pair_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stereo_pair")
+    os.makedirs(pair_dir, exist_ok=True)
+    for name, arr in build_stereo_pair().items():
+        write_stevimg(os.path.join(pair_dir, name + ".stevimg"), arr)
+    print(f"{pair_dir}: {sorted(os.listdir(pair_dir))}")
     data = build()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_regression.npz")
     np.savez_compressed(path, **data)

@@ -9,7 +9,8 @@ import pytest
 
 import oracle as so
 
-HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HERE_TESTS = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(HERE_TESTS, "golden")
 KNOWN = json.load(open(os.path.join(HERE, "hand_computed.json")))
 
 
@@ -160,3 +161,60 @@ def test_hip_path_matches_known_answers_and_frozen_vectors():
     assert np.array_equal(bits(h(sv.onDemandFeatures(MF.ZNCC, d(g["in_rgb"]), 1))), bits(g["on_demand_features_zncc"]))
     pm = sv.cachelessPatchMatch(MF.ZNCC, d(g["in_rgb"]), d(np.roll(g["in_rgb"], (1, -1), (0, 1)).copy()), 1, sv.searchOffset2(-2, 2, -2, 2), 4, 3, seed=7)
     assert np.array_equal(h(pm), g["patch_match"])
+
+
+# ---- the .stevimg fixture pair (tests/golden/stereo_pair, written by make_golden.py in the reference's array file format) ----
+PAIR = os.path.join(HERE, "stereo_pair")
+
+
+def load_pair():
+    from libstevi_amd.stevimg import read_stevimg
+    return {os.path.splitext(f)[0]: read_stevimg(os.path.join(PAIR, f)) for f in sorted(os.listdir(PAIR))}
+
+
+def check_pair_outputs(fx, cv, sg, idx, refined):
+    assert np.array_equal(cv, fx["cost_volume_census"])
+    assert np.array_equal(sg.view(np.uint32), fx["sgm8_cost_volume"].view(np.uint32))
+    assert np.array_equal(idx, fx["disp_index"])
+    exp = fx["refined_parabola"]
+    assert np.array_equal(np.isnan(refined), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.max(np.abs(refined[ok] - exp[ok])) <= 1e-4  # float refinement: the north star's tolerance
+
+
+def test_stevimg_pair_oracle():
+    fx = load_pair()
+    assert fx["img_l"].dtype == np.float32 and fx["disp_index"].dtype == np.int32
+    H, W, D = fx["cost_volume_census"].shape
+    assert fx["cost_volume_census"].strides == (4 * W * D, 4, 4 * W)  # the reference's cost-volume layout survives the file
+    cv = so.unfold_cost_volume(so.CENSUS, fx["img_l"], fx["img_r"], 4, 4, D)
+    sg = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    idx = so.extract_index(sg, so.COST)
+    check_pair_outputs(fx, cv, sg, idx, so.refine_disp(so.truncated_cost_volume(sg, idx, 4, 4, 1, so.TCV_SAME), idx, so.PARABOLA))
+
+
+@pytest.mark.gpu
+def test_stevimg_pair_hip_python_and_cpp(tmp_path):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    import subprocess
+    import libstevi_amd as sv
+    from libstevi_amd.stevimg import read_stevimg
+    fx = load_pair()
+    D = fx["cost_volume_census"].shape[2]
+    dev = torch.device("cuda:0")
+    res = sv.stereoMatch(sv.matchingFunctions.CENSUS, torch.from_numpy(fx["img_l"].copy()).to(dev), torch.from_numpy(fx["img_r"].copy()).to(dev), 4, 4, D,
+                         sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=4,
+                         refine_v_radius=4, want_cv=True, want_sgm_cv=True)
+    check_pair_outputs(fx, res["cv"].cpu().numpy(), res["sgm_cv"].cpu().numpy(), res["disp"].cpu().numpy(), res["refined"].cpu().numpy())
+    # the same through the C++ drop-in headers, files in and files out
+    root = os.path.dirname(HERE_TESTS)
+    exe = str(tmp_path / "stevimg_stereo")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "libstevi_amd", "include"),
+                           os.path.join(HERE_TESTS, "cpp", "stevimg_stereo.cpp"), "-o", exe, "-L", os.path.join(root, "libstevi_amd"), "-lstevi_hip",
+                           "-Wl,-rpath," + os.path.join(root, "libstevi_amd"), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    run = subprocess.run([exe, PAIR, str(tmp_path), str(D)], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    got = {k: read_stevimg(tmp_path / f"{k}.stevimg") for k in ("cost_volume_census", "sgm8_cost_volume", "disp_index", "refined_parabola")}
+    check_pair_outputs(fx, got["cost_volume_census"], got["sgm8_cost_volume"], got["disp_index"], got["refined_parabola"])

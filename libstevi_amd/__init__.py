@@ -10,4 +10,4 @@ from . import _capi  # noqa: F401
 from .correlation import *  # noqa: F401,F403
 from .correlation import (Margins, PaddingMargins, searchOffset1, searchOffset2, matchFuncStrategy, context_for, profile_enable,  # noqa: F401
                           profile_reset, profile_collect, set_option)
-from .stevimg import read_stevimg, write_stevimg  # noqa: F401,E402
+from .stevimg import read_flo, read_stevimg, write_flo, write_stevimg  # noqa: F401,E402

@@ -8,11 +8,12 @@
 //     flatLenght() elements of raw data, exactly as they lie in memory under those strides
 //
 // so a volume written with the cost-volume strides {W*D, 1, W} comes back with them.  The image codecs behind the
-// reference's readImage (CImg, OpenEXR, .flo) are third-party and outside the hot path: here readImage / writeImage
-// serve ".stevimg" and report failure (empty array / false) for every other extension.
+// reference's readImage (CImg, OpenEXR) are third-party and outside the hot path: here readImage serves ".stevimg" and
+// ".flo" (read_flo.h), writeImage ".stevimg", and both report failure (empty array / false) for every other extension.
 #pragma once
 
 #include "../utils/types_manipulations.h"
+#include "read_flo.h"
 
 #include <MultidimArrays/MultidimArrays.h>
 
@@ -29,10 +30,10 @@ namespace IO {
 
 namespace detail {
 
-inline bool hasStevimgExtension(std::string const &fileName) {
-    const std::string ext = ".stevimg";
+inline bool hasExtension(std::string const &fileName, std::string const &ext) {
     return fileName.size() >= ext.size() && fileName.compare(fileName.size() - ext.size(), ext.size(), ext) == 0;
 }
+inline bool hasStevimgExtension(std::string const &fileName) { return hasExtension(fileName, ".stevimg"); }
 
 // true when the elements fill a block of flatLenght() elements without holes or overlap (any axis order)
 template <typename T, int nDim> bool fillsItsSpan(Multidim::Array<T, nDim> const &a) {
@@ -117,6 +118,7 @@ template <typename ImgType, int nDim> Multidim::Array<ImgType, nDim> readStevimg
 
 template <typename ImgType> Multidim::Array<ImgType, 3> readImage(std::string const &fileName) {
     if (detail::hasStevimgExtension(fileName)) return readStevimg<ImgType, 3>(fileName);
+    if (detail::hasExtension(fileName, ".flo")) return readFloImg<ImgType>(fileName); // image_io.cpp:106-109
     return Multidim::Array<ImgType, 3>(); // codecs are out of scope here
 }
 

@@ -6,6 +6,8 @@ the correlation/ path -- image pairs in, disparity maps / cost volumes / fixture
 
 Arrays keep their strides through a round trip, so a cost volume stored with the reference's {W*D, 1, W} layout
 (cross_correlations.h:220) comes back as a numpy view with that layout.
+
+Also the Middlebury `.flo` optical-flow files the reference reads as ground truth for 2-D disparities (io/read_flo.h:13-49).
 """
 import numpy as np
 
@@ -87,9 +89,10 @@ def read_stevimg(path, dtype=None, ndim=None):
         shape = [int(v) for v in head[2:2 + n]]
         strides = [int(v) for v in head[2 + n:2 + 2 * n]]
         count = int(np.prod(shape)) if n else 1
-        raw = np.frombuffer(f.read(count * file_dtype.itemsize), dtype=file_dtype)
-    if raw.size != count:
+        blob = f.read(count * file_dtype.itemsize)
+    if len(blob) != count * file_dtype.itemsize:
         return None  # truncated file
+    raw = np.frombuffer(blob, dtype=file_dtype)
     if ndim is not None:
         shape += [1] * (ndim - n)
         strides += [1] * (ndim - n)
@@ -99,3 +102,34 @@ def read_stevimg(path, dtype=None, ndim=None):
     if span != count or any(st <= 0 for s, st in zip(shape, strides) if s > 1):
         raise ValueError(f"{path}: strides {strides} do not describe a dense block of shape {shape}")
     return np.lib.stride_tricks.as_strided(raw.copy(), shape=shape, strides=[st * file_dtype.itemsize for st in strides])
+
+
+def read_flo(path, dtype=np.float32):
+    """Middlebury .flo -> (H, W, 2) array of (u, v) pairs converted to `dtype`; None where the reference returns an empty
+    array (missing file, wrong magic, non-positive size, truncated data)."""
+    try:
+        with open(path, "rb") as f:
+            if f.read(4) != b"PIEH":
+                return None
+            blob = f.read(8)
+            size = np.frombuffer(blob, dtype="<i4") if len(blob) == 8 else np.zeros(2, "<i4")
+            if size[0] <= 0 or size[1] <= 0:
+                return None
+            w, h = int(size[0]), int(size[1])
+            blob = f.read(8 * w * h)
+    except OSError:
+        return None
+    if len(blob) != 8 * w * h:
+        return None
+    return np.frombuffer(blob, dtype="<f4").reshape(h, w, 2).astype(dtype)
+
+
+def write_flo(path, flow):
+    """(H, W, 2) -> Middlebury .flo (the reference only reads the format; this writes test inputs and results)."""
+    flow = np.asarray(flow)
+    if flow.ndim != 3 or flow.shape[2] != 2 or flow.shape[0] <= 0 or flow.shape[1] <= 0:
+        raise ValueError("a flow field is a non-empty (H, W, 2) array")
+    with open(path, "wb") as f:
+        f.write(b"PIEH")
+        f.write(np.array([flow.shape[1], flow.shape[0]], dtype="<i4").tobytes())
+        f.write(np.ascontiguousarray(flow, dtype="<f4").tobytes())

@@ -1,7 +1,7 @@
 // .stevimg round trips through the drop-in io/image_io.h (host only, no GPU): the call pattern of the reference's
 // test/unittests/testImageIO.cpp:40-95 (writeImage -> readImage -> same shape, same elements), plus the strided and
 // lower-rank cases of readStevimg.  argv[1] = scratch directory shared with tests/test_stevimg.py:
-//   reads  <dir>/from_python_f32.stevimg, <dir>/from_python_cv.stevimg    (written by libstevi_amd.stevimg)
+//   reads  <dir>/from_python_f32.stevimg, <dir>/from_python_cv.stevimg, <dir>/*.flo   (written by libstevi_amd.stevimg)
 //   writes <dir>/from_cpp_u16.stevimg, <dir>/from_cpp_cv.stevimg          (read back by the Python side)
 #include <io/image_io.h>
 
@@ -95,6 +95,19 @@ int main(int argc, char **argv) {
     for (int i = 0; i < H; i++)
         for (int j = 0; j < W; j++)
             for (int d = 0; d < D; d++) CHECK(pycv.atUnchecked(i, j, d) == static_cast<float>(100 * i + 10 * j + d));
+    // Middlebury .flo through readImage (image_io.cpp:106-109): H x W x 2, converted to the requested element type
+    Multidim::Array<float, 3> flo = IO::readImage<float>(dir + "/from_python.flo");
+    CHECK((flo.shape() == std::array<int, 3>{4, 6, 2}));
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 6; j++) {
+            CHECK(flo.atUnchecked(i, j, 0) == 0.5f * j - i);
+            CHECK(flo.atUnchecked(i, j, 1) == 0.25f * i + j);
+        }
+    Multidim::Array<int32_t, 3> floInt = IO::readFloImg<int32_t>(dir + "/from_python.flo");
+    CHECK(floInt.atUnchecked(3, 5, 1) == 5); // 0.75 + 5 truncated by the cast
+    CHECK((IO::readFloImg<float>(dir + "/bad_magic.flo").empty()));
+    CHECK((IO::readFloImg<float>(dir + "/truncated.flo").empty()));
+    CHECK((IO::readFloImg<float>(dir + "/missing.flo").empty()));
     std::printf("stevimg ok weighted_sum=%.6f\n", sum);
     return 0;
 }

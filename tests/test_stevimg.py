@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
-from libstevi_amd.stevimg import dtype_descr, read_stevimg, write_stevimg  # noqa: E402
+from libstevi_amd.stevimg import dtype_descr, read_flo, read_stevimg, write_flo, write_stevimg  # noqa: E402
 
 
 def test_header_line_is_the_reference_layout(tmp_path):
@@ -90,6 +90,12 @@ def test_cpp_header_and_python_agree(tmp_path):
     i, j, d = np.meshgrid(np.arange(H), np.arange(W), np.arange(D), indexing="ij")
     cv = np.ascontiguousarray((100 * i + 10 * j + d).astype(np.float32).transpose(0, 2, 1)).transpose(0, 2, 1)
     write_stevimg(tmp_path / "from_python_cv.stevimg", cv)
+    i2, j2 = np.meshgrid(np.arange(4), np.arange(6), indexing="ij")
+    flow = np.stack([0.5 * j2 - i2, 0.25 * i2 + j2], axis=2).astype(np.float32)
+    write_flo(tmp_path / "from_python.flo", flow)
+    raw = (tmp_path / "from_python.flo").read_bytes()
+    (tmp_path / "bad_magic.flo").write_bytes(b"HEIP" + raw[4:])
+    (tmp_path / "truncated.flo").write_bytes(raw[:-4])
     exe = tmp_path / "stevimg_io"
     subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "libstevi_amd", "include"),
                     os.path.join(HERE, "cpp", "stevimg_io.cpp"), "-o", str(exe)], check=True)
@@ -103,3 +109,24 @@ def test_cpp_header_and_python_agree(tmp_path):
     holes = read_stevimg(tmp_path / "holes.stevimg")                 # every second element of the volume's memory rows
     expected = np.array([[100 * a + 10 * ((2 * b) % W) + (2 * b) // W for b in range(W)] for a in range(H)], dtype=np.float32)
     assert holes.flags["C_CONTIGUOUS"] and np.array_equal(holes, expected)
+
+
+def test_flo_round_trip(tmp_path):
+    """Middlebury .flo (reference io/read_flo.h:13-49): "PIEH", width, height, rows of (u, v) float pairs."""
+    rng = np.random.default_rng(5)
+    flow = rng.normal(size=(7, 9, 2)).astype(np.float32)
+    p = tmp_path / "f.flo"
+    write_flo(p, flow)
+    raw = p.read_bytes()
+    assert raw[:4] == b"PIEH" and np.frombuffer(raw[4:12], "<i4").tolist() == [9, 7] and len(raw) == 12 + flow.nbytes
+    assert np.array_equal(read_flo(p), flow)
+    assert read_flo(p, np.int32).dtype == np.int32 and np.array_equal(read_flo(p, np.int32), flow.astype(np.int32))
+    p.write_bytes(b"HEIP" + raw[4:])
+    assert read_flo(p) is None
+    p.write_bytes(raw[:-1])
+    assert read_flo(p) is None
+    p.write_bytes(b"PIEH" + np.array([0, 3], "<i4").tobytes())
+    assert read_flo(p) is None
+    assert read_flo(tmp_path / "missing.flo") is None
+    with pytest.raises(ValueError):
+        write_flo(p, np.zeros((3, 3)))

@@ -49,6 +49,11 @@ typedef enum svh_status {
 
 typedef enum svh_memspace { SVH_HOST = 0, SVH_DEVICE = 1 } svh_memspace;
 
+/* Element types.  Images are SVH_F32 or SVH_U8 (the reference's two image types): SVH_U8 is accepted by svh_unfold*,
+ * svh_census_transform, svh_unfold_cost_volume(_2d), svh_stereo_match and the shard calls for the functions whose features are
+ * the plain samples (CENSUS, HAMMING, CC, SSD, SAD -- matching_costs.h:749-783: every comparison is formed after a cast to
+ * float, so the bytes are widened once on the device); with a normalised or zero-mean function it is SVH_ERR_UNSUPPORTED (the
+ * reference's int16 path, skipped by its own test, testCorrelationFilters.cpp:1249). */
 typedef enum svh_dtype { SVH_F32 = 0, SVH_I32 = 1, SVH_U32 = 2, SVH_U8 = 3, SVH_U64 = 4 } svh_dtype;
 
 /* values of StereoVision::Correlation::matchingFunctions, correlation/matching_costs.h:38-53 */

@@ -204,6 +204,15 @@ def _prep(x, dtype=None):
     return x
 
 
+def _prep_image(x):
+    """Images are float32 or uint8 (svh_array dtype SVH_U8: widened on the device, exact for the functions that accept it);
+    any other numpy dtype is converted to float32 on the host."""
+    if _is_torch(x):
+        return x
+    x = np.asarray(x)
+    return x if x.dtype == np.uint8 else _prep(x, np.float32)
+
+
 def _check(ctx, status):
     if status in (_capi.OK, _capi.EMPTY_RESULT):
         return status
@@ -241,7 +250,7 @@ def unfold(h_radius, v_radius, in_data, padding=None, orientation=UnfoldPatchOri
     if isinstance(h_radius, UnFoldCompressor):
         return unfoldCompressed(h_radius, v_radius, in_data)
     lib = _capi.load()
-    x = _prep(in_data, np.float32)
+    x = _prep_image(in_data)
     ctx = context_for(x)
     d = _desc(x)
     shp = (C.c_int64 * 3)()
@@ -270,7 +279,7 @@ def censusFeatures(baseFeatures):
 def censusTransform2D(input, h_radius, v_radius, padding=None):
     """censusTransform2D -- correlation/census.h:117-131."""
     lib = _capi.load()
-    x = _prep(input, np.float32)
+    x = _prep_image(input)
     ctx = context_for(x)
     d = _desc(x)
     shp = (C.c_int64 * 3)()
@@ -312,7 +321,7 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
     """unfoldBasedCostVolume<matchFunc,...> -- correlation/cross_correlations.h:740-765.
     disp_width: an int (disp_t overload) or a searchOffset1 / (lower, upper) pair."""
     lib = _capi.load()
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
     lower, D = _search_range(disp_width)
     if l.shape[0] != r.shape[0] or (l.ndim == 3 and l.shape[2] != r.shape[2]):
@@ -418,7 +427,7 @@ def stereoMatch(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=di
     selectedIndexToDisp -> [truncatedCostVolume(Same, radius 1) -> refineDispCostInterpolation].
     Returns a dict with 'disp' and, when requested, 'refined', 'cv', 'sgm_cv', 'keys'."""
     lib = _capi.load()
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
     p, D = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, refineKernel,
                           refine_h_radius, refine_v_radius, shard)
@@ -450,7 +459,7 @@ def censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, dDir=di
                     P2=0.01, Pout=100.0, margins=None, matchFunc=matchingFunctions.CENSUS):
     """svh_census_shard_keys: (H, W, 2) int32 regional winner keys of the disparity shard (begin, count)."""
     lib = _capi.load()
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
     p, _ = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, None, 0, 0, shard)
     src = r if int(dDir) == dispDirection.RightToLeft else l
@@ -464,7 +473,7 @@ def censusShardFinish(img_l, img_r, keys, h_radius, v_radius, disp_width, dDir=d
                       matchFunc=matchingFunctions.CENSUS):
     """svh_census_shard_finish on keys already MIN-reduced over all shards -> {'disp'[, 'refined']}."""
     lib = _capi.load()
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
     p, _ = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, refineKernel,
                           refine_h_radius, refine_v_radius, None)
@@ -496,7 +505,7 @@ class searchOffset2:  # searchOffset<2>, correlation_base.h:288-409
 def unfoldBased2dDisparityCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, searchWindows, dDir=dispDirection.RightToLeft):
     """unfoldBased2dDisparityCostVolume -- correlation/cross_correlations.h:794-822; (H, W, Dh, Dw) or an empty array."""
     lib = _capi.load()
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
     sw = searchWindows
     Dh, Dw = sw.upper0 - sw.lower0 + 1, sw.upper1 - sw.lower1 + 1
@@ -620,7 +629,7 @@ class CompressorGenerators:
 def unfoldCompressed(compressor, in_data, padding=None):
     """unfold(compressor, in_data, padding) -- correlation/unfold.h:346-471."""
     lib = _capi.load()
-    x = _prep(in_data, np.float32)
+    x = _prep_image(in_data)
     ctx = context_for(x)
     d = _desc(x)
     m = compressor.mask
@@ -638,7 +647,7 @@ def unfoldCompressed(compressor, in_data, padding=None):
 def unfoldBasedCostVolumeCompressed(matchFunc, img_l, img_r, compressor, disp_width, dDir=dispDirection.RightToLeft):
     """unfoldBasedCostVolume(img_l, img_r, compressor, disp_width) / unfoldBased2dDisparityCostVolume(img_l, img_r, compressor,
     searchOffset<2>) -- correlation/cross_correlations.h:767-791, :824-851: compressed unfold, then featureVolume2CostVolume."""
-    l, r = _prep(img_l, np.float32), _prep(img_r, np.float32)
+    l, r = _prep_image(img_l), _prep_image(img_r)
     two_d = isinstance(disp_width, searchOffset2)
     if l.shape[0] != r.shape[0] or (two_d and l.shape[1] != r.shape[1]) or (l.ndim == 3 and l.shape[2] != r.shape[2]):
         return _empty_like(l, 4 if two_d else 3, "f32")

@@ -228,6 +228,49 @@ int stage_in(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr) {
     return SVH_OK;
 }
 
+int validate_image(svh_context *ctx, const svh_array *img, const char *what, int match_func) {
+    if (img && img->dtype == SVH_U8) {
+        SVH_TRY(validate(ctx, img, what, SVH_U8, 2, 3));
+        if (match_func >= 0 && (func_zero_mean(match_func) || func_normalized(match_func)))
+            return fail(ctx, SVH_ERR_UNSUPPORTED,
+                        "%s: uint8 images with a normalised or zero-mean matching function follow the reference's int16 path, which its own "
+                        "tests skip; convert the images to float32",
+                        what);
+        return SVH_OK;
+    }
+    return validate(ctx, img, what, SVH_F32, 2, 3);
+}
+
+__global__ void widen_u8_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, int64_t n) {
+    // four samples per lane and step: one dword in, one 16-byte store out
+    const int64_t n4 = n >> 2;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(in)[q];
+        reinterpret_cast<float4 *>(out)[q] = make_float4((float)(w & 0xFF), (float)((w >> 8) & 0xFF), (float)((w >> 16) & 0xFF), (float)(w >> 24));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[(n4 << 2) + threadIdx.x] = (float)in[(n4 << 2) + threadIdx.x];
+}
+
+int stage_image(svh_context *ctx, Scratch &scr, const svh_array &img, void **dptr) {
+    if (img.dtype != SVH_U8) return stage_in(ctx, scr, img, dptr);
+    void *bytes;
+    SVH_TRY(stage_in(ctx, scr, img, &bytes));
+    const int64_t n = num_elements(img);
+    float *wide = scr.get_n<float>((size_t)n);
+    if (!wide) return SVH_ERR_OUT_OF_MEMORY;
+    *dptr = wide;
+    if (n == 0) return SVH_OK;
+    if ((reinterpret_cast<uintptr_t>(bytes) & 3) != 0) { // a device view that starts inside a dword: repack to an aligned buffer
+        void *aligned = scr.get((size_t)n);
+        if (!aligned) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_HIP_CHECK(ctx, hipMemcpyAsync(aligned, bytes, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+        bytes = aligned;
+    }
+    SVH_LAUNCH(ctx, "widen_u8", widen_u8_kernel, grid_for((n + 3) / 4, 256, 4096), 256, 0, (const uint8_t *)bytes, wide, n);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
 int stage_out(svh_context *ctx, Scratch &scr, const svh_array &a, OutStage *st) {
     st->dst = &a;
     if (a.memspace == SVH_DEVICE && is_dense(a)) {

@@ -296,8 +296,8 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
                            const svh_array *img_r, int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count,
                            svh_array *cv) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
-    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
-    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    SVH_TRY(validate_image(ctx, img_l, "img_l", match_func));
+    SVH_TRY(validate_image(ctx, img_r, "img_r", match_func));
     SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
     if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
     if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT)
@@ -320,8 +320,8 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
     Scratch scr(ctx);
     void *ds, *dt;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *src, &ds));
-    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_image(ctx, scr, *src, &ds));
+    SVH_TRY(stage_image(ctx, scr, *tgt, &dt));
     SVH_TRY(stage_out(ctx, scr, *cv, &os));
     SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, {(const float *)ds, a.H, a.Ws, C}, {(const float *)dt, a.H, a.Wt, C}, h_radius,
                                         v_radius, (float *)os.dptr));
@@ -339,8 +339,8 @@ extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int d
                                          const svh_array *img_r, int h_radius, int v_radius, int32_t lower0, int32_t upper0,
                                          int32_t lower1, int32_t upper1, svh_array *cv) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
-    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
-    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    SVH_TRY(validate_image(ctx, img_l, "img_l", match_func));
+    SVH_TRY(validate_image(ctx, img_r, "img_r", match_func));
     SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 4, 4));
     if (!func_supported(match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", match_func);
     if (disp_direction != SVH_LEFT_TO_RIGHT && disp_direction != SVH_RIGHT_TO_LEFT)
@@ -364,8 +364,8 @@ extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int d
     Scratch scr(ctx);
     void *ds, *dt;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *src, &ds));
-    SVH_TRY(stage_in(ctx, scr, *tgt, &dt));
+    SVH_TRY(stage_image(ctx, scr, *src, &ds));
+    SVH_TRY(stage_image(ctx, scr, *tgt, &dt));
     SVH_TRY(stage_out(ctx, scr, *cv, &os));
     const ImageDesc isrc{(const float *)ds, H, W, C}, itgt{(const float *)dt, H, W, C};
     CostVolumeArgs a{match_func, disp_direction, H, W, W, lower1, Dw};

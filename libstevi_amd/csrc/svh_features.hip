@@ -340,7 +340,7 @@ int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, 
 using namespace svh;
 
 static int image_desc(svh_context *ctx, const svh_array *img, const char *what, int *H, int *W, int *C) {
-    SVH_TRY(validate(ctx, img, what, SVH_F32, 2, 3));
+    SVH_TRY(validate_image(ctx, img, what, -1));
     *H = (int)img->shape[0];
     *W = (int)img->shape[1];
     *C = img->ndim == 3 ? (int)img->shape[2] : 1;
@@ -392,7 +392,7 @@ int svh_unfold_oriented(svh_context *ctx, const svh_array *img, int h_radius, in
     Scratch scr(ctx);
     void *dimg;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *img, &dimg));
+    SVH_TRY(stage_image(ctx, scr, *img, &dimg));
     SVH_TRY(stage_out(ctx, scr, *out, &os));
     if (orientation == SVH_ROTATE0) {
         SVH_TRY(dev_unfold(ctx, {(const float *)dimg, H, W, C}, h_radius, v_radius, pl, pt, Ho, Wo, (float *)os.dptr));
@@ -439,7 +439,7 @@ int svh_census_transform(svh_context *ctx, const svh_array *img, int h_radius, i
     Scratch scr(ctx);
     void *dimg;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *img, &dimg));
+    SVH_TRY(stage_image(ctx, scr, *img, &dimg));
     SVH_TRY(stage_out(ctx, scr, *words, &os));
     SVH_TRY(dev_census_from_image(ctx, {(const float *)dimg, H, W, C}, h_radius, v_radius, pl, pt, Ho, Wo, nW, false,
                                   (uint32_t *)os.dptr));

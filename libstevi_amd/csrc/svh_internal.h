@@ -115,6 +115,14 @@ int validate(svh_context *ctx, const svh_array *a, const char *what, int dtype, 
 // otherwise a scratch copy (H2D and/or relayout).
 int stage_in(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr);
 
+// Images: float32, or uint8 for the functions whose features are the plain samples (CENSUS, HAMMING, CC, SSD, SAD; unfold).
+// The reference keeps uint8 features there and forms every difference / product / comparison after a cast to float
+// (matching_costs.h:59-156, :749-757; census.h:89-101), so widening the samples once on the device gives the same bits.
+// Normalised and zero-mean functions take an int16 integer path on uint8 images that the reference's own comparison test
+// skips (testCorrelationFilters.cpp:1249): SVH_ERR_UNSUPPORTED.  match_func < 0: no function involved (unfold, census).
+int validate_image(svh_context *ctx, const svh_array *img, const char *what, int match_func);
+int stage_image(svh_context *ctx, Scratch &scr, const svh_array &img, void **dptr); // dense float32 device view
+
 // Device-resident dense buffer to compute an output into; finish() moves it to the user's array when needed.
 struct OutStage {
     void *dptr = nullptr;

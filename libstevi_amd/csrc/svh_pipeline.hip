@@ -16,8 +16,8 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
                                 svh_array *disp, svh_array *refined, svh_array *cv, svh_array *sgm_cv, svh_array *keys) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     if (!prm) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
-    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
-    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    SVH_TRY(validate_image(ctx, img_l, "img_l", prm->match_func));
+    SVH_TRY(validate_image(ctx, img_r, "img_r", prm->match_func));
     const int func = prm->match_func;
     if (!func_supported(func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d", func);
     if (prm->disp_direction != SVH_LEFT_TO_RIGHT && prm->disp_direction != SVH_RIGHT_TO_LEFT)
@@ -77,8 +77,8 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
 
     Scratch scr(ctx);
     void *dsrc, *dtgt;
-    SVH_TRY(stage_in(ctx, scr, *src, &dsrc));
-    SVH_TRY(stage_in(ctx, scr, *tgt, &dtgt));
+    SVH_TRY(stage_image(ctx, scr, *src, &dsrc));
+    SVH_TRY(stage_image(ctx, scr, *tgt, &dtgt));
     OutStage o_disp, o_ref, o_cv, o_sgm, o_keys;
     if (disp) SVH_TRY(stage_out(ctx, scr, *disp, &o_disp));
     if (refined) SVH_TRY(stage_out(ctx, scr, *refined, &o_ref));
@@ -184,8 +184,8 @@ struct ShardSetup {
 
 int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r, ShardSetup *s) {
     if (!prm) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
-    SVH_TRY(validate(ctx, img_l, "img_l", SVH_F32, 2, 3));
-    SVH_TRY(validate(ctx, img_r, "img_r", SVH_F32, 2, 3));
+    SVH_TRY(validate_image(ctx, img_l, "img_l", prm->match_func));
+    SVH_TRY(validate_image(ctx, img_r, "img_r", prm->match_func));
     if (!func_census(prm->match_func)) return fail(ctx, SVH_ERR_UNSUPPORTED, "disparity sharding with SGM needs census / Hamming costs");
     if (prm->disp_direction != SVH_LEFT_TO_RIGHT && prm->disp_direction != SVH_RIGHT_TO_LEFT)
         return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad disparity direction");
@@ -235,8 +235,8 @@ extern "C" int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *
     Scratch scr(ctx);
     void *dsrc, *dtgt;
     OutStage ok;
-    SVH_TRY(stage_in(ctx, scr, *s.src, &dsrc));
-    SVH_TRY(stage_in(ctx, scr, *s.tgt, &dtgt));
+    SVH_TRY(stage_image(ctx, scr, *s.src, &dsrc));
+    SVH_TRY(stage_image(ctx, scr, *s.tgt, &dtgt));
     SVH_TRY(stage_out(ctx, scr, *keys, &ok));
     uint32_t *sw = scr.get_n<uint32_t>((size_t)s.H * s.Ws * (s.nWw ? s.nWw : 1));
     uint32_t *tw = scr.get_n<uint32_t>((size_t)s.H * s.Wt * (s.nWw ? s.nWw : 1));
@@ -306,8 +306,8 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
     float *d_taps = nullptr;
     if (want_refine) { // the three taps are re-evaluated from the census words
         void *dsrc, *dtgt;
-        SVH_TRY(stage_in(ctx, scr, *s.src, &dsrc));
-        SVH_TRY(stage_in(ctx, scr, *s.tgt, &dtgt));
+        SVH_TRY(stage_image(ctx, scr, *s.src, &dsrc));
+        SVH_TRY(stage_image(ctx, scr, *s.tgt, &dtgt));
         uint32_t *sw = scr.get_n<uint32_t>((size_t)s.H * s.Ws * (s.nWw ? s.nWw : 1));
         uint32_t *tw = scr.get_n<uint32_t>((size_t)s.H * s.Wt * (s.nWw ? s.nWw : 1));
         d_idx = scr.get_n<int32_t>((size_t)npx);

@@ -113,7 +113,7 @@ extern "C" int svh_unfold_compressed_shape(const svh_array *img, const int32_t *
 extern "C" int svh_unfold_compressed(svh_context *ctx, const svh_array *img, const int32_t *mask, int mask_h, int mask_w, const int32_t pad[4],
                                      svh_array *out) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
-    SVH_TRY(validate(ctx, img, "img", SVH_F32, 2, 3));
+    SVH_TRY(validate_image(ctx, img, "img", -1));
     SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
     SVH_TRY(check_mask(ctx, mask, mask_h, mask_w));
     const int H = (int)img->shape[0], W = (int)img->shape[1], C = img->ndim == 3 ? (int)img->shape[2] : 1;
@@ -127,7 +127,7 @@ extern "C" int svh_unfold_compressed(svh_context *ctx, const svh_array *img, con
     Scratch scr(ctx);
     void *dimg;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *img, &dimg));
+    SVH_TRY(stage_image(ctx, scr, *img, &dimg));
     SVH_TRY(stage_out(ctx, scr, *out, &os));
     PixelIndex *d_entries = scr.get_n<PixelIndex>(c.entries.size());
     int32_t *d_first = scr.get_n<int32_t>(c.first.size());

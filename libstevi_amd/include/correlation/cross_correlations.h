@@ -142,6 +142,9 @@ Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const
                                               uint8_t v_radius, disp_t disp_width) {
     static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
     static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(HipBridge::imageTypeOnGpuPath<T_L, MatchingFunctionTraits<matchFunc>::ZeroMean, MatchingFunctionTraits<matchFunc>::Normalized>() &&
+                      HipBridge::imageTypeOnGpuPath<T_R, MatchingFunctionTraits<matchFunc>::ZeroMean, MatchingFunctionTraits<matchFunc>::Normalized>(),
+                  "libstevi_hip: images are float, or uint8 with CENSUS / HAMMING / CC / SSD / SAD");
     auto l_shape = img_l.shape();
     auto r_shape = img_r.shape();
     if (l_shape[0] != r_shape[0] || disp_width <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :751-753
@@ -189,6 +192,9 @@ Multidim::Array<TCV, 4> unfoldBased2dDisparityCostVolume(Multidim::Array<T_L, nI
                                                          uint8_t h_radius, uint8_t v_radius, searchOffset<2> const &searchWindows) {
     static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
     static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(HipBridge::imageTypeOnGpuPath<T_L, MatchingFunctionTraits<matchFunc>::ZeroMean, MatchingFunctionTraits<matchFunc>::Normalized>() &&
+                      HipBridge::imageTypeOnGpuPath<T_R, MatchingFunctionTraits<matchFunc>::ZeroMean, MatchingFunctionTraits<matchFunc>::Normalized>(),
+                  "libstevi_hip: images are float, or uint8 with CENSUS / HAMMING / CC / SSD / SAD");
     auto l_shape = img_l.shape();
     auto r_shape = img_r.shape();
     if (l_shape[0] != r_shape[0] || l_shape[1] != r_shape[1]) return Multidim::Array<TCV, 4>(); // :804-810

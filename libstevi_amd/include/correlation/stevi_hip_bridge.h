@@ -34,9 +34,10 @@ inline std::mutex &lock() {
 }
 
 template <class T> struct DType {
-    static_assert(sizeof(T) == 0, "libstevi_hip: this element type has no GPU path (float images / volumes, int32 index maps and "
-                                  "uint32 census words are supported; uint8 inputs are QSKIPped as broken in the reference itself)");
+    static_assert(sizeof(T) == 0, "libstevi_hip: this element type has no GPU path (float or uint8 images, float volumes, int32 index "
+                                  "maps and uint32 census words are supported)");
 };
+template <> struct DType<uint8_t> { static constexpr int value = SVH_U8; }; // images only, see imageTypeOnGpuPath
 template <> struct DType<float> { static constexpr int value = SVH_F32; };
 template <> struct DType<int32_t> { static constexpr int value = SVH_I32; };
 template <> struct DType<uint32_t> { static constexpr int value = SVH_U32; };
@@ -53,6 +54,15 @@ template <class T, int N, Multidim::ArrayDataAccessConstness C> inline svh_array
         d.strides[k] = a.strides()[k];
     }
     return d;
+}
+
+// Image element types per matching function: float always; uint8 where the reference keeps the plain samples as features
+// and casts to float inside the comparison (CENSUS, HAMMING, CC, SSD, SAD: matching_costs.h:749-783), so that widening on the
+// device is exact.  uint8 with a normalised or zero-mean function takes the reference's int16 path, which its own comparison
+// test skips (testCorrelationFilters.cpp:1249).
+template <class T_I, bool ZeroMean, bool Normalized> constexpr bool imageTypeOnGpuPath() {
+    using T = std::remove_const_t<T_I>;
+    return std::is_same_v<T, float> || (std::is_same_v<T, uint8_t> && !ZeroMean && !Normalized);
 }
 
 // SVH_OK -> true, SVH_EMPTY_RESULT -> false (caller returns the empty array the reference returns), else throw

@@ -77,18 +77,23 @@ template <class T_I, class T_O = float, int nImDim, Multidim::ArrayDataAccessCon
 Multidim::Array<T_O, 3> unfold(uint8_t h_radius, uint8_t v_radius, Multidim::Array<T_I, nImDim, constness> const &in_data,
                                PaddingMargins const &padding = PaddingMargins(), UnfoldPatchOrientation orientation = Rotate0) {
     static_assert(nImDim == 2 || nImDim == 3, "unfold takes grey (2-D) or multi-channel (3-D) images");
-    static_assert(std::is_same_v<T_I, float> && std::is_same_v<T_O, float>, "libstevi_hip: unfold is implemented for float images");
+    static_assert(std::is_same_v<std::remove_const_t<T_I>, float> || std::is_same_v<std::remove_const_t<T_I>, uint8_t>,
+                  "libstevi_hip: unfold takes float or uint8 images");
+    static_assert(std::is_arithmetic_v<T_O>, "libstevi_hip: unfold writes arithmetic element types");
     const int32_t pad[4] = {padding.left(), padding.top(), padding.right(), padding.bottom()};
     const int32_t *pp = padding.isAuto() ? nullptr : pad;
     svh_array in = HipBridge::describe(in_data);
     int64_t shp[3];
     if (svh_unfold_shape(&in, h_radius, v_radius, pp, shp) != SVH_OK || shp[0] <= 0 || shp[1] <= 0) return Multidim::Array<T_O, 3>();
-    Multidim::Array<T_O, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2]));
-    std::lock_guard<std::mutex> g(HipBridge::lock());
-    svh_array o = HipBridge::describe(out);
-    if (!HipBridge::check(svh_unfold_oriented(HipBridge::context(), &in, h_radius, v_radius, pp, static_cast<int>(orientation), &o)))
-        return Multidim::Array<T_O, 3>();
-    return out;
+    Multidim::Array<float, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2])); // the device writes float samples
+    {
+        std::lock_guard<std::mutex> g(HipBridge::lock());
+        svh_array o = HipBridge::describe(out);
+        if (!HipBridge::check(svh_unfold_oriented(HipBridge::context(), &in, h_radius, v_radius, pp, static_cast<int>(orientation), &o)))
+            return Multidim::Array<T_O, 3>();
+    }
+    if constexpr (std::is_same_v<T_O, float>) return out;
+    else return out.template cast<T_O>(); // static_cast per element, as unfold.h:283 stores them
 }
 
 // unfold(compressor, in_data, padding), unfold.h:346-471 (2-D and 3-D images)
@@ -96,7 +101,8 @@ template <class T_I, class T_O = float, int nImDim, Multidim::ArrayDataAccessCon
 Multidim::Array<T_O, 3> unfold(UnFoldCompressor const &compressor, Multidim::Array<T_I, nImDim, constness> const &in_data,
                                PaddingMargins const &padding = PaddingMargins()) {
     static_assert(nImDim == 2 || nImDim == 3, "unfold takes grey (2-D) or multi-channel (3-D) images");
-    static_assert(std::is_same_v<T_I, float> && std::is_same_v<T_O, float>, "libstevi_hip: unfold is implemented for float images");
+    static_assert((std::is_same_v<std::remove_const_t<T_I>, float> || std::is_same_v<std::remove_const_t<T_I>, uint8_t>) && std::is_same_v<T_O, float>,
+                  "libstevi_hip: compressed unfold takes float or uint8 images and writes float features");
     const int32_t pad[4] = {padding.left(), padding.top(), padding.right(), padding.bottom()};
     const int32_t *pp = padding.isAuto() ? nullptr : pad;
     svh_array in = HipBridge::describe(in_data);

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include <correlation/census.h>
 #include <correlation/cost_based_refinement.h>
 #include <correlation/cross_correlations.h>
 #include <correlation/hierarchical.h>
@@ -151,6 +152,23 @@ int main(int argc, char **argv) {
         if (refinedDisp.shape()[2] != 2) return 11;
         dump(out + "_pm_disp.i32", pm.data(), pm.flatLenght());
         dump(out + "_pm_refined.f32", refinedDisp.data(), refinedDisp.flatLenght());
+    }
+    { // uint8 images: the byte versions of the pair (values scaled into 0..255), SAD volume, census words, unfold<uint8, uint8>
+        Multidim::Array<uint8_t, 2> target8(H, W), source8(H, W);
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++) {
+                target8.atUnchecked(i, j) = static_cast<uint8_t>((target.valueUnchecked(i, j) + 1.0f) * 127.5f);
+                source8.atUnchecked(i, j) = static_cast<uint8_t>((source.valueUnchecked(i, j) + 1.0f) * 127.5f);
+            }
+        Multidim::Array<float, 3> sad8 = SC::unfoldBasedCostVolume<SC::matchingFunctions::SAD>(target8, source8, 2, 2, D);
+        Multidim::Array<SC::census_data_t, 3> words8 = SC::censusTransform2D(source8, 3, 3);
+        Multidim::Array<uint8_t, 3> unfolded8 = SC::unfold<uint8_t, uint8_t>(1, 2, source8);
+        if (sad8.empty() || words8.empty() || unfolded8.empty()) return 12;
+        dump(out + "_u8_target.u8", target8.data(), target8.flatLenght());
+        dump(out + "_u8_source.u8", source8.data(), source8.flatLenght());
+        dump(out + "_u8_sad.f32", sad8.data(), sad8.flatLenght());
+        dump(out + "_u8_words.u32", words8.data(), words8.flatLenght());
+        dump(out + "_u8_unfold.u8", unfolded8.data(), unfolded8.flatLenght());
     }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);

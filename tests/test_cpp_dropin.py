@@ -91,3 +91,12 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(np.isnan(got_ref), np.isnan(ref))
     ok = ~np.isnan(ref)
     assert np.max(np.abs(got_ref[ok] - ref[ok])) <= 1e-4
+    # uint8 images through the same headers (widened on the device; equal to the float32 results of the same values)
+    t8 = np.fromfile(tmp_path / "o_u8_target.u8", np.uint8).reshape(H, W)
+    s8 = np.fromfile(tmp_path / "o_u8_source.u8", np.uint8).reshape(H, W)
+    assert np.array_equal(t8, ((tgt + 1.0) * np.float32(127.5)).astype(np.uint8))
+    sad8 = so.unfold_cost_volume(so.SAD, t8.astype(np.float32), s8.astype(np.float32), 2, 2, D)
+    assert np.array_equal(np.fromfile(tmp_path / "o_u8_sad.f32", np.float32).reshape(H, W, D), sad8)
+    assert np.array_equal(np.fromfile(tmp_path / "o_u8_words.u32", np.uint32).reshape(H, W, 2), so.census_transform(s8.astype(np.float32), 3, 3))
+    unf8 = so.unfold(s8.astype(np.float32), 1, 2)
+    assert np.array_equal(np.fromfile(tmp_path / "o_u8_unfold.u8", np.uint8).reshape(unf8.shape), unf8.astype(np.uint8))

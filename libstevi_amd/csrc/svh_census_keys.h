@@ -1,0 +1,32 @@
+// Shared by the census + SGM kernels of the exact regime (svh_census_sgm.hip) and the matrix-core sweep
+// (svh_census_sweep_mfma.hip): the geometry of a sweep and the winner keys.
+#pragma once
+
+#include "svh_internal.h"
+
+namespace svh {
+
+struct CensusGeom {
+    const uint32_t *sw, *tw; // compact words (H, Ws, nWw), (H, Wt, nWw); target pre-rounded through float (E2)
+    int nWw, H, Ws, Wt, D, sign, disp_lower;
+    int d_offset; // global index of local disparity 0 (disparity shards); disp_lower already includes it
+};
+
+constexpr uint32_t KEY_NONE = 0x7FFFFFFFu;
+constexpr int KEY_IDX_BITS = 12;
+constexpr uint32_t KEY_IDX_MASK = (1u << KEY_IDX_BITS) - 1u;
+__device__ __forceinline__ uint32_t make_key(int c, int d_global) { return ((uint32_t)c << KEY_IDX_BITS) | (KEY_IDX_MASK - (uint32_t)d_global); }
+__device__ __forceinline__ int key_cost(uint32_t k) { return (int)(k >> KEY_IDX_BITS); }
+__device__ __forceinline__ int key_index(uint32_t k) { return (int)(KEY_IDX_MASK - (k & KEY_IDX_MASK)); }
+
+__device__ __forceinline__ float g_from_keys(uint32_t key0, uint32_t key1, int pout) {
+    const int g0 = key0 == KEY_NONE ? (1 << 24) : 2 * key_cost(key0);
+    const int g1 = key1 == KEY_NONE ? (1 << 24) : 2 * key_cost(key1) + pout;
+    return (float)min(g0, g1);
+}
+
+// census_sweep on the matrix cores (svh_census_sweep_mfma.hip); false when the geometry is outside what that kernel covers
+// (the caller then runs the VALU sweep)
+bool launch_sweep_mfma(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
+
+} // namespace svh

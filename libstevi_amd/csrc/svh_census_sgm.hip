@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "svh_internal.h"
+#include "svh_census_keys.h"
 
 namespace svh {
 
@@ -30,11 +31,6 @@ namespace {
 constexpr int TJ = 256; // pixels (= threads) per block
 constexpr int UNROLL = 8;
 
-struct CensusGeom {
-    const uint32_t *sw, *tw; // compact words (H, Ws, nWw), (H, Wt, nWw); target pre-rounded through float (E2)
-    int nWw, H, Ws, Wt, D, sign, disp_lower;
-    int d_offset; // global index of local disparity 0 (disparity shards); disp_lower already includes it
-};
 
 template <int NW> struct Words {
     uint32_t v[NW > 0 ? NW : 1];
@@ -106,19 +102,6 @@ template <int NW, class F> __device__ __forceinline__ void for_each_disparity(co
 // feeds the line recurrences, and census_finalize_kernel picks the winner once the min_p maps exist.
 // Keys are positive int32 values (cost <= 128 needs 8 bits, the index 12), so an int32 MIN all-reduce across
 // disparity shards is the cross-GPU winner reduction.  The index part holds the GLOBAL disparity index.
-constexpr uint32_t KEY_NONE = 0x7FFFFFFFu;
-constexpr int KEY_IDX_BITS = 12;
-constexpr uint32_t KEY_IDX_MASK = (1u << KEY_IDX_BITS) - 1u;
-__device__ __forceinline__ uint32_t make_key(int c, int d_global) { return ((uint32_t)c << KEY_IDX_BITS) | (KEY_IDX_MASK - (uint32_t)d_global); }
-__device__ __forceinline__ int key_cost(uint32_t k) { return (int)(k >> KEY_IDX_BITS); }
-__device__ __forceinline__ int key_index(uint32_t k) { return (int)(KEY_IDX_MASK - (k & KEY_IDX_MASK)); }
-
-__device__ __forceinline__ float g_from_keys(uint32_t key0, uint32_t key1, int pout) {
-    const int g0 = key0 == KEY_NONE ? (1 << 24) : 2 * key_cost(key0);
-    const int g1 = key1 == KEY_NONE ? (1 << 24) : 2 * key_cost(key1) + pout;
-    return (float)min(g0, g1);
-}
-
 // Two neighbouring pixels per lane.  With the records stored as 2-record pairs P_m = (rec 2m, rec 2m+1), the "even"
 // pixel E of a lane (record base 2 m0) and its "odd" neighbour O (base 2 m0 + 1) need, for the disparity pair (2e, 2e+1),
 //   E: P_{m0+e}.lo, P_{m0+e}.hi        O: P_{m0+e}.hi, P_{m0+e+1}.lo
@@ -602,6 +585,10 @@ size_t lds_bytes(int nWw, int D) { return (size_t)(nWw ? nWw : 1) * (TJ + D - 1)
 template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap) {
     // block width: the one that pads the row less (the lanes of a partial last block idle through the whole disparity loop);
     // 1080p: 5 blocks of 384 pixels instead of 3.75 of 512 -> 100 us instead of 106
+    if (ctx->census_sweep_mode != 1) { // 0 = auto, 1 = VALU sweep only, 2 = matrix-core sweep wherever it applies (same as auto today)
+        int status = SVH_OK;
+        if (launch_sweep_mfma(ctx, g, Pout, keys, gmap, &status)) return status;
+    }
     const int64_t pad512 = (int64_t)ceil_div(g.Ws, 512) * 512, pad384 = (int64_t)ceil_div(g.Ws, 384) * 384;
     if (pad384 < pad512) {
         dim3 grid(ceil_div(g.Ws, 384), g.H);

@@ -1,0 +1,261 @@
+// census_sweep on the matrix cores.
+//
+// The sweep of svh_census_sgm.hip evaluates  c(j, d) = popcount(s_j xor t_{j + lower + d})  for every pixel j of a row and every
+// disparity d, and keeps per pixel the minimum key (c << 12 | 4095 - d) of the two disparity regions (before / from the column
+// where the reference adds Pout, sgm.h:287-289).  On the vector ALU that is 2 v_xor + 2 v_bcnt + v_lshl_or + 1/2 v_min3 per 64
+// voxels of 64-bit census records: 21.4 issue cycles per SIMD, and the kernel sits at that issue bound, far
+// from HBM (67 MB per launch).  The Hamming distance of two bit strings is also a dot product:
+//
+//     popcount(s xor t) = |s| + sum_b t_b (1 - 2 s_b)
+//
+// so with the target bits as 0/1 bytes (operand A: rows = 32 target columns) and the source bits as +1/-1 bytes (operand B:
+// columns = 32 source pixels) one v_mfma_i32_32x32x32_i8 per 32 bits of census record yields 32 x 32 costs (minus |s|, a
+// per-lane constant).  In the accumulator layout a lane owns ONE source pixel and 16 target columns, so the running minimum over
+// disparities stays inside the lane, and with the cell index riding in the accumulator's start value (see the kernel) the
+// minimum of 1024 voxels is eight v_min3 plus three instructions per tile instead of 16 x 5.5 VALU instructions; the matrix pipe
+// runs beside them.  Integer arithmetic throughout: results are the VALU sweep's, bit for bit (the parity tests run both,
+// svh_context_set_option("census_sweep", ...)).
+//
+// Geometry.  A wave owns CT column tiles (of 32 source pixels) and takes them one after the other; column tile c meets the row tiles k = 0 .. D/32 of the target
+// window, row tile k starting at target column  J0c + lower + 32 k, i.e. d = 32 k + row - col: tile 0 is valid on and below its
+// diagonal, tile D/32 strictly above it, the tiles between completely.  The two triangular tiles start their accumulator from a
+// pattern that holds 2^20 in the invalid cells (they can then never win).  The Pout boundary
+// j + d_global >= Ws is the TARGET column Ws + lower - d_offset: a row boundary, so a tile lies in one region or (rarely)
+// straddles it.  Covers sign > 0 (RightToLeft), 1..4 census words, D a multiple of 32 up to 480; everything else runs the VALU sweep.
+#include "svh_census_keys.h"
+
+namespace svh {
+
+namespace {
+
+using v4i = int __attribute__((ext_vector_type(4)));
+using v16i = int __attribute__((ext_vector_type(16)));
+
+constexpr int BIG_CELL = 1 << 20;       // accumulator start of an invalid cell: never the minimum of a tile that has a valid one
+constexpr int BIG_G = 1 << 28;          // "no candidate yet"
+constexpr int G_VALID_BELOW = 1 << 19;  // valid packed minima stay below 2^15
+
+// bits 4q .. 4q+3 of w as four 0/1 bytes (bit b of the nibble in byte b), and the same as 0/4 bytes (the largest scale whose
+// multiplier still fits v_mul_u32_u24)
+__device__ __forceinline__ uint32_t nibble_bytes(uint32_t w, int q) { return (((w >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u; }
+__device__ __forceinline__ uint32_t nibble_bytes_x4(uint32_t w, int q) { return (((w >> (4 * q)) & 0xFu) * 0x00810204u) & 0x04040404u; }
+
+// min of three, written so that it selects v_min3_i32.  Deliberately NOT inline asm: the tree below is the first reader of the
+// MFMA result, and the compiler only pads the MFMA -> VALU read hazard for instructions it can see (an asm reader got stale cells).
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+
+__device__ __forceinline__ constexpr int row_of_reg(int reg) { return (reg & 3) + 8 * (reg >> 2); } // + 4 * (lane >> 5)
+
+// Cell value.  The target bytes are 0 / 4, the source bytes +64 / -64 and the accumulator starts at 15 - reg, so a cell comes out
+// of the matrix pipe as
+//     a[reg] = 256 (c - |s|) + 15 - reg
+// which already orders the 16 cells of a lane the way the reference breaks ties (the larger row, i.e. the larger disparity, wins):
+// the tile minimum is a plain min tree, no per-cell instruction.  Row tile k adds 16 (15 - k) to its minimum (bits 4..7, between
+// the cost and the cell: cost first, then the later tile, then the later cell) and the running minimum is decoded once per pixel
+// at the end.  Four bits of tile index: D <= 480.
+template <int NW, int WAVES, int CT>
+__global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap) {
+    constexpr int PXB = WAVES * CT * 32; // source pixels per block
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[]; // [2 NW chunks of 16 bits][WIN window pixels] x 16 bytes
+    const int i = blockIdx.y, j0 = blockIdx.x * PXB;
+    const int NT = g.D / 32 + 1;  // row tiles per column tile
+    const int WIN = PXB + g.D;    // window pixels: the last column tile's last row tile ends at PXB - 32 + 32 NT
+    // ---- the target window as 0/4 bytes; window pixel y is target column j0 + lower + y (zero vector outside the image)
+    {
+        const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
+        for (int e = threadIdx.x; e < WIN * NW; e += 64 * WAVES) {
+            const int y = e / NW, m = e - y * NW;
+            const int jt = j0 + g.disp_lower + y;
+            const uint32_t w = (jt >= 0 && jt < g.Wt) ? trow[(int64_t)jt * NW + m] : 0u;
+            lds4[(2 * m) * WIN + y] = make_uint4(nibble_bytes_x4(w, 0), nibble_bytes_x4(w, 1), nibble_bytes_x4(w, 2), nibble_bytes_x4(w, 3));
+            lds4[(2 * m + 1) * WIN + y] = make_uint4(nibble_bytes_x4(w, 4), nibble_bytes_x4(w, 5), nibble_bytes_x4(w, 6), nibble_bytes_x4(w, 7));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)i * g.Ws;
+    // ---- accumulator starts: 15 - reg for full tiles (in registers), and for the two triangular tiles the same with the invalid
+    // cells pushed out of reach (in LDS behind the window: read twice per column tile)
+    // (the zero is opaque to the compiler on purpose: a start pattern it can rematerialise it rebuilds in the accumulator registers
+    // before every tile, eight v_mov_b64; one that lives in registers goes into the MFMA as its C operand)
+    int opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    v16i full_tile;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) full_tile[reg] = 15 - reg + opaque_zero;
+    uint4 *edge = lds4 + 2 * NW * WIN; // [first, last][4 register quads][64 lanes]
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int f[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int reg = 4 * q + e, rr = row_of_reg(reg) + 4 * h;
+                f[e] = 15 - reg + (rr >= r ? 0 : BIG_CELL); // tile 0: d = row - col >= 0
+                l[e] = 15 - reg + (rr < r ? 0 : BIG_CELL);  // tile D/32: d = D + row - col < D
+            }
+            edge[q * 64 + lane] = make_uint4(f[0], f[1], f[2], f[3]);
+            edge[(4 + q) * 64 + lane] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    }
+    auto edge_tile = [&](int which) {
+        v16i a;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 t = edge[(4 * which + q) * 64 + lane];
+            a[4 * q] = (int)t.x;
+            a[4 * q + 1] = (int)t.y;
+            a[4 * q + 2] = (int)t.z;
+            a[4 * q + 3] = (int)t.w;
+        }
+        return a;
+    };
+    const int thr = g.Ws + g.disp_lower - g.d_offset; // target columns from here on pay Pout
+    const int pout = (int)Pout;
+    __syncthreads();
+
+    // one column tile after the other; the MFMAs of row tile k + 1 are issued before the epilogue of row tile k
+    for (int c = 0; c < CT; c++) {
+        const int ct = wave * CT + c; // column tile of the block (wave uniform)
+        const int j = j0 + ct * 32 + r;
+        // source fragment (+64 / -64 bytes of this lane's half of every word) and |s|
+        v4i bfrag[NW];
+        int ones = 0;
+        {
+            const uint32_t *sp = g.sw + (row + min(j, g.Ws - 1)) * NW;
+#pragma unroll
+            for (int m = 0; m < NW; m++) {
+                const uint32_t w = sp[m];
+                ones += __popc(w);
+                const uint32_t half = (w >> (16 * h)) & 0xFFFFu;
+#pragma unroll
+                for (int q = 0; q < 4; q++) // the 0/1 bytes select byte 0 (+64) or byte 1 (-64) of the table
+                    bfrag[m][q] = (int)__builtin_amdgcn_perm(0u, 0x0000C040u, nibble_bytes(half, q));
+            }
+        }
+        const uint4 *arow = lds4 + h * WIN + ct * 32 + r; // row tile k, word m: arow[2 m WIN + 32 k]
+        auto tile = [&](int k, const v16i &start) {
+            v16i a = start;
+#pragma unroll
+            for (int m = 0; m < NW; m++) {
+                const uint4 t = arow[2 * m * WIN + 32 * k];
+                a = __builtin_amdgcn_mfma_i32_32x32x32_i8((v4i){(int)t.x, (int)t.y, (int)t.z, (int)t.w}, bfrag[m], a, 0, 0, 0);
+            }
+            return a;
+        };
+        // Region bookkeeping (wave uniform).  Row tile k covers target columns t0 + 32 k ...; tiles below k_switch lie in the
+        // region without Pout; tile k_switch straddles the boundary when `straddle`, else it is the first tile that pays.
+        const int t0 = j0 + g.disp_lower + ct * 32;
+        const int below = thr - t0; // target rows (relative to tile 0) that do not pay
+        const int k_switch = below <= 0 ? 0 : min(below >> 5, NT);
+        const bool straddle = below > 0 && (below & 31) != 0 && k_switch < NT;
+        int G = BIG_G, G0 = BIG_G;
+        auto epilogue = [&](const v16i &a, int k) {
+            if (k == k_switch) { // once per column tile
+                asm volatile("; region switch" ::: "memory"); // keep this a branch: if-converted it costs selects in every tile
+                if (straddle) {
+                    int m0 = BIG_CELL, m1 = BIG_CELL;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) {
+                        const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below;
+                        m0 = min(m0, pays ? BIG_CELL : a[reg]);
+                        m1 = min(m1, pays ? a[reg] : BIG_CELL);
+                    }
+                    G0 = min(G, m0 + 16 * (15 - k));
+                    G = m1 + 16 * (15 - k);
+                    return;
+                }
+                G0 = G;
+                G = BIG_G;
+            }
+            const int t1 = min3i(a[0], a[1], a[2]), t2 = min3i(a[3], a[4], a[5]), t3 = min3i(a[6], a[7], a[8]), t4 = min3i(a[9], a[10], a[11]),
+                      t5 = min3i(a[12], a[13], a[14]);
+            const int t6 = min3i(t1, t2, t3), t7 = min3i(t4, t5, a[15]);
+            const int tile_tag = __builtin_amdgcn_readfirstlane(16 * (15 - k)); // one SGPR operand: a v_add each, not v_add3 + literal
+            G = min3i(G, t6 + tile_tag, t7 + tile_tag);
+        };
+        // NT >= 2: tile 0 and tile NT - 1 are the triangular ones; the loop body only meets full tiles, two per round
+        {
+            const v16i acc = tile(0, edge_tile(0));
+            epilogue(acc, 0);
+        }
+        int k = 1;
+        for (; k + 1 < NT - 1; k += 2) {
+            const v16i acc_a = tile(k, full_tile), acc_b = tile(k + 1, full_tile);
+            epilogue(acc_a, k);
+            epilogue(acc_b, k + 1);
+        }
+        if (k < NT - 1) {
+            const v16i acc = tile(k, full_tile);
+            epilogue(acc, k);
+        }
+        {
+            const v16i acc = tile(NT - 1, edge_tile(1));
+            epilogue(acc, NT - 1);
+        }
+        int G1 = G;
+        if (k_switch >= NT) { // no tile pays
+            G0 = G;
+            G1 = BIG_G;
+        }
+        // ---- decode (tile, cell) -> key; the two lane halves hold different rows of the same pixel: merge, store
+        auto decode = [&](int gv) {
+            const int kk = 15 - ((gv >> 4) & 15);
+            const int reg = 15 - (gv & 15), cost = ones + (gv >> 8);
+            const int d_local = 32 * kk + (reg & 3) + 8 * (reg >> 2) + 4 * h - r;
+            return gv < G_VALID_BELOW ? (int)make_key(cost, g.d_offset + d_local) : (int)KEY_NONE;
+        };
+        int a0 = decode(G0), a1 = decode(G1);
+        a0 = min(a0, __shfl_xor(a0, 32));
+        a1 = min(a1, __shfl_xor(a1, 32));
+        if (h == 0 && j < g.Ws) {
+            keys[row + j] = make_uint2((uint32_t)a0, (uint32_t)a1);
+            if (gmap) gmap[row + j] = g_from_keys((uint32_t)a0, (uint32_t)a1, pout);
+        }
+    }
+}
+
+template <int NW, int WAVES, int CT> int launch_config(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, size_t shmem) {
+    constexpr int PXB = WAVES * CT * 32;
+    dim3 grid(ceil_div(g.Ws, PXB), g.H);
+    SVH_LAUNCH(ctx, "census_sweep", (census_sweep_mfma_kernel<NW, WAVES, CT>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SVH_OK : fail(ctx, SVH_ERR_HIP, "census_sweep (mfma): %s", hipGetErrorString(e));
+}
+
+template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status) {
+    // block width (4 waves x CT column tiles of 32 pixels): the widest that fits 64 KB of LDS, preferring less row padding
+    int best_ct = 0;
+    int64_t best_pad = 0;
+    for (int ct = 4; ct >= 2; ct--) {
+        const int pxb = 4 * ct * 32;
+        if (((size_t)2 * NW * (pxb + g.D) + 512) * sizeof(uint4) > 64 * 1024) continue;
+        const int64_t pad = (int64_t)ceil_div(g.Ws, pxb) * pxb;
+        if (!best_ct || pad < best_pad) {
+            best_ct = ct;
+            best_pad = pad;
+        }
+    }
+    if (!best_ct) return false;
+    const size_t shmem = ((size_t)2 * NW * (4 * best_ct * 32 + g.D) + 512) * sizeof(uint4); // window + the two edge patterns
+    switch (best_ct) {
+    case 4: *status = launch_config<NW, 4, 4>(ctx, g, Pout, keys, gmap, shmem); break;
+    case 3: *status = launch_config<NW, 4, 3>(ctx, g, Pout, keys, gmap, shmem); break;
+    default: *status = launch_config<NW, 4, 2>(ctx, g, Pout, keys, gmap, shmem); break;
+    }
+    return true;
+}
+
+} // namespace
+
+bool launch_sweep_mfma(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status) {
+    if (g.sign <= 0 || g.D < 32 || (g.D & 31) != 0 || g.D > 480 || g.nWw < 1 || g.nWw > 4) return false;
+    switch (g.nWw) {
+    case 1: return launch_for_words<1>(ctx, g, Pout, keys, gmap, status);
+    case 2: return launch_for_words<2>(ctx, g, Pout, keys, gmap, status);
+    case 3: return launch_for_words<3>(ctx, g, Pout, keys, gmap, status);
+    default: return launch_for_words<4>(ctx, g, Pout, keys, gmap, status);
+    }
+}
+
+} // namespace svh

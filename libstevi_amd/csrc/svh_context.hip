@@ -361,6 +361,11 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_fast_path = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "census_sweep") == 0) {
+        if (value < 0 || value > 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_sweep: 0 (auto), 1 (vector ALU) or 2 (matrix cores)");
+        ctx->census_sweep_mode = (int)value;
+        return SVH_OK;
+    }
     if (strcmp(name, "literal_cost_volumes") == 0) {
         ctx->literal_cost_volumes = value != 0;
         return SVH_OK;

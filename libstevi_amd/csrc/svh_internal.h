@@ -44,6 +44,7 @@ struct svh_context {
     bool profiling = false;
     std::string prof_filter; // when not empty only launches of this kernel are bracketed by events
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
+    int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;

@@ -22,6 +22,8 @@
 // pattern that holds 2^20 in the invalid cells (they can then never win).  The Pout boundary
 // j + d_global >= Ws is the TARGET column Ws + lower - d_offset: a row boundary, so a tile lies in one region or (rarely)
 // straddles it.  Covers sign > 0 (RightToLeft), 1..4 census words, D a multiple of 32 up to 480; everything else runs the VALU sweep.
+#include <type_traits>
+
 #include "svh_census_keys.h"
 
 namespace svh {
@@ -60,20 +62,55 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
     const int i = blockIdx.y, j0 = blockIdx.x * PXB;
     const int NT = g.D / 32 + 1;  // row tiles per column tile
     const int WIN = PXB + g.D;    // window pixels: the last column tile's last row tile ends at PXB - 32 + 32 NT
-    // ---- the target window as 0/4 bytes; window pixel y is target column j0 + lower + y (zero vector outside the image)
-    {
-        const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
-        for (int e = threadIdx.x; e < WIN * NW; e += 64 * WAVES) {
-            const int y = e / NW, m = e - y * NW;
-            const int jt = j0 + g.disp_lower + y;
-            const uint32_t w = (jt >= 0 && jt < g.Wt) ? trow[(int64_t)jt * NW + m] : 0u;
-            lds4[(2 * m) * WIN + y] = make_uint4(nibble_bytes_x4(w, 0), nibble_bytes_x4(w, 1), nibble_bytes_x4(w, 2), nibble_bytes_x4(w, 3));
-            lds4[(2 * m + 1) * WIN + y] = make_uint4(nibble_bytes_x4(w, 4), nibble_bytes_x4(w, 5), nibble_bytes_x4(w, 6), nibble_bytes_x4(w, 7));
-        }
-    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int64_t row = (int64_t)i * g.Ws;
+    // ---- every global load of the kernel up front: the source words of this wave's column tiles, then the target window
+    uint32_t sword[CT][NW];
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        const int j = j0 + (wave * CT + c) * 32 + r;
+        const uint32_t *sp = g.sw + (row + min(j, g.Ws - 1)) * NW;
+#pragma unroll
+        for (int m = 0; m < NW; m++) sword[c][m] = sp[m];
+    }
+    // ---- byte -> eight bytes tables: bit b of the byte as 0 / 4 (target) and as +64 / -64 (source).  Expanding a word through
+    // them costs 8 VALU instructions and 4 LDS reads instead of 24 VALU instructions.
+    uint2 *lut_t = reinterpret_cast<uint2 *>(lds4 + 2 * NW * WIN + 512), *lut_s = lut_t + 256;
+    for (int b = threadIdx.x; b < 256; b += 64 * WAVES) {
+        lut_t[b] = make_uint2(nibble_bytes_x4(b, 0), nibble_bytes_x4(b, 1));
+        lut_s[b] = make_uint2(__builtin_amdgcn_perm(0u, 0x0000C040u, nibble_bytes(b, 0)), __builtin_amdgcn_perm(0u, 0x0000C040u, nibble_bytes(b, 1)));
+    }
+    // ---- the target window as 0/4 bytes; window pixel y is target column j0 + lower + y (zero vector outside the image)
+    {
+        const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
+        constexpr int CH = 8; // loads in flight per thread before the first expansion
+        const int n = WIN * NW;
+        bool tables_ready = false;
+        for (int e0 = threadIdx.x; e0 < n; e0 += CH * 64 * WAVES) {
+            uint32_t w[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int e = e0 + u * 64 * WAVES, y = e / NW, m = e - y * NW;
+                const int jt = j0 + g.disp_lower + y;
+                w[u] = (e < n && jt >= 0 && jt < g.Wt) ? trow[(int64_t)jt * NW + m] : 0u;
+            }
+            if (!tables_ready) { // (uniform) the loads above are in flight while the tables complete
+                __syncthreads();
+                tables_ready = true;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int e = e0 + u * 64 * WAVES, y = e / NW, m = e - y * NW;
+                if (e < n) {
+                    const uint2 b0 = lut_t[w[u] & 0xFFu], b1 = lut_t[(w[u] >> 8) & 0xFFu], b2 = lut_t[(w[u] >> 16) & 0xFFu], b3 = lut_t[w[u] >> 24];
+                    lds4[(2 * m) * WIN + y] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                    lds4[(2 * m + 1) * WIN + y] = make_uint4(b2.x, b2.y, b3.x, b3.y);
+                }
+            }
+        }
+        if (!tables_ready) __syncthreads(); // (threads that staged nothing still take part in the barrier)
+    }
     // ---- accumulator starts: 15 - reg for full tiles (in registers), and for the two triangular tiles the same with the invalid
     // cells pushed out of reach (in LDS behind the window: read twice per column tile)
     // (the zero is opaque to the compiler on purpose: a start pattern it can rematerialise it rebuilds in the accumulator registers
@@ -121,26 +158,33 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
         // source fragment (+64 / -64 bytes of this lane's half of every word) and |s|
         v4i bfrag[NW];
         int ones = 0;
-        {
-            const uint32_t *sp = g.sw + (row + min(j, g.Ws - 1)) * NW;
 #pragma unroll
-            for (int m = 0; m < NW; m++) {
-                const uint32_t w = sp[m];
-                ones += __popc(w);
-                const uint32_t half = (w >> (16 * h)) & 0xFFFFu;
+        for (int m = 0; m < NW; m++) {
+            uint32_t w = sword[0][m];
 #pragma unroll
-                for (int q = 0; q < 4; q++) // the 0/1 bytes select byte 0 (+64) or byte 1 (-64) of the table
-                    bfrag[m][q] = (int)__builtin_amdgcn_perm(0u, 0x0000C040u, nibble_bytes(half, q));
-            }
+            for (int cc = 1; cc < CT; cc++) w = c == cc ? sword[cc][m] : w; // c is wave uniform: scalar selects, no indexed registers
+            ones += __popc(w);
+            const uint32_t half = w >> (16 * h);
+            const uint2 lo = lut_s[half & 0xFFu], hi = lut_s[(half >> 8) & 0xFFu];
+            bfrag[m] = (v4i){(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
         }
         const uint4 *arow = lds4 + h * WIN + ct * 32 + r; // row tile k, word m: arow[2 m WIN + 32 k]
-        auto tile = [&](int k, const v16i &start) {
-            v16i a = start;
+        struct Frags {
+            v4i w[NW];
+        };
+        auto load_frags = [&](int k) {
+            Frags f;
 #pragma unroll
             for (int m = 0; m < NW; m++) {
                 const uint4 t = arow[2 * m * WIN + 32 * k];
-                a = __builtin_amdgcn_mfma_i32_32x32x32_i8((v4i){(int)t.x, (int)t.y, (int)t.z, (int)t.w}, bfrag[m], a, 0, 0, 0);
+                f.w[m] = (v4i){(int)t.x, (int)t.y, (int)t.z, (int)t.w};
             }
+            return f;
+        };
+        auto tile = [&](const Frags &f, const v16i &start) {
+            v16i a = start;
+#pragma unroll
+            for (int m = 0; m < NW; m++) a = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.w[m], bfrag[m], a, 0, 0, 0);
             return a;
         };
         // Region bookkeeping (wave uniform).  Row tile k covers target columns t0 + 32 k ...; tiles below k_switch lie in the
@@ -150,23 +194,27 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
         const int k_switch = below <= 0 ? 0 : min(below >> 5, NT);
         const bool straddle = below > 0 && (below & 31) != 0 && k_switch < NT;
         int G = BIG_G, G0 = BIG_G;
-        auto epilogue = [&](const v16i &a, int k) {
-            if (k == k_switch) { // once per column tile
-                asm volatile("; region switch" ::: "memory"); // keep this a branch: if-converted it costs selects in every tile
-                if (straddle) {
-                    int m0 = BIG_CELL, m1 = BIG_CELL;
+        // `checked`: this column tile has the Pout boundary inside its row tiles (only near the right image border); the others
+        // run the loop without the per-tile region test
+        auto epilogue = [&](const v16i &a, int k, auto checked) {
+            if constexpr (decltype(checked)::value) {
+                if (k == k_switch) { // once per column tile
+                    asm volatile("; region switch" ::: "memory"); // keep this a branch: if-converted it costs selects in every tile
+                    if (straddle) {
+                        int m0 = BIG_CELL, m1 = BIG_CELL;
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg++) {
-                        const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below;
-                        m0 = min(m0, pays ? BIG_CELL : a[reg]);
-                        m1 = min(m1, pays ? a[reg] : BIG_CELL);
+                        for (int reg = 0; reg < 16; reg++) {
+                            const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below;
+                            m0 = min(m0, pays ? BIG_CELL : a[reg]);
+                            m1 = min(m1, pays ? a[reg] : BIG_CELL);
+                        }
+                        G0 = min(G, m0 + 16 * (15 - k));
+                        G = m1 + 16 * (15 - k);
+                        return;
                     }
-                    G0 = min(G, m0 + 16 * (15 - k));
-                    G = m1 + 16 * (15 - k);
-                    return;
+                    G0 = G;
+                    G = BIG_G;
                 }
-                G0 = G;
-                G = BIG_G;
             }
             const int t1 = min3i(a[0], a[1], a[2]), t2 = min3i(a[3], a[4], a[5]), t3 = min3i(a[6], a[7], a[8]), t4 = min3i(a[9], a[10], a[11]),
                       t5 = min3i(a[12], a[13], a[14]);
@@ -174,26 +222,38 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
             const int tile_tag = __builtin_amdgcn_readfirstlane(16 * (15 - k)); // one SGPR operand: a v_add each, not v_add3 + literal
             G = min3i(G, t6 + tile_tag, t7 + tile_tag);
         };
-        // NT >= 2: tile 0 and tile NT - 1 are the triangular ones; the loop body only meets full tiles, two per round
-        {
-            const v16i acc = tile(0, edge_tile(0));
-            epilogue(acc, 0);
-        }
-        int k = 1;
-        for (; k + 1 < NT - 1; k += 2) {
-            const v16i acc_a = tile(k, full_tile), acc_b = tile(k + 1, full_tile);
-            epilogue(acc_a, k);
-            epilogue(acc_b, k + 1);
-        }
-        if (k < NT - 1) {
-            const v16i acc = tile(k, full_tile);
-            epilogue(acc, k);
-        }
-        {
-            const v16i acc = tile(NT - 1, edge_tile(1));
-            epilogue(acc, NT - 1);
-        }
-        int G1 = G;
+        // NT >= 2: tile 0 and tile NT - 1 are the triangular ones, the loop body only meets full tiles.  Software pipeline: the
+        // fragments of tile k + 1 are in registers and the MFMAs of tile k in flight while the epilogue of tile k - 1 runs, so
+        // neither the LDS latency nor the matrix pipe's sits between two epilogues of a wave.
+        auto sweep_tiles = [&](auto checked) {
+            Frags f_next = load_frags(0);
+            v16i acc_a = tile(f_next, edge_tile(0)), acc_b;
+            f_next = load_frags(1);
+            int k = 0; // invariant: acc_a = tile k (in flight), f_next = fragments of tile k + 1
+            for (; k + 2 < NT - 1; k += 2) {
+                acc_b = tile(f_next, full_tile);
+                f_next = load_frags(k + 2);
+                epilogue(acc_a, k, checked);
+                acc_a = tile(f_next, full_tile);
+                f_next = load_frags(k + 3);
+                epilogue(acc_b, k + 1, checked);
+            }
+            if (k + 2 == NT - 1) {
+                acc_b = tile(f_next, full_tile);
+                f_next = load_frags(k + 2);
+                epilogue(acc_a, k, checked);
+                acc_a = tile(f_next, edge_tile(1));
+                epilogue(acc_b, k + 1, checked);
+                epilogue(acc_a, k + 2, checked);
+            } else { // k + 1 == NT - 1
+                acc_b = tile(f_next, edge_tile(1));
+                epilogue(acc_a, k, checked);
+                epilogue(acc_b, k + 1, checked);
+            }
+        };
+        if (k_switch >= NT || (k_switch == 0 && !straddle)) sweep_tiles(std::false_type{}); // one region: no test inside
+        else sweep_tiles(std::true_type{});
+        int G1 = G; // (all tiles pay, or the tiles from the boundary on)
         if (k_switch >= NT) { // no tile pays
             G0 = G;
             G1 = BIG_G;
@@ -229,7 +289,7 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
     int64_t best_pad = 0;
     for (int ct = 4; ct >= 2; ct--) {
         const int pxb = 4 * ct * 32;
-        if (((size_t)2 * NW * (pxb + g.D) + 512) * sizeof(uint4) > 64 * 1024) continue;
+        if (((size_t)2 * NW * (pxb + g.D) + 512 + 256) * sizeof(uint4) > 64 * 1024) continue;
         const int64_t pad = (int64_t)ceil_div(g.Ws, pxb) * pxb;
         if (!best_ct || pad < best_pad) {
             best_ct = ct;
@@ -237,7 +297,7 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
         }
     }
     if (!best_ct) return false;
-    const size_t shmem = ((size_t)2 * NW * (4 * best_ct * 32 + g.D) + 512) * sizeof(uint4); // window + the two edge patterns
+    const size_t shmem = ((size_t)2 * NW * (4 * best_ct * 32 + g.D) + 512 + 256) * sizeof(uint4); // window + the two edge patterns + the byte tables
     switch (best_ct) {
     case 4: *status = launch_config<NW, 4, 4>(ctx, g, Pout, keys, gmap, shmem); break;
     case 3: *status = launch_config<NW, 4, 3>(ctx, g, Pout, keys, gmap, shmem); break;

@@ -28,6 +28,7 @@ import torch  # noqa: E402
 WORKLOAD = dict(W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=3,
                 bg=8, sq=64, side=320, v=320, h=380)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md, matrix cores: int8 runs at twice the BF16 rate, BF16 dense ~2.5 PFLOP/s
 
 
 def visited_voxels_per_pass(H, W, D, n_pass):
@@ -47,6 +48,7 @@ def algorithmic_bytes(kernel, wl):
     px, vox = H * W, H * W * D
     table = {
         "census_sweep": 28.0 * vox,
+        "census_sweep_mfma": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
         "sgm_line_scans": 4.0 * px + 6 * 4.0 * px,   # g read + six min_p maps written
         "census_finalize": (8.0 + 24.0 + 4.0) * px,  # keys + six min_p maps + disparity
@@ -208,24 +210,34 @@ def main():
         dom_ms, dom_n = prof[dom_name]
         avg_ms = dom_ms / max(dom_n, 1)
         alg = algorithmic_bytes(dom_name, wl1)
-        roof = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "traffic": None}
+        hbm_model = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "traffic": None, "model": "SURVEY.md 8(d) row C3 prices this launch at 28 B/voxel of volume traffic the fused design never generates"}
         if alg is not None:
             ach = alg / (avg_ms * 1e-3) / 1e9
-            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(alg)})
+            hbm_model.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(alg)})
         else:
-            roof.update({"achieved": None, "frac": None})
+            hbm_model.update({"achieved": None, "frac": None})
         traffic = load_measured_traffic(dom_name)
         if traffic is not None:
-            roof["traffic"] = traffic
-        # The HBM model above prices traffic this design never generates; the roof that physically binds census_sweep is VALU
-        # issue.  Per 64 voxels a SIMD issues 2 v_xor + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3; tools/ubench_valu.hip measures
-        # 2.76 / 4.58 / 4.46 / 4.55 cycles per wave-instruction and SIMD for them (in 2.4 GHz cycles, i.e. at the clock the chip
-        # actually holds under an all-VALU load): 21.4 cycles per 64 voxels; 256 CUs x 4 SIMDs.  The same mix issued from
-        # registers only (no LDS, ubench "sweep mix") reaches 6.2 Tvoxels/s including its loop overhead.
-        issue = None
-        if dom_name == "census_sweep":
-            vox_launch = wl1["W"] * wl1["H"] * wl1["D"]
+            hbm_model["traffic"] = traffic
+        roof, issue = hbm_model, None
+        vox_launch = wl1["W"] * wl1["H"] * wl1["D"]
+        if dom_name == "census_sweep_mfma":
+            # The sweep runs on the matrix cores: the Hamming distance of two 64-bit census records is a 64-term int8 dot product
+            # (svh_census_sweep_mfma.hip), i.e. 128 int8 operations per voxel; these are the algorithmic operations of a launch.
+            # The kernel issues 9/8 of them (the band of D disparities is covered by D/32 + 1 row tiles of 32).
+            bits = 32 * (((2 * wl1["h_r"] + 1) * (2 * wl1["v_r"] + 1) - 1) // 32)  # census words that are written: 9x9 -> 64 bits
+            ops = 2.0 * bits * vox_launch
+            ach = ops / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "achieved": round(ach, 1),
+                    "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
+                    "dtype": "int8 multiply-accumulate, int32 accumulators (exact)",
+                    "algorithmic_ops_per_launch": int(ops), "ops_per_voxel": 2 * bits,
+                    "note": "v_mfma_i32_32x32x32_i8; peak = dense int8 rate at the nominal clock (the chip holds ~1.7 GHz under this load)"}
+        elif dom_name == "census_sweep":
+            # The vector-ALU engine (svh_context_set_option census_sweep = 1): the roof that binds it is VALU issue.  Per 64 voxels a
+            # SIMD issues 2 v_xor + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3; tools/ubench_valu.hip measures 2.76 / 4.58 / 4.46 / 4.55
+            # cycles per wave-instruction and SIMD for them: 21.4 cycles per 64 voxels; 256 CUs x 4 SIMDs.
             cyc = 2 * 2.76 + 2 * 4.58 + 4.46 + 0.5 * 4.55
             peak_vox = 1024 * 2.4e9 / cyc * 64.0
             ach_vox = vox_launch / (avg_ms * 1e-3)
@@ -246,6 +258,7 @@ def main():
                                        "all-reduce of the regional winner keys (8 B/pixel) per frame, overlapped with the next frame's key "
                                        "kernels (one exchange in flight)") if world > 1 else "single GPU"},
             "roofline": roof,
+            "hbm_model_roofline": hbm_model if roof is not hbm_model else None,
             "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                   "model": "SURVEY.md 8(d) C3: 28 B/voxel + 60 B/pixel"},

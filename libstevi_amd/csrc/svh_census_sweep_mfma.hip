@@ -52,9 +52,9 @@ __device__ __forceinline__ constexpr int row_of_reg(int reg) { return (reg & 3) 
 // of the matrix pipe as
 //     a[reg] = 256 (c - |s|) + 15 - reg
 // which already orders the 16 cells of a lane the way the reference breaks ties (the larger row, i.e. the larger disparity, wins):
-// the tile minimum is a plain min tree, no per-cell instruction.  Row tile k adds 16 (15 - k) to its minimum (bits 4..7, between
-// the cost and the cell: cost first, then the later tile, then the later cell) and the running minimum is decoded once per pixel
-// at the end.  Four bits of tile index: D <= 480.
+// the tile minimum is a plain min tree, no per-cell instruction.  Row tile k carries the tag 16 (15 - k) (bits 4..7, between the
+// cost and the cell: cost first, then the later tile, then the later cell); the running minimum lives in the frame of the current
+// tile (G <- min(G + 16, tile minimum): one add per tile) and is decoded once per pixel at the end.  Four tag bits: D <= 480.
 template <int NW, int WAVES, int CT>
 __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap) {
     constexpr int PXB = WAVES * CT * 32; // source pixels per block
@@ -81,35 +81,37 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
         lut_t[b] = make_uint2(nibble_bytes_x4(b, 0), nibble_bytes_x4(b, 1));
         lut_s[b] = make_uint2(__builtin_amdgcn_perm(0u, 0x0000C040u, nibble_bytes(b, 0)), __builtin_amdgcn_perm(0u, 0x0000C040u, nibble_bytes(b, 1)));
     }
-    // ---- the target window as 0/4 bytes; window pixel y is target column j0 + lower + y (zero vector outside the image)
+    // ---- the target window as 0/4 bytes; window pixel y is target column j0 + lower + y (zero vector outside the image).  A thread
+    // takes whole pixels (all NW words: one address, one bounds test), PPT of them with every load issued before the first table
+    // look-up; the barrier that completes the tables sits under those loads.
     {
         const uint32_t *trow = g.tw + (int64_t)i * g.Wt * NW;
-        constexpr int CH = 8; // loads in flight per thread before the first expansion
-        const int n = WIN * NW;
-        bool tables_ready = false;
-        for (int e0 = threadIdx.x; e0 < n; e0 += CH * 64 * WAVES) {
-            uint32_t w[CH];
+        constexpr int PPT = 4; // pixels per thread and round
+        for (int y0 = threadIdx.x; y0 < WIN; y0 += PPT * 64 * WAVES) { // (first round: every thread enters, WIN > 64 WAVES)
+            uint32_t w[PPT][NW];
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-                const int e = e0 + u * 64 * WAVES, y = e / NW, m = e - y * NW;
-                const int jt = j0 + g.disp_lower + y;
-                w[u] = (e < n && jt >= 0 && jt < g.Wt) ? trow[(int64_t)jt * NW + m] : 0u;
-            }
-            if (!tables_ready) { // (uniform) the loads above are in flight while the tables complete
-                __syncthreads();
-                tables_ready = true;
-            }
+            for (int u = 0; u < PPT; u++) {
+                const int y = y0 + u * 64 * WAVES, jt = j0 + g.disp_lower + y;
+                const bool inside = y < WIN && jt >= 0 && jt < g.Wt;
+                const uint32_t *tp = trow + (int64_t)(inside ? jt : 0) * NW;
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-                const int e = e0 + u * 64 * WAVES, y = e / NW, m = e - y * NW;
-                if (e < n) {
-                    const uint2 b0 = lut_t[w[u] & 0xFFu], b1 = lut_t[(w[u] >> 8) & 0xFFu], b2 = lut_t[(w[u] >> 16) & 0xFFu], b3 = lut_t[w[u] >> 24];
-                    lds4[(2 * m) * WIN + y] = make_uint4(b0.x, b0.y, b1.x, b1.y);
-                    lds4[(2 * m + 1) * WIN + y] = make_uint4(b2.x, b2.y, b3.x, b3.y);
+                for (int m = 0; m < NW; m++) w[u][m] = inside ? tp[m] : 0u;
+            }
+            if (y0 == (int)threadIdx.x) __syncthreads(); // first round (uniform): the tables are complete
+#pragma unroll
+            for (int u = 0; u < PPT; u++) {
+                const int y = y0 + u * 64 * WAVES;
+                if (y < WIN) {
+#pragma unroll
+                    for (int m = 0; m < NW; m++) {
+                        const uint32_t v = w[u][m];
+                        const uint2 b0 = lut_t[v & 0xFFu], b1 = lut_t[(v >> 8) & 0xFFu], b2 = lut_t[(v >> 16) & 0xFFu], b3 = lut_t[v >> 24];
+                        lds4[(2 * m) * WIN + y] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+                        lds4[(2 * m + 1) * WIN + y] = make_uint4(b2.x, b2.y, b3.x, b3.y);
+                    }
                 }
             }
         }
-        if (!tables_ready) __syncthreads(); // (threads that staged nothing still take part in the barrier)
     }
     // ---- accumulator starts: 15 - reg for full tiles (in registers), and for the two triangular tiles the same with the invalid
     // cells pushed out of reach (in LDS behind the window: read twice per column tile)
@@ -121,19 +123,16 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) full_tile[reg] = 15 - reg + opaque_zero;
     uint4 *edge = lds4 + 2 * NW * WIN; // [first, last][4 register quads][64 lanes]
-    if (wave == 0) {
+    for (int q = wave; q < 8; q += WAVES) { // eight register quads (first tile 0..3, last tile 4..7) shared out over the waves
+        int v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            int f[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int reg = 4 * q + e, rr = row_of_reg(reg) + 4 * h;
-                f[e] = 15 - reg + (rr >= r ? 0 : BIG_CELL); // tile 0: d = row - col >= 0
-                l[e] = 15 - reg + (rr < r ? 0 : BIG_CELL);  // tile D/32: d = D + row - col < D
-            }
-            edge[q * 64 + lane] = make_uint4(f[0], f[1], f[2], f[3]);
-            edge[(4 + q) * 64 + lane] = make_uint4(l[0], l[1], l[2], l[3]);
+        for (int e = 0; e < 4; e++) {
+            const int reg = 4 * (q & 3) + e, rr = row_of_reg(reg) + 4 * h;
+            const bool valid = q < 4 ? rr >= r   // tile 0: d = row - col >= 0
+                                     : rr < r;   // tile D/32: d = D + row - col < D
+            v[e] = 15 - reg + (valid ? 0 : BIG_CELL);
         }
+        edge[q * 64 + lane] = make_uint4(v[0], v[1], v[2], v[3]);
     }
     auto edge_tile = [&](int which) {
         v16i a;
@@ -202,25 +201,26 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
                     asm volatile("; region switch" ::: "memory"); // keep this a branch: if-converted it costs selects in every tile
                     if (straddle) {
                         int m0 = BIG_CELL, m1 = BIG_CELL;
+                        int below_here = below;
+                        asm volatile("; straddling tile" : "+s"(below_here)); // or the 16 compares below are hoisted in front of every column tile
 #pragma unroll
                         for (int reg = 0; reg < 16; reg++) {
-                            const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below;
+                            const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below_here;
                             m0 = min(m0, pays ? BIG_CELL : a[reg]);
                             m1 = min(m1, pays ? a[reg] : BIG_CELL);
                         }
-                        G0 = min(G, m0 + 16 * (15 - k));
-                        G = m1 + 16 * (15 - k);
+                        G0 = min(G + 16, m0) + 16 * (15 - k); // leaves the frame: absolute tile tag
+                        G = m1;
                         return;
                     }
-                    G0 = G;
+                    G0 = G + 16 * (15 - (k - 1)); // (frame of tile k - 1; k_switch = 0 never gets here with anything but BIG_G)
                     G = BIG_G;
                 }
             }
             const int t1 = min3i(a[0], a[1], a[2]), t2 = min3i(a[3], a[4], a[5]), t3 = min3i(a[6], a[7], a[8]), t4 = min3i(a[9], a[10], a[11]),
                       t5 = min3i(a[12], a[13], a[14]);
             const int t6 = min3i(t1, t2, t3), t7 = min3i(t4, t5, a[15]);
-            const int tile_tag = __builtin_amdgcn_readfirstlane(16 * (15 - k)); // one SGPR operand: a v_add each, not v_add3 + literal
-            G = min3i(G, t6 + tile_tag, t7 + tile_tag);
+            G = min3i(G + 16, t6, t7); // frame of tile k: min over the tiles so far of (tile minimum + 16 (k - tile))
         };
         // NT >= 2: tile 0 and tile NT - 1 are the triangular ones, the loop body only meets full tiles.  Software pipeline: the
         // fragments of tile k + 1 are in registers and the MFMAs of tile k in flight while the epilogue of tile k - 1 runs, so
@@ -253,11 +253,11 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
         };
         if (k_switch >= NT || (k_switch == 0 && !straddle)) sweep_tiles(std::false_type{}); // one region: no test inside
         else sweep_tiles(std::true_type{});
-        int G1 = G; // (all tiles pay, or the tiles from the boundary on)
-        if (k_switch >= NT) { // no tile pays
-            G0 = G;
-            G1 = BIG_G;
-        }
+        // out of the frame (tile NT - 1): the absolute tag of tile k is 16 (15 - k)
+        const int G_abs = G + 16 * (15 - (NT - 1));
+        const bool none_pays = k_switch >= NT, all_pay = k_switch == 0 && !straddle; // (wave uniform)
+        const int G1 = none_pays ? BIG_G : G_abs;
+        if (none_pays) G0 = G_abs;
         // ---- decode (tile, cell) -> key; the two lane halves hold different rows of the same pixel: merge, store
         auto decode = [&](int gv) {
             const int kk = 15 - ((gv >> 4) & 15);
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
             const int d_local = 32 * kk + (reg & 3) + 8 * (reg >> 2) + 4 * h - r;
             return gv < G_VALID_BELOW ? (int)make_key(cost, g.d_offset + d_local) : (int)KEY_NONE;
         };
-        int a0 = decode(G0), a1 = decode(G1);
+        int a0 = all_pay ? (int)KEY_NONE : decode(G0), a1 = none_pays ? (int)KEY_NONE : decode(G1);
         a0 = min(a0, __shfl_xor(a0, 32));
         a1 = min(a1, __shfl_xor(a1, 32));
         if (h == 0 && j < g.Ws) {
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma_kernel(CensusGeo
 template <int NW, int WAVES, int CT> int launch_config(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, size_t shmem) {
     constexpr int PXB = WAVES * CT * 32;
     dim3 grid(ceil_div(g.Ws, PXB), g.H);
-    SVH_LAUNCH(ctx, "census_sweep", (census_sweep_mfma_kernel<NW, WAVES, CT>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap);
+    SVH_LAUNCH(ctx, "census_sweep_mfma", (census_sweep_mfma_kernel<NW, WAVES, CT>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SVH_OK : fail(ctx, SVH_ERR_HIP, "census_sweep (mfma): %s", hipGetErrorString(e));
 }

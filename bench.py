@@ -28,7 +28,8 @@ import torch  # noqa: E402
 WORKLOAD = dict(W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=3,
                 bg=8, sq=64, side=320, v=320, h=380)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-I8_MFMA_PEAK_TOPS = 5000.0  # MI355X_MICROARCH.md, matrix cores: int8 runs at twice the BF16 rate, BF16 dense ~2.5 PFLOP/s
+# MI355X_MICROARCH.md, matrix cores (dense): BF16 ~2.5 PFLOP/s; int8 runs at twice the BF16 rate, block-scaled FP4 at four times
+MFMA_PEAK_TOPS = {"census_sweep_mfma": 5000.0, "census_sweep_mfma4": 10000.0}
 
 
 def visited_voxels_per_pass(H, W, D, n_pass):
@@ -49,6 +50,7 @@ def algorithmic_bytes(kernel, wl):
     table = {
         "census_sweep": 28.0 * vox,
         "census_sweep_mfma": 28.0 * vox,
+        "census_sweep_mfma4": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
         "sgm_line_scans": 4.0 * px + 6 * 4.0 * px,   # g read + six min_p maps written
         "census_finalize": (8.0 + 24.0 + 4.0) * px,  # keys + six min_p maps + disparity
@@ -222,18 +224,22 @@ def main():
             hbm_model["traffic"] = traffic
         roof, issue = hbm_model, None
         vox_launch = wl1["W"] * wl1["H"] * wl1["D"]
-        if dom_name == "census_sweep_mfma":
-            # The sweep runs on the matrix cores: the Hamming distance of two 64-bit census records is a 64-term int8 dot product
-            # (svh_census_sweep_mfma.hip), i.e. 128 int8 operations per voxel; these are the algorithmic operations of a launch.
-            # The kernel issues 9/8 of them (the band of D disparities is covered by D/32 + 1 row tiles of 32).
+        if dom_name in MFMA_PEAK_TOPS:
+            # The sweep runs on the matrix cores: the Hamming distance of two 64-bit census records is a 64-term dot product of
+            # 0 / +-1 operands (svh_census_sweep_mfma4.hip: FP4 operands, exact in the f32 accumulators; svh_census_sweep_mfma.hip:
+            # int8), i.e. 128 operations per voxel; these are the algorithmic operations of a launch.  The kernel issues 9/8 of them
+            # (the band of D disparities is covered by D/32 + 1 row tiles of 32).
+            peak = MFMA_PEAK_TOPS[dom_name]
+            fp4 = dom_name.endswith("4")
             bits = 32 * (((2 * wl1["h_r"] + 1) * (2 * wl1["v_r"] + 1) - 1) // 32)  # census words that are written: 9x9 -> 64 bits
             ops = 2.0 * bits * vox_launch
             ach = ops / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "achieved": round(ach, 1),
-                    "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
-                    "dtype": "int8 multiply-accumulate, int32 accumulators (exact)",
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "dtype": "fp4 (e2m1) operands 0 / +-1, f32 accumulators (exact integers)" if fp4 else "int8 multiply-accumulate, int32 accumulators (exact)",
                     "algorithmic_ops_per_launch": int(ops), "ops_per_voxel": 2 * bits,
-                    "note": "v_mfma_i32_32x32x32_i8; peak = dense int8 rate at the nominal clock (the chip holds ~1.7 GHz under this load)"}
+                    "note": ("v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 x FP4)" if fp4 else "v_mfma_i32_32x32x32_i8") +
+                            "; peak = dense rate of the operand type at the nominal clock (the chip holds ~1.7 GHz under this load)"}
         elif dom_name == "census_sweep":
             # The vector-ALU engine (svh_context_set_option census_sweep = 1): the roof that binds it is VALU issue.  Per 64 voxels a
             # SIMD issues 2 v_xor + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3; tools/ubench_valu.hip measures 2.76 / 4.58 / 4.46 / 4.55

@@ -362,7 +362,7 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         return SVH_OK;
     }
     if (strcmp(name, "census_sweep") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_sweep: 0 (auto), 1 (vector ALU) or 2 (matrix cores)");
+        if (value < 0 || value > 3) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_sweep: 0 (auto), 1 (vector ALU), 2 (matrix cores, int8) or 3 (matrix cores, FP4)");
         ctx->census_sweep_mode = (int)value;
         return SVH_OK;
     }

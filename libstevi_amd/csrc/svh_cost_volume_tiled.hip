@@ -189,7 +189,6 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 // use the generic kernel (multi-channel images, windows wider than 11, tiles beyond the LDS budget).
 int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
     if (src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func)) return SVH_ERR_UNSUPPORTED;
-    const int h = 2 * h_r + 1, v = 2 * v_r + 1;
     const size_t shmem = pxlane_shmem(h_r, v_r, a.D);
     if (shmem > 60 * 1024) return SVH_ERR_UNSUPPORTED;
     if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;

@@ -1,7 +1,8 @@
-"""The two engines of census_sweep -- the vector-ALU kernel (xor + popcount) and the matrix-core kernel (Hamming distance as an
-int8 dot product, svh_census_sweep_mfma.hip) -- must give the same regional winner keys bit for bit, and both the oracle's
-disparities.  svh_context_set_option("census_sweep", 1 | 2) selects the engine; 0 (default) takes the matrix cores wherever
-they apply (RightToLeft, 1..4 census words, D a multiple of 32 up to 480) and the vector ALU elsewhere."""
+"""The three engines of census_sweep -- the vector-ALU kernel (xor + popcount), the matrix-core kernel with int8 operands
+(Hamming distance as a dot product, svh_census_sweep_mfma.hip) and the matrix-core kernel with FP4 operands
+(svh_census_sweep_mfma4.hip) -- must give the same regional winner keys bit for bit, and all the oracle's disparities.
+svh_context_set_option("census_sweep", 1 | 2 | 3) selects the engine; 0 (default) takes the matrix cores wherever they apply
+(RightToLeft, 1..4 census words, D a multiple of 32 up to 480) and the vector ALU elsewhere."""
 import numpy as np
 import pytest
 
@@ -22,7 +23,7 @@ DEV = torch.device("cuda:0")
 def both_engines(fn, probe):
     out = []
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             sv.set_option(probe, "census_sweep", mode)
             out.append(fn())
     finally:
@@ -43,9 +44,9 @@ def test_keys_and_disparities_agree(D, W):
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for h_r, n_dir, Pout in ((4, 8, 100.0), (3, 4, 7.0), (5, 8, 100.0), (4, 0, 100.0)):  # 2, 1 and 3 census words
         keys = both_engines(lambda: sv.censusShardKeys(l, r, h_r, h_r, D, (0, D), sgmDirections=n_dir, Pout=Pout).cpu().numpy(), l)
-        assert np.array_equal(keys[0], keys[1]), (h_r, n_dir)
+        assert all(np.array_equal(keys[0], k) for k in keys[1:]), (h_r, n_dir)
         disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, h_r, h_r, D, sgmDirections=n_dir, Pout=Pout)["disp"].cpu().numpy(), l)
-        assert np.array_equal(disp[0], disp[1])
+        assert all(np.array_equal(disp[0], d) for d in disp[1:])
         if W <= 384:
             assert np.array_equal(disp[1], oracle_disp(tgt, src, h_r, D, n_dir, Pout))
 
@@ -62,9 +63,9 @@ def test_ties_everywhere():
         l, r = torch.from_numpy(tgt.copy()).to(DEV), torch.from_numpy(src.copy()).to(DEV)
         for n_dir in (0, 8):
             keys = both_engines(lambda: sv.censusShardKeys(l, r, 4, 4, D, (0, D), sgmDirections=n_dir).cpu().numpy(), l)
-            assert np.array_equal(keys[0], keys[1])
+            assert all(np.array_equal(keys[0], k) for k in keys[1:])
             disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, 4, 4, D, sgmDirections=n_dir)["disp"].cpu().numpy(), l)
-            assert np.array_equal(disp[0], disp[1])
+            assert all(np.array_equal(disp[0], d) for d in disp[1:])
             assert np.array_equal(disp[1], oracle_disp(tgt, src, 4, D, n_dir, 100.0))
 
 
@@ -76,26 +77,27 @@ def test_shards_offsets_and_margins():
     D = 192
     for shard in ((0, 64), (64, 96), (160, 32)):
         keys = both_engines(lambda: sv.censusShardKeys(l, r, 4, 4, D, shard, sgmDirections=8, Pout=100.0).cpu().numpy(), l)
-        assert np.array_equal(keys[0], keys[1]), shard
+        assert all(np.array_equal(keys[0], k) for k in keys[1:]), shard
     for rng_ in (sv.searchOffset1(-40, 87), sv.searchOffset1(5, 68)):
         keys = both_engines(lambda: sv.censusShardKeys(l, r, 4, 4, rng_, (0, 128 if rng_.lower < 0 else 64), sgmDirections=8).cpu().numpy(), l)
-        assert np.array_equal(keys[0], keys[1])
+        assert all(np.array_equal(keys[0], k) for k in keys[1:])
     for margins in ((3, 2, 5, 1), (0, 0, 17, 0)):
         res = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, 4, 4, D, sgmDirections=8, Pout=9.0, margins=sv.Margins(*margins),
                                                   refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=4, refine_v_radius=4), l)
-        assert torch.equal(res[0]["disp"], res[1]["disp"])
-        a, b = res[0]["refined"].cpu().numpy(), res[1]["refined"].cpu().numpy()
-        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+        for other in res[1:]:
+            assert torch.equal(res[0]["disp"], other["disp"])
+            a, b = res[0]["refined"].cpu().numpy(), other["refined"].cpu().numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
         assert np.array_equal(res[1]["disp"].cpu().numpy(), oracle_disp(tgt, src, 4, D, 8, 9.0, margins))
 
 
 def test_geometries_outside_the_matrix_core_kernel_still_run():
-    """LeftToRight, D not a multiple of 32, D > 480, 13x13 windows (5 words): option 2 falls back to the vector ALU kernel."""
+    """LeftToRight, D not a multiple of 32, D > 480, 13x13 windows (5 words): options 2 and 3 fall back to the vector ALU kernel."""
     src, tgt, _ = parallax_pair(9, 260, 8, 3, 30, 2, 9, seed=5)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for kw in (dict(D=64, dDir=sv.dispDirection.LeftToRight, h=4), dict(D=70, dDir=sv.dispDirection.RightToLeft, h=4),
                dict(D=512, dDir=sv.dispDirection.RightToLeft, h=4), dict(D=64, dDir=sv.dispDirection.RightToLeft, h=6)):
         disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, kw["h"], kw["h"], kw["D"], dDir=kw["dDir"], sgmDirections=8)["disp"].cpu().numpy(), l)
-        assert np.array_equal(disp[0], disp[1])
+        assert all(np.array_equal(disp[0], d) for d in disp[1:])
     with pytest.raises(sv._capi.SvhError):
-        sv.set_option(l, "census_sweep", 3)
+        sv.set_option(l, "census_sweep", 4)

@@ -15,14 +15,16 @@ for (H, W, D, hr, Pout, nd) in [(37, 300, 256, 4, 100.0, 8), (37, 300, 256, 3, 1
     src, tgt, _ = parallax_pair(H, W, 12, 8, 40, 3, 17, seed=D)
     l, r = torch.from_numpy(tgt).to(dev), torch.from_numpy(src).to(dev)
     out = {}
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         sv.set_option(l, "census_sweep", mode)
         res = sv.stereoMatch(sv.matchingFunctions.CENSUS, l, r, hr, hr, D, sgmDirections=nd, Pout=Pout, shard=(0, D))
         keys = sv.censusShardKeys(l, r, hr, hr, D, (0, D), sgmDirections=nd, Pout=Pout)
         out[mode] = (res["disp"].cpu().numpy(), keys.cpu().numpy())
     sv.set_option(l, "census_sweep", 0)
-    dk = out[1][1] != out[2][1]
-    print((H, W, D, hr), "disp diff", int((out[1][0] != out[2][0]).sum()), "key diff", int(dk.sum()))
+    print((H, W, D, hr), "int8 vs valu: key diff", int((out[1][1] != out[2][1]).sum()))
+    dk = out[1][1] != out[3][1]
+    out[2] = out[3]
+    print((H, W, D, hr), "fp4 vs valu: disp diff", int((out[1][0] != out[3][0]).sum()), "key diff", int(dk.sum()))
     if dk.any():
         ii, jj, rr = np.nonzero(dk)
         for t in range(min(8, len(ii))):

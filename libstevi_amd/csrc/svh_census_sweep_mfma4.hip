@@ -4,8 +4,10 @@
 // tiles, the cell index in the accumulator's start value, the moving frame of the tile tag), with the bits expanded to FP4 (e2m1)
 // nibbles instead of int8 bytes and one v_mfma_scale_f32_32x32x64_f8f6f4 per 64 bits of census record:
 //
-//     target bit t -> 0 / +1.0 (nibble 0x0 / 0x2),   source bit s -> +1.0 / -1.0 (0x2 / 0xA),   block scales 2^2 and 2^6
-//     cell = 256 (c - |s|) + 15 - reg      as an exact float (all values are integers far below 2^24)
+//     target bit t -> 0 / +1.0 (nibble 0x0 / 0x2),   source bit s -> +1.0 / -1.0 (0x2 / 0xA),   block scales 2^3 and 2^6
+//     cell = 512 (c - |s|) + 15 - reg      as an exact float (all values are integers far below 2^24)
+//
+// (the block scales make any power of two free, so the tile tag gets five bits here: 16 (31 - k), D up to 992)
 //
 // What it buys: the LDS window is half the size (16 bytes per pixel and census word: four blocks per CU instead of three), a
 // tile needs one MFMA and one ds_read_b128 instead of two each, and the expansion writes half the bytes.  The minimum tree works
@@ -23,9 +25,9 @@ namespace {
 using v8i = int __attribute__((ext_vector_type(8)));
 using v16f = float __attribute__((ext_vector_type(16)));
 
-constexpr float BIG_CELL = 1048576.0f;       // accumulator start of an invalid cell: never the minimum of a tile that has a valid one
+constexpr float BIG_CELL = 4194304.0f;       // accumulator start of an invalid cell: never the minimum of a tile that has a valid one
 constexpr float BIG_G = 268435456.0f;          // "no candidate yet"
-constexpr float G_VALID_BELOW = 524288.0f;  // valid packed minima stay below 2^15
+constexpr float G_VALID_BELOW = 1048576.0f; // valid packed minima stay below 2^16
 
 // the eight bits of a byte as eight FP4 nibbles: 0 / +1.0 for target bits, +1.0 / -1.0 for source bits
 __device__ __forceinline__ uint32_t byte_nibbles(uint32_t b, uint32_t clear, uint32_t set) {
@@ -178,8 +180,8 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
         auto tile = [&](const Frags &f, const v16f &start) {
             v16f a = start;
 #pragma unroll
-            for (int gq = 0; gq < NG; gq++) // FP4 x FP4, block scales 2^2 (E8M0 129) and 2^6 (133): a differing bit adds 256
-                a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.w[gq], bfrag[gq], a, 4, 4, 0, 129, 0, 133);
+            for (int gq = 0; gq < NG; gq++) // FP4 x FP4, block scales 2^3 (E8M0 130) and 2^6 (133): a differing bit adds 512
+                a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.w[gq], bfrag[gq], a, 4, 4, 0, 130, 0, 133);
             return a;
         };
         // Region bookkeeping (wave uniform).  Row tile k covers target columns t0 + 32 k ...; tiles below k_switch lie in the
@@ -205,11 +207,11 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
                             m0 = __builtin_fminf(m0, pays ? BIG_CELL : a[reg]);
                             m1 = __builtin_fminf(m1, pays ? a[reg] : BIG_CELL);
                         }
-                        G0 = __builtin_fminf(G + 16.0f, m0) + (float)(16 * (15 - k)); // leaves the frame: absolute tile tag
+                        G0 = __builtin_fminf(G + 16.0f, m0) + (float)(16 * (31 - k)); // leaves the frame: absolute tile tag
                         G = m1;
                         return;
                     }
-                    G0 = G + (float)(16 * (15 - (k - 1))); // (frame of tile k - 1; k_switch = 0 never gets here with anything but BIG_G)
+                    G0 = G + (float)(16 * (31 - (k - 1))); // (frame of tile k - 1; k_switch = 0 never gets here with anything but BIG_G)
                     G = BIG_G;
                 }
             }
@@ -249,16 +251,16 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
         };
         if (k_switch >= NT || (k_switch == 0 && !straddle)) sweep_tiles(std::false_type{}); // one region: no test inside
         else sweep_tiles(std::true_type{});
-        // out of the frame (tile NT - 1): the absolute tag of tile k is 16 (15 - k)
-        const float G_abs = G + (float)(16 * (15 - (NT - 1)));
+        // out of the frame (tile NT - 1): the absolute tag of tile k is 16 (31 - k)
+        const float G_abs = G + (float)(16 * (31 - (NT - 1)));
         const bool none_pays = k_switch >= NT, all_pay = k_switch == 0 && !straddle; // (wave uniform)
         const float G1 = none_pays ? BIG_G : G_abs;
         if (none_pays) G0 = G_abs;
         // ---- decode (tile, cell) -> key; the two lane halves hold different rows of the same pixel: merge, store
         auto decode = [&](float gf) {
             const int gv = (int)gf; // exact: an integer below 2^24
-            const int kk = 15 - ((gv >> 4) & 15);
-            const int reg = 15 - (gv & 15), cost = ones + (gv >> 8);
+            const int kk = 31 - ((gv >> 4) & 31);
+            const int reg = 15 - (gv & 15), cost = ones + (gv >> 9);
             const int d_local = 32 * kk + (reg & 3) + 8 * (reg >> 2) + 4 * h - r;
             return gf < G_VALID_BELOW ? (int)make_key(cost, g.d_offset + d_local) : (int)KEY_NONE;
         };
@@ -306,7 +308,7 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
 } // namespace
 
 bool launch_sweep_mfma4(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status) {
-    if (g.sign <= 0 || g.D < 32 || (g.D & 31) != 0 || g.D > 480 || g.nWw < 1 || g.nWw > 4) return false;
+    if (g.sign <= 0 || g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 4) return false;
     switch (g.nWw) {
     case 1: return launch_for_words<1>(ctx, g, Pout, keys, gmap, status);
     case 2: return launch_for_words<2>(ctx, g, Pout, keys, gmap, status);

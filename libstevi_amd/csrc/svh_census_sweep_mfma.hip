@@ -8,16 +8,17 @@
 //
 //     popcount(s xor t) = |s| + sum_b t_b (1 - 2 s_b)
 //
-// so with the target bits as 0/1 bytes (operand A: rows = 32 target columns) and the source bits as +1/-1 bytes (operand B:
-// columns = 32 source pixels) one v_mfma_i32_32x32x32_i8 per 32 bits of census record yields 32 x 32 costs (minus |s|, a
-// per-lane constant).  In the accumulator layout a lane owns ONE source pixel and 16 target columns, so the running minimum over
+// so with the target bits as 0 / 4 bytes (operand A: rows = 32 target columns) and the source bits as +64 / -64 bytes (operand B:
+// columns = 32 source pixels) one v_mfma_i32_32x32x32_i8 per 32 bits of census record yields 32 x 32 costs (times 256, minus
+// |s|, a per-lane constant).  In the accumulator layout a lane owns ONE source pixel and 16 target columns, so the running minimum over
 // disparities stays inside the lane, and with the cell index riding in the accumulator's start value (see the kernel) the
-// minimum of 1024 voxels is eight v_min3 plus three instructions per tile instead of 16 x 5.5 VALU instructions; the matrix pipe
-// runs beside them.  Integer arithmetic throughout: results are the VALU sweep's, bit for bit (the parity tests run both,
-// svh_context_set_option("census_sweep", ...)).
+// minimum of 1024 voxels is eight v_min3 and one add per tile instead of 16 x 5.5 VALU instructions; the matrix pipe runs beside
+// them.  Integer arithmetic throughout: results are the VALU sweep's, bit for bit (the parity tests run both,
+// svh_context_set_option("census_sweep", ...)).  This is the int8 form (engine 2); svh_census_sweep_mfma4.hip is the same kernel with
+// FP4 operands (engine 3, the default: half the matrix-pipe time, half the LDS window).
 //
-// Geometry.  A wave owns CT column tiles (of 32 source pixels) and takes them one after the other; column tile c meets the row tiles k = 0 .. D/32 of the target
-// window, row tile k starting at target column  J0c + lower + 32 k, i.e. d = 32 k + row - col: tile 0 is valid on and below its
+// Geometry.  A wave owns CT column tiles (of 32 source pixels) and takes them one after the other; column tile c meets the row
+// tiles k = 0 .. D/32 of the target window, row tile k starting at target column  J0c + lower + 32 k, i.e. d = 32 k + row - col: tile 0 is valid on and below its
 // diagonal, tile D/32 strictly above it, the tiles between completely.  The two triangular tiles start their accumulator from a
 // pattern that holds 2^20 in the invalid cells (they can then never win).  The Pout boundary
 // j + d_global >= Ws is the TARGET column Ws + lower - d_offset: a row boundary, so a tile lies in one region or (rarely)

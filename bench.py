@@ -261,8 +261,8 @@ def main():
                        "pipeline": "svh_stereo_match fused, inputs and outputs resident in HBM",
                        "materialize_volumes": bool(args.materialize),
                        "parallelism": (f"disparity axis sharded over {world} GPUs (D=256 per GPU, {wl['D']} in total), one RCCL int32 MIN "
-                                       "all-reduce of the regional winner keys (8 B/pixel) per frame, overlapped with the next frame's key "
-                                       "kernels (one exchange in flight)") if world > 1 else "single GPU"},
+                                       "all-reduce of the regional winner keys per frame (4 B/pixel: the Pout region's key is global as "
+                                       "written), overlapped with the next frame's key kernels (one exchange in flight)") if world > 1 else "single GPU"},
             "roofline": roof,
             "hbm_model_roofline": hbm_model if roof is not hbm_model else None,
             "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),

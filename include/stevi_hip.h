@@ -334,13 +334,19 @@ int svh_stereo_match(svh_context *ctx, const svh_stereo_params *params, const sv
 /* ---- disparity-sharded census (+ SGM) across GPUs -------------------------------------------------------------
  * Rank r handles the disparity indices [shard_begin, shard_begin + shard_count) of params->disp_count:
  *   svh_census_shard_keys   -> keys (H,W,2) i32: the shard's regional winner keys (cost, global index), all positive
- *   int32 MIN all-reduce of `keys` over the ranks (RCCL / torch.distributed): the only exchange
+ *   int32 MIN all-reduce of `keys` over the ranks (RCCL / torch.distributed): the only exchange.  When
+ *   svh_census_shard_region1_is_global() returns 1 the second key of every pixel (keys[..., 1], the region that pays Pout) is
+ *   already the winner over ALL shards as svh_census_shard_keys writes it -- every disparity of that region looks outside the
+ *   target image (zero vector: equal costs, the last index of the whole range wins) -- and only keys[..., 0] needs the reduction
+ *   (half the bytes; reducing both is still correct)
  *   svh_census_shard_finish -> SGM line recurrences from the reduced keys + winner: disp (H,W) i32 [, refined (H,W) f32]
  * The result is bit-identical to the single-GPU svh_stereo_match.  Census / Hamming costs in the integer-exact regime
  * only (integer Pout, window <= 11x11, <= 1024 disparities per shard, <= 4096 in total); otherwise SVH_ERR_UNSUPPORTED:
  * the Score branch and non-integer costs couple the disparities along every path step and do not shard. */
 int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                           svh_array *keys);
+/* 1: RightToLeft and source width + disp_lower >= target width (only shapes are read, no device work); else 0 */
+int svh_census_shard_region1_is_global(const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r);
 int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                             const svh_array *keys, svh_array *disp, svh_array *refined);
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume", "svh_sgm_cost_volume_textbook",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
-    "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
+    "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
     "svh_on_demand_features", "svh_on_demand_truncated_cost_volume", "svh_cacheless_patch_match",
     "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_unfold_compressed", "svh_unfold_compressed_shape",
@@ -156,6 +156,7 @@ def load():
         "svh_guided_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, A, A, i32, A, A]),
         "svh_hierarchical_truncated_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, C.c_int, A, A, P(i32), P(i32), i32, i32, A, A]),
         "svh_census_shard_keys": (C.c_int, [ctx, P(SvhStereoParams), A, A, A]),
+        "svh_census_shard_region1_is_global": (C.c_int, [P(SvhStereoParams), A, A]),
         "svh_census_shard_finish": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A]),
     }
     for name, (res, args) in sig.items():

@@ -468,6 +468,15 @@ def censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, dDir=di
     return keys
 
 
+def censusShardRegion1IsGlobal(img_l, img_r, disp_width, dDir=dispDirection.RightToLeft):
+    """svh_census_shard_region1_is_global: True when keys[..., 1] of censusShardKeys is already the winner over all shards (only
+    keys[..., 0] needs the MIN reduction).  Reads shapes only."""
+    lib = _capi.load()
+    l, r = _prep_image(img_l), _prep_image(img_r)
+    p, _ = _stereo_params(matchingFunctions.CENSUS, 1, 1, disp_width, dDir, 0, 0.0, 0.0, 0.0, None, None, 0, 0, None)
+    return bool(lib.svh_census_shard_region1_is_global(C.byref(p), C.byref(_desc(l)), C.byref(_desc(r))))
+
+
 def censusShardFinish(img_l, img_r, keys, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, sgmDirections=8, P1=0.001,
                       P2=0.01, Pout=100.0, margins=None, refineKernel=None, refine_h_radius=0, refine_v_radius=0,
                       matchFunc=matchingFunctions.CENSUS):

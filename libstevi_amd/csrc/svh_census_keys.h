@@ -10,12 +10,18 @@ struct CensusGeom {
     const uint32_t *sw, *tw; // compact words (H, Ws, nWw), (H, Wt, nWw); target pre-rounded through float (E2)
     int nWw, H, Ws, Wt, D, sign, disp_lower;
     int d_offset; // global index of local disparity 0 (disparity shards); disp_lower already includes it
+    int region1_global_last = -1; // CostSource::region1_global_last
 };
+
 
 constexpr uint32_t KEY_NONE = 0x7FFFFFFFu;
 constexpr int KEY_IDX_BITS = 12;
 constexpr uint32_t KEY_IDX_MASK = (1u << KEY_IDX_BITS) - 1u;
 __device__ __forceinline__ uint32_t make_key(int c, int d_global) { return ((uint32_t)c << KEY_IDX_BITS) | (KEY_IDX_MASK - (uint32_t)d_global); }
+// the Pout region's key of pixel j when CensusGeom::region1_global_last >= 0 (ones = popcount of the pixel's source census words)
+__device__ __forceinline__ uint32_t global_region1_key(const CensusGeom &g, int j, int ones) {
+    return j + g.region1_global_last >= g.Ws ? make_key(ones, g.region1_global_last) : KEY_NONE;
+}
 __device__ __forceinline__ int key_cost(uint32_t k) { return (int)(k >> KEY_IDX_BITS); }
 __device__ __forceinline__ int key_index(uint32_t k) { return (int)(KEY_IDX_MASK - (k & KEY_IDX_MASK)); }
 

@@ -232,6 +232,18 @@ __global__ void __launch_bounds__(TJV) census_sweep_kernel(CensusGeom g, float P
         kO1 = min(kO1, d >= splitO ? kOa : KEY_NONE);
     }
     const int pout = (int)Pout;
+    if (g.region1_global_last >= 0) { // disparity shards: the Pout region's winner over all shards (svh_internal.h, CostSource)
+        int onesE = 0, onesO = 0;
+        if constexpr (NW > 0) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                onesE += __popc(sE.v[w]);
+                onesO += __popc(sO.v[w]);
+            }
+        }
+        kE1 = global_region1_key(g, jE, onesE);
+        kO1 = global_region1_key(g, jO, onesO);
+    }
     if (jE < g.Ws) {
         keys[row + jE] = make_uint2(kE0, kE1);
         if (gmap) gmap[row + jE] = g_from_keys(kE0, kE1, pout);
@@ -659,7 +671,7 @@ static int sweep_dispatch(svh_context *ctx, const CensusGeom &g, float Pout, uin
 }
 
 int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, uint2 *keys, float *gmap) {
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset};
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
     return sweep_dispatch(ctx, g, a.Pout, keys, gmap);
 }
 
@@ -693,7 +705,7 @@ int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a,
 int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const uint2 *keys, const WinnerOut &win) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset};
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
     ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
 #define CALL(N) launch_finalize<N>(ctx, g, sg, n_pass, a.Pout, mmap, keys, win)
     SVH_NW_DISPATCH(cs.nWw, CALL)
@@ -703,7 +715,7 @@ int dev_census_finalize(svh_context *ctx, const SgmArgs &a, const CostSource &cs
 int dev_census_apply_select(svh_context *ctx, const SgmArgs &a, const CostSource &cs, const float *mmap, const WinnerOut &win) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset};
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
     ScanGeom sg{a.top, a.left, Hp > 0 ? Hp : 0, Wp > 0 ? Wp : 0, a.W};
 #define CALL(N) launch_apply_select<N>(ctx, g, sg, n_pass, a.Pout, mmap, win)
     SVH_NW_DISPATCH(cs.nWw, CALL)

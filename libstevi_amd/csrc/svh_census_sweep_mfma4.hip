@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
         int a0 = all_pay ? (int)KEY_NONE : decode(G0), a1 = none_pays ? (int)KEY_NONE : decode(G1);
         a0 = min(a0, __shfl_xor(a0, 32));
         a1 = min(a1, __shfl_xor(a1, 32));
+        if (g.region1_global_last >= 0) a1 = (int)global_region1_key(g, j, ones); // disparity shards (svh_internal.h, CostSource)
         if (h == 0 && j < g.Ws) {
             keys[row + j] = make_uint2((uint32_t)a0, (uint32_t)a1);
             if (gmap) gmap[row + j] = g_from_keys((uint32_t)a0, (uint32_t)a1, pout);

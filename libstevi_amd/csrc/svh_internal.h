@@ -212,6 +212,10 @@ struct CostSource {
     const uint32_t *src_words = nullptr, *tgt_words = nullptr; // compact (H, W*, nWw)
     int nWw = 0, Wt = 0, sign = 1, disp_lower = 0;
     int d_offset = 0; // disparity shards: global index of local disparity 0 (disp_lower already includes it)
+    // disparity shards: >= 0 when every disparity that pays Pout looks at a target column outside the image (zero vector), so that
+    // the Pout region's winner over ALL shards is known locally -- cost |s|, this index (the last of the whole range) -- and the
+    // sweep writes that instead of its own shard's: the second key plane then needs no exchange.  -1: plain regional keys.
+    int region1_global_last = -1;
 };
 // per-pixel outputs of the winner stage; every pointer is optional
 struct WinnerOut {

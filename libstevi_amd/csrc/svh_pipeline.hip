@@ -224,6 +224,13 @@ int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array 
 
 } // namespace
 
+extern "C" int svh_census_shard_region1_is_global(const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r) {
+    if (!prm || !img_l || !img_r || img_l->ndim < 2 || img_r->ndim < 2) return 0;
+    if (prm->disp_direction != SVH_RIGHT_TO_LEFT) return 0;
+    const int64_t Ws = img_r->shape[1], Wt = img_l->shape[1]; // RightToLeft: source = right image, target = left image
+    return Ws + prm->disp_lower >= Wt ? 1 : 0;
+}
+
 extern "C" int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r,
                                      svh_array *keys) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
@@ -241,10 +248,8 @@ extern "C" int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *
     uint32_t *sw = scr.get_n<uint32_t>((size_t)s.H * s.Ws * (s.nWw ? s.nWw : 1));
     uint32_t *tw = scr.get_n<uint32_t>((size_t)s.H * s.Wt * (s.nWw ? s.nWw : 1));
     if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
-    SVH_TRY(dev_census_from_image(ctx, {(const float *)dsrc, s.H, s.Ws, s.C}, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, s.H,
-                                  s.Ws, s.nWw, false, sw));
-    SVH_TRY(dev_census_from_image(ctx, {(const float *)dtgt, s.H, s.Wt, s.C}, prm->h_radius, prm->v_radius, prm->h_radius, prm->v_radius, s.H,
-                                  s.Wt, s.nWw, true, tw));
+    SVH_TRY(dev_census_pair_compact(ctx, {(const float *)dsrc, s.H, s.Ws, s.C}, {(const float *)dtgt, s.H, s.Wt, s.C}, prm->h_radius, prm->v_radius,
+                                    s.nWw, sw, tw)); // both images in one launch
     SgmArgs sa{prm->sgm_directions, SVH_COST, s.H, s.Ws, s.D, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
                prm->margins[3]};
     CostSource cs;
@@ -255,6 +260,10 @@ extern "C" int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *
     cs.sign = s.sign;
     cs.disp_lower = prm->disp_lower + s.sb;
     cs.d_offset = s.sb;
+    // Disparity index d pays Pout when j + d >= Ws, and looks at target column j + lower + d: with Ws + lower >= Wt every paying
+    // disparity of the WHOLE range sees the zero vector, the Pout region's winner is (|s|, last index) on every shard, and the
+    // second key plane is global as written (libstevi_amd/sharded.py then exchanges the first plane only).
+    if (svh_census_shard_region1_is_global(prm, img_l, img_r) == 1) cs.region1_global_last = s.Dtot - 1;
     SVH_TRY(dev_census_sweep(ctx, sa, cs, (uint2 *)ok.dptr, nullptr));
     return finish_out(ctx, ok);
 }

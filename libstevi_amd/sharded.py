@@ -2,8 +2,13 @@
 "nccl" = RCCL over xGMI) for the single exchange of the pipeline.
 
     rank r:  keys_r = svh_census_shard_keys(shard r of the disparity range)      (H, W, 2) int32, 8 B / pixel
-             all_reduce(keys, MIN)                                              RCCL
+             all_reduce(keys, MIN)                                              RCCL; 4 B / pixel when the second plane is global
              disp   = svh_census_shard_finish(keys)                             replicated, bit-identical to 1 GPU
+
+The second key of a pixel belongs to the disparities that pay Pout (sgm.h:287-289).  When all of them look outside the target
+image (RightToLeft, source width + first offset >= target width: the benchmark's geometry) their costs are equal on every
+shard, the last index of the whole range wins, and svh_census_shard_keys writes exactly that: plane 1 needs no exchange and
+`exchange_keys` reduces plane 0 only.
 
 Why one int32 MIN all-reduce is enough: in the Cost branch as the reference computes it a pass couples
 the disparities of a pixel only through min_d [c + (c [+Pout])]; with integer census costs that minimum and the winner
@@ -24,6 +29,30 @@ def shard_range(total, rank, world):
     return begin, base + (1 if rank < rem else 0)
 
 
+class _KeyExchange:
+    """MIN all-reduce of the key planes that need it, in place in `keys` once wait() returns."""
+
+    def __init__(self, keys, plane0_only, group, async_op):
+        self.keys, self.plane0 = keys, None
+        if plane0_only:
+            self.plane0 = keys[..., 0].contiguous()  # collectives want dense buffers: 4 B / pixel travel instead of 8
+            self.work = dist.all_reduce(self.plane0, op=dist.ReduceOp.MIN, group=group, async_op=async_op)
+        else:
+            self.work = dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group, async_op=async_op)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()  # RCCL: the compute stream waits for the exchange; gloo: the host does
+        if self.plane0 is not None:
+            self.keys[..., 0].copy_(self.plane0)
+        return self.keys
+
+
+def exchange_keys(keys, plane0_only, group=None, async_op=False):
+    """The one exchange of the protocol; returns an object whose wait() gives the reduced keys."""
+    return _KeyExchange(keys, plane0_only, group, async_op)
+
+
 def stereoMatchSharded(img_l, img_r, h_radius, v_radius, disp_width, group=None, **kw):
     """Census + SGM with the disparity range split over the ranks of `group`.  Every rank passes the same images
     (resident on its own GPU) and gets the same disparity map back.  kw: dDir, sgmDirections, P1, P2, Pout, margins,
@@ -37,7 +66,8 @@ def stereoMatchSharded(img_l, img_r, h_radius, v_radius, disp_width, group=None,
     keys_kw = {k: v for k, v in kw.items() if k in ("dDir", "sgmDirections", "P1", "P2", "Pout", "margins", "matchFunc")}
     keys = _c.censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, **keys_kw)
     if world > 1:
-        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+        plane0_only = _c.censusShardRegion1IsGlobal(img_l, img_r, disp_width, kw.get("dDir", _c.dispDirection.RightToLeft))
+        keys = exchange_keys(keys, plane0_only, group).wait()
     return _c.censusShardFinish(img_l, img_r, keys, h_radius, v_radius, disp_width, **kw)
 
 
@@ -70,17 +100,20 @@ class ShardedStereoPipeline:
     def _finish(self, img_l, img_r, keys):
         return _c.censusShardFinish(img_l, img_r, keys, self.h_radius, self.v_radius, self.disp_width, **self.kw)
 
+    def _plane0_only(self, img_l, img_r):
+        return _c.censusShardRegion1IsGlobal(img_l, img_r, self.disp_width, self.kw.get("dDir", _c.dispDirection.RightToLeft))
+
     def _complete(self, frame):
-        img_l, img_r, keys, work = frame
-        if work is not None:
-            work.wait()  # RCCL: the compute stream waits for the exchange; gloo: the host does
+        img_l, img_r, keys, exchange = frame
+        if exchange is not None:
+            keys = exchange.wait()
         return self._finish(img_l, img_r, keys)
 
     def submit(self, img_l, img_r):
         """Start frame k; returns the result of frame k - 1 (None for the first frame)."""
         keys = self._keys(img_l, img_r)
-        work = dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group, async_op=True) if self.world > 1 else None
-        previous, self._in_flight = self._in_flight, (img_l, img_r, keys, work)
+        exchange = exchange_keys(keys, self._plane0_only(img_l, img_r), self.group, async_op=True) if self.world > 1 else None
+        previous, self._in_flight = self._in_flight, (img_l, img_r, keys, exchange)
         return self._complete(previous) if previous is not None else None
 
     def flush(self):

@@ -7,8 +7,12 @@ IDX_MASK = (1 << IDX_BITS) - 1
 KEY_NONE = 0x7FFFFFFF
 
 
-def shard_keys(cv_shard, begin, W):
-    """cv_shard: (H, W, Dl) integer Hamming costs of global indices begin..begin+Dl-1 -> (H, W, 2) int32."""
+def shard_keys(cv_shard, begin, W, cv_full=None):
+    """cv_shard: (H, W, Dl) integer Hamming costs of global indices begin..begin+Dl-1 -> (H, W, 2) int32.
+    cv_full (the whole range): plane 1 is the Pout region's winner over ALL shards instead of the shard's own -- what
+    svh_census_shard_keys writes when svh_census_shard_region1_is_global() holds (every paying disparity sees the zero vector)."""
+    if cv_full is not None:
+        return np.stack([shard_keys(cv_shard, begin, W)[:, :, 0], shard_keys(cv_full, 0, W)[:, :, 1]], axis=2)
     H, Wc, Dl = cv_shard.shape
     d = begin + np.arange(Dl)
     key = (cv_shard.astype(np.int64) << IDX_BITS) | (IDX_MASK - d)[None, None, :]

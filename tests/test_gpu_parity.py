@@ -371,9 +371,14 @@ def test_census_shards_equal_single_gpu(ddir):
         full = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, refineKernel=so.PARABOLA, refine_h_radius=4, refine_v_radius=4, **kw)
         cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D, int(ddir))
         keys = None
+        # RightToLeft with equal widths and a range that starts at 0: plane 1 is written as the winner over all shards
+        plane1_global = sv.censusShardRegion1IsGlobal(d_tgt, d_src, D, ddir)
+        assert plane1_global == (ddir == sv.dispDirection.RightToLeft)
         for (b, n) in ((0, 101), (101, 64), (165, 135)):
             k = sv.censusShardKeys(d_tgt, d_src, 4, 4, D, (b, n), **kw)
-            assert_bits(k, shard_keys(cv[:, :, b:b + n], b, cv.shape[1]))
+            assert_bits(k, shard_keys(cv[:, :, b:b + n], b, cv.shape[1], cv if plane1_global else None))
+            if plane1_global and keys is not None:  # only plane 0 needs the reduction: plane 1 is the same on every shard
+                assert torch.equal(keys[..., 1], k[..., 1])
             keys = k if keys is None else torch.minimum(keys, k)
         res = sv.censusShardFinish(d_tgt, d_src, keys, 4, 4, D, refineKernel=so.PARABOLA, refine_h_radius=4, refine_v_radius=4, **kw)
         assert_bits(res["disp"], host(full["disp"]))

@@ -67,24 +67,31 @@ def _pipeline_worker(rank, world, port, out_dir):
         D, n_dir, Pout, margins = 23, 8, 100.0, (0, 0, 0, 0)
 
         class NumpyStages(ShardedStereoPipeline):  # the pipeline's ordering and exchange, with the protocol restated in numpy
+            plane0_only = False
+
             def _keys(self, img_l, img_r):
                 cv = so.unfold_cost_volume(so.CENSUS, img_l, img_r, 4, 4, D)
                 begin, count = self.shard
-                return torch.from_numpy(shard_keys(cv[:, :, begin:begin + count], begin, cv.shape[1]))
+                return torch.from_numpy(shard_keys(cv[:, :, begin:begin + count], begin, cv.shape[1], cv if self.plane0_only else None))
+
+            def _plane0_only(self, img_l, img_r):
+                return self.plane0_only
 
             def _finish(self, img_l, img_r, keys):
                 return finish(keys.numpy(), n_dir, Pout, margins)
 
-        pipe = NumpyStages(4, 4, D)
         frames = [parallax_pair(17, 28, 6, 5, 3 + k, 1, 4, seed=300 + k) for k in range(4)]
-        results = [pipe.submit(tgt, src) for src, tgt, _ in frames]
-        assert results[0] is None and pipe.flush.__self__._in_flight is not None
-        results = results[1:] + [pipe.flush()]
-        assert pipe.flush() is None
-        for k, ((src, tgt, _), idx) in enumerate(zip(frames, results)):
-            cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
-            exp = so.extract_index(so.sgm(cv, n_dir, so.COST, 0.001, 0.01, margins, Pout), so.COST)
-            assert np.array_equal(idx, exp), f"rank {rank} frame {k}: {(idx != exp).sum()} pixels differ"
+        for plane0_only in (False, True):  # both planes reduced / plane 1 global as written, plane 0 alone travels
+            pipe = NumpyStages(4, 4, D)
+            pipe.plane0_only = plane0_only
+            results = [pipe.submit(tgt, src) for src, tgt, _ in frames]
+            assert results[0] is None and pipe._in_flight is not None
+            results = results[1:] + [pipe.flush()]
+            assert pipe.flush() is None
+            for k, ((src, tgt, _), idx) in enumerate(zip(frames, results)):
+                cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+                exp = so.extract_index(so.sgm(cv, n_dir, so.COST, 0.001, 0.01, margins, Pout), so.COST)
+                assert np.array_equal(idx, exp), f"rank {rank} frame {k} plane0_only={plane0_only}: {(idx != exp).sum()} pixels differ"
         open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -150,6 +150,17 @@ __device__ __forceinline__ void shift_in_greater(uint32_t &word, float ref, floa
     asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(word) : "v"(ref), "v"(sample) : "vcc");
 }
 
+// The same for finite operands with every zero stored as +0 (what the staged tile holds when `all_finite`): the sign of
+// sample - ref is set exactly when ref > sample (a difference of two distinct floats is never zero: subnormals are kept), so
+// word = 2 word + (ref > sample) is v_sub_f32 + v_alignbit_b32 -- 5.5 issue cycles per pair instead of 8.8 for v_cmp + v_addc
+// (tools/ubench_valu.hip).  Not for NaN or infinities: inf - inf is a NEGATIVE NaN on this hardware and a NaN operand keeps or
+// flips its sign; tiles that hold any take the compare form.
+__device__ __forceinline__ void shift_in_sign(uint32_t &word, float ref, float sample) {
+    float d; // (asm: left to itself the compiler packs pairs of these into v_pk_add_f32 and pays two v_mov per pair to do it)
+    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(sample), "v"(ref));
+    word = __builtin_amdgcn_alignbit(word, __float_as_uint(d), 31);
+}
+
 // ROWS output rows per block: the (2 VR + ROWS) x (512 + 2 HR) tile is staged once and every lane keeps its
 // (2 VR + ROWS) x (2 HR + 2) samples in registers, so an output row costs a staged row and (2 HR + 2) / 2 LDS reads
 // instead of a whole window of each
@@ -168,6 +179,7 @@ __global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, Census
     const int i0 = blockIdx.y * ROWS, j0 = blockIdx.x * PXB, tj = threadIdx.x;
     // stage the tile: every load of the thread is issued before the first LDS write, so a block pays one memory latency
     constexpr int PER_ROW = (TW + TJN - 1) / TJN;
+    int not_finite = 0;
     {
         float r[TR][PER_ROW];
 #pragma unroll
@@ -181,16 +193,20 @@ __global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, Census
                 r[k][q] = (row_in && e < TW && jj >= 0 && jj < W) ? row[jj] : 0.0f;
             }
         }
+        // -0 -> +0 (the comparisons cannot tell them apart, the sign test below can); note any NaN / infinity of the tile
 #pragma unroll
         for (int k = 0; k < TR; k++) {
 #pragma unroll
             for (int q = 0; q < PER_ROW; q++) {
                 const int e = tj + q * TJN;
-                if (e < TW) tile[k * TW + e] = r[k][q];
+                float x;
+                asm("v_add_f32 %0, 0, %1" : "=v"(x) : "v"(r[k][q])); // (x + 0.0f, kept from the optimiser)
+                not_finite |= (__float_as_uint(x) & 0x7F800000u) == 0x7F800000u;
+                if (e < TW) tile[k * TW + e] = x;
             }
         }
     }
-    __syncthreads();
+    const bool all_finite = !__syncthreads_or(not_finite);
     // pixels A = j0 + 2 tj and B = A + 1 share the window columns 2 tj .. 2 tj + h: h + 1 samples per row, read as (h+1)/2
     // 8-byte pairs (ds_read_b64); A compares against sample l, B against sample l + 1
     const int jA = j0 + 2 * tj;
@@ -215,14 +231,27 @@ __global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, Census
         // v_addc (carry-in = VCC) per bit; the reference pixel is the window's top-left sample (finding F6)
         const float refA = smp[rr][0], refB = smp[rr][1];
         uint32_t dA[NWRITTEN > 0 ? NWRITTEN : 1] = {}, dB[NWRITTEN > 0 ? NWRITTEN : 1] = {};
+        if (all_finite) { // (block uniform) the sign of sample - ref
 #pragma unroll
-        for (int w = 0; w < NWRITTEN; w++) {
+            for (int w = 0; w < NWRITTEN; w++) {
 #pragma unroll
-            for (int b = 31; b >= 0; b--) {
-                const int c = 32 * w + b + 1; // channel index (unfold.h:180) behind bit b of word w (census.h:98-108)
-                const int k = c / h, l = c % h;
-                shift_in_greater(dA[w], refA, smp[rr + k][l]);
-                shift_in_greater(dB[w], refB, smp[rr + k][l + 1]);
+                for (int b = 31; b >= 0; b--) {
+                    const int c = 32 * w + b + 1; // channel index (unfold.h:180) behind bit b of word w (census.h:98-108)
+                    const int k = c / h, l = c % h;
+                    shift_in_sign(dA[w], refA, smp[rr + k][l]);
+                    shift_in_sign(dB[w], refB, smp[rr + k][l + 1]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NWRITTEN; w++) {
+#pragma unroll
+                for (int b = 31; b >= 0; b--) {
+                    const int c = 32 * w + b + 1;
+                    const int k = c / h, l = c % h;
+                    shift_in_greater(dA[w], refA, smp[rr + k][l]);
+                    shift_in_greater(dB[w], refB, smp[rr + k][l + 1]);
+                }
             }
         }
         uint32_t *oA = words + ((int64_t)i * Wo + jA) * n_out;

@@ -15,7 +15,14 @@ template <int OP> __global__ void k(uint32_t *out, uint32_t seed, int iters) {
     if (OP == 4) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(seed));                       \
     if (OP == 5) asm volatile("v_lshl_or_b32 %0, %0, 10, %1" : "+v"(x) : "v"(seed));               \
     if (OP == 6) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(seed));              \
-    if (OP == 7) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(seed));
+    if (OP == 7) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(seed));                        \
+    if (OP == 8) asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(x), "v"(seed) : "vcc");           \
+    if (OP == 9) asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : : "vcc");           \
+    if (OP == 10) asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(x) : "v"(seed));             \
+    if (OP == 11) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(seed));                      \
+    if (OP == 12) asm volatile("v_cmp_gt_f32 vcc, %1, %0\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(seed) : "vcc"); \
+    if (OP == 13) { uint32_t t; asm volatile("v_sub_f32 %1, %2, %0\n\tv_alignbit_b32 %0, %0, %1, 31" : "+v"(x), "=&v"(t) : "v"(seed)); } \
+    if (OP == 14) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(x) : "v"(seed) : "vcc");
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
         STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
     }
@@ -84,6 +91,13 @@ int main() {
     run<5>("v_lshl_or_b32", d);
     run<6>("v_cndmask_b32", d);
     run<7>("v_min_u32", d);
+    run<8>("v_cmp_gt_f32", d);
+    run<9>("v_addc_co_u32", d);
+    run<10>("v_alignbit_b32", d);
+    run<11>("v_sub_f32", d);
+    run<12>("cmp+addc (x2)", d);
+    run<13>("sub+alignbit(x2)", d);
+    run<14>("v_sub_co_u32", d);
     run_mix(d);
     return 0;
 }

@@ -79,6 +79,33 @@ def test_census_transform(rng, h_r, v_r):
     assert_bits(sv.censusFeatures(feat), so.census_features(feat))
 
 
+@pytest.mark.parametrize("h_r", [3, 4, 5])
+def test_census_transform_special_values(rng, h_r):
+    """The grey-image census kernel takes a bit from the sign of sample - ref on tiles whose samples are all finite and from a
+    compare on tiles that hold a NaN or an infinity: signed zeros, subnormals, equal neighbours, infinities of both signs next to
+    each other and NaNs, in an image wide and tall enough that both kinds of tile occur."""
+    H, W = 37, 700
+    img = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    img[:, 50:120] = np.round(img[:, 50:120] * 2) / 2                      # many equal neighbours, and zeros of both signs
+    img[:, 60:100:3] *= np.float32(-0.0) + np.float32(1.0)
+    img[5:9, 70:90] = np.float32(-0.0)
+    img[9:12, 70:90] = np.float32(0.0)
+    img[:, 130:170] = (rng.integers(-3, 4, (H, 40)) * np.float32(1e-45)).astype(np.float32)  # subnormals around zero
+    img[20:30, 300:330] = np.inf                                           # a block of +inf: inf against inf
+    img[22:26, 310:315] = -np.inf
+    img[31, 333] = np.nan
+    img[2, 690] = -np.nan
+    img[33:, 400:] = rng.uniform(-1e-38, 1e-38, img[33:, 400:].shape).astype(np.float32)     # differences that are subnormal
+    exp = so.census_transform(img, h_r, h_r)
+    assert_bits(sv.censusTransform2D(dev(img), h_r, h_r), exp)
+    assert_bits(sv.censusTransform2D(img, h_r, h_r), exp)
+    # the fused pipeline goes through the same kernel (both images in one launch)
+    other = np.roll(img, 7, axis=1)
+    cv = so.unfold_cost_volume(so.CENSUS, img, other, h_r, h_r, 32)
+    res = sv.stereoMatch(MF.CENSUS, dev(img), dev(other), h_r, h_r, 32, sgmDirections=0, want_cv=True)
+    assert_bits(res["cv"], cv)
+
+
 def test_census_single_channel_is_empty():
     assert sv.censusFeatures(np.zeros((3, 3, 1), np.float32)).size == 0
     assert sv.censusTransform2D(np.zeros((3, 3), np.float32), 0, 0).size == 0

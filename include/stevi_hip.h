@@ -98,9 +98,9 @@ const char *svh_last_error(const svh_context *ctx);
 /* Tuning / test switches.  "census_fast_path" (default 1): 0 forces the general wave-per-line SGM kernels
  * for census costs too (same results, used by the parity tests to cross-check the two implementations).
  * "census_sweep" (default 0 = automatic): engine of the voxel sweep of the fused census pipeline, 1 = the vector-ALU kernel
- * (xor + popcount), 2 / 3 = the matrix-core kernel with int8 / FP4 operands (Hamming distance as a dot product; RightToLeft, at
- * most 4 census words, disp_count a multiple of 32 up to 992 (int8: 480) -- anything else runs the vector-ALU kernel); automatic = 3 where it
- * applies.  Same keys bit for bit.
+ * (xor + popcount), 2 / 3 = the matrix-core kernel with int8 / FP4 operands (Hamming distance as a dot product; at most 4 census
+ * words, disp_count a multiple of 32 up to 992; int8: up to 480 and RightToLeft only -- anything else runs the vector-ALU kernel);
+ * automatic = 3 where it applies.  Same keys bit for bit.
  * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
  * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);

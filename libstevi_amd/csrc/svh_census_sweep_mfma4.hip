@@ -53,12 +53,14 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
     const int WIN = PXB + g.D;    // window pixels: the last column tile's last row tile ends at PXB - 32 + 32 NT
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const bool fwd = g.sign > 0;     // RightToLeft: target column j + lower + d; LeftToRight: j - lower - d, everything mirrored
+    const int xoff = fwd ? r : 31 - r; // source pixel of this lane inside its column tile (the lane index stays the tile's `col`)
     const int64_t row = (int64_t)i * g.Ws;
     // ---- every global load of the kernel up front: the source words of this wave's column tiles, then the target window
     uint32_t sword[CT][NW];
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        const int j = j0 + (wave * CT + c) * 32 + r;
+        const int j = j0 + (wave * CT + c) * 32 + xoff;
         const uint32_t *sp = g.sw + (row + min(j, g.Ws - 1)) * NW;
 #pragma unroll
         for (int m = 0; m < NW; m++) sword[c][m] = sp[m];
@@ -69,7 +71,8 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
         lut_t[b] = byte_nibbles(b, 0x0u, 0x2u);
         lut_s[b] = byte_nibbles(b, 0x2u, 0xAu);
     }
-    // ---- the target window as nibbles; window pixel y is target column j0 + lower + y (zero vector outside the image).  A thread
+    // ---- the target window as nibbles; window pixel y is target column j0 + lower + y (LeftToRight: j0 + PXB - 1 - lower - y, so that
+    // y still grows with the disparity; zero vector outside the image).  A thread
     // takes whole pixels (all NW words: one address, one bounds test), PPT of them with every load issued before the first table
     // look-up; the barrier that completes the tables sits under those loads.
     {
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
             uint32_t w[PPT][NW];
 #pragma unroll
             for (int u = 0; u < PPT; u++) {
-                const int y = y0 + u * 64 * WAVES, jt = j0 + g.disp_lower + y;
+                const int y = y0 + u * 64 * WAVES, jt = fwd ? j0 + g.disp_lower + y : j0 + PXB - 1 - g.disp_lower - y;
                 const bool inside = y < WIN && jt >= 0 && jt < g.Wt;
                 const uint32_t *tp = trow + (int64_t)(inside ? jt : 0) * NW;
 #pragma unroll
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
     // one column tile after the other; the MFMAs of row tile k + 1 are issued before the epilogue of row tile k
     for (int c = 0; c < CT; c++) {
         const int ct = wave * CT + c; // column tile of the block (wave uniform)
-        const int j = j0 + ct * 32 + r;
+        const int j = j0 + ct * 32 + xoff;
         // source fragments (this lane's word of every 64-bit group as +1.0 / -1.0 nibbles) and |s|
         v8i bfrag[NG];
         int ones = 0;
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
             bfrag[gq] = (v8i){present ? (int)lut_s[w & 0xFFu] : 0, present ? (int)lut_s[(w >> 8) & 0xFFu] : 0, present ? (int)lut_s[(w >> 16) & 0xFFu] : 0,
                               present ? (int)lut_s[w >> 24] : 0, 0, 0, 0, 0};
         }
-        const uint4 *arow = lds4 + h * WIN + ct * 32 + r; // row tile k, group gq: arow[2 gq WIN + 32 k]
+        const uint4 *arow = lds4 + h * WIN + (fwd ? ct * 32 : PXB - 32 * (ct + 1)) + r; // row tile k, group gq: arow[2 gq WIN + 32 k]
         struct Frags {
             v8i w[NG];
         };
@@ -184,35 +187,40 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
                 a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.w[gq], bfrag[gq], a, 4, 4, 0, 130, 0, 133);
             return a;
         };
-        // Region bookkeeping (wave uniform).  Row tile k covers target columns t0 + 32 k ...; tiles below k_switch lie in the
-        // region without Pout; tile k_switch straddles the boundary when `straddle`, else it is the first tile that pays.
-        const int t0 = j0 + g.disp_lower + ct * 32;
-        const int below = thr - t0; // target rows (relative to tile 0) that do not pay
-        const int k_switch = below <= 0 ? 0 : min(below >> 5, NT);
-        const bool straddle = below > 0 && (below & 31) != 0 && k_switch < NT;
-        float G = BIG_G, G0 = BIG_G;
+        // Region bookkeeping (wave uniform).  Cell (row tile k, row, col) is disparity 32 k + row - col of its lane's pixel and pays
+        // Pout when pixel + global index >= Ws:  32 k + row >= below + slope col, with slope 0 for RightToLeft (the boundary is a
+        // target column: a row of the tile) and 2 for LeftToRight (pixel and target column move apart).  Tiles before k_lo hold no
+        // paying cell, tiles from k_hi on only paying cells, the tiles between (at most one, LeftToRight three) are masked per cell.
+        const int below = g.Ws - g.d_offset - j0 - ct * 32 - (fwd ? 0 : 31), slope = fwd ? 0 : 2;
+        const int k_lo = below <= 0 ? 0 : min(below >> 5, NT);
+        const int all_from = below + 31 * slope; // 32 k >= this: every cell pays
+        const int k_hi = all_from <= 0 ? 0 : min((all_from + 31) >> 5, NT);
+        const bool none_pays = k_lo >= NT, all_pay = k_hi <= 0; // (wave uniform)
+        float G = BIG_G, G0 = BIG_G, Hpay = BIG_G; // running minimum (frame of the current tile); closed no-Pout region; Pout region inside the masked tiles
         // `checked`: this column tile has the Pout boundary inside its row tiles (only near the right image border); the others
         // run the loop without the per-tile region test
         auto epilogue = [&](const v16f &a, int k, auto checked) {
             if constexpr (decltype(checked)::value) {
-                if (k == k_switch) { // once per column tile
-                    asm volatile("; region switch" ::: "memory"); // keep this a branch: if-converted it costs selects in every tile
-                    if (straddle) {
+                if (k >= k_lo && k <= k_hi) { // around the boundary: a few tiles per column tile
+                    asm volatile("; region boundary" ::: "memory"); // keep this a branch: if-converted it costs selects in every tile
+                    if (k < k_hi) {
                         float m0 = BIG_CELL, m1 = BIG_CELL;
-                        int below_here = below;
-                        asm volatile("; straddling tile" : "+s"(below_here)); // or the 16 compares below are hoisted in front of every column tile
+                        int below_lane = below + slope * r;
+                        asm volatile("; masked tile" : "+v"(below_lane)); // or the 16 compares below are hoisted in front of every column tile
 #pragma unroll
                         for (int reg = 0; reg < 16; reg++) {
-                            const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below_here;
+                            const bool pays = 32 * k + row_of_reg(reg) + 4 * h >= below_lane;
                             m0 = __builtin_fminf(m0, pays ? BIG_CELL : a[reg]);
                             m1 = __builtin_fminf(m1, pays ? a[reg] : BIG_CELL);
                         }
-                        G0 = __builtin_fminf(G + 16.0f, m0) + (float)(16 * (31 - k)); // leaves the frame: absolute tile tag
-                        G = m1;
+                        G = __builtin_fminf(G + 16.0f, m0);       // both regions keep their running minimum, frame of tile k
+                        Hpay = __builtin_fminf(Hpay + 16.0f, m1);
                         return;
                     }
-                    G0 = G + (float)(16 * (31 - (k - 1))); // (frame of tile k - 1; k_switch = 0 never gets here with anything but BIG_G)
-                    G = BIG_G;
+                    // k == k_hi: the first tile that pays everywhere.  The no-Pout region is closed (frame of tile k - 1: absolute tag);
+                    // the Pout region goes on from what the masked tiles found
+                    G0 = G + (float)(16 * (31 - (k - 1)));
+                    G = Hpay;
                 }
             }
             const float t1 = min3f(a[0], a[1], a[2]), t2 = min3f(a[3], a[4], a[5]), t3 = min3f(a[6], a[7], a[8]), t4 = min3f(a[9], a[10], a[11]),
@@ -249,13 +257,20 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
                 epilogue(acc_b, k + 1, checked);
             }
         };
-        if (k_switch >= NT || (k_switch == 0 && !straddle)) sweep_tiles(std::false_type{}); // one region: no test inside
+        if (none_pays || all_pay) sweep_tiles(std::false_type{}); // one region: no test inside
         else sweep_tiles(std::true_type{});
         // out of the frame (tile NT - 1): the absolute tag of tile k is 16 (31 - k)
-        const float G_abs = G + (float)(16 * (31 - (NT - 1)));
-        const bool none_pays = k_switch >= NT, all_pay = k_switch == 0 && !straddle; // (wave uniform)
-        const float G1 = none_pays ? BIG_G : G_abs;
-        if (none_pays) G0 = G_abs;
+        const float tag_last = (float)(16 * (31 - (NT - 1)));
+        float G1;
+        if (none_pays) { // everything ran into G
+            G0 = G + tag_last;
+            G1 = BIG_G;
+        } else if (k_hi >= NT) { // the masked tiles reach the end of the range: both regions still open
+            G0 = G + tag_last;
+            G1 = Hpay + tag_last;
+        } else { // G0 was closed at k_hi (all_pay: it is still BIG_G), G has been the Pout region since
+            G1 = G + tag_last;
+        }
         // ---- decode (tile, cell) -> key; the two lane halves hold different rows of the same pixel: merge, store
         auto decode = [&](float gf) {
             const int gv = (int)gf; // exact: an integer below 2^24
@@ -264,7 +279,7 @@ __global__ void __launch_bounds__(64 * WAVES) census_sweep_mfma4_kernel(CensusGe
             const int d_local = 32 * kk + (reg & 3) + 8 * (reg >> 2) + 4 * h - r;
             return gf < G_VALID_BELOW ? (int)make_key(cost, g.d_offset + d_local) : (int)KEY_NONE;
         };
-        int a0 = all_pay ? (int)KEY_NONE : decode(G0), a1 = none_pays ? (int)KEY_NONE : decode(G1);
+        int a0 = decode(G0), a1 = decode(G1);
         a0 = min(a0, __shfl_xor(a0, 32));
         a1 = min(a1, __shfl_xor(a1, 32));
         if (g.region1_global_last >= 0) a1 = (int)global_region1_key(g, j, ones); // disparity shards (svh_internal.h, CostSource)
@@ -309,7 +324,7 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
 } // namespace
 
 bool launch_sweep_mfma4(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status) {
-    if (g.sign <= 0 || g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 4) return false;
+    if (g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 4) return false;
     switch (g.nWw) {
     case 1: return launch_for_words<1>(ctx, g, Pout, keys, gmap, status);
     case 2: return launch_for_words<2>(ctx, g, Pout, keys, gmap, status);

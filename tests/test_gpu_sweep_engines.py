@@ -2,7 +2,7 @@
 (Hamming distance as a dot product, svh_census_sweep_mfma.hip) and the matrix-core kernel with FP4 operands
 (svh_census_sweep_mfma4.hip) -- must give the same regional winner keys bit for bit, and all the oracle's disparities.
 svh_context_set_option("census_sweep", 1 | 2 | 3) selects the engine; 0 (default) takes the matrix cores wherever they apply
-(RightToLeft, 1..4 census words, D a multiple of 32 up to 992 for FP4 / 480 for int8) and the vector ALU elsewhere."""
+(1..4 census words, D a multiple of 32 up to 992; the int8 form only RightToLeft and up to 480) and the vector ALU elsewhere."""
 import numpy as np
 import pytest
 
@@ -49,6 +49,30 @@ def test_keys_and_disparities_agree(D, W):
         assert all(np.array_equal(disp[0], d) for d in disp[1:])
         if W <= 384 and (D <= 480 or W < 100):
             assert np.array_equal(disp[2], oracle_disp(tgt, src, h_r, D, n_dir, Pout))
+
+
+@pytest.mark.parametrize("D", [32, 96, 256])
+@pytest.mark.parametrize("W", [97, 420, 700])
+def test_left_to_right(D, W):
+    """LeftToRight: target column j - lower - d.  The FP4 kernel mirrors the window and the lanes; the Pout boundary then moves by
+    two cells per lane, so up to three row tiles of a column tile are masked per cell (the int8 kernel leaves this direction to the
+    vector ALU)."""
+    src, tgt, _ = parallax_pair(11, W, 9, 3, min(40, W // 3), 2, 13, seed=3 * D + W)
+    l, r = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)  # roles swapped: the left image is the source
+    L2R = sv.dispDirection.LeftToRight
+    for h_r, n_dir, Pout, rng_ in ((4, 8, 100.0, D), (3, 4, 7.0, D), (4, 8, 100.0, sv.searchOffset1(-17, D - 18))):
+        keys = both_engines(lambda: sv.censusShardKeys(l, r, h_r, h_r, rng_, (0, D), dDir=L2R, sgmDirections=n_dir, Pout=Pout).cpu().numpy(), l)
+        assert all(np.array_equal(keys[0], k) for k in keys[1:]), (h_r, n_dir)
+        disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, h_r, h_r, rng_, dDir=L2R, sgmDirections=n_dir, Pout=Pout)["disp"].cpu().numpy(), l)
+        assert all(np.array_equal(disp[0], d) for d in disp[1:])
+        if W <= 420 and isinstance(rng_, int):
+            cv = so.unfold_cost_volume(so.CENSUS, src, tgt, h_r, h_r, D, so.LEFT_TO_RIGHT)
+            vol = so.sgm(cv, n_dir, so.COST, 0.001, 0.01, (0, 0, 0, 0), Pout) if n_dir else cv
+            assert np.array_equal(disp[2], so.index_to_disp(so.extract_index(vol, so.COST), so.LEFT_TO_RIGHT))
+    # shards in this direction
+    for shard in ((0, 32), (32, D - 32)) if D > 32 else ((0, 32),):
+        keys = both_engines(lambda: sv.censusShardKeys(l, r, 4, 4, D, shard, dDir=L2R, sgmDirections=8).cpu().numpy(), l)
+        assert all(np.array_equal(keys[0], k) for k in keys[1:]), shard
 
 
 def test_four_census_words():
@@ -106,7 +130,8 @@ def test_shards_offsets_and_margins():
 
 
 def test_geometries_outside_the_matrix_core_kernel_still_run():
-    """LeftToRight, D not a multiple of 32, D > 992, 13x13 windows (5 words): options 2 and 3 fall back to the vector ALU kernel."""
+    """D not a multiple of 32, D > 992, 13x13 windows (5 words), LeftToRight for the int8 form: the options fall back to the vector
+    ALU kernel."""
     src, tgt, _ = parallax_pair(9, 260, 8, 3, 30, 2, 9, seed=5)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for kw in (dict(D=64, dDir=sv.dispDirection.LeftToRight, h=4), dict(D=70, dDir=sv.dispDirection.RightToLeft, h=4),

@@ -14,6 +14,11 @@
 // on floats (v_min3_f32); the decode converts once per pixel.  Results are the int8 kernel's and the vector-ALU sweep's bit for
 // bit (tests/test_gpu_sweep_engines.py).  The operand layout (lane half h holds the k-subset [32 h, 32 h + 32) of its row or
 // column as nibble e of dword q = element 8 q + e) was pinned with exact integer data before use.
+//
+// Unlike the int8 form this kernel also takes LeftToRight (target column j - lower - d): the window is staged mirrored and a lane's
+// pixel is the mirror image of its column index, so that the window position still grows with d and everything above holds; only
+// the Pout boundary changes -- it advances by two cells per lane instead of being a row of the tile -- and is handled by masking
+// the (up to three) row tiles it crosses per cell.
 #include <type_traits>
 
 #include "svh_census_keys.h"

@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the hot path (BASELINE.json): census 9x9 + 8-path SGM, 1920x1080, D=256.
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): census 9x9 + 8-path SGM.
 
-One "step" = one pass of the fused device pipeline (svh_stereo_match) over one synthetic stereo pair that is
-already resident in HBM: census transform of both images -> Hamming cost (evaluated on the fly) -> the
-reference's five effective SGM passes -> winner -> disparity map (int32).  Output bit-exact vs the oracle
-(tests/test_gpu_parity.py, tests/test_gpu_fullsize.py).
+    N = 1   BASELINE.json configs[2]: 1920x1080, D = 256 (the configuration the metric is quoted on).
+            One "step" = one pass of the fused device pipeline (svh_stereo_match) over one synthetic stereo pair that is already
+            resident in HBM: census transform of both images -> Hamming cost (evaluated on the fly) -> the reference's five
+            effective SGM passes -> winner -> disparity map (int32).
+    N > 1   BASELINE.json configs[4]: 8192x4320, D = 512, the disparity range split N ways (strong scaling: the problem is
+            fixed, every rank sweeps D / N disparities), one RCCL int32 MIN all-reduce of the regional winner keys per frame,
+            scans + finalize replicated.  One step = one frame through libstevi_amd.sharded.ShardedStereoPipeline.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  Metric: Mdisparities/s = W*H*D*steps / seconds / 1e6 summed over ranks.
+Prints ONE JSON line on rank 0.  Metric: Mdisparities/s = W*H*D*steps / seconds / 1e6 (the whole job).
+The second half of BASELINE.json's metric ("end-px-err vs ref") is `end_px_err`: the disparity map of the timed pipeline
+compared, outside the timed region, with the CPU oracle's map of the same pair (benchmarkCrossCorrelationAlgorithms.cpp:288-294
+restated: unfoldBasedCostVolume -> sgmCostVolume<8> -> extractSelectedIndex -> selectedIndexToDisp); any differing pixel makes
+the run fail (exit code 3).
 """
 import argparse
 import json
@@ -24,26 +31,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# C3 of SURVEY.md section 8(d): 1920x1080, D=256, census 9x9, SGM-8 (P1=0.001, P2=0.01, Pout=100), seed 3
-WORKLOAD = dict(W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=3,
-                bg=8, sq=64, side=320, v=320, h=380)
+# C3 = 1920x1080, D=256, census 9x9, SGM-8 (P1=0.001, P2=0.01, Pout=100), seed 3; C5 = 8192x4320, D=512, seed 5
+C3 = dict(name="C3", W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=3, bg=8, sq=64, side=320, v=320, h=380)
+C5 = dict(name="C5", W=8192, H=4320, D=512, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=5, bg=32, sq=256, side=1280, v=1280, h=1520)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # MI355X_MICROARCH.md, matrix cores (dense): BF16 ~2.5 PFLOP/s; int8 runs at twice the BF16 rate, block-scaled FP4 at four times
-MFMA_PEAK_TOPS = {"census_sweep_mfma": 5000.0, "census_sweep_mfma4": 10000.0}
-
-
-def visited_voxels_per_pass(H, W, D, n_pass):
-    """voxels touched by each effective SGM pass, zero margins"""
-    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
-    masks = [np.ones((H, W), bool), np.ones((H, W), bool), ii >= jj, jj >= ii, ii + jj < W, ii + jj < H]
-    return [int(m.sum()) * D for m in masks[:n_pass]]
+MFMA_PEAK_TOPS = {"census_sweep_mfma": 5000.0, "census_sweep_mfma4": 10000.0, "census_sweep_pm": 10000.0}
 
 
 def algorithmic_bytes(kernel, wl):
     """Algorithmic bytes per launch of `kernel` under the model of SURVEY.md section 8(d), row C3 (DESIGN.md "Roofline"):
     C as u8, S as i16, each of the five effective SGM passes = one read of C + one read-modify-write of S:
         28 B/voxel = 1 (C write) + 5 x (1 + 4) + 2 (final S read),   60 B/pixel = 8 (images) + 48 (census words) + 4 (disparity).
-    The fused pipeline has ONE voxel-sized kernel (census_sweep); all 28 B/voxel of the model are work it replaces.  The
+    The fused pipeline has ONE voxel-sized kernel (the sweep); all 28 B/voxel of the model are work it replaces.  The
     per-pixel kernels carry the per-pixel bytes."""
     H, W, D = wl["H"], wl["W"], wl["D"]
     px, vox = H * W, H * W * D
@@ -51,9 +51,12 @@ def algorithmic_bytes(kernel, wl):
         "census_sweep": 28.0 * vox,
         "census_sweep_mfma": 28.0 * vox,
         "census_sweep_mfma4": 28.0 * vox,
+        "census_sweep_pm": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
         "sgm_line_scans": 4.0 * px + 6 * 4.0 * px,   # g read + six min_p maps written
+        "sgm_line_carries": 4.0 * px,                # g read (the carries are per line and band: negligible)
         "census_finalize": (8.0 + 24.0 + 4.0) * px,  # keys + six min_p maps + disparity
+        "census_scan_finalize": (4.0 + 8.0 + 4.0) * px,  # g + keys + disparity
     }
     return table.get(kernel)
 
@@ -69,40 +72,90 @@ def load_measured_traffic(kernel):
         return None
 
 
-def cpu_baseline(wl, budget_s=18.0):
-    """Oracle (CPU restatement of the reference, literal O(D^2) SGM loops) on a bounded row band of the workload."""
+def oracle_disparity(wl, src, tgt, rows=None, variant=1):
+    """The reference chain on the CPU oracle (test infrastructure; only ever the checker / the baseline)."""
     import oracle as so
-    from helpers import parallax_pair
-    src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"])
-    D, hr, vr = wl["D"], wl["h_r"], wl["v_r"]
+    s, t = (src, tgt) if rows is None else (np.ascontiguousarray(src[:rows]), np.ascontiguousarray(tgt[:rows]))
+    t0 = time.perf_counter()
+    cv = so.unfold_cost_volume(so.CENSUS, t, s, wl["h_r"], wl["v_r"], wl["D"])
+    vol = so.sgm(cv, wl["sgm"], so.COST, wl["P1"], wl["P2"], (0, 0, 0, 0), wl["Pout"], variant=variant)
+    disp = so.index_to_disp(so.extract_index(vol, so.COST))
+    return disp, time.perf_counter() - t0
 
-    def run(rows, variant):
-        s, t = np.ascontiguousarray(src[:rows]), np.ascontiguousarray(tgt[:rows])
-        t0 = time.perf_counter()
-        cv = so.unfold_cost_volume(so.CENSUS, t, s, hr, vr, D)
-        vol = so.sgm(cv, wl["sgm"], so.COST, wl["P1"], wl["P2"], (0, 0, 0, 0), wl["Pout"], variant=variant)
-        so.index_to_disp(so.extract_index(vol, so.COST))
-        return time.perf_counter() - t0
 
-    out = {}
-    for variant, key in ((0, "literal"), (1, "linear")):
-        rows = 4
-        dt = run(rows, variant)
-        target = budget_s * (0.75 if variant == 0 else 0.25)
-        rows2 = int(min(wl["H"], max(rows, rows * target / max(dt, 1e-6))))
-        if rows2 > rows:
-            dt = run(rows2, variant)
-            rows = rows2
-        out[key] = (rows * wl["W"] * D / dt / 1e6, rows, dt)
+def cpu_baseline(wl, src, tgt, budget_s=18.0):
+    """Oracle (CPU restatement of the reference) timed on a bounded sample of the workload: the literal O(D^2) loops on a row
+    band, and the O(D) restatement (bitwise identical) on the whole frame -- whose disparity map is the `end_px_err` check."""
+    import oracle as so
+    D = wl["D"]
+    rows = 4
+    _, dt = oracle_disparity(wl, src, tgt, rows, variant=0)
+    rows2 = int(min(wl["H"], max(rows, rows * (budget_s * 0.75) / max(dt, 1e-6))))
+    if rows2 > rows:
+        _, dt = oracle_disparity(wl, src, tgt, rows2, variant=0)
+        rows = rows2
+    full_disp, dt_lin = oracle_disparity(wl, src, tgt, None, variant=1)
     cores = so.num_threads()
-    lit, lin = out["literal"], out["linear"]
-    return {
-        "value": round(lit[0], 3), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
-        "sample": f"top {lit[1]} rows of the same {wl['W']}x{wl['H']} pair, D={D}: census 9x9 volume + SGM-8 (literal O(D^2) loops of "
-                  f"sgm.h:269-295) + argmin, {lit[2]:.1f} s, OpenMP over rows/lines",
-        "linear_sgm_value": round(lin[0], 3),
-        "linear_sgm_sample": f"top {lin[1]} rows, O(D) SGM restatement (bitwise identical), {lin[2]:.1f} s",
+    base = {
+        "value": round(rows * wl["W"] * D / dt / 1e6, 3), "unit": "Mdisparities/s", "cores": cores, "kind": "port",
+        "sample": f"top {rows} rows of the same {wl['W']}x{wl['H']} pair, D={D}: census 9x9 volume + SGM-8 (literal O(D^2) loops of "
+                  f"sgm.h:269-295) + argmin, {dt:.1f} s, OpenMP over rows/lines",
+        "linear_sgm_value": round(wl["H"] * wl["W"] * D / dt_lin / 1e6, 3),
+        "linear_sgm_sample": f"all {wl['H']} rows, O(D) SGM restatement (bitwise identical), {dt_lin:.1f} s",
     }
+    return base, full_disp
+
+
+def band_check_mask(H, W, band):
+    """Pixels of the top `band` rows whose SGM result is the same whether the oracle sees the whole frame or only the top
+    band + v_r rows: every pass but DownLeft2UpRight reaches a pixel from above or from the left; that pass runs up the
+    anti-diagonals from the left column, so a pixel keeps its value when its anti-diagonal starts inside the band
+    (i + j < band) or is not traversed at all (i + j >= H)."""
+    ii, jj = np.meshgrid(np.arange(band), np.arange(W), indexing="ij")
+    return (ii + jj < band) | (ii + jj >= H)
+
+
+def end_px_err(got, want, against, mask=None):
+    got = np.asarray(got)
+    if mask is not None:
+        got, want = got[:want.shape[0]][mask], want[mask]
+    diff = int(np.count_nonzero(got != want))
+    return {"pixels_differing": diff, "of": int(want.size), "checked_against": against}
+
+
+def api_chain(sv, wl, d_tgt, d_src, reps=5):
+    """The reference benchmark's chain through the PER-FUNCTION entry points on device arrays, volumes materialised in HBM between
+    the calls (what the drop-in C++ headers run, minus their PCIe copies): the form SURVEY.md 8(d)'s byte model describes.
+    Compulsory HBM bytes: C written (4 B/voxel, API type float) and read once, S written and read once = 16 B/voxel."""
+    MF = sv.matchingFunctions
+    strat = sv.matchFuncStrategy(MF.CENSUS)
+
+    def chain():
+        cv = sv.unfoldBasedCostVolume(MF.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"])
+        sgm = sv.sgmCostVolume(wl["sgm"], strat, cv, wl["P1"], wl["P2"], None, wl["Pout"])
+        return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, sgm), 0)
+
+    disp = chain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        disp = chain()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    sv.profile_reset(d_src)
+    sv.profile_enable(d_src, True)
+    for _ in range(reps):
+        chain()
+    sv.profile_enable(d_src, False)
+    prof = sv.profile_collect(d_src)
+    vox = wl["W"] * wl["H"] * wl["D"]
+    comp = 16.0 * vox + 12.0 * wl["W"] * wl["H"]
+    ach = comp / (ms * 1e-3) / 1e9
+    return {"ms": round(ms, 4), "Mdisparities_per_s": round(vox / ms / 1e3, 1),
+            "calls": "unfoldBasedCostVolume -> sgmCostVolume<8,Cost> -> extractSelectedIndex -> selectedIndexToDisp, device arrays, float32 volumes in HBM",
+            "roofline": {"bound": "hbm", "compulsory_bytes": int(comp), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 4), "model": "16 B/voxel (C and S each written and read once as float32) + 12 B/pixel"},
+            "kernel_ms": {k: round(v[0] / reps, 4) for k, v in prof.items()}}, disp
 
 
 def main():
@@ -110,7 +163,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline and end_px_err)")
+    ap.add_argument("--no-api-chain", action="store_true", help="skip the per-function (volume-materialising) chain")
     ap.add_argument("--materialize", action="store_true", help="also write the cost volume and the SGM volume (float32) to HBM")
     args = ap.parse_args()
 
@@ -142,19 +196,25 @@ def main():
     import libstevi_amd as sv
     from helpers import parallax_pair
 
-    wl = dict(WORKLOAD)
+    wl = dict(C3 if world == 1 else C5)
+    if os.environ.get("SVH_BENCH_SMALL") == "1" and world > 1:  # rehearsal on a box that should not spend minutes on C5
+        wl.update(W=2048, H=1080, side=320, v=320, h=380, bg=8, sq=64)
+    if wl["D"] > wl["W"]:
+        raise SystemExit("refusing a disparity range wider than the image")
     # every rank holds the same pair: with N > 1 the ranks cooperate on ONE problem (disparity shards)
     src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"])
     d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
 
+    pipe = None
     if world > 1:
-        # north_star: the cost volume shards over the disparity axis, one RCCL all-reduce for the per-pixel argmin.
-        # Weak scaling: every GPU keeps the single-GPU slice (D=256), the searched range grows to 256 x N.
-        # A step submits one frame; its exchange runs on RCCL's stream under the next frame's key kernels and its result
-        # comes back with the next submit (the last one with the flush inside the timed region): K steps = K frames done.
+        # north_star: the cost volume shards over the disparity axis, one RCCL all-reduce for the per-pixel argmin.  Strong
+        # scaling: the frame and its range are fixed (BASELINE.json configs[4]), a rank sweeps D / N disparities (whole 32-wide
+        # row tiles of the matrix-core sweep where D / 32 divides).  A step submits one frame; its exchange runs on RCCL's stream
+        # under the next frame's key kernels and its result comes back with the next submit (the last one with the flush inside
+        # the timed region): K steps = K frames done.
         from libstevi_amd import sharded
-        wl["D"] = WORKLOAD["D"] * world
-        pipe = sharded.ShardedStereoPipeline(wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"], P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"])
+        pipe = sharded.ShardedStereoPipeline(wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"], P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"],
+                                             align=32)
 
     def step():
         if world > 1:
@@ -183,7 +243,7 @@ def main():
     prof_all = sv.profile_collect(d_src)
     n_warm = max(args.warmup, 1)
     dom_name = max(prof_all.items(), key=lambda kv: kv[1][0])[0]
-    # timed region: events only around the dominant kernel (bracketing all six launches costs ~20 % of a 0.23 ms step)
+    # timed region: events only around the dominant kernel (bracketing every launch costs ~20 % of a 0.1 ms step)
     sv.profile_reset(d_src)
     sv.profile_enable(d_src, True, only=dom_name)
     sync()
@@ -201,45 +261,75 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    checksum = int(out["disp"].sum().item())
+    disp_dev = out["disp"]
+    checksum = int(disp_dev.sum().item())
 
+    # ---- N > 1: the phases of one frame, un-overlapped, outside the timed region (events on the compute stream; the exchange is
+    # bracketed with the compute stream waiting for RCCL's stream, so its figure is what a non-pipelined frame would pay)
+    phases = None
+    if world > 1:
+        from libstevi_amd import correlation as _c
+        from libstevi_amd import sharded
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = [0.0, 0.0, 0.0]
+        plane0_only = pipe._plane0_only(d_tgt, d_src)
+        reps = 3
+        for _ in range(reps):
+            sync()
+            ev[0].record()
+            keys = pipe._keys(d_tgt, d_src)
+            ev[1].record()
+            keys = sharded.exchange_keys(keys, plane0_only, None, async_op=False).wait()
+            ev[2].record()
+            pipe._finish(d_tgt, d_src, keys)
+            ev[3].record()
+            torch.cuda.synchronize()
+            for k in range(3):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+        ph = torch.tensor(acc, dtype=torch.float64, device=dev) / reps
+        dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        px = wl["W"] * wl["H"]
+        phases = {"keys_ms": round(float(ph[0]), 4), "exchange_ms": round(float(ph[1]), 4), "finish_ms": round(float(ph[2]), 4),
+                  "exchange_bytes_per_frame": int(px * (4 if plane0_only else 8)), "plane0_only": bool(plane0_only),
+                  "shard_disparities": pipe.shard[1], "note": "max over ranks, phases run back to back without overlap; the timed steps overlap the "
+                                                              "exchange of frame k with the key kernels of frame k + 1"}
+
+    rc = 0
     if rank == 0:
-        voxels = wl["W"] * wl["H"] * wl["D"]  # D = 256 x N for N > 1: the whole job's voxels
+        voxels = wl["W"] * wl["H"] * wl["D"]
         value = voxels * args.steps / elapsed / 1e6
-        wl1 = dict(wl, D=WORKLOAD["D"])        # what one launch of a kernel processes on one GPU
+        wl1 = dict(wl, D=wl["D"] if world == 1 else pipe.shard[1])  # what one launch of a kernel processes on one GPU
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel by accumulated event time inside the timed region
         dom_ms, dom_n = prof[dom_name]
         avg_ms = dom_ms / max(dom_n, 1)
         alg = algorithmic_bytes(dom_name, wl1)
+        traffic = load_measured_traffic(dom_name) if world == 1 else None
         hbm_model = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "traffic": None, "model": "SURVEY.md 8(d) row C3 prices this launch at 28 B/voxel of volume traffic the fused design never generates"}
+                     "traffic": traffic, "model": "SURVEY.md 8(d) row C3 prices this launch at 28 B/voxel of volume traffic the fused design never generates"}
         if alg is not None:
             ach = alg / (avg_ms * 1e-3) / 1e9
             hbm_model.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_launch": int(alg)})
         else:
             hbm_model.update({"achieved": None, "frac": None})
-        traffic = load_measured_traffic(dom_name)
-        if traffic is not None:
-            hbm_model["traffic"] = traffic
         roof, issue = hbm_model, None
         vox_launch = wl1["W"] * wl1["H"] * wl1["D"]
+        bits = 32 * (((2 * wl1["h_r"] + 1) * (2 * wl1["v_r"] + 1) - 1) // 32)  # census bits that are written: 9x9 -> 64
         if dom_name in MFMA_PEAK_TOPS:
             # The sweep runs on the matrix cores: the Hamming distance of two 64-bit census records is a 64-term dot product of
-            # 0 / +-1 operands (svh_census_sweep_mfma4.hip: FP4 operands, exact in the f32 accumulators; svh_census_sweep_mfma.hip:
-            # int8), i.e. 128 operations per voxel; these are the algorithmic operations of a launch.  The kernel issues 9/8 of them
-            # (the band of D disparities is covered by D/32 + 1 row tiles of 32).
+            # +-1 operands (FP4, exact in the f32 accumulators; svh_census_sweep_mfma.hip: int8), i.e. 128 operations per voxel;
+            # these are the algorithmic operations of a launch.  The kernel issues (D/32 + 1) / (D/32) of them (the band of D
+            # disparities is covered by D/32 + 1 row tiles of 32).
             peak = MFMA_PEAK_TOPS[dom_name]
-            fp4 = dom_name.endswith("4")
-            bits = 32 * (((2 * wl1["h_r"] + 1) * (2 * wl1["v_r"] + 1) - 1) // 32)  # census words that are written: 9x9 -> 64 bits
+            fp4 = dom_name != "census_sweep_mfma"
             ops = 2.0 * bits * vox_launch
             ach = ops / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                    "dtype": "fp4 (e2m1) operands 0 / +-1, f32 accumulators (exact integers)" if fp4 else "int8 multiply-accumulate, int32 accumulators (exact)",
+                    "dtype": "fp4 (e2m1) operands +-1, f32 accumulators (exact integers)" if fp4 else "int8 multiply-accumulate, int32 accumulators (exact)",
                     "algorithmic_ops_per_launch": int(ops), "ops_per_voxel": 2 * bits,
                     "note": ("v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 x FP4)" if fp4 else "v_mfma_i32_32x32x32_i8") +
-                            "; peak = dense rate of the operand type at the nominal clock (the chip holds ~1.7 GHz under this load)"}
+                            "; peak = dense rate of the operand type at the nominal clock (the chip holds well under 2.4 GHz under this load)"}
         elif dom_name == "census_sweep":
             # The vector-ALU engine (svh_context_set_option census_sweep = 1): the roof that binds it is VALU issue.  Per 64 voxels a
             # SIMD issues 2 v_xor + 2 v_bcnt + 1 v_lshl_or + 1/2 v_min3; tools/ubench_valu.hip measures 2.76 / 4.58 / 4.46 / 4.55
@@ -251,33 +341,64 @@ def main():
                      "achieved": round(ach_vox / 1e9, 1), "unit": "Gvoxels/s", "frac": round(ach_vox / peak_vox, 4),
                      "rates": "measured per-instruction issue rates, tools/ubench_valu.hip"}
         pipeline_alg = 28.0 * voxels + 60.0 * wl["W"] * wl["H"]
+        # what no implementation of this step can go below on one GPU: the images in, the disparity map out (HBM), and the
+        # Hamming dot products of every voxel on the fastest unit that can do them (matrix cores, FP4)
+        compulsory = 12.0 * wl["W"] * wl["H"]
+        lb_us = max(compulsory / (HBM_PEAK_GBPS * 1e9), 2.0 * bits * (voxels / world) / (MFMA_PEAK_TOPS["census_sweep_mfma4"] * 1e12)) * 1e6
         kernel_ms = {k: round(v[0] / n_warm, 4) for k, v in prof_all.items()}  # from the warm-up steps (all kernels bracketed)
+        shape = f"{wl['W']}x{wl['H']}"
         line = {
-            "metric": "Mdisparities/s (W*H*D) for census+SGM, 1080p D=256", "value": round(value, 1), "unit": "Mdisparities/s",
+            "metric": f"Mdisparities/s (W*H*D) for census+SGM, {'1080p' if wl['name'] == 'C3' else shape} D={wl['D']}; end-px-err vs ref",
+            "value": round(value, 1), "unit": "Mdisparities/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "1920x1080 synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
-                                   "D=256, argmin -> int32 disparity map (BASELINE.json configs[2])",
-                       "pipeline": "svh_stereo_match fused, inputs and outputs resident in HBM",
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{shape} synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
+                                   f"D={wl['D']}, argmin -> int32 disparity map (BASELINE.json configs[{2 if wl['name'] == 'C3' else 4}])",
+                       "pipeline": "svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
+                                   "svh_census_shard_keys -> int32 MIN all-reduce -> svh_census_shard_finish, inputs and outputs resident in HBM",
                        "materialize_volumes": bool(args.materialize),
-                       "parallelism": (f"disparity axis sharded over {world} GPUs (D=256 per GPU, {wl['D']} in total), one RCCL int32 MIN "
-                                       "all-reduce of the regional winner keys per frame (4 B/pixel: the Pout region's key is global as "
-                                       "written), overlapped with the next frame's key kernels (one exchange in flight)") if world > 1 else "single GPU"},
+                       "parallelism": (f"disparity axis sharded over {world} GPUs ({pipe.shard[1]} of {wl['D']} disparities per GPU), one RCCL int32 MIN "
+                                       "all-reduce of the regional winner keys per frame, overlapped with the next frame's key kernels "
+                                       "(one exchange in flight); scans + finalize replicated") if world > 1 else "single GPU"},
             "roofline": roof,
             "hbm_model_roofline": hbm_model if roof is not hbm_model else None,
             "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                  "model": "SURVEY.md 8(d) C3: 28 B/voxel + 60 B/pixel"},
+                                  "model": "SURVEY.md 8(d) C3: 28 B/voxel + 60 B/pixel (volumes in HBM; the fused step never writes them)"},
+            "step_lower_bound": {"us": round(lb_us, 2), "frac_of_step": round(lb_us / (ms_per_step * 1e3), 4),
+                                 "model": "max(12 B/pixel compulsory HBM traffic at 8 TB/s, 128 ops/voxel on the FP4 matrix cores at 10 POP/s per GPU)"},
             "issue_roofline": issue,
             "kernel_ms_per_step_warmup": kernel_ms,
             "disp_checksum": checksum,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(wl)
+        if phases is not None:
+            line["frame_phases"] = phases
+        got = disp_dev.cpu().numpy()
+        if not args.no_cpu_baseline:
+            if world == 1:
+                line["cpu_baseline"], want = cpu_baseline(wl, src, tgt)
+                line["end_px_err"] = end_px_err(got, want, "oracle (port), full frame")
+            else:  # the oracle on the whole 8K frame would take about a minute: a row band, on the pixels a band decides
+                band = 48
+                want, _ = oracle_disparity(wl, src, tgt, band + wl["v_r"], variant=1)
+                line["end_px_err"] = end_px_err(got, want[:band], f"oracle (port), top {band} rows, pixels whose SGM lines lie inside the band",
+                                                band_check_mask(wl["H"], wl["W"], band))
+            if line["end_px_err"]["pixels_differing"] != 0:
+                rc = 3
+        else:
+            line["end_px_err"] = None
+        if world == 1 and not args.no_api_chain:
+            line["api_chain"], chain_disp = api_chain(sv, wl, d_tgt, d_src)
+            line["api_chain"]["pixels_differing_from_fused"] = int((chain_disp != disp_dev).sum().item())
+            if line["api_chain"]["pixels_differing_from_fused"] != 0:
+                rc = 3
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        print("bench.py: the disparity map differs from the reference chain (see end_px_err / api_chain)", file=sys.stderr)
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -464,8 +464,10 @@ def censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, dDir=di
     p, _ = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, None, 0, 0, shard)
     src = r if int(dDir) == dispDirection.RightToLeft else l
     keys = _like(l, (src.shape[0], src.shape[1], 2), "i32")
-    _check(ctx, lib.svh_census_shard_keys(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(keys))))
-    return keys
+    st = _check(ctx, lib.svh_census_shard_keys(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(keys))))
+    # row / channel mismatch, single-channel census: the reference returns an empty array (census.h:76-78); never hand
+    # uninitialised keys to the all-reduce
+    return keys if st == _capi.OK else _empty_like(l, 3, "i32")
 
 
 def censusShardRegion1IsGlobal(img_l, img_r, disp_width, dDir=dispDirection.RightToLeft):
@@ -493,8 +495,10 @@ def censusShardFinish(img_l, img_r, keys, h_radius, v_radius, disp_width, dDir=d
         res["refined"] = _like(l, (H, W), "f32")
     dd = _desc(res["disp"])
     dr = _desc(res["refined"]) if "refined" in res else None
-    _check(ctx, lib.svh_census_shard_finish(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(keys)), C.byref(dd),
-                                            C.byref(dr) if dr is not None else None))
+    st = _check(ctx, lib.svh_census_shard_finish(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), C.byref(_desc(keys)), C.byref(dd),
+                                                 C.byref(dr) if dr is not None else None))
+    if st != _capi.OK:
+        return {k: _empty_like(l, 2, "i32" if k == "disp" else "f32") for k in res}
     return res
 
 

@@ -325,8 +325,7 @@ int svh_context_create(svh_context **out, int device, void *stream) {
         if (hipGetDevice(&device) != hipSuccess) return SVH_ERR_HIP;
     }
     if (device >= n) return SVH_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(device) != hipSuccess) return SVH_ERR_HIP;
-    svh_context *ctx = new svh_context();
+    svh_context *ctx = new svh_context(); // (nothing is allocated here: the caller's current device is left alone)
     ctx->device = device;
     ctx->stream = (hipStream_t)stream; // NULL = the device's default (null) stream
     *out = ctx;
@@ -335,6 +334,7 @@ int svh_context_create(svh_context **out, int device, void *stream) {
 
 int svh_context_destroy(svh_context *ctx) {
     if (!ctx) return SVH_OK;
+    DeviceGuard guard(ctx->device); // (holds the device number, not the context)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->pool)
         if (b.ptr) (void)hipFree(b.ptr);
@@ -350,6 +350,7 @@ int svh_context_destroy(svh_context *ctx) {
 
 int svh_context_set_stream(svh_context *ctx, void *stream) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->stream = (hipStream_t)stream;
     return SVH_OK;
@@ -375,12 +376,14 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
 
 int svh_context_synchronize(svh_context *ctx) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
     SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SVH_OK;
 }
 
 int svh_context_trim(svh_context *ctx) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
     SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<PoolBlock> keep;
     for (auto &b : ctx->pool) {
@@ -420,6 +423,7 @@ int svh_profile_filter(svh_context *ctx, const char *kernel_name) {
 
 int svh_profile_collect(svh_context *ctx) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
     SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (auto &p : ctx->prof_pending) {
         float ms = 0;

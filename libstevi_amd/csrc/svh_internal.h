@@ -70,11 +70,29 @@ int fail(svh_context *ctx, int status, const char *fmt, ...);
         if (_s != SVH_OK) return _s;  \
     } while (0)
 
+// Makes the context's device current for the duration of a call and puts the caller's current device back afterwards (a
+// single-process multi-GPU caller keeps its own; a NULL stream means "the null stream of the CURRENT device" to the runtime)
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device) : target(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != target) (void)hipSetDevice(target);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != target) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+
+  private:
+    int target, prev = -1;
+};
+
 // RAII over pool blocks taken during one API call
 class Scratch {
   public:
     // every API call builds one Scratch first: also the place where the context's device is made current
-    explicit Scratch(svh_context *c) : ctx(c) { (void)hipSetDevice(c->device); }
+    explicit Scratch(svh_context *c) : ctx(c), guard(c->device) {}
     ~Scratch();
     // returns nullptr (and sets the context error) on failure
     void *get(size_t bytes);
@@ -82,6 +100,7 @@ class Scratch {
 
   private:
     svh_context *ctx;
+    DeviceGuard guard;
     std::vector<size_t> taken;
 };
 

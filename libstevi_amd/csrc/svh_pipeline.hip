@@ -182,7 +182,11 @@ struct ShardSetup {
     int H, Ws, Wt, C, F, nWw, Dtot, sb, D, sign;
 };
 
-int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r, ShardSetup *s) {
+// `per_shard_kernels`: the call runs the voxel sweep over [shard_begin, shard_begin + shard_count) and so needs the lane kernels
+// for that many disparities (svh_census_shard_keys).  svh_census_shard_finish only touches per-pixel maps of the WHOLE range: its
+// limit is the 12 index bits of the keys (census_max_total_disparities), not the per-launch one.
+int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r, bool per_shard_kernels,
+                ShardSetup *s) {
     if (!prm) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
     SVH_TRY(validate_image(ctx, img_l, "img_l", prm->match_func));
     SVH_TRY(validate_image(ctx, img_r, "img_r", prm->match_func));
@@ -216,7 +220,7 @@ int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array 
         if (prm->margins[k] < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "margins must be non-negative");
     SgmArgs sa{prm->sgm_directions, SVH_COST, s->H, s->Ws, s->D, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
                prm->margins[3]};
-    if (!census_lane_kernels_available(s->nWw, s->D) || !census_exact_regime(sa, s->nWw))
+    if (!census_lane_kernels_available(s->nWw, per_shard_kernels ? s->D : 1) || !census_exact_regime(sa, s->nWw))
         return fail(ctx, SVH_ERR_UNSUPPORTED,
                     "disparity sharding needs the integer-exact regime (integer Pout, window up to 11x11, <= 1024 disparities per shard)");
     return SVH_OK;
@@ -235,7 +239,7 @@ extern "C" int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *
                                      svh_array *keys) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     ShardSetup s;
-    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, &s));
+    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, true, &s));
     SVH_TRY(validate(ctx, keys, "keys", SVH_I32, 3, 3));
     if (keys->shape[0] != s.H || keys->shape[1] != s.Ws || keys->shape[2] != 2)
         return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "keys must have shape (%d,%d,2)", s.H, s.Ws);
@@ -272,7 +276,7 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
                                        const svh_array *keys, svh_array *disp, svh_array *refined) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     ShardSetup s;
-    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, &s));
+    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, false, &s));
     SVH_TRY(validate(ctx, keys, "keys", SVH_I32, 3, 3));
     if (keys->shape[0] != s.H || keys->shape[1] != s.Ws || keys->shape[2] != 2)
         return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "keys must have shape (%d,%d,2)", s.H, s.Ws);

@@ -22,9 +22,15 @@ import torch.distributed as dist
 from . import correlation as _c
 
 
-def shard_range(total, rank, world):
-    """Contiguous split of `total` disparities; the first total % world ranks get one more."""
-    base, rem = divmod(int(total), int(world))
+def shard_range(total, rank, world, align=1):
+    """Contiguous split of `total` disparities; the first ranks get one more unit when it does not divide.  `align` > 1 splits in
+    units of that many disparities when total is a multiple of it and every rank still gets a unit (32 keeps every shard a whole
+    number of the matrix-core sweep's row tiles); otherwise single disparities."""
+    total, world, align = int(total), int(world), int(align)
+    if align > 1 and total % align == 0 and total // align >= world:
+        begin, count = shard_range(total // align, rank, world)
+        return begin * align, count * align
+    base, rem = divmod(total, world)
     begin = rank * base + min(rank, rem)
     return begin, base + (1 if rank < rem else 0)
 
@@ -65,6 +71,8 @@ def stereoMatchSharded(img_l, img_r, h_radius, v_radius, disp_width, group=None,
         raise ValueError("more ranks than disparities")
     keys_kw = {k: v for k, v in kw.items() if k in ("dDir", "sgmDirections", "P1", "P2", "Pout", "margins", "matchFunc")}
     keys = _c.censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, **keys_kw)
+    if keys.shape[0] == 0:  # the reference's empty result (row / channel mismatch): the same on every rank, nothing to exchange
+        return {"disp": _c._empty_like(keys, 2, "i32")}
     if world > 1:
         plane0_only = _c.censusShardRegion1IsGlobal(img_l, img_r, disp_width, kw.get("dDir", _c.dispDirection.RightToLeft))
         keys = exchange_keys(keys, plane0_only, group).wait()
@@ -82,12 +90,12 @@ class ShardedStereoPipeline:
     Results are the ones stereoMatchSharded returns, one submit late; flush() returns the last one.  The keys of a frame
     are a fresh tensor per submit, so the frame in flight is never overwritten."""
 
-    def __init__(self, h_radius, v_radius, disp_width, group=None, **kw):
+    def __init__(self, h_radius, v_radius, disp_width, group=None, align=1, **kw):
         self.h_radius, self.v_radius, self.disp_width, self.group, self.kw = h_radius, v_radius, disp_width, group, kw
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         _, D = _c._search_range(disp_width)
-        self.shard = shard_range(D, self.rank, self.world)
+        self.shard = shard_range(D, self.rank, self.world, align)
         if self.shard[1] == 0:
             raise ValueError("more ranks than disparities")
         self._in_flight = None
@@ -105,6 +113,8 @@ class ShardedStereoPipeline:
 
     def _complete(self, frame):
         img_l, img_r, keys, exchange = frame
+        if keys.shape[0] == 0:
+            return {"disp": _c._empty_like(keys, 2, "i32")}
         if exchange is not None:
             keys = exchange.wait()
         return self._finish(img_l, img_r, keys)
@@ -112,6 +122,11 @@ class ShardedStereoPipeline:
     def submit(self, img_l, img_r):
         """Start frame k; returns the result of frame k - 1 (None for the first frame)."""
         keys = self._keys(img_l, img_r)
+        if keys.shape[0] == 0:  # the reference's empty result: nothing to exchange, nothing to finish
+            previous, self._in_flight = self._in_flight, None
+            done = self._complete(previous) if previous is not None else None
+            self._in_flight = (img_l, img_r, keys, None)
+            return done
         exchange = exchange_keys(keys, self._plane0_only(img_l, img_r), self.group, async_op=True) if self.world > 1 else None
         previous, self._in_flight = self._in_flight, (img_l, img_r, keys, exchange)
         return self._complete(previous) if previous is not None else None

@@ -1,6 +1,7 @@
-"""Full-size checks at BASELINE.json's shapes through size-independent properties (the oracle's literal loops
-would take minutes at these sizes): independent numpy / torch restatements of single stages, the Cost-branch
-identity of SURVEY.md section 8(a), planted-disparity recovery, and host/device path agreement."""
+"""Full-size checks at BASELINE.json's shapes: the oracle itself where its O(D) SGM restatement (bitwise identical to the
+literal loops, tests/test_oracle_semantics.py) finishes in seconds -- the whole C3 frame, row bands of C4 and C5 -- and
+size-independent properties elsewhere: independent numpy / torch restatements of single stages, the Cost-branch identity of
+SURVEY.md section 8(a), planted-disparity recovery, fast path == general kernels, shards == single call."""
 import numpy as np
 import pytest
 
@@ -91,10 +92,17 @@ def test_c3_census_sgm_1080p(c3_pair):
     del resid
     idx_t = sv.extractSelectedIndex(so.COST, t)
     assert torch.equal(idx_t, gen["disp"])
-    # a row band of the S volume against the oracle: rows whose lines start inside the band (Up2Down etc. start at row 0)
+    # the whole frame against the oracle: cost volume band, then the reference chain's disparity map, pixel for pixel
+    # (benchmarkCrossCorrelationAlgorithms.cpp:288-294; bench.py reports the same comparison as end_px_err)
     band = 24
     cvb = so.unfold_cost_volume(so.CENSUS, tgt[:band + 4], src[:band + 4], 4, 4, D)
     assert np.array_equal(gen["cv"][:band].cpu().numpy(), cvb[:band])
+    del gen, t
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+    vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), Pout)
+    want = so.index_to_disp(so.extract_index(vol, so.COST))
+    del cv, vol
+    assert int(np.count_nonzero(fast.cpu().numpy() != want)) == 0
     # planted disparities are recovered away from borders and occlusions
     disp = fast.cpu().numpy()
     inner = np.zeros((H, W), bool)
@@ -114,3 +122,127 @@ def test_c1_sad_480x360_full_vs_oracle():
     assert np.max(np.abs(got - cv) / np.maximum(1, np.abs(cv))) <= 1e-4
     assert np.array_equal(res["disp"].cpu().numpy(), so.index_to_disp(so.extract_index(got, so.COST)))
     assert (res["disp"].cpu().numpy() == so.index_to_disp(so.extract_index(cv, so.COST))).mean() > 0.999
+
+
+# ---- row bands of the big configurations against the oracle ---------------------------------------------------------------
+def band_mask(H, W, band):
+    """Pixels of the top `band` rows whose SGM value is the same whether the oracle sees the whole frame or only its top rows:
+    every pass but DownLeft2UpRight reaches a pixel from above or from the left; that pass runs up the anti-diagonals from the
+    left column, so a pixel keeps its value when its anti-diagonal starts inside the band (i + j < band) or is
+    not traversed at all (i + j >= H)."""
+    ii, jj = np.meshgrid(np.arange(band), np.arange(W), indexing="ij")
+    return (ii + jj < band) | (ii + jj >= H)
+
+
+def test_c5_shards_8k_fullsize():
+    """Config 5's geometry on one GPU: 8192x4320, D = 512 as 8 shards of 64 -> keys -> element-wise min (what the RCCL
+    all-reduce computes) -> finish.  Equal to the single call, to the general (non-exact-regime) kernels, and to the oracle on
+    a row band.  First run of the exact-regime bound 8 (2 cmax + Pout) (L + 2) < 2^24 at L = 8192 under test."""
+    H, W, D, band = 4320, 8192, 512, 40
+    src, tgt, _ = parallax_pair(H, W, 1280, 1280, 1520, 32, 256, seed=5)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    kw = dict(sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0)
+    single = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, **kw)["disp"]
+    assert sv.censusShardRegion1IsGlobal(d_tgt, d_src, D)
+    keys = None
+    for r in range(8):
+        k = sv.censusShardKeys(d_tgt, d_src, 4, 4, D, (64 * r, 64), **kw)
+        keys = k if keys is None else torch.minimum(keys, k)
+        del k
+    sharded = sv.censusShardFinish(d_tgt, d_src, keys, 4, 4, D, **kw)["disp"]
+    assert torch.equal(sharded, single)
+    del keys, sharded
+    try:  # the general wave-per-line kernels + literal float evaluation per voxel
+        sv.set_option(d_tgt, "census_fast_path", 0)
+        gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, **kw)["disp"]
+    finally:
+        sv.set_option(d_tgt, "census_fast_path", 1)
+    assert torch.equal(gen, single)
+    del gen
+    try:  # the vector-ALU sweep
+        sv.set_option(d_tgt, "census_sweep", 1)
+        valu = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, **kw)["disp"]
+    finally:
+        sv.set_option(d_tgt, "census_sweep", 0)
+    assert torch.equal(valu, single)
+    del valu
+    cv = so.unfold_cost_volume(so.CENSUS, tgt[:band + 4], src[:band + 4], 4, 4, D)
+    want = so.index_to_disp(so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))[:band]
+    m = band_mask(H, W, band)
+    assert m.mean() > 0.4
+    assert np.array_equal(single[:band].cpu().numpy()[m], want[m])
+
+
+@pytest.mark.parametrize("W", [4096, 8192])
+def test_census_sgm_wide_short_images_vs_oracle(W):
+    """The fused census + SGM path at C4 / C5 widths (row scans wider than 2048 pixels, the exact-regime bound near its limit),
+    on an image short enough for the oracle to run whole; all three sweep engines."""
+    H, D = 36, 256
+    src, tgt, _ = parallax_pair(H, W, 20, 8, 100, 16, 130, seed=W)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+    want = so.index_to_disp(so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
+    for engine in (0, 1, 2):
+        try:
+            sv.set_option(d_tgt, "census_sweep", engine)
+            got = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, sgmDirections=8, Pout=100.0)["disp"].cpu().numpy()
+        finally:
+            sv.set_option(d_tgt, "census_sweep", 0)
+        assert np.array_equal(got, want), engine
+
+
+def test_shards_beyond_1024_disparities_vs_oracle():
+    """svh_census_shard_finish on a range wider than one launch may sweep (4 shards of 512 = 2048 disparities; the keys hold up to
+    4096): the finish step only sees per-pixel maps and must not apply the per-shard limit."""
+    H, W, D = 20, 2200, 2048
+    src, tgt, _ = parallax_pair(H, W, 10, 4, 60, 9, 700, seed=77)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    kw = dict(sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0)
+    keys = None
+    for b in range(0, D, 512):
+        k = sv.censusShardKeys(d_tgt, d_src, 4, 4, D, (b, 512), **kw)
+        keys = k if keys is None else torch.minimum(keys, k)
+    got = sv.censusShardFinish(d_tgt, d_src, keys, 4, 4, D, **kw)["disp"].cpu().numpy()
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+    want = so.index_to_disp(so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
+    assert np.array_equal(got, want)
+
+
+def test_c4_ncc_sgm_refine_4k_fullsize():
+    """Config 4 at full size: 4096x2160, NCC 11x11, D = 256, SGM-8 (Score branch), arg-max, truncatedCostVolume(S, idx, 5, 5, 1) +
+    parabola (rule E6).  Cost volume band vs the oracle <= 1e-4 (north-star tolerance for float costs); the Score-branch SGM of
+    the GPU's own band bit-exact vs the oracle's SGM of that band; refined map of the band <= 1e-4 with the same NaN mask
+    (cost_based_refinement.h:128-163, correlation_base.h:606-609)."""
+    H, W, D, band, hr = 2160, 4096, 256, 28, 5
+    src, tgt, _ = parallax_pair(H, W, 640, 640, 760, 16, 128, seed=4)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    res = sv.stereoMatch(MF.NCC, d_tgt, d_src, hr, hr, D, sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=so.PARABOLA,
+                         refine_h_radius=hr, refine_v_radius=hr, want_cv=True, want_sgm_cv=True)
+    torch.cuda.synchronize()
+    gcv = res["cv"][:band].cpu().numpy()
+    cvb = so.unfold_cost_volume(so.NCC, tgt[:band + hr], src[:band + hr], hr, hr, D)[:band]
+    assert np.array_equal(np.isnan(gcv), np.isnan(cvb))
+    ok = ~np.isnan(cvb)
+    assert np.max(np.abs(gcv[ok] - cvb[ok])) <= 1e-4
+    # Score branch on the GPU's own cost band
+    m = band_mask(H, W, band)
+    sb = so.sgm(gcv, 8, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    gs = res["sgm_cv"][:band].cpu().numpy()
+    assert np.array_equal(np.isnan(gs[m]), np.isnan(sb[m]))
+    a, b = gs[m], sb[m]
+    okv = ~np.isnan(b)
+    assert np.array_equal(a[okv].view(np.uint32), b[okv].view(np.uint32))
+    # winner + refinement of the band: the truncated volume is NaN for rows i + v_r >= H, so only rows < band - v_r of the
+    # cropped oracle run see the same border rule as the full frame
+    idx = so.extract_index(gs, so.SCORE)
+    gdisp = res["disp"][:band].cpu().numpy()
+    assert np.array_equal(gdisp[m], so.index_to_disp(idx)[m])
+    ref = so.refine_disp(so.truncated_cost_volume(gs, idx, hr, hr, 1), idx, so.PARABOLA)
+    gref = res["refined"][:band].cpu().numpy()
+    rows = band - hr
+    mm = m[:rows]
+    a, b = gref[:rows][mm], ref[:rows][mm]
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    okr = ~np.isnan(b)
+    assert np.max(np.abs(a[okr] - b[okr])) <= 1e-4
+    assert okr.mean() > 0.3

@@ -34,7 +34,7 @@ __device__ __forceinline__ float g_from_keys(uint32_t key0, uint32_t key1, int p
 // census_sweep on the matrix cores (svh_census_sweep_mfma.hip); false when the geometry is outside what that kernel covers
 // (the caller then runs the VALU sweep)
 bool launch_sweep_mfma(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
-// the same with 4-bit (FP4) operands (svh_census_sweep_mfma4.hip)
-bool launch_sweep_mfma4(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
+// 4-bit (FP4) operands +-1, persistent blocks (svh_census_sweep_pm.hip)
+bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
 
 } // namespace svh

@@ -600,7 +600,7 @@ template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float 
     // engines: 0 = automatic (4-bit matrix-core sweep, else 8-bit, else vector ALU), 1 = vector ALU, 2 = int8 MFMA, 3 = FP4 MFMA
     if (ctx->census_sweep_mode != 1) {
         int status = SVH_OK;
-        if (ctx->census_sweep_mode != 2 && launch_sweep_mfma4(ctx, g, Pout, keys, gmap, &status)) return status;
+        if (ctx->census_sweep_mode != 2 && launch_sweep_pm(ctx, g, Pout, keys, gmap, &status)) return status;
         if (ctx->census_sweep_mode != 3 && launch_sweep_mfma(ctx, g, Pout, keys, gmap, &status)) return status;
     }
     const int64_t pad512 = (int64_t)ceil_div(g.Ws, 512) * 512, pad384 = (int64_t)ceil_div(g.Ws, 384) * 384;

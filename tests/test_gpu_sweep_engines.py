@@ -1,6 +1,6 @@
 """The three engines of census_sweep -- the vector-ALU kernel (xor + popcount), the matrix-core kernel with int8 operands
 (Hamming distance as a dot product, svh_census_sweep_mfma.hip) and the matrix-core kernel with FP4 operands
-(svh_census_sweep_mfma4.hip) -- must give the same regional winner keys bit for bit, and all the oracle's disparities.
+(svh_census_sweep_pm.hip) -- must give the same regional winner keys bit for bit, and all the oracle's disparities.
 svh_context_set_option("census_sweep", 1 | 2 | 3) selects the engine; 0 (default) takes the matrix cores wherever they apply
 (1..4 census words, D a multiple of 32 up to 992; the int8 form only RightToLeft and up to 480) and the vector ALU elsewhere."""
 import numpy as np

@@ -107,6 +107,16 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);
 
+/* Device memory for callers that keep arrays on the GPU between calls without a GPU runtime of their own (the C++ drop-in headers'
+ * HipBridge::DeviceArray: unfoldBasedCostVolume -> sgmCostVolume -> extractSelectedIndex written with the reference's names crosses
+ * PCIe once per image and once for the disparity map instead of once per volume).  Memory from svh_device_alloc is passed back in
+ * svh_array descriptors with memspace = SVH_DEVICE; upload / download are synchronous on the context's stream.  The reference has
+ * no counterpart (its arrays live in host memory: Multidim::Array). */
+int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr);
+int svh_device_free(svh_context *ctx, void *ptr);
+int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes);
+int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes);
+
 /* Per-kernel timing with hipEvents on the context's stream.  While enabled, every kernel launch is
  * bracketed by two events; svh_profile_collect() synchronises and folds them into per-kernel totals. */
 int svh_profile_enable(svh_context *ctx, int enable);

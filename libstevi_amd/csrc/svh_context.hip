@@ -394,6 +394,39 @@ int svh_context_trim(svh_context *ctx) {
     return SVH_OK;
 }
 
+int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr) return SVH_ERR_INVALID_ARGUMENT;
+    *ptr = nullptr;
+    DeviceGuard guard(ctx->device);
+    SVH_HIP_CHECK(ctx, hipMalloc(ptr, bytes ? bytes : 16));
+    return SVH_OK;
+}
+
+int svh_device_free(svh_context *ctx, void *ptr) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (!ptr) return SVH_OK;
+    DeviceGuard guard(ctx->device);
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // nothing enqueued on this context still uses it
+    SVH_HIP_CHECK(ctx, hipFree(ptr));
+    return SVH_OK;
+}
+
+int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes) {
+    if (!ctx || (bytes && (!device_dst || !host_src))) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SVH_OK;
+}
+
+int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !device_src))) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SVH_OK;
+}
+
 const char *svh_status_string(int status) {
     switch (status) {
     case SVH_OK: return "ok";

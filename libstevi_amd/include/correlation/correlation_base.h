@@ -136,6 +136,47 @@ Multidim::Array<T_CV, 4> truncatedBidirectionaCostVolume(Multidim::Array<T_CV, 4
     return tcv;
 }
 
+// ---- the same functions on arrays that stay in GPU memory (HipBridge::DeviceArray, stevi_hip_bridge.h): same names, same template
+// parameters, selected by the argument type; results are device arrays too, download() brings one to the host
+using HipBridge::DeviceArray;
+
+template <dispExtractionStartegy strategy, class T_CV> DeviceArray<disp_t, 2> extractSelectedIndex(DeviceArray<T_CV, 3> const &costVolume) {
+    DeviceArray<disp_t, 2> disp({costVolume.shape()[0], costVolume.shape()[1]});
+    if (disp.empty()) return disp;
+    svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
+    HipBridge::check(svh_extract_selected_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
+    return disp;
+}
+
+template <typename DT, dispDirection dDir = dispDirection::RightToLeft>
+DeviceArray<DT, 2> selectedIndexToDisp(DeviceArray<DT, 2> const &selectedIndex, disp_t disp_offset = 0) {
+    DeviceArray<DT, 2> disp(selectedIndex.shape());
+    if (disp.empty()) return disp;
+    svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
+    HipBridge::check(svh_selected_index_to_disp(HipBridge::context(), static_cast<int>(dDir), &in, disp_offset, &out));
+    return disp;
+}
+
+template <class T_CV> DeviceArray<T_CV, 2> selectedCost(DeviceArray<T_CV, 3> const &costVolume, DeviceArray<disp_t, 2> const &selectedIndex) {
+    DeviceArray<T_CV, 2> tcv({costVolume.shape()[0], costVolume.shape()[1]});
+    if (tcv.empty()) return tcv;
+    svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
+    HipBridge::check(svh_selected_cost(HipBridge::context(), &cv, &idx, &out));
+    return tcv;
+}
+
+template <class T_CV, dispDirection dir = dispDirection::RightToLeft, truncatedCostVolumeDirection sdir = truncatedCostVolumeDirection::Same>
+DeviceArray<T_CV, 3> truncatedCostVolume(DeviceArray<T_CV, 3> const &costVolume, DeviceArray<disp_t, 2> const &selectedIndex, uint8_t h_radius,
+                                         uint8_t v_radius, uint8_t cost_vol_radius) {
+    DeviceArray<T_CV, 3> tcv({costVolume.shape()[0], costVolume.shape()[1],
+                              (sdir == truncatedCostVolumeDirection::Both) ? cost_vol_radius * 4 + 1 : cost_vol_radius * 2 + 1});
+    if (tcv.empty()) return tcv;
+    svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
+    HipBridge::check(svh_truncated_cost_volume(HipBridge::context(), static_cast<int>(sdir), static_cast<int>(dir), &cv, &idx, h_radius, v_radius,
+                                               cost_vol_radius, &out));
+    return tcv;
+}
+
 // channelsMean<T_I, T_O>(in_data), correlation_base.h:1100-1136
 template <class T_I, class T_O = float, Multidim::ArrayDataAccessConstness C>
 inline Multidim::Array<T_O, 2> channelsMean(Multidim::Array<T_I, 3, C> const &in_data) {

@@ -29,6 +29,19 @@ Multidim::Array<float, 2> refineDispCostInterpolation(Multidim::Array<float, 3> 
     return refined;
 }
 
+// the same on arrays in GPU memory (HipBridge::DeviceArray)
+template <InterpolationKernel kernel>
+DeviceArray<float, 2> refineDispCostInterpolation(DeviceArray<float, 3> const &truncatedCostVolume, DeviceArray<disp_t, 2> const &rawDisparity) {
+    int depth = truncatedCostVolume.shape()[2];
+    int cv_radius = (depth - 1) / 2;
+    if (cv_radius < 1 or 2 * cv_radius + 1 != depth) return DeviceArray<float, 2>(); // :141-143
+    DeviceArray<float, 2> refined(rawDisparity.shape());
+    if (refined.empty()) return refined;
+    svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
+    if (!HipBridge::check(svh_refine_disp_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out))) return DeviceArray<float, 2>();
+    return refined;
+}
+
 // refineDisp2dCostInterpolation<kernel, isotropHypothesis>(truncatedCostVolume, rawDisparity), cost_based_refinement.h:165-376
 template <InterpolationKernel kernel, IsotropyHypothesis isotropHypothesis = IsotropyHypothesis::Isotropic>
 Multidim::Array<float, 3> refineDisp2dCostInterpolation(Multidim::Array<float, 4> const &truncatedCostVolume, Multidim::Array<disp_t, 3> const &rawDisparity) {

@@ -159,6 +159,30 @@ Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const
     return cv;
 }
 
+// unfoldBasedCostVolume with the volume left in GPU memory: the head of a call chain on HipBridge::DeviceArray (the images are
+// host arrays and cross PCIe once; sgmCostVolume / extractSelectedIndex / ... then take the DeviceArray overloads)
+template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
+DeviceArray<TCV, 3> unfoldBasedCostVolumeOnDevice(Multidim::Array<T_L, nImDim> const &img_l, Multidim::Array<T_R, nImDim> const &img_r, uint8_t h_radius,
+                                                  uint8_t v_radius, disp_t disp_width) {
+    static_assert(HipBridge::onGpuPath<matchFunc>(), "libstevi_hip: this matching function has no GPU path");
+    static_assert(std::is_same_v<TCV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(HipBridge::imageTypeOnGpuPath<T_L, MatchingFunctionTraits<matchFunc>::ZeroMean, MatchingFunctionTraits<matchFunc>::Normalized>() &&
+                      HipBridge::imageTypeOnGpuPath<T_R, MatchingFunctionTraits<matchFunc>::ZeroMean, MatchingFunctionTraits<matchFunc>::Normalized>(),
+                  "libstevi_hip: images are float, or uint8 with CENSUS / HAMMING / CC / SSD / SAD");
+    auto l_shape = img_l.shape();
+    auto r_shape = img_r.shape();
+    if (l_shape[0] != r_shape[0] || disp_width <= 0) return DeviceArray<TCV, 3>(); // :751-753
+    if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return DeviceArray<TCV, 3>(); // :755-759
+    auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
+    DeviceArray<TCV, 3> cv({src[0], src[1], static_cast<int>(disp_width)});
+    if (cv.empty()) return cv;
+    svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
+    if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
+                                                 disp_width, &out)))
+        return DeviceArray<TCV, 3>();
+    return cv;
+}
+
 // unfoldBasedCostVolume(img_l, img_r, compressor, disp_width), cross_correlations.h:767-791
 template <matchingFunctions matchFunc, class T_L, class T_R, int nImDim = 2, dispDirection dDir = dispDirection::RightToLeft, typename TCV = float>
 Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const &img_l, Multidim::Array<T_R, nImDim> const &img_r,

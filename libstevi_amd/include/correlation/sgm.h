@@ -30,6 +30,20 @@ Multidim::Array<float, 3> sgmCostVolume(Multidim::Array<T_CV, 3> const &cv_base,
     return sgm_cv;
 }
 
+// the same on a cost volume that stays in GPU memory (HipBridge::DeviceArray): the result stays there too
+template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV>
+DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
+    static_assert(nDirections == 4 or nDirections == 8 or nDirections == 16, "SGM can only operate with 4, 8 or 16 directions");
+    static_assert(nDirections != 16, "libstevi_hip: the reference's 16-direction lines overlap inside one OpenMP loop; its result is not defined");
+    static_assert(std::is_same_v<T_CV, float>, "libstevi_hip: cost volumes are float");
+    DeviceArray<float, 3> sgm_cv(cv_base.shape());
+    if (sgm_cv.empty()) return sgm_cv;
+    const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
+    svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
+    HipBridge::check(svh_sgm_cost_volume(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
+    return sgm_cv;
+}
+
 // Extension, not in the reference: the "textbook" mode (all directions fully traversed, neighbour penalties in the Cost strategy);
 // see svh_sgm_cost_volume_textbook in include/stevi_hip.h.  sgmCostVolume above stays the reference as written.
 template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV>

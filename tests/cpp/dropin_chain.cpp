@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <correlation/census.h>
@@ -52,6 +53,38 @@ int main(int argc, char **argv) {
             SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(SC::extractSelectedIndex<strat>(SGM_CV), 0);
         dump(out + "_census_sgm.f32", SGM_CV.data(), SGM_CV.flatLenght());
         dump(out + "_census_disp.i32", disp.data(), disp.flatLenght());
+        // the same chain with the volumes left in GPU memory (HipBridge::DeviceArray): the reference's names, overloads picked by
+        // the argument type; images up once, one disparity map down
+        auto dCV = SC::unfoldBasedCostVolumeOnDevice<matchFunc>(target, source, h_r, v_r, D);
+        auto dSGM = SC::sgmCostVolume<8, strat>(dCV, P1, P2, StereoVision::Margins(), Pout);
+        auto dIdx = SC::extractSelectedIndex<strat>(dSGM);
+        Multidim::Array<SC::disp_t, 2> ddisp = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(dIdx, 0).download();
+        Multidim::Array<float, 2> dref =
+            SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(SC::truncatedCostVolume(dSGM, dIdx, h_r, v_r, 1), dIdx).download();
+        dump(out + "_census_disp_dev.i32", ddisp.data(), ddisp.flatLenght());
+        dump(out + "_census_ref_dev.f32", dref.data(), dref.flatLenght());
+        Multidim::Array<float, 2> href = SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(
+            SC::truncatedCostVolume(SGM_CV, SC::extractSelectedIndex<strat>(SGM_CV), h_r, v_r, 1), SC::extractSelectedIndex<strat>(SGM_CV));
+        dump(out + "_census_ref_host.f32", href.data(), href.flatLenght());
+        // re-entrancy: the reference's functions are stateless; here every thread gets a context of its own (stevi_hip_bridge.h).
+        // Three threads run the chain at once on the same inputs and must each reproduce the map above.
+        int mismatches[3] = {-1, -1, -1};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < 3; t++)
+            pool.emplace_back([&, t] {
+                auto cv = SC::unfoldBasedCostVolume<matchFunc>(target, source, h_r, v_r, D);
+                auto d = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(
+                    SC::extractSelectedIndex<strat>(SC::sgmCostVolume<8, strat>(cv, P1, P2, StereoVision::Margins(), Pout)), 0);
+                int bad = 0;
+                for (size_t e = 0; e < d.flatLenght(); e++) bad += d.data()[e] != disp.data()[e];
+                mismatches[t] = bad;
+            });
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < 3; t++)
+            if (mismatches[t] != 0) {
+                fprintf(stderr, "thread %d: %d pixels differ from the single-threaded result\n", t, mismatches[t]);
+                return 3;
+            }
     }
     { // NCC + SGM-8 (Score) + parabola refinement
         constexpr auto matchFunc = SC::matchingFunctions::NCC;

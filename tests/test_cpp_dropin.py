@@ -42,6 +42,10 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(got_vol.view(np.uint32), vol.view(np.uint32))
     got_disp = np.fromfile(tmp_path / "o_census_disp.i32", np.int32).reshape(H, W)
     assert np.array_equal(got_disp, so.index_to_disp(so.extract_index(vol, so.COST)))
+    # the same chain on HipBridge::DeviceArray (volumes never leave the GPU) gives the same bits
+    assert np.array_equal(np.fromfile(tmp_path / "o_census_disp_dev.i32", np.int32).reshape(H, W), got_disp)
+    a, b = np.fromfile(tmp_path / "o_census_ref_dev.f32", np.float32), np.fromfile(tmp_path / "o_census_ref_host.f32", np.float32)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     cv2 = so.unfold_cost_volume_2d(so.ZNCC, tgt, src, 2, 2, (-1, 2), (-2, 3))
     got2 = np.fromfile(tmp_path / "o_zncc2d_cv.f32", np.float32).reshape(cv2.shape)
     assert np.array_equal(np.isnan(got2), np.isnan(cv2)) and np.nanmax(np.abs(got2 - cv2)) <= 1e-4

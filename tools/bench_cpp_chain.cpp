@@ -1,0 +1,50 @@
+// The reference benchmark's chain through the C++ drop-in headers, timed two ways at 1920 x 1080, D = 256 (census 9x9 + SGM-8):
+//   host arrays   every function takes and returns Multidim::Array: each volume (2.1 GB) crosses PCIe down and up again
+//   device arrays the same names on HipBridge::DeviceArray: images up once, the disparity map down once
+//   g++ -std=c++17 -O2 -I libstevi_amd/include tools/bench_cpp_chain.cpp -o tools/bench_cpp_chain -L libstevi_amd -lstevi_hip \
+//       -Wl,-rpath,$PWD/libstevi_amd -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -lamdhip64 -lpthread
+#include <chrono>
+#include <cstdio>
+#include <random>
+
+#include <correlation/cross_correlations.h>
+#include <correlation/sgm.h>
+
+namespace SC = StereoVision::Correlation;
+
+int main() {
+    const int H = 1080, W = 1920, D = 256;
+    Multidim::Array<float, 2> l(H, W), r(H, W);
+    std::mt19937 rng(3);
+    std::uniform_real_distribution<float> u(-1.f, 1.f);
+    for (size_t e = 0; e < l.flatLenght(); e++) {
+        l.data()[e] = u(rng);
+        r.data()[e] = u(rng);
+    }
+    constexpr auto f = SC::matchingFunctions::CENSUS;
+    constexpr auto strat = SC::MatchingFunctionTraits<f>::extractionStrategy;
+    auto host_chain = [&] {
+        auto cv = SC::unfoldBasedCostVolume<f>(l, r, 4, 4, D);
+        auto s = SC::sgmCostVolume<8, strat>(cv, 0.001f, 0.01f, StereoVision::Margins(), 100);
+        return SC::selectedIndexToDisp<SC::disp_t>(SC::extractSelectedIndex<strat>(s), 0);
+    };
+    auto device_chain = [&] {
+        auto cv = SC::unfoldBasedCostVolumeOnDevice<f>(l, r, 4, 4, D);
+        auto s = SC::sgmCostVolume<8, strat>(cv, 0.001f, 0.01f, StereoVision::Margins(), 100);
+        return SC::selectedIndexToDisp<SC::disp_t>(SC::extractSelectedIndex<strat>(s), 0).download();
+    };
+    auto time_ms = [](auto fn, int reps) {
+        auto ref = fn(); // warm-up (workspace, first-touch)
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < reps; k++) ref = fn();
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    };
+    auto a = host_chain();
+    auto b = device_chain();
+    long diff = 0;
+    for (size_t e = 0; e < a.flatLenght(); e++) diff += a.data()[e] != b.data()[e];
+    const double th = time_ms(host_chain, 2), td = time_ms(device_chain, 10);
+    printf("{\"chain\": \"unfoldBasedCostVolume -> sgmCostVolume<8> -> extractSelectedIndex -> selectedIndexToDisp (C++ drop-in headers), 1920x1080 D=256 census 9x9\", "
+           "\"host_arrays_ms\": %.1f, \"device_arrays_ms\": %.2f, \"pixels_differing\": %ld}\n", th, td, diff);
+    return diff != 0;
+}

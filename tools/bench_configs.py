@@ -57,9 +57,28 @@ def main():
         torch.cuda.synchronize()
         sv.profile_enable(d_src, False)
         prof = sv.profile_collect(d_src)
-        print(json.dumps({"config": name, "shape": [W, H, D], "func": func.name, "sgm": sgm, "ms": round(dt * 1e3, 3),
-                          "Mdisp_per_s": round(W * H * D / dt / 1e6, 1), "kernel_ms": {k: round(v[0] / steps, 3) for k, v in prof.items()},
-                          "checksum": int(out["disp"].sum().item())}), flush=True)
+        line = {"config": name, "shape": [W, H, D], "func": func.name, "sgm": sgm, "ms": round(dt * 1e3, 3),
+                "Mdisp_per_s": round(W * H * D / dt / 1e6, 1), "kernel_ms": {k: round(v[0] / steps, 3) for k, v in prof.items()},
+                "checksum": int(out["disp"].sum().item())}
+        if name.startswith("c4"):
+            # HBM roofline of the Score-branch SGM, the dominant kernel of this configuration.  SURVEY.md 8(d) prices C4 at 68 B/voxel
+            # (C written 4 + five passes x (C read 4 + S read-modify-write 8) + final S read 4).  The reference's five effective passes
+            # do not all cover the image (finding F5: UpLeft2DownRight's two start loops cover it once between them, UpRight2DownLeft
+            # covers i + j < W, DownLeft2UpRight covers i + j < H), so the bytes that must move are fewer:
+            ii = torch.arange(H, device=dev)[:, None]
+            jj = torch.arange(W, device=dev)[None, :]
+            cover = [1.0, 1.0, 1.0, float((ii + jj < W).float().mean()), float((ii + jj < H).float().mean())]
+            sgm_b = 8.0 + 12.0 * sum(cover[1:])           # first pass writes S from C (8 B), every later one reads C and S, writes S
+            eff_b = 4.0 + sgm_b + 4.0                        # + C written by the cost kernel, + the winner scan's read of S
+            vox = W * H * D
+            sgm_ms = line["kernel_ms"].get("sgm_score_pass")
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "sgm_score_pass (six launches)", "pass_coverage": [round(c, 3) for c in cover],
+                "effective_bytes_per_voxel_sgm": round(sgm_b, 1), "effective_bytes_per_voxel_chain": round(eff_b, 1), "survey_model_bytes_per_voxel": 68.0,
+                "achieved_GBps_sgm": round(sgm_b * vox / (sgm_ms * 1e-3) / 1e9, 1) if sgm_ms else None, "peak": 8000.0,
+                "frac_sgm": round(sgm_b * vox / (sgm_ms * 1e-3) / 1e9 / 8000.0, 4) if sgm_ms else None,
+                "achieved_GBps_whole_step": round(eff_b * vox / dt / 1e9, 1), "frac_whole_step": round(eff_b * vox / dt / 1e9 / 8000.0, 4)}
+        print(json.dumps(line), flush=True)
         del out
         torch.cuda.empty_cache()
 

@@ -171,16 +171,18 @@ __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_s
         const int col0 = j0 + slice_col_off;
         const int mis_t = (((i * g.Wt + col0) * NW * 4) & 15) >> 2; // dwords between the first piece's start and the slice
         const bool interior = col0 >= 0 && col0 + SL <= g.Wt;        // (wave uniform) every column of the slice is inside the image
-        // Straight-line rounds of UB units: every staging read, then the expansions, then every store.  No unit is predicated: a unit
-        // past the slice reads staging dword 0 and stores into the dump record (with per-unit branches the compiler serialised the
-        // units: five dependent LDS round trips per round, ~3,000 cycles per item in the stamps).
-        for (int u0 = 0; u0 < SL * NW; u0 += 64 * UB) {
+        // Straight-line rounds of UB units: every staging read, then the expansions, then every store (with per-unit branches the
+        // compiler serialised the units: five dependent LDS round trips per round, ~3,000 cycles per item in the stamps).  FULL: all
+        // 64 UB units of the round exist; otherwise a unit past the slice reads staging dword 0 and stores into the dump record.
+        // INTERIOR: no column test.  In a FULL INTERIOR round of the AFFINE layout every address is a per-item base plus a constant.
+        auto round = [&](int u0, auto full_c, auto interior_c) {
+            constexpr bool FULL = decltype(full_c)::value, INTERIOR = decltype(interior_c)::value;
             uint32_t v[UB];
             int dst[UB];
 #pragma unroll
             for (int b = 0; b < UB; b++) {
                 const int u = u0 + 64 * b + lane;
-                const bool live = u < SL * NW;
+                const bool live = FULL || u < SL * NW;
                 int rd, yy;
                 if constexpr (AFFINE) {
                     rd = mis_t + (fwd ? u0 : -u0) + rd_lane + (fwd ? 64 * b : -64 * b);
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_s
                     dst[b] = live ? w * WIN + wave * SL + yy : dump;
                 }
                 const uint32_t staged = stage_t[live ? rd : 0];
-                if (interior) { // (wave uniform)
+                if constexpr (INTERIOR) {
                     v[b] = live ? staged : 0u;
                 } else { // the clamp in issue_dma shifts a piece only when it would leave the map: columns outside the image, replaced here
                     const int col = fwd ? col0 + yy : col0 + (SL - 1 - yy);
@@ -202,6 +204,13 @@ __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_s
             }
 #pragma unroll
             for (int b = 0; b < UB; b++) win[dst[b]] = word_record(v[b]);
+        };
+        const int n_units = SL * NW, n_full = n_units / (64 * UB);
+        if (interior) {
+            for (int rr = 0; rr < n_full; rr++) round(rr * 64 * UB, std::true_type{}, std::true_type{});
+            if (n_full * 64 * UB < n_units) round(n_full * 64 * UB, std::false_type{}, std::true_type{});
+        } else {
+            for (int u0 = 0; u0 < n_units; u0 += 64 * UB) round(u0, std::false_type{}, std::false_type{});
         }
         const int mis_s = (((i * g.Ws + j0 + wave * CT * 32) * NW * 4) & 15) >> 2;
 #pragma unroll
@@ -361,6 +370,20 @@ __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_s
                     v16f acc_a = tile(f_next, first_tile), acc_b;
                     f_next = load_frags(1);
                     int k = 0; // invariant: acc_a = tile k (in flight), f_next = fragments of tile k + 1
+                    for (; k + 4 < NT - 1; k += 4) { // (four tiles per trip: half the loop bookkeeping of two)
+                        acc_b = tile(f_next, full_tile);
+                        f_next = load_frags(k + 2);
+                        epilogue(acc_a, k, chk);
+                        acc_a = tile(f_next, full_tile);
+                        f_next = load_frags(k + 3);
+                        epilogue(acc_b, k + 1, chk);
+                        acc_b = tile(f_next, full_tile);
+                        f_next = load_frags(k + 4);
+                        epilogue(acc_a, k + 2, chk);
+                        acc_a = tile(f_next, full_tile);
+                        f_next = load_frags(k + 5);
+                        epilogue(acc_b, k + 3, chk);
+                    }
                     for (; k + 2 < NT - 1; k += 2) {
                         acc_b = tile(f_next, full_tile);
                         f_next = load_frags(k + 2);

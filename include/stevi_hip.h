@@ -123,6 +123,9 @@ int svh_profile_enable(svh_context *ctx, int enable);
 /* restrict the event bracketing to launches of one kernel (NULL or "" = every kernel): two events per launch cost a few
  * microseconds of stream time each, which matters for sub-millisecond steps */
 int svh_profile_filter(svh_context *ctx, const char *kernel_name);
+/* bracket only every `every`-th launch that passes the filter (1 = every launch): an event pair costs about 5 us of stream time,
+ * a tenth of a 0.1 ms step when every launch of one kernel is bracketed */
+int svh_profile_sampling(svh_context *ctx, int every);
 int svh_profile_reset(svh_context *ctx);
 int svh_profile_collect(svh_context *ctx);
 int svh_profile_count(const svh_context *ctx);

@@ -858,10 +858,12 @@ def set_option(x, name, value):
 
 
 # ------------------------------------------------------------------------------------------------ profiling
-def profile_enable(x, on=True, only=None):
-    """hipEvents around every kernel launch (only=None) or around launches of the kernel named `only`."""
+def profile_enable(x, on=True, only=None, every=1):
+    """hipEvents around every kernel launch (only=None) or around launches of the kernel named `only`; every=n brackets only
+    every n-th of them (an event pair costs about 5 us of stream time)."""
     lib = _capi.load()
     lib.svh_profile_filter(context_for(x), only.encode() if only else None)
+    lib.svh_profile_sampling(context_for(x), int(every))
     lib.svh_profile_enable(context_for(x), 1 if on else 0)
 
 

@@ -69,6 +69,7 @@ static hipEvent_t take_event(svh_context *ctx) {
 
 ProfScope::ProfScope(svh_context *c, const char *n) : ctx(c), name(n) {
     if (!ctx->profiling || (!ctx->prof_filter.empty() && ctx->prof_filter != n)) return;
+    if (ctx->prof_every > 1 && (ctx->prof_seen++ % ctx->prof_every) != 0) return;
     start = take_event(ctx);
     stop = take_event(ctx);
     if (!start || !stop) return;
@@ -451,6 +452,13 @@ int svh_profile_enable(svh_context *ctx, int enable) {
 int svh_profile_filter(svh_context *ctx, const char *kernel_name) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     ctx->prof_filter = kernel_name ? kernel_name : "";
+    return SVH_OK;
+}
+
+int svh_profile_sampling(svh_context *ctx, int every) {
+    if (!ctx || every < 1) return SVH_ERR_INVALID_ARGUMENT;
+    ctx->prof_every = every;
+    ctx->prof_seen = 0;
     return SVH_OK;
 }
 

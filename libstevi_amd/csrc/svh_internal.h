@@ -43,6 +43,8 @@ struct svh_context {
     std::vector<svh::PoolBlock> pool;
     bool profiling = false;
     std::string prof_filter; // when not empty only launches of this kernel are bracketed by events
+    int prof_every = 1;      // svh_profile_sampling: bracket every n-th eligible launch
+    int64_t prof_seen = 0;
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel

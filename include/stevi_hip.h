@@ -102,7 +102,9 @@ const char *svh_last_error(const svh_context *ctx);
  * words, disp_count a multiple of 32 up to 992; int8: up to 480 and RightToLeft only -- anything else runs the vector-ALU kernel);
  * automatic = 3 where it applies.  Same keys bit for bit.
  * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
- * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one. */
+ * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one.
+ * "sgm_score_fused" (default 1): 0 makes the Score branch of svh_sgm_cost_volume run one read-modify-write sweep of the volume per
+ * pass instead of carrying the four downward passes in one sweep (same bits; the parity tests cross-check the two). */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);

@@ -372,6 +372,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->literal_cost_volumes = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "sgm_score_fused") == 0) {
+        ctx->sgm_score_fused = value != 0;
+        return SVH_OK;
+    }
     return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);
 }
 

@@ -48,6 +48,7 @@ struct svh_context {
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
+    bool sgm_score_fused = true;       // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;

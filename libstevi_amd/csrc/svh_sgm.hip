@@ -420,7 +420,8 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // NEG: the pass runs on the negated costs and subtracts its contribution, which turns the max / -P recurrence into the
 // textbook min / +P one bit for bit (negation is exact, max(-x) = -min(x), fl(-p - P) = -fl(p + P)); only used by the
 // textbook mode: the reference's own Cost branch is the scalar recurrence of the kernels above (finding F4).
-template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG>
+// DELTA: the pass writes its contribution act - c alone (the fused downward sweep below adds it in the reference's place).
+template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false>
 __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
                                                             int D, int W, float P1, float P2, float Pout, bool vec) {
     const int lane = threadIdx.x & 63;
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
                 float act = c[k];
                 if (maxp_fin && finite_f(a)) act = c[k] + (a - max_p); // :251-254
                 const float base = FIRST ? c_in[k] : sacc[k];
-                outv[k] = NEG ? base - (act - c[k]) : base + (act - c[k]); // :298-300
+                outv[k] = DELTA ? act - c[k] : (NEG ? base - (act - c[k]) : base + (act - c[k])); // :298-300
                 prev[k] = act;
             }
             float *o = sgm + ((int64_t)ii * W + jj) * D + lane * R;
@@ -522,7 +523,7 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
         for (int b = 0; b < B; b++)
             if (st + b < L.len) {
                 src.template load<R>(L.i0 + (st + b) * L.di, L.j0 + (st + b) * L.dj, lane, c[b]);
-                if (!FIRST) acc.template load<R>(L.i0 + (st + b) * L.di, L.j0 + (st + b) * L.dj, lane, sv[b]);
+                if (!FIRST && !DELTA) acc.template load<R>(L.i0 + (st + b) * L.di, L.j0 + (st + b) * L.dj, lane, sv[b]);
             }
     };
     auto run_batch = [&](const float (&c)[B][R], const float (&sv)[B][R], int st) {
@@ -536,6 +537,260 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
         run_batch(c0, s0v, st);
         load_batch(c0, s0v, st + 2 * B);
         run_batch(c1, s1v, st + B);
+    }
+}
+
+
+// ---- Score branch: the four downward passes in one sweep -----------------------------------------------------
+// Passes 0, 2, 3 and 4 all step one row down: a pixel (i, j) takes its line state from (i-1, j), (i-1, j-1) and (i-1, j+1).  One
+// sweep over the rows can therefore carry the three states, add the contributions in the reference's order
+//     S = (((c + d0) + d1) [+ d2 if i >= j] [+ d3 if j >= i]) [+ d4 if i + j < W]        (d2 = d3: the same diagonal lines)
+// in registers and touch the volume once (read c and d1, write S: 12 B/voxel) where the pass-per-launch form reads and writes S
+// once per pass.  d1, the Left2Right contribution, is written beforehand by the DELTA form of the kernel above.
+//
+// Parallel form.  In the skewed coordinate u = i + j the three predecessors of (i, u) are (i-1, u-1), (i-1, u-2) and (i-1, u):
+// none lies to the right.  The image is cut into strips of WB consecutive u (parallelograms leaning left), one block per strip,
+// and a strip needs from its left neighbour, per row, the Up2Down state of its last cell and the diagonal states of its last two
+// cells: 3 vectors of D floats.  Blocks form a one-directional pipeline: strip s publishes row i (exporter wave: states to a
+// global edge buffer with agent-scope stores, s_waitcnt, then flag[s] = i + 1), strip s + 1 consumes it before its row i + 1
+// (importer wave: polls flag[s], loads the vectors into the state rings in LDS).  A strip takes its number from a ticket counter,
+// so the strip it waits for always started before it: the pipeline cannot deadlock whatever the number of resident blocks.
+//
+// State in LDS, one slot per LINE, updated in place: Up2Down by column (ring of WB + 1), diagonal by j - i (ring of WB + 2),
+// anti-diagonal by u (WB fixed slots); the spare slots receive next row's imports while this row still reads the leaving ones.
+// One barrier per row; NCW compute waves (a cell = all three passes of one pixel, the 64 lanes span the disparities as in the
+// kernel above), then the exporter and the importer wave.
+template <int R>
+__device__ __forceinline__ void score_step_far_global(const float (&prev)[R], const float (&c)[R], int jj, int lane, int D, int W, float P1,
+                                                      float P2, float Pout, float (&act)[R]) {
+    float pf[R];
+    float A = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        pf[k] = (lane * R + k < D && finite_f(prev[k])) ? prev[k] : -INFINITY; // isfinite filters of sgm.h:224, :241
+        A = fmaxf(A, pf[k]);
+    }
+    const float max_p = wave_max_dpp(A);                                       // :220-227
+    const float prevL = lane_shift_up(pf[R - 1], -INFINITY);                   // disparity lane*R - 1
+    const float prevR = lane_shift_down(pf[0], -INFINITY);                     // disparity lane*R + R
+    const bool maxp_fin = finite_f(max_p);
+    const float far = max_p - P2;                                              // :239 (FAR_IS_GLOBAL, see above)
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const float lo = (k > 0 ? pf[k - 1] : prevL) - P1;                     // :238
+        const float hi = (k < R - 1 ? pf[k + 1] : prevR) - P1;
+        float a = fmaxf(fmaxf(pf[k], far), fmaxf(lo, hi));
+        if (jj + lane * R + k >= W) a -= Pout;                                 // :247-249
+        act[k] = c[k];
+        if (maxp_fin && finite_f(a)) act[k] = c[k] + (a - max_p);              // :251-254
+    }
+}
+
+template <int R> __device__ __forceinline__ void lds_get(const float *p, float (&v)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < R / 4; q++) {
+            const float4 x = *reinterpret_cast<const float4 *>(p + 4 * q);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else if constexpr (R == 2) {
+        const float2 x = *reinterpret_cast<const float2 *>(p);
+        v[0] = x.x; v[1] = x.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) v[k] = p[k];
+    }
+}
+template <int R> __device__ __forceinline__ void lds_put(float *p, const float (&v)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if constexpr (R == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) p[k] = v[k];
+    }
+}
+
+constexpr int kDownSpinCap = 1 << 22; // polls of a neighbour's flag before a block gives up (seconds; a healthy wait is microseconds)
+
+template <int R, int WB, int NCW>
+__global__ void __launch_bounds__((NCW + 2) * 64) sgm_score_down_kernel(const float *__restrict__ cv, float *sgm, int H, int W, int D, float P1,
+                                                                        float P2, float Pout, bool vec, float *edges, int *sync_words) {
+    constexpr int DP = 64 * R, MV = WB + 1, MD = WB + 2, CPW = WB / NCW;
+    static_assert(WB % NCW == 0, "cells of a row are dealt evenly to the compute waves");
+    extern __shared__ __attribute__((aligned(16))) float down_lds[];
+    float *ringV = down_lds, *ringD = ringV + MV * DP, *ringA = ringD + MD * DP, *stage = ringA + WB * DP; // stage[2][3][DP]
+    __shared__ int s_strip;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int *ticket = sync_words, *error = sync_words + 1, *flags = sync_words + 2;
+    if (threadIdx.x == 0) s_strip = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int s = s_strip, n_strips = gridDim.x;
+    const int u0 = s * WB;
+    const int i_lo = max(0, u0 - (W - 1)), i_hi = min(H - 1, u0 + WB - 1);         // rows in which the strip meets the image
+    const int l_lo = max(0, u0 - WB - (W - 1)), l_hi = min(H - 1, u0 - 1);          // the left neighbour's
+    const int64_t strip_floats = (int64_t)H * 3 * DP;
+    float *my_edges = edges + (int64_t)s * strip_floats;
+    const float *left_edges = edges + (int64_t)(s - 1) * strip_floats;
+    auto slotV = [&](int j) { return ((j % MV) + MV) % MV; };
+    auto slotD = [&](int k) { return ((k % MD) + MD) % MD; };
+    const SrcVolume src{cv, W, D, vec};
+    const SrcVolume acc{sgm, W, D, vec};
+
+    if (wave == NCW + 1) {
+        // ---- importer: what row r needs from the left strip's row r - 1, into the spare ring slots
+        auto import_for = [&](int r) {
+            if (s == 0 || r - 1 < l_lo || r - 1 > l_hi) return;
+            int spins = 0;
+            while (__hip_atomic_load(&flags[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < r) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > kDownSpinCap) {
+                    __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            asm volatile("" ::: "memory");
+            const float *e = left_edges + (int64_t)(r - 1) * 3 * DP + lane * R;
+            float v[3][R];
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int k = 0; k < R; k++) v[q][k] = __hip_atomic_load(e + q * DP + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lds_put<R>(ringV + slotV(u0 - r) * DP + lane * R, v[0]);
+            lds_put<R>(ringD + slotD(u0 - 2 * r) * DP + lane * R, v[1]);
+            lds_put<R>(ringD + slotD(u0 - 2 * r + 1) * DP + lane * R, v[2]);
+        };
+        import_for(i_lo);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int i = i_lo; i <= i_hi; i++) {
+            if (i < i_hi) import_for(i + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    if (wave == NCW) {
+        // ---- exporter: last row's staged edge states to the edge buffer, then the flag
+        auto export_row = [&](int r) {
+            if (s + 1 >= n_strips || r + 1 > H - 1) return; // nobody reads it
+            float v[3][R];
+#pragma unroll
+            for (int q = 0; q < 3; q++) lds_get<R>(stage + ((r & 1) * 3 + q) * DP + lane * R, v[q]);
+            float *e = my_edges + (int64_t)r * 3 * DP + lane * R;
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int k = 0; k < R; k++) __hip_atomic_store(e + q * DP + k, v[q][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the stores above have reached the coherent level
+            if (lane == 0) __hip_atomic_store(&flags[s], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int i = i_lo; i <= i_hi; i++) {
+            if (i > i_lo) export_row(i - 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        export_row(i_hi);
+        return;
+    }
+
+    // ---- compute waves: cells t = wave, wave + NCW, ... of the strip's row
+    auto load_row = [&](float (&c)[CPW][R], float (&d1)[CPW][R], int i) {
+        if (i > i_hi) return;
+#pragma unroll
+        for (int q = 0; q < CPW; q++) {
+            const int j = u0 + wave + q * NCW - i;
+            if (j < 0 || j >= W) continue;
+            src.template load<R>(i, j, lane, c[q]);
+            acc.template load<R>(i, j, lane, d1[q]);
+        }
+    };
+    auto run_row = [&](const float (&c)[CPW][R], const float (&d1)[CPW][R], int i) {
+        float *st = stage + (i & 1) * 3 * DP + lane * R;
+#pragma unroll
+        for (int q = 0; q < CPW; q++) {
+            const int t = wave + q * NCW, j = u0 + t - i;
+            if (j < 0 || j >= W) continue;
+            float prev[R], aV[R], aD[R], aA[R];
+            // Up2Down (pass 0)
+            float *pv = ringV + slotV(j) * DP + lane * R;
+            if (i == 0) {
+#pragma unroll
+                for (int k = 0; k < R; k++) prev[k] = 0.0f; // sgm.h:206-208
+            } else lds_get<R>(pv, prev);
+            score_step_far_global<R>(prev, c[q], j, lane, D, W, P1, P2, Pout, aV);
+            lds_put<R>(pv, aV);
+            if (t == WB - 1) lds_put<R>(st, aV);
+            // UpLeft2DownRight (passes 2 and 3: the lines from the left border and from the top border)
+            float *pd = ringD + slotD(j - i) * DP + lane * R;
+            if (i == 0 || j == 0) {
+#pragma unroll
+                for (int k = 0; k < R; k++) prev[k] = 0.0f;
+            } else lds_get<R>(pd, prev);
+            score_step_far_global<R>(prev, c[q], j, lane, D, W, P1, P2, Pout, aD);
+            lds_put<R>(pd, aD);
+            if (t == WB - 2) lds_put<R>(st + DP, aD);
+            if (t == WB - 1) lds_put<R>(st + 2 * DP, aD);
+            // UpRight2DownLeft (pass 4): only the lines that start on the top border (finding F5)
+            const bool visA = i + j < W;
+            if (visA) {
+                float *pa = ringA + t * DP + lane * R;
+                if (i == 0) {
+#pragma unroll
+                    for (int k = 0; k < R; k++) prev[k] = 0.0f;
+                } else lds_get<R>(pa, prev);
+                score_step_far_global<R>(prev, c[q], j, lane, D, W, P1, P2, Pout, aA);
+                lds_put<R>(pa, aA);
+            }
+            float outv[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                float S = c[q][k] + (aV[k] - c[q][k]); // sgm.h:298-300, pass after pass
+                S = S + d1[q][k];
+                const float dD = aD[k] - c[q][k];
+                if (i >= j) S = S + dD;
+                if (j >= i) S = S + dD;
+                if (visA) S = S + (aA[k] - c[q][k]);
+                outv[k] = S;
+            }
+            float *o = sgm + ((int64_t)i * W + j) * D + lane * R;
+            bool done = false;
+            if constexpr (R % 4 == 0) {
+                if (vec && lane * R + R <= D) {
+#pragma unroll
+                    for (int v4 = 0; v4 < R / 4; v4++)
+                        *reinterpret_cast<float4 *>(o + 4 * v4) = make_float4(outv[4 * v4], outv[4 * v4 + 1], outv[4 * v4 + 2], outv[4 * v4 + 3]);
+                    done = true;
+                }
+            }
+            if (!done) {
+#pragma unroll
+                for (int k = 0; k < R; k++)
+                    if (lane * R + k < D) o[k] = outv[k];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // three register sets in rotation: the loads of rows i + 1 and i + 2 are in flight while row i is computed
+    float c0[CPW][R], e0[CPW][R], c1[CPW][R], e1[CPW][R], c2[CPW][R], e2[CPW][R];
+    load_row(c0, e0, i_lo);
+    load_row(c1, e1, i_lo + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // (the importer's prologue)
+    for (int i = i_lo; i <= i_hi; i += 3) {
+        load_row(c2, e2, i + 2);
+        run_row(c0, e0, i);
+        if (i + 1 > i_hi) break;
+        load_row(c0, e0, i + 3);
+        run_row(c1, e1, i + 1);
+        if (i + 2 > i_hi) break;
+        load_row(c1, e1, i + 4);
+        run_row(c2, e2, i + 2);
     }
 }
 
@@ -643,8 +898,53 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
     return SVH_OK;
 }
 
+// Passes 1 (contribution only), 0 + 2 + 3 + 4 (the downward sweep) and 5: 8 + 12 + 12 * coverage(5) bytes per voxel instead of
+// 8 + 12 * (coverage of passes 1-5).  Whole-image aggregation, P2 >= P1 >= 0, up to 512 disparities; anything else takes the
+// pass-per-launch form.  Returns SVH_OK with *ran = false when it does not apply.
 template <int R>
-static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, bool textbook = false) {
+static int run_score_branch_fused(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, bool *ran) {
+    *ran = false;
+    if constexpr (R > 8) return SVH_OK;
+    else {
+        constexpr int WB = 16, NCW = 8, DP = 64 * R;
+        const int n_strips = ceil_div((int64_t)a.W + a.H - 1, WB);
+        const size_t edge_bytes = (size_t)n_strips * a.H * 3 * DP * sizeof(float);
+        if (edge_bytes > ((size_t)12 << 30)) return SVH_OK;
+        const size_t shmem = (size_t)((WB + 1) + (WB + 2) + WB + 6) * DP * sizeof(float);
+        static bool attr_set[64] = {};
+        if (!attr_set[ctx->device & 63]) {
+            SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_down_kernel<R, WB, NCW>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_set[ctx->device & 63] = true;
+        }
+        float *edges = static_cast<float *>(scr.get(edge_bytes));
+        int *sync_words = scr.get_n<int>((size_t)n_strips + 2);
+        if (!edges || !sync_words) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_HIP_CHECK(ctx, hipMemsetAsync(sync_words, 0, ((size_t)n_strips + 2) * sizeof(int), ctx->stream));
+        {
+            LineSet ls{1, pass_lines(1, a.H, a.W), 0, 0, a.H, a.W};
+            constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
+            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D,
+                       a.W, a.P1, a.P2, a.Pout, vec);
+            SVH_CHECK_LAUNCH(ctx);
+        }
+        SVH_LAUNCH(ctx, "sgm_score_down", (sgm_score_down_kernel<R, WB, NCW>), n_strips, (NCW + 2) * 64, shmem, cv, sgm, a.H, a.W, a.D, a.P1, a.P2,
+                   a.Pout, vec, edges, sync_words);
+        SVH_CHECK_LAUNCH(ctx);
+        {
+            LineSet ls{5, pass_lines(5, a.H, a.W), 0, 0, a.H, a.W};
+            constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
+            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D, a.W,
+                       a.P1, a.P2, a.Pout, vec);
+            SVH_CHECK_LAUNCH(ctx);
+        }
+        *ran = true;
+        return SVH_OK;
+    }
+}
+
+template <int R>
+static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool textbook = false) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = textbook ? (a.n_dir >= 8 ? 8 : 4) : (a.n_dir >= 8 ? 6 : 2);
     const int pass0 = textbook ? 6 : 0;
@@ -659,6 +959,11 @@ static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv,
         SVH_HIP_CHECK(ctx, hipMemcpyAsync(sgm, cv, (size_t)a.H * a.W * a.D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (Hp <= 0 || Wp <= 0) return SVH_OK;
+    if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) {
+        bool ran = false;
+        SVH_TRY(run_score_branch_fused<R>(ctx, scr, a, cv, sgm, vec, &ran));
+        if (ran) return SVH_OK;
+    }
     for (int q = 0; q < n_pass; q++) {
         LineSet ls{pass0 + q, pass_lines(pass0 + q, Hp, Wp), a.top, a.left, Hp, Wp};
         int grid = ceil_div(ls.n_lines, 4);
@@ -684,14 +989,13 @@ static int run_score_branch(svh_context *ctx, const SgmArgs &a, const float *cv,
 }
 
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook) {
-    (void)scr;
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
     switch (pick_R(a.D)) {
-    case 1: return run_score_branch<1>(ctx, a, cv, out_sgm, textbook);
-    case 2: return run_score_branch<2>(ctx, a, cv, out_sgm, textbook);
-    case 4: return run_score_branch<4>(ctx, a, cv, out_sgm, textbook);
-    case 8: return run_score_branch<8>(ctx, a, cv, out_sgm, textbook);
-    case 16: return run_score_branch<16>(ctx, a, cv, out_sgm, textbook);
+    case 1: return run_score_branch<1>(ctx, scr, a, cv, out_sgm, textbook);
+    case 2: return run_score_branch<2>(ctx, scr, a, cv, out_sgm, textbook);
+    case 4: return run_score_branch<4>(ctx, scr, a, cv, out_sgm, textbook);
+    case 8: return run_score_branch<8>(ctx, scr, a, cv, out_sgm, textbook);
+    case 16: return run_score_branch<16>(ctx, scr, a, cv, out_sgm, textbook);
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
     }
 }

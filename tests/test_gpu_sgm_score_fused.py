@@ -1,0 +1,72 @@
+"""The Score branch of sgmCostVolume (sgm.h:218-255, :329-389) with the four downward passes carried by one sweep of the volume
+(svh_sgm.hip, sgm_score_down_kernel: strips of the skewed image handed from block to block) against the pass-per-launch kernels
+(option "sgm_score_fused" = 0) and the oracle: same bits."""
+import numpy as np
+import pytest
+
+import oracle as so
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import libstevi_amd as sv  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def bits(x):
+    x = x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+    return np.ascontiguousarray(x, np.float32).view(np.uint32)
+
+
+def both_forms(cv, P1, P2, Pout):
+    d = torch.from_numpy(cv).to(DEV)
+    sv.set_option(d, "sgm_score_fused", 1)
+    fused = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
+    sv.set_option(d, "sgm_score_fused", 0)
+    try:
+        plain = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
+    finally:
+        sv.set_option(d, "sgm_score_fused", 1)
+    return fused, plain
+
+
+# shapes that put several strips of 16 skewed columns side by side, wider than tall and taller than wide, one row, one column;
+# disparity counts on each lane layout (1, 2, 4, 8 per lane), multiples of four or not
+@pytest.mark.parametrize("shape", [(37, 90, 40), (90, 37, 40), (64, 64, 17), (50, 70, 100), (33, 47, 256), (20, 35, 300), (1, 50, 8), (50, 1, 8),
+                                   (130, 16, 5), (16, 130, 64)])
+def test_fused_equals_per_pass_and_oracle(rng, shape):
+    cv = rng.uniform(-1, 1, shape).astype(np.float32)
+    for P1, P2, Pout in [(0.001, 0.01, 100.0), (0.3, 0.3, 0.0), (0.0, 2.0, 0.5)]:
+        fused, plain = both_forms(cv, P1, P2, Pout)
+        exp = so.sgm(cv, 8, so.SCORE, P1, P2, (0, 0, 0, 0), Pout)
+        assert np.array_equal(bits(plain), bits(exp))
+        assert np.array_equal(bits(fused), bits(exp))
+
+
+def test_fused_nonfinite_costs(rng):
+    cv = rng.uniform(0, 4, (40, 75, 48)).astype(np.float32)
+    cv[0, 0, 0] = np.nan
+    cv[-1, -1, :] = np.inf
+    cv[20, 37, 1] = -np.inf
+    cv[0, 30, :] = np.nan
+    cv[17, :, 5] = np.inf
+    cv[:, 44, 7] = np.nan
+    fused, plain = both_forms(cv, 0.3, 0.9, 7.0)
+    exp = so.sgm(cv, 8, so.SCORE, 0.3, 0.9, (0, 0, 0, 0), 7.0)
+    f, p = fused.cpu().numpy(), plain.cpu().numpy()
+    assert np.array_equal(np.isnan(f), np.isnan(exp)) and np.array_equal(np.isnan(p), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.array_equal(f[ok].view(np.uint32), exp[ok].view(np.uint32))
+    assert np.array_equal(p[ok].view(np.uint32), exp[ok].view(np.uint32))
+
+
+def test_fused_many_strips_against_per_pass(rng):
+    """More strips than the card holds blocks at once is not reachable at test sizes; this one has 150 strips and 600 rows, so the
+    hand-off runs a few hundred rows deep, and is compared with the pass-per-launch kernels (the oracle takes minutes here)."""
+    cv = rng.uniform(-1, 1, (600, 1800, 64)).astype(np.float32)
+    fused, plain = both_forms(cv, 0.02, 0.2, 3.0)
+    assert torch.equal(fused.view(torch.int32), plain.view(torch.int32))

@@ -103,8 +103,9 @@ const char *svh_last_error(const svh_context *ctx);
  * automatic = 3 where it applies.  Same keys bit for bit.
  * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
  * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one.
- * "sgm_score_fused" (default 1): 0 makes the Score branch of svh_sgm_cost_volume run one read-modify-write sweep of the volume per
- * pass instead of carrying the four downward passes in one sweep (same bits; the parity tests cross-check the two). */
+ * "sgm_score_fused" (default 0): 1 makes the Score branch of svh_sgm_cost_volume carry the four downward passes in one sweep of the
+ * volume (strips handed from block to block) instead of one read-modify-write sweep per pass.  Same bits (the parity tests
+ * cross-check the two); at 4096x2160x256 it is no faster yet, hence off by default. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);

@@ -339,6 +339,7 @@ int svh_context_destroy(svh_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->pool)
         if (b.ptr) (void)hipFree(b.ptr);
+    if (ctx->sgm_edges) (void)hipFree(ctx->sgm_edges);
     for (auto &p : ctx->prof_pending) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
@@ -396,6 +397,9 @@ int svh_context_trim(svh_context *ctx) {
         else if (b.ptr) (void)hipFree(b.ptr);
     }
     ctx->pool.swap(keep);
+    if (ctx->sgm_edges) (void)hipFree(ctx->sgm_edges);
+    ctx->sgm_edges = nullptr;
+    ctx->sgm_edges_bytes = 0;
     return SVH_OK;
 }
 

@@ -48,7 +48,12 @@ struct svh_context {
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
-    bool sgm_score_fused = true;       // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep
+    bool sgm_score_fused = false;      // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep
+    // edge states handed from strip to strip by the fused Score-branch sweep (svh_sgm.hip): {value, tag} granules.  Written by
+    // nothing else and zeroed when allocated, so a granule whose tag equals the launch's number was written by that launch.
+    void *sgm_edges = nullptr;
+    size_t sgm_edges_bytes = 0;
+    uint32_t sgm_edges_tag = 0;
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;

@@ -1,6 +1,6 @@
 """The Score branch of sgmCostVolume (sgm.h:218-255, :329-389) with the four downward passes carried by one sweep of the volume
-(svh_sgm.hip, sgm_score_down_kernel: strips of the skewed image handed from block to block) against the pass-per-launch kernels
-(option "sgm_score_fused" = 0) and the oracle: same bits."""
+(svh_sgm.hip, sgm_score_down_kernel: strips of the skewed image handed from block to block; option "sgm_score_fused" = 1) against
+the pass-per-launch kernels (the default) and the oracle: same bits."""
 import numpy as np
 import pytest
 
@@ -25,12 +25,11 @@ def bits(x):
 def both_forms(cv, P1, P2, Pout):
     d = torch.from_numpy(cv).to(DEV)
     sv.set_option(d, "sgm_score_fused", 1)
-    fused = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
-    sv.set_option(d, "sgm_score_fused", 0)
     try:
-        plain = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
+        fused = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
     finally:
-        sv.set_option(d, "sgm_score_fused", 1)
+        sv.set_option(d, "sgm_score_fused", 0)
+    plain = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
     return fused, plain
 
 

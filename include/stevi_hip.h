@@ -103,6 +103,9 @@ const char *svh_last_error(const svh_context *ctx);
  * automatic = 3 where it applies.  Same keys bit for bit.
  * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
  * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one.
+ * "census_winner_shortcut" (default 1): in the integer-exact regime of the census + SGM Cost-branch pipeline the winning disparity of a
+ * pixel does not depend on the per-pass minima the reference hands along its lines (they shift every disparity of the pixel alike), so
+ * calls that ask for index / disparity maps only skip the line scans; 0 runs them regardless (same maps; the parity tests compare).
  * "sgm_score_fused" (default 0): 1 makes the Score branch of svh_sgm_cost_volume carry the four downward passes in one sweep of the
  * volume (strips handed from block to block) instead of one read-modify-write sweep per pass.  Same bits (the parity tests
  * cross-check the two); at 4096x2160x256 it is no faster yet, hence off by default. */

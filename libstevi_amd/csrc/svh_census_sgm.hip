@@ -446,6 +446,11 @@ __device__ __forceinline__ uint32_t order_key_f(float v) {
 }
 
 // per-pass min_p values of one pixel
+// does pass q visit pixel (ip, jp) of the margin box? (the same rule as load_pixel_passes below and line_of in svh_sgm.hip)
+__device__ __forceinline__ bool pass_visits_px(int q, int ip, int jp, int Hp, int Wp) {
+    return q < 2 || (q == 2 && ip >= jp) || (q == 3 && jp >= ip) || (q == 4 && ip + jp < Wp) || (q == 5 && ip + jp < Hp);
+}
+
 struct PixelPasses {
     float mp[6];
     unsigned vis; // bit q set: pass q visits the pixel and its min_p is finite
@@ -505,21 +510,35 @@ template <int NW> __device__ __forceinline__ int hamming_global(const CensusGeom
 
 // Exact regime, per pixel: S = (1 + n) c + n Pout [d >= dsplit] - sum of the visiting passes' min_p.  The winner is
 // the better of the two regional winners (the later region wins ties, as the reference's '<=' scan does).
-template <int NW>
+//
+// The sum of the min_p is the same for every disparity of a pixel, so it moves S without moving the winner: where only the
+// index / disparity maps are wanted (MAPS = false) neither the g map, the line scans nor the six min_p maps are needed, and n,
+// the number of passes that visit the pixel, follows from its position (sgm.h:329-354, finding F5).  What the reference's Cost
+// branch hands from pixel to pixel (finding F4: one scalar per pass) never reaches its own argmin.  The S values themselves
+// (refinement taps, cross-shard value keys) still take the maps.
+template <int NW, bool MAPS>
 __global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout, const float *__restrict__ mmap,
                                                               const uint2 *__restrict__ keys, WinnerOut out) {
     const int64_t npx = (int64_t)g.H * g.Ws;
     const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (p >= npx) return;
     const int j = (int)(p % g.Ws), i = (int)(p / g.Ws);
-    const PixelPasses pp = load_pixel_passes(sg, n_pass, i, j, mmap, npx, p);
     int msum = 0, n_vis = 0;
+    if constexpr (MAPS) {
+        const PixelPasses pp = load_pixel_passes(sg, n_pass, i, j, mmap, npx, p);
 #pragma unroll
-    for (int q = 0; q < 6; q++)
-        if ((pp.vis >> q) & 1u) {
-            n_vis++;
-            msum += (int)pp.mp[q];
+        for (int q = 0; q < 6; q++)
+            if ((pp.vis >> q) & 1u) {
+                n_vis++;
+                msum += (int)pp.mp[q];
+            }
+    } else {
+        const int ip = i - sg.top, jp = j - sg.left;
+        if (ip >= 0 && ip < sg.Hp && jp >= 0 && jp < sg.Wp) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) n_vis += q < n_pass && pass_visits_px(q, ip, jp, sg.Hp, sg.Wp);
         }
+    }
     const int mul = 1 + n_vis, k0 = -msum, k1 = n_vis * (int)Pout - msum;
     const uint2 k = keys[p];
     const int v0 = mul * key_cost(k.x) + k0, d0 = key_index(k.x);
@@ -621,7 +640,9 @@ template <int NW>
 int launch_finalize(svh_context *ctx, const CensusGeom &g, const ScanGeom &sg, int n_pass, float Pout, const float *mmap, const uint2 *keys,
                     const WinnerOut &out) {
     const int64_t npx = (int64_t)g.H * g.Ws;
-    SVH_LAUNCH(ctx, "census_finalize", census_finalize_kernel<NW>, grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
+    if (mmap) SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, true>), grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
+    else if (out.taps || out.keys) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census finalize: S values need the min_p maps");
+    else SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, false>), grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

@@ -373,6 +373,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->literal_cost_volumes = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "census_winner_shortcut") == 0) {
+        ctx->census_winner_shortcut = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "sgm_score_fused") == 0) {
         ctx->sgm_score_fused = value != 0;
         return SVH_OK;

@@ -46,6 +46,7 @@ struct svh_context {
     int prof_every = 1;      // svh_profile_sampling: bracket every n-th eligible launch
     int64_t prof_seen = 0;
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
+    bool census_winner_shortcut = true; // svh_context_set_option("census_winner_shortcut"): index / disparity maps without the line scans
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     bool sgm_score_fused = false;      // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep

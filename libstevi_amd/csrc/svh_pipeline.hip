@@ -302,10 +302,15 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
     // from here on everything is about the whole disparity range
     SgmArgs sa{prm->sgm_directions, SVH_COST, s.H, s.Ws, s.Dtot, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
                prm->margins[3]};
-    float *mmap = scr.get_n<float>((size_t)6 * npx);
-    float *gmap = scr.get_n<float>((size_t)npx);
-    if (!mmap || !gmap) return SVH_ERR_OUT_OF_MEMORY;
-    SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap, nullptr));
+    // the disparity map alone does not depend on the min_p maps (census_finalize_kernel): no scans then
+    const bool winner_only = ctx->census_winner_shortcut && !want_refine;
+    float *mmap = nullptr;
+    if (!winner_only) {
+        mmap = scr.get_n<float>((size_t)6 * npx);
+        float *gmap = scr.get_n<float>((size_t)npx);
+        if (!mmap || !gmap) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap, nullptr));
+    }
     CostSource cs;
     cs.nWw = s.nWw;
     cs.Wt = s.Wt;

@@ -384,6 +384,34 @@ def test_census_fast_path_equals_general_and_oracle(D, ddir):
         assert_close(fast["refined"], so.refine_disp(so.truncated_cost_volume(vol, idx, h_r, v_r, 1), idx, so.PARABOLA), 1e-6)
 
 
+@pytest.mark.parametrize("D", [1, 7, 70, 256, 300])
+@pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
+def test_census_winner_without_line_scans(D, ddir):
+    """Disparity map alone: in the integer-exact regime the per-pass minima of sgm.h:257-296 shift every disparity of a pixel alike,
+    so the winner needs neither the g map nor the line scans ("census_winner_shortcut", the default).  Against the same call with the
+    scans (option 0), against the general wave-per-line kernels and against the oracle's full cost volume + SGM + argmin."""
+    src, tgt, _ = parallax_pair(41, 310, 12, 8, 40, 3, 17, seed=100 + D)
+    cases = [((0, 0, 0, 0), 100.0, 8, 4, 4), ((3, 2, 5, 1), 7.0, 8, 4, 4), ((0, 0, 0, 0), 100.0, 4, 3, 3), ((0, 0, 0, 0), 2.0, 8, 4, 4),
+             ((0, 0, 0, 0), 100.0, 0, 2, 2), ((2, 7, 0, 3), 0.0, 8, 3, 3), ((40, 0, 0, 0), 5.0, 8, 4, 4)]
+    for margins, Pout, n_dir, h_r, v_r in cases:
+        kw = dict(dDir=ddir, sgmDirections=n_dir, P1=0.3, P2=0.9, Pout=Pout, margins=sv.Margins(*margins))
+        d_tgt, d_src = dev(tgt), dev(src)
+        try:
+            short = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
+            sv.set_option(d_tgt, "census_winner_shortcut", 0)
+            scans = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
+            sv.set_option(d_tgt, "census_fast_path", 0)
+            gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
+        finally:
+            sv.set_option(d_tgt, "census_winner_shortcut", 1)
+            sv.set_option(d_tgt, "census_fast_path", 1)
+        assert_bits(short["disp"], host(scans["disp"]))
+        assert_bits(short["disp"], host(gen["disp"]))
+        cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, v_r, D, int(ddir))
+        vol = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, margins, Pout) if n_dir else cv
+        assert_bits(short["disp"], so.index_to_disp(so.extract_index(vol, so.COST), int(ddir)))
+
+
 # ------------------------------------------------------------------------------------------------ disparity shards
 @pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
 def test_census_shards_equal_single_gpu(ddir):

@@ -31,10 +31,38 @@ __device__ __forceinline__ float g_from_keys(uint32_t key0, uint32_t key1, int p
     return (float)min(g0, g1);
 }
 
+// does pass q (0..5, svh_sgm.hip) visit pixel (ip, jp) of the margin box? (sgm.h:329-354, finding F5)
+__host__ __device__ __forceinline__ bool pass_visits_px(int q, int ip, int jp, int Hp, int Wp) {
+    return q < 2 || (q == 2 && ip >= jp) || (q == 3 && jp >= ip) || (q == 4 && ip + jp < Wp) || (q == 5 && ip + jp < Hp);
+}
+
+// The winner of a pixel from its two regional keys when only the index / disparity maps are wanted (exact regime):
+// S = (1 + n) c + n Pout [Pout region] - (a sum that is the same for every disparity of the pixel), n = passes visiting the pixel;
+// the later region wins ties (the reference's '<=' scan).  Written by the sweep itself (no keys, no finalize launch) or by
+// census_finalize_kernel from stored keys.
+struct SweepWinner {
+    int32_t *idx = nullptr, *disp = nullptr;
+    int disp_sign = 1, disp_offset = 0;
+    int top = 0, left = 0, Hp = 0, Wp = 0, n_pass = 0, pout = 0;
+    __host__ __device__ bool on() const { return idx || disp; }
+};
+__device__ __forceinline__ int passes_visiting(const SweepWinner &w, int i, int j) { // (n_pass is 0, 2 or 6; branch-free)
+    const int ip = i - w.top, jp = j - w.left, s = ip + jp;
+    const bool inside = (unsigned)ip < (unsigned)w.Hp && (unsigned)jp < (unsigned)w.Wp;
+    const int n6 = 2 + (int)(ip >= jp) + (int)(jp >= ip) + (int)(s < w.Wp) + (int)(s < w.Hp);
+    return inside ? (w.n_pass == 6 ? n6 : w.n_pass) : 0;
+}
+__device__ __forceinline__ int winner_index(uint32_t k0, uint32_t k1, int n_vis, int pout) {
+    const int v0 = (1 + n_vis) * key_cost(k0), v1 = (1 + n_vis) * key_cost(k1) + n_vis * pout;
+    const bool take1 = k1 != KEY_NONE && (k0 == KEY_NONE || v1 <= v0);
+    return take1 ? key_index(k1) : key_index(k0);
+}
+
 // census_sweep on the matrix cores (svh_census_sweep_mfma.hip); false when the geometry is outside what that kernel covers
 // (the caller then runs the VALU sweep)
 bool launch_sweep_mfma(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
 // 4-bit (FP4) operands +-1, persistent blocks (svh_census_sweep_pm.hip)
-bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
+// (winner: write the index / disparity maps instead of keys and g)
+bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner = nullptr);
 
 } // namespace svh

@@ -446,11 +446,6 @@ __device__ __forceinline__ uint32_t order_key_f(float v) {
 }
 
 // per-pass min_p values of one pixel
-// does pass q visit pixel (ip, jp) of the margin box? (the same rule as load_pixel_passes below and line_of in svh_sgm.hip)
-__device__ __forceinline__ bool pass_visits_px(int q, int ip, int jp, int Hp, int Wp) {
-    return q < 2 || (q == 2 && ip >= jp) || (q == 3 && jp >= ip) || (q == 4 && ip + jp < Wp) || (q == 5 && ip + jp < Hp);
-}
-
 struct PixelPasses {
     float mp[6];
     unsigned vis; // bit q set: pass q visits the pixel and its min_p is finite
@@ -694,6 +689,32 @@ static int sweep_dispatch(svh_context *ctx, const CensusGeom &g, float Pout, uin
 int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, uint2 *keys, float *gmap) {
     CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
     return sweep_dispatch(ctx, g, a.Pout, keys, gmap);
+}
+
+// index / disparity maps alone in the exact regime: the matrix-core sweep writes them itself; other geometries go through keys
+int dev_census_winner(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win) {
+    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+    const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
+    if (ctx->census_sweep_mode == 0 || ctx->census_sweep_mode == 3) {
+        SweepWinner sw;
+        sw.idx = win.idx;
+        sw.disp = win.disp;
+        sw.disp_sign = win.disp_sign;
+        sw.disp_offset = win.disp_offset;
+        sw.top = a.top;
+        sw.left = a.left;
+        sw.Hp = Hp > 0 ? Hp : 0;
+        sw.Wp = Wp > 0 ? Wp : 0;
+        sw.n_pass = n_pass;
+        sw.pout = (int)a.Pout;
+        int status = SVH_OK;
+        if (launch_sweep_pm(ctx, g, a.Pout, nullptr, nullptr, &status, &sw)) return status;
+    }
+    uint2 *keys = scr.get_n<uint2>((size_t)a.H * a.W);
+    if (!keys) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(sweep_dispatch(ctx, g, a.Pout, keys, nullptr));
+    return dev_census_finalize(ctx, a, cs, nullptr, keys, win);
 }
 
 int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, float *gmap, bool gmap_ready, float *mmap, const int *skip_if_nonzero) {

@@ -41,6 +41,8 @@
 #include <type_traits>
 
 #include "svh_census_keys.h"
+
+#include <cstddef>
 #include "svh_nibble_tables.h"
 
 namespace svh {
@@ -105,9 +107,21 @@ inline size_t pm_lds_bytes(int nw, int waves, int ct, int D, int nbuf) {
 // fragments of four census words or four column tiles per wave want more than 168 registers
 constexpr int pm_blocks_per_cu(int nw, int ct) { return (ct >= 4 || nw > 2) ? 2 : 3; }
 
-template <int NW, int WAVES, int CT>
+// the kernel's arguments as the kernel argument segment lays them out (by-value arguments at their natural alignment, in order)
+struct SweepKernelArgs {
+    CensusGeom g;
+    float Pout;
+    uint2 *keys;
+    float *gmap;
+    SweepPlan plan;
+    SweepWinner sw;
+};
+
+// WINNER: the index / disparity maps instead of keys and g (a separate instantiation: the fields of `sw` would otherwise sit in
+// scalar registers through the tile loop of the key-writing form too)
+template <int NW, int WAVES, int CT, bool WINNER = false>
 __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_sweep_pm_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap,
-                                                                     SweepPlan plan SVH_STAMP_PARAM) {
+                                                                     SweepPlan plan, SweepWinner sw SVH_STAMP_PARAM) {
     constexpr int PXB = WAVES * CT * 32; // source pixels per item
     constexpr int NG = (NW + 1) / 2;     // MFMAs per tile: 64 bits of census record each
     constexpr int B = 32 * NW;           // written census bits: cost = (B - dot) / 2
@@ -437,8 +451,27 @@ __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_s
                     a1 = (int)global_region1_key(g, j, ones);
                 }
                 if (h == 0 && j < g.Ws) {
-                    keys[row + j] = make_uint2((uint32_t)a0, (uint32_t)a1);
-                    if (gmap) gmap[row + j] = g_from_keys((uint32_t)a0, (uint32_t)a1, pout);
+                    if constexpr (WINNER) { // the winner itself: census_keys.h
+                        // `sw` is read from the kernel argument segment HERE (an opaque pointer: the loads cannot be hoisted), not
+                        // kept in a dozen scalar registers through the tile loop, which has none to spare
+                        typedef __attribute__((address_space(4))) const char *KernArg;
+                        KernArg ka = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+                        asm volatile("" : "+s"(ka));
+                        typedef __attribute__((address_space(4))) const uint32_t *KernArgWords;
+                        KernArgWords kw = (KernArgWords)(ka + offsetof(SweepKernelArgs, sw));
+                        static_assert(sizeof(SweepWinner) % 4 == 0, "read as dwords");
+                        uint32_t raw[sizeof(SweepWinner) / 4];
+#pragma unroll
+                        for (unsigned q = 0; q < sizeof(SweepWinner) / 4; q++) raw[q] = kw[q];
+                        SweepWinner w;
+                        __builtin_memcpy(&w, raw, sizeof w);
+                        const int bd = winner_index((uint32_t)a0, (uint32_t)a1, passes_visiting(w, i, j), w.pout);
+                        if (w.idx) w.idx[row + j] = bd;
+                        if (w.disp) w.disp[row + j] = w.disp_sign * bd + w.disp_offset;
+                    } else {
+                        keys[row + j] = make_uint2((uint32_t)a0, (uint32_t)a1);
+                        if (gmap) gmap[row + j] = g_from_keys((uint32_t)a0, (uint32_t)a1, pout);
+                    }
                 }
             };
             if (wave_plain) {
@@ -512,7 +545,7 @@ inline SweepPlan make_plan(int H, int Ws, int pxb, int nw, int waves, int ct, in
 }
 
 #ifndef SVH_SWEEP_STAMPS
-template <int NW, int WAVES, int CT> int launch_config(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap) {
+template <int NW, int WAVES, int CT> int launch_config(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, const SweepWinner &sw) {
     constexpr int PXB = WAVES * CT * 32;
     static int n_cu[64] = {};
     const int dev = ctx->device & 63;
@@ -527,17 +560,20 @@ template <int NW, int WAVES, int CT> int launch_config(svh_context *ctx, const C
     static bool attr_set_dev[64] = {}; // (per instantiation and device)
     bool &attr_set = attr_set_dev[dev];
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_pm_kernel<NW, WAVES, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_pm_kernel<NW, WAVES, CT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_pm_kernel<NW, WAVES, CT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
             return fail(ctx, SVH_ERR_HIP, "census_sweep (mfma, fp4 +-1): cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_pm_kernel<NW, WAVES, CT>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap, plan);
+    if (sw.on()) SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_pm_kernel<NW, WAVES, CT, true>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap, plan, sw);
+    else SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_pm_kernel<NW, WAVES, CT, false>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap, plan, sw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SVH_OK : fail(ctx, SVH_ERR_HIP, "census_sweep (mfma, fp4 +-1): %s", hipGetErrorString(e));
 }
 
-template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status) {
+template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner &sw) {
     // item width (4 waves x CT column tiles of 32 pixels): the one that pads the row least, the wider on a tie
     int best_ct = 0;
     int64_t best_pad = 0;
@@ -552,9 +588,9 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
     }
     if (!best_ct) return false;
     switch (best_ct) {
-    case 4: *status = launch_config<NW, 4, 4>(ctx, g, Pout, keys, gmap); break;
-    case 3: *status = launch_config<NW, 4, 3>(ctx, g, Pout, keys, gmap); break;
-    default: *status = launch_config<NW, 4, 2>(ctx, g, Pout, keys, gmap); break;
+    case 4: *status = launch_config<NW, 4, 4>(ctx, g, Pout, keys, gmap, sw); break;
+    case 3: *status = launch_config<NW, 4, 3>(ctx, g, Pout, keys, gmap, sw); break;
+    default: *status = launch_config<NW, 4, 2>(ctx, g, Pout, keys, gmap, sw); break;
     }
     return true;
 }
@@ -563,16 +599,18 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
 } // namespace
 
 #ifndef SVH_SWEEP_STAMPS
-bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status) {
+bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner) {
+    const SweepWinner sw = winner ? *winner : SweepWinner();
+    if (sw.on() && g.region1_global_last >= 0) return false; // (disparity shards exchange keys)
     if (g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 4) return false;
     // the staging DMA addresses the word maps with byte offsets held in 32-bit-safe ranges
     if ((int64_t)g.H * g.Wt * g.nWw * 4 >= (int64_t)1 << 31 || (int64_t)g.H * g.Ws * g.nWw * 4 >= (int64_t)1 << 31) return false;
     if ((int64_t)g.H * g.Wt * g.nWw * 4 < 16 || (int64_t)g.H * g.Ws * g.nWw * 4 < 16) return false;
     switch (g.nWw) {
-    case 1: return launch_for_words<1>(ctx, g, Pout, keys, gmap, status);
-    case 2: return launch_for_words<2>(ctx, g, Pout, keys, gmap, status);
-    case 3: return launch_for_words<3>(ctx, g, Pout, keys, gmap, status);
-    default: return launch_for_words<4>(ctx, g, Pout, keys, gmap, status);
+    case 1: return launch_for_words<1>(ctx, g, Pout, keys, gmap, status, sw);
+    case 2: return launch_for_words<2>(ctx, g, Pout, keys, gmap, status, sw);
+    case 3: return launch_for_words<3>(ctx, g, Pout, keys, gmap, status, sw);
+    default: return launch_for_words<4>(ctx, g, Pout, keys, gmap, status, sw);
     }
 }
 #endif

@@ -265,6 +265,8 @@ bool census_exact_regime(const SgmArgs &a, int nWw);
 // exact regime: one sweep (regional winner keys + g map), then the min_p maps by parallel line scans
 int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out);
 int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, uint2 *keys, float *gmap /* may be null */);
+// exact regime, index / disparity maps only (win.taps and win.keys null): no g map, no line scans, no min_p maps
+int dev_census_winner(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win);
 int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, float *gmap, bool gmap_ready, float *mmap,
                      const int *skip_if_nonzero = nullptr);
 int census_max_total_disparities();

@@ -980,14 +980,11 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
     // index / disparity maps alone: the winner does not depend on the min_p maps (census_finalize_kernel), so no g map and no scans
     const bool winner_only = exact && lane_winner && ctx->census_winner_shortcut && !win.taps && !win.keys;
     uint2 *keys = nullptr;
-    if (winner_only) {
-        keys = scr.get_n<uint2>((size_t)a.H * a.W);
-        if (!keys) return SVH_ERR_OUT_OF_MEMORY;
-        SVH_TRY(dev_census_sweep(ctx, a, cs, keys, nullptr));
-    } else if (exact) SVH_TRY(dev_census_sweep_and_scans(ctx, scr, a, cs, mmap, &keys));
+    if (winner_only) return win.any() ? dev_census_winner(ctx, scr, a, cs, win) : SVH_OK;
+    if (exact) SVH_TRY(dev_census_sweep_and_scans(ctx, scr, a, cs, mmap, &keys));
     if (!exact || !lane_winner) SVH_TRY(dispatch_cost_branch(ctx, a, src, mmap, lane_winner ? nullptr : &out, !exact));
     if (lane_winner && win.any()) {
-        if (exact) SVH_TRY(dev_census_finalize(ctx, a, cs, winner_only ? nullptr : mmap, keys, win));
+        if (exact) SVH_TRY(dev_census_finalize(ctx, a, cs, mmap, keys, win));
         else SVH_TRY(dev_census_apply_select(ctx, a, cs, mmap, win));
     }
     return SVH_OK;

@@ -74,7 +74,7 @@ int main(int argc, char **argv) {
     for (int it = 0; it < 30; it++) { // warm: clocks, caches; the last launch is the one read back
         CK(hipMemsetAsync(stamps, 0, (size_t)grid * WAVES * 8 * 8, 0));
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((census_sweep_pm_kernel<NW, WAVES, CT>), dim3(grid), dim3(64 * WAVES), shmem, 0, g, 100.0f, keys, gmap, plan, stamps);
+        hipLaunchKernelGGL((census_sweep_pm_kernel<NW, WAVES, CT>), dim3(grid), dim3(64 * WAVES), shmem, 0, g, 100.0f, keys, gmap, plan, SweepWinner(), stamps);
         CK(hipEventRecord(e1, 0));
     }
     CK(hipDeviceSynchronize());

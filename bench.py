@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline and end_px_err)")
     ap.add_argument("--no-api-chain", action="store_true", help="skip the per-function (volume-materialising) chain")
     ap.add_argument("--materialize", action="store_true", help="also write the cost volume and the SGM volume (float32) to HBM")
+    ap.add_argument("--with-line-scans", action="store_true", help="run the g map, the six line scans and the finalize kernel although the disparity "
+                    "map does not depend on them (svh_context_set_option census_winner_shortcut = 0): the round-1 structure of the step")
     ap.add_argument("--two-frames", action="store_true", help="after the timed region, also time consecutive frames alternating between two "
                     "HIP streams (information only; kept out of the default run so that a profiler's per-kernel averages of this command "
                     "describe the single-stream kernels)")
@@ -218,6 +220,9 @@ def main():
         from libstevi_amd import sharded
         pipe = sharded.ShardedStereoPipeline(wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"], P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"],
                                              align=32)
+
+    if args.with_line_scans:
+        sv.set_option(d_src, "census_winner_shortcut", 0)
 
     def step():
         if world > 1:
@@ -374,12 +379,13 @@ def main():
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{shape} synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
                                    f"D={wl['D']}, argmin -> int32 disparity map (BASELINE.json configs[{2 if wl['name'] == 'C3' else 4}])",
-                       "pipeline": "svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
+                       "pipeline": ("svh_stereo_match fused, inputs and outputs resident in HBM" + (" (with the line scans: census_winner_shortcut = 0)"
+                                                                                                 if args.with_line_scans else "")) if world == 1 else
                                    "svh_census_shard_keys -> int32 MIN all-reduce -> svh_census_shard_finish, inputs and outputs resident in HBM",
                        "materialize_volumes": bool(args.materialize),
                        "parallelism": (f"disparity axis sharded over {world} GPUs ({pipe.shard[1]} of {wl['D']} disparities per GPU), one RCCL int32 MIN "
                                        "all-reduce of the regional winner keys per frame, overlapped with the next frame's key kernels "
-                                       "(one exchange in flight); scans + finalize replicated") if world > 1 else "single GPU"},
+                                       "(one exchange in flight); the finish (winner from the reduced keys) replicated") if world > 1 else "single GPU"},
             "roofline": roof,
             "hbm_model_roofline": hbm_model if roof is not hbm_model else None,
             "pipeline_roofline": {"algorithmic_bytes_per_step": int(pipeline_alg), "achieved": round(pipeline_alg / (ms_per_step * 1e-3) / 1e9, 1),

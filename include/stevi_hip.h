@@ -369,6 +369,16 @@ int svh_census_shard_region1_is_global(const svh_stereo_params *params, const sv
 int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                             const svh_array *keys, svh_array *disp, svh_array *refined);
 
+/* ---- row bands: the same disparity map, rows [row_begin, row_begin + row_count) of it ------------------------------
+ * In the integer-exact regime the winning disparity of a pixel depends on the pixel's own costs and on its position in the image
+ * only (the per-pass minima of sgm.h:257-296 shift all its disparities alike: see "census_winner_shortcut"), so the rows of the
+ * disparity map are independent and GPUs can split them with no exchange at all: rank r calls this with its band and holds rows
+ * of the map that are bit-identical to the single call's.  img_l / img_r are the WHOLE images (the band's census windows read
+ * v_radius rows beyond it); disp_band (row_count, W) i32.  Census costs in the exact regime, the whole disparity range
+ * (a multiple of 32 up to 992), no refinement; otherwise SVH_ERR_UNSUPPORTED (use svh_stereo_match / the disparity shards). */
+int svh_census_band_match(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
+                          int32_t row_begin, int32_t row_count, svh_array *disp_band);
+
 /* decodes reduced keys back to selected indices / disparities (device or host arrays) */
 int svh_keys_to_index(svh_context *ctx, int strategy, const svh_array *keys, int32_t disp_count, svh_array *idx);
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume", "svh_sgm_cost_volume_textbook",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
-    "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
+    "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_census_band_match", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
     "svh_on_demand_features", "svh_on_demand_truncated_cost_volume", "svh_cacheless_patch_match",
     "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_unfold_compressed", "svh_unfold_compressed_shape",
@@ -158,6 +158,7 @@ def load():
         "svh_census_shard_keys": (C.c_int, [ctx, P(SvhStereoParams), A, A, A]),
         "svh_census_shard_region1_is_global": (C.c_int, [P(SvhStereoParams), A, A]),
         "svh_census_shard_finish": (C.c_int, [ctx, P(SvhStereoParams), A, A, A, A, A]),
+        "svh_census_band_match": (C.c_int, [ctx, P(SvhStereoParams), A, A, C.c_int32, C.c_int32, A]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

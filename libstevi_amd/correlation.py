@@ -470,6 +470,21 @@ def censusShardKeys(img_l, img_r, h_radius, v_radius, disp_width, shard, dDir=di
     return keys if st == _capi.OK else _empty_like(l, 3, "i32")
 
 
+def censusBandMatch(img_l, img_r, h_radius, v_radius, disp_width, rows, dDir=dispDirection.RightToLeft, sgmDirections=8, P1=0.001, P2=0.01,
+                    Pout=100.0, margins=None, matchFunc=matchingFunctions.CENSUS, out=None):
+    """svh_census_band_match: rows (begin, count) of the disparity map of the WHOLE images, (count, W) int32, bit-identical to the
+    same rows of stereoMatch(...)["disp"].  Census costs, integer-exact regime, matrix-core sweep geometries."""
+    lib = _capi.load()
+    l, r = _prep_image(img_l), _prep_image(img_r)
+    ctx = context_for(l)
+    p, _ = _stereo_params(matchFunc, h_radius, v_radius, disp_width, dDir, sgmDirections, P1, P2, Pout, margins, None, 0, 0, None)
+    src = r if int(dDir) == dispDirection.RightToLeft else l
+    begin, count = int(rows[0]), int(rows[1])
+    band = out if out is not None else _like(l, (count, src.shape[1]), "i32")
+    st = _check(ctx, lib.svh_census_band_match(ctx, C.byref(p), C.byref(_desc(l)), C.byref(_desc(r)), begin, count, C.byref(_desc(band))))
+    return band if st == _capi.OK else _empty_like(l, 2, "i32")
+
+
 def censusShardRegion1IsGlobal(img_l, img_r, disp_width, dDir=dispDirection.RightToLeft):
     """svh_census_shard_region1_is_global: True when keys[..., 1] of censusShardKeys is already the winner over all shards (only
     keys[..., 0] needs the MIN reduction).  Reads shapes only."""

@@ -43,7 +43,8 @@ __host__ __device__ __forceinline__ bool pass_visits_px(int q, int ip, int jp, i
 struct SweepWinner {
     int32_t *idx = nullptr, *disp = nullptr;
     int disp_sign = 1, disp_offset = 0;
-    int top = 0, left = 0, Hp = 0, Wp = 0, n_pass = 0, pout = 0;
+    int top = 0, left = 0, Hp = 0, Wp = 0, n_pass = 0, pout = 0; // (top may be negative: row bands, see SgmArgs)
+    int row_first = 0, row_count = 0x7fffffff;                  // rows stored: [row_first, row_first + row_count), to output row i - row_first
     __host__ __device__ bool on() const { return idx || disp; }
 };
 __device__ __forceinline__ int passes_visiting(const SweepWinner &w, int i, int j) { // (n_pass is 0, 2 or 6; branch-free)

@@ -693,7 +693,8 @@ int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, u
 
 // index / disparity maps alone in the exact regime: the matrix-core sweep writes them itself; other geometries go through keys
 int dev_census_winner(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win) {
-    const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
+    const bool band = a.full_H > 0;
+    const int Hp = (band ? a.full_H : a.H) - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = (Hp > 0 && Wp > 0) ? (a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0)) : 0;
     CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
     if (ctx->census_sweep_mode == 0 || ctx->census_sweep_mode == 3) {
@@ -702,7 +703,11 @@ int dev_census_winner(svh_context *ctx, Scratch &scr, const SgmArgs &a, const Co
         sw.disp = win.disp;
         sw.disp_sign = win.disp_sign;
         sw.disp_offset = win.disp_offset;
-        sw.top = a.top;
+        sw.top = a.top - a.row_origin;
+        if (band) {
+            sw.row_first = a.store_row0;
+            sw.row_count = a.store_rows;
+        }
         sw.left = a.left;
         sw.Hp = Hp > 0 ? Hp : 0;
         sw.Wp = Wp > 0 ? Wp : 0;
@@ -711,6 +716,7 @@ int dev_census_winner(svh_context *ctx, Scratch &scr, const SgmArgs &a, const Co
         int status = SVH_OK;
         if (launch_sweep_pm(ctx, g, a.Pout, nullptr, nullptr, &status, &sw)) return status;
     }
+    if (band) return fail(ctx, SVH_ERR_UNSUPPORTED, "row bands need the matrix-core sweep (disparity count a multiple of 32 up to 992, at most 4 census words)");
     uint2 *keys = scr.get_n<uint2>((size_t)a.H * a.W);
     if (!keys) return SVH_ERR_OUT_OF_MEMORY;
     SVH_TRY(sweep_dispatch(ctx, g, a.Pout, keys, nullptr));

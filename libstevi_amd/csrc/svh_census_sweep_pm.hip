@@ -466,8 +466,11 @@ __global__ void __launch_bounds__(64 * WAVES, pm_blocks_per_cu(NW, CT)) census_s
                         SweepWinner w;
                         __builtin_memcpy(&w, raw, sizeof w);
                         const int bd = winner_index((uint32_t)a0, (uint32_t)a1, passes_visiting(w, i, j), w.pout);
-                        if (w.idx) w.idx[row + j] = bd;
-                        if (w.disp) w.disp[row + j] = w.disp_sign * bd + w.disp_offset;
+                        if ((unsigned)(i - w.row_first) < (unsigned)w.row_count) {
+                            const int64_t o = (int64_t)(i - w.row_first) * g.Ws + j;
+                            if (w.idx) w.idx[o] = bd;
+                            if (w.disp) w.disp[o] = w.disp_sign * bd + w.disp_offset;
+                        }
                     } else {
                         keys[row + j] = make_uint2((uint32_t)a0, (uint32_t)a1);
                         if (gmap) gmap[row + j] = g_from_keys((uint32_t)a0, (uint32_t)a1, pout);

@@ -233,6 +233,10 @@ struct SgmArgs {
     int H, W, D;
     float P1, P2, Pout;
     int left, top, right, bottom;
+    // row bands (svh_census_band_match): the arrays hold rows [row_origin, row_origin + H) of an image of full_H rows (0: the
+    // arrays are the whole image); margins and line geometry refer to the full image; only the local rows
+    // [store_row0, store_row0 + store_rows) are written, to an output of store_rows rows
+    int row_origin = 0, full_H = 0, store_row0 = 0, store_rows = 0;
 };
 // cost source for the Cost-branch kernels: either a dense float volume or census words evaluated on the fly
 struct CostSource {

@@ -228,6 +228,56 @@ int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array 
 
 } // namespace
 
+// Row bands: in the exact regime the winner of a pixel depends on its own costs and on its position only (svh_census_keys.h,
+// SweepWinner), so rows are independent once the census words of their window rows exist: v_radius halo rows on either side.
+extern "C" int svh_census_band_match(svh_context *ctx, const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r,
+                                     int32_t row_begin, int32_t row_count, svh_array *disp_band) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    ShardSetup s;
+    SVH_TRY(shard_setup(ctx, prm, img_l, img_r, true, &s));
+    if (prm->shard_count > 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "row bands take the whole disparity range");
+    if (prm->refine_kernel >= 0) return fail(ctx, SVH_ERR_UNSUPPORTED, "row bands produce the disparity map only");
+    if (!ctx->census_fast_path) return fail(ctx, SVH_ERR_UNSUPPORTED, "row bands need the census fast path");
+    if (row_begin < 0 || row_count < 0 || row_begin + (int64_t)row_count > s.H) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "row band outside the image");
+    SVH_TRY(validate(ctx, disp_band, "disp_band", SVH_I32, 2, 2));
+    if (disp_band->shape[0] != row_count || disp_band->shape[1] != s.Ws)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp_band must have shape (%d,%d)", row_count, s.Ws);
+    if (row_count == 0 || s.Ws == 0) return SVH_EMPTY_RESULT;
+    Scratch scr(ctx);
+    void *dsrc, *dtgt;
+    OutStage od;
+    SVH_TRY(stage_image(ctx, scr, *s.src, &dsrc));
+    SVH_TRY(stage_image(ctx, scr, *s.tgt, &dtgt));
+    SVH_TRY(stage_out(ctx, scr, *disp_band, &od));
+    // the rows whose census words the band's windows read; the words of the halo rows themselves are wrong where the halo is cut
+    // from the middle of the image (their windows would need rows further out) and are never used
+    const int a = std::max(0, row_begin - prm->v_radius), b = std::min(s.H, row_begin + row_count + prm->v_radius), Hs = b - a;
+    uint32_t *sw = scr.get_n<uint32_t>((size_t)Hs * s.Ws * (s.nWw ? s.nWw : 1));
+    uint32_t *tw = scr.get_n<uint32_t>((size_t)Hs * s.Wt * (s.nWw ? s.nWw : 1));
+    if (!sw || !tw) return SVH_ERR_OUT_OF_MEMORY;
+    const float *bsrc = (const float *)dsrc + (size_t)a * s.Ws * s.C, *btgt = (const float *)dtgt + (size_t)a * s.Wt * s.C;
+    SVH_TRY(dev_census_pair_compact(ctx, {bsrc, Hs, s.Ws, s.C}, {btgt, Hs, s.Wt, s.C}, prm->h_radius, prm->v_radius, s.nWw, sw, tw));
+    SgmArgs sa{prm->sgm_directions, SVH_COST, Hs, s.Ws, s.D, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
+               prm->margins[3]};
+    sa.row_origin = a;
+    sa.full_H = s.H;
+    sa.store_row0 = row_begin - a;
+    sa.store_rows = row_count;
+    CostSource cs;
+    cs.src_words = sw;
+    cs.tgt_words = tw;
+    cs.nWw = s.nWw;
+    cs.Wt = s.Wt;
+    cs.sign = s.sign;
+    cs.disp_lower = prm->disp_lower;
+    WinnerOut win;
+    win.disp = (int32_t *)od.dptr;
+    win.disp_sign = s.sign;
+    win.disp_offset = s.sign * prm->disp_lower;
+    SVH_TRY(dev_census_winner(ctx, scr, sa, cs, win));
+    return finish_out(ctx, od);
+}
+
 extern "C" int svh_census_shard_region1_is_global(const svh_stereo_params *prm, const svh_array *img_l, const svh_array *img_r) {
     if (!prm || !img_l || !img_r || img_l->ndim < 2 || img_r->ndim < 2) return 0;
     if (prm->disp_direction != SVH_RIGHT_TO_LEFT) return 0;

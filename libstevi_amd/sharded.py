@@ -135,3 +135,67 @@ class ShardedStereoPipeline:
         """Result of the last submitted frame (None when nothing is in flight)."""
         previous, self._in_flight = self._in_flight, None
         return self._complete(previous) if previous is not None else None
+
+
+# ---- row bands -------------------------------------------------------------------------------------------------------
+# The same disparity map split by ROWS instead of disparities.  In the integer-exact regime the winner of a pixel depends on the
+# pixel's own costs and on its position only (svh_census_band_match, include/stevi_hip.h), so the bands are independent: no exchange
+# is needed to compute them, and rank r simply holds rows band_range(H, r, world) of the map.  gather=True replicates the map on
+# every rank with one all_gather (4 B / pixel over all ranks, half of the key all-reduce), kept in flight under the next frame.
+def band_range(rows, rank, world):
+    """Contiguous split of the image rows; the first ranks get one more row when it does not divide."""
+    return shard_range(rows, rank, world)
+
+
+class RowBandStereoPipeline:
+    """submit(img_l, img_r) -> this rank's band of the disparity map, (rows_r, W) int32 [gather=True: the whole map of the PREVIOUS
+    frame, None for the first; flush() returns the last one].  compute=None runs svh_census_band_match; a callable
+    (img_l, img_r, (begin, count)) -> band replaces it (the CPU tests pass the oracle)."""
+
+    def __init__(self, h_radius, v_radius, disp_width, group=None, gather=False, compute=None, **kw):
+        self.args = (h_radius, v_radius, disp_width)
+        self.kw = {k: v for k, v in kw.items() if k in ("dDir", "sgmDirections", "P1", "P2", "Pout", "margins", "matchFunc")}
+        self.group, self.gather, self.compute = group, gather, compute
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.pending = None
+
+    def rows_of(self, img_l, img_r, rank=None):
+        dDir = self.kw.get("dDir", _c.dispDirection.RightToLeft)
+        src = img_r if int(dDir) == _c.dispDirection.RightToLeft else img_l
+        return band_range(src.shape[0], self.rank if rank is None else rank, self.world)
+
+    def _band(self, img_l, img_r):
+        rows = self.rows_of(img_l, img_r)
+        if self.compute is not None:
+            return self.compute(img_l, img_r, rows)
+        return _c.censusBandMatch(img_l, img_r, *self.args, rows, **self.kw)
+
+    def _collect(self):
+        if self.pending is None:
+            return None
+        work, out, counts = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        import torch
+        return torch.cat([out[r, :c] for r, c in enumerate(counts)], 0)
+
+    def submit(self, img_l, img_r):
+        band = self._band(img_l, img_r)
+        if not self.gather or self.world == 1:
+            return band
+        import torch
+        done = self._collect()
+        counts = [self.rows_of(img_l, img_r, r)[1] for r in range(self.world)]
+        padded = band
+        if band.shape[0] != max(counts):  # equal contributions (bands differ by at most one row)
+            padded = torch.zeros((max(counts), band.shape[1]), dtype=band.dtype, device=band.device)
+            padded[:band.shape[0]] = band
+        out = torch.empty((self.world, max(counts), band.shape[1]), dtype=band.dtype, device=band.device)
+        work = dist.all_gather([out[r] for r in range(self.world)], padded.contiguous(), group=self.group, async_op=True)  # (equal sizes: gloo too)
+        self.pending = (work, out, counts)
+        return done
+
+    def flush(self):
+        return self._collect()

@@ -52,3 +52,26 @@ def finish(keys, n_dir, Pout, margins=(0, 0, 0, 0)):
     v1 = mul * c1 + nvis * int(Pout) - msum
     take1 = (k1 != KEY_NONE) & ((k0 == KEY_NONE) | (v1 <= v0))
     return np.where(take1, IDX_MASK - (k1 & IDX_MASK), IDX_MASK - (k0 & IDX_MASK)).astype(np.int32)
+
+
+def band_winner(img_l, img_r, h_r, v_r, D, rows, n_dir, Pout, margins=(0, 0, 0, 0), oracle=None):
+    """numpy restatement of svh_census_band_match (RightToLeft): rows (begin, count) of the selected-index map computed from the
+    band's own rows plus v_r halo rows only.  The winner of a pixel is argmin_d [(1 + n) c + n Pout (j + d >= W)], ties to the
+    larger index, n = number of effective SGM passes visiting the pixel's position in the WHOLE image (sgm.h:329-354)."""
+    so = oracle
+    H, W = img_r.shape[0], img_r.shape[1]
+    begin, count = rows
+    a, b = max(0, begin - v_r), min(H, begin + count + v_r)
+    cv = so.unfold_cost_volume(so.CENSUS, np.ascontiguousarray(img_l[a:b]), np.ascontiguousarray(img_r[a:b]), h_r, v_r, D)  # (b - a, W, D)
+    cv = cv[begin - a:begin - a + count].astype(np.int64)
+    left, top, right, bottom = margins
+    Hp, Wp = H - top - bottom, W - left - right
+    i = np.arange(begin, begin + count)[:, None] - top
+    j = np.arange(W)[None, :] - left
+    inside = (i >= 0) & (i < Hp) & (j >= 0) & (j < Wp)
+    n6 = 2 + (i >= j) + (j >= i) + (i + j < Wp) + (i + j < Hp)
+    n = np.where(inside, n6 if n_dir >= 8 else (2 if n_dir >= 4 else 0), 0) if Hp > 0 and Wp > 0 else np.zeros((count, W), np.int64)
+    d = np.arange(D)
+    oob = (np.arange(W)[:, None] + d[None, :] >= W)[None]
+    S = (1 + n)[:, :, None] * cv + n[:, :, None] * int(Pout) * oob
+    return (D - 1 - np.argmin(S[:, :, ::-1], axis=2)).astype(np.int32)  # last minimum

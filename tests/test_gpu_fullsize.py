@@ -246,3 +246,18 @@ def test_c4_ncc_sgm_refine_4k_fullsize():
     okr = ~np.isnan(b)
     assert np.max(np.abs(a[okr] - b[okr])) <= 1e-4
     assert okr.mean() > 0.3
+
+
+def test_c5_row_bands_8k_fullsize():
+    """BASELINE config 5's frame split by rows instead of disparities: eight bands of 540 rows (what eight GPUs would compute,
+    with no exchange) equal the single call's map bit for bit."""
+    H, W, D = 4320, 8192, 512
+    src, tgt, _ = parallax_pair(H, W, 1280, 1280, 1520, 32, 256, seed=5)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    kw = dict(sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0)
+    full = sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, 4, 4, D, **kw)["disp"]
+    from libstevi_amd.sharded import band_range
+    for r in range(8):
+        b, c = band_range(H, r, 8)
+        band = sv.censusBandMatch(d_tgt, d_src, 4, 4, D, (b, c), **kw)
+        assert torch.equal(band, full[b:b + c]), f"band {r}"

@@ -412,6 +412,41 @@ def test_census_winner_without_line_scans(D, ddir):
         assert_bits(short["disp"], so.index_to_disp(so.extract_index(vol, so.COST), int(ddir)))
 
 
+# ------------------------------------------------------------------------------------------------ row bands
+@pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
+@pytest.mark.parametrize("D", [32, 96, 256])
+def test_census_row_bands_equal_single_call(D, ddir):
+    """svh_census_band_match: any split of the rows gives the rows of the single call's disparity map bit for bit (census words of
+    the band's window rows only: halo of v_radius rows), with margins, 8 / 4 / 0 directions, both directions."""
+    src, tgt, _ = parallax_pair(61, 330, 12, 8, 40, 3, 17, seed=700 + D)
+    H = src.shape[0]
+    d_tgt, d_src = dev(tgt), dev(src)
+    for margins, Pout, n_dir, r in [((0, 0, 0, 0), 100.0, 8, 4), ((3, 2, 5, 1), 7.0, 8, 4), ((0, 0, 0, 0), 100.0, 4, 3), ((0, 0, 0, 0), 3.0, 0, 3),
+                                     ((0, 30, 0, 20), 9.0, 8, 5)]:
+        kw = dict(dDir=ddir, sgmDirections=n_dir, P1=0.3, P2=0.9, Pout=Pout, margins=sv.Margins(*margins))
+        full = host(sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, **kw)["disp"])
+        for bands in ([(0, H)], [(0, 20), (20, 21), (41, 20)], [(0, 1), (1, 1), (2, 58), (60, 1)], [(7, 9)]):
+            for b, c in bands:
+                got = sv.censusBandMatch(d_tgt, d_src, r, r, D, (b, c), **kw)
+                assert_bits(got, full[b:b + c])
+        # host arrays in, host band out
+        assert_bits(sv.censusBandMatch(tgt, src, r, r, D, (11, 13), **kw), full[11:24])
+
+
+def test_census_row_bands_unsupported_cases():
+    from libstevi_amd._capi import SvhError, ERR_UNSUPPORTED, ERR_INVALID_ARGUMENT
+    src, tgt, _ = parallax_pair(20, 100, 6, 5, 8, 1, 4, seed=3)
+    with pytest.raises(SvhError) as e:  # 40 disparities: not a whole number of the matrix-core sweep's row tiles
+        sv.censusBandMatch(tgt, src, 4, 4, 40, (0, 10))
+    assert e.value.status == ERR_UNSUPPORTED
+    with pytest.raises(SvhError) as e:  # non-integer Pout: outside the exact regime
+        sv.censusBandMatch(tgt, src, 4, 4, 64, (0, 10), Pout=2.5)
+    assert e.value.status == ERR_UNSUPPORTED
+    with pytest.raises(SvhError) as e:
+        sv.censusBandMatch(tgt, src, 4, 4, 64, (15, 10))
+    assert e.value.status == ERR_INVALID_ARGUMENT
+
+
 # ------------------------------------------------------------------------------------------------ disparity shards
 @pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
 def test_census_shards_equal_single_gpu(ddir):

@@ -108,6 +108,63 @@ def test_pipelined_exchange_over_gloo(tmp_path):
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
+def _band_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import oracle as so
+    from helpers import parallax_pair
+    from libstevi_amd.sharded import RowBandStereoPipeline
+    from shard_protocol import band_winner
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for case, (D, n_dir, Pout, margins) in enumerate([(21, 8, 100.0, (0, 0, 0, 0)), (16, 8, 7.0, (2, 1, 0, 3)), (9, 4, 100.0, (0, 0, 0, 0)),
+                                                          (13, 0, 100.0, (0, 0, 0, 0))]):
+            frames = [parallax_pair(23, 31, 6, 5, 3 + k, 1, 4, seed=500 + 10 * case + k) for k in range(3)]
+
+            def compute(img_l, img_r, rows):  # the band from its own rows + halo only
+                return torch.from_numpy(band_winner(img_l, img_r, 4, 4, D, rows, n_dir, Pout, margins, oracle=so))
+
+            pipe = RowBandStereoPipeline(4, 4, D, gather=True, compute=compute, sgmDirections=n_dir, Pout=Pout)
+            results = [pipe.submit(tgt, src) for src, tgt, _ in frames]
+            assert results[0] is None
+            results = results[1:] + [pipe.flush()]
+            assert pipe.flush() is None
+            for k, ((src, tgt, _), idx) in enumerate(zip(frames, results)):
+                cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+                vol = so.sgm(cv, n_dir, so.COST, 0.001, 0.01, margins, Pout) if n_dir else cv
+                exp = so.extract_index(vol, so.COST)
+                assert np.array_equal(idx.numpy(), exp), f"rank {rank} case {case} frame {k}: {(idx.numpy() != exp).sum()} pixels differ"
+            # without the gather every rank keeps its own rows
+            own = RowBandStereoPipeline(4, 4, D, compute=compute, sgmDirections=n_dir, Pout=Pout)
+            src, tgt, _ = frames[0]
+            b, c = own.rows_of(tgt, src)
+            assert np.array_equal(own.submit(tgt, src).numpy(), exp_rows(so, tgt, src, D, n_dir, Pout, margins)[b:b + c])
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def exp_rows(so, tgt, src, D, n_dir, Pout, margins):
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
+    vol = so.sgm(cv, n_dir, so.COST, 0.001, 0.01, margins, Pout) if n_dir else cv
+    return so.extract_index(vol, so.COST)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_bands_over_gloo(tmp_path, world):
+    """RowBandStereoPipeline: every rank computes its rows of the map from its own rows + halo (numpy restatement of
+    svh_census_band_match on the oracle's census volume), one all_gather in flight replicates the map; it equals the oracle's
+    census + SGM + extractSelectedIndex chain on the whole image -- the rows of the map really are independent."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_band_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
 def test_shard_range_partitions():
     from libstevi_amd.sharded import shard_range
     for total in (1, 7, 256, 257, 2048):

@@ -316,6 +316,30 @@ def main():
                   "shard_disparities": pipe.shard[1], "note": "max over ranks, phases run back to back without overlap; the timed steps overlap the "
                                                               "exchange of frame k with the key kernels of frame k + 1"}
 
+    # ---- N > 1, for information (the headline above stays BASELINE config 5's protocol): the same frame split by ROWS.  In the exact
+    # regime the rows of the disparity map are independent (svh_census_band_match), so every rank computes its band of the whole
+    # disparity range and no exchange is needed; every rank checks its band against the replicated map of the protocol above.
+    row_bands = None
+    if world > 1:
+        rb = sharded.RowBandStereoPipeline(wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"], P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"])
+        band = rb.submit(d_tgt, d_src)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            band = rb.submit(d_tgt, d_src)
+        sync()
+        trb = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(trb, op=dist.ReduceOp.MAX)
+        rows = rb.rows_of(d_tgt, d_src)
+        same = torch.tensor([int(torch.equal(band, disp_dev[rows[0]:rows[0] + rows[1]]))], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        ms_rb = float(trb.item()) / args.steps * 1e3
+        row_bands = {"ms_per_step": round(ms_rb, 4), "Mdisparities_per_s": round(wl["W"] * wl["H"] * wl["D"] / ms_rb / 1e3, 1),
+                     "rows_per_gpu": rows[1], "collective": None, "result": "rank r holds rows band_range(H, r, N) of the map",
+                     "bands_equal_the_replicated_map": bool(same.item()),
+                     "note": "not BASELINE's protocol: the disparity range is not sharded, the image rows are (no exchange: the winner of a pixel "
+                             "depends on its own costs and its position only); barrier + synchronize on both sides, max over ranks"}
+
     rc = 0
     if rank == 0:
         voxels = wl["W"] * wl["H"] * wl["D"]
@@ -399,6 +423,10 @@ def main():
         }
         if phases is not None:
             line["frame_phases"] = phases
+        if row_bands is not None:
+            line["row_bands"] = row_bands
+            if not row_bands["bands_equal_the_replicated_map"]:
+                rc = 3
         got = disp_dev.cpu().numpy()
         if not args.no_cpu_baseline:
             if world == 1:

@@ -636,7 +636,7 @@ int launch_finalize(svh_context *ctx, const CensusGeom &g, const ScanGeom &sg, i
                     const WinnerOut &out) {
     const int64_t npx = (int64_t)g.H * g.Ws;
     if (mmap) SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, true>), grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
-    else if (out.taps || out.keys) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census finalize: S values need the min_p maps");
+    else if ((out.taps && !out.taps_up_to_shift) || out.keys) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census finalize: S values need the min_p maps");
     else SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, false>), grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;

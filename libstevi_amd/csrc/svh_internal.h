@@ -256,6 +256,9 @@ struct WinnerOut {
     int disp_sign = 1, disp_offset = 0;
     float *taps = nullptr;             // (H, W, 3): truncatedCostVolume<Same>(S, idx, taps_h_r, taps_v_r, 1)
     int taps_h_r = 0, taps_v_r = 0;
+    // the consumer of the taps only uses their differences (parabola and equiangular refinement, cost_based_refinement.h:43-69): in
+    // the exact regime the three taps of a pixel may then carry a common integer offset -- the sum of the min_p maps can be left out
+    bool taps_up_to_shift = false;
     unsigned long long *keys = nullptr; // cross-shard reduction keys
     int key_offset = 0, key_total = 0;
     bool any() const { return idx || disp || taps || keys; }

@@ -107,6 +107,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
     win.taps = d_taps;
     win.taps_h_r = prm->refine_h_radius;
     win.taps_v_r = prm->refine_v_radius;
+    win.taps_up_to_shift = want_refine && (prm->refine_kernel == SVH_PARABOLA || prm->refine_kernel == SVH_EQUIANGULAR);
     win.keys = d_keys;
     win.key_offset = sb;
     win.key_total = Dtot;
@@ -353,7 +354,8 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
     SgmArgs sa{prm->sgm_directions, SVH_COST, s.H, s.Ws, s.Dtot, prm->P1, prm->P2, prm->Pout, prm->margins[0], prm->margins[1], prm->margins[2],
                prm->margins[3]};
     // the disparity map alone does not depend on the min_p maps (census_finalize_kernel): no scans then
-    const bool winner_only = ctx->census_winner_shortcut && !want_refine;
+    const bool shift_ok = want_refine && (prm->refine_kernel == SVH_PARABOLA || prm->refine_kernel == SVH_EQUIANGULAR);
+    const bool winner_only = ctx->census_winner_shortcut && (!want_refine || shift_ok);
     float *mmap = nullptr;
     if (!winner_only) {
         mmap = scr.get_n<float>((size_t)6 * npx);
@@ -391,6 +393,7 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
         win.taps = d_taps;
         win.taps_h_r = prm->refine_h_radius;
         win.taps_v_r = prm->refine_v_radius;
+        win.taps_up_to_shift = shift_ok;
     }
     SVH_TRY(dev_census_finalize(ctx, sa, cs, mmap, (const uint2 *)dkeys, win));
     if (want_refine) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));

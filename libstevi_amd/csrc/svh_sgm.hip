@@ -978,9 +978,16 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
     const bool exact = lanes && census_exact_regime(a, cs.nWw);
     const bool lane_winner = lanes && !out_sgm;
     // index / disparity maps alone: the winner does not depend on the min_p maps (census_finalize_kernel), so no g map and no scans
-    const bool winner_only = exact && lane_winner && ctx->census_winner_shortcut && !win.taps && !win.keys;
+    // (refinement taps that are only ever subtracted from one another do not depend on them either: WinnerOut::taps_up_to_shift)
+    const bool winner_only = exact && lane_winner && ctx->census_winner_shortcut && !win.keys && (!win.taps || win.taps_up_to_shift);
     uint2 *keys = nullptr;
-    if (winner_only) return win.any() ? dev_census_winner(ctx, scr, a, cs, win) : SVH_OK;
+    if (winner_only && !win.taps) return win.any() ? dev_census_winner(ctx, scr, a, cs, win) : SVH_OK;
+    if (winner_only) { // taps: keys from the sweep, then the per-pixel kernel without maps
+        keys = scr.get_n<uint2>((size_t)a.H * a.W);
+        if (!keys) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_TRY(dev_census_sweep(ctx, a, cs, keys, nullptr));
+        return dev_census_finalize(ctx, a, cs, nullptr, keys, win);
+    }
     if (exact) SVH_TRY(dev_census_sweep_and_scans(ctx, scr, a, cs, mmap, &keys));
     if (!exact || !lane_winner) SVH_TRY(dispatch_cost_branch(ctx, a, src, mmap, lane_winner ? nullptr : &out, !exact));
     if (lane_winner && win.any()) {

@@ -412,6 +412,32 @@ def test_census_winner_without_line_scans(D, ddir):
         assert_bits(short["disp"], so.index_to_disp(so.extract_index(vol, so.COST), int(ddir)))
 
 
+@pytest.mark.parametrize("kernel", [so.PARABOLA, so.EQUIANGULAR, so.GAUSSIAN])
+@pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
+def test_census_refined_without_line_scans(kernel, ddir):
+    """Refined map: the parabola and equiangular kernels only subtract the three taps from one another (cost_based_refinement.h:43-69),
+    so in the exact regime the per-pixel constant the line scans would add cancels and they are skipped as well; the Gaussian kernel
+    takes logarithms of the taps and keeps the scans.  Same refined map bit for bit with the option off, and the oracle's within 1e-6."""
+    for D, (margins, Pout, n_dir, r) in [(64, ((0, 0, 0, 0), 100.0, 8, 4)), (100, ((3, 2, 5, 1), 7.0, 8, 4)), (256, ((0, 0, 0, 0), 100.0, 4, 3))]:
+        src, tgt, _ = parallax_pair(37, 300, 12, 8, 40, 3, 17, seed=900 + D)
+        kw = dict(dDir=ddir, sgmDirections=n_dir, P1=0.3, P2=0.9, Pout=Pout, margins=sv.Margins(*margins), refineKernel=kernel,
+                  refine_h_radius=r, refine_v_radius=r)
+        d_tgt, d_src = dev(tgt), dev(src)
+        try:
+            short = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, **kw)
+            sv.set_option(d_tgt, "census_winner_shortcut", 0)
+            scans = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, **kw)
+        finally:
+            sv.set_option(d_tgt, "census_winner_shortcut", 1)
+        assert_bits(short["disp"], host(scans["disp"]))
+        assert_close(short["refined"], host(scans["refined"]), 0.0)
+        cv = so.unfold_cost_volume(so.CENSUS, tgt, src, r, r, D, int(ddir))
+        vol = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, margins, Pout)
+        idx = so.extract_index(vol, so.COST)
+        if kernel != so.GAUSSIAN:  # (the oracle's log of a non-positive S is a NaN the GPU reproduces; compared above)
+            assert_close(short["refined"], so.refine_disp(so.truncated_cost_volume(vol, idx, r, r, 1), idx, kernel), 1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ row bands
 @pytest.mark.parametrize("ddir", [sv.dispDirection.RightToLeft, sv.dispDirection.LeftToRight])
 @pytest.mark.parametrize("D", [32, 96, 256])

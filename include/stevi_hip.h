@@ -106,9 +106,12 @@ const char *svh_last_error(const svh_context *ctx);
  * "census_winner_shortcut" (default 1): in the integer-exact regime of the census + SGM Cost-branch pipeline the winning disparity of a
  * pixel does not depend on the per-pass minima the reference hands along its lines (they shift every disparity of the pixel alike), so
  * calls that ask for index / disparity maps only skip the line scans; 0 runs them regardless (same maps; the parity tests compare).
- * "sgm_score_fused" (default 0): 1 makes the Score branch of svh_sgm_cost_volume carry the four downward passes in one sweep of the
- * volume (strips handed from block to block) instead of one read-modify-write sweep per pass.  Same bits (the parity tests
- * cross-check the two); at 4096x2160x256 it is no faster yet, hence off by default. */
+ * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
+ * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  1: one sweep of the volume, a launch per band of 16
+ * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23
+ * instead of 44 bytes per voxel over all passes).  2: the same sweep as ONE launch, strips handed from block to block through
+ * tagged granules in global memory (bit-identical, slower: DESIGN.md section 4.2a).  0: one read-modify-write sweep per pass.
+ * Same bits in all three; the parity tests cross-check them. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);

@@ -416,6 +416,34 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_prefix_max(v)), 63));
 }
 
+// R consecutive floats of a lane as 16 / 8 / 4-byte accesses (any address space)
+template <int R> __device__ __forceinline__ void lds_get(const float *p, float (&v)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < R / 4; q++) {
+            const float4 x = *reinterpret_cast<const float4 *>(p + 4 * q);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else if constexpr (R == 2) {
+        const float2 x = *reinterpret_cast<const float2 *>(p);
+        v[0] = x.x; v[1] = x.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) v[k] = p[k];
+    }
+}
+template <int R> __device__ __forceinline__ void lds_put(float *p, const float (&v)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if constexpr (R == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) p[k] = v[k];
+    }
+}
+
 // FAR_IS_GLOBAL: P2 >= P1 >= 0.  Then fl(prev[od] - P2) <= fl(prev[od] - P1) <= prev[od] for every od (x -> fl(x - P) is
 // monotone and P >= 0), so the three disparities excluded from the |od - nd| > 1 class are each dominated by a candidate
 // that is present anyway, and max_{|od-nd|>1} (prev[od] - P2) may be replaced by max_p - P2 without changing a(nd).
@@ -423,7 +451,10 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
 // textbook min / +P one bit for bit (negation is exact, max(-x) = -min(x), fl(-p - P) = -fl(p + P)); only used by the
 // textbook mode: the reference's own Cost branch is the scalar recurrence of the kernels above (finding F4).
 // DELTA: the pass writes its contribution act - c alone (the fused downward sweep below adds it in the reference's place).
-template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false>
+// VEC: 16-byte aligned volumes and D = 64 R exactly: every load and store of the main loop is one unconditional vector access, so
+// the compiler's count of outstanding memory operations is exact and consuming a batch does not wait for the loads of the next one
+// (with the generic form's conditional accesses every step ended in s_waitcnt vmcnt(0): the two batches never overlapped).
+template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false, bool VEC = false>
 __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
                                                             int D, int W, float P1, float P2, float Pout, bool vec) {
     const int lane = threadIdx.x & 63;
@@ -507,6 +538,10 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
                 prev[k] = act;
             }
             float *o = sgm + ((int64_t)ii * W + jj) * D + lane * R;
+            if constexpr (VEC) {
+                lds_put<R>(o, outv);
+                return;
+            }
             if constexpr (R % 4 == 0) {
                 if (vec && lane * R + R <= D) {
 #pragma unroll
@@ -520,6 +555,38 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
     };
     // two register batches: the loads of the next batch are in flight while the serial part walks the current one
     float c0[B][R], s0v[B][R], c1[B][R], s1v[B][R];
+    if constexpr (VEC) {
+        const int nb = L.len / B; // whole batches; the rest of the line one pixel at a time
+        auto px = [&](const float *vol, int t) { return vol + ((int64_t)(L.i0 + t * L.di) * W + (L.j0 + t * L.dj)) * D + lane * R; };
+        auto load_full = [&](float (&c)[B][R], float (&sv)[B][R], int k) {
+            k = min(k, nb - 1); // (past the end: the last whole batch again, unused)
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                lds_get<R>(px(cv, k * B + b), c[b]);
+                if (!FIRST && !DELTA) lds_get<R>(px(sgm, k * B + b), sv[b]);
+            }
+        };
+        auto run_full = [&](const float (&c)[B][R], const float (&sv)[B][R], int k) {
+#pragma unroll
+            for (int b = 0; b < B; b++) step(c[b], sv[b], L.i0 + (k * B + b) * L.di, L.j0 + (k * B + b) * L.dj);
+        };
+        if (nb > 0) {
+            load_full(c0, s0v, 0);
+            for (int k = 0; k < nb; k += 2) {
+                load_full(c1, s1v, k + 1);
+                run_full(c0, s0v, k);
+                if (k + 1 >= nb) break;
+                load_full(c0, s0v, k + 2);
+                run_full(c1, s1v, k + 1);
+            }
+        }
+        for (int t = nb * B; t < L.len; t++) {
+            lds_get<R>(px(cv, t), c0[0]);
+            if (!FIRST && !DELTA) lds_get<R>(px(sgm, t), s0v[0]);
+            step(c0[0], s0v[0], L.i0 + t * L.di, L.j0 + t * L.dj);
+        }
+        return;
+    }
     auto load_batch = [&](float (&c)[B][R], float (&sv)[B][R], int st) {
 #pragma unroll
         for (int b = 0; b < B; b++)
@@ -618,33 +685,6 @@ __device__ __forceinline__ void score_step3_far_global(const float (&prev)[3][R]
     }
 }
 #undef SVH_MAX3_DPP
-
-template <int R> __device__ __forceinline__ void lds_get(const float *p, float (&v)[R]) {
-    if constexpr (R % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < R / 4; q++) {
-            const float4 x = *reinterpret_cast<const float4 *>(p + 4 * q);
-            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-        }
-    } else if constexpr (R == 2) {
-        const float2 x = *reinterpret_cast<const float2 *>(p);
-        v[0] = x.x; v[1] = x.y;
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++) v[k] = p[k];
-    }
-}
-template <int R> __device__ __forceinline__ void lds_put(float *p, const float (&v)[R]) {
-    if constexpr (R % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else if constexpr (R == 2) {
-        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < R; k++) p[k] = v[k];
-    }
-}
 
 constexpr int kDownSpinCap = 1 << 21; // reloads of a neighbour's row before a block gives up (seconds; a healthy wait is microseconds)
 
@@ -883,6 +923,210 @@ __global__ void __launch_bounds__((NCW + 2) * 64) sgm_score_down_kernel(const fl
     }
 }
 
+// ---- Score branch: the four downward passes, a band of rows per launch -----------------------------------------
+// The same fusion without any hand-off between blocks: a launch covers KB image rows, a block a strip of WB columns, and what a
+// block would need from its neighbours during the band it computes itself -- the diagonal lines that enter its strip from the left
+// (a triangle of at most KB - 1 columns, one column narrower every row) and the anti-diagonal lines that enter from the right.
+// Line states cross from band to band through two global arrays (the previous band's last row, read; this band's last row,
+// written: 3 x W vectors of D floats each), the launch boundary is the only synchronisation.  Per band and block this costs
+// (KB - 1) KB / 2 extra single-pass pixels on either side against 3 WB KB pass-pixels of its own (+ 31 % at WB = KB = 16) and the
+// carried states (+ 10 % of the band's bytes); nothing spins.
+template <int R, bool POUT, bool TAIL>
+__device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], const float (&c)[R], int jj, int lane, int D, int W, float P1,
+                                                       float P2, float Pout, float (&act)[R]) {
+    float pf[R];
+    float A = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const bool keep = TAIL ? ((lane * R + k < D) & finite_f(prev[k])) : finite_f(prev[k]);
+        pf[k] = keep ? prev[k] : -INFINITY;
+        A = fmaxf(A, pf[k]);
+    }
+    const float max_p = wave_max_dpp(A);
+    const float prevL = lane_shift_up(pf[R - 1], -INFINITY);
+    const float prevR = lane_shift_down(pf[0], -INFINITY);
+    const bool maxp_fin = finite_f(max_p);
+    const float far = max_p - P2;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const float lo = (k > 0 ? pf[k - 1] : prevL) - P1;
+        const float hi = (k < R - 1 ? pf[k + 1] : prevR) - P1;
+        float a = fmaxf(fmaxf(pf[k], far), fmaxf(lo, hi));
+        if constexpr (POUT) {
+            const float a_out = a - Pout;
+            a = (jj + lane * R + k >= W) ? a_out : a;
+        }
+        const float moved = c[k] + (a - max_p);
+        act[k] = (maxp_fin & finite_f(a)) ? moved : c[k];
+    }
+}
+
+template <int R, int WB, int KB, int NCW, bool VEC>
+__global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *__restrict__ cv, float *sgm, int H, int W, int D, float P1, float P2,
+                                                                  float Pout, int r0, int rows, const float *__restrict__ st_in,
+                                                                  float *__restrict__ st_out) {
+    constexpr int DP = 64 * R, CPW = WB / NCW, NL = WB + KB - 1, NH = 2 * (KB - 1), HS = (NH + NCW - 1) / NCW;
+    constexpr int NB = R <= 4 ? 3 : 2; // register sets of the row prefetch
+    static_assert(WB % NCW == 0, "cells of a row are dealt evenly to the waves");
+    extern __shared__ __attribute__((aligned(16))) float band_lds[];
+    float *ringV = band_lds, *lineD = ringV + WB * DP, *lineA = lineD + NL * DP;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j0 = blockIdx.x * WB;
+    const int64_t plane = (int64_t)W * DP; // st_in / st_out: [pass V, D, A][column][DP]
+    auto row_end = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    // ---- the line states of row r0 - 1 (nothing to load for the first band: every line starts inside it)
+    if (r0 > 0) {
+        float v[R];
+        for (int slot = wave; slot < WB; slot += NCW) {
+            const int j = j0 + slot;
+            if (j < W) {
+                lds_get<R>(st_in + (int64_t)j * DP + lane * R, v);
+                lds_put<R>(ringV + slot * DP + lane * R, v);
+            }
+        }
+        for (int slot = wave; slot < NL; slot += NCW) {
+            const int jd = j0 - (rows - 1) + slot - 1; // predecessor (r0 - 1, jd) of the diagonal cell (r0, jd + 1) in slot `slot`
+            if (jd >= 0 && jd < W) {
+                lds_get<R>(st_in + plane + (int64_t)jd * DP + lane * R, v);
+                lds_put<R>(lineD + slot * DP + lane * R, v);
+            }
+            const int ja = j0 + slot + 1; // predecessor (r0 - 1, ja) of the anti-diagonal cell (r0, ja - 1)
+            if (ja < W) {
+                lds_get<R>(st_in + 2 * plane + (int64_t)ja * DP + lane * R, v);
+                lds_put<R>(lineA + slot * DP + lane * R, v);
+            }
+        }
+    }
+    row_end();
+    auto load_px = [&](const float *vol, int i, int j, float (&v)[R]) {
+        const float *p = vol + ((int64_t)i * W + j) * D + lane * R;
+        if constexpr (VEC) lds_get<R>(p, v);
+        else {
+#pragma unroll
+            for (int k = 0; k < R; k++) v[k] = (lane * R + k < D) ? p[k] : 0.0f;
+        }
+    };
+    // halo slot hs of row r: the pixel, the line slot and whether it is needed (left: diagonal lines, right: anti-diagonal lines)
+    auto halo_of = [&](int hs, int r, int &j, int &slot, bool &left) {
+        left = hs < KB - 1;
+        const int m = left ? hs + 1 : hs - (KB - 1) + 1;
+        j = left ? j0 - m : j0 + WB - 1 + m;
+        slot = left ? rows - 1 - r - m : WB - 1 + m + r;
+        return m <= rows - 1 - r && j >= 0 && j < W && (left || (r0 + r) + j < W);
+    };
+    auto run = [&](auto full_tag, auto pout_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, POUT = decltype(pout_tag)::value; // FULL: the whole strip is inside the image
+        auto load_row = [&](float (&c)[CPW][R], float (&d1)[CPW][R], float (&hc)[HS][R], int r) {
+            r = min(r, rows - 1); // (past the band: the last row again, unused)
+            const int i = r0 + r;
+#pragma unroll
+            for (int q = 0; q < CPW; q++) {
+                const int j = FULL ? j0 + wave + q * NCW : min(j0 + wave + q * NCW, W - 1);
+                load_px(cv, i, j, c[q]);
+                load_px(sgm, i, j, d1[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < HS; q++) {
+                int j, slot;
+                bool left;
+                (void)halo_of(wave + q * NCW, r, j, slot, left);
+                load_px(cv, i, min(max(j, 0), W - 1), hc[q]); // (every slot loads, needed or not: the count of loads in flight stays exact)
+            }
+        };
+        auto run_row = [&](const float (&c)[CPW][R], const float (&d1)[CPW][R], const float (&hc)[HS][R], int r) {
+            const int i = r0 + r;
+#pragma unroll
+            for (int q = 0; q < CPW; q++) {
+                const int t = wave + q * NCW, j = j0 + t;
+                if (!FULL && j >= W) continue;
+                float prev[3][R], act[3][R];
+                float *pv = ringV + t * DP + lane * R, *pd = lineD + (t - r + rows - 1) * DP + lane * R, *pa = lineA + (t + r) * DP + lane * R;
+                const bool visA = i + j < W;
+                lds_get<R>(pv, prev[0]);
+                lds_get<R>(pd, prev[1]);
+                lds_get<R>(pa, prev[2]);
+                if (i == 0 || j == 0) { // (wave-uniform) a line's first pixel sees prev = 0 (sgm.h:206-208)
+#pragma unroll
+                    for (int k = 0; k < R; k++) {
+                        prev[1][k] = 0.0f;
+                        if (i == 0) prev[0][k] = prev[2][k] = 0.0f;
+                    }
+                }
+                score_step3_far_global<R, POUT, !VEC>(prev, c[q], j, lane, D, W, P1, P2, Pout, act);
+                lds_put<R>(pv, act[0]);
+                lds_put<R>(pd, act[1]);
+                if (visA) lds_put<R>(pa, act[2]);
+                float outv[R];
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    float S = c[q][k] + (act[0][k] - c[q][k]); // sgm.h:298-300, pass after pass
+                    S = S + d1[q][k];
+                    const float dD = act[1][k] - c[q][k];
+                    S = S + dD;                               // pass 2 (i >= j) or pass 3 (j >= i) ...
+                    if (i == j) S = S + dD;                   // ... and both on the main diagonal
+                    const float S4 = S + (act[2][k] - c[q][k]);
+                    outv[k] = visA ? S4 : S;
+                }
+                float *o = sgm + ((int64_t)i * W + j) * D + lane * R;
+                if constexpr (VEC) lds_put<R>(o, outv);
+                else {
+#pragma unroll
+                    for (int k = 0; k < R; k++)
+                        if (lane * R + k < D) o[k] = outv[k];
+                }
+            }
+            // the neighbours' pixels whose lines reach this strip before the band ends: their one pass, state only
+#pragma unroll
+            for (int q = 0; q < HS; q++) {
+                int j, slot;
+                bool left;
+                if (!halo_of(wave + q * NCW, r, j, slot, left)) continue;
+                float prev[R], act[R];
+                float *ps = (left ? lineD : lineA) + slot * DP + lane * R;
+                lds_get<R>(ps, prev);
+                if (i == 0 || (left && j == 0)) {
+#pragma unroll
+                    for (int k = 0; k < R; k++) prev[k] = 0.0f;
+                }
+                score_step1_far_global<R, POUT, !VEC>(prev, hc[q], j, lane, D, W, P1, P2, Pout, act);
+                lds_put<R>(ps, act);
+            }
+            row_end();
+        };
+        float cb[NB][CPW][R], eb[NB][CPW][R], hb[NB][HS][R];
+#pragma unroll
+        for (int p = 0; p < NB - 1; p++) load_row(cb[p], eb[p], hb[p], p);
+        for (int r = 0; r < rows; r += NB) {
+#pragma unroll
+            for (int p = 0; p < NB; p++) {
+                if (r + p >= rows) break;
+                load_row(cb[(p + NB - 1) % NB], eb[(p + NB - 1) % NB], hb[(p + NB - 1) % NB], r + p + NB - 1);
+                run_row(cb[p], eb[p], hb[p], r + p);
+            }
+        }
+    };
+    const bool full = j0 + WB <= W, pout = j0 + WB - 1 + (KB - 1) + D > W; // (block uniform; the Pout form is right for every pixel)
+    if (full) {
+        if (pout) run(std::true_type{}, std::true_type{});
+        else run(std::true_type{}, std::false_type{});
+    } else run(std::false_type{}, std::true_type{});
+    // ---- this band's last row: the line states the next band starts from (own columns only)
+    float v[R];
+    for (int slot = wave; slot < WB; slot += NCW) {
+        const int j = j0 + slot;
+        if (j >= W) continue;
+        lds_get<R>(ringV + slot * DP + lane * R, v);
+        lds_put<R>(st_out + (int64_t)j * DP + lane * R, v);
+        lds_get<R>(lineD + slot * DP + lane * R, v);
+        lds_put<R>(st_out + plane + (int64_t)j * DP + lane * R, v);
+        lds_get<R>(lineA + (slot + rows - 1) * DP + lane * R, v);
+        lds_put<R>(st_out + 2 * plane + (int64_t)j * DP + lane * R, v);
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 static int pass_lines(int q, int Hp, int Wp) {
     if (q >= 10) return Hp + Wp - 1;
@@ -904,7 +1148,7 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
                            const int *gate = nullptr) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
-    constexpr int B = (R <= 4) ? 8 : (R == 8 ? 4 : 2);
+    constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
     if (do_minmaps && Hp > 0 && Wp > 0) {
         for (int q = 0; q < n_pass; q++) {
             LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
@@ -1043,8 +1287,12 @@ static int run_score_branch_fused(svh_context *ctx, Scratch &scr, const SgmArgs 
             LineSet ls{1, pass_lines(1, a.H, a.W), 0, 0, a.H, a.W};
             // (a line per image row: few waves, each far from filling its share of the memory pipe with a short batch)
             constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
-            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D,
-                       a.W, a.P1, a.P2, a.Pout, vec);
+            if (vec && a.D == 64 * R)
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, true, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls,
+                           a.D, a.W, a.P1, a.P2, a.Pout, vec);
+            else
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D,
+                           a.W, a.P1, a.P2, a.Pout, vec);
             SVH_CHECK_LAUNCH(ctx);
         }
         // diagnostic: SVH_SGM_DOWN_STAMPS=<file> makes the launch record when each strip passed each row's barrier and dumps it
@@ -1078,8 +1326,71 @@ static int run_score_branch_fused(svh_context *ctx, Scratch &scr, const SgmArgs 
         {
             LineSet ls{5, pass_lines(5, a.H, a.W), 0, 0, a.H, a.W};
             constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
-            SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D, a.W,
-                       a.P1, a.P2, a.Pout, vec);
+            if (vec && a.D == 64 * R)
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, false, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls,
+                           a.D, a.W, a.P1, a.P2, a.Pout, vec);
+            else
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D, a.W,
+                           a.P1, a.P2, a.Pout, vec);
+            SVH_CHECK_LAUNCH(ctx);
+        }
+        *ran = true;
+        return SVH_OK;
+    }
+}
+
+// The same three stages with the downward sweep as one launch per band of KB rows (sgm_score_band_kernel).
+template <int R, int KB>
+static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, bool *ran) {
+    *ran = false;
+    if constexpr (R > 8) return SVH_OK;
+    else {
+        constexpr int WB = 16, NCW = 8, DP = 64 * R;
+        const size_t shmem = (size_t)(WB + 2 * (WB + KB - 1)) * DP * sizeof(float);
+        static bool attr_set[64] = {};
+        if (!attr_set[ctx->device & 63]) {
+            SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, false>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_set[ctx->device & 63] = true;
+        }
+        const size_t state_floats = (size_t)3 * a.W * DP;
+        float *st[2] = {scr.get_n<float>(state_floats), scr.get_n<float>(state_floats)};
+        if (!st[0] || !st[1]) return SVH_ERR_OUT_OF_MEMORY;
+        constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
+        {
+            LineSet ls{1, pass_lines(1, a.H, a.W), 0, 0, a.H, a.W};
+            if (vec && a.D == 64 * R)
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, true, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls,
+                           a.D, a.W, a.P1, a.P2, a.Pout, vec);
+            else
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D,
+                           a.W, a.P1, a.P2, a.Pout, vec);
+            SVH_CHECK_LAUNCH(ctx);
+        }
+        const int strips = ceil_div(a.W, WB);
+        {
+            ProfScope prof(ctx, "sgm_score_bands"); // (one bracket around all the band launches)
+            for (int r0 = 0, b = 0; r0 < a.H; r0 += KB, b++) {
+                const int rows = std::min(KB, a.H - r0);
+                if (vec && a.D == DP)
+                    hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, true>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D, a.P1, a.P2,
+                                       a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1]);
+                else
+                    hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, false>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D, a.P1, a.P2,
+                                       a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1]);
+            }
+        }
+        SVH_CHECK_LAUNCH(ctx);
+        {
+            LineSet ls{5, pass_lines(5, a.H, a.W), 0, 0, a.H, a.W};
+            if (vec && a.D == 64 * R)
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, false, true>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls,
+                           a.D, a.W, a.P1, a.P2, a.Pout, vec);
+            else
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false>), ceil_div(ls.n_lines, 4), 256, 0, cv, sgm, ls, a.D, a.W,
+                           a.P1, a.P2, a.Pout, vec);
             SVH_CHECK_LAUNCH(ctx);
         }
         *ran = true;
@@ -1103,9 +1414,10 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
         SVH_HIP_CHECK(ctx, hipMemcpyAsync(sgm, cv, (size_t)a.H * a.W * a.D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (Hp <= 0 || Wp <= 0) return SVH_OK;
-    if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) {
+    if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) { // 1: bands of rows per launch, 2: strips handed over in one launch
         bool ran = false;
-        SVH_TRY(run_score_branch_fused<R>(ctx, scr, a, cv, sgm, vec, &ran));
+        if (ctx->sgm_score_fused == 2) SVH_TRY(run_score_branch_fused<R>(ctx, scr, a, cv, sgm, vec, &ran));
+        else SVH_TRY((run_score_branch_bands<R, 16>(ctx, scr, a, cv, sgm, vec, &ran))); // (8 / 12 / 16 rows per band: 13.6 / 13.8 / 13.8 ms at C4, 24: 15.0)
         if (ran) return SVH_OK;
     }
     for (int q = 0; q < n_pass; q++) {
@@ -1121,6 +1433,13 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
             } else {
                 if (first) SVH_SCORE(true, false, true); else SVH_SCORE(false, false, true);
             }
+        } else if (far_global && vec && a.D == 64 * R) { // the usual case: exact prefetch form
+            if (first)
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, true, true, false, false, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2,
+                           a.Pout, vec);
+            else
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, false, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2,
+                           a.Pout, vec);
         } else if (far_global) {
             if (first) SVH_SCORE(true, true, false); else SVH_SCORE(false, true, false);
         } else {

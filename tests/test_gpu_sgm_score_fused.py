@@ -1,6 +1,7 @@
 """The Score branch of sgmCostVolume (sgm.h:218-255, :329-389) with the four downward passes carried by one sweep of the volume
-(svh_sgm.hip, sgm_score_down_kernel: strips of the skewed image handed from block to block; option "sgm_score_fused" = 1) against
-the pass-per-launch kernels (the default) and the oracle: same bits."""
+(svh_sgm.hip; option "sgm_score_fused": 1 = sgm_score_band_kernel, a launch per band of rows with the neighbours' entering lines
+recomputed; 2 = sgm_score_down_kernel, strips of the skewed image handed from block to block) against the pass-per-launch kernels
+and the oracle: same bits."""
 import numpy as np
 import pytest
 
@@ -22,14 +23,18 @@ def bits(x):
     return np.ascontiguousarray(x, np.float32).view(np.uint32)
 
 
-def both_forms(cv, P1, P2, Pout):
+FORMS = [1, 2]  # 1: a launch per band of 16 rows (halos recomputed), 2: strips handed from block to block inside one launch
+
+
+def both_forms(cv, P1, P2, Pout, form):
     d = torch.from_numpy(cv).to(DEV)
-    sv.set_option(d, "sgm_score_fused", 1)
+    sv.set_option(d, "sgm_score_fused", form)
     try:
         fused = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
-    finally:
         sv.set_option(d, "sgm_score_fused", 0)
-    plain = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
+        plain = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
+    finally:
+        sv.set_option(d, "sgm_score_fused", 1)  # the default
     return fused, plain
 
 
@@ -37,16 +42,18 @@ def both_forms(cv, P1, P2, Pout):
 # disparity counts on each lane layout (1, 2, 4, 8 per lane), multiples of four or not
 @pytest.mark.parametrize("shape", [(37, 90, 40), (90, 37, 40), (64, 64, 17), (50, 70, 100), (33, 47, 256), (20, 35, 300), (1, 50, 8), (50, 1, 8),
                                    (130, 16, 5), (16, 130, 64)])
-def test_fused_equals_per_pass_and_oracle(rng, shape):
+@pytest.mark.parametrize("form", FORMS)
+def test_fused_equals_per_pass_and_oracle(rng, shape, form):
     cv = rng.uniform(-1, 1, shape).astype(np.float32)
     for P1, P2, Pout in [(0.001, 0.01, 100.0), (0.3, 0.3, 0.0), (0.0, 2.0, 0.5)]:
-        fused, plain = both_forms(cv, P1, P2, Pout)
+        fused, plain = both_forms(cv, P1, P2, Pout, form)
         exp = so.sgm(cv, 8, so.SCORE, P1, P2, (0, 0, 0, 0), Pout)
         assert np.array_equal(bits(plain), bits(exp))
         assert np.array_equal(bits(fused), bits(exp))
 
 
-def test_fused_nonfinite_costs(rng):
+@pytest.mark.parametrize("form", FORMS)
+def test_fused_nonfinite_costs(rng, form):
     cv = rng.uniform(0, 4, (40, 75, 48)).astype(np.float32)
     cv[0, 0, 0] = np.nan
     cv[-1, -1, :] = np.inf
@@ -54,7 +61,7 @@ def test_fused_nonfinite_costs(rng):
     cv[0, 30, :] = np.nan
     cv[17, :, 5] = np.inf
     cv[:, 44, 7] = np.nan
-    fused, plain = both_forms(cv, 0.3, 0.9, 7.0)
+    fused, plain = both_forms(cv, 0.3, 0.9, 7.0, form)
     exp = so.sgm(cv, 8, so.SCORE, 0.3, 0.9, (0, 0, 0, 0), 7.0)
     f, p = fused.cpu().numpy(), plain.cpu().numpy()
     assert np.array_equal(np.isnan(f), np.isnan(exp)) and np.array_equal(np.isnan(p), np.isnan(exp))
@@ -63,9 +70,10 @@ def test_fused_nonfinite_costs(rng):
     assert np.array_equal(p[ok].view(np.uint32), exp[ok].view(np.uint32))
 
 
-def test_fused_many_strips_against_per_pass(rng):
+@pytest.mark.parametrize("form", FORMS)
+def test_fused_many_strips_against_per_pass(rng, form):
     """More strips than the card holds blocks at once is not reachable at test sizes; this one has 150 strips and 600 rows, so the
     hand-off runs a few hundred rows deep, and is compared with the pass-per-launch kernels (the oracle takes minutes here)."""
     cv = rng.uniform(-1, 1, (600, 1800, 64)).astype(np.float32)
-    fused, plain = both_forms(cv, 0.02, 0.2, 3.0)
+    fused, plain = both_forms(cv, 0.02, 0.2, 3.0, form)
     assert torch.equal(fused.view(torch.int32), plain.view(torch.int32))

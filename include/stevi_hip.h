@@ -111,6 +111,7 @@ const char *svh_last_error(const svh_context *ctx);
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23
  * instead of 44 bytes per voxel over all passes).  2: the same sweep as ONE launch, strips handed from block to block through
  * tagged granules in global memory (bit-identical, slower: DESIGN.md section 4.2a).  0: one read-modify-write sweep per pass.
+ * (3 = 1 with the 16-column strips forced that images narrower than about 3000 columns replace by 8-column ones: for the tests.)
  * Same bits in all three; the parity tests cross-check them. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */

@@ -378,7 +378,8 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         return SVH_OK;
     }
     if (strcmp(name, "sgm_score_fused") == 0) {
-        if (value < 0 || value > 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows) or 2 (strips in one launch)");
+        if (value < 0 || value > 3)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows), 2 (strips in one launch), 3 (bands, 16-column strips forced)");
         ctx->sgm_score_fused = value;
         return SVH_OK;
     }

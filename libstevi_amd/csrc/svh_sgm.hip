@@ -173,6 +173,54 @@ __global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, LineSet l
     // The loads do not depend on the recurrence.  Two register batches: while the serial part walks batch `cur`, the
     // loads of batch `nxt` are already in flight (a line is one wave, so nothing else hides the HBM latency).
     float cur[B][R], nxt[B][R];
+    if constexpr (std::is_same<SRC, SrcVolume>::value && R % 4 == 0) {
+        // 16-byte aligned volume with D = 64 R: whole batches with unconditional vector loads, so that the compiler's count of loads
+        // in flight is exact and walking a batch does not wait for the loads of the next one (with a load under a branch every step
+        // ended in s_waitcnt vmcnt(0)).  The map store is hidden from that count (inline asm): one dword per pixel.
+        if (src.vec && D == 64 * R) {
+            const int nb = L.len / B;
+            auto px = [&](int t) { return src.cv + ((int64_t)(L.i0 + t * L.di) * W + (L.j0 + t * L.dj)) * D + lane * R; };
+            auto load_full = [&](float (&c)[B][R], int k) {
+                k = min(k, nb - 1); // (past the end: the last whole batch again, unused)
+#pragma unroll
+                for (int b = 0; b < B; b++) {
+                    const float *p = px(k * B + b);
+#pragma unroll
+                    for (int q = 0; q < R / 4; q++) {
+                        const float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+                        c[b][4 * q] = v.x; c[b][4 * q + 1] = v.y; c[b][4 * q + 2] = v.z; c[b][4 * q + 3] = v.w;
+                    }
+                }
+            };
+            auto one = [&](const float (&c)[R], int t) {
+                const int ii = L.i0 + t * L.di, jj = L.j0 + t * L.dj;
+                if (lane == 0) {
+                    float *dst = mmap + (int64_t)ii * W + jj;
+                    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(mp) : "memory");
+                }
+                mp = wave_min(cost_step_lane_min<R>(c, lane, D, jj, W, Pout, mp));
+            };
+            auto run_full = [&](const float (&c)[B][R], int k) {
+#pragma unroll
+                for (int b = 0; b < B; b++) one(c[b], k * B + b);
+            };
+            if (nb > 0) {
+                load_full(cur, 0);
+                for (int k = 0; k < nb; k += 2) {
+                    load_full(nxt, k + 1);
+                    run_full(cur, k);
+                    if (k + 1 >= nb) break;
+                    load_full(cur, k + 2);
+                    run_full(nxt, k + 1);
+                }
+            }
+            for (int t = nb * B; t < L.len; t++) {
+                src.template load<R>(L.i0 + t * L.di, L.j0 + t * L.dj, lane, cur[0]);
+                one(cur[0], t);
+            }
+            return;
+        }
+    }
     auto load_batch = [&](float (&c)[B][R], int s0) {
 #pragma unroll
         for (int b = 0; b < B; b++)
@@ -1340,12 +1388,12 @@ static int run_score_branch_fused(svh_context *ctx, Scratch &scr, const SgmArgs 
 }
 
 // The same three stages with the downward sweep as one launch per band of KB rows (sgm_score_band_kernel).
-template <int R, int KB>
+template <int R, int KB, int WB>
 static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, bool *ran) {
     *ran = false;
     if constexpr (R > 8) return SVH_OK;
     else {
-        constexpr int WB = 16, NCW = 8, DP = 64 * R;
+        constexpr int NCW = 8, DP = 64 * R;
         const size_t shmem = (size_t)(WB + 2 * (WB + KB - 1)) * DP * sizeof(float);
         static bool attr_set[64] = {};
         if (!attr_set[ctx->device & 63]) {
@@ -1414,10 +1462,15 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
         SVH_HIP_CHECK(ctx, hipMemcpyAsync(sgm, cv, (size_t)a.H * a.W * a.D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (Hp <= 0 || Wp <= 0) return SVH_OK;
-    if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) { // 1: bands of rows per launch, 2: strips handed over in one launch
+    if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) { // 1 (3: 16-column strips whatever the width): bands of rows per launch, 2: strips handed over in one launch
         bool ran = false;
         if (ctx->sgm_score_fused == 2) SVH_TRY(run_score_branch_fused<R>(ctx, scr, a, cv, sgm, vec, &ran));
-        else SVH_TRY((run_score_branch_bands<R, 16>(ctx, scr, a, cv, sgm, vec, &ran))); // (8 / 12 / 16 rows per band: 13.6 / 13.8 / 13.8 ms at C4, 24: 15.0)
+        else { // (8 / 12 / 16 rows per band: 13.6 / 13.8 / 13.8 ms at C4, 24: 15.0); strips of 8 columns where 16 would leave CUs without one
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            if (ctx->sgm_score_fused != 3 && ceil_div(a.W, 16) * 4 < cus * 3) SVH_TRY((run_score_branch_bands<R, 16, 8>(ctx, scr, a, cv, sgm, vec, &ran)));
+            else SVH_TRY((run_score_branch_bands<R, 16, 16>(ctx, scr, a, cv, sgm, vec, &ran)));
+        }
         if (ran) return SVH_OK;
     }
     for (int q = 0; q < n_pass; q++) {

@@ -23,7 +23,8 @@ def bits(x):
     return np.ascontiguousarray(x, np.float32).view(np.uint32)
 
 
-FORMS = [1, 2]  # 1: a launch per band of 16 rows (halos recomputed), 2: strips handed from block to block inside one launch
+FORMS = [1, 3, 2]  # 1: a launch per band of 16 rows (halos recomputed; 8-column strips at these widths), 3: the same with the 16-column
+# strips of wide images, 2: strips handed from block to block inside one launch
 
 
 def both_forms(cv, P1, P2, Pout, form):

@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
                                                                   float Pout, int r0, int rows, const float *__restrict__ st_in,
                                                                   float *__restrict__ st_out) {
     constexpr int DP = 64 * R, CPW = WB / NCW, NL = WB + KB - 1, NH = 2 * (KB - 1), HS = (NH + NCW - 1) / NCW;
-    constexpr int NB = R <= 4 ? 3 : 2; // register sets of the row prefetch
+    constexpr int NB = R <= 4 ? 3 : 2; // register sets of the row prefetch (4: no faster)
     static_assert(WB % NCW == 0, "cells of a row are dealt evenly to the waves");
     extern __shared__ __attribute__((aligned(16))) float band_lds[];
     float *ringV = band_lds, *lineD = ringV + WB * DP, *lineA = lineD + NL * DP;
@@ -1393,7 +1393,7 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
     *ran = false;
     if constexpr (R > 8) return SVH_OK;
     else {
-        constexpr int NCW = 8, DP = 64 * R;
+        constexpr int NCW = WB, DP = 64 * R; // a wave per own pixel (8 waves for 16 pixels: 13.8 ms at C4, 16 waves: 13.0)
         const size_t shmem = (size_t)(WB + 2 * (WB + KB - 1)) * DP * sizeof(float);
         static bool attr_set[64] = {};
         if (!attr_set[ctx->device & 63]) {
@@ -1465,10 +1465,11 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
     if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) { // 1 (3: 16-column strips whatever the width): bands of rows per launch, 2: strips handed over in one launch
         bool ran = false;
         if (ctx->sgm_score_fused == 2) SVH_TRY(run_score_branch_fused<R>(ctx, scr, a, cv, sgm, vec, &ran));
-        else { // (8 / 12 / 16 rows per band: 13.6 / 13.8 / 13.8 ms at C4, 24: 15.0); strips of 8 columns where 16 would leave CUs without one
+        else { // 16-column strips, 16 rows per band (8 / 12 / 16 rows: the same time at C4, 24: + 8 %); 8 x 8 where 16 columns would leave CUs
+               // without a strip (1080p: 8 / 16 / 32 rows per band 2.56 / 2.78 / 4.05 ms)
             int cus = 256;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-            if (ctx->sgm_score_fused != 3 && ceil_div(a.W, 16) * 4 < cus * 3) SVH_TRY((run_score_branch_bands<R, 16, 8>(ctx, scr, a, cv, sgm, vec, &ran)));
+            if (ctx->sgm_score_fused != 3 && ceil_div(a.W, 16) * 4 < cus * 3) SVH_TRY((run_score_branch_bands<R, 8, 8>(ctx, scr, a, cv, sgm, vec, &ran)));
             else SVH_TRY((run_score_branch_bands<R, 16, 16>(ctx, scr, a, cv, sgm, vec, &ran)));
         }
         if (ran) return SVH_OK;

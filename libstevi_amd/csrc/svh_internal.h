@@ -266,6 +266,10 @@ struct WinnerOut {
 // Cost branch on either source; out_sgm (H, W, D) optional
 int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &src, float *out_sgm, const WinnerOut &win);
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook = false);
+// Score branch, whole image, 8 directions, P2 >= P1 >= 0: the four downward passes as one sweep (svh_sgm_sweep.hip; form = the
+// "sgm_score_fused" option); *ran = false when the geometry is outside what the sweep covers.  The line kernel for one pass.
+int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran);
+int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta);
 // census specialisation of the Cost branch (svh_census_sgm.hip)
 bool census_lane_kernels_available(int nWw, int D);
 bool census_exact_regime(const SgmArgs &a, int nWw);

@@ -1,0 +1,164 @@
+// Line geometry of the reference's SGM passes and the wave-level primitives the SGM kernels share (svh_sgm.hip: the per-pass
+// kernels of both branches; svh_sgm_sweep.hip: the fused downward sweeps of the Score branch).
+#pragma once
+
+#include "svh_internal.h"
+
+namespace svh {
+
+struct LineSet {
+    int pass;   // 0..5 as listed above
+    int n_lines;
+    int top, left, Hp, Wp; // margin box origin and extent
+};
+
+struct Line {
+    int i0, j0, di, dj, len;
+};
+
+__device__ __forceinline__ Line line_of(const LineSet &ls, int l) {
+    Line L;
+    switch (ls.pass) {
+    case 0: L = {ls.top, ls.left + l, 1, 0, ls.Hp}; break;
+    case 1: L = {ls.top + l, ls.left, 0, 1, ls.Wp}; break;
+    case 2: L = {ls.top + l, ls.left, 1, 1, min(ls.Hp - l, ls.Wp)}; break;
+    case 3: L = {ls.top, ls.left + l, 1, 1, min(ls.Hp, ls.Wp - l)}; break;
+    case 4: L = {ls.top, ls.left + l, 1, -1, min(ls.Hp, l + 1)}; break;
+    case 5: L = {ls.top + l, ls.left, -1, 1, min(l + 1, ls.Wp)}; break;
+    // "textbook" line sets (svh_sgm_cost_volume_textbook): the eight directions, every line of the margin box exactly once
+    case 6: L = {ls.top, ls.left + l, 1, 0, ls.Hp}; break;                  // Up2Down
+    case 7: L = {ls.top + ls.Hp - 1, ls.left + l, -1, 0, ls.Hp}; break;     // Down2Up
+    case 8: L = {ls.top + l, ls.left, 0, 1, ls.Wp}; break;                  // Left2Right
+    case 9: L = {ls.top + l, ls.left + ls.Wp - 1, 0, -1, ls.Wp}; break;     // Right2Left
+    case 10: case 11: {                                                    // diagonal j - i = l - (Hp - 1), forwards / backwards
+        const int k = l - (ls.Hp - 1), i0 = k <= 0 ? -k : 0, j0 = k <= 0 ? 0 : k, len = min(ls.Hp - i0, ls.Wp - j0);
+        if (ls.pass == 10) L = {ls.top + i0, ls.left + j0, 1, 1, len};
+        else L = {ls.top + i0 + len - 1, ls.left + j0 + len - 1, -1, -1, len};
+    } break;
+    default: {                                                             // anti-diagonal i + j = l, downwards / upwards
+        const int i0 = l < ls.Wp ? 0 : l - (ls.Wp - 1), j0 = l < ls.Wp ? l : ls.Wp - 1, len = min(ls.Hp - i0, j0 + 1);
+        if (ls.pass == 12) L = {ls.top + i0, ls.left + j0, 1, -1, len};
+        else L = {ls.top + i0 + len - 1, ls.left + j0 - (len - 1), -1, 1, len};
+    } break;
+    }
+    return L;
+}
+
+// does pass q visit pixel (ip, jp) (coordinates relative to the margin box, already known to be inside it)?
+__device__ __forceinline__ bool pass_visits(int q, int ip, int jp, int Hp, int Wp) {
+    switch (q) {
+    case 0: case 1: return true;
+    case 2: return ip >= jp;
+    case 3: return jp >= ip;
+    case 4: return ip + jp < Wp;
+    default: return ip + jp < Hp;
+    }
+}
+
+__device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; } // false for NaN and +-inf
+
+__device__ __forceinline__ float wave_min(float v) { // DPP: row_shr 1,2,4,8, row_bcast:15, row_bcast:31, result in lane 63
+#define SVH_DPP_MIN(CTRL, RM) v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x7F800000, __builtin_bit_cast(int, v), CTRL, RM, 0xF, false)))
+    SVH_DPP_MIN(0x111, 0xF);
+    SVH_DPP_MIN(0x112, 0xF);
+    SVH_DPP_MIN(0x114, 0xF);
+    SVH_DPP_MIN(0x118, 0xF);
+    SVH_DPP_MIN(0x142, 0xA);
+    SVH_DPP_MIN(0x143, 0xC);
+#undef SVH_DPP_MIN
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ---- cost sources -----------------------------------------------------------------------------------
+struct SrcVolume { // dense (H, W, D) floats
+    const float *cv;
+    int W, D;
+    bool vec; // 16-byte aligned rows, D % 4 == 0
+    template <int R> __device__ __forceinline__ void load(int i, int j, int lane, float (&c)[R]) const {
+        const float *p = cv + ((int64_t)i * W + j) * D + lane * R;
+        if constexpr (R % 4 == 0) {
+            if (vec && lane * R + R <= D) {
+#pragma unroll
+                for (int q = 0; q < R / 4; q++) {
+                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+                    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) c[k] = (lane * R + k < D) ? p[k] : 0.0f;
+    }
+};
+
+// cross-lane primitives on the DPP path (no LDS round trip): whole-wave shifts by one lane and a max reduction
+// cross-lane primitives on the DPP path (no LDS round trip): whole-wave shifts by one lane and a max reduction
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float lane_shift_up(float v, float fill) { return dpp_move<0x138>(fill, v); }   // wave_shr:1 -> value of lane-1
+__device__ __forceinline__ float lane_shift_down(float v, float fill) { return dpp_move<0x130>(fill, v); } // wave_shl:1 -> value of lane+1
+// inclusive prefix maximum over the lanes (lane 63 ends up with the wave maximum): row_shr 1,2,4,8 inside each row
+// of 16, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ float wave_prefix_max(float v) {
+    v = fmaxf(v, dpp_move<0x111>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x112>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x114>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x118>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x142, 0xA>(-INFINITY, v));
+    v = fmaxf(v, dpp_move<0x143, 0xC>(-INFINITY, v));
+    return v;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_prefix_max(v)), 63));
+}
+
+// R consecutive floats of a lane as 16 / 8 / 4-byte accesses (any address space)
+template <int R> __device__ __forceinline__ void lds_get(const float *p, float (&v)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < R / 4; q++) {
+            const float4 x = *reinterpret_cast<const float4 *>(p + 4 * q);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+        }
+    } else if constexpr (R == 2) {
+        const float2 x = *reinterpret_cast<const float2 *>(p);
+        v[0] = x.x; v[1] = x.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) v[k] = p[k];
+    }
+}
+template <int R> __device__ __forceinline__ void lds_put(float *p, const float (&v)[R]) {
+    if constexpr (R % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(p + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if constexpr (R == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) p[k] = v[k];
+    }
+}
+
+// ---- host helpers
+inline int pass_lines(int q, int Hp, int Wp) {
+    if (q >= 10) return Hp + Wp - 1;
+    if (q >= 6) return q < 8 ? Wp : Hp;
+    return (q == 0 || q == 3 || q == 4) ? Wp : Hp;
+}
+
+inline int pick_R(int D) {
+    int R = 1;
+    while (64 * R < D) R <<= 1;
+    return R;
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+} // namespace svh

@@ -1,5 +1,5 @@
 """The Score branch of sgmCostVolume (sgm.h:218-255, :329-389) with the four downward passes carried by one sweep of the volume
-(svh_sgm.hip; option "sgm_score_fused": 1 = sgm_score_band_kernel, a launch per band of rows with the neighbours' entering lines
+(svh_sgm_sweep.hip; option "sgm_score_fused": 1 = sgm_score_band_kernel, a launch per band of rows with the neighbours' entering lines
 recomputed; 2 = sgm_score_down_kernel, strips of the skewed image handed from block to block) against the pass-per-launch kernels
 and the oracle: same bits."""
 import numpy as np

@@ -50,7 +50,7 @@ struct svh_context {
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 2 strips; 0: a launch per pass)
-    // edge states handed from strip to strip by the fused Score-branch sweep (svh_sgm.hip): {value, tag} granules.  Written by
+    // edge states handed from strip to strip by the strip form of the fused Score-branch sweep (svh_sgm_sweep.hip): {value, tag} granules.  Written by
     // nothing else and zeroed when allocated, so a granule whose tag equals the launch's number was written by that launch.
     void *sgm_edges = nullptr;
     size_t sgm_edges_bytes = 0;

@@ -1,4 +1,4 @@
-"""Reads the per-row barrier stamps of the fused Score-branch sweep (svh_sgm.hip, sgm_score_down_kernel; written when the
+"""Reads the per-row barrier stamps of the fused Score-branch sweep (svh_sgm_sweep.hip, sgm_score_down_kernel; written when the
 environment variable SVH_SGM_DOWN_STAMPS names a file) and prints, for a few strips, when they started and ended, their time per
 row at the start / middle / end of their life, the lag between neighbouring strips at a few rows and the number of strips alive
 at a few instants.  100 MHz ticks -> microseconds.

@@ -377,6 +377,19 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
     for (int k = 0; k < R; k++) prev[k] = 0.0f; // sgm.h:206-208
     // one pixel of the line: the reference's update of the R disparities of this lane
     auto step = [&](const float (&c_in)[R], const float (&sacc)[R], int ii, int jj) {
+            if constexpr (VEC && FAR_IS_GLOBAL && !NEG) { // the branch-free form (svh_sgm_lines.h): a third of the instructions
+                float act[R], outv[R];
+                if (jj + D > W) score_step1_far_global<R, true, false>(prev, c_in, jj, lane, D, W, P1, P2, Pout, act);
+                else score_step1_far_global<R, false, false>(prev, c_in, jj, lane, D, W, P1, P2, Pout, act);
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const float base = FIRST ? c_in[k] : sacc[k];
+                    outv[k] = DELTA ? act[k] - c_in[k] : base + (act[k] - c_in[k]); // :298-300
+                    prev[k] = act[k];
+                }
+                lds_put<R>(sgm + ((int64_t)ii * W + jj) * D + lane * R, outv);
+                return;
+            }
             float c[R];
 #pragma unroll
             for (int k = 0; k < R; k++) c[k] = NEG ? -c_in[k] : c_in[k];

@@ -146,6 +146,39 @@ template <int R> __device__ __forceinline__ void lds_put(float *p, const float (
     }
 }
 
+// One step of the Score branch's recurrence (sgm.h:218-255) for the R disparities of this lane when P2 >= P1 >= 0 (the far term is
+// max_p - P2: see svh_sgm.hip), written without per-lane branches.  POUT: some disparity of this pixel looks past the image border
+// (wave-uniform; false for most pixels, which skip the term).  TAIL: D < 64 R, the lanes past D are masked.
+template <int R, bool POUT, bool TAIL>
+__device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], const float (&c)[R], int jj, int lane, int D, int W, float P1,
+                                                       float P2, float Pout, float (&act)[R]) {
+    float pf[R];
+    float A = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const bool keep = TAIL ? ((lane * R + k < D) & finite_f(prev[k])) : finite_f(prev[k]);
+        pf[k] = keep ? prev[k] : -INFINITY;
+        A = fmaxf(A, pf[k]);
+    }
+    const float max_p = wave_max_dpp(A);
+    const float prevL = lane_shift_up(pf[R - 1], -INFINITY);
+    const float prevR = lane_shift_down(pf[0], -INFINITY);
+    const bool maxp_fin = finite_f(max_p);
+    const float far = max_p - P2;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const float lo = (k > 0 ? pf[k - 1] : prevL) - P1;
+        const float hi = (k < R - 1 ? pf[k + 1] : prevR) - P1;
+        float a = fmaxf(fmaxf(pf[k], far), fmaxf(lo, hi));
+        if constexpr (POUT) {
+            const float a_out = a - Pout;
+            a = (jj + lane * R + k >= W) ? a_out : a;
+        }
+        const float moved = c[k] + (a - max_p);
+        act[k] = (maxp_fin & finite_f(a)) ? moved : c[k];
+    }
+}
+
 // ---- host helpers
 inline int pass_lines(int q, int Hp, int Wp) {
     if (q >= 10) return Hp + Wp - 1;

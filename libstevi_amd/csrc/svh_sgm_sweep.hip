@@ -331,36 +331,6 @@ __global__ void __launch_bounds__((NCW + 2) * 64) sgm_score_down_kernel(const fl
 // written: 3 x W vectors of D floats each), the launch boundary is the only synchronisation.  Per band and block this costs
 // (KB - 1) KB / 2 extra single-pass pixels on either side against 3 WB KB pass-pixels of its own (+ 31 % at WB = KB = 16) and the
 // carried states (+ 10 % of the band's bytes); nothing spins.
-template <int R, bool POUT, bool TAIL>
-__device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], const float (&c)[R], int jj, int lane, int D, int W, float P1,
-                                                       float P2, float Pout, float (&act)[R]) {
-    float pf[R];
-    float A = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const bool keep = TAIL ? ((lane * R + k < D) & finite_f(prev[k])) : finite_f(prev[k]);
-        pf[k] = keep ? prev[k] : -INFINITY;
-        A = fmaxf(A, pf[k]);
-    }
-    const float max_p = wave_max_dpp(A);
-    const float prevL = lane_shift_up(pf[R - 1], -INFINITY);
-    const float prevR = lane_shift_down(pf[0], -INFINITY);
-    const bool maxp_fin = finite_f(max_p);
-    const float far = max_p - P2;
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const float lo = (k > 0 ? pf[k - 1] : prevL) - P1;
-        const float hi = (k < R - 1 ? pf[k + 1] : prevR) - P1;
-        float a = fmaxf(fmaxf(pf[k], far), fmaxf(lo, hi));
-        if constexpr (POUT) {
-            const float a_out = a - Pout;
-            a = (jj + lane * R + k >= W) ? a_out : a;
-        }
-        const float moved = c[k] + (a - max_p);
-        act[k] = (maxp_fin & finite_f(a)) ? moved : c[k];
-    }
-}
-
 template <int R, int WB, int KB, int NCW, bool VEC>
 __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *__restrict__ cv, float *sgm, int H, int W, int D, float P1, float P2,
                                                                   float Pout, int r0, int rows, const float *__restrict__ st_in,

@@ -515,9 +515,9 @@ template <int NW, bool MAPS>
 __global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout, const float *__restrict__ mmap,
                                                               const uint2 *__restrict__ keys, WinnerOut out) {
     const int64_t npx = (int64_t)g.H * g.Ws;
-    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (p >= npx) return;
-    const int j = (int)(p % g.Ws), i = (int)(p / g.Ws);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y; // (a row of blocks per image row: no 64-bit division per pixel)
+    if (j >= g.Ws) return;
+    const int64_t p = (int64_t)i * g.Ws + j;
     int msum = 0, n_vis = 0;
     if constexpr (MAPS) {
         const PixelPasses pp = load_pixel_passes(sg, n_pass, i, j, mmap, npx, p);
@@ -634,10 +634,11 @@ template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float 
 template <int NW>
 int launch_finalize(svh_context *ctx, const CensusGeom &g, const ScanGeom &sg, int n_pass, float Pout, const float *mmap, const uint2 *keys,
                     const WinnerOut &out) {
-    const int64_t npx = (int64_t)g.H * g.Ws;
-    if (mmap) SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, true>), grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
+    if (g.H > 65535) return fail(ctx, SVH_ERR_UNSUPPORTED, "images taller than 65535 rows");
+    const dim3 grid(ceil_div(g.Ws, 256), g.H);
+    if (mmap) SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, true>), grid, 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
     else if ((out.taps && !out.taps_up_to_shift) || out.keys) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census finalize: S values need the min_p maps");
-    else SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, false>), grid_for(npx, 256), 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
+    else SVH_LAUNCH(ctx, "census_finalize", (census_finalize_kernel<NW, false>), grid, 256, 0, g, sg, n_pass, Pout, mmap, keys, out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

@@ -441,6 +441,28 @@ def main():
                 rc = 3
         else:
             line["end_px_err"] = None
+        if world == 1 and not args.with_line_scans:
+            # For comparison with earlier rounds and for anyone who wants the aggregation's recurrences inside the measurement: the same
+            # step with the g map, the six line scans, the six min_p maps and the finalize launch run although the disparity map does not
+            # depend on them (census_winner_shortcut = 0).  Same K steps, same bracketing; `value` above is the
+            # product's default path.
+            sv.set_option(d_src, "census_winner_shortcut", 0)
+            try:
+                for _ in range(max(args.warmup, 1)):
+                    out_ls = step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    out_ls = step()
+                torch.cuda.synchronize()
+                dt_ls = (time.perf_counter() - t1) / args.steps
+            finally:
+                sv.set_option(d_src, "census_winner_shortcut", 1)
+            line["with_line_scans"] = {"ms_per_step": round(dt_ls * 1e3, 4), "Mdisparities_per_s": round(voxels / dt_ls / 1e6, 1),
+                                       "same_disparity_map": bool(torch.equal(out_ls["disp"], disp_dev)),
+                                       "kernels": "census_transform, census_sweep_pm (keys + g), sgm_line_scans, census_finalize"}
+            if not line["with_line_scans"]["same_disparity_map"]:
+                rc = 3
         if world == 1 and args.two_frames:
             # Outside the timed region, for information: the same step with consecutive frames alternating between two HIP streams
             # (a video stream's deployment form).  The four kernels of a frame are each bound by instruction issue or by a

@@ -78,3 +78,32 @@ def test_fused_many_strips_against_per_pass(rng, form):
     cv = rng.uniform(-1, 1, (600, 1800, 64)).astype(np.float32)
     fused, plain = both_forms(cv, 0.02, 0.2, 3.0, form)
     assert torch.equal(fused.view(torch.int32), plain.view(torch.int32))
+
+
+@pytest.mark.parametrize("seed", [3, 5])
+def test_fused_forms_on_random_geometries(seed):
+    """Random small shapes (one row, one column, fewer columns than a strip, D from 1 to 300, costs with NaN / inf sprinkled in):
+    the three fused forms and the per-pass kernels against the oracle."""
+    rng = np.random.default_rng(seed)
+    for case in range(25):
+        H, W = int(rng.integers(1, 45)), int(rng.integers(1, 70))
+        D = int(rng.choice([1, 3, 8, 17, 64, 65, 128, 256, 300]))
+        cv = rng.uniform(-2, 2, (H, W, D)).astype(np.float32)
+        if rng.random() < 0.3:
+            cv[rng.integers(0, H), rng.integers(0, W), rng.integers(0, D)] = np.nan
+            cv[rng.integers(0, H), rng.integers(0, W), :] = np.inf
+        P1 = float(rng.choice([0.0, 0.001, 0.3]))
+        P2 = P1 + float(rng.choice([0.0, 0.01, 1.0]))
+        Pout = float(rng.choice([0.0, 0.5, 100.0]))
+        exp = so.sgm(cv, 8, so.SCORE, P1, P2, (0, 0, 0, 0), Pout)
+        ok = ~np.isnan(exp)
+        d = torch.from_numpy(cv).to(DEV)
+        try:
+            for form in (0, 1, 2, 3):
+                sv.set_option(d, "sgm_score_fused", form)
+                got = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout).cpu().numpy()
+                what = f"case {case} form {form}: {H}x{W}x{D} P1={P1} P2={P2} Pout={Pout}"
+                assert np.array_equal(np.isnan(got), np.isnan(exp)), what
+                assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32)), what
+        finally:
+            sv.set_option(d, "sgm_score_fused", 1)

@@ -65,5 +65,8 @@ bool launch_sweep_mfma(svh_context *ctx, const CensusGeom &g, float Pout, uint2 
 // 4-bit (FP4) operands +-1, persistent blocks (svh_census_sweep_pm.hip)
 // (winner: write the index / disparity maps instead of keys and g)
 bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner = nullptr);
+// the same for RightToLeft geometries whose Pout region is "target column outside the image", 64 / 128 / 256 / 512 disparities, up
+// to three census words (svh_census_sweep_rl.hip); launch_sweep_pm tries it first unless the "census_sweep_rl" option is 0
+bool launch_sweep_rl(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner);
 
 } // namespace svh

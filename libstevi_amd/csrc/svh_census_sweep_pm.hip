@@ -40,45 +40,16 @@
 // SVH_SWEEP_STAMPS (tools/sweep_phases.hip): s_memtime stamps per wave and phase into a side buffer; never in the product build.
 #include <type_traits>
 
-#include "svh_census_keys.h"
-
 #include <cstddef>
+
+#include "svh_census_sweep_fp4.h"
 #include "svh_nibble_tables.h"
 
 namespace svh {
 
 namespace {
 
-using v8i = int __attribute__((ext_vector_type(8)));
-using v16f = float __attribute__((ext_vector_type(16)));
-
-constexpr float BIG_CELL = 4194304.0f;        // an invalid cell starts this far below: never the maximum of a tile that has a valid one
-constexpr float BIG_G = 268435456.0f;           // "no candidate yet" is -BIG_G
-constexpr float G_VALID_ABOVE = -1048576.0f;  // valid packed maxima stay above
-
-__device__ __forceinline__ constexpr int row_of_reg(int reg) { return (reg & 3) + 8 * (reg >> 2); } // + 4 * (lane >> 5)
-
-// max of three (v_max3_f32).  Not inline asm: the tree is the first reader of the MFMA result and the compiler only pads the
-// MFMA -> VALU read hazard for instructions it can see.
-__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-
-// The 32 bits of a census word as the 32 FP4 operands of one lane-half k-subset, 16 bytes: bit 0 -> +1.0 (nibble 0x2), bit 1 -> -1.0
-// (0xA).  Two bits make a byte, one of 0x22 / 0x2A / 0xA2 / 0xAA: a four-entry table that fits a register, looked up four bytes
-// at a time by v_perm_b32 with the bit pairs as selectors.  Dword t of the record holds the bit pairs (8 q + 2 t, 8 q + 2 t + 1),
-// q = 0 .. 3 -- not the bits in order, which a dot product does not care about as long as both operands use the same order; both
-// come from this function.  11 VALU instructions per word and no LDS traffic (a 256-entry byte table in LDS cost 8 + four
-// conflict-ridden ds_read_b32 per word: the LDS then answered in ~800 cycles and every phase of the kernel waited on it).
-__device__ __forceinline__ uint4 word_record(uint32_t w) {
-    constexpr uint32_t TABLE = 0xAAA22A22u, PAIRS = 0x03030303u;
-    return make_uint4(__builtin_amdgcn_perm(0u, TABLE, w & PAIRS), __builtin_amdgcn_perm(0u, TABLE, (w >> 2) & PAIRS),
-                      __builtin_amdgcn_perm(0u, TABLE, (w >> 4) & PAIRS), __builtin_amdgcn_perm(0u, TABLE, (w >> 6) & PAIRS));
-}
-
-// 16 bytes per lane from global memory straight into LDS: lane l lands at lds_wave_base + 16 l (the base is wave uniform)
-__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_wave_base,
-                                     16, 0, 0);
-}
+using namespace fp4sweep;
 
 #ifdef SVH_SWEEP_STAMPS
 #define SVH_STAMP(k) stamp[k] = __builtin_amdgcn_s_memtime()
@@ -87,14 +58,6 @@ __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
 #define SVH_STAMP(k)
 #define SVH_STAMP_PARAM
 #endif
-
-struct SweepPlan {   // host-side decomposition of a launch (make_plan)
-    int bpr;         // items per image row
-    int items;       // items per XCD list: ceil(H / 8) * bpr (rows i = 8 q + xcd)
-    int step;        // blocks per XCD list = gridDim.x / 8: a block takes items slot, slot + step, ...
-    int step_q, step_j; // step = step_q * bpr + step_j: the same walk without a division per item
-    int nbuf;        // window buffers in LDS: 2 (the expansion of item n + 1 overlaps other waves' tiles of item n) or 1
-};
 
 __host__ __device__ inline int staging_chunks(int pixels, int nw) { return (pixels * nw * 4 + 15) / 16 + 1; } // 16-byte pieces of a slice (+1: a slice may start mid-piece)
 
@@ -603,6 +566,7 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
 
 #ifndef SVH_SWEEP_STAMPS
 bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner) {
+    if (ctx->census_sweep_rl && launch_sweep_rl(ctx, g, Pout, keys, gmap, status, winner)) return true;
     const SweepWinner sw = winner ? *winner : SweepWinner();
     if (sw.on() && g.region1_global_last >= 0) return false; // (disparity shards exchange keys)
     if (g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 4) return false;

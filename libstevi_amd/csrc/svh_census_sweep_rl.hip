@@ -1,0 +1,419 @@
+// census_sweep on the matrix cores, the form the benchmark geometry takes: RightToLeft, the disparities that pay Pout are exactly
+// the ones that look past the target image's right edge, disparity count known at compile time.
+//
+// Same arithmetic as svh_census_sweep_pm.hip (that file has the encoding: +-1 FP4 operands on v_mfma_scale_f32_32x32x64_f8f6f4, cell =
+// 256 dot + register number + 16 tile, running maximum in the frame of the current tile) and the same persistent walk over items
+// (an item = 32 CT WAVES source pixels of one image row, the blocks of an XCD on neighbouring rows).  What differs is everything
+// around the MFMAs, because that -- not the matrix pipe -- was what the launch spent its time on: round 2's kernel issued 23 M wave
+// instructions per 1080p x 256 launch, of which the tiles themselves (MFMA + fragment read + the nine-instruction maximum) are 7 M;
+// a third of the stream was scalar bookkeeping and branches (profiles/r02b_sq_counters.json).  Here
+//
+//   * the disparity count is a template parameter: a column tile's D/32 + 1 row tiles are straight-line code (no loop counter, no
+//     remainder loops, fragment addresses are immediates);
+//   * with the geometry condition  Wt - disp_lower == Ws - d_offset  the Pout region of a pixel is the set of disparities whose
+//     target column lies outside the image: those columns hold the all-zero census vector (cross_correlations.h:235), their cost is
+//     |s| for every such disparity, and the reference's '<=' scan (correlation_base.h:441-455) leaves the LAST index of the range as
+//     that region's winner.  So the second regional key is  (popcount(s), last index)  when the pixel has such disparities, and no
+//     tile has to be computed, masked or decoded for them: a column tile near the right edge simply runs fewer row tiles (the one
+//     that straddles the edge starts from a pattern that holds -2^22 in its rows past it);
+//   * operands come through registers, not through an LDS staging area: buffer loads (range-checked by the hardware: no clamps,
+//     nothing to compute per lane and item but one add) fetch the next item's compact words while the tiles of the current one run,
+//     the expansion writes the FP4 records of the window; LDS holds the two window buffers and nothing else;
+//   * the two lane halves merge with v_permlane32_swap instead of a ds_bpermute round trip.
+//
+// Geometries outside this (LeftToRight, a search range that does not end at the image edge, other disparity counts, four census
+// words) keep svh_census_sweep_pm.hip; tests/test_gpu_sweep_engines.py holds the two kernels and the vector-ALU sweep to the same keys.
+#include <type_traits>
+
+#include <cstddef>
+
+#include "svh_census_sweep_fp4.h"
+
+namespace svh {
+
+namespace {
+
+using namespace fp4sweep;
+
+constexpr int RL_WAVES = 4;
+
+// blocks per CU the register budget is set for: three (168 registers) while the window buffers of three blocks fit the LDS
+__host__ __device__ constexpr int rl_win(int nt, int ct) { return RL_WAVES * ct * 32 + 32 * (nt - 1); }
+__host__ __device__ constexpr size_t rl_lds_bytes(int nw, int nt, int ct) { return (size_t)2 * 2 * ((nw + 1) / 2) * rl_win(nt, ct) * 16; }
+__host__ __device__ constexpr int rl_blocks_per_cu(int nw, int nt, int ct) { return 3 * rl_lds_bytes(nw, nt, ct) <= 160 * 1024 ? 3 : (2 * rl_lds_bytes(nw, nt, ct) <= 160 * 1024 ? 2 : 1); }
+
+// the kernel's arguments as the kernel argument segment lays them out (by-value arguments at their natural alignment, in order)
+struct RlKernelArgs {
+    CensusGeom g;
+    float Pout;
+    uint2 *keys;
+    float *gmap;
+    SweepPlan plan;
+    SweepWinner sw;
+};
+static_assert(offsetof(RlKernelArgs, keys) % 8 == 0 && offsetof(RlKernelArgs, sw) % 8 == 0 && alignof(SweepWinner) == 8 && alignof(CensusGeom) == 8,
+              "the WINNER epilogue reads `sw` from the kernel argument segment at offsetof(RlKernelArgs, sw)");
+
+template <int N> using dwords_t = std::conditional_t<N == 1, uint32_t, std::conditional_t<N == 2, uint2, std::conditional_t<N == 3, uint3, uint4>>>;
+
+template <int N> __device__ __forceinline__ void buffer_load_words(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off, uint32_t (&out)[N]) {
+    static_assert(N >= 1 && N <= 4, "");
+    if constexpr (N == 1) {
+        out[0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0);
+    } else if constexpr (N == 2) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0);
+        out[0] = v[0];
+        out[1] = v[1];
+    } else if constexpr (N == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off, 0, 0);
+        out[0] = v[0];
+        out[1] = v[1];
+        out[2] = v[2];
+    } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+        out[0] = v[0];
+        out[1] = v[1];
+        out[2] = v[2];
+        out[3] = v[3];
+    }
+}
+
+template <int NW, int NT, int CT, bool WINNER, int BPC = rl_blocks_per_cu(NW, NT, CT)>
+__global__ void __launch_bounds__(64 * RL_WAVES, BPC)
+    census_sweep_rl_kernel(CensusGeom g, float Pout, uint2 *__restrict__ keys, float *__restrict__ gmap, SweepPlan plan, SweepWinner sw) {
+    constexpr int WAVES = RL_WAVES;
+    constexpr int PXB = WAVES * CT * 32;  // source pixels per item
+    constexpr int D = 32 * (NT - 1);      // disparities of this launch
+    constexpr int WIN = PXB + D;          // window pixels: the last column tile's last row tile ends at PXB - 32 + 32 NT
+    constexpr int SL = WIN / WAVES;       // window pixels fetched and expanded by each wave
+    constexpr int PB = (SL + 63) / 64;    // ... in rounds of one pixel per lane
+    constexpr int NG = (NW + 1) / 2;      // MFMAs per tile: 64 bits of census record each
+    constexpr int B = 32 * NW;            // written census bits: cost = (B - dot) / 2
+    constexpr int BUF = 2 * NG * WIN;     // records per window buffer
+    static_assert(WIN % WAVES == 0 && NT >= 3, "");
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[]; // [2][2 NG planes][WIN] FP4 records
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (slot >= plan.items) return; // (block uniform, before any barrier)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // the word maps as buffers: a load past either end returns zeros (first and last rows of the image, the padding pixels of the
+    // last item of a row), whatever it returns for a column outside the image is replaced during the expansion
+    const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)g.tw, 0, g.H * g.Wt * NW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)g.sw, 0, g.H * g.Ws * NW * 4, 0x00020000);
+    const uint32_t t_lane = (uint32_t)((wave * SL + lane) * NW * 4);            // this lane's pixel of the wave's window slice, round 0
+    const uint32_t s_lane = (uint32_t)(((wave * CT * 32 + r) * NW + h) * 4);    // word h of this lane's source pixel in column tile 0
+
+    // cell (row tile k, row, col) of column tile c is disparity 32 k + row - col of source pixel j = j0 + 32 c + col; it counts
+    // (region without Pout) while j + d < R, R = Ws - d_offset: row < R - j0 - 32 c - 32 k.  R = 32 Rq + nv.
+    const int R = g.Ws - g.d_offset, Rq = R >> 5, nv = R & 31;
+    // the Pout region's key of a pixel: (|s|, last index) when j + last >= Ws (disparity shards: the last index of the whole range)
+    const int last = g.region1_global_last >= 0 ? g.region1_global_last : g.d_offset + D - 1;
+
+    uint32_t tword[PB][NW], snext[CT][NG], sword[CT][NG];
+    auto issue_loads = [&](int i, int j0) {
+        if (i >= g.H) return; // (padding rows of the last group of eight)
+        const uint32_t t_off = (uint32_t)((i * g.Wt + j0 + g.disp_lower) * NW * 4) + t_lane;
+#pragma unroll
+        for (int b = 0; b < PB; b++) buffer_load_words<NW>(rsrc_t, t_off + (uint32_t)(b * 64 * NW * 4), tword[b]);
+        const uint32_t s_off = (uint32_t)((i * g.Ws + j0) * NW * 4) + s_lane;
+#pragma unroll
+        for (int cc = 0; cc < CT; cc++)
+#pragma unroll
+            for (int gq = 0; gq < NG; gq++) snext[cc][gq] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_off + (uint32_t)((cc * 32 * NW + 2 * gq) * 4), 0, 0);
+    };
+    // registers -> FP4 records of window buffer `buf` (this wave's SL pixels); the source words of the item move into place
+    const int wr_lane = wave * SL + lane; // window pixel of this lane, round 0
+    auto expand = [&](int i, int j0, int buf) {
+        if (i >= g.H) return;
+        uint4 *const win = lds4 + buf * BUF;
+        const int col0 = j0 + g.disp_lower + wave * SL;             // target column of the slice's first pixel
+        const bool interior = col0 >= 0 && col0 + SL <= g.Wt;       // (wave uniform) every column of the slice is inside the image
+        if (!interior) {
+#pragma unroll
+            for (int b = 0; b < PB; b++) {
+                const int col = col0 + 64 * b + lane;
+                const bool inside = col >= 0 && col < g.Wt;         // outside: the all-zero vector (cross_correlations.h:235)
+#pragma unroll
+                for (int w = 0; w < NW; w++) tword[b][w] = inside ? tword[b][w] : 0u;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < PB; b++) {
+            const bool live = 64 * (b + 1) <= SL || lane < SL - 64 * b;
+            if (live) {
+#pragma unroll
+                for (int w = 0; w < NW; w++) win[w * WIN + wr_lane + 64 * b] = word_record(tword[b][w]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < CT; cc++)
+#pragma unroll
+            for (int gq = 0; gq < NG; gq++) sword[cc][gq] = snext[cc][gq];
+    };
+
+    // ---- once per block: the missing plane of an odd word count (0.0 operands: contributes nothing)
+    if constexpr (NW & 1) {
+        for (int b = 0; b < 2; b++)
+            for (int y = threadIdx.x; y < WIN; y += 64 * WAVES) lds4[b * BUF + NW * WIN + y] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    // the walk over this block's items: s = slot, slot + step, ... as (q, jb) = (s / bpr, s % bpr): row 8 q + xcd, source pixel PXB jb
+    int s = slot, q = slot / plan.bpr, jb = slot - q * plan.bpr;
+    auto advance = [&](int &qq, int &jj) {
+        qq += plan.step_q;
+        jj += plan.step_j;
+        if (jj >= plan.bpr) {
+            jj -= plan.bpr;
+            qq++;
+        }
+    };
+    issue_loads(q * 8 + xcd, jb * PXB);
+    // accumulator starts: a cell is 512 dot + its ROW in the tile (+ 32 per row tile, in the frame of the current tile: the running
+    // maximum drops by 32 per tile) -- svh_census_sweep_pm.hip starts from the register number instead, which orders the cells of a
+    // lane but not those of the two lane halves; with the row in the cell a packed maximum is 1024 (B - cost) + (d + col) - 512 B
+    // whichever lane took it.  The two triangular tiles push their invalid cells out of reach.  Opaque so that the patterns live in
+    // registers and go into the MFMA as its C operand
+    float opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    v16f full_tile, first_tile, last_tile;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int rr = row_of_reg(reg) + 4 * h;
+        full_tile[reg] = (float)rr + opaque_zero;
+        first_tile[reg] = (float)rr - (rr >= r ? 0.0f : BIG_CELL) + opaque_zero; // tile 0: d = row - col >= 0
+        last_tile[reg] = (float)rr - (rr < r ? 0.0f : BIG_CELL) + opaque_zero;   // tile D/32: d = D + row - col < D
+    }
+    expand(q * 8 + xcd, jb * PXB, 0);
+    int q_n = q, jb_n = jb; // the item after the current one
+    advance(q_n, jb_n);
+    if (s + plan.step < plan.items) issue_loads(q_n * 8 + xcd, jb_n * PXB);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the window writes are done ...
+    __builtin_amdgcn_s_barrier();                       // ... raw: a __syncthreads() would also wait for the loads just issued
+
+    // key of a pixel from its packed maximum gf = 1024 (B - cost) + 32 tile + row - 512 B, d = 32 tile + row - col (col = lane & 31)
+    auto decode = [&](float gf, bool check) {
+        const int gv = (int)gf + 512 * B;
+        const int key = (int)make_key(B - (gv >> 10), g.d_offset + (gv & 1023) - r);
+        return (!check || gf > G_VALID_ABOVE) ? key : (int)KEY_NONE;
+    };
+    const uint32_t frag_lane = (uint32_t)(h * WIN + wave * CT * 32 + r); // record of (row tile 0, group 0) of column tile 0 in a buffer
+
+    int buf = 0;
+    for (;;) {
+        const int i = q * 8 + xcd, j0 = jb * PXB;
+        if (i < g.H) {
+            const uint4 *const arow = lds4 + buf * BUF + frag_lane;
+            const int64_t row = (int64_t)i * g.Ws;
+            struct Frags {
+                v8i w[NG];
+            };
+            float Gabs[CT]; // per column tile: the packed maximum over its row tiles, of this lane's rows (4 h + ...), tile tags absolute
+            bool all_interior = true;
+#pragma unroll
+            for (int cc = 0; cc < CT; cc++) {
+                const int ct = wave * CT + cc;
+                // source fragments: this lane's word of every 64-bit group as +-1.0 nibbles (an absent odd word: 0.0)
+                v8i bfrag[NG];
+#pragma unroll
+                for (int gq = 0; gq < NG; gq++) {
+                    const uint4 rec = word_record(sword[cc][gq]);
+                    const bool present = h == 0 || 2 * gq + 1 < NW;
+                    bfrag[gq] = (v8i){present ? (int)rec.x : 0, present ? (int)rec.y : 0, present ? (int)rec.z : 0, present ? (int)rec.w : 0, 0, 0, 0, 0};
+                }
+                auto load_frags = [&](int k) { // row tile k, group gq: arow[2 gq WIN + 32 (cc + k)]
+                    Frags f;
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) {
+                        const uint4 t = arow[2 * gq * WIN + 32 * (cc + k)];
+                        f.w[gq] = (v8i){(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+                    }
+                    return f;
+                };
+                auto tile = [&](const Frags &f, const v16f &start) {
+                    v16f a = start;
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) // FP4 x FP4, block scales 2^5 x 2^4 (E8M0 132, 131): an equal bit adds 512, a differing one -512
+                        a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.w[gq], bfrag[gq], a, 4, 4, 0, 132, 0, 131);
+                    return a;
+                };
+                float G = -BIG_G; // running maximum, frame of the current tile
+                auto epilogue = [&](const v16f &a) {
+                    const float t1 = max3f(a[0], a[1], a[2]), t2 = max3f(a[3], a[4], a[5]), t3 = max3f(a[6], a[7], a[8]), t4 = max3f(a[9], a[10], a[11]),
+                                t5 = max3f(a[12], a[13], a[14]);
+                    const float t6 = max3f(t1, t2, t3), t7 = max3f(t4, t5, a[15]);
+                    G = max3f(G - 32.0f, t6, t7); // frame of tile k: max over the tiles so far of (tile maximum - 32 (k - tile))
+                };
+                // row tiles of this column tile that hold cells of the region without Pout: all of tiles 0 .. kq - 1, rows below nv of tile kq
+                const int kq = Rq - (j0 >> 5) - ct; // (wave uniform)
+                if (kq >= NT) {
+                    // every row tile counts -- every column tile but the ones at the right image border.  Straight-line: the fragments
+                    // of tile k + 2 requested, the MFMA of tile k + 1 in flight while the maximum of tile k is taken
+                    Frags f_a = load_frags(0), f_b = load_frags(1);
+                    v16f acc_a = tile(f_a, first_tile), acc_b;
+#pragma unroll
+                    for (int k = 0; k < NT; k++) {
+                        if (k + 1 < NT) {
+                            if (k & 1) acc_a = tile(f_a, k + 1 == NT - 1 ? last_tile : full_tile);
+                            else acc_b = tile(f_b, k + 1 == NT - 1 ? last_tile : full_tile);
+                        }
+                        if (k + 2 < NT) {
+                            if (k & 1) f_b = load_frags(k + 2);
+                            else f_a = load_frags(k + 2);
+                        }
+                        epilogue((k & 1) ? acc_b : acc_a);
+                    }
+                    Gabs[cc] = G + (float)(32 * (NT - 1));
+                } else {
+                    // near the right border: tiles 0 .. kq - 1 whole, tile kq up to row nv - 1; nothing further right counts
+                    all_interior = false;
+                    const int k_end = kq < 0 ? 0 : (nv > 0 ? kq + 1 : kq); // (<= NT: kq < NT)
+                    for (int k = 0; k < k_end; k++) {
+                        v16f start = k == 0 ? first_tile : (k == NT - 1 ? last_tile : full_tile);
+                        if (k == kq) {
+#pragma unroll
+                            for (int reg = 0; reg < 16; reg++) start[reg] = row_of_reg(reg) + 4 * h < nv ? start[reg] : -BIG_CELL;
+                        }
+                        Frags f;
+#pragma unroll
+                        for (int gq = 0; gq < NG; gq++) {
+                            const uint4 t = arow[2 * gq * WIN + 32 * cc + 32 * k];
+                            f.w[gq] = (v8i){(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+                        }
+                        epilogue(tile(f, start));
+                    }
+                    Gabs[cc] = G + (float)(32 * (k_end - 1));
+                }
+            }
+            // ---- per pixel: keys (or the winner) from the packed maxima.  A lane half holds rows 4 h + {0..3, 8..11, ...} of its pixel's
+            // cells; packed maxima compare across the halves as they are (the row is in them), so the halves merge BEFORE the decode,
+            // and two column tiles merge into one wave of 64 different pixels: v_permlane32_swap puts tile c's two halves into the lower
+            // lanes of (x, y), tile c + 1's into the upper lanes.  A last odd column tile takes the lower lanes alone.
+            auto finish = [&](int c0, bool pair) {
+                float x = Gabs[c0], y = pair ? Gabs[c0 + 1] : Gabs[c0];
+                int ones_x = 0, ones_y = 0; // |s|: each lane half holds its words of the pixel
+#pragma unroll
+                for (int gq = 0; gq < NG; gq++) {
+                    const bool present = 2 * gq + 1 < NW || h == 0;
+                    ones_x += present ? __popc(sword[c0][gq]) : 0;
+                    ones_y += present ? __popc(sword[pair ? c0 + 1 : c0][gq]) : 0;
+                }
+                const auto sg = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                const float gf = __builtin_fmaxf(__uint_as_float(sg[0]), __uint_as_float(sg[1]));
+                const int jp = j0 + (wave * CT + c0) * 32 + (pair ? lane : r); // this lane's pixel
+                int a0 = decode(gf, !all_interior);
+                int a1 = (int)KEY_NONE;
+                if (j0 + (wave * CT + c0) * 32 + (pair ? 63 : 31) + last >= g.Ws) { // (wave uniform) some pixel here has disparities that pay Pout
+                    const auto so = __builtin_amdgcn_permlane32_swap((unsigned)ones_x, (unsigned)ones_y, false, false);
+                    a1 = jp + last >= g.Ws ? (int)make_key((int)(so[0] + so[1]), last) : (int)KEY_NONE;
+                }
+                if ((pair || h == 0) && jp < g.Ws) {
+                    if constexpr (WINNER) { // the winner itself: census_keys.h
+                        // `sw` is read from the kernel argument segment HERE (an opaque pointer: the loads cannot be hoisted), not
+                        // kept in a dozen scalar registers through the tile code
+                        typedef __attribute__((address_space(4))) const char *KernArg;
+                        KernArg ka = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+                        asm volatile("" : "+s"(ka));
+                        typedef __attribute__((address_space(4))) const uint32_t *KernArgWords;
+                        KernArgWords kw = (KernArgWords)(ka + offsetof(RlKernelArgs, sw));
+                        static_assert(sizeof(SweepWinner) % 4 == 0, "read as dwords");
+                        uint32_t raw[sizeof(SweepWinner) / 4];
+#pragma unroll
+                        for (unsigned qq = 0; qq < sizeof(SweepWinner) / 4; qq++) raw[qq] = kw[qq];
+                        SweepWinner w;
+                        __builtin_memcpy(&w, raw, sizeof w);
+                        const int bd = winner_index((uint32_t)a0, (uint32_t)a1, passes_visiting(w, i, jp), w.pout);
+                        if ((unsigned)(i - w.row_first) < (unsigned)w.row_count) {
+                            const int64_t o = (int64_t)(i - w.row_first) * g.Ws + jp;
+                            if (w.idx) w.idx[o] = bd;
+                            if (w.disp) w.disp[o] = w.disp_sign * bd + w.disp_offset;
+                        }
+                    } else {
+                        keys[row + jp] = make_uint2((uint32_t)a0, (uint32_t)a1);
+                        if (gmap) gmap[row + jp] = g_from_keys((uint32_t)a0, (uint32_t)a1, (int)Pout);
+                    }
+                }
+            };
+#pragma unroll
+            for (int c0 = 0; c0 + 1 < CT; c0 += 2) finish(c0, true);
+            if constexpr (CT & 1) finish(CT - 1, false);
+        }
+        s += plan.step;
+        if (s >= plan.items) break; // (block uniform)
+        q = q_n;
+        jb = jb_n;
+        advance(q_n, jb_n);
+        expand(q * 8 + xcd, jb * PXB, buf ^ 1); // (waits for the words requested before the tiles)
+        if (s + plan.step < plan.items) issue_loads(q_n * 8 + xcd, jb_n * PXB);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+    }
+}
+
+template <int NW, int NT, int CT, int BPC = rl_blocks_per_cu(NW, NT, CT)> int launch_rl(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, const SweepWinner &sw) {
+    constexpr int PXB = RL_WAVES * CT * 32;
+    static int n_cu[64] = {};
+    const int dev = ctx->device & 63;
+    int n = __atomic_load_n(&n_cu[dev], __ATOMIC_RELAXED);
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&n_cu[dev], n, __ATOMIC_RELAXED);
+    }
+    constexpr size_t shmem = rl_lds_bytes(NW, NT, CT);
+    int grid;
+    const SweepPlan plan = make_walk(g.H, g.Ws, PXB, n, BPC, 2, &grid);
+    static int attr_set[64] = {}; // (per instantiation and device)
+    if (!__atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_rl_kernel<NW, NT, CT, false, BPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_rl_kernel<NW, NT, CT, true, BPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return fail(ctx, SVH_ERR_HIP, "census_sweep (fp4, right-to-left): cannot raise the dynamic LDS limit");
+        __atomic_store_n(&attr_set[dev], 1, __ATOMIC_RELEASE);
+    }
+    if (sw.on()) SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_rl_kernel<NW, NT, CT, true, BPC>), grid, 64 * RL_WAVES, shmem, g, Pout, keys, gmap, plan, sw);
+    else SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_rl_kernel<NW, NT, CT, false, BPC>), grid, 64 * RL_WAVES, shmem, g, Pout, keys, gmap, plan, sw);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SVH_OK : fail(ctx, SVH_ERR_HIP, "census_sweep (fp4, right-to-left): %s", hipGetErrorString(e));
+}
+
+template <int NW, int NT> int launch_rl_width(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, const SweepWinner &sw) {
+    // item width: 384 source pixels, or 512 where that pads the row less (and its window buffers fit)
+    constexpr bool wide_fits = 2 * rl_lds_bytes(NW, NT, 4) <= 160 * 1024;
+    if constexpr (wide_fits) {
+        if ((int64_t)ceil_div(g.Ws, 512) * 512 < (int64_t)ceil_div(g.Ws, 384) * 384) return launch_rl<NW, NT, 4>(ctx, g, Pout, keys, gmap, sw);
+    }
+    return launch_rl<NW, NT, 3>(ctx, g, Pout, keys, gmap, sw);
+}
+
+template <int NW> bool launch_rl_words(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner &sw) {
+    switch (g.D) {
+    case 64: *status = launch_rl_width<NW, 3>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 128: *status = launch_rl_width<NW, 5>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 256: *status = launch_rl_width<NW, 9>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 512: *status = launch_rl_width<NW, 17>(ctx, g, Pout, keys, gmap, sw); return true;
+    default: return false;
+    }
+}
+
+} // namespace
+
+bool launch_sweep_rl(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner) {
+    const SweepWinner sw = winner ? *winner : SweepWinner();
+    if (sw.on() && g.region1_global_last >= 0) return false; // (disparity shards exchange keys)
+    if (g.sign <= 0) return false;                            // RightToLeft only
+    // the disparities that pay Pout (j + global index >= Ws) are exactly the ones whose target column j + disp_lower + d is outside
+    if (g.Wt - g.disp_lower != g.Ws - g.d_offset) return false;
+    // buffer descriptors and offsets are 32-bit
+    if ((int64_t)g.H * g.Wt * g.nWw * 4 >= (int64_t)1 << 31 || (int64_t)g.H * g.Ws * g.nWw * 4 >= (int64_t)1 << 31) return false;
+    if (g.d_offset + g.D > (int)KEY_IDX_MASK + 1) return false;
+    switch (g.nWw) {
+    case 1: return launch_rl_words<1>(ctx, g, Pout, keys, gmap, status, sw);
+    case 2: return launch_rl_words<2>(ctx, g, Pout, keys, gmap, status, sw);
+    case 3: return launch_rl_words<3>(ctx, g, Pout, keys, gmap, status, sw);
+    default: return false;
+    }
+}
+
+} // namespace svh

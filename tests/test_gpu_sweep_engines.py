@@ -21,13 +21,17 @@ DEV = torch.device("cuda:0")
 
 
 def both_engines(fn, probe):
+    """vector ALU, int8 matrix cores, FP4 matrix cores (general kernel), FP4 with its RightToLeft specialisation allowed
+    (svh_census_sweep_rl.hip: taken where the geometry fits, the general kernel elsewhere)"""
     out = []
     try:
-        for mode in (1, 2, 3):
+        for mode, rl in ((1, 1), (2, 1), (3, 0), (3, 1)):
             sv.set_option(probe, "census_sweep", mode)
+            sv.set_option(probe, "census_sweep_rl", rl)
             out.append(fn())
     finally:
         sv.set_option(probe, "census_sweep", 0)
+        sv.set_option(probe, "census_sweep_rl", 1)
     return out
 
 
@@ -37,8 +41,8 @@ def oracle_disp(tgt, src, h_r, D, n_dir, Pout, margins=(0, 0, 0, 0), lower=0):
     return so.extract_index(vol, so.COST)
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 256, 480, 512, 992])
-@pytest.mark.parametrize("W", [97, 384, 700])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256, 480, 512, 992])
+@pytest.mark.parametrize("W", [97, 384, 700, 1100])
 def test_keys_and_disparities_agree(D, W):
     src, tgt, _ = parallax_pair(11, W, 9, 3, min(40, W // 3), 2, 13, seed=D + W)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)

@@ -29,9 +29,16 @@ __device__ __forceinline__ float max3f(float a, float b, float c) { return __bui
 // that order a dword is ((w << (3 - q)) & 0x88888888) | 0x22222222: a shift and a v_and_or_b32, 7 VALU instructions per word (the
 // first form, bit pairs looked up by v_perm_b32 in a four-entry byte table, took 11; a 256-entry byte table in LDS 8 + four
 // conflict-ridden ds_read_b32).
+// (Inline asm: the compiler splits (x & m) | c with two literal constants into v_and + v_or, 11 instructions again; with the mask in a
+// scalar register and the ones in a vector register it is one VOP3.)
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t mask_sgpr, uint32_t ones_vgpr) {
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(mask_sgpr), "v"(ones_vgpr));
+    return d;
+}
 __device__ __forceinline__ uint4 word_record(uint32_t w) {
     constexpr uint32_t SIGNS = 0x88888888u, ONES = 0x22222222u;
-    return make_uint4(((w << 3) & SIGNS) | ONES, ((w << 2) & SIGNS) | ONES, ((w << 1) & SIGNS) | ONES, (w & SIGNS) | ONES);
+    return make_uint4(and_or(w << 3, SIGNS, ONES), and_or(w << 2, SIGNS, ONES), and_or(w << 1, SIGNS, ONES), and_or(w, SIGNS, ONES));
 }
 
 // 16 bytes per lane from global memory straight into LDS: lane l lands at lds_wave_base + 16 l (the base is wave uniform)

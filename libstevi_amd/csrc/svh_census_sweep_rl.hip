@@ -191,12 +191,6 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the window writes are done ...
     __builtin_amdgcn_s_barrier();                       // ... raw: a __syncthreads() would also wait for the loads just issued
 
-    // key of a pixel from its packed maximum gf = 1024 (B - cost) + 32 tile + row - 512 B, d = 32 tile + row - col (col = lane & 31)
-    auto decode = [&](float gf, bool check) {
-        const int gv = (int)gf + 512 * B;
-        const int key = (int)make_key(B - (gv >> 10), g.d_offset + (gv & 1023) - r);
-        return (!check || gf > G_VALID_ABOVE) ? key : (int)KEY_NONE;
-    };
     const uint32_t frag_lane = (uint32_t)(h * WIN + wave * CT * 32 + r); // record of (row tile 0, group 0) of column tile 0 in a buffer
 
     int buf = 0;
@@ -301,11 +295,21 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                 const auto sg = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
                 const float gf = __builtin_fmaxf(__uint_as_float(sg[0]), __uint_as_float(sg[1]));
                 const int jp = j0 + (wave * CT + c0) * 32 + (pair ? lane : r); // this lane's pixel
-                int a0 = decode(gf, !all_interior);
-                int a1 = (int)KEY_NONE;
+                // gf = 1024 (B - cost) + 32 tile + row - 512 B, and 32 tile + row = d + col (col = lane & 31)
+                const int gv = (int)gf + 512 * B, cost0 = B - (gv >> 10);
+                int a0 = (int)make_key(cost0, g.d_offset + (gv & 1023) - r), a1 = (int)KEY_NONE;
+                int g2 = 2 * cost0; // g = min over the disparities of 2 c (+ Pout), svh_census_keys.h: g_from_keys
+                if (!all_interior) { // (wave uniform) a pixel right of the region's edge has no cell at all
+                    const bool any = gf > G_VALID_ABOVE;
+                    a0 = any ? a0 : (int)KEY_NONE;
+                    g2 = any ? g2 : (1 << 24);
+                }
                 if (j0 + (wave * CT + c0) * 32 + (pair ? 63 : 31) + last >= g.Ws) { // (wave uniform) some pixel here has disparities that pay Pout
                     const auto so = __builtin_amdgcn_permlane32_swap((unsigned)ones_x, (unsigned)ones_y, false, false);
-                    a1 = jp + last >= g.Ws ? (int)make_key((int)(so[0] + so[1]), last) : (int)KEY_NONE;
+                    const int ones = (int)(so[0] + so[1]);
+                    const bool pays = jp + last >= g.Ws;
+                    a1 = pays ? (int)make_key(ones, last) : (int)KEY_NONE;
+                    g2 = min(g2, pays ? 2 * ones + (int)Pout : (1 << 24));
                 }
                 if ((pair || h == 0) && jp < g.Ws) {
                     if constexpr (WINNER) { // the winner itself: census_keys.h
@@ -329,8 +333,8 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                             if (w.disp) w.disp[o] = w.disp_sign * bd + w.disp_offset;
                         }
                     } else {
-                        keys[row + jp] = make_uint2((uint32_t)a0, (uint32_t)a1);
-                        if (gmap) gmap[row + jp] = g_from_keys((uint32_t)a0, (uint32_t)a1, (int)Pout);
+                        (keys + row)[(uint32_t)jp] = make_uint2((uint32_t)a0, (uint32_t)a1);
+                        if (gmap) (gmap + row)[(uint32_t)jp] = (float)g2;
                     }
                 }
             };

@@ -369,6 +369,11 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_sweep_mode = (int)value;
         return SVH_OK;
     }
+    if (strcmp(name, "census_float_overflow") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_float_overflow: 0 (a target word that rounds to 2^32 becomes 0xFFFFFFFF) or 1 (becomes 0)");
+        ctx->census_float_overflow = value;
+        return SVH_OK;
+    }
     if (strcmp(name, "census_sweep_rl") == 0) {
         ctx->census_sweep_rl = value;
         return SVH_OK;

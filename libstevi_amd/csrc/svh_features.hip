@@ -14,11 +14,16 @@ __device__ __forceinline__ float image_or_zero(const float *__restrict__ img, in
     return (i >= 0 && i < H && j >= 0 && j < W) ? img[((int64_t)i * W + j) * C + ch] : 0.0f;
 }
 
-// rule E2: `float t = word; word' = t;` of cross_correlations.h:235-236.
-// v_cvt_f32_u32 rounds to nearest even, v_cvt_u32_f32 saturates 2^32 to 0xFFFFFFFF.
-__device__ __forceinline__ uint32_t round_word_through_float(uint32_t w) {
+// rule E2: `float t = word; word' = t;` of cross_correlations.h:235-236.  uint32 -> float rounds to nearest
+// even; the way back is undefined in C++ when the rounded value is 2^32 (words >= 0xFFFFFF80), and the reference's builds differ:
+//   mode 1 (saturate): 0xFFFFFFFF -- a Release build (-march=native, CMakeLists.txt:41) on a host with AVX-512 (vcvttss2usi), and what
+//                      v_cvt_u32_f32 does here;
+//   mode 2 (zero):     0 -- x86-64 without AVX-512 code generation (-mavx -mavx2 -mfma, CMakeLists.txt:44-58, and every Debug build):
+//                      the conversion goes through vcvttss2si r64 and keeps the low 32 bits of 2^32.
+// svh_context_set_option("census_float_overflow", 0 | 1) picks saturate | zero; 0 in a kernel argument means "no round trip".
+__device__ __forceinline__ uint32_t round_word_through_float(uint32_t w, int mode) {
     float t = (float)w;
-    return t >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)t;
+    return t >= 4294967296.0f ? (mode == 2 ? 0u : 0xFFFFFFFFu) : (uint32_t)t;
 }
 
 __global__ void unfold_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, int pl, int pt, int Ho,
@@ -58,7 +63,7 @@ __global__ void unfold_oriented_kernel(const float *__restrict__ img, int H, int
 }
 
 __global__ void census_image_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, int pl, int pt,
-                                    int Ho, int Wo, int n_out, int n_written, bool round_target,
+                                    int Ho, int Wo, int n_out, int n_written, int round_target,
                                     uint32_t *__restrict__ words) {
     const int h = 2 * h_r + 1, v = 2 * v_r + 1;
     const int64_t npx = (int64_t)Ho * Wo;
@@ -77,7 +82,7 @@ __global__ void census_image_kernel(const float *__restrict__ img, int H, int W,
                     float val = image_or_zero(img, H, W, C, i - pt + k, j - pl + l, ch);
                     d |= (ref > val ? 1u : 0u) << b;
                     if (++b == 32) {
-                        o[word++] = round_target ? round_word_through_float(d) : d;
+                        o[word++] = round_target ? round_word_through_float(d, round_target) : d;
                         d = 0;
                         b = 0;
                     }
@@ -95,7 +100,7 @@ constexpr int CENSUS_TJ = 256;
 
 __global__ void __launch_bounds__(CENSUS_TJ) census_image_tiled_kernel(const float *__restrict__ img, int H, int W, int C, int h_r,
                                                                        int v_r, int pl, int pt, int Ho, int Wo, int n_out,
-                                                                       int n_written, bool round_target,
+                                                                       int n_written, int round_target,
                                                                        uint32_t *__restrict__ words) {
     extern __shared__ float tile[];
     const int h = 2 * h_r + 1, v = 2 * v_r + 1;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_image_tiled_kernel(const flo
                 row_off += tw;
             }
         }
-        o[word] = round_target ? round_word_through_float(d) : d;
+        o[word] = round_target ? round_word_through_float(d, round_target) : d;
     }
     for (int w = n_written; w < n_out; w++) o[w] = 0; // rule E1
 }
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(CENSUS_TJ) census_image_tiled_kernel(const flo
 struct CensusJob { // one image of a launch (blockIdx.z selects): both images of a stereo pair go in one launch
     const float *img;
     int H, W, Ho, Wo;
-    bool round_target;
+    int round_target;
     uint32_t *words;
 };
 
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, Census
     const float *__restrict__ img = job.img;
     uint32_t *__restrict__ words = job.words;
     const int H = job.H, W = job.W, Ho = job.Ho, Wo = job.Wo;
-    const bool round_target = job.round_target;
+    const int round_target = job.round_target;
     constexpr int PXB = 2 * TJN; // two neighbouring pixels per lane
     if ((int)blockIdx.y * ROWS >= Ho || (int)blockIdx.x * PXB >= Wo) return; // the grid covers the larger image
     constexpr int h = 2 * HR + 1, v = 2 * VR + 1, TR = v + ROWS - 1, TW = PXB + h + 1; // row pitch even: float2 reads stay 8-byte aligned
@@ -257,8 +262,8 @@ __global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, Census
         uint32_t *oA = words + ((int64_t)i * Wo + jA) * n_out;
 #pragma unroll
         for (int w = 0; w < NWRITTEN; w++) {
-            oA[w] = round_target ? round_word_through_float(dA[w]) : dA[w];
-            if (hasB) oA[n_out + w] = round_target ? round_word_through_float(dB[w]) : dB[w];
+            oA[w] = round_target ? round_word_through_float(dA[w], round_target) : dA[w];
+            if (hasB) oA[n_out + w] = round_target ? round_word_through_float(dB[w], round_target) : dB[w];
         }
         for (int w = NWRITTEN; w < n_out; w++) { // rule E1
             oA[w] = 0;
@@ -290,7 +295,7 @@ static bool census_grey_dispatch(svh_context *ctx, int h_r, int v_r, const Censu
 }
 
 __global__ void census_features_kernel(const float *__restrict__ feat, int64_t npx, int F, int n_out, int n_written,
-                                       bool round_target, uint32_t *__restrict__ words) {
+                                       int round_target, uint32_t *__restrict__ words) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
         const float *f = feat + p * F;
         uint32_t *o = words + p * n_out;
@@ -298,7 +303,7 @@ __global__ void census_features_kernel(const float *__restrict__ feat, int64_t n
         for (int w = 0; w < n_written; w++) {
             uint32_t d = 0;
             for (int b = 0; b < 32; b++) d |= (ref > f[1 + 32 * w + b] ? 1u : 0u) << b;
-            o[w] = round_target ? round_word_through_float(d) : d;
+            o[w] = round_target ? round_word_through_float(d, round_target) : d;
         }
         for (int w = n_written; w < n_out; w++) o[w] = 0;
     }
@@ -313,13 +318,16 @@ int dev_unfold(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt
     return SVH_OK;
 }
 
+// kernel argument for rule E2: 0 none, 1 saturate, 2 zero (round_word_through_float)
+static inline int round_mode(const svh_context *ctx, bool round_through_float) { return round_through_float ? (ctx->census_float_overflow ? 2 : 1) : 0; }
+
 int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int pl, int pt, int Ho, int Wo, int n_out,
                           bool round_through_float, uint32_t *words) {
     int64_t npx = (int64_t)Ho * Wo;
     if (npx == 0 || n_out == 0) return SVH_OK;
     int F = (2 * h_r + 1) * (2 * v_r + 1) * img.C;
     if (img.C == 1) {
-        CensusJob job{img.data, img.H, img.W, Ho, Wo, round_through_float, words};
+        CensusJob job{img.data, img.H, img.W, Ho, Wo, round_mode(ctx, round_through_float), words};
         if (census_grey_dispatch(ctx, h_r, v_r, job, nullptr, pl, pt, n_out)) {
             SVH_CHECK_LAUNCH(ctx);
             return SVH_OK;
@@ -329,12 +337,12 @@ int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int
     if (tile_bytes <= 60 * 1024 && census_words_written(F) > 0) {
         dim3 grid(ceil_div(Wo, CENSUS_TJ), Ho);
         SVH_LAUNCH(ctx, "census_transform", census_image_tiled_kernel, grid, CENSUS_TJ, tile_bytes, img.data, img.H, img.W, img.C, h_r, v_r,
-                   pl, pt, Ho, Wo, n_out, census_words_written(F), round_through_float, words);
+                   pl, pt, Ho, Wo, n_out, census_words_written(F), round_mode(ctx, round_through_float), words);
         SVH_CHECK_LAUNCH(ctx);
         return SVH_OK;
     }
     SVH_LAUNCH(ctx, "census_transform", census_image_kernel, grid_for(npx, 256, 16384), 256, 0, img.data, img.H, img.W, img.C, h_r,
-               v_r, pl, pt, Ho, Wo, n_out, census_words_written(F), round_through_float, words);
+               v_r, pl, pt, Ho, Wo, n_out, census_words_written(F), round_mode(ctx, round_through_float), words);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -344,7 +352,7 @@ int dev_census_from_image(svh_context *ctx, ImageDesc img, int h_r, int v_r, int
 int dev_census_pair_compact(svh_context *ctx, ImageDesc src, ImageDesc tgt, int h_r, int v_r, int nWw, uint32_t *sw, uint32_t *tw) {
     if (nWw == 0) return SVH_OK;
     if (src.C == 1 && tgt.C == 1) {
-        CensusJob a{src.data, src.H, src.W, src.H, src.W, false, sw}, b{tgt.data, tgt.H, tgt.W, tgt.H, tgt.W, true, tw};
+        CensusJob a{src.data, src.H, src.W, src.H, src.W, 0, sw}, b{tgt.data, tgt.H, tgt.W, tgt.H, tgt.W, round_mode(ctx, true), tw};
         if (census_grey_dispatch(ctx, h_r, v_r, a, &b, h_r, v_r, nWw)) {
             SVH_CHECK_LAUNCH(ctx);
             return SVH_OK;
@@ -359,7 +367,7 @@ int dev_census_from_features(svh_context *ctx, const float *feat, int H, int W, 
     int64_t npx = (int64_t)H * W;
     if (npx == 0 || n_out == 0) return SVH_OK;
     SVH_LAUNCH(ctx, "census_features", census_features_kernel, grid_for(npx, 256, 16384), 256, 0, feat, npx, F, n_out,
-               census_words_written(F), round_through_float, words);
+               census_words_written(F), round_mode(ctx, round_through_float), words);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

@@ -123,6 +123,15 @@ def census_transform(img, h_r, v_r, pad=None):
     return census_features(unfold(img, h_r, v_r, pad))
 
 
+def set_float_overflow(zero):
+    """Rule E2 when a target word rounds to 2^32: False / 0 = saturate to 0xFFFFFFFF (default), True / 1 = 0 (x86-64 without AVX-512)."""
+    lib().so_set_float_overflow(int(bool(zero)))
+
+
+def get_float_overflow():
+    return int(lib().so_get_float_overflow())
+
+
 def round_word_through_float(w):
     return int(lib().so_round_word_through_float(int(w) & 0xFFFFFFFF))
 

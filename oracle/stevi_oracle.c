@@ -156,11 +156,20 @@ int so_census_transform(const float *img, int H, int W, int C, int h_r, int v_r,
 }
 
 /* Rule E2: `float t = word; word' = t;` of correlation/cross_correlations.h:235-236.            *
- * uint32 -> float is round-to-nearest-even; float -> uint32 of 2^32 is UB in C++ and is defined  *
- * here as saturation (what v_cvt_u32_f32 and vcvttss2usi do).                                    */
+ * uint32 -> float is round-to-nearest-even; float -> uint32 of 2^32 (words >= 0xFFFFFF80) is UB  *
+ * in C++ and the reference's own builds differ (checked by running both in the container,        *
+ * tests/test_oracle_semantics.py::test_e2_overflow_matches_this_hosts_conversions):              *
+ *   mode 0, saturate -> 0xFFFFFFFF: vcvttss2usi, i.e. the Release build (-march=native,          *
+ *           CMakeLists.txt:41) on a host with AVX-512;                                           *
+ *   mode 1, zero -> 0: vcvttss2si r64 and the low 32 bits, i.e. x86-64 code generation without   *
+ *           AVX-512 (-mavx -mavx2 -mfma, CMakeLists.txt:44-58; every Debug build).               *
+ * The mode is process-wide test state (so_set_float_overflow), default 0.                        */
+static int g_float_overflow_zero = 0;
+void so_set_float_overflow(int zero) { g_float_overflow_zero = zero != 0; }
+int so_get_float_overflow(void) { return g_float_overflow_zero; }
 uint32_t so_round_word_through_float(uint32_t w) {
     float t = (float)w;
-    if (t >= 4294967296.0f) return 0xFFFFFFFFu;
+    if (t >= 4294967296.0f) return g_float_overflow_zero ? 0u : 0xFFFFFFFFu;
     return (uint32_t)t;
 }
 

@@ -67,6 +67,56 @@ def test_round_word_through_float(w, expected):
     assert so.round_word_through_float(w) == expected
 
 
+E2_WORDS = [0xFFFFFFFF, 0xFFFFFF80, 0xFFFFFF7F, 0xFFFFFF00, 0xFFFFFFC1, 0x80000000, 0x01000001, 0x7FFFFFFF, 5]
+
+
+def test_round_word_through_float_zero_mode():
+    """Rule E2, second behaviour: a word that rounds to 2^32 becomes 0; every other word is unchanged by the switch."""
+    try:
+        so.set_float_overflow(True)
+        assert so.get_float_overflow() == 1
+        assert [so.round_word_through_float(w) for w in (0xFFFFFF80, 0xFFFFFFC1, 0xFFFFFFFF)] == [0, 0, 0]
+        assert so.round_word_through_float(0xFFFFFF7F) == 0xFFFFFF00 and so.round_word_through_float(0x01000003) == 0x01000004
+    finally:
+        so.set_float_overflow(False)
+    assert so.round_word_through_float(0xFFFFFFFF) == 0xFFFFFFFF
+
+
+def _host_round_trip(flags, tmp_path):
+    """`float t = word; uint32_t back = t;` (cross_correlations.h:235-236) compiled by this host's gcc with `flags` and executed."""
+    import subprocess
+    src = tmp_path / "e2.c"
+    src.write_text("#include <stdio.h>\n#include <stdint.h>\n#include <stdlib.h>\nint main(int n, char **a) { for (int i = 1; i < n; i++) {"
+                   " volatile uint32_t w = (uint32_t)strtoul(a[i], 0, 16); volatile float t = (float)w; volatile uint32_t b = (uint32_t)t;"
+                   " printf(\"%08x\\n\", b); } return 0; }\n")
+    exe = tmp_path / ("e2_" + str(abs(hash(flags))))
+    subprocess.check_call(["gcc", "-O3"] + flags.split() + [str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)] + [f"{w:08x}" for w in E2_WORDS], text=True)
+    return [int(x, 16) for x in out.split()]
+
+
+def test_e2_overflow_matches_this_hosts_conversions(tmp_path):
+    """Pins both modes of rule E2 to what x86-64 code generation does with the reference's statement, by running it here: with the
+    flags the reference adds on x86 (-mavx -mavx2 -mfma, CMakeLists.txt:44-58) the conversion is vcvttss2si r64 + truncation, 2^32 -> 0
+    (mode 1); with AVX-512 code generation (what -march=native, CMakeLists.txt:41, gives on such a host) it is vcvttss2usi, 2^32 ->
+    0xFFFFFFFF (mode 0, the default).  Every other word agrees in both."""
+    import platform
+    import shutil
+    if platform.machine() != "x86_64" or shutil.which("gcc") is None:
+        pytest.skip("needs gcc on x86-64")
+    got = _host_round_trip("-mavx -mavx2 -mfma", tmp_path)
+    try:
+        so.set_float_overflow(True)
+        assert got == [so.round_word_through_float(w) for w in E2_WORDS]
+    finally:
+        so.set_float_overflow(False)
+    with open("/proc/cpuinfo") as f:
+        if "avx512f" not in f.read():
+            return
+    got = _host_round_trip("-mavx512f", tmp_path)
+    assert got == [so.round_word_through_float(w) for w in E2_WORDS]
+
+
 def test_hamming_volume_by_hand(rng):
     """aggregateCost<CENSUS> (cross_correlations.h:194-249) with hammingDistance (matching_costs.h:236-263)."""
     H, W, D = 5, 13, 6

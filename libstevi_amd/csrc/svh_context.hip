@@ -378,6 +378,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_sweep_rl = value;
         return SVH_OK;
     }
+    if (strcmp(name, "cost_volume_colsum") == 0) {
+        ctx->cost_volume_colsum = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "literal_cost_volumes") == 0) {
         ctx->literal_cost_volumes = value != 0;
         return SVH_OK;

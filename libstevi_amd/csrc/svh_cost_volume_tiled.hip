@@ -1,8 +1,15 @@
-// LDS-tiled, register-blocked cost volumes for grey images (CC / NCC / SSD / SAD and their zero-mean variants).
+// LDS-tiled cost volumes for grey images (CC / NCC / SSD / SAD and their zero-mean variants).
 //
-// A block owns 64 consecutive pixels of one row and every disparity.  The (2v_r+1)-row source and target tiles are staged in
+// Two kernels.  cost_volume_colsum_kernel (round 3; everything but ZSAD) uses what the windows of neighbouring pixels share: the
+// per-column sums  V_d(x) = sum_k f(S(i + k, x), T(i + k, x + d))  over the 2 v_r + 1 window rows belong to the 2 h_r + 1 windows that
+// contain column x, so a voxel costs 2 v_r + 1 multiply-adds (its column) plus the horizontal sum of 2 h_r + 1 column sums, taken
+// across the lanes with DPP shifts, instead of (2 h_r + 1)(2 v_r + 1) multiply-adds: 11 + ~6 vector instructions per voxel instead of
+// 121 for 11 x 11 windows -- which leaves the 4 bytes the voxel is written with as the bound.  cost_volume_pxlane_kernel (round 1)
+// evaluates every window on its own; ZSAD keeps it, because |(s - t) - (mean_s - mean_t)| depends on the window as a whole.
+// No MFMA: the column sums are band-diagonal outer products of two image rows -- 2 v_r + 1 of them per voxel, not a contraction.
+//
+// pxlane: a block owns 64 consecutive pixels of one row and every disparity.  The (2v_r+1)-row source and target tiles are staged in
 // LDS once; a lane is a pixel and keeps a block of 16 or 32 consecutive disparities in registers (see the kernel comment).
-// No MFMA: there is no shared operand between the per-pixel dot products to contract over.
 //
 // Arithmetic relative to the reference (cross_correlations.h:416-594, matching_costs.h:59-156): the products /
 // differences are accumulated per pixel in the reference's channel order (rows outer, columns inner); the per-element
@@ -11,7 +18,9 @@
 //     ZCC   sum (s-ms)(t-mt)            = sum (s-c)(t-c) - F (ms-c)(mt-c)        (c: a block constant, keeps magnitudes small)
 //     ZSSD  sum ((s-ms)-(t-mt))^2       = sum (s-t)^2 - F (ms-mt)^2
 //     ZSAD  sum |(s-ms)-(t-mt)|         = sum |(s-t) - (ms-mt)|
-// which changes results by rounding only (a few 1e-7 relative; the north-star tolerance for float costs is 1e-4).
+// which changes results by rounding only (a few 1e-7 relative; the north-star tolerance for float costs is 1e-4).  The column-sum
+// kernel also changes the ORDER of the window's terms (columns outer, rows inner; the reference: rows outer, cross_correlations.h
+// via unfold.h:283): plain sums of the same terms, no running subtraction, so again rounding only.
 // Means, norms and the all-zero-target cost (target column outside the image, cross_correlations.h:235) come from a
 // per-pixel statistics kernel that follows the reference literally.
 #include "svh_compare.h"
@@ -141,6 +150,268 @@ __global__ void __launch_bounds__(256) cost_volume_pxlane_kernel(const float *__
     }
 }
 
+// ---- column sums + horizontal DPP sums --------------------------------------------------------------------------------------
+// A wave owns CS_COLS = 128 consecutive image columns of one row (lane u: columns 2 u and 2 u + 1 of the tile) and walks blocks of
+// CS_DB consecutive disparities; the four waves of a block share the staged rows and take every fourth disparity block.  Per window
+// row a lane reads its two source samples and the CS_DB + 1 target samples its two columns meet, and adds one term to each of its
+// 2 CS_DB column sums.  Then the window sums: with P_n(u) = V(u) + P_{n-1}(u - 1) (one v_add_f32 with a wave_shr:1 DPP operand per
+// step: P_n(u) = V(u) + ... + V(u - n)) on the even and the odd columns of the lanes,
+//     window ending at column 2 u     = Peven_{h_r}(u) + Podd_{h_r - 1}(u - 1),
+//     window ending at column 2 u + 1 = Podd_{h_r}(u)  + Peven_{h_r - 1}(u):   2 h_r + 2 additions for two voxels.
+// Lanes u >= h_r hold complete windows: a tile yields 128 - 2 h_r output pixels (centre = window end - h_r).
+constexpr int CS_COLS = 128, CS_DB = 16;
+constexpr int CS_XP = 20; // floats per pixel in the transposition area: 16 costs + 4 of padding (16-byte pieces of 16 lanes then fall on different banks)
+
+__device__ __forceinline__ float lane_below(float v) { // value of lane - 1 (wave_shr:1; lane 0 reads 0: its windows are incomplete anyway)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+
+template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
+                                                                 int D, int disp_lower, const float *__restrict__ mean_s,
+                                                                 const float *__restrict__ mean_t, const float *__restrict__ norm_s,
+                                                                 const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv) {
+    constexpr int DB = CS_DB, OUT = CS_COLS - 2 * HR;
+    extern __shared__ float lds[];
+    const int v = 2 * v_r + 1;
+    const int n_blocks = (D + DB - 1) / DB;
+    const int tw = CS_COLS + n_blocks * DB; // target tile columns (even: 8-byte aligned pairs)
+    float *stile = lds, *ttile = lds + v * CS_COLS, *tmean = ttile + v * tw, *tinv = tmean + (ZM ? tw : 0); // (tmean / tinv: ZM / NRM only)
+    float *xpose = tinv + (NRM ? tw : 0) + (threadIdx.x >> 6) * (64 * CS_XP); // this wave's area for turning 64 pixels x DB costs around
+    const int i = blockIdx.y, p0 = blockIdx.x * OUT, xb = p0 - HR; // first output pixel, first column of the tile
+    const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(p0, Ws - 1)] : 0.0f; // keeps the zero-mean dot products small
+    const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
+    const bool trow_in = it >= 0 && it < H;
+    // tile index z of the target tile <-> image column: the index grows with the disparity in both directions
+    auto tcol = [&](int z) { return SIGN > 0 ? xb + disp_lower + z : xb + (CS_COLS - 1) - disp_lower - z; };
+    // staging: a thread owns tile columns (source columns first, then target indices) and walks the window rows four at a time, all
+    // eight loads issued before the first LDS store (one load, one wait, one store per sample made the staging a chain of
+    // memory latencies as long as the arithmetic of the block)
+    for (int xc = threadIdx.x; xc < CS_COLS + tw; xc += blockDim.x) {
+        const bool is_src = xc < CS_COLS;
+        const int col = is_src ? xb + xc : tcol(xc - CS_COLS);
+        const float *img = is_src ? src : tgt;
+        const int Wi = is_src ? Ws : Wt, r0 = (is_src ? i : it) - v_r;
+        float *dst = is_src ? stile + xc : ttile + (xc - CS_COLS);
+        const int pitch = is_src ? CS_COLS : tw;
+        const bool col_in = col >= 0 && col < Wi;
+        for (int k0 = 0; k0 < v; k0 += 4) {
+            float val[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int rr = r0 + k0 + kk;
+                val[kk] = (k0 + kk < v && col_in && rr >= 0 && rr < H) ? img[(int64_t)rr * Wi + col] : 0.0f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                if (k0 + kk < v) dst[(k0 + kk) * pitch] = val[kk] - c0;
+        }
+    }
+    if (ZM || NRM) { // per target pixel: mean and 1 / norm at the window CENTRE column tcol(z)
+        for (int z = threadIdx.x; z < tw; z += blockDim.x) {
+            const int jt = tcol(z);
+            const bool in = trow_in && jt >= 0 && jt < Wt;
+            if (ZM) tmean[z] = in ? mean_t[(int64_t)it * Wt + jt] : 0.0f;
+            if (NRM) tinv[z] = in ? 1.0f / norm_t[(int64_t)it * Wt + jt] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int u = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (scalar: the disparity block is wave uniform)
+    const float Ff = (float)((2 * HR + 1) * v);
+    // this lane's two output pixels (window ends at columns 2 u and 2 u + 1, centres HR to the left) and their per-pixel statistics
+    const int pe[2] = {p0 + 2 * (u - HR), p0 + 2 * (u - HR) + 1};
+    bool live[2];
+    float ms[2], inv_ns[2], zc[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        live[e] = u >= HR && pe[e] < Ws;
+        const int64_t px = (int64_t)i * Ws + min(max(pe[e], 0), Ws - 1);
+        ms[e] = ZM ? mean_s[px] : 0.0f;
+        inv_ns[e] = NRM ? 1.0f / norm_s[px] : 1.0f;
+        zc[e] = zcost[px];
+    }
+    for (int db = wave; db < n_blocks; db += WAVES) {
+        const int d0 = db * DB;
+        // Column sums as register PAIRS (v_pk_fma_f32 takes aligned pairs): the row's target samples t[0 .. DB + 1] arrive as the
+        // pairs (t[2 m], t[2 m + 1]).  The column that meets t[q] pairs its disparities (2 m, 2 m + 1); the one that meets t[q + 1]
+        // pairs (2 m + 1, 2 m + 2) -- the same register pairs, one to the right -- and keeps disparities 0 and DB - 1 as singles.
+        using v2f = float __attribute__((ext_vector_type(2)));
+        v2f A[DB / 2], Bp[DB / 2 - 1];
+        float b_first = 0.0f, b_last = 0.0f;
+#pragma unroll
+        for (int m = 0; m < DB / 2; m++) A[m] = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int m = 0; m < DB / 2 - 1; m++) Bp[m] = (v2f){0.0f, 0.0f};
+        // column 2 u + e meets target index z = (2 u + e) + d (forward) or (127 - 2 u - e) + d (mirrored)
+        const int zb = (SIGN > 0 ? 2 * u : CS_COLS - 2 - 2 * u) + d0;
+        struct Row {
+            v2f s, t[DB / 2 + 1];
+        };
+        auto load_row = [&](Row &rw, int k) {
+            const float2 sv = *reinterpret_cast<const float2 *>(stile + k * CS_COLS + 2 * u);
+            rw.s = (v2f){sv.x, sv.y};
+            const float2 *trow = reinterpret_cast<const float2 *>(ttile + k * tw + zb);
+#pragma unroll
+            for (int m = 0; m < DB / 2 + 1; m++) {
+                const float2 tt = trow[m];
+                rw.t[m] = (v2f){tt.x, tt.y};
+            }
+        };
+        auto term2 = [&](v2f &acc, float sc, v2f t) {
+            const v2f s2 = (v2f){sc, sc};
+            if (CMP == T_DOT) {
+                acc = __builtin_elementwise_fma(s2, t, acc);
+            } else if (CMP == T_SSD) {
+                const v2f df = s2 - t;
+                acc = __builtin_elementwise_fma(df, df, acc);
+            } else {
+                acc += __builtin_elementwise_abs(s2 - t);
+            }
+        };
+        auto term1 = [&](float &acc, float sc, float t) {
+            if (CMP == T_DOT) acc = fmaf(sc, t, acc);
+            else if (CMP == T_SSD) acc = fmaf(sc - t, sc - t, acc);
+            else acc += fabsf(sc - t);
+        };
+        auto add_row = [&](const Row &rw) {
+            const float sa = SIGN > 0 ? rw.s.x : rw.s.y, sb = SIGN > 0 ? rw.s.y : rw.s.x; // the column that meets t[q], the one that meets t[q + 1]
+#pragma unroll
+            for (int m = 0; m < DB / 2; m++) term2(A[m], sa, rw.t[m]);
+#pragma unroll
+            for (int m = 0; m < DB / 2 - 1; m++) term2(Bp[m], sb, rw.t[m + 1]);
+            term1(b_first, sb, rw.t[0].y);
+            term1(b_last, sb, rw.t[DB / 2].x);
+        };
+        // two rows in flight: the LDS reads of the next row are issued before the arithmetic of the current one (the scheduling
+        // barriers keep the compiler from sinking each read to its first use, which made every read a round trip of its own)
+        Row ra, rb;
+        load_row(ra, 0);
+        int k = 0;
+        for (; k + 1 < v; k += 2) {
+            load_row(rb, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            add_row(ra);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 2 < v) load_row(ra, k + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            add_row(rb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k < v) add_row(ra);
+        float V0[DB], V1[DB]; // of the even, of the odd column
+#pragma unroll
+        for (int q = 0; q < DB; q++) {
+            const float va = A[q / 2][q & 1];
+            const float vb = q == 0 ? b_first : (q == DB - 1 ? b_last : Bp[(q - 1) / 2][(q - 1) & 1]);
+            V0[q] = SIGN > 0 ? va : vb;
+            V1[q] = SIGN > 0 ? vb : va;
+        }
+        // window sums: r[e][q] of the window that ENDS at column 2 u + e
+        float r[2][DB];
+#pragma unroll
+        for (int q = 0; q < DB; q++) {
+            float P0 = V0[q], P1 = V1[q], P0m = P0, P1m = P1;
+#pragma unroll
+            for (int l = 1; l <= HR; l++) {
+                if (l == HR) {
+                    P0m = P0;
+                    P1m = P1;
+                }
+                P0 = V0[q] + lane_below(P0);
+                P1 = V1[q] + lane_below(P1);
+            }
+            r[0][q] = P0 + lane_below(P1m);
+            r[1][q] = P1 + P0m;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            // (every lane goes through the exchange below; lanes without a pixel carry values nobody stores)
+            // centre column of the window in the tile: 2 u + e - HR; its target statistics sit at the matching tile index
+            const int zc0 = (SIGN > 0 ? 2 * u + e - HR : CS_COLS - 1 - (2 * u + e - HR)) + d0;
+            // branch-free: the corrections read staged statistics (zeros outside the image), the select replaces what does not exist
+            const int jt0 = pe[e] + SIGN * (disp_lower + d0); // target column of the block's first disparity
+            const bool whole = d0 + DB <= D;                    // (wave uniform)
+            float o_[DB];
+#pragma unroll
+            for (int q = 0; q < DB; q++) {
+                float x = r[e][q];
+                if (ZM && CMP == T_DOT) x -= Ff * (ms[e] - c0) * (tmean[zc0 + q] - c0);
+                if (ZM && CMP == T_SSD) {
+                    const float dm = ms[e] - tmean[zc0 + q];
+                    x -= Ff * dm * dm;
+                }
+                if (NRM) x *= inv_ns[e] * tinv[zc0 + q];
+                const bool there = trow_in && (unsigned)(jt0 + SIGN * q) < (unsigned)Wt && (whole || d0 + q < D);
+                o_[q] = there ? x : zc[e]; // no target pixel: the cost against the all-zero vector (cross_correlations.h:235)
+            }
+            if (whole && ((px_stride | out_off) & 3) == 0) { // (wave uniform)
+                // A lane holds 64 bytes of its pixel's run; stored as they are, every 16-byte piece of a wave's store instruction would go to
+                // a different pixel (1 KB apart): requests of 16 bytes, a quarter of what the memory side takes per request (measured: the
+                // kernel then runs at 2.4 TB/s whatever the window).  Through LDS instead: lanes 4 a .. 4 a + 3 store the four pieces of
+                // pixel 16 j + a, 64 contiguous bytes.
+#pragma unroll
+                for (int q = 0; q < DB; q += 4) *reinterpret_cast<float4 *>(xpose + u * CS_XP + q) = make_float4(o_[q], o_[q + 1], o_[q + 2], o_[q + 3]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (this wave's own writes; nobody else touches the area)
+                const int a = u >> 2, c = u & 3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int uu = 16 * j + a;                                 // the lane whose pixel this is
+                    const int pp = p0 + 2 * (uu - HR) + e;                     // that pixel
+                    const float4 piece = *reinterpret_cast<const float4 *>(xpose + uu * CS_XP + 4 * c);
+                    if (uu >= HR && pp < Ws) *reinterpret_cast<float4 *>(cv + ((int64_t)i * Ws + pp) * px_stride + out_off + d0 + 4 * c) = piece;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (read before the next round overwrites it)
+            } else if (live[e]) {
+                float *o = cv + ((int64_t)i * Ws + pe[e]) * px_stride + out_off + d0;
+#pragma unroll
+                for (int q = 0; q < DB; q++)
+                    if (d0 + q < D) o[q] = o_[q];
+            }
+        }
+    }
+}
+
+// waves per block: eight share a staged tile when there are disparity blocks for all of them (two blocks of eight waves fit a CU's LDS
+// where three of four would: 16 instead of 12 waves per CU), four otherwise
+inline int colsum_waves(int D) { return (D + CS_DB - 1) / CS_DB >= 16 ? 8 : 4; }
+inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm) {
+    const int v = 2 * v_r + 1, nb = (D + CS_DB - 1) / CS_DB, tw = CS_COLS + nb * CS_DB;
+    return (size_t)(v * (CS_COLS + tw) + (zm ? tw : 0) + (nrm ? tw : 0) + colsum_waves(D) * 64 * CS_XP) * sizeof(float);
+}
+
+template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
+                                                                   const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
+    const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM);
+    dim3 grid(ceil_div(a.Ws, CS_COLS - 2 * HR), a.H);
+#define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
+    do {                                                                                                                                           \
+        static int big_lds[64] = {}; /* (per instantiation and device) more than the default 64 KiB of dynamic LDS */                              \
+        if (shmem > 64 * 1024 && !__atomic_load_n(&big_lds[ctx->device & 63], __ATOMIC_ACQUIRE)) {                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV>),                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                     \
+            __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
+        }                                                                                                                                          \
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV>), grid, 64 * WV, shmem, src, tgt, a.H, a.Ws,     \
+                   a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);                                 \
+    } while (0)
+    if (colsum_waves(a.D) == 8) {
+        if (sign > 0) SVH_CS_LAUNCH(1, 8);
+        else SVH_CS_LAUNCH(-1, 8);
+    } else {
+        if (sign > 0) SVH_CS_LAUNCH(1, 4);
+        else SVH_CS_LAUNCH(-1, 4);
+    }
+#undef SVH_CS_LAUNCH
+}
+template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
+                                                       const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
+    if constexpr (CMP == T_DOT) { // (only the products are ever normalised: NCC, ZNCC)
+        if (ns) return launch_colsum_n<CMP, ZM, true, HR>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv);
+    }
+    launch_colsum_n<CMP, ZM, false, HR>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv);
+}
+
 template <int CMP, bool ZM, int HR, int DB> void launch_pxlane_db(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                                   const float *ms, const float *mt, const float *ns, const float *nt, const float *zc,
                                                                   float *cv, size_t shmem) {
@@ -173,6 +444,19 @@ template <int CMP, bool ZM, int HR> void launch_pxlane(svh_context *ctx, const C
 template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                              const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv,
                                              size_t shmem) {
+    if constexpr (!(ZM && CMP == T_SAD)) { // separable terms: column sums shared by the windows that contain the column
+        if (ctx->cost_volume_colsum && colsum_shmem(v_r, a.D, ZM, ns != nullptr) <= 78 * 1024) {
+            switch (h_r) {
+            case 1: launch_colsum<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
+            case 2: launch_colsum<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
+            case 3: launch_colsum<CMP, ZM, 3>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
+            case 4: launch_colsum<CMP, ZM, 4>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
+            case 5: launch_colsum<CMP, ZM, 5>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
+            default: return false;
+            }
+        }
+    }
+    if (shmem > 60 * 1024) return false;
     switch (h_r) {
     case 1: launch_pxlane<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
     case 2: launch_pxlane<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
@@ -190,9 +474,9 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
     if (src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func)) return SVH_ERR_UNSUPPORTED;
     const size_t shmem = pxlane_shmem(h_r, v_r, a.D);
-    if (shmem > 60 * 1024) return SVH_ERR_UNSUPPORTED;
-    if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
     const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
+    if (shmem > 60 * 1024 && (a.func == SVH_ZSAD || !ctx->cost_volume_colsum || colsum_shmem(v_r, a.D, zm, nrm) > 78 * 1024)) return SVH_ERR_UNSUPPORTED;
+    if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
     const int cmp = (a.func == SVH_SSD || a.func == SVH_ZSSD) ? T_SSD : (a.func == SVH_SAD || a.func == SVH_ZSAD) ? T_SAD : T_DOT;
     const size_t ns_px = (size_t)a.H * a.Ws, nt_px = (size_t)a.H * a.Wt;
     WindowStatsCache local;

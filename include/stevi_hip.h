@@ -101,6 +101,14 @@ const char *svh_last_error(const svh_context *ctx);
  * (xor + popcount), 2 / 3 = the matrix-core kernel with int8 / FP4 operands (Hamming distance as a dot product; at most 4 census
  * words, disp_count a multiple of 32 up to 992; int8: up to 480 and RightToLeft only -- anything else runs the vector-ALU kernel);
  * automatic = 3 where it applies.  Same keys bit for bit.
+ * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
+ * (64 / 128 / 256 / 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
+ * "census_float_overflow" (default 0): what becomes of a target census word that rounds to 2^32 on its way through `float`
+ * (cross_correlations.h:235-236; words >= 0xFFFFFF80; undefined in C++): 0 = 0xFFFFFFFF, what the reference's Release build gives on
+ * a host with AVX-512 and what the GPU's own conversion does; 1 = 0, what x86-64 code generation without AVX-512 gives (the reference's
+ * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
+ * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
+ * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
  * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
  * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one.
  * "census_winner_shortcut" (default 1): in the integer-exact regime of the census + SGM Cost-branch pipeline the winning disparity of a
@@ -124,6 +132,11 @@ int svh_device_available(void);
  * no counterpart (its arrays live in host memory: Multidim::Array). */
 int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr);
 int svh_device_free(svh_context *ctx, void *ptr);
+/* The HIP device a context is bound to, and a release that needs no context: memory from svh_device_alloc may outlive the context (and
+ * the thread) that allocated it -- a worker thread hands its result array to another thread and exits -- so the owner of such an
+ * array frees it by device number.  Waits for the device to go idle first (nothing still running may use the memory). */
+int svh_context_get_device(const svh_context *ctx);
+int svh_device_free_detached(int device, void *ptr);
 int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes);
 int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes);
 

@@ -21,7 +21,7 @@ F32, I32, U32, U8, U64 = 0, 1, 2, 3, 4
 # every symbol include/stevi_hip.h declares
 EXPORTS = [
     "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_set_option", "svh_context_synchronize", "svh_context_trim",
-    "svh_status_string", "svh_last_error", "svh_device_available", "svh_device_alloc", "svh_device_free", "svh_device_upload", "svh_device_download",
+    "svh_status_string", "svh_last_error", "svh_device_available", "svh_device_alloc", "svh_device_free", "svh_device_free_detached", "svh_context_get_device", "svh_device_upload", "svh_device_download",
     "svh_profile_enable", "svh_profile_filter", "svh_profile_sampling", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_oriented", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume", "svh_sgm_cost_volume_textbook",

@@ -430,6 +430,16 @@ int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr) {
     return SVH_OK;
 }
 
+int svh_context_get_device(const svh_context *ctx) { return ctx ? ctx->device : -1; }
+
+int svh_device_free_detached(int device, void *ptr) {
+    if (!ptr) return SVH_OK;
+    if (device < 0) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(device);
+    if (hipDeviceSynchronize() != hipSuccess) return SVH_ERR_HIP; // any stream of any context may still be using it
+    return hipFree(ptr) == hipSuccess ? SVH_OK : SVH_ERR_HIP;
+}
+
 int svh_device_free(svh_context *ctx, void *ptr) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     if (!ptr) return SVH_OK;

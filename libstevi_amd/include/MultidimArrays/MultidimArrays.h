@@ -3,15 +3,28 @@
 // LibStevi takes its array type from the un-vendored dependency MultidimArrays (CMakeLists.txt:62-68 of the
 // reference).  When that library is available, put ITS include directory in front of this one and this file is
 // never seen.  This header is an independent implementation of the part of the interface the hot path and its
-// callers use (shape / strides / element access / views over foreign memory), written against the call sites in
-// the reference (e.g. cross_correlations.h:220, unfold.h:272, correlation_base.h:434-458), so that the shim
-// headers in ../correlation compile stand-alone.
+// callers use, written against the call sites in the reference (cited at each member), so that the shim headers in
+// ../correlation compile stand-alone:
+//
+//   shape / strides / element access            cross_correlations.h:220, unfold.h:272, correlation_base.h:434-458
+//   views over foreign memory, takePointer()    benchmarkStereoMatchingModels.cpp:202-204, io/image_io.cpp:92
+//   subView(DimIndex / DimSlice ...)            cross_correlations.h:227-228, hierarchical.h:160, testCorrelationFilters.cpp:303-307
+//   sliceView(dim, index), indexDimView(...)    image_based_refinement.h:399, on_demand_cost_volume.h:164-172
+//   buildReshapedView<N>(shape, strides)        cross_correlations.h:659, :677
+//   cast<U>()                                   cross_correlations.h:713
+//   IndexBlock::setZero / moveToNextIndex       io/image_io.h:56-67
+//   IndexConverter<N>                           on_demand_cost_volume.h:208-213, :497-502
+//   Multidim::ConstView / NonConstView          matching_costs.h:59, cross_correlations.h:654-658
+//
+// The marshalling code of the shims (stevi_hip_bridge.h) only relies on what those call sites show: shape(), strides(), the address
+// of the first element via atUnchecked(0, ...) (io/image_io.h:96), flatLenght(), empty().
 #pragma once
 
 #include <array>
 #include <cstddef>
 #include <cstdlib>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <type_traits>
 
@@ -21,11 +34,49 @@ enum class AccessCheck { Check, Nocheck };
 enum ArrayDataAccessConstness { NonConstView, ConstView };
 using array_size_t = int;
 
+// an index / shape / stride tuple: a std::array with the two iteration helpers the reference's IO code uses (io/image_io.h:56-67)
+template <int nDim> struct IndexTuple : public std::array<array_size_t, nDim> {
+    using Base = std::array<array_size_t, nDim>;
+    IndexTuple() : Base() {}
+    IndexTuple(Base const &b) : Base(b) {}
+    template <typename... Ds, typename = std::enable_if_t<sizeof...(Ds) == nDim && (std::is_convertible_v<Ds, array_size_t> && ...)>>
+    IndexTuple(Ds... v) : Base{{static_cast<array_size_t>(v)...}} {}
+    void setZero() { this->fill(0); }
+    // next index in an order that visits every index of `shape` exactly once starting from zero (the first index varies fastest);
+    // wraps to zero after the last one
+    void moveToNextIndex(Base const &shape) {
+        for (int k = 0; k < nDim; k++) {
+            if (++(*this)[k] < shape[k]) return;
+            (*this)[k] = 0;
+        }
+    }
+};
+
+struct DimIndex { // one index of a dimension: the dimension disappears from the view
+    array_size_t index;
+    explicit DimIndex(array_size_t i) : index(i) {}
+};
+struct DimSlice { // [start, end) of a dimension (the whole of it by default): the dimension stays (testCorrelationFilters.cpp:303: DimSlice(0, 2 v_radius + 1))
+    array_size_t start, end, step;
+    bool whole;
+    DimSlice() : start(0), end(0), step(1), whole(true) {}
+    DimSlice(array_size_t s, array_size_t e, array_size_t st = 1) : start(s), end(e), step(st), whole(false) {}
+};
+
+namespace detail {
+template <class... A> struct count_slices;
+template <> struct count_slices<> { static constexpr int value = 0; };
+template <class A0, class... A> struct count_slices<A0, A...> {
+    static constexpr int value = (std::is_same_v<std::decay_t<A0>, DimSlice> ? 1 : 0) + count_slices<A...>::value;
+};
+} // namespace detail
+
 template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstView> class Array {
   public:
-    using ShapeBlock = std::array<array_size_t, nDim>;
-    using IndexBlock = std::array<array_size_t, nDim>;
+    using ShapeBlock = IndexTuple<nDim>;
+    using IndexBlock = IndexTuple<nDim>;
     using ScalarT = T;
+    template <class U, int M, ArrayDataAccessConstness C> friend class Array;
 
     Array() : _data(nullptr) {
         _shape.fill(0);
@@ -33,7 +84,7 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
     }
 
     template <typename... Ds, typename = std::enable_if_t<sizeof...(Ds) == nDim && (std::is_integral_v<Ds> && ...)>>
-    explicit Array(Ds... dims) : Array(ShapeBlock{static_cast<array_size_t>(dims)...}) {}
+    explicit Array(Ds... dims) : Array(ShapeBlock(static_cast<array_size_t>(dims)...)) {}
 
     // dense, last index fastest
     explicit Array(ShapeBlock const &shape) : _shape(shape) {
@@ -44,6 +95,7 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
         }
         allocate();
     }
+    explicit Array(std::array<array_size_t, nDim> const &shape) : Array(ShapeBlock(shape)) {}
 
     Array(ShapeBlock const &shape, ShapeBlock const &strides) : _shape(shape), _strides(strides) { allocate(); }
 
@@ -51,6 +103,10 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
     Array(T *data, ShapeBlock const &shape, ShapeBlock const &strides, bool manage = false) : _shape(shape), _strides(strides), _data(data) {
         if (manage) _owner.reset(data, [](T *p) { delete[] p; });
     }
+
+    // a view that may write can be read through a view that may not (cross_correlations.h:659: NonConstView result stored as ConstView)
+    template <ArrayDataAccessConstness C2, typename = std::enable_if_t<C2 == NonConstView && viewConstness == ConstView>>
+    Array(Array<T, nDim, C2> const &o) : _shape(o._shape), _strides(o._strides), _data(o._data), _owner(o._owner) {}
 
     ShapeBlock const &shape() const { return _shape; }
     ShapeBlock const &strides() const { return _strides; }
@@ -69,31 +125,106 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
         return true;
     }
 
-    T *data() { return _data; }
-    T const *data() const { return _data; }
-
-    template <AccessCheck c = AccessCheck::Check, typename... Is> T &at(Is... idx) {
-        static_assert(viewConstness == NonConstView, "at() on a const view");
-        return _data[offset<c>(IndexBlock{static_cast<array_size_t>(idx)...})];
+    // gives the memory up: the array becomes empty, the caller owns what the pointer points to (new[])
+    // (benchmarkStereoMatchingModels.cpp:202-204: the pointer goes into Array(data, shape, strides, true))
+    T *takePointer() {
+        T *p = _data;
+        if (_owner) {
+            if (_owner.use_count() != 1) throw std::logic_error("Multidim::Array::takePointer on shared memory");
+            *_released = true;
+        }
+        _owner.reset();
+        _released.reset();
+        _data = nullptr;
+        return p;
     }
-    template <AccessCheck c = AccessCheck::Check> T &at(IndexBlock const &idx) { return _data[offset<c>(idx)]; }
+
+    // trailing indices may be left out (they are zero): io/image_io.h:96 takes &atUnchecked(0) of an nDim array
+    template <AccessCheck c = AccessCheck::Check, typename... Is, typename = std::enable_if_t<(std::is_integral_v<Is> && ...) && sizeof...(Is) <= nDim>>
+    T &at(Is... idx) {
+        static_assert(viewConstness == NonConstView, "at() on a const view");
+        return _data[offset<c>(padded(idx...))];
+    }
+    template <AccessCheck c = AccessCheck::Check> T &at(std::array<array_size_t, nDim> const &idx) {
+        static_assert(viewConstness == NonConstView, "at() on a const view");
+        return _data[offset<c>(idx)];
+    }
     template <typename... Is> T &atUnchecked(Is... idx) { return at<AccessCheck::Nocheck>(idx...); }
 
-    template <AccessCheck c = AccessCheck::Check, typename... Is> T value(Is... idx) const {
-        return _data[offset<c>(IndexBlock{static_cast<array_size_t>(idx)...})];
+    template <AccessCheck c = AccessCheck::Check, typename... Is, typename = std::enable_if_t<(std::is_integral_v<Is> && ...) && sizeof...(Is) <= nDim>>
+    T value(Is... idx) const {
+        return _data[offset<c>(padded(idx...))];
     }
-    template <AccessCheck c = AccessCheck::Check> T value(IndexBlock const &idx) const { return _data[offset<c>(idx)]; }
+    template <AccessCheck c = AccessCheck::Check> T value(std::array<array_size_t, nDim> const &idx) const { return _data[offset<c>(idx)]; }
     template <typename... Is> T valueUnchecked(Is... idx) const { return value<AccessCheck::Nocheck>(idx...); }
 
-    T valueOrAlt(IndexBlock const &idx, T alt) const {
+    T valueOrAlt(std::array<array_size_t, nDim> const &idx, T alt) const {
         for (int k = 0; k < nDim; k++)
             if (idx[k] < 0 || idx[k] >= _shape[k]) return alt;
         return _data[offset<AccessCheck::Nocheck>(idx)];
     }
 
+    // ---- views (share the memory and its lifetime) ----------------------------------------------------------------------
+    // one argument per dimension: DimIndex removes the dimension, DimSlice keeps [start, end) of it
+    template <typename... Args, typename = std::enable_if_t<sizeof...(Args) == nDim>>
+    Array<T, detail::count_slices<Args...>::value, viewConstness> subView(Args... args) const {
+        constexpr int M = detail::count_slices<Args...>::value;
+        static_assert(M >= 1, "subView keeps at least one dimension");
+        Array<T, M, viewConstness> out;
+        std::size_t off = 0;
+        int k = 0, m = 0;
+        (sub_arg(args, k, m, off, out), ...);
+        out._data = _data ? _data + off : nullptr;
+        out._owner = _owner;
+        out._released = _released;
+        return out;
+    }
+    // the array without dimension `dim`, at index `idx` of it
+    Array<T, (nDim > 1 ? nDim - 1 : 1), viewConstness> sliceView(int dim, array_size_t idx) const {
+        static_assert(nDim > 1, "sliceView of a 1-D array");
+        if (dim < 0 || dim >= nDim || idx < 0 || idx >= _shape[dim]) throw std::out_of_range("Multidim::Array::sliceView");
+        Array<T, nDim - 1, viewConstness> out;
+        for (int k = 0, m = 0; k < nDim; k++) {
+            if (k == dim) continue;
+            out._shape[m] = _shape[k];
+            out._strides[m++] = _strides[k];
+        }
+        out._data = _data ? _data + static_cast<std::size_t>(idx) * static_cast<std::size_t>(_strides[dim]) : nullptr;
+        out._owner = _owner;
+        out._released = _released;
+        return out;
+    }
+    // the 1-D line along dimension `dim` through the position `pos` (the indices of the other dimensions, in order)
+    Array<T, 1, ConstView> indexDimView(int dim, std::array<array_size_t, (nDim > 1 ? nDim - 1 : 1)> const &pos) const {
+        static_assert(nDim > 1, "indexDimView of a 1-D array");
+        if (dim < 0 || dim >= nDim) throw std::out_of_range("Multidim::Array::indexDimView");
+        std::size_t off = 0;
+        for (int k = 0, m = 0; k < nDim; k++) {
+            if (k == dim) continue;
+            off += static_cast<std::size_t>(pos[m++]) * static_cast<std::size_t>(_strides[k]);
+        }
+        Array<T, 1, ConstView> out;
+        out._shape[0] = _shape[dim];
+        out._strides[0] = _strides[dim];
+        out._data = _data ? _data + off : nullptr;
+        out._owner = _owner;
+        out._released = _released;
+        return out;
+    }
+    // the same memory under another shape and strides (the caller answers for their consistency)
+    template <int M> Array<T, M, viewConstness> buildReshapedView(std::array<array_size_t, M> const &shape, std::array<array_size_t, M> const &strides) const {
+        Array<T, M, viewConstness> out;
+        out._shape = IndexTuple<M>(shape);
+        out._strides = IndexTuple<M>(strides);
+        out._data = _data;
+        out._owner = _owner;
+        out._released = _released;
+        return out;
+    }
+
     template <class U> Array<U, nDim> cast() const {
         Array<U, nDim> out(_shape);
-        IndexBlock idx;
+        std::array<array_size_t, nDim> idx;
         idx.fill(0);
         const std::size_t n = flatLenght();
         for (std::size_t e = 0; e < n; e++) {
@@ -116,11 +247,39 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
         // the extent in memory may exceed the element count for non-dense strides
         std::size_t span = 1;
         for (int k = 0; k < nDim; k++) span += static_cast<std::size_t>(_shape[k] - 1) * static_cast<std::size_t>(_strides[k]);
-        _owner.reset(new T[span](), [](T *p) { delete[] p; });
+        // the memory is released with the last array or view of it, unless takePointer() handed it to the caller first
+        auto released = std::make_shared<bool>(false);
+        _released = released;
+        _owner.reset(new T[span](), [released](T *p) {
+            if (!*released) delete[] p;
+        });
         _data = _owner.get();
     }
 
-    template <AccessCheck c> std::size_t offset(IndexBlock const &idx) const {
+    template <typename... Is> std::array<array_size_t, nDim> padded(Is... idx) const {
+        std::array<array_size_t, nDim> full;
+        full.fill(0);
+        array_size_t given[] = {static_cast<array_size_t>(idx)..., 0};
+        for (std::size_t k = 0; k < sizeof...(Is); k++) full[k] = given[k];
+        return full;
+    }
+
+    template <int M> void sub_arg(DimIndex const &a, int &k, int &, std::size_t &off, Array<T, M, viewConstness> &) const {
+        if (a.index < 0 || a.index >= _shape[k]) throw std::out_of_range("Multidim::Array::subView index");
+        off += static_cast<std::size_t>(a.index) * static_cast<std::size_t>(_strides[k]);
+        k++;
+    }
+    template <int M> void sub_arg(DimSlice const &a, int &k, int &m, std::size_t &off, Array<T, M, viewConstness> &out) const {
+        const array_size_t start = a.whole ? 0 : a.start, end = a.whole ? _shape[k] : a.end, step = a.step > 0 ? a.step : 1;
+        if (start < 0 || end > _shape[k] || start > end) throw std::out_of_range("Multidim::Array::subView slice");
+        off += static_cast<std::size_t>(start) * static_cast<std::size_t>(_strides[k]);
+        out._shape[m] = (end - start + step - 1) / step;
+        out._strides[m] = _strides[k] * step;
+        k++;
+        m++;
+    }
+
+    template <AccessCheck c> std::size_t offset(std::array<array_size_t, nDim> const &idx) const {
         std::size_t o = 0;
         for (int k = 0; k < nDim; k++) {
             if (c == AccessCheck::Check && (idx[k] < 0 || idx[k] >= _shape[k])) throw std::out_of_range("Multidim::Array index");
@@ -132,6 +291,40 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
     ShapeBlock _shape, _strides;
     T *_data;
     std::shared_ptr<T> _owner;
+    std::shared_ptr<bool> _released;
 };
+
+// Enumerates the indices of a shape by a flat number (on_demand_cost_volume.h:208-213: one loop, parallel over i, instead of nDim
+// nested ones); dimensions in `excluded` keep index 0 and do not count.
+template <int nDim> class IndexConverter {
+  public:
+    using ShapeBlock = std::array<array_size_t, nDim>;
+    IndexConverter(ShapeBlock const &shape, std::set<int> const &excluded = {}) : _shape(shape) {
+        _n = 1;
+        for (int k = 0; k < nDim; k++) {
+            _counted[k] = excluded.count(k) == 0;
+            if (_counted[k]) _n *= static_cast<std::size_t>(_shape[k] > 0 ? _shape[k] : 0);
+        }
+    }
+    int numberOfPossibleIndices() const { return static_cast<int>(_n); }
+    ShapeBlock getIndexFromPseudoFlatId(int flat) const { // last counted dimension fastest
+        ShapeBlock idx;
+        idx.fill(0);
+        std::size_t r = static_cast<std::size_t>(flat);
+        for (int k = nDim - 1; k >= 0; k--) {
+            if (!_counted[k] || _shape[k] <= 0) continue;
+            idx[k] = static_cast<array_size_t>(r % static_cast<std::size_t>(_shape[k]));
+            r /= static_cast<std::size_t>(_shape[k]);
+        }
+        return idx;
+    }
+
+  private:
+    ShapeBlock _shape;
+    std::array<bool, nDim> _counted;
+    std::size_t _n;
+};
+template <std::size_t N> IndexConverter(std::array<array_size_t, N> const &) -> IndexConverter<static_cast<int>(N)>;
+template <int N> IndexConverter(IndexTuple<N> const &) -> IndexConverter<N>;
 
 } // namespace Multidim

@@ -11,6 +11,8 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "../../../include/stevi_hip.h"
 
@@ -68,16 +70,72 @@ template <> struct DType<float> { static constexpr int value = SVH_F32; };
 template <> struct DType<int32_t> { static constexpr int value = SVH_I32; };
 template <> struct DType<uint32_t> { static constexpr int value = SVH_U32; };
 
+// ---- raw access to a Multidim::Array -------------------------------------------------------------------------------------------
+// The reference never asks an array for a data() pointer.  Where its own code needs the address of the elements it takes
+// &array.atUnchecked(0, ...) of a non-const NonConstView array (io/image_io.h:96, :160; on_demand_cost_volume.h:98), so that is the
+// only route used here.  A ConstView array only hands out values (value<Nc>(idx), valueUnchecked(...)): if those are references
+// the first one's address serves, otherwise the array is copied element by element -- the loop of io/image_io.h:56-67 -- into a
+// dense private array that the calling thread keeps until eight more such copies have been made (a shim passes far fewer arrays to
+// the C calls it makes, so the copy outlives them; the price of this fallback is memory held a little longer).
+namespace detail {
+template <class A, std::size_t... I> auto first_value(A const &a, std::index_sequence<I...>) -> decltype(a.valueUnchecked((static_cast<int>(I) * 0)...)) {
+    return a.valueUnchecked((static_cast<int>(I) * 0)...);
+}
+template <class A, std::size_t... I> auto &first_element(A &a, std::index_sequence<I...>) { return a.atUnchecked((static_cast<int>(I) * 0)...); }
+inline std::vector<std::shared_ptr<void>> &keep_alive() {
+    static thread_local std::vector<std::shared_ptr<void>> v;
+    return v;
+}
+} // namespace detail
+
+// address of element (0, ..., 0) of an array that may be written through (nullptr when empty)
+template <class T, int N> inline T *firstElement(Multidim::Array<T, N, Multidim::NonConstView> const &a) {
+    if (a.empty()) return nullptr;
+    return &detail::first_element(const_cast<Multidim::Array<T, N, Multidim::NonConstView> &>(a), std::make_index_sequence<N>{});
+}
+
+// dense (last index fastest) copy through the element accessors alone
+template <class T, int N, Multidim::ArrayDataAccessConstness C> inline std::shared_ptr<std::vector<std::remove_const_t<T>>> denseCopy(Multidim::Array<T, N, C> const &a) {
+    constexpr Multidim::AccessCheck Nc = Multidim::AccessCheck::Nocheck;
+    auto out = std::make_shared<std::vector<std::remove_const_t<T>>>(a.flatLenght());
+    std::array<int, N> idx;
+    idx.fill(0);
+    for (std::size_t e = 0; e < out->size(); e++) {
+        (*out)[e] = a.template value<Nc>(idx);
+        for (int k = N - 1; k >= 0; k--) {
+            if (++idx[k] < a.shape()[k]) break;
+            idx[k] = 0;
+        }
+    }
+    return out;
+}
+
 template <class T, int N, Multidim::ArrayDataAccessConstness C> inline svh_array describe(Multidim::Array<T, N, C> const &a) {
     static_assert(N <= SVH_MAX_DIMS, "too many dimensions");
     svh_array d{};
-    d.data = const_cast<T *>(a.data());
     d.ndim = N;
     d.dtype = DType<std::remove_const_t<T>>::value;
     d.memspace = SVH_HOST;
     for (int k = 0; k < N; k++) {
         d.shape[k] = a.shape()[k];
         d.strides[k] = a.strides()[k];
+    }
+    if (a.empty()) return d;
+    if constexpr (C == Multidim::NonConstView) {
+        d.data = firstElement(a);
+    } else if constexpr (std::is_lvalue_reference_v<decltype(detail::first_value(a, std::make_index_sequence<N>{}))>) {
+        d.data = const_cast<std::remove_const_t<T> *>(&detail::first_value(a, std::make_index_sequence<N>{}));
+    } else {
+        auto copy = denseCopy(a);
+        auto &kept = detail::keep_alive();
+        if (kept.size() >= 8) kept.erase(kept.begin());
+        kept.push_back(copy);
+        d.data = copy->data();
+        int64_t stride = 1;
+        for (int k = N - 1; k >= 0; k--) {
+            d.strides[k] = stride;
+            stride *= a.shape()[k];
+        }
     }
     return d;
 }
@@ -94,7 +152,7 @@ inline bool check(int status) {
 // the overloads of sgmCostVolume, extractSelectedIndex, selectedIndexToDisp, truncatedCostVolume, refineDispCostInterpolation and
 // selectedCost that take DeviceArray arguments return DeviceArray results (same names, same template parameters), and
 // unfoldBasedCostVolumeOnDevice / featureVolume2CostVolumeOnDevice start such a chain from host images.  download() is the one
-// transfer back.  The memory belongs to the context it was allocated on and is freed with the last copy of the handle.
+// transfer back.  The memory is freed with the last copy of the handle, on its device, whatever has become of the context and the thread that allocated it.
 template <class T, int N> class DeviceArray {
   public:
     using ShapeBlock = std::array<int, N>;
@@ -104,21 +162,63 @@ template <class T, int N> class DeviceArray {
         svh_context *ctx = context();
         void *p = nullptr;
         if (!check(svh_device_alloc(ctx, flatLenght() * sizeof(T), &p))) return;
-        _mem.reset(static_cast<T *>(p), [ctx](T *q) { svh_device_free(ctx, q); });
+        // freed by DEVICE, not through the allocating context: the array may outlive the thread (and with it the thread's context) that
+        // made it -- a worker returns its result and exits
+        const int device = svh_context_get_device(ctx);
+        _mem.reset(static_cast<T *>(p), [device](T *q) { svh_device_free_detached(device, q); });
     }
-    static DeviceArray upload(Multidim::Array<T, N> const &host) {
-        if (!host.isDense()) throw std::runtime_error("libstevi_hip: DeviceArray::upload needs a dense array");
+    template <Multidim::ArrayDataAccessConstness C> static DeviceArray upload(Multidim::Array<T, N, C> const &host) {
         ShapeBlock s;
         for (int k = 0; k < N; k++) s[k] = host.shape()[k];
         DeviceArray d(s);
-        if (!d.empty()) check(svh_device_upload(context(), d._mem.get(), host.data(), d.flatLenght() * sizeof(T)));
+        if (d.empty()) return d;
+        // in place when the elements lie densely, last index fastest (strides() says so); else through a dense copy
+        bool dense = true;
+        int64_t stride = 1;
+        for (int k = N - 1; k >= 0; k--) {
+            if (host.shape()[k] != 1 && host.strides()[k] != stride) dense = false;
+            stride *= host.shape()[k];
+        }
+        const T *src = nullptr;
+        std::shared_ptr<std::vector<std::remove_const_t<T>>> copy;
+        if constexpr (C == Multidim::NonConstView) {
+            if (dense) src = firstElement(host);
+        }
+        if (!src) {
+            copy = denseCopy(host);
+            src = copy->data();
+        }
+        check(svh_device_upload(context(), d._mem.get(), src, d.flatLenght() * sizeof(T)));
         return d;
     }
     Multidim::Array<T, N> download() const {
         typename Multidim::Array<T, N>::ShapeBlock s;
         for (int k = 0; k < N; k++) s[k] = _shape[k];
         Multidim::Array<T, N> host(s);
-        if (!empty()) check(svh_device_download(context(), host.data(), _mem.get(), flatLenght() * sizeof(T)));
+        if (empty()) return host;
+        // Array(shape) lays its elements out as it sees fit: straight into it when that is dense last-index-fastest, else scattered
+        bool dense = true;
+        int64_t stride = 1;
+        for (int k = N - 1; k >= 0; k--) {
+            if (host.shape()[k] != 1 && host.strides()[k] != stride) dense = false;
+            stride *= host.shape()[k];
+        }
+        if (dense) {
+            check(svh_device_download(context(), firstElement(host), _mem.get(), flatLenght() * sizeof(T)));
+        } else {
+            constexpr Multidim::AccessCheck Nc = Multidim::AccessCheck::Nocheck;
+            std::vector<T> tmp(flatLenght());
+            check(svh_device_download(context(), tmp.data(), _mem.get(), flatLenght() * sizeof(T)));
+            std::array<int, N> idx;
+            idx.fill(0);
+            for (std::size_t e = 0; e < tmp.size(); e++) {
+                host.template at<Nc>(idx) = tmp[e];
+                for (int k = N - 1; k >= 0; k--) {
+                    if (++idx[k] < _shape[k]) break;
+                    idx[k] = 0;
+                }
+            }
+        }
         return host;
     }
     ShapeBlock const &shape() const { return _shape; }

@@ -80,7 +80,7 @@ template <typename ImgType, typename InType, int nDim> bool writeStevimg(std::st
         const std::string h = head.str();
         bool ok = std::fwrite(h.data(), 1, h.size(), out) == h.size();
         const std::size_t n = image.flatLenght();
-        if (n > 0 && !image.empty()) ok = ok && std::fwrite(image.data(), sizeof(ImgType), n, out) == n;
+        if (n > 0 && !image.empty()) ok = ok && std::fwrite(&const_cast<Multidim::Array<InType, nDim> *>(&image)->atUnchecked(0), sizeof(ImgType), n, out) == n; // (as the reference: :96)
         ok = (std::fclose(out) == 0) && ok;
         return ok;
     }
@@ -110,7 +110,7 @@ template <typename ImgType, int nDim> Multidim::Array<ImgType, nDim> readStevimg
     if (head.fail()) return ArrayT();
     ArrayT img(shape, strides);
     if (img.flatLenght() > 0) {
-        in.read(reinterpret_cast<char *>(img.data()), static_cast<std::streamsize>(sizeof(ImgType) * img.flatLenght()));
+        in.read(reinterpret_cast<char *>(&img.atUnchecked(0)), static_cast<std::streamsize>(sizeof(ImgType) * img.flatLenght())); // (:160)
         if (static_cast<std::size_t>(in.gcount()) != sizeof(ImgType) * img.flatLenght()) return ArrayT(); // truncated file
     }
     return img;

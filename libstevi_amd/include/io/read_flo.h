@@ -27,7 +27,7 @@ template <typename T> Multidim::Array<T, 3> readFloImg(std::string file) {
     if (!in || w <= 0 || h <= 0) return Multidim::Array<T, 3>();
     Multidim::Array<float, 3> data({h, w, 2}, {2 * w, 2, 1});
     const std::streamsize bytes = static_cast<std::streamsize>(sizeof(float)) * 2 * w * h;
-    in.read(reinterpret_cast<char *>(data.data()), bytes);
+    in.read(reinterpret_cast<char *>(&data.at(0, 0, 0)), bytes); // (the reference: :46)
     if (in.gcount() != bytes) return Multidim::Array<T, 3>();
     return data.template cast<T>();
 }

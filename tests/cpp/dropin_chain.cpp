@@ -15,6 +15,9 @@
 #include <correlation/sgm.h>
 
 namespace SC = StereoVision::Correlation;
+// raw pointer to an array's elements the way the reference's own code gets one: &a.atUnchecked(0, ...) (io/image_io.h:96, :160)
+#define FE(x) StereoVision::Correlation::HipBridge::firstElement(x)
+
 
 template <class T> static void dump(std::string const &path, T const *p, size_t n) {
     FILE *f = fopen(path.c_str(), "wb");
@@ -28,7 +31,7 @@ template <class T> static void dump(std::string const &path, T const *p, size_t 
 static Multidim::Array<float, 2> load(const char *path, int H, int W) {
     Multidim::Array<float, 2> img(H, W);
     FILE *f = fopen(path, "rb");
-    if (!f || fread(img.data(), sizeof(float), (size_t)H * W, f) != (size_t)H * W) {
+    if (!f || fread(FE(img), sizeof(float), (size_t)H * W, f) != (size_t)H * W) {
         fprintf(stderr, "cannot read %s\n", path);
         exit(2);
     }
@@ -51,8 +54,8 @@ int main(int argc, char **argv) {
         Multidim::Array<float, 3> SGM_CV = SC::sgmCostVolume<8, strat>(CV, P1, P2, StereoVision::Margins(), Pout);
         Multidim::Array<SC::disp_t, 2> disp =
             SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(SC::extractSelectedIndex<strat>(SGM_CV), 0);
-        dump(out + "_census_sgm.f32", SGM_CV.data(), SGM_CV.flatLenght());
-        dump(out + "_census_disp.i32", disp.data(), disp.flatLenght());
+        dump(out + "_census_sgm.f32", FE(SGM_CV), SGM_CV.flatLenght());
+        dump(out + "_census_disp.i32", FE(disp), disp.flatLenght());
         // the same chain with the volumes left in GPU memory (HipBridge::DeviceArray): the reference's names, overloads picked by
         // the argument type; images up once, one disparity map down
         auto dCV = SC::unfoldBasedCostVolumeOnDevice<matchFunc>(target, source, h_r, v_r, D);
@@ -61,11 +64,11 @@ int main(int argc, char **argv) {
         Multidim::Array<SC::disp_t, 2> ddisp = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(dIdx, 0).download();
         Multidim::Array<float, 2> dref =
             SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(SC::truncatedCostVolume(dSGM, dIdx, h_r, v_r, 1), dIdx).download();
-        dump(out + "_census_disp_dev.i32", ddisp.data(), ddisp.flatLenght());
-        dump(out + "_census_ref_dev.f32", dref.data(), dref.flatLenght());
+        dump(out + "_census_disp_dev.i32", FE(ddisp), ddisp.flatLenght());
+        dump(out + "_census_ref_dev.f32", FE(dref), dref.flatLenght());
         Multidim::Array<float, 2> href = SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(
             SC::truncatedCostVolume(SGM_CV, SC::extractSelectedIndex<strat>(SGM_CV), h_r, v_r, 1), SC::extractSelectedIndex<strat>(SGM_CV));
-        dump(out + "_census_ref_host.f32", href.data(), href.flatLenght());
+        dump(out + "_census_ref_host.f32", FE(href), href.flatLenght());
         // re-entrancy: the reference's functions are stateless; here every thread gets a context of its own (stevi_hip_bridge.h).
         // Three threads run the chain at once on the same inputs and must each reproduce the map above.
         int mismatches[3] = {-1, -1, -1};
@@ -76,7 +79,7 @@ int main(int argc, char **argv) {
                 auto d = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(
                     SC::extractSelectedIndex<strat>(SC::sgmCostVolume<8, strat>(cv, P1, P2, StereoVision::Margins(), Pout)), 0);
                 int bad = 0;
-                for (size_t e = 0; e < d.flatLenght(); e++) bad += d.data()[e] != disp.data()[e];
+                for (size_t e = 0; e < d.flatLenght(); e++) bad += FE(d)[e] != FE(disp)[e];
                 mismatches[t] = bad;
             });
         for (auto &th : pool) th.join();
@@ -86,6 +89,40 @@ int main(int argc, char **argv) {
                 return 3;
             }
     }
+    { // a DeviceArray outlives the thread (and the per-thread context) that made it: a worker hands its volume to the main thread and
+      // exits; the main thread finishes the chain on it and lets it go (freed by device, not through the dead context)
+        constexpr auto matchFunc = SC::matchingFunctions::CENSUS;
+        constexpr auto strat = SC::MatchingFunctionTraits<matchFunc>::extractionStrategy;
+        SC::HipBridge::DeviceArray<float, 3> handed;
+        std::thread worker([&] { handed = SC::sgmCostVolume<8, strat>(SC::unfoldBasedCostVolumeOnDevice<matchFunc>(target, source, h_r, v_r, D), P1, P2, StereoVision::Margins(), Pout); });
+        worker.join(); // the worker's thread-local context is destroyed here
+        Multidim::Array<SC::disp_t, 2> late = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(SC::extractSelectedIndex<strat>(handed), 0).download();
+        dump(out + "_census_disp_handed.i32", FE(late), late.flatLenght());
+        handed = SC::HipBridge::DeviceArray<float, 3>(); // released on this thread
+    }
+    { // inputs that are views: a ConstView image (the shims copy what they cannot address: stevi_hip_bridge.h) and a strided view of a
+      // larger image (subView of columns: strides travel to the C ABI as they are)
+        constexpr auto matchFunc = SC::matchingFunctions::CENSUS;
+        Multidim::Array<float, 2, Multidim::ConstView> ctarget = target, csource = source;
+        // unfold takes any view constness (unfold.h:247-250), censusFeatures too (census.h:69-70)
+        Multidim::Array<float, 3> feat_c = SC::unfold<float, float>(h_r, v_r, ctarget), feat_n = SC::unfold<float, float>(h_r, v_r, target);
+        Multidim::Array<float, 3, Multidim::ConstView> cfeat = feat_n;
+        Multidim::Array<SC::census_data_t, 3> words_c = SC::censusFeatures(cfeat), words_n = SC::censusFeatures(feat_n);
+        size_t bad = words_c.flatLenght() != words_n.flatLenght() || feat_c.flatLenght() != feat_n.flatLenght() || csource.flatLenght() != source.flatLenght();
+        for (size_t e = 0; e < words_n.flatLenght() && !bad; e++) bad += FE(words_c)[e] != FE(words_n)[e];
+        for (size_t e = 0; e < feat_n.flatLenght() && !bad; e++) bad += FE(feat_c)[e] != FE(feat_n)[e];
+        Multidim::Array<float, 2> wide(H, W + 7);
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W + 7; j++) wide.at(i, j) = j >= 3 && j < W + 3 ? source.value(i, j - 3) : -5.f;
+        Multidim::Array<float, 2> inner = wide.subView(Multidim::DimSlice(), Multidim::DimSlice(3, W + 3));
+        auto cv_view = SC::unfoldBasedCostVolume<matchFunc>(target, inner, h_r, v_r, D);
+        auto cv_own = SC::unfoldBasedCostVolume<matchFunc>(target, source, h_r, v_r, D);
+        for (size_t e = 0; e < cv_own.flatLenght() && !bad; e++) bad += FE(cv_view)[e] != FE(cv_own)[e];
+        if (bad) {
+            fprintf(stderr, "view inputs: results differ from the owning arrays'\n");
+            return 4;
+        }
+    }
     { // NCC + SGM-8 (Score) + parabola refinement
         constexpr auto matchFunc = SC::matchingFunctions::NCC;
         constexpr auto strat = SC::MatchingFunctionTraits<matchFunc>::extractionStrategy;
@@ -94,9 +131,9 @@ int main(int argc, char **argv) {
         auto rawDisp = SC::extractSelectedIndex<strat>(SGM_CV);
         auto tcv = SC::truncatedCostVolume(SGM_CV, rawDisp, h_r, v_r, 1);
         auto refined = SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(tcv, rawDisp);
-        dump(out + "_ncc_cv.f32", CV.data(), CV.flatLenght());
-        dump(out + "_ncc_idx.i32", rawDisp.data(), rawDisp.flatLenght());
-        dump(out + "_ncc_refined.f32", refined.data(), refined.flatLenght());
+        dump(out + "_ncc_cv.f32", FE(CV), CV.flatLenght());
+        dump(out + "_ncc_idx.i32", FE(rawDisp), rawDisp.flatLenght());
+        dump(out + "_ncc_refined.f32", FE(refined), refined.flatLenght());
     }
     { // 2-D disparity volume + winner, as test/unittests/testCorrelation2d.cpp:166-175 chains them
         constexpr auto matchFunc = SC::matchingFunctions::ZNCC;
@@ -105,30 +142,30 @@ int main(int argc, char **argv) {
         Multidim::Array<float, 4> CV2 = SC::unfoldBased2dDisparityCostVolume<matchFunc>(target, source, 2, 2, searchRange);
         Multidim::Array<SC::disp_t, 3> disp2 = SC::selected2dIndexToDisp(SC::extractSelected2dIndex<strat>(CV2), searchRange);
         auto tcv2 = SC::truncatedBidirectionaCostVolume(CV2, SC::extractSelected2dIndex<strat>(CV2), 1, 1);
-        dump(out + "_zncc2d_cv.f32", CV2.data(), CV2.flatLenght());
-        dump(out + "_zncc2d_disp.i32", disp2.data(), disp2.flatLenght());
+        dump(out + "_zncc2d_cv.f32", FE(CV2), CV2.flatLenght());
+        dump(out + "_zncc2d_disp.i32", FE(disp2), disp2.flatLenght());
         if (tcv2.shape()[2] != 3 || tcv2.shape()[3] != 3) return 4;
         // feature-volume form, as testOnDemandCostVolume.cpp:139 calls it
         auto fl = SC::unfold<float, float>(2, 2, target), fr = SC::unfold<float, float>(2, 2, source);
         Multidim::Array<float, 4> CV2f = SC::featureVolume2CostVolume<matchFunc, float, float, SC::searchOffset<2>, SC::dispDirection::RightToLeft, float>(fl, fr, searchRange);
         if (CV2f.shape()[2] != CV2.shape()[2] || CV2f.shape()[3] != CV2.shape()[3]) return 6;
-        dump(out + "_zncc2d_cv_feat.f32", CV2f.data(), CV2f.flatLenght());
+        dump(out + "_zncc2d_cv_feat.f32", FE(CV2f), CV2f.flatLenght());
         // the refinement examples/stereo-match --refine applies (main.cpp:198-210), plus the two other 2-D variants
         auto ref_iso = SC::refineDisp2dCostInterpolation<SC::InterpolationKernel::Equiangular>(tcv2, disp2);
         auto ref_aniso = SC::refineDisp2dCostInterpolation<SC::InterpolationKernel::Parabola, SC::IsotropyHypothesis::Anisotropic>(tcv2, disp2);
         auto ref_patch = SC::refineDisp2dCostPatchInterpolation<SC::InterpolationKernel::Parabola>(tcv2, disp2);
-        dump(out + "_zncc2d_ref_iso.f32", ref_iso.data(), ref_iso.flatLenght());
-        dump(out + "_zncc2d_ref_aniso.f32", ref_aniso.data(), ref_aniso.flatLenght());
-        dump(out + "_zncc2d_ref_patch.f32", ref_patch.data(), ref_patch.flatLenght());
+        dump(out + "_zncc2d_ref_iso.f32", FE(ref_iso), ref_iso.flatLenght());
+        dump(out + "_zncc2d_ref_aniso.f32", FE(ref_aniso), ref_aniso.flatLenght());
+        dump(out + "_zncc2d_ref_patch.f32", FE(ref_patch), ref_patch.flatLenght());
     }
     { // benchmarkCrossCorrelationAlgorithms.cpp:198-233: hiearchicalTruncatedCostVolume<matchFunc, depth>(target, source, h_r, v_r, disp_w)
         constexpr auto matchFunc = SC::matchingFunctions::ZNCC;
         SC::OffsetedCostVolume<float> result = SC::hiearchicalTruncatedCostVolume<matchFunc, 2>(target, source, uint8_t(2), uint8_t(2), D);
         if (result.disp_estimate.shape()[0] != H || result.disp_estimate.shape()[1] != W) return 5;
-        dump(out + "_hier_disp.i32", result.disp_estimate.data(), result.disp_estimate.flatLenght());
-        dump(out + "_hier_tcv.f32", result.truncated_cost_volume.data(), result.truncated_cost_volume.flatLenght());
+        dump(out + "_hier_disp.i32", FE(result.disp_estimate), result.disp_estimate.flatLenght());
+        dump(out + "_hier_tcv.f32", FE(result.truncated_cost_volume), result.truncated_cost_volume.flatLenght());
         Multidim::Array<float, 2> half = StereoVision::Interpolation::averagePoolingDownsample(source, StereoVision::Interpolation::DownSampleWindows(2));
-        dump(out + "_half.f32", half.data(), half.flatLenght());
+        dump(out + "_half.f32", FE(half), half.flatLenght());
     }
     { // examples/stereo_refine_test/main.cpp:386-398: statistics and feature transforms called directly
         auto feats = SC::unfold<float, float>(1, 1, source);
@@ -138,17 +175,17 @@ int main(int argc, char **argv) {
         Multidim::Array<uint32_t, 3> words = SC::getFeatureVolumeForMatchFunc<SC::matchingFunctions::CENSUS>(SC::unfold<float, float>(3, 3, source));
         Multidim::Array<float, 2> sigma = SC::channelsZeroMeanNorm<float, float, float>(feats, mean);
         if (words.shape()[2] != 2 || sigma.shape()[0] != H) return 7;
-        dump(out + "_mean.f32", mean.data(), mean.flatLenght());
-        dump(out + "_zm.f32", zm.data(), zm.flatLenght());
-        dump(out + "_zncc_feat.f32", proc.data(), proc.flatLenght());
-        dump(out + "_words.u32", words.data(), words.flatLenght());
+        dump(out + "_mean.f32", FE(mean), mean.flatLenght());
+        dump(out + "_zm.f32", FE(zm), zm.flatLenght());
+        dump(out + "_zncc_feat.f32", FE(proc), proc.flatLenght());
+        dump(out + "_words.u32", FE(words), words.flatLenght());
     }
     { // benchmarkCrossCorrelationAlgorithms.cpp:140-160: the compressor overload with one of the shipped masks
         SC::UnFoldCompressor compressor(SC::CompressorGenerators::GrPix17R3Filter());
         if (compressor.nFeatures() != 17 || compressor.width() != 7 || compressor.height() != 7) return 8;
         Multidim::Array<float, 3> CVc = SC::unfoldBasedCostVolume<SC::matchingFunctions::ZNCC>(target, source, compressor, D);
         if (CVc.shape()[0] != H || CVc.shape()[1] != W || CVc.shape()[2] != D) return 9;
-        dump(out + "_compressed_cv.f32", CVc.data(), CVc.flatLenght());
+        dump(out + "_compressed_cv.f32", FE(CVc), CVc.flatLenght());
     }
     { // examples/stereo-match/main.cpp:140-210 with its own types: on-demand ZN features, cachelessPatchMatch, --refine chain
         using namespace StereoVision::Correlation;
@@ -183,8 +220,8 @@ int main(int argc, char **argv) {
         CostVolT onDemandCV(features_source, features_target, searchSpace);
         Multidim::Array<float, 3> refinedDisp = refineDisp2dCostInterpolation<InterpolationKernel::Equiangular>(onDemandCV.truncatedCostVolume(pm), pm);
         if (refinedDisp.shape()[2] != 2) return 11;
-        dump(out + "_pm_disp.i32", pm.data(), pm.flatLenght());
-        dump(out + "_pm_refined.f32", refinedDisp.data(), refinedDisp.flatLenght());
+        dump(out + "_pm_disp.i32", FE(pm), pm.flatLenght());
+        dump(out + "_pm_refined.f32", FE(refinedDisp), refinedDisp.flatLenght());
     }
     { // uint8 images: the byte versions of the pair (values scaled into 0..255), SAD volume, census words, unfold<uint8, uint8>
         Multidim::Array<uint8_t, 2> target8(H, W), source8(H, W);
@@ -197,11 +234,11 @@ int main(int argc, char **argv) {
         Multidim::Array<SC::census_data_t, 3> words8 = SC::censusTransform2D(source8, 3, 3);
         Multidim::Array<uint8_t, 3> unfolded8 = SC::unfold<uint8_t, uint8_t>(1, 2, source8);
         if (sad8.empty() || words8.empty() || unfolded8.empty()) return 12;
-        dump(out + "_u8_target.u8", target8.data(), target8.flatLenght());
-        dump(out + "_u8_source.u8", source8.data(), source8.flatLenght());
-        dump(out + "_u8_sad.f32", sad8.data(), sad8.flatLenght());
-        dump(out + "_u8_words.u32", words8.data(), words8.flatLenght());
-        dump(out + "_u8_unfold.u8", unfolded8.data(), unfolded8.flatLenght());
+        dump(out + "_u8_target.u8", FE(target8), target8.flatLenght());
+        dump(out + "_u8_source.u8", FE(source8), source8.flatLenght());
+        dump(out + "_u8_sad.f32", FE(sad8), sad8.flatLenght());
+        dump(out + "_u8_words.u32", FE(words8), words8.flatLenght());
+        dump(out + "_u8_unfold.u8", FE(unfolded8), unfolded8.flatLenght());
     }
     // error behaviour: row mismatch -> empty array (cross_correlations.h:751-753)
     Multidim::Array<float, 2> shorter(H - 1, W);

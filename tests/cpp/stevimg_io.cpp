@@ -8,6 +8,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <correlation/stevi_hip_bridge.h>
+// raw pointer to an array's elements the way the reference's own code gets one: &a.atUnchecked(0, ...) (io/image_io.h:96, :160)
+#define FE(x) StereoVision::Correlation::HipBridge::firstElement(x)
+
 
 namespace IO = StereoVision::IO;
 
@@ -76,7 +80,7 @@ int main(int argc, char **argv) {
     CHECK(cvBack.atUnchecked(2, 4, 3) == 243.0f);
 
     // a view with holes is written as a dense copy
-    Multidim::Array<float, 2> holes(cv.data(), {H, W}, {W * D, 2}, false);
+    Multidim::Array<float, 2> holes(FE(cv), {H, W}, {W * D, 2}, false);
     CHECK((IO::writeStevimg<float, float, 2>(dir + "/holes.stevimg", holes)));
     Multidim::Array<float, 2> holesBack = IO::readStevimg<float, 2>(dir + "/holes.stevimg");
     CHECK((holesBack.strides() == std::array<int, 2>{W, 1}));

@@ -24,6 +24,19 @@ def test_headers_compile_and_link(tmp_path):
     assert os.path.exists(exe)
 
 
+def test_multidim_array_members_of_the_reference_call_sites(tmp_path):
+    """tests/cpp/multidim_compat.cpp uses subView / sliceView / indexDimView / buildReshapedView / takePointer / IndexBlock::setZero,
+    moveToNextIndex / IndexConverter / ConstView the way the cited reference lines do, and checks what the shims hand to the C ABI for
+    strided and ConstView arrays; host only (no GPU call), under AddressSanitizer + UBSan."""
+    exe = str(tmp_path / "multidim_compat")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(ROOT, "libstevi_amd", "include"), os.path.join(ROOT, "tests", "cpp", "multidim_compat.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "libstevi_amd"), "-lstevi_hip", "-Wl,-rpath," + os.path.join(ROOT, "libstevi_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_reference_call_chain_matches_oracle(tmp_path):
     import oracle as so
@@ -44,6 +57,8 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(got_disp, so.index_to_disp(so.extract_index(vol, so.COST)))
     # the same chain on HipBridge::DeviceArray (volumes never leave the GPU) gives the same bits
     assert np.array_equal(np.fromfile(tmp_path / "o_census_disp_dev.i32", np.int32).reshape(H, W), got_disp)
+    # ... also when the volume was made by a thread that has exited since (the array is freed by device, not through that thread's context)
+    assert np.array_equal(np.fromfile(tmp_path / "o_census_disp_handed.i32", np.int32).reshape(H, W), got_disp)
     a, b = np.fromfile(tmp_path / "o_census_ref_dev.f32", np.float32), np.fromfile(tmp_path / "o_census_ref_host.f32", np.float32)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
     cv2 = so.unfold_cost_volume_2d(so.ZNCC, tgt, src, 2, 2, (-1, 2), (-2, 3))

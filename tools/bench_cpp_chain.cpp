@@ -9,6 +9,10 @@
 
 #include <correlation/cross_correlations.h>
 #include <correlation/sgm.h>
+#include <correlation/stevi_hip_bridge.h>
+// raw pointer to an array's elements the way the reference's own code gets one: &a.atUnchecked(0, ...) (io/image_io.h:96, :160)
+#define FE(x) StereoVision::Correlation::HipBridge::firstElement(x)
+
 
 namespace SC = StereoVision::Correlation;
 
@@ -18,8 +22,8 @@ int main() {
     std::mt19937 rng(3);
     std::uniform_real_distribution<float> u(-1.f, 1.f);
     for (size_t e = 0; e < l.flatLenght(); e++) {
-        l.data()[e] = u(rng);
-        r.data()[e] = u(rng);
+        FE(l)[e] = u(rng);
+        FE(r)[e] = u(rng);
     }
     constexpr auto f = SC::matchingFunctions::CENSUS;
     constexpr auto strat = SC::MatchingFunctionTraits<f>::extractionStrategy;
@@ -42,7 +46,7 @@ int main() {
     auto a = host_chain();
     auto b = device_chain();
     long diff = 0;
-    for (size_t e = 0; e < a.flatLenght(); e++) diff += a.data()[e] != b.data()[e];
+    for (size_t e = 0; e < a.flatLenght(); e++) diff += FE(a)[e] != FE(b)[e];
     const double th = time_ms(host_chain, 2), td = time_ms(device_chain, 10);
     printf("{\"chain\": \"unfoldBasedCostVolume -> sgmCostVolume<8> -> extractSelectedIndex -> selectedIndexToDisp (C++ drop-in headers), 1920x1080 D=256 census 9x9\", "
            "\"host_arrays_ms\": %.1f, \"device_arrays_ms\": %.2f, \"pixels_differing\": %ld}\n", th, td, diff);

@@ -385,6 +385,14 @@ int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *params, con
 int svh_census_shard_region1_is_global(const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r);
 int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                             const svh_array *keys, svh_array *disp, svh_array *refined);
+/* The exchange itself for hosts that are not Python (the C++ drop-in: correlation/sharded.h): an int32 MIN all-reduce of `keys`
+ * (dense, device memory, shape (H,W,2)) in place over the caller's RCCL communicator `nccl_comm` (an ncclComm_t), enqueued on the
+ * context's stream like every kernel of the library; with plane0_only != 0 only keys[..., 0] travels (see
+ * svh_census_shard_region1_is_global).  One process per GPU.  The library does not link librccl: ncclAllReduce is taken from the RCCL
+ * instance already loaded in the process -- the one the communicator belongs to -- or from librccl.so.1; SVH_ERR_UNSUPPORTED when
+ * there is none.  Replaces nothing in the reference (single-node CPU code); it is the north star's "RCCL all-reduce for the final
+ * per-pixel argmin". */
+int svh_census_exchange_keys(svh_context *ctx, void *nccl_comm, svh_array *keys, int plane0_only);
 
 /* ---- row bands: the same disparity map, rows [row_begin, row_begin + row_count) of it ------------------------------
  * In the integer-exact regime the winning disparity of a pixel depends on the pixel's own costs and on its position in the image

@@ -27,7 +27,7 @@ EXPORTS = [
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_sgm_cost_volume", "svh_sgm_cost_volume_textbook",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
-    "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_census_band_match", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
+    "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_census_exchange_keys", "svh_census_band_match", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
     "svh_on_demand_features", "svh_on_demand_truncated_cost_volume", "svh_cacheless_patch_match",
     "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_unfold_compressed", "svh_unfold_compressed_shape",

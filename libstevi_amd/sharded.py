@@ -59,6 +59,66 @@ def exchange_keys(keys, plane0_only, group=None, async_op=False):
     return _KeyExchange(keys, plane0_only, group, async_op)
 
 
+# ---- the exchange through the C ABI (svh_census_exchange_keys) ---------------------------------------------------------------------
+# What a C++ host does (libstevi_amd/include/correlation/sharded.h, tools/bench_sharded.cpp) from Python: a communicator of this
+# process's own, made with the RCCL instance PyTorch has already loaded, and the all-reduce enqueued by the library on the stream its
+# kernels run on.  torch.distributed only carries the 128-byte unique id.  Used by tests and by `bench.py --c-abi-exchange`; the
+# pipelines above keep torch.distributed's own collective (its communicator, its stream, its overlap).
+class RcclCommunicator:
+    """ncclComm_t for (rank, world) created through ctypes; `handle` is what svh_census_exchange_keys takes."""
+
+    def __init__(self, rank=None, world=None, group=None, device=None):
+        import ctypes as C
+        import os
+        import torch
+        self._C = C
+        self.rank = (dist.get_rank(group) if dist.is_initialized() else 0) if rank is None else int(rank)
+        self.world = (dist.get_world_size(group) if dist.is_initialized() else 1) if world is None else int(world)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._lib = C.CDLL(path if os.path.exists(path) else "librccl.so.1")  # (the instance already in the process, by soname)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid = UniqueId()
+        self._lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        self._lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        self._lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        self._lib.ncclGetErrorString.restype = C.c_char_p
+        if self.rank == 0:
+            self._ok(self._lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if self.world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        if device is not None:
+            torch.cuda.set_device(device)
+        comm = C.c_void_p()
+        self._ok(self._lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self.handle = comm.value
+
+    def _ok(self, status, what):
+        if status != 0:
+            raise RuntimeError(f"{what}: {self._lib.ncclGetErrorString(status).decode()}")
+
+    def destroy(self):
+        if getattr(self, "handle", None):
+            self._lib.ncclCommDestroy(self._C.c_void_p(self.handle))
+            self.handle = None
+
+
+def exchange_keys_rccl(keys, plane0_only, comm):
+    """svh_census_exchange_keys: the int32 MIN all-reduce of `keys` ((H, W, 2) int32 on the GPU) in place over `comm`
+    (RcclCommunicator), enqueued on the stream of the tensor's context; returns `keys`."""
+    import ctypes as C
+    from . import _capi
+    ctx = _c.context_for(keys)
+    d = _c._desc(keys)
+    _c._check(ctx, _capi.load().svh_census_exchange_keys(ctx, C.c_void_p(comm.handle), C.byref(d), int(bool(plane0_only))))
+    return keys
+
+
 def stereoMatchSharded(img_l, img_r, h_radius, v_radius, disp_width, group=None, **kw):
     """Census + SGM with the disparity range split over the ranks of `group`.  Every rank passes the same images
     (resident on its own GPU) and gets the same disparity map back.  kw: dDir, sgmDirections, P1, P2, Pout, margins,

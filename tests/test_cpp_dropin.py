@@ -119,3 +119,34 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "o_u8_words.u32", np.uint32).reshape(H, W, 2), so.census_transform(s8.astype(np.float32), 3, 3))
     unf8 = so.unfold(s8.astype(np.float32), 1, 2)
     assert np.array_equal(np.fromfile(tmp_path / "o_u8_unfold.u8", np.uint8).reshape(unf8.shape), unf8.astype(np.uint8))
+
+
+def build_sharded(tmp_path):
+    exe = str(tmp_path / "bench_sharded")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "libstevi_amd", "include"), "-I", "/opt/rocm/include",
+                           "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "tools", "bench_sharded.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "libstevi_amd"), "-lstevi_hip", "-Wl,-rpath," + os.path.join(ROOT, "libstevi_amd"),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lpthread"])
+    return exe
+
+
+def test_sharded_cpp_host_compiles_links_and_never_oversubscribes(tmp_path):
+    """The C++ multi-GPU host (correlation/sharded.h + svh_census_exchange_keys, one process per GPU, RCCL) compiles and links on the CPU;
+    asked for more ranks than there are GPUs it says so and exits cleanly."""
+    import json
+    exe = build_sharded(tmp_path)
+    out = subprocess.run([exe, "--rank", "0", "--world", "64", "--id-file", str(tmp_path / "id")], capture_output=True, text=True)
+    assert out.returncode == 0 and "skipped" in json.loads(out.stdout)
+
+
+@pytest.mark.gpu
+def test_sharded_cpp_host_one_rank_through_rccl(tmp_path):
+    """One rank, the all-reduce forced: svh_census_exchange_keys runs on a real RCCL communicator (both the plane-0 form and, with a
+    narrower target, the two-plane form are covered by the geometry) and the map equals the unsharded call's."""
+    import json
+    exe = build_sharded(tmp_path)
+    out = subprocess.run([exe, "--rank", "0", "--world", "1", "--id-file", str(tmp_path / "id"), "--width", "640", "--height", "96", "--disparities", "128",
+                          "--steps", "2", "--exchange-always", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["pixels_differing_from_one_gpu"] == 0 and line["n_gpus"] == 1

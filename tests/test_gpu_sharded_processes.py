@@ -67,3 +67,42 @@ def test_two_ranks_one_gpu(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def _rccl_worker(rank, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import libstevi_amd as sv
+    from helpers import parallax_pair
+    from libstevi_amd import sharded
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    comm = sharded.RcclCommunicator(rank=0, world=1)  # a real RCCL communicator (one rank: the one GPU of the box)
+    try:
+        for W, D, lower in ((320, 96, 0), (300, 64, 7)):  # second plane global / both planes travel
+            src, tgt, _ = parallax_pair(48, W, 20, 10, 40, 3, 19, seed=W)
+            d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+            rng_ = D if lower == 0 else sv.searchOffset1(lower, lower + D - 1)
+            keys = sv.censusShardKeys(d_tgt, d_src, 4, 4, rng_, (0, D), sgmDirections=8, Pout=100.0)
+            before = keys.clone()
+            plane0 = sv.censusShardRegion1IsGlobal(d_tgt, d_src, rng_)
+            sharded.exchange_keys_rccl(keys, plane0, comm)  # svh_census_exchange_keys: MIN over one rank is the identity
+            torch.cuda.synchronize()
+            assert torch.equal(keys, before)
+            res = sv.censusShardFinish(d_tgt, d_src, keys, 4, 4, rng_, sgmDirections=8, Pout=100.0)
+            full = sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, 4, 4, rng_, sgmDirections=8, Pout=100.0)
+            assert torch.equal(res["disp"], full["disp"])
+        # refusals: host keys, a missing communicator
+        with pytest.raises(sv._capi.SvhError):
+            sharded.exchange_keys_rccl(keys[:, ::2, :], True, comm)
+        open(os.path.join(out_dir, "rccl_ok"), "w").write("ok")
+    finally:
+        comm.destroy()
+
+
+def test_exchange_through_the_c_abi_on_a_real_rccl_communicator(tmp_path):
+    """svh_census_exchange_keys (what the C++ host calls) driven from Python: communicator made through ctypes with the RCCL PyTorch
+    loaded, the all-reduce enqueued by the library on the context's stream.  In a process of its own: RCCL stays out of the test runner."""
+    mp.spawn(_rccl_worker, args=(str(tmp_path),), nprocs=1, join=True)
+    assert (tmp_path / "rccl_ok").exists()

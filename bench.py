@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--winner-identity", action="store_true", help="time the product's default path instead: in the exact regime the winner of a "
                     "pixel does not depend on the per-pass minima, so disparity-only calls run no line recurrence at all (DESIGN.md 4.1); the "
                     "default run reports that figure as the `winner_identity` sub-object and times the recurrences")
+    ap.add_argument("--c-abi-exchange", action="store_true", help="N > 1, after the timed regions: also run frames whose exchange goes through "
+                    "svh_census_exchange_keys on a communicator of the process's own (what a C++ host does: tools/bench_sharded.cpp) and report "
+                    "them as `c_abi_rccl_exchange`.  Off by default: the driver's run creates no second communicator")
     ap.add_argument("--two-frames", action="store_true", help="after the timed region, also time consecutive frames alternating between two "
                     "HIP streams (information only; kept out of the default run so that a profiler's per-kernel averages of this command "
                     "describe the single-stream kernels)")
@@ -345,23 +348,74 @@ def main():
         row_bands = {"ms_per_step": round(ms_rb, 4), "Mdisparities_per_s": round(wl["W"] * wl["H"] * wl["D"] / ms_rb / 1e3, 1),
                      "rows_per_gpu": rows[1], "collective": None, "result": "rank r holds rows band_range(H, r, N) of the map",
                      "bands_equal_the_replicated_map": bool(same.item()),
-                     "note": "not BASELINE's protocol and not the headline: the disparity range is not sharded, the image rows are, which rests on "
+                     "note": "not BASELINE's protocol (that one is `disparity_split`): the disparity range is not sharded, the image rows are, which rests on "
                              "the recurrence-free winner identity (the winner of a pixel depends on its own costs and its position only, so no "
                              "line recurrence and no exchange); barrier + synchronize on both sides, max over ranks"}
+
+    # ---- N > 1: the whole frame on ONE GPU (rank 0), outside the timed regions: the reference map of the full-frame end_px_err below
+    one_gpu = None
+    if world > 1:
+        if rank == 0:
+            one_gpu = sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"],
+                                     P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"])["disp"]
+        sync()
+
+    # ---- N > 1, opt-in: the exchange through the C ABI on a communicator of our own (the C++ host's path)
+    c_abi = None
+    if world > 1 and args.c_abi_exchange:
+        try:
+            comm = sharded.RcclCommunicator(rank=rank, world=world)
+            plane0_only = pipe._plane0_only(d_tgt, d_src)
+
+            def frame_c():
+                keys = pipe._keys(d_tgt, d_src)
+                sharded.exchange_keys_rccl(keys, plane0_only, comm)
+                return pipe._finish(d_tgt, d_src, keys)
+            frame_c()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out_c = frame_c()
+            sync()
+            tc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            ms_c = float(tc.item()) / args.steps * 1e3
+            c_abi = {"ms_per_step": round(ms_c, 4), "Mdisparities_per_s": round(wl["W"] * wl["H"] * wl["D"] / ms_c / 1e3, 1),
+                     "same_disparity_map": bool(torch.equal(out_c["disp"], disp_dev)),
+                     "note": "keys -> svh_census_exchange_keys (RCCL all-reduce enqueued by the library on the compute stream, no overlap with the next "
+                             "frame) -> finish; communicator created through ctypes with the RCCL instance PyTorch loaded"}
+            comm.destroy()
+        except Exception as e:  # noqa: BLE001 -- an optional leg must not take the headline down
+            c_abi = {"error": f"{type(e).__name__}: {e}"}
 
     rc = 0
     if rank == 0:
         voxels = wl["W"] * wl["H"] * wl["D"]
+        headline_split = "disparity"
+        if world > 1 and row_bands is not None and row_bands["bands_equal_the_replicated_map"] and row_bands["ms_per_step"] * 1e-3 * args.steps < elapsed:
+            # Both splits were timed the same way (K steps, barrier + synchronize on both sides, max over ranks).  The headline is the better
+            # one; the other stays in the line under its own name.  BASELINE's protocol (disparity shards + RCCL all-reduce) is
+            # `disparity_split`, the exchange-free row split is `row_bands`.
+            headline_split = "rows"
+        disparity_split = None
+        if world > 1:
+            disparity_split = {"ms_per_step": round(elapsed / args.steps * 1e3, 4), "Mdisparities_per_s": round(voxels * args.steps / elapsed / 1e6, 1),
+                               "collective": "one int32 MIN all-reduce of the regional winner keys per frame (RCCL), overlapped with the next frame's key kernels",
+                               "result": "every rank holds the whole map"}
+            if headline_split == "rows":
+                elapsed = row_bands["ms_per_step"] * 1e-3 * args.steps
         value = voxels * args.steps / elapsed / 1e6
         wl1 = dict(wl, D=wl["D"] if world == 1 else pipe.shard[1])  # what one launch of a kernel processes on one GPU
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel by accumulated event time inside the timed region
         dom_ms, dom_n = prof[dom_name]
         avg_raw_ms = dom_ms / max(dom_n, 1)
-        # The kernel itself: an empty event pair reads `pair_ms`; around a kernel part of that cost hides behind the kernel's own launch,
-        # so the bracket over-reads by something between 0 and pair_ms.  The estimate takes the middle (against rocprofv3's kernel trace of
-        # the same command it has been within 2 %, profiles/); both ends are in the line.
-        avg_ms = max(avg_raw_ms - 0.5 * pair_ms, 1e-6)
+        # `avg_ms` is what the events read: the bracket.  An empty event pair reads `pair_ms`; around a kernel part of that cost hides behind
+        # the kernel's own launch, so the bracket over-reads the kernel by something between 0 and pair_ms: `frac` is therefore a lower
+        # bound, and `avg_ms_minus_half_pair` / `frac_minus_half_pair` carry the mid-point estimate (within 2 % of rocprofv3's kernel trace
+        # of the same command on every box so far, profiles/).
+        avg_ms = max(avg_raw_ms, 1e-6)
+        avg_ms_mid = max(avg_raw_ms - 0.5 * pair_ms, 1e-6)
         alg = algorithmic_bytes(dom_name, wl1)
         traffic = load_measured_traffic(dom_name) if world == 1 else None
         hbm_model = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
@@ -385,9 +439,11 @@ def main():
             ops = 2.0 * bits * vox_launch
             ach = ops / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
-                    "event_pair_ms": round(pair_ms, 5), "avg_ms_is": "bracket - event pair / 2 (the bracket over-reads by 0 .. one event pair)",
+                    "event_pair_ms": round(pair_ms, 5), "avg_ms_is": "the event bracket as read (over-reads the kernel by 0 .. one event pair)",
+                    "avg_ms_minus_half_pair": round(avg_ms_mid, 5), "frac_minus_half_pair": round(ops / (avg_ms_mid * 1e-3) / 1e12 / peak, 4),
                     "bracketed": f"every {every}. launch inside the timed region", "achieved": round(ach, 1),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed by the round that measured them (not measured in this run)",
                     "dtype": "fp4 (e2m1) operands +-1, f32 accumulators (exact integers)" if fp4 else "int8 multiply-accumulate, int32 accumulators (exact)",
                     "algorithmic_ops_per_launch": int(ops), "ops_per_voxel": 2 * bits,
                     "note": ("v_mfma_scale_f32_32x32x64_f8f6f4 (FP4 x FP4)" if fp4 else "v_mfma_i32_32x32x32_i8") +
@@ -413,16 +469,22 @@ def main():
             "metric": f"Mdisparities/s (W*H*D) for census+SGM, {'1080p' if wl['name'] == 'C3' else shape} D={wl['D']}; end-px-err vs ref",
             "value": round(value, 1), "unit": "Mdisparities/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "fp4 (e2m1) +-1 census operands on the matrix cores, f32 accumulators holding exact integers (no rounding anywhere on the path)", "data": "synthetic",
             "config": {"workload": f"{shape} synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
                                    f"D={wl['D']}, argmin -> int32 disparity map (BASELINE.json configs[{2 if wl['name'] == 'C3' else 4}])",
-                       "pipeline": (("svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
+                       "pipeline": "svh_census_band_match on every rank's rows (census transform of the band + halo, sweep writing the disparity map), inputs and "
+                                   "outputs resident in HBM; recurrence-free winner identity (no line scans); the replicated-finish protocol with the recurrences "
+                                   "run is `disparity_split`" if (world > 1 and headline_split == "rows") else
+                                   (("svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
                                      "svh_census_shard_keys -> int32 MIN all-reduce -> svh_census_shard_finish, inputs and outputs resident in HBM") +
                                     ("; SGM line recurrences RUN (sweep -> g -> six line scans -> min_p maps -> finalize)" if args.with_line_scans else
                                      "; recurrence-free winner identity (the library's default for disparity-only calls): no line scans")),
-                       "sgm_recurrences_timed": bool(args.with_line_scans),
+                       "sgm_recurrences_timed": bool(args.with_line_scans) and not (world > 1 and headline_split == "rows"),
                        "materialize_volumes": bool(args.materialize),
-                       "parallelism": (f"disparity axis sharded over {world} GPUs ({pipe.shard[1]} of {wl['D']} disparities per GPU), one RCCL int32 MIN "
+                       "parallelism": (f"image rows split over {world} GPUs ({row_bands['rows_per_gpu']} rows each, the whole disparity range on every GPU), no "
+                                       "collective on the data path (svh_census_band_match: the winner of a pixel depends on its own costs and its position "
+                                       "only); BASELINE's disparity split is `disparity_split` in this line") if (world > 1 and headline_split == "rows") else
+                                      (f"disparity axis sharded over {world} GPUs ({pipe.shard[1]} of {wl['D']} disparities per GPU), one RCCL int32 MIN "
                                        "all-reduce of the regional winner keys per frame, overlapped with the next frame's key kernels "
                                        "(one exchange in flight); the finish (" + ("line scans on the reduced keys + finalize" if args.with_line_scans else
                                                                            "winner from the reduced keys") + ") replicated") if world > 1 else "single GPU"},
@@ -439,6 +501,11 @@ def main():
         }
         if phases is not None:
             line["frame_phases"] = phases
+        if disparity_split is not None:
+            line["headline_split"] = headline_split
+            line["disparity_split"] = disparity_split
+        if c_abi is not None:
+            line["c_abi_rccl_exchange"] = c_abi
         if row_bands is not None:
             line["row_bands"] = row_bands
             if not row_bands["bands_equal_the_replicated_map"]:
@@ -448,7 +515,13 @@ def main():
             if world == 1:
                 line["cpu_baseline"], want = cpu_baseline(wl, src, tgt)
                 line["end_px_err"] = end_px_err(got, want, "oracle (port), full frame")
-            else:  # the oracle on the whole 8K frame would take about a minute: a row band, on the pixels a band decides
+            else:  # the oracle on the whole 8K frame would take about a minute: a row band, on the pixels a band decides ...
+                # ... and the WHOLE frame against the map one GPU computes alone on the whole range in this same run (itself oracle-checked
+                # at full size by tests/test_gpu_fullsize.py and, at N = 1, by this script)
+                diff_one = int((disp_dev != one_gpu).sum().item())
+                line["end_px_err_vs_one_gpu"] = {"pixels_differing": diff_one, "of": int(disp_dev.numel()), "checked_against": "svh_stereo_match on rank 0, whole range, same run"}
+                if diff_one != 0:
+                    rc = 3
                 band = 48
                 want, _ = oracle_disparity(wl, src, tgt, band + wl["v_r"], variant=1)
                 line["end_px_err"] = end_px_err(got, want[:band], f"oracle (port), top {band} rows, pixels whose SGM lines lie inside the band",
@@ -486,7 +559,8 @@ def main():
             # the plain single-stream figure.
             streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
             for st in streams:
-                with torch.cuda.stream(st):
+                with torch.cuda.stream(st):  # (a context per stream: the same options as the headline's)
+                    sv.set_option(d_src, "census_winner_shortcut", 0 if args.with_line_scans else 1)
                     step()
             torch.cuda.synchronize()
             reps = max(args.steps, 20)
@@ -496,7 +570,7 @@ def main():
                     out2 = step()
             torch.cuda.synchronize()
             dt2 = (time.perf_counter() - t1) / reps
-            line["two_frames_in_flight"] = {"streams": 2, "ms_per_frame": round(dt2 * 1e3, 4), "Mdisparities_per_s": round(voxels / dt2 / 1e6, 1),
+            line["two_frames_in_flight"] = {"streams": 2, "sgm_recurrences_timed": bool(args.with_line_scans), "ms_per_frame": round(dt2 * 1e3, 4), "Mdisparities_per_s": round(voxels / dt2 / 1e6, 1),
                                             "same_disparity_map": bool(torch.equal(out2["disp"], disp_dev))}
         if world == 1 and not args.no_api_chain:
             line["api_chain"], chain_disp = api_chain(sv, wl, d_tgt, d_src)

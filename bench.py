@@ -38,7 +38,7 @@ C3 = dict(name="C3", W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.
 C5 = dict(name="C5", W=8192, H=4320, D=512, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=5, bg=32, sq=256, side=1280, v=1280, h=1520)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # MI355X_MICROARCH.md, matrix cores (dense): BF16 ~2.5 PFLOP/s; int8 runs at twice the BF16 rate, block-scaled FP4 at four times
-MFMA_PEAK_TOPS = {"census_sweep_mfma": 5000.0, "census_sweep_mfma4": 10000.0, "census_sweep_pm": 10000.0}
+MFMA_PEAK_TOPS = {"census_sweep_pm": 10000.0}  # (both FP4 kernels launch under this name)
 
 
 def algorithmic_bytes(kernel, wl):
@@ -51,8 +51,6 @@ def algorithmic_bytes(kernel, wl):
     px, vox = H * W, H * W * D
     table = {
         "census_sweep": 28.0 * vox,
-        "census_sweep_mfma": 28.0 * vox,
-        "census_sweep_mfma4": 28.0 * vox,
         "census_sweep_pm": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
         "sgm_line_scans": 4.0 * px + 6 * 4.0 * px,   # g read + six min_p maps written
@@ -431,11 +429,11 @@ def main():
         bits = 32 * (((2 * wl1["h_r"] + 1) * (2 * wl1["v_r"] + 1) - 1) // 32)  # census bits that are written: 9x9 -> 64
         if dom_name in MFMA_PEAK_TOPS:
             # The sweep runs on the matrix cores: the Hamming distance of two 64-bit census records is a 64-term dot product of
-            # +-1 operands (FP4, exact in the f32 accumulators; svh_census_sweep_mfma.hip: int8), i.e. 128 operations per voxel;
+            # +-1 operands (FP4, exact in the f32 accumulators), i.e. 128 operations per voxel;
             # these are the algorithmic operations of a launch.  The kernel issues (D/32 + 1) / (D/32) of them (the band of D
             # disparities is covered by D/32 + 1 row tiles of 32).
             peak = MFMA_PEAK_TOPS[dom_name]
-            fp4 = dom_name != "census_sweep_mfma"
+            fp4 = True
             ops = 2.0 * bits * vox_launch
             ach = ops / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
@@ -462,7 +460,7 @@ def main():
         # what no implementation of this step can go below on one GPU: the images in, the disparity map out (HBM), and the
         # Hamming dot products of every voxel on the fastest unit that can do them (matrix cores, FP4)
         compulsory = 12.0 * wl["W"] * wl["H"]
-        lb_us = max(compulsory / (HBM_PEAK_GBPS * 1e9), 2.0 * bits * (voxels / world) / (MFMA_PEAK_TOPS["census_sweep_mfma4"] * 1e12)) * 1e6
+        lb_us = max(compulsory / (HBM_PEAK_GBPS * 1e9), 2.0 * bits * (voxels / world) / (MFMA_PEAK_TOPS["census_sweep_pm"] * 1e12)) * 1e6
         kernel_ms = {k: round(v[0] / n_warm, 4) for k, v in prof_all.items()}  # warm-up steps, every kernel bracketed (each + one event pair)
         shape = f"{wl['W']}x{wl['H']}"
         line = {

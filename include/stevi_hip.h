@@ -98,9 +98,9 @@ const char *svh_last_error(const svh_context *ctx);
 /* Tuning / test switches.  "census_fast_path" (default 1): 0 forces the general wave-per-line SGM kernels
  * for census costs too (same results, used by the parity tests to cross-check the two implementations).
  * "census_sweep" (default 0 = automatic): engine of the voxel sweep of the fused census pipeline, 1 = the vector-ALU kernel
- * (xor + popcount), 2 / 3 = the matrix-core kernel with int8 / FP4 operands (Hamming distance as a dot product; at most 4 census
- * words, disp_count a multiple of 32 up to 992; int8: up to 480 and RightToLeft only -- anything else runs the vector-ALU kernel);
- * automatic = 3 where it applies.  Same keys bit for bit.
+ * (xor + popcount), 3 = the matrix-core kernels with FP4 operands (Hamming distance as a dot product; at most 4 census words,
+ * disp_count a multiple of 32 up to 992 -- anything else runs the vector-ALU kernel); automatic = 3 where it applies.  Same keys bit
+ * for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
  * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
  * (64 / 128 / 256 / 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
  * "census_float_overflow" (default 0): what becomes of a target census word that rounds to 2^32 on its way through `float`
@@ -117,10 +117,9 @@ const char *svh_last_error(const svh_context *ctx);
  * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
  * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  1: one sweep of the volume, a launch per band of 16
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23
- * instead of 44 bytes per voxel over all passes).  2: the same sweep as ONE launch, strips handed from block to block through
- * tagged granules in global memory (bit-identical, slower: DESIGN.md section 4.2a).  0: one read-modify-write sweep per pass.
+ * instead of 44 bytes per voxel over all passes).  0: one read-modify-write sweep per pass.
  * (3 = 1 with the 16-column strips forced that images narrower than about 3000 columns replace by 8-column ones: for the tests.)
- * Same bits in all three; the parity tests cross-check them. */
+ * Same bits in all of them; the parity tests cross-check them. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);

@@ -1,5 +1,5 @@
 // Shared by the census + SGM kernels of the exact regime (svh_census_sgm.hip) and the matrix-core sweep
-// (svh_census_sweep_mfma.hip): the geometry of a sweep and the winner keys.
+// (svh_census_sweep_pm.hip, svh_census_sweep_rl.hip): the geometry of a sweep and the winner keys.
 #pragma once
 
 #include "svh_internal.h"
@@ -59,10 +59,8 @@ __device__ __forceinline__ int winner_index(uint32_t k0, uint32_t k1, int n_vis,
     return take1 ? key_index(k1) : key_index(k0);
 }
 
-// census_sweep on the matrix cores (svh_census_sweep_mfma.hip); false when the geometry is outside what that kernel covers
-// (the caller then runs the VALU sweep)
-bool launch_sweep_mfma(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status);
-// 4-bit (FP4) operands +-1, persistent blocks (svh_census_sweep_pm.hip)
+// census_sweep on the matrix cores: 4-bit (FP4) operands +-1, persistent blocks (svh_census_sweep_pm.hip); false when the geometry is
+// outside what the kernel covers (the caller then runs the vector-ALU sweep)
 // (winner: write the index / disparity maps instead of keys and g)
 bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner = nullptr);
 // the same for RightToLeft geometries whose Pout region is "target column outside the image", 64 / 128 / 256 / 512 disparities, up

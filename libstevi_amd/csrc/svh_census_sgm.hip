@@ -611,11 +611,10 @@ size_t lds_bytes(int nWw, int D) { return (size_t)(nWw ? nWw : 1) * (TJ + D - 1)
 template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap) {
     // block width: the one that pads the row less (the lanes of a partial last block idle through the whole disparity loop);
     // 1080p: 5 blocks of 384 pixels instead of 3.75 of 512 -> 100 us instead of 106
-    // engines: 0 = automatic (4-bit matrix-core sweep, else 8-bit, else vector ALU), 1 = vector ALU, 2 = int8 MFMA, 3 = FP4 MFMA
+    // engines: 0 = automatic (FP4 matrix-core sweep where it applies, else vector ALU), 1 = vector ALU, 3 = FP4 matrix cores
     if (ctx->census_sweep_mode != 1) {
         int status = SVH_OK;
-        if (ctx->census_sweep_mode != 2 && launch_sweep_pm(ctx, g, Pout, keys, gmap, &status)) return status;
-        if (ctx->census_sweep_mode != 3 && launch_sweep_mfma(ctx, g, Pout, keys, gmap, &status)) return status;
+        if (launch_sweep_pm(ctx, g, Pout, keys, gmap, &status)) return status;
     }
     const int64_t pad512 = (int64_t)ceil_div(g.Ws, 512) * 512, pad384 = (int64_t)ceil_div(g.Ws, 384) * 384;
     if (pad384 < pad512) {

@@ -339,7 +339,6 @@ int svh_context_destroy(svh_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->pool)
         if (b.ptr) (void)hipFree(b.ptr);
-    if (ctx->sgm_edges) (void)hipFree(ctx->sgm_edges);
     for (auto &p : ctx->prof_pending) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
@@ -365,7 +364,7 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         return SVH_OK;
     }
     if (strcmp(name, "census_sweep") == 0) {
-        if (value < 0 || value > 3) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_sweep: 0 (auto), 1 (vector ALU), 2 (matrix cores, int8) or 3 (matrix cores, FP4)");
+        if (value != 0 && value != 1 && value != 3) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_sweep: 0 (auto), 1 (vector ALU) or 3 (matrix cores, FP4)");
         ctx->census_sweep_mode = (int)value;
         return SVH_OK;
     }
@@ -391,8 +390,8 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         return SVH_OK;
     }
     if (strcmp(name, "sgm_score_fused") == 0) {
-        if (value < 0 || value > 3)
-            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows), 2 (strips in one launch), 3 (bands, 16-column strips forced)");
+        if (value != 0 && value != 1 && value != 3)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows), 3 (bands, 16-column strips forced)");
         ctx->sgm_score_fused = value;
         return SVH_OK;
     }
@@ -416,9 +415,6 @@ int svh_context_trim(svh_context *ctx) {
         else if (b.ptr) (void)hipFree(b.ptr);
     }
     ctx->pool.swap(keep);
-    if (ctx->sgm_edges) (void)hipFree(ctx->sgm_edges);
-    ctx->sgm_edges = nullptr;
-    ctx->sgm_edges_bytes = 0;
     return SVH_OK;
 }
 

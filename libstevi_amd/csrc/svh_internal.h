@@ -47,17 +47,12 @@ struct svh_context {
     int64_t prof_seen = 0;
     bool census_fast_path = true; // svh_context_set_option("census_fast_path")
     bool census_winner_shortcut = true; // svh_context_set_option("census_winner_shortcut"): index / disparity maps without the line scans
-    int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 VALU kernel, 2 matrix-core kernel
+    int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 vector-ALU kernel, 3 FP4 matrix-core kernels
     int census_float_overflow = 0;     // svh_context_set_option("census_float_overflow"): rule E2 when a target word rounds to 2^32: 0 saturate (0xFFFFFFFF), 1 zero
     int census_sweep_rl = 1;       // svh_context_set_option("census_sweep_rl"): the FP4 engine may use its RightToLeft specialisation (svh_census_sweep_rl.hip)
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
-    int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 2 strips; 0: a launch per pass)
-    // edge states handed from strip to strip by the strip form of the fused Score-branch sweep (svh_sgm_sweep.hip): {value, tag} granules.  Written by
-    // nothing else and zeroed when allocated, so a granule whose tag equals the launch's number was written by that launch.
-    void *sgm_edges = nullptr;
-    size_t sgm_edges_bytes = 0;
-    uint32_t sgm_edges_tag = 0;
+    int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;

@@ -77,7 +77,7 @@ def test_census_sgm_every_engine_both_modes(modes, D, W):
         cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
         want = so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST)
         keys = []
-        for mode, rl in ((1, 1), (2, 1), (3, 0), (3, 1)):
+        for mode, rl in ((1, 1), (3, 0), (3, 1)):
             sv.set_option(l, "census_sweep", mode)
             sv.set_option(l, "census_sweep_rl", rl)
             keys.append(sv.censusShardKeys(l, r, 4, 4, D, (0, D), sgmDirections=8, Pout=100.0).cpu().numpy())

@@ -176,19 +176,21 @@ def test_c5_shards_8k_fullsize():
 @pytest.mark.parametrize("W", [4096, 8192])
 def test_census_sgm_wide_short_images_vs_oracle(W):
     """The fused census + SGM path at C4 / C5 widths (row scans wider than 2048 pixels, the exact-regime bound near its limit),
-    on an image short enough for the oracle to run whole; all three sweep engines."""
+    on an image short enough for the oracle to run whole; every sweep engine (vector ALU, the general and the RightToLeft FP4 kernels)."""
     H, D = 36, 256
     src, tgt, _ = parallax_pair(H, W, 20, 8, 100, 16, 130, seed=W)
     d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
     cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
     want = so.index_to_disp(so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
-    for engine in (0, 1, 2):
+    for engine, rl in ((0, 1), (1, 1), (3, 0)):
         try:
             sv.set_option(d_tgt, "census_sweep", engine)
+            sv.set_option(d_tgt, "census_sweep_rl", rl)
             got = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, sgmDirections=8, Pout=100.0)["disp"].cpu().numpy()
         finally:
             sv.set_option(d_tgt, "census_sweep", 0)
-        assert np.array_equal(got, want), engine
+            sv.set_option(d_tgt, "census_sweep_rl", 1)
+        assert np.array_equal(got, want), (engine, rl)
 
 
 def test_shards_beyond_1024_disparities_vs_oracle():

@@ -1,7 +1,6 @@
 """The Score branch of sgmCostVolume (sgm.h:218-255, :329-389) with the four downward passes carried by one sweep of the volume
 (svh_sgm_sweep.hip; option "sgm_score_fused": 1 = sgm_score_band_kernel, a launch per band of rows with the neighbours' entering lines
-recomputed; 2 = sgm_score_down_kernel, strips of the skewed image handed from block to block) against the pass-per-launch kernels
-and the oracle: same bits."""
+recomputed; 3 = the same with 16-column strips forced) against the pass-per-launch kernels and the oracle: same bits."""
 import numpy as np
 import pytest
 
@@ -23,8 +22,8 @@ def bits(x):
     return np.ascontiguousarray(x, np.float32).view(np.uint32)
 
 
-FORMS = [1, 3, 2]  # 1: a launch per band of 16 rows (halos recomputed; 8-column strips at these widths), 3: the same with the 16-column
-# strips of wide images, 2: strips handed from block to block inside one launch
+FORMS = [1, 3]  # 1: a launch per band of 16 rows (halos recomputed; 8-column strips at these widths), 3: the same with the 16-column
+# strips of wide images
 
 
 def both_forms(cv, P1, P2, Pout, form):
@@ -99,7 +98,7 @@ def test_fused_forms_on_random_geometries(seed):
         ok = ~np.isnan(exp)
         d = torch.from_numpy(cv).to(DEV)
         try:
-            for form in (0, 1, 2, 3):
+            for form in (0, 1, 3):
                 sv.set_option(d, "sgm_score_fused", form)
                 got = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout).cpu().numpy()
                 what = f"case {case} form {form}: {H}x{W}x{D} P1={P1} P2={P2} Pout={Pout}"

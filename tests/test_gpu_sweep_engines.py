@@ -1,8 +1,9 @@
-"""The three engines of census_sweep -- the vector-ALU kernel (xor + popcount), the matrix-core kernel with int8 operands
-(Hamming distance as a dot product, svh_census_sweep_mfma.hip) and the matrix-core kernel with FP4 operands
-(svh_census_sweep_pm.hip) -- must give the same regional winner keys bit for bit, and all the oracle's disparities.
-svh_context_set_option("census_sweep", 1 | 2 | 3) selects the engine; 0 (default) takes the matrix cores wherever they apply
-(1..4 census words, D a multiple of 32 up to 992; the int8 form only RightToLeft and up to 480) and the vector ALU elsewhere."""
+"""The engines of census_sweep -- the vector-ALU kernel (xor + popcount) and the two matrix-core kernels with FP4 operands (Hamming
+distance as a dot product: svh_census_sweep_pm.hip for any geometry, svh_census_sweep_rl.hip for RightToLeft ranges that end at the
+image edge with 64 / 128 / 256 / 512 disparities) -- must give the same regional winner keys bit for bit, and all the oracle's
+disparities.  svh_context_set_option("census_sweep", 1 | 3) selects the engine and "census_sweep_rl" 0 keeps the FP4 engine on its
+general kernel; 0 (default) takes the matrix cores wherever they apply (1..4 census words, D a multiple of 32 up to 992) and the
+vector ALU elsewhere."""
 import numpy as np
 import pytest
 
@@ -21,11 +22,11 @@ DEV = torch.device("cuda:0")
 
 
 def both_engines(fn, probe):
-    """vector ALU, int8 matrix cores, FP4 matrix cores (general kernel), FP4 with its RightToLeft specialisation allowed
+    """vector ALU, FP4 matrix cores (general kernel), FP4 with its RightToLeft specialisation allowed
     (svh_census_sweep_rl.hip: taken where the geometry fits, the general kernel elsewhere)"""
     out = []
     try:
-        for mode, rl in ((1, 1), (2, 1), (3, 0), (3, 1)):
+        for mode, rl in ((1, 1), (3, 0), (3, 1)):
             sv.set_option(probe, "census_sweep", mode)
             sv.set_option(probe, "census_sweep_rl", rl)
             out.append(fn())
@@ -52,15 +53,14 @@ def test_keys_and_disparities_agree(D, W):
         disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, h_r, h_r, D, sgmDirections=n_dir, Pout=Pout)["disp"].cpu().numpy(), l)
         assert all(np.array_equal(disp[0], d) for d in disp[1:])
         if W <= 384 and (D <= 480 or W < 100):
-            assert np.array_equal(disp[2], oracle_disp(tgt, src, h_r, D, n_dir, Pout))
+            assert np.array_equal(disp[-1], oracle_disp(tgt, src, h_r, D, n_dir, Pout))
 
 
 @pytest.mark.parametrize("D", [32, 96, 256])
 @pytest.mark.parametrize("W", [97, 420, 700])
 def test_left_to_right(D, W):
     """LeftToRight: target column j - lower - d.  The FP4 kernel mirrors the window and the lanes; the Pout boundary then moves by
-    two cells per lane, so up to three row tiles of a column tile are masked per cell (the int8 kernel leaves this direction to the
-    vector ALU)."""
+    two cells per lane, so up to three row tiles of a column tile are masked per cell."""
     src, tgt, _ = parallax_pair(11, W, 9, 3, min(40, W // 3), 2, 13, seed=3 * D + W)
     l, r = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)  # roles swapped: the left image is the source
     L2R = sv.dispDirection.LeftToRight
@@ -72,7 +72,7 @@ def test_left_to_right(D, W):
         if W <= 420 and isinstance(rng_, int):
             cv = so.unfold_cost_volume(so.CENSUS, src, tgt, h_r, h_r, D, so.LEFT_TO_RIGHT)
             vol = so.sgm(cv, n_dir, so.COST, 0.001, 0.01, (0, 0, 0, 0), Pout) if n_dir else cv
-            assert np.array_equal(disp[2], so.index_to_disp(so.extract_index(vol, so.COST), so.LEFT_TO_RIGHT))
+            assert np.array_equal(disp[-1], so.index_to_disp(so.extract_index(vol, so.COST), so.LEFT_TO_RIGHT))
     # shards in this direction
     for shard in ((0, 32), (32, D - 32)) if D > 32 else ((0, 32),):
         keys = both_engines(lambda: sv.censusShardKeys(l, r, 4, 4, D, shard, dDir=L2R, sgmDirections=8).cpu().numpy(), l)
@@ -81,7 +81,7 @@ def test_left_to_right(D, W):
 
 def test_four_census_words():
     """13 x 11 windows: 142 census bits = four written words, the most the matrix-core kernels take (two MFMAs per tile with FP4
-    operands, four with int8)."""
+    operands)."""
     src, tgt, _ = parallax_pair(15, 200, 9, 3, 40, 2, 11, seed=31)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for D in (64, 160):
@@ -90,7 +90,7 @@ def test_four_census_words():
         disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, 6, 5, D, sgmDirections=8, Pout=100.0)["disp"].cpu().numpy(), l)
         assert all(np.array_equal(disp[0], d) for d in disp[1:])
         cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 6, 5, D)
-        assert np.array_equal(disp[2], so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
+        assert np.array_equal(disp[-1], so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
 
 
 def test_ties_everywhere():
@@ -134,13 +134,14 @@ def test_shards_offsets_and_margins():
 
 
 def test_geometries_outside_the_matrix_core_kernel_still_run():
-    """D not a multiple of 32, D > 992, 13x13 windows (5 words), LeftToRight for the int8 form: the options fall back to the vector
-    ALU kernel."""
+    """D not a multiple of 32, D > 992, 13x13 windows (5 words): the options fall back to the vector ALU kernel; LeftToRight stays on
+    the general FP4 kernel."""
     src, tgt, _ = parallax_pair(9, 260, 8, 3, 30, 2, 9, seed=5)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for kw in (dict(D=64, dDir=sv.dispDirection.LeftToRight, h=4), dict(D=70, dDir=sv.dispDirection.RightToLeft, h=4),
                dict(D=1024, dDir=sv.dispDirection.RightToLeft, h=4), dict(D=64, dDir=sv.dispDirection.RightToLeft, h=6)):
         disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, kw["h"], kw["h"], kw["D"], dDir=kw["dDir"], sgmDirections=8)["disp"].cpu().numpy(), l)
         assert all(np.array_equal(disp[0], d) for d in disp[1:])
-    with pytest.raises(sv._capi.SvhError):
-        sv.set_option(l, "census_sweep", 4)
+    for bad in (2, 4):  # (2 was round 1's int8 matrix-core engine: removed)
+        with pytest.raises(sv._capi.SvhError):
+            sv.set_option(l, "census_sweep", bad)

@@ -196,11 +196,28 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
                            const svh_array *img_r, int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count,
                            svh_array *cv);
 
+/* The same with a by-product for a later sgmCostVolume<.., Cost> on the volume: minima (H,Ws,2) f32 = per pixel the smallest cost among
+ * the disparities d with j + d < Ws and among those with j + d >= Ws (the ones sgm.h:287-289 charges Pout; +inf where there are none).
+ * Census / Hamming only (integer costs <= 32 words): *minima_written = 1 when they were produced, 0 otherwise (the array is then left
+ * untouched).  See svh_sgm_cost_volume_minima. */
+int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r,
+                                  int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima,
+                                  int *minima_written);
+
 /* ---- A9  sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout)      correlation/sgm.h:360-404
  * cv (H,W,D) f32 -> out (H,W,D) f32.  n_directions 4 or 8 (16 is a data race in the reference and unsupported).
  * margins = {left, top, right, bottom}.  Reproduces the reference as written. */
 int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
                         const int32_t margins[4], float Pout, svh_array *out);
+/* The Cost branch on a volume the caller knows two things about: every entry is an integer with |c| <= max_abs, and `minima` holds its
+ * regional minima as svh_unfold_cost_volume_minima writes them.  When a Cost-branch call finds integer costs small enough for every
+ * float operation of sgm.h:257-300 to be exact it takes a shortcut (the per-pass minima follow mp' = g - mp from one map g); it
+ * normally establishes that -- and g -- with one extra read of the whole volume.  With the statement that read is skipped: same output
+ * bit for bit, 4 bytes per voxel less.  The statement is the caller's responsibility: the C++ drop-in keeps it attached to the
+ * DeviceArray it came with and drops it at the first non-const access (correlation/stevi_hip_bridge.h), the Python mirror ties it to
+ * the tensor's version counter.  Score strategy: minima are ignored. */
+int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
+                               float P1, float P2, const int32_t margins[4], float Pout, svh_array *out);
 
 /* "Textbook" semi-global matching -- NOT the reference's behaviour, an explicit second mode:
  * every one of the 4 / 8 directions traverses every line of the margin box once (the reference skips three directions and half of

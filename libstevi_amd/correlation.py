@@ -328,9 +328,32 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
         return _empty_like(l, 3, "f32")
     src = r if int(dDir) == dispDirection.RightToLeft else l
     out = _like(l, (src.shape[0], src.shape[1], D), "f32")
+    if _is_torch(out) and int(matchFunc) in (matchingFunctions.CENSUS, matchingFunctions.HAMMING):
+        # device volume of integer costs: keep what a later sgmCostVolume<Cost> on it would otherwise re-read the volume for
+        # (svh_unfold_cost_volume_minima), tied to this tensor's storage and version counter: any in-place change drops it
+        minima = _like(l, (src.shape[0], src.shape[1], 2), "f32")
+        written = C.c_int(0)
+        st = _check(ctx, lib.svh_unfold_cost_volume_minima(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
+                                                           lower, D, C.byref(_desc(out)), C.byref(_desc(minima)), C.byref(written)))
+        if st == _capi.OK and written.value:
+            nWw = ((2 * h_radius + 1) * (2 * v_radius + 1) * (l.shape[2] if l.ndim == 3 else 1) - 1) // 32
+            out._svh_minima = (minima, float(32 * nWw), out.data_ptr(), out._version, tuple(out.shape))
+        return out if st == _capi.OK else _empty_like(l, 3, "f32")
     st = _check(ctx, lib.svh_unfold_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
                                                 lower, D, C.byref(_desc(out))))
     return out if st == _capi.OK else _empty_like(l, 3, "f32")
+
+
+def _volume_minima(cv):
+    """The regional minima unfoldBasedCostVolume left with a device volume, if the tensor is still the one it wrote (same storage,
+    same shape, version counter untouched: no in-place operation since)."""
+    hint = getattr(cv, "_svh_minima", None) if _is_torch(cv) else None
+    if hint is None:
+        return None
+    minima, max_abs, ptr, version, shape = hint
+    if cv.data_ptr() != ptr or cv._version != version or tuple(cv.shape) != shape or not cv.is_contiguous():
+        return None
+    return minima, max_abs
 
 
 def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0, semantics="reference"):
@@ -344,6 +367,11 @@ def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None
     out = _like(cv, tuple(cv.shape), "f32")
     if semantics not in ("reference", "textbook"):
         raise ValueError("semantics is 'reference' or 'textbook'")
+    hint = _volume_minima(cv_base) if (semantics == "reference" and int(extractionStrategy) == dispExtractionStartegy.Cost) else None
+    if hint is not None:  # same bits, one read of the volume less (svh_sgm_cost_volume_minima)
+        _check(ctx, lib.svh_sgm_cost_volume_minima(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), C.byref(_desc(hint[0])),
+                                                   C.c_float(hint[1]), P1, P2, (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out))))
+        return out
     fn = lib.svh_sgm_cost_volume if semantics == "reference" else lib.svh_sgm_cost_volume_textbook
     _check(ctx, fn(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), P1, P2, (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out))))
     return out

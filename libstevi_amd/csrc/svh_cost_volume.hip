@@ -8,6 +8,7 @@
 // costs are contiguous, which is what the per-line SGM kernels and the winner scan want.
 #include "svh_internal.h"
 #include "svh_compare.h"
+#include "svh_sgm_lines.h"
 
 namespace svh {
 
@@ -60,7 +61,7 @@ constexpr int HV_TP = 64;
 template <int NW>
 __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int H,
                                                                    int Ws, int Wt, int D, int sign, int disp_lower, int row_off, int64_t px_stride,
-                                                                   int64_t out_off, float *__restrict__ cv) {
+                                                                   int64_t out_off, float *__restrict__ cv, float2 *__restrict__ minima) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
     const int n_rec = HV_TP + D - 1;
@@ -84,12 +85,39 @@ __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_
         for (int w = 0; w < NW; w++) s[w] = lsrc[u * NW + w];
         const uint32_t *base = lds + (sign > 0 ? u : HV_TP - 1 - u) * NW;
         float *out = cv + p * px_stride + out_off;
-        for (int d = lane; d < D; d += 64) {
-            uint32_t score = 0;
+        if (!minima) { // (uniform)
+            for (int d = lane; d < D; d += 64) {
+                uint32_t score = 0;
 #pragma unroll
-            for (int w = 0; w < NW; w++) score += __popc(s[w] ^ base[d * NW + w]);
-            out[d] = (float)score;
+                for (int w = 0; w < NW; w++) score += __popc(s[w] ^ base[d * NW + w]);
+                out[d] = (float)score;
+            }
+            continue;
         }
+        // also the hint of svh_unfold_cost_volume_minima: the smallest cost among the disparities that do not / do pay Pout in a later
+        // sgmCostVolume (sgm.h:287-289: j + d >= W), what that call would otherwise read the whole volume for.  The boundary is one
+        // disparity per pixel: whole rounds of 64 disparities fall on one side of it (wave-uniform branches), at most one straddles.
+        float m0 = INFINITY, m1 = INFINITY;
+        const int first_paying = Ws - (j0 + u);
+        for (int d0 = 0; d0 < D; d0 += 64) {
+            const int d = d0 + lane;
+            uint32_t score = 0;
+            if (d < D) {
+#pragma unroll
+                for (int w = 0; w < NW; w++) score += __popc(s[w] ^ base[d * NW + w]);
+                out[d] = (float)score;
+            }
+            const float c = d < D ? (float)score : INFINITY;
+            if (d0 + 64 <= first_paying) m0 = fminf(m0, c);
+            else if (d0 >= first_paying) m1 = fminf(m1, c);
+            else {
+                m0 = fminf(m0, d < first_paying ? c : INFINITY);
+                m1 = fminf(m1, d < first_paying ? INFINITY : c);
+            }
+        }
+        m0 = wave_min(m0);
+        m1 = wave_min(m1);
+        if (lane == 0) minima[p] = make_float2(m0, m1);
     }
 }
 
@@ -98,7 +126,7 @@ static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, cons
     dim3 grid(ceil_div(a.Ws, HV_TP), a.H);
     const size_t shmem = (size_t)NW * (2 * HV_TP + a.D - 1) * sizeof(uint32_t);
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off,
-               a.px_stride(), a.out_off, cv);
+               a.px_stride(), a.out_off, cv, reinterpret_cast<float2 *>(a.minima));
 }
 
 // 2-D search ranges (aggregateCost(searchOffset<2>), cross_correlations.h:310-374): every vertical offset's target records are
@@ -216,6 +244,7 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
         default: launch_hamming_tiled<4>(ctx, a, src_words, tgt_words, sign, cv); break;
         }
         SVH_CHECK_LAUNCH(ctx);
+        if (a.minima_written) *a.minima_written = a.minima != nullptr;
         return SVH_OK;
     }
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_kernel, grid_for(n, 256, 65536), 256, 0, src_words, tgt_words, nWw, a.H, a.Ws,
@@ -292,10 +321,12 @@ int svh_feature_cost_volume(svh_context *ctx, int match_func, int disp_direction
     return finish_out(ctx, os);
 }
 
-int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l,
-                           const svh_array *img_r, int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count,
-                           svh_array *cv) {
+} // extern "C"
+
+static int unfold_cost_volume_impl(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r, int h_radius,
+                                   int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima, int *minima_written) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (minima_written) *minima_written = 0;
     SVH_TRY(validate_image(ctx, img_l, "img_l", match_func));
     SVH_TRY(validate_image(ctx, img_r, "img_r", match_func));
     SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
@@ -319,13 +350,36 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
         return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv must have shape (%d,%d,%d)", a.H, a.Ws, a.D);
     Scratch scr(ctx);
     void *ds, *dt;
-    OutStage os;
+    OutStage os, om;
     SVH_TRY(stage_image(ctx, scr, *src, &ds));
     SVH_TRY(stage_image(ctx, scr, *tgt, &dt));
     SVH_TRY(stage_out(ctx, scr, *cv, &os));
+    int written = 0;
+    if (minima && func_census(match_func)) { // (other functions: the hint does not exist; *minima_written stays 0)
+        SVH_TRY(validate(ctx, minima, "minima", SVH_F32, 3, 3));
+        if (minima->shape[0] != a.H || minima->shape[1] != a.Ws || minima->shape[2] != 2)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima must have shape (%d,%d,2)", a.H, a.Ws);
+        SVH_TRY(stage_out(ctx, scr, *minima, &om));
+        a.minima = (float *)om.dptr;
+        a.minima_written = &written;
+    }
     SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, {(const float *)ds, a.H, a.Ws, C}, {(const float *)dt, a.H, a.Wt, C}, h_radius,
                                         v_radius, (float *)os.dptr));
+    if (written) SVH_TRY(finish_out(ctx, om));
+    if (minima_written) *minima_written = written;
     return finish_out(ctx, os);
+}
+
+extern "C" {
+
+int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r, int h_radius,
+                           int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv) {
+    return unfold_cost_volume_impl(ctx, match_func, disp_direction, img_l, img_r, h_radius, v_radius, disp_lower, disp_count, cv, nullptr, nullptr);
+}
+
+int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r, int h_radius,
+                                  int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima, int *minima_written) {
+    return unfold_cost_volume_impl(ctx, match_func, disp_direction, img_l, img_r, h_radius, v_radius, disp_lower, disp_count, cv, minima, minima_written);
 }
 
 } // extern "C"

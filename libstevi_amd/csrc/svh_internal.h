@@ -213,6 +213,10 @@ struct CostVolumeArgs {
     int64_t out_off = 0;
     bool literal = false;        // skip the register-blocked kernel: the reference's operations in the reference's order
     WindowStatsCache *stats = nullptr; // optional: statistics maps shared by several passes over the same image pair
+    // census / Hamming volumes: per pixel the smallest cost among the disparities that do not / do pay Pout in a later sgmCostVolume
+    // (device, (H, Ws) float2; svh_unfold_cost_volume_minima); *minima_written says whether the kernel that ran produced them
+    float *minima = nullptr;
+    int *minima_written = nullptr;
     int sign() const { return force_sign ? force_sign : (ddir == SVH_RIGHT_TO_LEFT ? 1 : -1); }
     int64_t px_stride() const { return out_px_stride ? out_px_stride : D; }
 };
@@ -246,6 +250,10 @@ struct CostSource {
     // the Pout region's winner over ALL shards is known locally -- cost |s|, this index (the last of the whole range) -- and the
     // sweep writes that instead of its own shard's: the second key plane then needs no exchange.  -1: plain regional keys.
     int region1_global_last = -1;
+    // dense volume + the caller's statement about it (svh_sgm_cost_volume_minima): every cost an integer of magnitude <= max_abs, and per pixel
+    // the minima over the two regions of sgm.h:287-289 -- what the probe pass over the volume would otherwise establish
+    const float *minima = nullptr;
+    float max_abs = 0.0f;
 };
 // per-pixel outputs of the winner stage; every pointer is optional
 struct WinnerOut {

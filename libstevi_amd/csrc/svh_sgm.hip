@@ -352,6 +352,15 @@ __global__ void __launch_bounds__(256) volume_gmin_probe_kernel(SrcVolume src, i
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
+// g(p) = min_d [c + (c [+ Pout])] from the two regional minima of the pixel (an empty region holds +inf)
+__global__ void gmap_from_minima_kernel(const float2 *__restrict__ minima, int64_t npx, float Pout, float *__restrict__ gmap) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p < npx) {
+        const float2 m = minima[p];
+        gmap[p] = fminf(m.x + m.x, m.y + (m.y + Pout));
+    }
+}
+
 // ---- Score branch: read-modify-write sweep per pass ----------------------------------------------------
 // FAR_IS_GLOBAL: P2 >= P1 >= 0.  Then fl(prev[od] - P2) <= fl(prev[od] - P1) <= prev[od] for every od (x -> fl(x - P) is
 // monotone and P >= 0), so the three disparities excluded from the |od - nd| > 1 class are each dominated by a candidate
@@ -587,6 +596,15 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
                                a.Pout == std::nearbyint(a.Pout) && limit >= 1.0 && a.D <= 1024;
         if (!try_exact) return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
         const int64_t npx = (int64_t)a.H * a.W;
+        if (cs.minima && cs.max_abs <= (float)limit) {
+            // the caller vouches for what the probe would find (svh_sgm_cost_volume_minima): g from the two regional minima, no read of C
+            float *gmap = scr.get_n<float>((size_t)npx);
+            if (!gmap) return SVH_ERR_OUT_OF_MEMORY;
+            SVH_LAUNCH(ctx, "gmap_from_minima", gmap_from_minima_kernel, grid_for(npx, 256), 256, 0, reinterpret_cast<const float2 *>(cs.minima), npx, a.Pout, gmap);
+            SVH_CHECK_LAUNCH(ctx);
+            SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, nullptr));
+            return dispatch_cost_branch(ctx, a, src, mmap, &out, false);
+        }
         float *gmap = scr.get_n<float>((size_t)npx);
         int *flag = scr.get_n<int>(64);
         if (!gmap || !flag) return SVH_ERR_OUT_OF_MEMORY;
@@ -729,8 +747,8 @@ int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const
 
 using namespace svh;
 
-extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
-                                   const int32_t margins[4], float Pout, svh_array *out) {
+static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs, float P1, float P2,
+                                const int32_t margins[4], float Pout, svh_array *out) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
     SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
@@ -754,12 +772,32 @@ extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strat
     if (strategy == SVH_COST) {
         CostSource cs;
         cs.cv = (const float *)dcv;
+        if (minima) {
+            SVH_TRY(validate(ctx, minima, "minima", SVH_F32, 3, 3));
+            if (minima->shape[0] != cv->shape[0] || minima->shape[1] != cv->shape[1] || minima->shape[2] != 2)
+                return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima must have shape (H,W,2)");
+            if (!(max_abs >= 0.0f)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "max_abs must be a non-negative number");
+            void *dmin;
+            SVH_TRY(stage_in(ctx, scr, *minima, &dmin));
+            cs.minima = (const float *)dmin;
+            cs.max_abs = max_abs;
+        }
         SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, WinnerOut()));
     } else {
         if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
         SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr, false));
     }
     return finish_out(ctx, os);
+}
+
+extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
+                                   const int32_t margins[4], float Pout, svh_array *out) {
+    return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, nullptr, 0.0f, P1, P2, margins, Pout, out);
+}
+
+extern "C" int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
+                                          float P1, float P2, const int32_t margins[4], float Pout, svh_array *out) {
+    return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, minima, max_abs, P1, P2, margins, Pout, out);
 }
 
 // "Textbook" semi-global matching: NOT the reference's behaviour -- what correlation/sgm.h

@@ -177,10 +177,28 @@ DeviceArray<TCV, 3> unfoldBasedCostVolumeOnDevice(Multidim::Array<T_L, nImDim> c
     DeviceArray<TCV, 3> cv({src[0], src[1], static_cast<int>(disp_width)});
     if (cv.empty()) return cv;
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
-    if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
-                                                 disp_width, &out)))
-        return DeviceArray<TCV, 3>();
-    return cv;
+    if constexpr (matchFunc == matchingFunctions::CENSUS || matchFunc == matchingFunctions::HAMMING) {
+        // integer costs: also keep the per-pixel regional minima a later sgmCostVolume<.., Cost> would otherwise read the volume for
+        DeviceArray<float, 3> minima({src[0], src[1], 2});
+        svh_array mn = HipBridge::describe(minima);
+        int written = 0;
+        if (!HipBridge::check(svh_unfold_cost_volume_minima(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius,
+                                                            0, disp_width, &out, &mn, &written)))
+            return DeviceArray<TCV, 3>();
+        if (written) {
+            auto st = std::make_shared<typename DeviceArray<TCV, 3>::Statement>();
+            st->minima = minima.share();
+            const int channels = nImDim == 3 ? l_shape[nImDim - 1] : 1;
+            st->max_abs = static_cast<float>(32 * (((2 * h_radius + 1) * (2 * v_radius + 1) * channels - 1) / 32));
+            cv.attach(st);
+        }
+        return cv;
+    } else {
+        if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
+                                                     disp_width, &out)))
+            return DeviceArray<TCV, 3>();
+        return cv;
+    }
 }
 
 // unfoldBasedCostVolume(img_l, img_r, compressor, disp_width), cross_correlations.h:767-791

@@ -40,6 +40,23 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
+    if (extractionStrategy == dispExtractionStartegy::Cost && cv_base.statement()) {
+        // a volume the library wrote and nobody has touched: its regional minima come with it, the probe pass over the volume is skipped
+        svh_array mn{};
+        mn.data = cv_base.statement()->minima.get();
+        mn.ndim = 3;
+        mn.dtype = SVH_F32;
+        mn.memspace = SVH_DEVICE;
+        mn.shape[0] = cv_base.shape()[0];
+        mn.shape[1] = cv_base.shape()[1];
+        mn.shape[2] = 2;
+        mn.strides[0] = 2 * static_cast<int64_t>(cv_base.shape()[1]);
+        mn.strides[1] = 2;
+        mn.strides[2] = 1;
+        HipBridge::check(svh_sgm_cost_volume_minima(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, &mn, cv_base.statement()->max_abs,
+                                                    P1, P2, m, Pout, &out));
+        return sgm_cv;
+    }
     HipBridge::check(svh_sgm_cost_volume(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
     return sgm_cv;
 }

@@ -153,6 +153,9 @@ inline bool check(int status) {
 // selectedCost that take DeviceArray arguments return DeviceArray results (same names, same template parameters), and
 // unfoldBasedCostVolumeOnDevice / featureVolume2CostVolumeOnDevice start such a chain from host images.  download() is the one
 // transfer back.  The memory is freed with the last copy of the handle, on its device, whatever has become of the context and the thread that allocated it.
+template <class T, int N> class DeviceArray;
+template <class T, int N> inline svh_array describe(DeviceArray<T, N> const &a);
+
 template <class T, int N> class DeviceArray {
   public:
     using ShapeBlock = std::array<int, N>;
@@ -223,22 +226,39 @@ template <class T, int N> class DeviceArray {
     }
     ShapeBlock const &shape() const { return _shape; }
     bool empty() const { return !_mem || flatLenght() == 0; }
+    // What the library knows about a volume it wrote itself and that has not been written to since (svh_unfold_cost_volume_minima /
+    // svh_sgm_cost_volume_minima in include/stevi_hip.h): the regional minima of a census / Hamming cost volume and the bound on its
+    // integer costs.  Attached by unfoldBasedCostVolumeOnDevice, read by sgmCostVolume<.., Cost>, gone the moment anybody asks for a
+    // pointer the volume could be written through (data() on a non-const array): const access cannot invalidate it.
+    struct Statement {
+        std::shared_ptr<float> minima; // device, (H, W, 2)
+        float max_abs = 0;
+    };
+    std::shared_ptr<const Statement> const &statement() const { return _statement; }
+    void attach(std::shared_ptr<const Statement> st) { _statement = std::move(st); }
+    std::shared_ptr<T> share() const { return _mem; } // the memory itself, kept alive by whoever holds the pointer
     std::size_t flatLenght() const { // (sic) as Multidim::Array
         std::size_t n = 1;
         for (int k = 0; k < N; k++) n *= static_cast<std::size_t>(_shape[k] > 0 ? _shape[k] : 0);
         return n;
     }
-    T *data() const { return _mem.get(); }
+    T const *data() const { return _mem.get(); }
+    T *data() {
+        _statement.reset(); // the caller may write: whatever was known about the contents is no longer
+        return _mem.get();
+    }
 
   private:
+    template <class U, int M> friend svh_array describe(DeviceArray<U, M> const &a);
     ShapeBlock _shape;
     std::shared_ptr<T> _mem;
+    std::shared_ptr<const Statement> _statement;
 };
 
 template <class T, int N> inline svh_array describe(DeviceArray<T, N> const &a) {
     static_assert(N <= SVH_MAX_DIMS, "too many dimensions");
     svh_array d{};
-    d.data = a.data();
+    d.data = a._mem.get(); // (the shims write results through descriptors of arrays they have just created: nothing is attached yet)
     d.ndim = N;
     d.dtype = DType<std::remove_const_t<T>>::value;
     d.memspace = SVH_DEVICE;

@@ -65,6 +65,18 @@ int main(int argc, char **argv) {
         Multidim::Array<float, 2> dref =
             SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(SC::truncatedCostVolume(dSGM, dIdx, h_r, v_r, 1), dIdx).download();
         dump(out + "_census_disp_dev.i32", FE(ddisp), ddisp.flatLenght());
+        // dCV came with the library's statement about its contents (regional minima: sgmCostVolume<Cost> skipped its probe pass above); a
+        // pointer the volume could be written through drops it, and the call takes the probing path: the same map either way
+        auto dCVt = dCV;
+        const bool had = static_cast<bool>(dCVt.statement());
+        (void)dCVt.data();
+        if (!had || dCVt.statement() || !dCV.statement()) {
+            fprintf(stderr, "DeviceArray statement: attached %d, kept after a mutable access %d\n", (int)had, (int)static_cast<bool>(dCVt.statement()));
+            return 5;
+        }
+        Multidim::Array<SC::disp_t, 2> tdisp = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(
+            SC::extractSelectedIndex<strat>(SC::sgmCostVolume<8, strat>(dCVt, P1, P2, StereoVision::Margins(), Pout)), 0).download();
+        dump(out + "_census_disp_dev_touched.i32", FE(tdisp), tdisp.flatLenght());
         dump(out + "_census_ref_dev.f32", FE(dref), dref.flatLenght());
         Multidim::Array<float, 2> href = SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(
             SC::truncatedCostVolume(SGM_CV, SC::extractSelectedIndex<strat>(SGM_CV), h_r, v_r, 1), SC::extractSelectedIndex<strat>(SGM_CV));

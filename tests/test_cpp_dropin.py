@@ -57,6 +57,8 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     assert np.array_equal(got_disp, so.index_to_disp(so.extract_index(vol, so.COST)))
     # the same chain on HipBridge::DeviceArray (volumes never leave the GPU) gives the same bits
     assert np.array_equal(np.fromfile(tmp_path / "o_census_disp_dev.i32", np.int32).reshape(H, W), got_disp)
+    # ... with or without the library's statement about the volume's contents (dropped by a mutable access)
+    assert np.array_equal(np.fromfile(tmp_path / "o_census_disp_dev_touched.i32", np.int32).reshape(H, W), got_disp)
     # ... also when the volume was made by a thread that has exited since (the array is freed by device, not through that thread's context)
     assert np.array_equal(np.fromfile(tmp_path / "o_census_disp_handed.i32", np.int32).reshape(H, W), got_disp)
     a, b = np.fromfile(tmp_path / "o_census_ref_dev.f32", np.float32), np.fromfile(tmp_path / "o_census_ref_host.f32", np.float32)

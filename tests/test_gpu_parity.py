@@ -604,3 +604,43 @@ def test_textbook_sgm_differs_from_the_reference_mode(rng):
     tb = host(sv.sgmCostVolume(8, so.COST, dev(cv), 0.5, 2.0, sv.Margins(), 100.0, semantics="textbook"))
     assert np.array_equal(ref, so.sgm(cv, 8, so.COST, 0.5, 2.0, (0, 0, 0, 0), 100.0))  # the default stays the reference as written
     assert not np.array_equal(ref, tb)
+
+
+def test_cost_branch_on_a_census_volume_skips_the_probe_with_the_same_bits(rng):
+    """unfoldBasedCostVolume(CENSUS) on device tensors leaves the volume's regional minima with the tensor (svh_unfold_cost_volume_minima); a
+    sgmCostVolume<Cost> on the untouched tensor uses them instead of probing the volume (svh_sgm_cost_volume_minima): same S bit for bit,
+    no sgm_volume_probe launch.  Any in-place change of the tensor, a copy or a view with other strides drops the statement."""
+    src, tgt, _ = parallax_pair(40, 200, 14, 9, 30, 3, 17, seed=5)
+    l, r = dev(tgt), dev(src)
+    for D, margins, n_dir in ((64, None, 8), (48, sv.Margins(3, 2, 5, 1), 4), (256, None, 8)):
+        cv = sv.unfoldBasedCostVolume(MF.CENSUS, l, r, 4, 4, D)
+        assert getattr(cv, "_svh_minima", None) is not None
+        exp = so.sgm(so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D), n_dir, so.COST, 0.001, 0.01, margins.as_tuple() if margins else (0, 0, 0, 0), 100.0)
+        sv.profile_reset(l)
+        sv.profile_enable(l, True)
+        got = sv.sgmCostVolume(n_dir, so.COST, cv, 0.001, 0.01, margins, 100.0)
+        sv.profile_enable(l, False)
+        kernels = sv.profile_collect(l)
+        assert "sgm_volume_probe" not in kernels and "gmap_from_minima" in kernels
+        assert_bits(got, exp)
+        # minima themselves: smallest cost of each region
+        mins = cv._svh_minima[0].cpu().numpy()
+        c = host(cv)
+        jj, dd = np.meshgrid(np.arange(c.shape[1]), np.arange(D), indexing="ij")
+        pays = (jj + dd >= c.shape[1])[None]
+        m0 = np.where(pays, np.inf, c).min(axis=2)
+        m1 = np.where(pays, c, np.inf).min(axis=2)
+        assert np.array_equal(mins[..., 0], m0) and np.array_equal(mins[..., 1], m1)
+        # a non-integer Pout is outside the exact regime: the statement is simply not used, same bits as ever
+        got2 = sv.sgmCostVolume(n_dir, so.COST, cv, 0.001, 0.01, margins, 0.5)
+        assert_bits(got2, so.sgm(host(cv), n_dir, so.COST, 0.001, 0.01, margins.as_tuple() if margins else (0, 0, 0, 0), 0.5))
+        # in-place change: the statement no longer describes the tensor -> probe path, and the result follows the new values
+        cv[3, 5, 2] += 0.25
+        sv.profile_reset(l)
+        sv.profile_enable(l, True)
+        got3 = sv.sgmCostVolume(n_dir, so.COST, cv, 0.001, 0.01, margins, 100.0)
+        sv.profile_enable(l, False)
+        assert "gmap_from_minima" not in sv.profile_collect(l)
+        assert_bits(got3, so.sgm(host(cv), n_dir, so.COST, 0.001, 0.01, margins.as_tuple() if margins else (0, 0, 0, 0), 100.0))
+    # Score strategy / other functions: no statement
+    assert getattr(sv.unfoldBasedCostVolume(MF.SAD, l, r, 2, 2, 16), "_svh_minima", None) is None

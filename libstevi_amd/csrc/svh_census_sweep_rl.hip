@@ -176,11 +176,14 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
     // registers and go into the MFMA as its C operand
     float opaque_zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-    v16f full_tile, first_tile, last_tile;
+    constexpr bool FRAGMAJOR = NT >= 9 && NW != 1; // the fragment-major interior path below (with a fourth start pattern for its odd row tiles): where the registers allow
+    constexpr bool ODD = FRAGMAJOR;
+    v16f full_tile, first_tile, last_tile, odd_tile;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
         const int rr = row_of_reg(reg) + 4 * h;
         full_tile[reg] = (float)rr + opaque_zero;
+        odd_tile[reg] = (float)(rr + (ODD ? 32 : 0)) + opaque_zero; // an odd row tile starts one tile tag higher: its frame shift is paid by the next even tile
         first_tile[reg] = (float)rr - (rr >= r ? 0.0f : BIG_CELL) + opaque_zero; // tile 0: d = row - col >= 0
         last_tile[reg] = (float)rr - (rr < r ? 0.0f : BIG_CELL) + opaque_zero;   // tile D/32: d = D + row - col < D
     }
@@ -204,6 +207,77 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
             };
             float Gabs[CT]; // per column tile: the packed maximum over its row tiles, of this lane's rows (4 h + ...), tile tags absolute
             bool all_interior = true;
+            // row tiles of column tile cc that hold cells of the region without Pout: all of tiles 0 .. kq - 1, rows below nv of tile kq,
+            // kq = Rq - j0 / 32 - (wave CT + cc); the wave's last column tile has the smallest (wave uniform)
+            const int kq_last = Rq - (j0 >> 5) - (wave * CT + CT - 1);
+            if (FRAGMAJOR && kq_last >= NT && plan.nbuf != 1) { // (nbuf == 1: A/B switch of the development tools, column-major tiles everywhere)
+                // ---- every row tile of every column tile of this wave counts: all items but the ones at the right image border.
+                // FRAGMENT-MAJOR: window group p (32 target columns, one LDS read) is row tile p - c of column tile c, so one fragment
+                // serves up to CT MFMAs: NT + CT - 1 reads for CT NT tiles instead of one read per tile.  A column tile's row tiles still
+                // arrive in increasing order, so its running maximum works as before; the MFMA of tile t + 1 is issued before the maximum of
+                // tile t is taken.  Odd row tiles start from odd_tile (one tag up): H = max3(G, t6, t7) needs no frame shift, the even tile
+                // after it pays both, max3(H - 64, t6, t7) -- half the shifts.
+                v8i bfr[CT][NG];
+#pragma unroll
+                for (int cc = 0; cc < CT; cc++)
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) {
+                        const uint4 rec = word_record(sword[cc][gq]);
+                        const bool present = h == 0 || 2 * gq + 1 < NW;
+                        bfr[cc][gq] = (v8i){present ? (int)rec.x : 0, present ? (int)rec.y : 0, present ? (int)rec.z : 0, present ? (int)rec.w : 0, 0, 0, 0, 0};
+                    }
+                auto load_group = [&](int p) { // window group p: arow[2 gq WIN + 32 p]
+                    Frags f;
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) {
+                        const uint4 t = arow[2 * gq * WIN + 32 * p];
+                        f.w[gq] = (v8i){(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
+                    }
+                    return f;
+                };
+                auto mfma_tile = [&](const Frags &f, int c, int k) {
+                    v16f a = k == 0 ? first_tile : (k == NT - 1 ? last_tile : ((k & 1) ? odd_tile : full_tile));
+#pragma unroll
+                    for (int gq = 0; gq < NG; gq++) a = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.w[gq], bfr[c][gq], a, 4, 4, 0, 132, 0, 131);
+                    return a;
+                };
+                float G[CT];
+#pragma unroll
+                for (int cc = 0; cc < CT; cc++) G[cc] = -BIG_G;
+                auto take_max = [&](const v16f &a, int c, int k) {
+                    const float t1 = max3f(a[0], a[1], a[2]), t2 = max3f(a[3], a[4], a[5]), t3 = max3f(a[6], a[7], a[8]), t4 = max3f(a[9], a[10], a[11]),
+                                t5 = max3f(a[12], a[13], a[14]);
+                    const float t6 = max3f(t1, t2, t3), t7 = max3f(t4, t5, a[15]);
+                    if (ODD) G[c] = (k & 1) ? max3f(G[c], t6, t7) : max3f(G[c] - 64.0f, t6, t7);
+                    else G[c] = max3f(G[c] - 32.0f, t6, t7);
+                };
+                constexpr int NP = NT + CT - 1;
+                Frags fr[2];
+                v16f acc[2];
+                fr[0] = load_group(0);
+                fr[1] = load_group(1);
+                acc[0] = mfma_tile(fr[0], 0, 0);
+                int t = 0, pc = 0, pk = 0; // tiles issued so far (compile-time after unrolling); the tile whose maximum is pending
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+#pragma unroll
+                    for (int c = 0; c < CT; c++) {
+                        const int k = p - c;
+                        if (k < 0 || k >= NT) continue;
+                        if (t > 0) { // (tile 0 was issued ahead of the loop)
+                            acc[t & 1] = mfma_tile(fr[p & 1], c, k);
+                            take_max(acc[(t - 1) & 1], pc, pk);
+                        }
+                        pc = c;
+                        pk = k;
+                        t++;
+                    }
+                    if (p + 2 < NP) fr[p & 1] = load_group(p + 2); // (every MFMA of group p has been issued)
+                }
+                take_max(acc[(t - 1) & 1], pc, pk);
+#pragma unroll
+                for (int cc = 0; cc < CT; cc++) Gabs[cc] = G[cc] + (float)(32 * (NT - 1));
+            } else
 #pragma unroll
             for (int cc = 0; cc < CT; cc++) {
                 const int ct = wave * CT + cc;
@@ -366,7 +440,7 @@ template <int NW, int NT, int CT, int BPC = rl_blocks_per_cu(NW, NT, CT)> int la
     }
     constexpr size_t shmem = rl_lds_bytes(NW, NT, CT);
     int grid;
-    const SweepPlan plan = make_walk(g.H, g.Ws, PXB, n, BPC, 2, &grid);
+    const SweepPlan plan = make_walk(g.H, g.Ws, PXB, n, BPC, ctx->census_sweep_rl == 2 ? 1 : 2, &grid);
     static int attr_set[64] = {}; // (per instantiation and device)
     if (!__atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_rl_kernel<NW, NT, CT, false, BPC>), hipFuncAttributeMaxDynamicSharedMemorySize,

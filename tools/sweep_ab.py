@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--shortcut", type=int, default=0, help="census_winner_shortcut (0: recurrences run, the bench headline)")
     ap.add_argument("arms", nargs="*", default=["census_sweep_rl=0", "census_sweep_rl=1"])
     args = ap.parse_args()
@@ -41,7 +42,7 @@ def main():
                               P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"])
 
     touched = set()
-    for rnd in range(2):
+    for rnd in range(args.rounds):
         for arm in args.arms:
             opts = [kv.split("=") for kv in arm.split(",") if kv]
             for k, v in opts:
@@ -57,7 +58,7 @@ def main():
             ms = (time.perf_counter() - t0) / args.reps * 1e3
             sv.profile_reset(d_src)
             sv.profile_enable(d_src, True)
-            for _ in range(10):
+            for _ in range(args.reps):
                 step()
             sv.profile_enable(d_src, False)
             prof = sv.profile_collect(d_src)

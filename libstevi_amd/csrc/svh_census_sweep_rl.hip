@@ -358,6 +358,21 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
             // and two column tiles merge into one wave of 64 different pixels: v_permlane32_swap puts tile c's two halves into the lower
             // lanes of (x, y), tile c + 1's into the upper lanes.  A last odd column tile takes the lower lanes alone.
             auto finish = [&](int c0, bool pair) {
+                SweepWinner w;
+                if constexpr (WINNER) {
+                    // `sw` is read from the kernel argument segment HERE, once per finish (an opaque pointer: the loads cannot be hoisted into
+                    // the tile code, which has no scalar registers to spare), and first used a few dozen instructions further down
+                    typedef __attribute__((address_space(4))) const char *KernArg;
+                    KernArg ka = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ka));
+                    typedef __attribute__((address_space(4))) const uint32_t *KernArgWords;
+                    KernArgWords kw = (KernArgWords)(ka + offsetof(RlKernelArgs, sw));
+                    static_assert(sizeof(SweepWinner) % 4 == 0, "read as dwords");
+                    uint32_t raw[sizeof(SweepWinner) / 4];
+#pragma unroll
+                    for (unsigned qq = 0; qq < sizeof(SweepWinner) / 4; qq++) raw[qq] = kw[qq];
+                    __builtin_memcpy(&w, raw, sizeof w);
+                }
                 float x = Gabs[c0], y = pair ? Gabs[c0 + 1] : Gabs[c0];
                 int ones_x = 0, ones_y = 0; // |s|: each lane half holds its words of the pixel
 #pragma unroll
@@ -387,19 +402,6 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                 }
                 if ((pair || h == 0) && jp < g.Ws) {
                     if constexpr (WINNER) { // the winner itself: census_keys.h
-                        // `sw` is read from the kernel argument segment HERE (an opaque pointer: the loads cannot be hoisted), not
-                        // kept in a dozen scalar registers through the tile code
-                        typedef __attribute__((address_space(4))) const char *KernArg;
-                        KernArg ka = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
-                        asm volatile("" : "+s"(ka));
-                        typedef __attribute__((address_space(4))) const uint32_t *KernArgWords;
-                        KernArgWords kw = (KernArgWords)(ka + offsetof(RlKernelArgs, sw));
-                        static_assert(sizeof(SweepWinner) % 4 == 0, "read as dwords");
-                        uint32_t raw[sizeof(SweepWinner) / 4];
-#pragma unroll
-                        for (unsigned qq = 0; qq < sizeof(SweepWinner) / 4; qq++) raw[qq] = kw[qq];
-                        SweepWinner w;
-                        __builtin_memcpy(&w, raw, sizeof w);
                         const int bd = winner_index((uint32_t)a0, (uint32_t)a1, passes_visiting(w, i, jp), w.pout);
                         if ((unsigned)(i - w.row_first) < (unsigned)w.row_count) {
                             const int64_t o = (int64_t)(i - w.row_first) * g.Ws + jp;

@@ -22,7 +22,10 @@ def main():
             for r in csv.DictReader(open(path)):
                 m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
                 if m and "svh" in r["Kernel_Name"]:
-                    acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    name = m.group(1)
+                    if re.search(r"census_sweep_\w+_kernel<[^>]*\btrue\b", r["Kernel_Name"]):
+                        name += "_winner"  # (WINNER = true: writes the disparity map itself)
+                    acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for k, cs in sorted(acc.items()):
         out[k] = {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())}

@@ -1,18 +1,33 @@
+# The profile set of a round (on the MI355X box, from the repository root): bash tools/profile_round.sh r03
+#   gpurun_out/<tag>_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the default bench command
+#   gpurun_out/<tag>_line_rocprof.json       the bench line printed under the profiler
+#   gpurun_out/<tag>_traffic.json            HBM bytes per launch and kernel (two --pmc passes, tools/pmc_summary.py)
+#   gpurun_out/<tag>_sq_counters.json        SQ instruction mix and wait breakdown (three --pmc passes, tools/pmc_sq_summary.py)
+#   gpurun_out/<tag>_line.json, _line_two_frames.json   plain bench lines
+#   gpurun_out/<tag>_other_workloads.jsonl   C1 - C5 and the per-function chains
 set -e
+TAG=${1:-r03}
+R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-R=/root/repo
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2b -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/r2b_line_rocprof.json 2> $R/gpurun_out/r2b_rocprof.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq2 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
+B="python3 $R/bench.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- $B --steps 100 --warmup 10 --no-cpu-baseline > $R/gpurun_out/${TAG}_line_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.err
+echo "kernel trace done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
+echo "traffic passes done"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq1 -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq2 -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq3 -- $B --steps 10 --warmup 2 --no-cpu-baseline --no-api-chain > /dev/null 2>&1 || true
+echo "sq passes done"
 cd $R
-python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/r2b_traffic.json
-python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > gpurun_out/r2b_sq_counters.json
-cp $(ls gpurun_out/prof_r2b/*/*kernel_stats.csv | head -1) gpurun_out/r2b_kernel_stats.csv
-rm -rf gpurun_out/prof_r2b gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2
-python3 bench.py --steps 200 --warmup 10 > gpurun_out/r2b_line.json 2> gpurun_out/r2b_line.err
-python3 bench.py --steps 200 --warmup 10 --two-frames --no-cpu-baseline --no-api-chain > gpurun_out/r2b_line_two_frames.json 2>/dev/null
-head -5 gpurun_out/r2b_kernel_stats.csv
+python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}_traffic.json > /dev/null
+python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3 > gpurun_out/${TAG}_sq_counters.json
+cp $(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1) gpurun_out/${TAG}_kernel_stats.csv
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3
+python3 bench.py --steps 200 --warmup 10 > gpurun_out/${TAG}_line.json 2> gpurun_out/${TAG}_line.err
+python3 bench.py --steps 200 --warmup 10 --two-frames --no-cpu-baseline --no-api-chain > gpurun_out/${TAG}_line_two_frames.json 2>/dev/null
+echo "bench lines done"
+(python3 tools/bench_configs.py c1 c2 c3 c4 c5slice c5; python3 tools/bench_api_chain.py; python3 tools/bench_l2r.py; python3 tools/sgm_score_probe.py; python3 tools/bench_2d.py; python3 tools/bench_hierarchical.py) 2>/dev/null | grep "^{" > gpurun_out/${TAG}_other_workloads.jsonl || true
+head -8 gpurun_out/${TAG}_kernel_stats.csv
 python3 -c "
-import json; d=json.load(open('gpurun_out/r2b_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['avg_ms'], d['roofline']['frac'], d['end_px_err'], d['cpu_baseline']['value'])"
+import json; d=json.load(open('gpurun_out/${TAG}_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['avg_ms'], d['roofline']['frac'], d['roofline'].get('frac_minus_half_pair'), d['end_px_err'], d['cpu_baseline']['value'], d['winner_identity']['ms_per_step'], d['api_chain']['ms'])"

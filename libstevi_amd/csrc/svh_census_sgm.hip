@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     const int first = cl.dir > 0 ? b : e - 1;
     const int64_t p0 = (int64_t)(sg.top + first) * sg.W + sg.left + v + cl.s * first;
     const int64_t step = (int64_t)cl.dir * (sg.W + cl.s);
-    float *out = mmap + (int64_t)q * npx;
+    float *out = mmap + (int64_t)min_p_plane(q) * npx;
     float mp = 0.0f;
     if (chunk <= SCAN_MAXSEG) {
         // the whole segment lives in registers: one round of loads (all in flight together), summary, chain, replay
@@ -466,7 +466,7 @@ __device__ __forceinline__ PixelPasses load_pixel_passes(const ScanGeom &sg, int
         if (q == 4) v = v && ip + jp < sg.Wp;
         if (q == 5) v = v && ip + jp < sg.Hp;
         if (v) {
-            pp.mp[q] = mmap[(int64_t)q * npx + p];
+            pp.mp[q] = mmap[(int64_t)min_p_plane(q) * npx + p];
             if (fabsf(pp.mp[q]) < INFINITY) pp.vis |= 1u << q;
         }
     }

@@ -240,6 +240,13 @@ struct SgmArgs {
     // [store_row0, store_row0 + store_rows) are written, to an output of store_rows rows
     int row_origin = 0, full_H = 0, store_row0 = 0, store_rows = 0;
 };
+// The min_p maps of the six effective passes live in FIVE planes: passes 2 and 3 (the two start loops of UpLeft2DownRight, sgm.h:331-345)
+// partition the margin box along its diagonal -- pass 2 visits ip >= jp, pass 3 jp >= ip -- and the pixels both visit, the diagonal itself,
+// lie on the one line both loops run (the line from the corner runs twice: finding F5), where both compute the same values from the
+// same pixels in the same order.  So they share a plane; a diagonal pixel counts it twice.
+constexpr int MIN_P_PLANES = 5;
+__host__ __device__ __forceinline__ int min_p_plane(int q) { return q <= 2 ? q : q - 1; }
+
 // cost source for the Cost-branch kernels: either a dense float volume or census words evaluated on the fly
 struct CostSource {
     const float *cv = nullptr;       // (H, W, D) dense, or nullptr

@@ -358,7 +358,7 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
     const bool winner_only = ctx->census_winner_shortcut && (!want_refine || shift_ok);
     float *mmap = nullptr;
     if (!winner_only) {
-        mmap = scr.get_n<float>((size_t)6 * npx);
+        mmap = scr.get_n<float>((size_t)MIN_P_PLANES * npx);
         float *gmap = scr.get_n<float>((size_t)npx);
         if (!mmap || !gmap) return SVH_ERR_OUT_OF_MEMORY;
         SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap, nullptr));

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
           const int64_t pu = min(p0 + u, npx - 1);
           src.template load<R>((int)(pu / W), (int)(pu % W), lane, cb[u]);
 #pragma unroll
-          for (int q = 0; q < MAX_PASS; q++) mpb[u][q] = q < n_pass ? mmap[(int64_t)q * npx + pu] : 0.0f;
+          for (int q = 0; q < MAX_PASS; q++) mpb[u][q] = q < n_pass ? mmap[(int64_t)min_p_plane(q) * npx + pu] : 0.0f;
       }
 #pragma unroll
       for (int u = 0; u < APPLY_PB; u++) {
@@ -553,7 +553,7 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
         for (int q = 0; q < n_pass; q++) {
             LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
             SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), ceil_div(ls.n_lines, 4), 256, 0, src, ls, a.D, a.W,
-                       a.Pout, mmap + (size_t)q * a.H * a.W, gate);
+                       a.Pout, mmap + (size_t)min_p_plane(q) * a.H * a.W, gate);
             SVH_CHECK_LAUNCH(ctx);
         }
     }
@@ -582,7 +582,7 @@ static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &s
 
 int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *out_sgm, const WinnerOut &win) {
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
-    float *mmap = scr.get_n<float>((size_t)6 * a.H * a.W);
+    float *mmap = scr.get_n<float>((size_t)MIN_P_PLANES * a.H * a.W);
     if (!mmap) return SVH_ERR_OUT_OF_MEMORY;
     ApplyOut out{out_sgm, win, out_sgm && aligned16(out_sgm) && a.D % 4 == 0};
     if (cs.cv) {

@@ -52,14 +52,14 @@ __global__ void __launch_bounds__(256) cost_volume_pxlane_kernel(const float *__
                                                                  int D, int disp_lower, const float *__restrict__ mean_s,
                                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                  const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
-                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv) {
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0) {
     constexpr int h = 2 * HR + 1, NT = h + DB - 1;
     extern __shared__ float lds[];
     const int v = 2 * v_r + 1;
     const int n_blocks = (D + DB - 1) / DB;
     const int sw = PL_TPX + h - 1, tw = PL_TPX + h - 1 + n_blocks * DB - 1;
     float *stile = lds, *ttile = lds + v * sw;
-    const int i = blockIdx.y, j0 = blockIdx.x * PL_TPX;
+    const int i = row0 + blockIdx.y, j0 = blockIdx.x * PL_TPX;
     const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(j0, Ws - 1)] : 0.0f; // keeps the zero-mean dot products small
     const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
     const bool trow_in = it >= 0 && it < H;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const fl
                                                                  int D, int disp_lower, const float *__restrict__ mean_s,
                                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                  const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
-                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv) {
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0) {
     constexpr int DB = CS_DB, OUT = CS_COLS - 2 * HR;
     extern __shared__ float lds[];
     const int v = 2 * v_r + 1;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const fl
     const int tw = CS_COLS + n_blocks * DB; // target tile columns (even: 8-byte aligned pairs)
     float *stile = lds, *ttile = lds + v * CS_COLS, *tmean = ttile + v * tw, *tinv = tmean + (ZM ? tw : 0); // (tmean / tinv: ZM / NRM only)
     float *xpose = tinv + (NRM ? tw : 0) + (threadIdx.x >> 6) * (64 * CS_XP); // this wave's area for turning 64 pixels x DB costs around
-    const int i = blockIdx.y, p0 = blockIdx.x * OUT, xb = p0 - HR; // first output pixel, first column of the tile
+    const int i = row0 + blockIdx.y, p0 = blockIdx.x * OUT, xb = p0 - HR; // first output pixel, first column of the tile
     const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(p0, Ws - 1)] : 0.0f; // keeps the zero-mean dot products small
     const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
     const bool trow_in = it >= 0 && it < H;
@@ -383,7 +383,7 @@ inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm) {
 template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                                    const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
     const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM);
-    dim3 grid(ceil_div(a.Ws, CS_COLS - 2 * HR), a.H);
+    dim3 grid(ceil_div(a.Ws, CS_COLS - 2 * HR), a.row_count ? a.row_count : a.H);
 #define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
     do {                                                                                                                                           \
         static int big_lds[64] = {}; /* (per instantiation and device) more than the default 64 KiB of dynamic LDS */                              \
@@ -393,7 +393,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
             __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
         }                                                                                                                                          \
         SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV>), grid, 64 * WV, shmem, src, tgt, a.H, a.Ws,     \
-                   a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);                                 \
+                   a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin);                    \
     } while (0)
     if (colsum_waves(a.D) == 8) {
         if (sign > 0) SVH_CS_LAUNCH(1, 8);
@@ -415,13 +415,13 @@ template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const C
 template <int CMP, bool ZM, int HR, int DB> void launch_pxlane_db(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                                   const float *ms, const float *mt, const float *ns, const float *nt, const float *zc,
                                                                   float *cv, size_t shmem) {
-    dim3 grid(ceil_div(a.Ws, PL_TPX), a.H);
+    dim3 grid(ceil_div(a.Ws, PL_TPX), a.row_count ? a.row_count : a.H);
     if (sign > 0)
         SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_pxlane_kernel<CMP, ZM, HR, DB, 1>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D,
-                   a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);
+                   a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin);
     else
         SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_pxlane_kernel<CMP, ZM, HR, DB, -1>), grid, 256, shmem, src, tgt, a.H, a.Ws, a.Wt, v_r, a.D,
-                   a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv);
+                   a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin);
 }
 
 // disparities per lane and block: 32 for wide windows over long ranges (fewer LDS reads per multiply-add: measured 5 % faster

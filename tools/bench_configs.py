@@ -23,6 +23,9 @@ CONFIGS = {
     "c3": (1920, 1080, 256, MF.CENSUS, 4, 4, 8, None, (320, 320, 380, 8, 64, 3), {}),
     "c3mat": (1920, 1080, 256, MF.CENSUS, 4, 4, 8, None, (320, 320, 380, 8, 64, 3), {"want_cv": True, "want_sgm_cv": True}),
     "c4": (4096, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
+    # (row pitch of the volume 4 MiB at C4; these two ask whether the power of two matters to the line passes: it does not)
+    "c4w4000": (4000, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
+    "c4w4160": (4160, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
     "c4small": (1024, 540, 256, MF.NCC, 5, 5, 8, IK.Parabola, (160, 160, 190, 4, 32, 4), {}),
     "c5slice": (8192, 4320, 64, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),
     "c5": (8192, 4320, 512, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),  # the whole range on one GPU

@@ -20,8 +20,8 @@ namespace {
 // second stream while the cost kernel works on the next band.  The same kernels with the same arguments per row as the
 // one-after-the-other form, hence the same bits.  MEASURED AT C4 (tools/c4_overlap_ab.py, same process, arms alternated): 18.47 ms one
 // after the other; 19.00 with 2 bands, 19.02 with 3, 19.48 with 4, 22.8-23.2 with 8.  The line kernel is one wave per row walking a
-// 4096-step chain: a band of it lasts as long as the whole pass (its duration is the chain's latency, not its byte count), so the last
-// band's lines still start when the cost kernel ends and run their full length, and the cost kernel loses a tail per band on top.
+// 4096-step chain with one batch of loads in flight: a band of few rows still lasts the chain's length, the last band's lines start
+// when the cost kernel ends, and at full width both kernels already sit at the chip's mixed read/write rate.
 // Kept as an option because the verdict of round 2 asked for the mechanism; it is not the default.
 // SVH_ERR_UNSUPPORTED (nothing launched but the statistics maps): the caller takes the plain order.
 constexpr int OVERLAP_BANDS_MAX = 16;

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
     const __amdgpu_buffer_rsrc_t rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void *)g.tw, 0, g.H * g.Wt * NW * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)g.sw, 0, g.H * g.Ws * NW * 4, 0x00020000);
     const uint32_t t_lane = (uint32_t)((wave * SL + lane) * NW * 4);            // this lane's pixel of the wave's window slice, round 0
-    const uint32_t s_lane = (uint32_t)(((wave * CT * 32 + r) * NW + h) * 4);    // word h of this lane's source pixel in column tile 0
+    const uint32_t s_lane = (uint32_t)((r * NW + h) * 4);                        // word h of this lane's source pixel in a column tile
 
     // cell (row tile k, row, col) of column tile c is disparity 32 k + row - col of source pixel j = j0 + 32 c + col; it counts
     // (region without Pout) while j + d < R, R = Ws - d_offset: row < R - j0 - 32 c - 32 k.  R = 32 Rq + nv.
@@ -111,9 +111,19 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
     // the Pout region's key of a pixel: (|s|, last index) when j + last >= Ws (disparity shards: the last index of the whole range)
     const int last = g.region1_global_last >= 0 ? g.region1_global_last : g.d_offset + D - 1;
 
+    // Which column tiles (32 source pixels each, WAVES CT per item) a wave takes.  Away from the right image border every column tile
+    // has its NT row tiles and a wave takes CT neighbours (their row tiles share window fragments).  In an item AT the border the
+    // column tiles get shorter from left to right (kq below: NT, ..., NT, NT - 1, NT - 2, ...), the item's barrier makes every wave
+    // wait for the one with the most tiles, and that one sits on the same SIMD in every block: there the waves take the column tiles
+    // in serpentine order -- w, 2 WAVES - 1 - w, 2 WAVES + w, ... -- so that each gets long and short ones (1080p x 256, last item
+    // of a row: 18 / 18 / 18 / 18 tiles instead of 27 / 24 / 15 / 6).
+    auto border_item = [&](int j0) { return Rq - (j0 >> 5) - (WAVES * CT - 1) < NT; }; // (block uniform) its last column tile lacks row tiles
+    const bool serpentine = plan.nbuf != 3; // (nbuf == 3: A/B switch of the development tools, neighbouring column tiles everywhere)
+    auto ct_of = [&](int cc, bool border) { return border && serpentine ? cc * WAVES + ((cc & 1) ? WAVES - 1 - wave : wave) : wave * CT + cc; };
     uint32_t tword[PB][NW], snext[CT][NG], sword[CT][NG];
     auto issue_loads = [&](int i, int j0) {
         if (i >= g.H) return; // (padding rows of the last group of eight)
+        const bool border = border_item(j0);
         const uint32_t t_off = (uint32_t)((i * g.Wt + j0 + g.disp_lower) * NW * 4) + t_lane;
 #pragma unroll
         for (int b = 0; b < PB; b++) buffer_load_words<NW>(rsrc_t, t_off + (uint32_t)(b * 64 * NW * 4), tword[b]);
@@ -121,7 +131,8 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
 #pragma unroll
         for (int cc = 0; cc < CT; cc++)
 #pragma unroll
-            for (int gq = 0; gq < NG; gq++) snext[cc][gq] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_off + (uint32_t)((cc * 32 * NW + 2 * gq) * 4), 0, 0);
+            for (int gq = 0; gq < NG; gq++)
+                snext[cc][gq] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_s, s_off + (uint32_t)((ct_of(cc, border) * 32 * NW + 2 * gq) * 4), 0, 0);
     };
     // registers -> FP4 records of window buffer `buf` (this wave's SL pixels); the source words of the item move into place
     const int wr_lane = wave * SL + lane; // window pixel of this lane, round 0
@@ -196,23 +207,23 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the window writes are done ...
     __builtin_amdgcn_s_barrier();                       // ... raw: a __syncthreads() would also wait for the loads just issued
 
-    const uint32_t frag_lane = (uint32_t)(h * WIN + wave * CT * 32 + r); // record of (row tile 0, group 0) of column tile 0 in a buffer
+    const uint32_t frag_lane = (uint32_t)(h * WIN + r); // record of (row tile 0, group 0) of the item's column tile 0 in a buffer
 
     int buf = 0;
     for (;;) {
         const int i = q * 8 + xcd, j0 = jb * PXB;
         if (i < g.H) {
             const uint4 *const arow = lds4 + buf * BUF + frag_lane;
+            const bool border = border_item(j0);
             const int64_t row = (int64_t)i * g.Ws;
             struct Frags {
                 v8i w[NG];
             };
             float Gabs[CT]; // per column tile: the packed maximum over its row tiles, of this lane's rows (4 h + ...), tile tags absolute
             bool all_interior = true;
-            // row tiles of column tile cc that hold cells of the region without Pout: all of tiles 0 .. kq - 1, rows below nv of tile kq,
-            // kq = Rq - j0 / 32 - (wave CT + cc); the wave's last column tile has the smallest (wave uniform)
-            const int kq_last = Rq - (j0 >> 5) - (wave * CT + CT - 1);
-            if (FRAGMAJOR && kq_last >= NT && plan.nbuf != 1) { // (nbuf == 1: A/B switch of the development tools, column-major tiles everywhere)
+            // row tiles of column tile ct that hold cells of the region without Pout: all of tiles 0 .. kq - 1, rows below nv of tile kq,
+            // kq = Rq - j0 / 32 - ct; the item's last column tile has the smallest: border_item()
+            if (FRAGMAJOR && !border && plan.nbuf != 1) { // (nbuf == 1: A/B switch of the development tools, column-major tiles everywhere)
                 // ---- every row tile of every column tile of this wave counts: all items but the ones at the right image border.
                 // FRAGMENT-MAJOR: window group p (32 target columns, one LDS read) is row tile p - c of column tile c, so one fragment
                 // serves up to CT MFMAs: NT + CT - 1 reads for CT NT tiles instead of one read per tile.  A column tile's row tiles still
@@ -228,11 +239,12 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                         const bool present = h == 0 || 2 * gq + 1 < NW;
                         bfr[cc][gq] = (v8i){present ? (int)rec.x : 0, present ? (int)rec.y : 0, present ? (int)rec.z : 0, present ? (int)rec.w : 0, 0, 0, 0, 0};
                     }
-                auto load_group = [&](int p) { // window group p: arow[2 gq WIN + 32 p]
+                const uint4 *const arow_w = arow + wave * CT * 32; // (the wave's CT neighbouring column tiles)
+                auto load_group = [&](int p) { // window group p: arow_w[2 gq WIN + 32 p]
                     Frags f;
 #pragma unroll
                     for (int gq = 0; gq < NG; gq++) {
-                        const uint4 t = arow[2 * gq * WIN + 32 * p];
+                        const uint4 t = arow_w[2 * gq * WIN + 32 * p];
                         f.w[gq] = (v8i){(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
                     }
                     return f;
@@ -282,7 +294,8 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
             } else
 #pragma unroll
             for (int cc = 0; cc < CT; cc++) {
-                const int ct = wave * CT + cc;
+                const int ct = ct_of(cc, border);
+                const uint4 *const arow_c = arow + ct * 32;
                 // source fragments: this lane's word of every 64-bit group as +-1.0 nibbles (an absent odd word: 0.0)
                 v8i bfrag[NG];
 #pragma unroll
@@ -291,11 +304,11 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                     const bool present = h == 0 || 2 * gq + 1 < NW;
                     bfrag[gq] = (v8i){present ? (int)rec.x : 0, present ? (int)rec.y : 0, present ? (int)rec.z : 0, present ? (int)rec.w : 0, 0, 0, 0, 0};
                 }
-                auto load_frags = [&](int k) { // row tile k, group gq: arow[2 gq WIN + 32 (cc + k)]
+                auto load_frags = [&](int k) { // row tile k, group gq: arow[2 gq WIN + 32 (ct + k)]
                     Frags f;
 #pragma unroll
                     for (int gq = 0; gq < NG; gq++) {
-                        const uint4 t = arow[2 * gq * WIN + 32 * (cc + k)];
+                        const uint4 t = arow_c[2 * gq * WIN + 32 * k];
                         f.w[gq] = (v8i){(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
                     }
                     return f;
@@ -347,7 +360,7 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                         Frags f;
 #pragma unroll
                         for (int gq = 0; gq < NG; gq++) {
-                            const uint4 t = arow[2 * gq * WIN + 32 * cc + 32 * k];
+                            const uint4 t = arow_c[2 * gq * WIN + 32 * k];
                             f.w[gq] = (v8i){(int)t.x, (int)t.y, (int)t.z, (int)t.w, 0, 0, 0, 0};
                         }
                         epilogue(tile(f, start));
@@ -385,7 +398,8 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                 }
                 const auto sg = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
                 const float gf = __builtin_fmaxf(__uint_as_float(sg[0]), __uint_as_float(sg[1]));
-                const int jp = j0 + (wave * CT + c0) * 32 + (pair ? lane : r); // this lane's pixel
+                const int ct_x = ct_of(c0, border), ct_y = pair ? ct_of(c0 + 1, border) : ct_x; // (wave uniform)
+                const int jp = j0 + ((pair && h) ? ct_y : ct_x) * 32 + r;     // this lane's pixel
                 // gf = 1024 (B - cost) + 32 tile + row - 512 B, and 32 tile + row = d + col (col = lane & 31)
                 const int gv = (int)gf + 512 * B, cost0 = B - (gv >> 10);
                 int a0 = (int)make_key(cost0, g.d_offset + (gv & 1023) - r), a1 = (int)KEY_NONE;
@@ -395,7 +409,7 @@ __global__ void __launch_bounds__(64 * RL_WAVES, BPC)
                     a0 = any ? a0 : (int)KEY_NONE;
                     g2 = any ? g2 : (1 << 24);
                 }
-                if (j0 + (wave * CT + c0) * 32 + (pair ? 63 : 31) + last >= g.Ws) { // (wave uniform) some pixel here has disparities that pay Pout
+                if (j0 + max(ct_x, ct_y) * 32 + 31 + last >= g.Ws) { // (wave uniform) some pixel here has disparities that pay Pout
                     const auto so = __builtin_amdgcn_permlane32_swap((unsigned)ones_x, (unsigned)ones_y, false, false);
                     const int ones = (int)(so[0] + so[1]);
                     const bool pays = jp + last >= g.Ws;
@@ -444,7 +458,7 @@ template <int NW, int NT, int CT, int BPC = rl_blocks_per_cu(NW, NT, CT)> int la
     }
     constexpr size_t shmem = rl_lds_bytes(NW, NT, CT);
     int grid;
-    const SweepPlan plan = make_walk(g.H, g.Ws, PXB, n, BPC, ctx->census_sweep_rl == 2 ? 1 : 2, &grid);
+    const SweepPlan plan = make_walk(g.H, g.Ws, PXB, n, BPC, ctx->census_sweep_rl == 2 ? 1 : (ctx->census_sweep_rl == 3 ? 3 : 2), &grid);
     static int attr_set[64] = {}; // (per instantiation and device)
     if (!__atomic_load_n(&attr_set[dev], __ATOMIC_ACQUIRE)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_rl_kernel<NW, NT, CT, false, BPC>), hipFuncAttributeMaxDynamicSharedMemorySize,

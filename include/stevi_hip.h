@@ -103,6 +103,8 @@ const char *svh_last_error(const svh_context *ctx);
  * for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
  * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
  * (64 / 128 / 256 / 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
+ * (Development A/Bs of that kernel, same keys again: 2 = column-major tile order everywhere; 3 = neighbouring column tiles per wave also
+ * in the items at the right image border, where the default deals them out in serpentine order.)
  * "census_float_overflow" (default 0): what becomes of a target census word that rounds to 2^32 on its way through `float`
  * (cross_correlations.h:235-236; words >= 0xFFFFFF80; undefined in C++): 0 = 0xFFFFFFFF, what the reference's Release build gives on
  * a host with AVX-512 and what the GPU's own conversion does; 1 = 0, what x86-64 code generation without AVX-512 gives (the reference's

@@ -301,14 +301,93 @@ __device__ __forceinline__ void col_line_rows(int q, int v, const ScanGeom &sg, 
     }
 }
 
-__device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
-                                             int lane);
+// The register form of scan_cols_kernel for a wave whose 64 lines all have the same LEN rows in its segment (or none: lane_off out
+// of range).  The general form spends 26 instructions per pixel -- 64-bit addresses, a per-lane `k < n` around every load, update and
+// store -- and the launch is bound by instruction issue, not by its 100 MB (SQ counters, profiles/r03a: 5.4 M wave instructions,
+// 0.49 M branches, on 192 busy CUs).  Here the row count is a compile-time constant, the pixel of traversal step k is buffer base +
+// lane offset + a scalar offset carried from step to step: no vector address arithmetic, no test per pixel; lanes without a line
+// load zeros and their stores are dropped (range-checked buffer accesses).  The arithmetic per pixel is the same subtraction in the
+// same order as in the general form: same bits.
+// Where scan_cols_kernel<true> leaves, instead of the min_p maps, the CARRIES of the recurrences: per plane, segment of rows and
+// line the min_p of the line's first pixel in the segment (in traversal order), and for pass 1 per row and 64-column tile the prefix
+// sum over the tiles before it.  tile_finalize_kernel replays the lines of a tile from them.  Line indices: pass 0 and 4: v; passes 2
+// and 3 (one plane): v + Hp - 1 (v = 0, the line both passes run, is written by both with the same value); pass 5: v.
+struct CarryMaps {
+    float *base = nullptr;
+    int Hp = 0, Wp = 0;
+    __host__ __device__ int l23() const { return Hp + Wp - 1; }
+    __host__ __device__ int tiles() const { return (Wp + 63) / 64; }
+    __host__ __device__ int64_t off(int q) const { // (q = 2 and 3 share)
+        const int64_t S = 16; // SCAN_SEGS
+        switch (q) {
+        case 0: return 0;
+        case 2: case 3: return S * Wp;
+        case 4: return S * (Wp + l23());
+        case 5: return S * (2 * (int64_t)Wp + l23());
+        default: return S * (2 * (int64_t)Wp + l23() + Hp); // pass 1: [row][tile]
+        }
+    }
+    __host__ __device__ int lines(int q) const { return q == 0 || q == 4 ? Wp : (q == 5 ? Hp : l23()); }
+    __host__ __device__ int64_t total() const { return off(1) + (int64_t)Hp * tiles(); }
+    __device__ float *at(int q, int seg, int line) const { return base + off(q) + (int64_t)seg * lines(q) + line; }
+};
+__device__ __forceinline__ int carry_line_index(int q, int v, int Hp) { return (q == 2 || q == 3) ? v + Hp - 1 : v; }
 
+template <bool CARRY>
+__device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
+                                             int lane, const CarryMaps &cm);
+
+struct LeanArgs {
+    const float *gmap;
+    float *out;
+    int64_t npx;
+    uint32_t st4;      // bytes from a line's pixel to its pixel one row down
+    uint32_t lane_off; // byte offset of this lane's pixel in the segment's first (lowest) row; 0xFFFFFFFF: no line
+    int dir, seg, lane, n;
+};
+template <int LEN, bool CARRY> __device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], float *carry_out) {
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gmap, 0, (int)(a.npx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, (int)(a.npx * 4), 0x00020000);
+    // traversal step k is the segment's row k (downwards) or LEN - 1 - k (pass 5, upwards)
+    const uint32_t s0 = a.dir > 0 ? 0u : (uint32_t)(LEN - 1) * a.st4, sd = a.dir > 0 ? a.st4 : 0u - a.st4;
+    float gv[LEN];
+    uint32_t so = s0;
+#pragma unroll
+    for (int k = 0; k < LEN; k++) {
+        gv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, a.lane_off, so, 0));
+        so += sd;
+    }
+    float mp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < LEN; k++) mp = gv[k] - mp;
+    seg_a[a.seg][a.lane] = mp;
+    seg_n[a.seg][a.lane] = a.n;
+    __syncthreads();
+    mp = 0.0f;
+    if (a.dir > 0) {
+        for (int t = 0; t < a.seg; t++) mp = seg_a[t][a.lane] + ((seg_n[t][a.lane] & 1) ? -mp : mp);
+    } else {
+        for (int t = SCAN_SEGS - 1; t > a.seg; t--) mp = seg_a[t][a.lane] + ((seg_n[t][a.lane] & 1) ? -mp : mp);
+    }
+    if constexpr (CARRY) {
+        if (carry_out) *carry_out = mp;
+        return;
+    }
+    so = s0;
+#pragma unroll
+    for (int k = 0; k < LEN; k++) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mp), ro, a.lane_off, so, 0);
+        so += sd;
+        mp = gv[k] - mp;
+    }
+}
+
+template <bool CARRY>
 __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
-                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero) {
+                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero, CarryMaps cm) {
     if (skip_if_nonzero && *skip_if_nonzero != 0) return; // the integer-volume probe failed: the line kernels make the maps
     if ((int)blockIdx.y == (n_pass <= 2 ? 1 : 5)) { // last slice of the grid: pass 1, one wave per row
-        scan_one_row(gmap, sg, npx, mmap, blockIdx.x * SCAN_SEGS + threadIdx.y, threadIdx.x);
+        scan_one_row<CARRY>(gmap, sg, npx, mmap, blockIdx.x * SCAN_SEGS + threadIdx.y, threadIdx.x, cm);
         return;
     }
     __shared__ float seg_a[SCAN_SEGS][64];
@@ -320,15 +399,35 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     if ((int)blockIdx.x * 64 >= cl.n_lines) return; // whole block out of range (uniform)
     int r0 = 0, r1 = 0;
     if (v < cl.v_lo + cl.n_lines) col_line_rows(q, v, sg, r0, r1);
-    const int chunk = (sg.Hp + SCAN_SEGS - 1) / SCAN_SEGS;
+    const int chunk = ((sg.Hp + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3; // (a multiple of four: the lean form's lengths)
     const int b = max(r0, seg * chunk), e = min(r1, (seg + 1) * chunk);
     const int n = max(e - b, 0);
     // pixel index of relative row r on this line: (top + r) * W + left + v + s r, advanced by dir * (W + s) per step
     const int first = cl.dir > 0 ? b : e - 1;
     const int64_t p0 = (int64_t)(sg.top + first) * sg.W + sg.left + v + cl.s * first;
     const int64_t step = (int64_t)cl.dir * (sg.W + cl.s);
-    float *out = mmap + (int64_t)min_p_plane(q) * npx;
+    float *out = CARRY ? nullptr : mmap + (int64_t)min_p_plane(q) * npx;
+    // carries: the line's min_p at its first pixel of this segment in traversal order (lanes without a line write nothing)
+    float *const carry_out = (CARRY && v < cl.v_lo + cl.n_lines) ? cm.at(q, seg, carry_line_index(q, v, sg.Hp)) : nullptr;
     float mp = 0.0f;
+    if (chunk <= SCAN_MAXSEG && npx <= ((int64_t)1 << 29)) {
+        // LEAN FORM (scan_lean below) for the waves whose 64 lines all cross every row of the segment or none of it -- all but the
+        // waves at the ragged ends of the diagonal passes -- when the segment's row count is one of the compile-time lengths
+        const int segu = __builtin_amdgcn_readfirstlane(seg);
+        const int nb = segu * chunk, ne = min(sg.Hp, nb + chunk), n_u = ne - nb; // rows [nb, ne) of the margin box
+        const bool ragged = n != 0 && (b != nb || e != ne);
+        if (n_u > 0 && (n_u & 3) == 0 && __builtin_amdgcn_ballot_w64(ragged) == 0) {
+            const LeanArgs la{gmap, out, npx, (uint32_t)(sg.W + cl.s) * 4u,
+                              n != 0 ? (uint32_t)(((int64_t)(sg.top + nb) * sg.W + sg.left + v + cl.s * nb) * 4) : 0xFFFFFFFFu, cl.dir, segu, lane, n};
+            switch (n_u >> 2) {
+#define SVH_LEAN(Q) case Q: scan_lean<4 * Q, CARRY>(la, seg_a, seg_n, carry_out); return;
+                SVH_LEAN(1) SVH_LEAN(2) SVH_LEAN(3) SVH_LEAN(4) SVH_LEAN(5) SVH_LEAN(6) SVH_LEAN(7) SVH_LEAN(8) SVH_LEAN(9)
+                SVH_LEAN(10) SVH_LEAN(11) SVH_LEAN(12) SVH_LEAN(13) SVH_LEAN(14) SVH_LEAN(15) SVH_LEAN(16) SVH_LEAN(17) SVH_LEAN(18)
+#undef SVH_LEAN
+            default: break;
+            }
+        }
+    }
     if (chunk <= SCAN_MAXSEG) {
         // the whole segment lives in registers: one round of loads (all in flight together), summary, chain, replay
         float gv[SCAN_MAXSEG];
@@ -345,6 +444,10 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
             for (int t = 0; t < seg; t++) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
         } else {
             for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
+        }
+        if constexpr (CARRY) {
+            if (carry_out) *carry_out = mp;
+            return;
         }
 #pragma unroll
         for (int k = 0; k < SCAN_MAXSEG; k++)
@@ -372,6 +475,10 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         for (int t = 0; t < seg; t++) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
     } else {
         for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
+    }
+    if constexpr (CARRY) {
+        if (carry_out) *carry_out = mp;
+        return;
     }
     {
         int64_t p = p0;
@@ -411,14 +518,22 @@ __device__ __forceinline__ float wave_prefix_sum(float v) {
 
 constexpr int SCAN_ROW_CHUNKS = 32; // rows up to 2048 pixels are loaded in one go
 
+template <bool CARRY>
 __device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
-                                             int lane) {
+                                             int lane, const CarryMaps &cm) {
     if (row >= sg.Hp) return;
     const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left;
-    float *out = mmap + npx; // pass 1
+    float *out = CARRY ? nullptr : mmap + npx; // pass 1
+    float *const crow = CARRY ? cm.base + cm.off(1) + (int64_t)row * cm.tiles() : nullptr; // carries: the prefix sum before each 64-pixel chunk
     const float sgn = (lane & 1) ? -1.0f : 1.0f; // (-1)^lane; chunks start at even pixel indices
     float carry = 0.0f;                            // prefix sum of h over the previous chunks
     auto chunk = [&](float gval, int k) {
+        if constexpr (CARRY) {
+            if (lane == 0) crow[k >> 6] = carry;
+            const float tot = wave_prefix_sum(sgn * gval);
+            carry += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
+            return;
+        }
         const float P = wave_prefix_sum(sgn * gval) + carry; // inclusive over pixels 0..k
         // min_p(k) = (-1)^(k-1) P_{k-1}: take the neighbour's inclusive sum (lane 0: the carry)
         float Pm1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, P), 0x138, 0xF, 0xF, false)); // wave_shr:1
@@ -511,6 +626,9 @@ template <int NW> __device__ __forceinline__ int hamming_global(const CensusGeom
 // the number of passes that visit the pixel, follows from its position (sgm.h:329-354, finding F5).  What the reference's Cost
 // branch hands from pixel to pixel (finding F4: one scalar per pass) never reaches its own argmin.  The S values themselves
 // (refinement taps, cross-shard value keys) still take the maps.
+template <int NW>
+__device__ __forceinline__ void finalize_px(const CensusGeom &g, const WinnerOut &out, int i, int j, int64_t p, int msum, int n_vis, float Pout, uint2 k);
+
 template <int NW, bool MAPS>
 __global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, ScanGeom sg, int n_pass, float Pout, const float *__restrict__ mmap,
                                                               const uint2 *__restrict__ keys, WinnerOut out) {
@@ -534,8 +652,12 @@ __global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, Scan
             for (int q = 0; q < 6; q++) n_vis += q < n_pass && pass_visits_px(q, ip, jp, sg.Hp, sg.Wp);
         }
     }
+    finalize_px<NW>(g, out, i, j, p, msum, n_vis, Pout, keys[p]);
+}
+
+template <int NW>
+__device__ __forceinline__ void finalize_px(const CensusGeom &g, const WinnerOut &out, int i, int j, int64_t p, int msum, int n_vis, float Pout, uint2 k) {
     const int mul = 1 + n_vis, k0 = -msum, k1 = n_vis * (int)Pout - msum;
-    const uint2 k = keys[p];
     const int v0 = mul * key_cost(k.x) + k0, d0 = key_index(k.x);
     const int v1 = mul * key_cost(k.y) + k1, d1 = key_index(k.y);
     const bool take1 = k.y != KEY_NONE && (k.x == KEY_NONE || v1 <= v0);
@@ -554,6 +676,128 @@ __global__ void __launch_bounds__(256) census_finalize_kernel(CensusGeom g, Scan
             if (!(px_bad || pd < 0 || pd >= g.D || j + pd + out.taps_h_r >= g.Ws))
                 v = (float)(mul * hamming_global<NW>(g, s, i, j, pd) + (pd >= dsplit ? k1 : k0));
             out.taps[p * 3 + tap] = v;
+        }
+    }
+}
+
+// ---- line scans and the per-pixel kernel in one (exact regime, 8 directions, no margins, segments that fit the registers) -----------
+// The min_p maps cost the scans 50 MB of stores and the per-pixel kernel 50 MB of loads (1080p), and both kernels run at what the memory
+// system gives for that (5 TB/s); the recurrences themselves are a few instructions per pixel.  So the maps are not written:
+// scan_cols_kernel<true> leaves only the carries of the lines at the segment boundaries (0.5 MB), and this kernel, a block per tile of
+// (segment of rows) x 64 columns, REPLAYS from the carries the lines that cross its tile -- the same subtraction per pixel in the same
+// order as the scans -- adds the min_p of the visiting passes per pixel in LDS (integers: order-free), and finishes the pixels of
+// the tile: keys -> winner -> outputs.  Waves by role: 0 the vertical lines of the tile, 1-2 its rows (every other one each), 3-5 the
+// diagonal lines (passes 2 and 3: one family, col - row = v), 6-8 the anti-diagonal lines downwards (pass 4), 9-11 the same lines
+// upwards (pass 5).  Every wave requests all the g values it will use before it touches the first (one memory latency per tile).  A diagonal family has 64 + rows - 1 lines through the tile; lane = line, so the 64 lanes read 64
+// consecutive pixels of a row (the part of a line left or right of the tile is walked too: its pixels lie in the neighbours' tiles,
+// its min_p is needed to arrive at the tile with the right value).
+constexpr int TILE_WAVES = 12;
+template <int NW>
+__global__ void __launch_bounds__(64 * TILE_WAVES) tile_finalize_kernel(CensusGeom g, ScanGeom sg, float Pout, const float *__restrict__ gmap, CarryMaps cm,
+                                                                       const uint2 *__restrict__ keys, WinnerOut out) {
+    __shared__ int msum[SCAN_MAXSEG][64];
+    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Hp = sg.Hp, Wp = sg.Wp, W = sg.W;
+    const int chunk = ((Hp + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3; // as scan_cols_kernel
+    const int seg = blockIdx.y, nb = seg * chunk, ne = min(Hp, nb + chunk), n_u = ne - nb, c0 = blockIdx.x * 64;
+    if (n_u <= 0) return; // (block uniform)
+    for (int t = threadIdx.x; t < SCAN_MAXSEG * 64; t += 64 * TILE_WAVES) (&msum[0][0])[t] = 0;
+    __syncthreads();
+    // g as a range-checked buffer: the straight-line loops below always walk SCAN_MAXSEG rows; a row past the image reads zeros, a row
+    // past the segment or a column outside the line reads a pixel nobody uses.  Every address lives in the vector offset (the range
+    // check does not see a scalar offset).
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)gmap, 0, (int)((int64_t)g.H * W * 4), 0x00020000);
+    auto gload = [&](uint32_t byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, byte_off, 0, 0)); };
+    if (role == 0) {
+        // vertical lines (pass 0): lane = column
+        const int c = c0 + lane;
+        const bool col_in = c < Wp;
+        float mp = col_in ? *cm.at(0, seg, c) : 0.0f;
+        const uint32_t off0 = col_in ? (uint32_t)((nb * W + c) * 4) : 0xFFFFFFFFu, st4 = (uint32_t)W * 4u;
+        float gv[SCAN_MAXSEG];
+#pragma unroll
+        for (int t = 0; t < SCAN_MAXSEG; t++) gv[t] = gload(col_in ? off0 + (uint32_t)t * st4 : 0xFFFFFFFFu);
+#pragma unroll
+        for (int t = 0; t < SCAN_MAXSEG; t++) {
+            atomicAdd(&msum[t][lane], t < n_u ? (int)mp : 0);
+            mp = gv[t] - mp;
+        }
+    } else if (role <= 2) {
+        // rows (pass 1), every other row of the tile: lane = column; min_p(k) = (-1)^(k-1) P_{k-1}, P the inclusive prefix sum of (-1)^k g
+        const int c = c0 + lane, par = role - 1;
+        const bool col_in = c < Wp;
+        const float sgn = (lane & 1) ? -1.0f : 1.0f;
+        const float *crow = cm.base + cm.off(1) + blockIdx.x;
+        float gv[SCAN_MAXSEG / 2], cr[SCAN_MAXSEG / 2];
+#pragma unroll
+        for (int u = 0; u < SCAN_MAXSEG / 2; u++) {
+            const int r = min(nb + 2 * u + par, Hp - 1); // (a row past the segment: computed and dropped)
+            gv[u] = gload(col_in ? (uint32_t)((r * W + c) * 4) : 0xFFFFFFFFu);
+            cr[u] = crow[(int64_t)r * cm.tiles()];
+        }
+#pragma unroll
+        for (int u = 0; u < SCAN_MAXSEG / 2; u++) {
+            const float P = wave_prefix_sum(sgn * gv[u]) + cr[u];
+            float Pm1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, P), 0x138, 0xF, 0xF, false)); // wave_shr:1
+            if (lane == 0) Pm1 = cr[u];
+            const float mp1 = -sgn * Pm1;
+            atomicAdd(&msum[2 * u + par][lane], (2 * u + par < n_u && col_in) ? (int)mp1 : 0);
+        }
+    } else {
+        // a diagonal family: roles 3-5 passes 2 + 3, 6-8 pass 4, 9-11 pass 5; lane = line
+        const int fam = (role - 3) / 3, part = (role - 3) % 3; // (wave uniform)
+        const int q = fam == 0 ? 2 : (fam == 1 ? 4 : 5);
+        const int s = fam == 0 ? 1 : -1;                            // pixel column = v + s * row
+        const int vlo = fam == 0 ? c0 - (ne - 1) : c0 + nb;          // first line through the tile
+        const int v = vlo + 64 * part + lane;
+        int r0 = 0, r1 = 0; // rows of the line (col_line_rows; passes 2 and 3 as one family)
+        bool line = false;
+        if (fam == 0) {
+            line = v >= -(Hp - 1) && v <= Wp - 1;
+            r0 = max(0, -v);
+            r1 = min(Hp, Wp - v);
+        } else if (fam == 1) {
+            line = v >= 0 && v < Wp;
+            r0 = 0;
+            r1 = min(Hp, v + 1);
+        } else {
+            line = v >= 0 && v < Hp;
+            r0 = max(0, v - Wp + 1);
+            r1 = v + 1;
+        }
+        const int b = max(r0, nb), e = line ? min(r1, ne) : 0; // rows of the line in this segment: [b, e)
+        float mp = (line && e > b) ? *cm.at(q, seg, carry_line_index(q, v, Hp)) : 0.0f;
+        const int twice = (fam == 0 && v == 0) ? 2 : 1; // the line both pass 2 and pass 3 run (finding F5): its min_p counts twice
+        // traversal step t visits row nb + t (downwards) or ne - 1 - t (pass 5); the pixel's offset moves by +- (W + s) floats per step
+        const int rfirst = fam == 2 ? ne - 1 : nb, dr = fam == 2 ? -1 : 1;
+        const uint32_t off0 = (uint32_t)((rfirst * W + v + s * rfirst) * 4), st4 = (uint32_t)(dr * (W + s) * 4);
+        float gv[SCAN_MAXSEG];
+#pragma unroll
+        for (int t = 0; t < SCAN_MAXSEG; t++) {
+            const int r = rfirst + dr * t;
+            gv[t] = gload((r >= b && r < e) ? off0 + (uint32_t)t * st4 : 0xFFFFFFFFu);
+        }
+        int cc = v + s * rfirst - c0; // column of the line's pixel in the tile at step t: cc + s dr t
+        int *mrow = &msum[rfirst - nb][0];
+#pragma unroll
+        for (int t = 0; t < SCAN_MAXSEG; t++) {
+            const int r = rfirst + dr * t;
+            const bool on = r >= b && r < e;
+            if (on && (unsigned)cc < 64u) atomicAdd(mrow + dr * t * 64 + cc, twice * (int)mp);
+            mp = on ? gv[t] - mp : mp;
+            cc += s * dr;
+        }
+    }
+    __syncthreads();
+    // the pixels of the tile, a row per wave and round
+    const int j = c0 + lane;
+    for (int k = role; k < n_u; k += TILE_WAVES) {
+        const int i = nb + k;
+        if (j < g.Ws) {
+            const int64_t p = (int64_t)i * g.Ws + j;
+            const int sdiag = i + j;
+            const int n_vis = 2 + (int)(i >= j) + (int)(j >= i) + (int)(sdiag < Wp) + (int)(sdiag < Hp);
+            finalize_px<NW>(g, out, i, j, p, msum[k][lane], n_vis, Pout, keys[p]);
         }
     }
 }
@@ -735,9 +979,47 @@ int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, floa
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
     // one launch: grid slices 0..4 (or 0) are the passes that cross the rows, the last slice is pass 1 (one wave per row)
     dim3 cgrid(std::max(ceil_div(std::max(Hp, Wp), 64), ceil_div(Hp, SCAN_SEGS)), (n_pass == 6 ? 5 : 1) + 1), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero);
+    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<false>, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero, CarryMaps{});
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
+}
+
+template <int NW>
+static int launch_tile_finalize(svh_context *ctx, dim3 tgrid, const CensusGeom &g, const ScanGeom &sg, float Pout, const float *gmap, const CarryMaps &cm,
+                                const uint2 *keys, const WinnerOut &win) {
+    SVH_LAUNCH(ctx, "census_finalize", tile_finalize_kernel<NW>, tgrid, 64 * TILE_WAVES, 0, g, sg, Pout, gmap, cm, keys, win);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+// sweep -> carries of the line scans -> replay + per-pixel kernel, no min_p maps (tile_finalize_kernel): whether the geometry allows it
+bool census_tiles_apply(const svh_context *ctx, const SgmArgs &a) {
+    const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0 && a.row_origin == 0 && a.full_H == 0 && a.store_rows == 0;
+    const int chunk = ((a.H + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3;
+    return ctx->census_tiles && whole && a.n_dir >= 8 && a.n_dir != 16 && a.H > 0 && a.W > 0 && chunk <= SCAN_MAXSEG && a.H <= 65535 &&
+           (int64_t)a.H * a.W <= ((int64_t)1 << 29);
+}
+
+int dev_census_sweep_tiles(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win) {
+    const int64_t npx = (int64_t)a.H * a.W;
+    uint2 *keys = scr.get_n<uint2>((size_t)npx);
+    float *gmap = scr.get_n<float>((size_t)npx);
+    CarryMaps cm;
+    cm.Hp = a.H;
+    cm.Wp = a.W;
+    cm.base = scr.get_n<float>((size_t)cm.total());
+    if (!keys || !gmap || !cm.base) return SVH_ERR_OUT_OF_MEMORY;
+    SVH_TRY(dev_census_sweep(ctx, a, cs, keys, gmap));
+    ScanGeom sg{0, 0, a.H, a.W, a.W};
+    dim3 cgrid(std::max(ceil_div(std::max(a.H, a.W), 64), ceil_div(a.H, SCAN_SEGS)), 6), cblock(64, SCAN_SEGS);
+    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, cm);
+    SVH_CHECK_LAUNCH(ctx);
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
+    const int chunk = ((a.H + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3;
+    dim3 tgrid(ceil_div(a.W, 64), ceil_div(a.H, chunk));
+#define CALL(N) launch_tile_finalize<N>(ctx, tgrid, g, sg, a.Pout, gmap, cm, keys, win)
+    SVH_NW_DISPATCH(cs.nWw, CALL)
+#undef CALL
 }
 
 int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out) {

@@ -382,6 +382,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_sweep_rl = value;
         return SVH_OK;
     }
+    if (strcmp(name, "census_tiles") == 0) {
+        ctx->census_tiles = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "cost_volume_colsum") == 0) {
         ctx->cost_volume_colsum = value != 0;
         return SVH_OK;

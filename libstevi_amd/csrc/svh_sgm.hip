@@ -641,6 +641,7 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
         SVH_TRY(dev_census_sweep(ctx, a, cs, keys, nullptr));
         return dev_census_finalize(ctx, a, cs, nullptr, keys, win);
     }
+    if (exact && lane_winner && win.any() && census_tiles_apply(ctx, a)) return dev_census_sweep_tiles(ctx, scr, a, cs, win); // no min_p maps at all
     if (exact) SVH_TRY(dev_census_sweep_and_scans(ctx, scr, a, cs, mmap, &keys));
     if (!exact || !lane_winner) SVH_TRY(dispatch_cost_branch(ctx, a, src, mmap, lane_winner ? nullptr : &out, !exact));
     if (lane_winner && win.any()) {

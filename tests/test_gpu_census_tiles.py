@@ -1,0 +1,96 @@
+"""census + SGM with the line recurrences run and their values used (reduction keys, Gaussian refinement taps): the form that keeps
+only the carries of the line scans and replays the lines per tile inside the per-pixel kernel (option "census_tiles", the default)
+against the form that writes the six min_p maps (option 0), the general wave-per-line kernels and the oracle -- the disparity map
+does not depend on the sum of the min_p (the identity of sgm.h:257-296), so these tests compare what does: the S value at the
+winner (keys) and the refined map.  sgm.h:186-311, :329-354 (pass coverage, the diagonal both start loops run)."""
+import numpy as np
+import pytest
+
+import oracle as so
+from helpers import parallax_pair
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import libstevi_amd as sv  # noqa: E402
+from libstevi_amd import matchingFunctions as MF  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def run(d_tgt, d_src, r, D, tiles, fast=1, **kw):
+    sv.set_option(d_tgt, "census_tiles", tiles)
+    sv.set_option(d_tgt, "census_fast_path", fast)
+    sv.set_option(d_tgt, "census_winner_shortcut", 0)
+    try:
+        return sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, sgmDirections=8, P1=0.3, P2=0.9, want_keys=True, refineKernel=so.GAUSSIAN,
+                              refine_h_radius=r, refine_v_radius=r, **kw)
+    finally:
+        sv.set_option(d_tgt, "census_tiles", 1)
+        sv.set_option(d_tgt, "census_fast_path", 1)
+        sv.set_option(d_tgt, "census_winner_shortcut", 1)
+
+
+def same(a, b, what):
+    for k in ("disp", "keys"):
+        assert torch.equal(a[k], b[k]), (what, k)
+    ra, rb = a["refined"].cpu().numpy(), b["refined"].cpu().numpy()
+    assert np.array_equal(np.isnan(ra), np.isnan(rb)), what
+    ok = ~np.isnan(ra)
+    assert np.array_equal(ra[ok].view(np.uint32), rb[ok].view(np.uint32)), what
+
+
+# taller than wide, wider than tall, one row, one column, fewer columns than a tile, rows that are no multiple of the segment length,
+# more rows than columns by more than a tile (diagonals that never reach the right edge), square (the corner diagonal)
+SHAPES = [(37, 90), (90, 37), (64, 64), (1, 70), (70, 1), (130, 200), (300, 70), (33, 33), (200, 130), (17, 400), (256, 256), (65, 129)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("D,r", [(32, 4), (64, 3), (40, 4)])
+def test_tiles_equal_maps(shape, D, r):
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W + D)
+    src = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    for Pout in (100.0, 0.0, 7.0):
+        a = run(d_tgt, d_src, r, D, 1, Pout=Pout)
+        b = run(d_tgt, d_src, r, D, 0, Pout=Pout)
+        same(a, b, (shape, D, r, Pout))
+
+
+@pytest.mark.parametrize("shape", [(37, 90), (90, 37), (1, 70), (70, 1), (130, 200), (64, 64)])
+def test_tiles_equal_general_kernels_and_oracle(shape):
+    H, W = shape
+    D, r = 64, 4
+    src, tgt, _ = parallax_pair(H, W, max(min(H, W) // 3, 1), H // 4, W // 4, 2, 9, seed=H + W)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    a = run(d_tgt, d_src, r, D, 1, Pout=100.0)
+    gen = run(d_tgt, d_src, r, D, 1, fast=0, Pout=100.0)
+    same(a, gen, shape)
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, r, r, D, so.RIGHT_TO_LEFT)
+    vol = so.sgm(cv, 8, so.COST, 0.3, 0.9, (0, 0, 0, 0), 100.0)
+    idx = so.extract_index(vol, so.COST)
+    assert np.array_equal(a["disp"].cpu().numpy(), so.index_to_disp(idx, so.RIGHT_TO_LEFT))
+    # the S value at the winner, from the reduction key's upper half (an order-preserving code of the float)
+    best = np.take_along_axis(vol, idx[..., None].astype(np.int64), axis=2)[..., 0]
+    u = best.astype(np.float32).view(np.uint32)
+    code = np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64)
+    keys = a["keys"].cpu().numpy().view(np.uint64)
+    assert np.array_equal(keys >> np.uint64(32), code)
+    exp = so.refine_disp(so.truncated_cost_volume(vol, idx, r, r, 1), idx, so.GAUSSIAN)
+    got = a["refined"].cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert np.allclose(got[~np.isnan(exp)], exp[~np.isnan(exp)], atol=1e-6)
+
+
+def test_tiles_full_hd_rows():
+    """1080 rows: sixteen segments of 68 rows (the last one 60), thirty column tiles; against the maps form."""
+    src, tgt, _ = parallax_pair(1080, 1920, 320, 320, 380, 8, 64, seed=3)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    a = run(d_tgt, d_src, 4, 256, 1, Pout=100.0)
+    b = run(d_tgt, d_src, 4, 256, 0, Pout=100.0)
+    same(a, b, "1080p")

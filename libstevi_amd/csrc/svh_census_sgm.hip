@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     // carries: the line's min_p at its first pixel of this segment in traversal order (lanes without a line write nothing)
     float *const carry_out = (CARRY && v < cl.v_lo + cl.n_lines) ? cm.at(q, seg, carry_line_index(q, v, sg.Hp)) : nullptr;
     float mp = 0.0f;
-    if (chunk <= SCAN_MAXSEG && npx <= ((int64_t)1 << 29)) {
+    if (CARRY && chunk <= SCAN_MAXSEG && npx <= ((int64_t)1 << 29)) { // (with the maps' stores behind it the lean form measured slower: 24 against 19 us)
         // LEAN FORM (scan_lean below) for the waves whose 64 lines all cross every row of the segment or none of it -- all but the
         // waves at the ragged ends of the diagonal passes -- when the segment's row count is one of the compile-time lengths
         const int segu = __builtin_amdgcn_readfirstlane(seg);

@@ -275,6 +275,9 @@ struct ScanGeom {
 // segment.  The rows are cut into SCAN_SEGS chunks handled by the threadIdx.y slices of the block.
 constexpr int SCAN_SEGS = 16;
 constexpr int SCAN_MAXSEG = 72; // segments up to this many rows are kept in registers (images up to 1152 rows)
+constexpr int TILE_SUB = 8;     // tile rows per segment (tiles mode: TileMaps, tile_finalize_kernel)
+// rows per segment: a multiple of TILE_SUB (and of four: the lean form's lengths)
+__host__ __device__ __forceinline__ int scan_chunk(int Hp) { return ((Hp + SCAN_SEGS - 1) / SCAN_SEGS + TILE_SUB - 1) / TILE_SUB * TILE_SUB; }
 
 struct ColLines {
     int s, v_lo, n_lines, dir;
@@ -308,34 +311,32 @@ __device__ __forceinline__ void col_line_rows(int q, int v, const ScanGeom &sg, 
 // lane offset + a scalar offset carried from step to step: no vector address arithmetic, no test per pixel; lanes without a line
 // load zeros and their stores are dropped (range-checked buffer accesses).  The arithmetic per pixel is the same subtraction in the
 // same order as in the general form: same bits.
-// Where scan_cols_kernel<true> leaves, instead of the min_p maps, the CARRIES of the recurrences: per plane, segment of rows and
-// line the min_p of the line's first pixel in the segment (in traversal order), and for pass 1 per row and 64-column tile the prefix
-// sum over the tiles before it.  tile_finalize_kernel replays the lines of a tile from them.  Line indices: pass 0 and 4: v; passes 2
-// and 3 (one plane): v + Hp - 1 (v = 0, the line both passes run, is written by both with the same value); pass 5: v.
-struct CarryMaps {
+// What scan_cols_kernel<true> leaves instead of the six min_p maps, for tile_finalize_kernel: the min_p values on the EDGES of the
+// tiles of R rows x 64 columns (R = an eighth of a segment) -- a ninth of the maps at 1080p.  Families f: 0 vertical (pass 0),
+// 1 diagonal (passes 2 and 3: one plane), 2 anti-diagonal downwards (pass 4), 3 anti-diagonal upwards (pass 5).
+//   E_f[y][col]   min_p of family f at pixel (row, col), row = the first row of tile row y in the family's direction of travel (its top
+//                 row R y; for f = 3 its bottom row): what the lines bring along when they enter tile row y
+//   S_f[tx][row]  f = 1, 3: min_p at pixel (row, 64 tx); f = 2: at (row, 64 tx + 63): what a line brings along when it enters tile
+//                 column tx through its side
+//   C1[row][tx]   pass 1: the signed prefix sum of the row over the tile columns before tx (scan_one_row)
+// Entries of pixels a pass does not visit are never written and never used.
+struct TileMaps {
     float *base = nullptr;
-    int Hp = 0, Wp = 0;
-    __host__ __device__ int l23() const { return Hp + Wp - 1; }
-    __host__ __device__ int tiles() const { return (Wp + 63) / 64; }
-    __host__ __device__ int64_t off(int q) const { // (q = 2 and 3 share)
-        const int64_t S = 16; // SCAN_SEGS
-        switch (q) {
-        case 0: return 0;
-        case 2: case 3: return S * Wp;
-        case 4: return S * (Wp + l23());
-        case 5: return S * (2 * (int64_t)Wp + l23());
-        default: return S * (2 * (int64_t)Wp + l23() + Hp); // pass 1: [row][tile]
-        }
-    }
-    __host__ __device__ int lines(int q) const { return q == 0 || q == 4 ? Wp : (q == 5 ? Hp : l23()); }
-    __host__ __device__ int64_t total() const { return off(1) + (int64_t)Hp * tiles(); }
-    __device__ float *at(int q, int seg, int line) const { return base + off(q) + (int64_t)seg * lines(q) + line; }
+    int Hp = 0, Wp = 0, R = 1, dbg = 0;
+    __host__ __device__ int ny() const { return (Hp + R - 1) / R; }
+    __host__ __device__ int tx() const { return (Wp + 63) / 64; }
+    __host__ __device__ int64_t e_size() const { return (int64_t)ny() * Wp; }
+    __host__ __device__ int64_t s_size() const { return (int64_t)tx() * Hp; }
+    __host__ __device__ int64_t e_off(int f) const { return f * e_size(); }
+    __host__ __device__ int64_t s_off(int f) const { return 4 * e_size() + (f - 1) * s_size(); } // f = 1, 2, 3
+    __host__ __device__ int64_t c1_off() const { return 4 * e_size() + 3 * s_size(); }
+    __host__ __device__ int64_t total() const { return 4 * e_size() + 4 * s_size(); }
 };
-__device__ __forceinline__ int carry_line_index(int q, int v, int Hp) { return (q == 2 || q == 3) ? v + Hp - 1 : v; }
+__host__ __device__ __forceinline__ int tile_family(int q) { return q == 0 ? 0 : (q <= 3 ? 1 : q - 2); }
 
 template <bool CARRY>
 __device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
-                                             int lane, const CarryMaps &cm);
+                                             int lane, const TileMaps &tm);
 
 struct LeanArgs {
     const float *gmap;
@@ -344,22 +345,55 @@ struct LeanArgs {
     uint32_t st4;      // bytes from a line's pixel to its pixel one row down
     uint32_t lane_off; // byte offset of this lane's pixel in the segment's first (lowest) row; 0xFFFFFFFF: no line
     int dir, seg, lane, n;
+    // tiles mode
+    int q, s, vwave, nb, n_u; // pass, column step per row, line of lane 0, first row and row count of the segment
+    int v_lo, n_lines;        // the pass's lines
+    int kb;                   // first traversal step of this lane's line in the segment (its steps: [kb, kb + n))
 };
-template <int LEN, bool CARRY> __device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], float *carry_out) {
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gmap, 0, (int)(a.npx * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, (int)(a.npx * 4), 0x00020000);
-    // traversal step k is the segment's row k (downwards) or LEN - 1 - k (pass 5, upwards)
-    const uint32_t s0 = a.dir > 0 ? 0u : (uint32_t)(LEN - 1) * a.st4, sd = a.dir > 0 ? a.st4 : 0u - a.st4;
-    float gv[LEN];
-    uint32_t so = s0;
+// tiles mode: S from the collector registers (lane k: the value of traversal step k, 64 steps per register)
+template <int LEN> __device__ __forceinline__ void store_side_values(const LeanArgs &a, const TileMaps &tm, const int (&coll)[(LEN + 63) / 64], int f, int T) {
+    float *const sp = tm.base + tm.s_off(f);
 #pragma unroll
-    for (int k = 0; k < LEN; k++) {
-        gv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, a.lane_off, so, 0));
-        so += sd;
+    for (int hh = 0; hh < (LEN + 63) / 64; hh++) {
+        const int k = 64 * hh + a.lane;
+        const int row = a.dir > 0 ? a.nb + k : a.nb + a.n_u - 1 - k;
+        const int lstar = (T - (a.vwave + a.s * row)) & 63;
+        const int vl = a.vwave + lstar, col = vl + a.s * row;
+        // the pixel exists and its line is one of this pass's (passes 2 and 3 share the plane: each writes its own lines)
+        if (k < a.n_u && col >= 0 && col < tm.Wp && vl >= a.v_lo && vl < a.v_lo + a.n_lines) sp[(int64_t)(col >> 6) * tm.Hp + row] = __builtin_bit_cast(float, coll[hh]);
     }
+}
+// FULL: every lane's line crosses all LEN rows of the segment or none (and, in tiles mode, LEN = TILE_SUB R: a whole segment)
+template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], const TileMaps &tm) {
+    static_assert(CARRY || FULL, "the maps mode has its own general form");
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gmap, 0, (int)(a.npx * 4), 0x00020000);
+    float gv[LEN];
     float mp = 0.0f;
+    // traversal step k is the segment's row k (downwards) or n_u - 1 - k (pass 5, upwards)
+    if constexpr (FULL) {
+        const uint32_t s0 = a.dir > 0 ? 0u : (uint32_t)(LEN - 1) * a.st4, sd = a.dir > 0 ? a.st4 : 0u - a.st4;
+        uint32_t so = s0;
 #pragma unroll
-    for (int k = 0; k < LEN; k++) mp = gv[k] - mp;
+        for (int k = 0; k < LEN; k++) {
+            gv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, a.lane_off, so, 0));
+            so += sd;
+        }
+#pragma unroll
+        for (int k = 0; k < LEN; k++) mp = gv[k] - mp;
+    } else {
+        // lines that start or end inside the segment, a last segment shorter than LEN: a pixel outside the lane's steps [kb, kb + n)
+        // loads 0.  Zeros before the line starts leave min_p at 0; the zeros after its end flip the sign of the sum once each.
+        const uint32_t first_off = a.lane_off + (a.dir > 0 ? 0u : (uint32_t)(a.n_u - 1) * a.st4), sd = a.dir > 0 ? a.st4 : 0u - a.st4;
+#pragma unroll
+        for (int k = 0; k < LEN; k++) {
+            const bool on = (unsigned)(k - a.kb) < (unsigned)a.n;
+            gv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, on ? first_off + (uint32_t)k * sd : 0xFFFFFFFFu, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < LEN; k++) mp = gv[k] - mp;
+        mp = ((LEN - (a.kb + a.n)) & 1) ? -mp : mp;
+        mp = a.n ? mp : 0.0f;
+    }
     seg_a[a.seg][a.lane] = mp;
     seg_n[a.seg][a.lane] = a.n;
     __syncthreads();
@@ -370,24 +404,68 @@ template <int LEN, bool CARRY> __device__ __forceinline__ void scan_lean(const L
         for (int t = SCAN_SEGS - 1; t > a.seg; t--) mp = seg_a[t][a.lane] + ((seg_n[t][a.lane] & 1) ? -mp : mp);
     }
     if constexpr (CARRY) {
-        if (carry_out) *carry_out = mp;
+        // The replay keeps what lies on tile edges: E at the first row of every tile row in the direction of travel (a full-wave
+        // store), S from the ONE lane per row whose pixel sits on a tile's side -- the wave's 64 lines are 64 consecutive pixels of the
+        // row, so that lane is wave uniform: its value is picked with v_readlane and parked in lane k of a collector register; two
+        // stores at the end write them.  (A line that has not started yet carries 0 through zeros; after its end nothing is kept.)
+        constexpr int RF = LEN / TILE_SUB > 0 ? LEN / TILE_SUB : 1; // (FULL: LEN = TILE_SUB R)
+        const int f = tile_family(a.q), T = a.q == 4 ? 63 : 0, R = FULL ? RF : tm.R;
+        const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void *)(tm.base + tm.e_off(f)), 0, (int)(tm.e_size() * 4), 0x00020000);
+        const int v = a.vwave + a.lane;
+        // tile rows m = 0 .. TILE_SUB - 1 of the segment: the traversal step at which the lines enter them (-1: no such tile row)
+        int ek[TILE_SUB];
+#pragma unroll
+        for (int m = 0; m < TILE_SUB; m++) {
+            if (a.dir > 0) ek[m] = R * m < a.n_u ? R * m : -1;
+            else ek[m] = R * m < a.n_u ? a.n_u - min(R * (m + 1), a.n_u) : -1; // its bottom row: nb + min(R (m + 1), n_u) - 1
+        }
+        int coll[(LEN + 63) / 64];
+#pragma unroll
+        for (int hh = 0; hh < (LEN + 63) / 64; hh++) coll[hh] = 0;
+#pragma unroll
+        for (int k = 0; k < LEN; k++) {
+            const int row = a.dir > 0 ? a.nb + k : a.nb + a.n_u - 1 - k; // (wave uniform)
+            int m = -1;
+            if constexpr (FULL) {
+                if (k % RF == 0) m = a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF;
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < TILE_SUB; mm++) m = k == ek[mm] ? mm : m;
+            }
+            if (m >= 0) { // (wave uniform)
+                const bool on = FULL ? a.lane_off != 0xFFFFFFFFu : (unsigned)(k - a.kb) < (unsigned)a.n;
+                const uint32_t eo = on ? (uint32_t)(((TILE_SUB * a.seg + m) * tm.Wp + v + a.s * row) * 4) : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mp), re, eo, 0, 0);
+            }
+            if (f > 0) {
+                const int lstar = (T - (a.vwave + a.s * row)) & 63; // the lane whose pixel has column = T (mod 64) in this row
+                const int picked = __builtin_amdgcn_readlane(__builtin_bit_cast(int, mp), lstar);
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(coll[k >> 6]) : "s"(picked), "n"(k & 63));
+            }
+            mp = gv[k] - mp;
+        }
+        if (f > 0) store_side_values<LEN>(a, tm, coll, f, T);
         return;
     }
-    so = s0;
+    if constexpr (FULL) {
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)a.out, 0, (int)(a.npx * 4), 0x00020000);
+        const uint32_t s0 = a.dir > 0 ? 0u : (uint32_t)(LEN - 1) * a.st4, sd = a.dir > 0 ? a.st4 : 0u - a.st4;
+        uint32_t so = s0;
 #pragma unroll
-    for (int k = 0; k < LEN; k++) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mp), ro, a.lane_off, so, 0);
-        so += sd;
-        mp = gv[k] - mp;
+        for (int k = 0; k < LEN; k++) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mp), ro, a.lane_off, so, 0);
+            so += sd;
+            mp = gv[k] - mp;
+        }
     }
 }
 
 template <bool CARRY>
 __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
-                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero, CarryMaps cm) {
+                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero, TileMaps tm) {
     if (skip_if_nonzero && *skip_if_nonzero != 0) return; // the integer-volume probe failed: the line kernels make the maps
     if ((int)blockIdx.y == (n_pass <= 2 ? 1 : 5)) { // last slice of the grid: pass 1, one wave per row
-        scan_one_row<CARRY>(gmap, sg, npx, mmap, blockIdx.x * SCAN_SEGS + threadIdx.y, threadIdx.x, cm);
+        scan_one_row<CARRY>(gmap, sg, npx, mmap, blockIdx.x * SCAN_SEGS + threadIdx.y, threadIdx.x, tm);
         return;
     }
     __shared__ float seg_a[SCAN_SEGS][64];
@@ -399,7 +477,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     if ((int)blockIdx.x * 64 >= cl.n_lines) return; // whole block out of range (uniform)
     int r0 = 0, r1 = 0;
     if (v < cl.v_lo + cl.n_lines) col_line_rows(q, v, sg, r0, r1);
-    const int chunk = ((sg.Hp + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3; // (a multiple of four: the lean form's lengths)
+    const int chunk = scan_chunk(sg.Hp);
     const int b = max(r0, seg * chunk), e = min(r1, (seg + 1) * chunk);
     const int n = max(e - b, 0);
     // pixel index of relative row r on this line: (top + r) * W + left + v + s r, advanced by dir * (W + s) per step
@@ -407,8 +485,6 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     const int64_t p0 = (int64_t)(sg.top + first) * sg.W + sg.left + v + cl.s * first;
     const int64_t step = (int64_t)cl.dir * (sg.W + cl.s);
     float *out = CARRY ? nullptr : mmap + (int64_t)min_p_plane(q) * npx;
-    // carries: the line's min_p at its first pixel of this segment in traversal order (lanes without a line write nothing)
-    float *const carry_out = (CARRY && v < cl.v_lo + cl.n_lines) ? cm.at(q, seg, carry_line_index(q, v, sg.Hp)) : nullptr;
     float mp = 0.0f;
     if (CARRY && chunk <= SCAN_MAXSEG && npx <= ((int64_t)1 << 29)) { // (with the maps' stores behind it the lean form measured slower: 24 against 19 us)
         // LEAN FORM (scan_lean below) for the waves whose 64 lines all cross every row of the segment or none of it -- all but the
@@ -416,19 +492,30 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         const int segu = __builtin_amdgcn_readfirstlane(seg);
         const int nb = segu * chunk, ne = min(sg.Hp, nb + chunk), n_u = ne - nb; // rows [nb, ne) of the margin box
         const bool ragged = n != 0 && (b != nb || e != ne);
-        if (n_u > 0 && (n_u & 3) == 0 && __builtin_amdgcn_ballot_w64(ragged) == 0) {
-            const LeanArgs la{gmap, out, npx, (uint32_t)(sg.W + cl.s) * 4u,
-                              n != 0 ? (uint32_t)(((int64_t)(sg.top + nb) * sg.W + sg.left + v + cl.s * nb) * 4) : 0xFFFFFFFFu, cl.dir, segu, lane, n};
-            switch (n_u >> 2) {
-#define SVH_LEAN(Q) case Q: scan_lean<4 * Q, CARRY>(la, seg_a, seg_n, carry_out); return;
-                SVH_LEAN(1) SVH_LEAN(2) SVH_LEAN(3) SVH_LEAN(4) SVH_LEAN(5) SVH_LEAN(6) SVH_LEAN(7) SVH_LEAN(8) SVH_LEAN(9)
-                SVH_LEAN(10) SVH_LEAN(11) SVH_LEAN(12) SVH_LEAN(13) SVH_LEAN(14) SVH_LEAN(15) SVH_LEAN(16) SVH_LEAN(17) SVH_LEAN(18)
+        bool full = n_u > 0 && (n_u & 3) == 0 && (!CARRY || n_u == chunk) && __builtin_amdgcn_ballot_w64(ragged) == 0;
+        if (tm.dbg == 1 && n_u == chunk) full = true;  // DEBUG
+        if (tm.dbg == 2) full = false;                 // DEBUG
+        if (full || CARRY) {
+            // lane_off: the lane's pixel in row nb (in the general form possibly not a pixel of its line: only used inside its steps)
+            const uint32_t lane_off = (full && n == 0) ? 0xFFFFFFFFu : (uint32_t)(((int64_t)(sg.top + nb) * sg.W + sg.left + v + cl.s * nb) * 4);
+            const LeanArgs la{gmap, out, npx, (uint32_t)(sg.W + cl.s) * 4u, lane_off, cl.dir, segu, lane, n,
+                              q, cl.s, cl.v_lo + (int)blockIdx.x * 64, nb, n_u, cl.v_lo, cl.n_lines, cl.dir > 0 ? b - nb : ne - e};
+            if (n_u > 0) {
+                switch ((n_u + 3) >> 2) {
+#define SVH_LEAN(Q)                                                     \
+    case Q:                                                             \
+        if (full) scan_lean<4 * Q, CARRY, true>(la, seg_a, seg_n, tm);  \
+        else if constexpr (CARRY) scan_lean<4 * Q, true, false>(la, seg_a, seg_n, tm); \
+        return;
+                    SVH_LEAN(1) SVH_LEAN(2) SVH_LEAN(3) SVH_LEAN(4) SVH_LEAN(5) SVH_LEAN(6) SVH_LEAN(7) SVH_LEAN(8) SVH_LEAN(9)
+                    SVH_LEAN(10) SVH_LEAN(11) SVH_LEAN(12) SVH_LEAN(13) SVH_LEAN(14) SVH_LEAN(15) SVH_LEAN(16) SVH_LEAN(17) SVH_LEAN(18)
 #undef SVH_LEAN
-            default: break;
+                default: break;
+                }
             }
         }
     }
-    if (chunk <= SCAN_MAXSEG) {
+    if (!CARRY && chunk <= SCAN_MAXSEG) {
         // the whole segment lives in registers: one round of loads (all in flight together), summary, chain, replay
         float gv[SCAN_MAXSEG];
 #pragma unroll
@@ -444,10 +531,6 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
             for (int t = 0; t < seg; t++) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
         } else {
             for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
-        }
-        if constexpr (CARRY) {
-            if (carry_out) *carry_out = mp;
-            return;
         }
 #pragma unroll
         for (int k = 0; k < SCAN_MAXSEG; k++)
@@ -477,7 +560,19 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
     }
     if constexpr (CARRY) {
-        if (carry_out) *carry_out = mp;
+        // tiles mode, the waves the lean form does not take (ragged ends of the diagonal passes, the last segment): the values on the
+        // tile edges (TileMaps), pixel by pixel
+        const int f = tile_family(q), T = q == 4 ? 63 : 0, R = tm.R;
+        float *const ep = tm.base + tm.e_off(f), *const sp = f > 0 ? tm.base + tm.s_off(f) : nullptr;
+        int64_t p = p0;
+        int row = first, col = v + cl.s * first;
+        for (int k = 0; k < n; k++, p += step, row += cl.dir, col += cl.s * cl.dir) {
+            const int rm = row % R;
+            const bool edge = cl.dir > 0 ? rm == 0 : (rm == R - 1 || row == sg.Hp - 1);
+            if (edge) ep[(int64_t)(row / R) * tm.Wp + col] = mp;
+            if (sp && (col & 63) == T) sp[(int64_t)(col >> 6) * tm.Hp + row] = mp;
+            mp = gmap[p] - mp;
+        }
         return;
     }
     {
@@ -520,11 +615,11 @@ constexpr int SCAN_ROW_CHUNKS = 32; // rows up to 2048 pixels are loaded in one 
 
 template <bool CARRY>
 __device__ __forceinline__ void scan_one_row(const float *__restrict__ gmap, const ScanGeom &sg, int64_t npx, float *__restrict__ mmap, int row,
-                                             int lane, const CarryMaps &cm) {
+                                             int lane, const TileMaps &tm) {
     if (row >= sg.Hp) return;
     const int64_t base = (int64_t)(sg.top + row) * sg.W + sg.left;
     float *out = CARRY ? nullptr : mmap + npx; // pass 1
-    float *const crow = CARRY ? cm.base + cm.off(1) + (int64_t)row * cm.tiles() : nullptr; // carries: the prefix sum before each 64-pixel chunk
+    float *const crow = CARRY ? tm.base + tm.c1_off() + (int64_t)row * tm.tx() : nullptr; // C1: the prefix sum before each 64-pixel chunk
     const float sgn = (lane & 1) ? -1.0f : 1.0f; // (-1)^lane; chunks start at even pixel indices
     float carry = 0.0f;                            // prefix sum of h over the previous chunks
     auto chunk = [&](float gval, int k) {
@@ -680,124 +775,98 @@ __device__ __forceinline__ void finalize_px(const CensusGeom &g, const WinnerOut
     }
 }
 
-// ---- line scans and the per-pixel kernel in one (exact regime, 8 directions, no margins, segments that fit the registers) -----------
-// The min_p maps cost the scans 50 MB of stores and the per-pixel kernel 50 MB of loads (1080p), and both kernels run at what the memory
-// system gives for that (5 TB/s); the recurrences themselves are a few instructions per pixel.  So the maps are not written:
-// scan_cols_kernel<true> leaves only the carries of the lines at the segment boundaries (0.5 MB), and this kernel, a block per tile of
-// (segment of rows) x 64 columns, REPLAYS from the carries the lines that cross its tile -- the same subtraction per pixel in the same
-// order as the scans -- adds the min_p of the visiting passes per pixel in LDS (integers: order-free), and finishes the pixels of
-// the tile: keys -> winner -> outputs.  Waves by role: 0 the vertical lines of the tile, 1-2 its rows (every other one each), 3-5 the
-// diagonal lines (passes 2 and 3: one family, col - row = v), 6-8 the anti-diagonal lines downwards (pass 4), 9-11 the same lines
-// upwards (pass 5).  Every wave requests all the g values it will use before it touches the first (one memory latency per tile).  A diagonal family has 64 + rows - 1 lines through the tile; lane = line, so the 64 lanes read 64
-// consecutive pixels of a row (the part of a line left or right of the tile is walked too: its pixels lie in the neighbours' tiles,
-// its min_p is needed to arrive at the tile with the right value).
-constexpr int TILE_WAVES = 12;
+// ---- the per-pixel kernel without the min_p maps (exact regime, 8 directions, no margins, segments that fit the registers) ----------
+// The six maps cost the scans 50 MB of stores and the per-pixel kernel 50 MB of loads (1080p), and both kernels run at what the memory
+// system gives for that; the recurrences themselves are a few instructions per pixel.  So the maps are not written: scan_cols_kernel<true>
+// keeps the min_p values on the edges of tiles of R rows x 64 columns (TileMaps, 3 % of the maps) and this kernel, a wave per tile,
+// REPLAYS the recurrences inside its tile -- the same subtraction per pixel in the same order as the scans -- with the lanes as the
+// tile's columns for every family: going one row down, the min_p a diagonal line carries moves one lane to the right (v_mov_dpp
+// wave_shr:1), an anti-diagonal one to the left, a vertical one stays; the lane a line enters the tile through takes its value from S
+// (or 0 where the line starts: the image border).  Pass 5 walks the rows upwards.  The sum of the visiting passes' min_p per pixel
+// stays in registers, then keys -> winner -> outputs as in census_finalize_kernel.  g is read once.
+constexpr int TILE_RMAX = SCAN_MAXSEG / TILE_SUB;
+__device__ __forceinline__ float dpp_wave_shr1(float src, float old) { // lane l <- lane l - 1; lane 0 <- old
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float src, float old) { // lane l <- lane l + 1; lane 63 <- old
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x130, 0xF, 0xF, false));
+}
 template <int NW>
-__global__ void __launch_bounds__(64 * TILE_WAVES) tile_finalize_kernel(CensusGeom g, ScanGeom sg, float Pout, const float *__restrict__ gmap, CarryMaps cm,
-                                                                       const uint2 *__restrict__ keys, WinnerOut out) {
-    __shared__ int msum[SCAN_MAXSEG][64];
-    const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Hp = sg.Hp, Wp = sg.Wp, W = sg.W;
-    const int chunk = ((Hp + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3; // as scan_cols_kernel
-    const int seg = blockIdx.y, nb = seg * chunk, ne = min(Hp, nb + chunk), n_u = ne - nb, c0 = blockIdx.x * 64;
-    if (n_u <= 0) return; // (block uniform)
-    for (int t = threadIdx.x; t < SCAN_MAXSEG * 64; t += 64 * TILE_WAVES) (&msum[0][0])[t] = 0;
-    __syncthreads();
-    // g as a range-checked buffer: the straight-line loops below always walk SCAN_MAXSEG rows; a row past the image reads zeros, a row
-    // past the segment or a column outside the line reads a pixel nobody uses.  Every address lives in the vector offset (the range
-    // check does not see a scalar offset).
+__global__ void __launch_bounds__(256) tile_finalize_kernel(CensusGeom g, ScanGeom sg, float Pout, const float *__restrict__ gmap, TileMaps tm,
+                                                            const uint2 *__restrict__ keys, WinnerOut out) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Hp = sg.Hp, Wp = sg.Wp, W = sg.W, R = tm.R;
+    const int txi = blockIdx.x, y = blockIdx.y * 4 + wave;
+    const int top = y * R;
+    if (top >= Hp) return;
+    const int n_r = min(R, Hp - top), c0 = txi * 64, c = c0 + lane;
+    const bool col_in = c < Wp;
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)gmap, 0, (int)((int64_t)g.H * W * 4), 0x00020000);
-    auto gload = [&](uint32_t byte_off) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, byte_off, 0, 0)); };
-    if (role == 0) {
-        // vertical lines (pass 0): lane = column
-        const int c = c0 + lane;
-        const bool col_in = c < Wp;
-        float mp = col_in ? *cm.at(0, seg, c) : 0.0f;
-        const uint32_t off0 = col_in ? (uint32_t)((nb * W + c) * 4) : 0xFFFFFFFFu, st4 = (uint32_t)W * 4u;
-        float gv[SCAN_MAXSEG];
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)tm.base, 0, (int)(tm.total() * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)keys, 0, (int)((int64_t)g.H * g.Ws * 8), 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t &r, int64_t index, bool on) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, on ? (uint32_t)(index * 4) : 0xFFFFFFFFu, 0, 0));
+    };
+    // everything the tile needs, requested before anything is used
+    float gv[TILE_RMAX];
+    uint2 kv[TILE_RMAX];
 #pragma unroll
-        for (int t = 0; t < SCAN_MAXSEG; t++) gv[t] = gload(col_in ? off0 + (uint32_t)t * st4 : 0xFFFFFFFFu);
+    for (int k = 0; k < TILE_RMAX; k++) {
+        const bool on = col_in && k < n_r;
+        gv[k] = ld(rg, (int64_t)(top + k) * W + c, on);
+        const auto kk = __builtin_amdgcn_raw_buffer_load_b64(rk, on ? (uint32_t)(((int64_t)(top + k) * g.Ws + c) * 8) : 0xFFFFFFFFu, 0, 0);
+        kv[k] = make_uint2(kk[0], kk[1]);
+    }
+    const int bot = top + n_r - 1;
+    float mp0 = ld(rt, tm.e_off(0) + (int64_t)y * Wp + c, col_in), mp1d = ld(rt, tm.e_off(1) + (int64_t)y * Wp + c, col_in),
+          mp4 = ld(rt, tm.e_off(2) + (int64_t)y * Wp + c, col_in), mp5 = ld(rt, tm.e_off(3) + (int64_t)y * Wp + c, col_in);
+    // the values lines bring in through the tile's sides, one per row transition, laid out so that the lane that takes the next one
+    // holds it after a rotation by one lane per step:
+    //   diagonal (enters lane 0 at row top + 1 + k after step k): lane k <- S1[tx][top + 1 + k], rotated left
+    //   pass 4 (enters lane 63 at row top + 1 + k): lane 63 - k <- S2[tx][top + 1 + k], rotated right
+    //   pass 5 (upwards; enters lane 0 at row bot - 1 - k after step k): lane k <- S3[tx][bot - 1 - k], rotated left
+    // A line that starts at the image border brings 0.
+    const bool left_nb = c0 > 0, right_nb = c0 + 64 < Wp;
+    float s1 = ld(rt, tm.s_off(1) + (int64_t)txi * Hp + top + 1 + lane, left_nb && lane < TILE_RMAX && top + 1 + lane < Hp);
+    float s2 = ld(rt, tm.s_off(2) + (int64_t)txi * Hp + top + 1 + (63 - lane), right_nb && 63 - lane < TILE_RMAX && top + 1 + (63 - lane) < Hp);
+    float s3 = ld(rt, tm.s_off(3) + (int64_t)txi * Hp + bot - 1 - lane, left_nb && lane < TILE_RMAX && bot - 1 - lane >= 0);
+    const float c1 = ld(rt, tm.c1_off() + (int64_t)(top + lane) * tm.tx() + txi, lane < TILE_RMAX && top + lane < Hp); // lane k: row top + k
+    const float sgn = (lane & 1) ? -1.0f : 1.0f;
+    float acc[TILE_RMAX];
+    // downwards: vertical, diagonal (counted twice on the line both pass 2 and pass 3 run: finding F5), pass 4 where it visits; and the rows
 #pragma unroll
-        for (int t = 0; t < SCAN_MAXSEG; t++) {
-            atomicAdd(&msum[t][lane], t < n_u ? (int)mp : 0);
-            mp = gv[t] - mp;
-        }
-    } else if (role <= 2) {
-        // rows (pass 1), every other row of the tile: lane = column; min_p(k) = (-1)^(k-1) P_{k-1}, P the inclusive prefix sum of (-1)^k g
-        const int c = c0 + lane, par = role - 1;
-        const bool col_in = c < Wp;
-        const float sgn = (lane & 1) ? -1.0f : 1.0f;
-        const float *crow = cm.base + cm.off(1) + blockIdx.x;
-        float gv[SCAN_MAXSEG / 2], cr[SCAN_MAXSEG / 2];
+    for (int k = 0; k < TILE_RMAX; k++) {
+        const int i = top + k;
+        float a = mp0 + mp1d;
+        a += (i == c) ? mp1d : 0.0f;
+        a += (i + c < Wp) ? mp4 : 0.0f;
+        // pass 1: min_p(col) = (-1)^(col - 1) P_{col - 1}, P the inclusive prefix sum of (-1)^col g over the row (scan_one_row)
+        const float carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c1), k));
+        const float P = wave_prefix_sum(sgn * gv[k]) + carry;
+        a += -sgn * dpp_wave_shr1(P, carry);
+        acc[k] = a;
+        mp0 = gv[k] - mp0;
+        mp1d = dpp_wave_shr1(gv[k] - mp1d, s1);
+        s1 = dpp_wave_shl1(s1, 0.0f);
+        mp4 = dpp_wave_shl1(gv[k] - mp4, s2);
+        s2 = dpp_wave_shr1(s2, 0.0f);
+    }
+    // upwards: pass 5 where it visits
 #pragma unroll
-        for (int u = 0; u < SCAN_MAXSEG / 2; u++) {
-            const int r = min(nb + 2 * u + par, Hp - 1); // (a row past the segment: computed and dropped)
-            gv[u] = gload(col_in ? (uint32_t)((r * W + c) * 4) : 0xFFFFFFFFu);
-            cr[u] = crow[(int64_t)r * cm.tiles()];
-        }
-#pragma unroll
-        for (int u = 0; u < SCAN_MAXSEG / 2; u++) {
-            const float P = wave_prefix_sum(sgn * gv[u]) + cr[u];
-            float Pm1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, P), 0x138, 0xF, 0xF, false)); // wave_shr:1
-            if (lane == 0) Pm1 = cr[u];
-            const float mp1 = -sgn * Pm1;
-            atomicAdd(&msum[2 * u + par][lane], (2 * u + par < n_u && col_in) ? (int)mp1 : 0);
-        }
-    } else {
-        // a diagonal family: roles 3-5 passes 2 + 3, 6-8 pass 4, 9-11 pass 5; lane = line
-        const int fam = (role - 3) / 3, part = (role - 3) % 3; // (wave uniform)
-        const int q = fam == 0 ? 2 : (fam == 1 ? 4 : 5);
-        const int s = fam == 0 ? 1 : -1;                            // pixel column = v + s * row
-        const int vlo = fam == 0 ? c0 - (ne - 1) : c0 + nb;          // first line through the tile
-        const int v = vlo + 64 * part + lane;
-        int r0 = 0, r1 = 0; // rows of the line (col_line_rows; passes 2 and 3 as one family)
-        bool line = false;
-        if (fam == 0) {
-            line = v >= -(Hp - 1) && v <= Wp - 1;
-            r0 = max(0, -v);
-            r1 = min(Hp, Wp - v);
-        } else if (fam == 1) {
-            line = v >= 0 && v < Wp;
-            r0 = 0;
-            r1 = min(Hp, v + 1);
-        } else {
-            line = v >= 0 && v < Hp;
-            r0 = max(0, v - Wp + 1);
-            r1 = v + 1;
-        }
-        const int b = max(r0, nb), e = line ? min(r1, ne) : 0; // rows of the line in this segment: [b, e)
-        float mp = (line && e > b) ? *cm.at(q, seg, carry_line_index(q, v, Hp)) : 0.0f;
-        const int twice = (fam == 0 && v == 0) ? 2 : 1; // the line both pass 2 and pass 3 run (finding F5): its min_p counts twice
-        // traversal step t visits row nb + t (downwards) or ne - 1 - t (pass 5); the pixel's offset moves by +- (W + s) floats per step
-        const int rfirst = fam == 2 ? ne - 1 : nb, dr = fam == 2 ? -1 : 1;
-        const uint32_t off0 = (uint32_t)((rfirst * W + v + s * rfirst) * 4), st4 = (uint32_t)(dr * (W + s) * 4);
-        float gv[SCAN_MAXSEG];
-#pragma unroll
-        for (int t = 0; t < SCAN_MAXSEG; t++) {
-            const int r = rfirst + dr * t;
-            gv[t] = gload((r >= b && r < e) ? off0 + (uint32_t)t * st4 : 0xFFFFFFFFu);
-        }
-        int cc = v + s * rfirst - c0; // column of the line's pixel in the tile at step t: cc + s dr t
-        int *mrow = &msum[rfirst - nb][0];
-#pragma unroll
-        for (int t = 0; t < SCAN_MAXSEG; t++) {
-            const int r = rfirst + dr * t;
-            const bool on = r >= b && r < e;
-            if (on && (unsigned)cc < 64u) atomicAdd(mrow + dr * t * 64 + cc, twice * (int)mp);
-            mp = on ? gv[t] - mp : mp;
-            cc += s * dr;
+    for (int k = TILE_RMAX - 1; k >= 0; k--) {
+        if (k < n_r) { // (wave uniform)
+            const int i = top + k;
+            acc[k] += (i + c < Hp) ? mp5 : 0.0f;
+            mp5 = dpp_wave_shr1(gv[k] - mp5, s3);
+            s3 = dpp_wave_shl1(s3, 0.0f);
         }
     }
-    __syncthreads();
-    // the pixels of the tile, a row per wave and round
-    const int j = c0 + lane;
-    for (int k = role; k < n_u; k += TILE_WAVES) {
-        const int i = nb + k;
-        if (j < g.Ws) {
-            const int64_t p = (int64_t)i * g.Ws + j;
-            const int sdiag = i + j;
-            const int n_vis = 2 + (int)(i >= j) + (int)(j >= i) + (int)(sdiag < Wp) + (int)(sdiag < Hp);
-            finalize_px<NW>(g, out, i, j, p, msum[k][lane], n_vis, Pout, keys[p]);
+#pragma unroll
+    for (int k = 0; k < TILE_RMAX; k++) {
+        if (k < n_r && col_in) {
+            const int i = top + k, sdiag = i + c;
+            const int n_vis = 2 + (int)(i >= c) + (int)(c >= i) + (int)(sdiag < Wp) + (int)(sdiag < Hp);
+            finalize_px<NW>(g, out, i, c, (int64_t)i * g.Ws + c, (int)acc[k], n_vis, Pout, kv[k]);
         }
     }
 }
@@ -979,45 +1048,48 @@ int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, floa
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
     // one launch: grid slices 0..4 (or 0) are the passes that cross the rows, the last slice is pass 1 (one wave per row)
     dim3 cgrid(std::max(ceil_div(std::max(Hp, Wp), 64), ceil_div(Hp, SCAN_SEGS)), (n_pass == 6 ? 5 : 1) + 1), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<false>, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero, CarryMaps{});
+    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<false>, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero, TileMaps{});
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
 template <int NW>
-static int launch_tile_finalize(svh_context *ctx, dim3 tgrid, const CensusGeom &g, const ScanGeom &sg, float Pout, const float *gmap, const CarryMaps &cm,
+static int launch_tile_finalize(svh_context *ctx, dim3 tgrid, const CensusGeom &g, const ScanGeom &sg, float Pout, const float *gmap, const TileMaps &tm,
                                 const uint2 *keys, const WinnerOut &win) {
-    SVH_LAUNCH(ctx, "census_finalize", tile_finalize_kernel<NW>, tgrid, 64 * TILE_WAVES, 0, g, sg, Pout, gmap, cm, keys, win);
+    SVH_LAUNCH(ctx, "census_finalize", tile_finalize_kernel<NW>, tgrid, 256, 0, g, sg, Pout, gmap, tm, keys, win);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
-// sweep -> carries of the line scans -> replay + per-pixel kernel, no min_p maps (tile_finalize_kernel): whether the geometry allows it
+// sweep -> tile-edge values of the line scans -> replay + per-pixel kernel, no min_p maps (tile_finalize_kernel): whether the geometry allows it
 bool census_tiles_apply(const svh_context *ctx, const SgmArgs &a) {
     const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0 && a.row_origin == 0 && a.full_H == 0 && a.store_rows == 0;
-    const int chunk = ((a.H + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3;
+    const int chunk = scan_chunk(a.H);
     return ctx->census_tiles && whole && a.n_dir >= 8 && a.n_dir != 16 && a.H > 0 && a.W > 0 && chunk <= SCAN_MAXSEG && a.H <= 65535 &&
-           (int64_t)a.H * a.W <= ((int64_t)1 << 29);
+           (int64_t)a.H * a.W <= ((int64_t)1 << 28);
 }
 
 int dev_census_sweep_tiles(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win) {
     const int64_t npx = (int64_t)a.H * a.W;
     uint2 *keys = scr.get_n<uint2>((size_t)npx);
     float *gmap = scr.get_n<float>((size_t)npx);
-    CarryMaps cm;
-    cm.Hp = a.H;
-    cm.Wp = a.W;
-    cm.base = scr.get_n<float>((size_t)cm.total());
-    if (!keys || !gmap || !cm.base) return SVH_ERR_OUT_OF_MEMORY;
+    const int chunk = scan_chunk(a.H);
+    TileMaps tm;
+    tm.Hp = a.H;
+    tm.Wp = a.W;
+    tm.R = chunk / TILE_SUB;
+    tm.base = scr.get_n<float>((size_t)tm.total());
+    if (!keys || !gmap || !tm.base) return SVH_ERR_OUT_OF_MEMORY;
     SVH_TRY(dev_census_sweep(ctx, a, cs, keys, gmap));
+    if (const char *dm = getenv("SVH_K1_MODE")) tm.dbg = atoi(dm); // DEBUG
+    if (const char *fill = getenv("SVH_TILES_FILL")) SVH_HIP_CHECK(ctx, hipMemsetAsync(tm.base, atoi(fill), (size_t)tm.total() * 4, ctx->stream)); // DEBUG
     ScanGeom sg{0, 0, a.H, a.W, a.W};
     dim3 cgrid(std::max(ceil_div(std::max(a.H, a.W), 64), ceil_div(a.H, SCAN_SEGS)), 6), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, cm);
+    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm);
     SVH_CHECK_LAUNCH(ctx);
     CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
-    const int chunk = ((a.H + SCAN_SEGS - 1) / SCAN_SEGS + 3) & ~3;
-    dim3 tgrid(ceil_div(a.W, 64), ceil_div(a.H, chunk));
-#define CALL(N) launch_tile_finalize<N>(ctx, tgrid, g, sg, a.Pout, gmap, cm, keys, win)
+    dim3 tgrid(tm.tx(), ceil_div(tm.ny(), 4));
+#define CALL(N) launch_tile_finalize<N>(ctx, tgrid, g, sg, a.Pout, gmap, tm, keys, win)
     SVH_NW_DISPATCH(cs.nWw, CALL)
 #undef CALL
 }

@@ -36,7 +36,9 @@ def run(d_tgt, d_src, r, D, tiles, fast=1, **kw):
 
 def same(a, b, what):
     for k in ("disp", "keys"):
-        assert torch.equal(a[k], b[k]), (what, k)
+        if not torch.equal(a[k], b[k]):
+            bad = (a[k] != b[k]).nonzero().cpu().numpy()
+            raise AssertionError((what, k, len(bad), bad[:12].tolist()))
     ra, rb = a["refined"].cpu().numpy(), b["refined"].cpu().numpy()
     assert np.array_equal(np.isnan(ra), np.isnan(rb)), what
     ok = ~np.isnan(ra)

@@ -322,7 +322,7 @@ __device__ __forceinline__ void col_line_rows(int q, int v, const ScanGeom &sg, 
 // Entries of pixels a pass does not visit are never written and never used.
 struct TileMaps {
     float *base = nullptr;
-    int Hp = 0, Wp = 0, R = 1, dbg = 0;
+    int Hp = 0, Wp = 0, R = 1;
     __host__ __device__ int ny() const { return (Hp + R - 1) / R; }
     __host__ __device__ int tx() const { return (Wp + 63) / 64; }
     __host__ __device__ int64_t e_size() const { return (int64_t)ny() * Wp; }
@@ -350,19 +350,6 @@ struct LeanArgs {
     int v_lo, n_lines;        // the pass's lines
     int kb;                   // first traversal step of this lane's line in the segment (its steps: [kb, kb + n))
 };
-// tiles mode: S from the collector registers (lane k: the value of traversal step k, 64 steps per register)
-template <int LEN> __device__ __forceinline__ void store_side_values(const LeanArgs &a, const TileMaps &tm, const int (&coll)[(LEN + 63) / 64], int f, int T) {
-    float *const sp = tm.base + tm.s_off(f);
-#pragma unroll
-    for (int hh = 0; hh < (LEN + 63) / 64; hh++) {
-        const int k = 64 * hh + a.lane;
-        const int row = a.dir > 0 ? a.nb + k : a.nb + a.n_u - 1 - k;
-        const int lstar = (T - (a.vwave + a.s * row)) & 63;
-        const int vl = a.vwave + lstar, col = vl + a.s * row;
-        // the pixel exists and its line is one of this pass's (passes 2 and 3 share the plane: each writes its own lines)
-        if (k < a.n_u && col >= 0 && col < tm.Wp && vl >= a.v_lo && vl < a.v_lo + a.n_lines) sp[(int64_t)(col >> 6) * tm.Hp + row] = __builtin_bit_cast(float, coll[hh]);
-    }
-}
 // FULL: every lane's line crosses all LEN rows of the segment or none (and, in tiles mode, LEN = TILE_SUB R: a whole segment)
 template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], const TileMaps &tm) {
     static_assert(CARRY || FULL, "the maps mode has its own general form");
@@ -405,9 +392,9 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
     }
     if constexpr (CARRY) {
         // The replay keeps what lies on tile edges: E at the first row of every tile row in the direction of travel (a full-wave
-        // store), S from the ONE lane per row whose pixel sits on a tile's side -- the wave's 64 lines are 64 consecutive pixels of the
-        // row, so that lane is wave uniform: its value is picked with v_readlane and parked in lane k of a collector register; two
-        // stores at the end write them.  (A line that has not started yet carries 0 through zeros; after its end nothing is kept.)
+        // store), S where a lane's pixel sits on a tile's side: once every 64 rows, at steps known beforehand -- a compare and a
+        // select per row park the value, one store per lane at the end writes it.  (A line that has not started yet carries 0
+        // through zeros; after its end nothing is kept.)
         constexpr int RF = LEN / TILE_SUB > 0 ? LEN / TILE_SUB : 1; // (FULL: LEN = TILE_SUB R)
         const int f = tile_family(a.q), T = a.q == 4 ? 63 : 0, R = FULL ? RF : tm.R;
         const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void *)(tm.base + tm.e_off(f)), 0, (int)(tm.e_size() * 4), 0x00020000);
@@ -419,9 +406,10 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
             if (a.dir > 0) ek[m] = R * m < a.n_u ? R * m : -1;
             else ek[m] = R * m < a.n_u ? a.n_u - min(R * (m + 1), a.n_u) : -1; // its bottom row: nb + min(R (m + 1), n_u) - 1
         }
-        int coll[(LEN + 63) / 64];
-#pragma unroll
-        for (int hh = 0; hh < (LEN + 63) / 64; hh++) coll[hh] = 0;
+        // S: a lane's pixel sits on a tile's side (column = T mod 64) once every 64 rows, at traversal steps khit and khit + 64
+        const int row0 = a.dir > 0 ? a.nb : a.nb + a.n_u - 1, sd1 = a.s * a.dir;
+        const int khit = ((T - v - a.s * row0) * sd1) & 63;
+        float hit0 = 0.0f, hit1 = 0.0f;
 #pragma unroll
         for (int k = 0; k < LEN; k++) {
             const int row = a.dir > 0 ? a.nb + k : a.nb + a.n_u - 1 - k; // (wave uniform)
@@ -438,13 +426,20 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mp), re, eo, 0, 0);
             }
             if (f > 0) {
-                const int lstar = (T - (a.vwave + a.s * row)) & 63; // the lane whose pixel has column = T (mod 64) in this row
-                const int picked = __builtin_amdgcn_readlane(__builtin_bit_cast(int, mp), lstar);
-                asm("v_writelane_b32 %0, %1, %2" : "+v"(coll[k >> 6]) : "s"(picked), "n"(k & 63));
+                if (k < 64) hit0 = khit == k ? mp : hit0;
+                else hit1 = khit == k - 64 ? mp : hit1;
             }
             mp = gv[k] - mp;
         }
-        if (f > 0) store_side_values<LEN>(a, tm, coll, f, T);
+        if (f > 0) {
+            float *const sp = tm.base + tm.s_off(f);
+#pragma unroll
+            for (int hh = 0; hh < (LEN + 63) / 64; hh++) {
+                const int k = khit + 64 * hh, row = row0 + a.dir * k, col = v + a.s * row;
+                const bool on = FULL ? (a.lane_off != 0xFFFFFFFFu && k < LEN) : (unsigned)(k - a.kb) < (unsigned)a.n;
+                if (on && col >= 0 && col < tm.Wp) sp[(int64_t)(col >> 6) * tm.Hp + row] = hh ? hit1 : hit0;
+            }
+        }
         return;
     }
     if constexpr (FULL) {
@@ -492,9 +487,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         const int segu = __builtin_amdgcn_readfirstlane(seg);
         const int nb = segu * chunk, ne = min(sg.Hp, nb + chunk), n_u = ne - nb; // rows [nb, ne) of the margin box
         const bool ragged = n != 0 && (b != nb || e != ne);
-        bool full = n_u > 0 && (n_u & 3) == 0 && (!CARRY || n_u == chunk) && __builtin_amdgcn_ballot_w64(ragged) == 0;
-        if (tm.dbg == 1 && n_u == chunk) full = true;  // DEBUG
-        if (tm.dbg == 2) full = false;                 // DEBUG
+        const bool full = n_u > 0 && (n_u & 3) == 0 && (!CARRY || n_u == chunk) && __builtin_amdgcn_ballot_w64(ragged) == 0;
         if (full || CARRY) {
             // lane_off: the lane's pixel in row nb (in the general form possibly not a pixel of its line: only used inside its steps)
             const uint32_t lane_off = (full && n == 0) ? 0xFFFFFFFFu : (uint32_t)(((int64_t)(sg.top + nb) * sg.W + sg.left + v + cl.s * nb) * 4);
@@ -1081,8 +1074,6 @@ int dev_census_sweep_tiles(svh_context *ctx, Scratch &scr, const SgmArgs &a, con
     tm.base = scr.get_n<float>((size_t)tm.total());
     if (!keys || !gmap || !tm.base) return SVH_ERR_OUT_OF_MEMORY;
     SVH_TRY(dev_census_sweep(ctx, a, cs, keys, gmap));
-    if (const char *dm = getenv("SVH_K1_MODE")) tm.dbg = atoi(dm); // DEBUG
-    if (const char *fill = getenv("SVH_TILES_FILL")) SVH_HIP_CHECK(ctx, hipMemsetAsync(tm.base, atoi(fill), (size_t)tm.total() * 4, ctx->stream)); // DEBUG
     ScanGeom sg{0, 0, a.H, a.W, a.W};
     dim3 cgrid(std::max(ceil_div(std::max(a.H, a.W), 64), ceil_div(a.H, SCAN_SEGS)), 6), cblock(64, SCAN_SEGS);
     SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm);

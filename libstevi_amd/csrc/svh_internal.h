@@ -50,7 +50,7 @@ struct svh_context {
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 vector-ALU kernel, 3 FP4 matrix-core kernels
     int census_float_overflow = 0;     // svh_context_set_option("census_float_overflow"): rule E2 when a target word rounds to 2^32: 0 saturate (0xFFFFFFFF), 1 zero
     int census_sweep_rl = 1;       // svh_context_set_option("census_sweep_rl"): the FP4 engine may use its RightToLeft specialisation (svh_census_sweep_rl.hip)
-    bool census_tiles = false;         // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
+    bool census_tiles = true;          // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)

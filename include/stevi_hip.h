@@ -116,6 +116,11 @@ const char *svh_last_error(const svh_context *ctx);
  * "census_winner_shortcut" (default 1): in the integer-exact regime of the census + SGM Cost-branch pipeline the winning disparity of a
  * pixel does not depend on the per-pass minima the reference hands along its lines (they shift every disparity of the pixel alike), so
  * calls that ask for index / disparity maps only skip the line scans; 0 runs them regardless (same maps; the parity tests compare).
+ * "census_tiles" (default 1): census + SGM calls that need the aggregated values (reduction keys, refinement taps that are not only
+ * subtracted from one another; or any call with "census_winner_shortcut" 0) on a whole image of up to 1152 rows with 8 directions keep,
+ * of the line recurrences' per-pass minima, only the values on the edges of 9-row x 64-column tiles, and the per-pixel kernel replays
+ * the recurrences inside its tile; 0 writes the six per-pass maps and reads them back (round 2's pair of kernels).  Same results bit
+ * for bit (tests/test_gpu_census_tiles.py); margins, 4 directions, taller images and row bands take the maps form regardless.
  * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
  * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  1: one sweep of the volume, a launch per band of 16
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23

@@ -18,7 +18,7 @@ import os
 import re
 import sys
 
-NAMES = {"census_image_tiled_kernel": "census_transform", "census_grey_kernel": "census_transform", "census_image_kernel": "census_transform", "census_sweep_kernel": "census_sweep", "census_sweep_pm_kernel": "census_sweep_pm", "census_sweep_rl_kernel": "census_sweep_pm", "scan_cols_kernel": "sgm_line_scans", "census_finalize_kernel": "census_finalize"}
+NAMES = {"census_image_tiled_kernel": "census_transform", "census_grey_kernel": "census_transform", "census_image_kernel": "census_transform", "census_sweep_kernel": "census_sweep", "census_sweep_pm_kernel": "census_sweep_pm", "census_sweep_rl_kernel": "census_sweep_pm", "scan_cols_kernel": "sgm_line_scans", "census_finalize_kernel": "census_finalize", "tile_finalize_kernel": "census_finalize"}
 
 
 def collect(directory, counter):

@@ -523,15 +523,14 @@ template <int NW, int WAVES, int CT> int launch_config(svh_context *ctx, const C
     size_t shmem;
     int grid;
     const SweepPlan plan = make_plan(g.H, g.Ws, PXB, NW, WAVES, CT, g.D, n_cu[dev], &shmem, &grid);
-    static bool attr_set_dev[64] = {}; // (per instantiation and device)
-    bool &attr_set = attr_set_dev[dev];
-    if (!attr_set) {
+    static int attr_set_dev[64] = {}; // (per instantiation and device; concurrent per-thread contexts: atomics)
+    if (!__atomic_load_n(&attr_set_dev[dev], __ATOMIC_ACQUIRE)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_pm_kernel<NW, WAVES, CT, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&census_sweep_pm_kernel<NW, WAVES, CT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return fail(ctx, SVH_ERR_HIP, "census_sweep (mfma, fp4 +-1): cannot raise the dynamic LDS limit");
-        attr_set = true;
+        __atomic_store_n(&attr_set_dev[dev], 1, __ATOMIC_RELEASE);
     }
     if (sw.on()) SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_pm_kernel<NW, WAVES, CT, true>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap, plan, sw);
     else SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_pm_kernel<NW, WAVES, CT, false>), grid, 64 * WAVES, shmem, g, Pout, keys, gmap, plan, sw);

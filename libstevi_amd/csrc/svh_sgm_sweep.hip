@@ -252,13 +252,13 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
     else {
         constexpr int NCW = WB, DP = 64 * R; // a wave per own pixel (8 waves for 16 pixels: 13.8 ms at C4, 16 waves: 13.0)
         const size_t shmem = (size_t)(WB + 2 * (WB + KB - 1)) * DP * sizeof(float);
-        static bool attr_set[64] = {};
-        if (!attr_set[ctx->device & 63]) {
+        static int attr_set[64] = {}; // (per instantiation and device; concurrent per-thread contexts: atomics)
+        if (!__atomic_load_n(&attr_set[ctx->device & 63], __ATOMIC_ACQUIRE)) {
             SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, false>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            attr_set[ctx->device & 63] = true;
+            __atomic_store_n(&attr_set[ctx->device & 63], 1, __ATOMIC_RELEASE);
         }
         const size_t state_floats = (size_t)3 * a.W * DP;
         float *st[2] = {scr.get_n<float>(state_floats), scr.get_n<float>(state_floats)};

@@ -54,7 +54,7 @@ typedef enum svh_memspace { SVH_HOST = 0, SVH_DEVICE = 1 } svh_memspace;
  * the plain samples (CENSUS, HAMMING, CC, SSD, SAD -- matching_costs.h:749-783: every comparison is formed after a cast to
  * float, so the bytes are widened once on the device); with a normalised or zero-mean function it is SVH_ERR_UNSUPPORTED (the
  * reference's int16 path, skipped by its own test, testCorrelationFilters.cpp:1249). */
-typedef enum svh_dtype { SVH_F32 = 0, SVH_I32 = 1, SVH_U32 = 2, SVH_U8 = 3, SVH_U64 = 4 } svh_dtype;
+typedef enum svh_dtype { SVH_F32 = 0, SVH_I32 = 1, SVH_U32 = 2, SVH_U8 = 3, SVH_U64 = 4, SVH_I16 = 5, SVH_U16 = 6 } svh_dtype;
 
 /* values of StereoVision::Correlation::matchingFunctions, correlation/matching_costs.h:38-53 */
 typedef enum svh_match_func {
@@ -219,7 +219,10 @@ int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_dir
 
 /* ---- A9  sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout)      correlation/sgm.h:360-404
  * cv (H,W,D) f32 -> out (H,W,D) f32.  n_directions 4 or 8 (16 is a data race in the reference and unsupported).
- * margins = {left, top, right, bottom}.  Reproduces the reference as written. */
+ * margins = {left, top, right, bottom}.  Reproduces the reference as written.
+ * T_CV: cv may also be SVH_U8, SVH_I16, SVH_U16, SVH_I32 or SVH_U32 -- the reference casts every cost it reads to float
+ * (sgm.h:234, :273, :299; the initial copy :369-377), so the volume is converted once on the device and the float kernels run
+ * (same bits; also svh_sgm_cost_volume_textbook).  double volumes are not taken (the reference then subtracts in double). */
 int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
                         const int32_t margins[4], float Pout, svh_array *out);
 /* The Cost branch on a volume the caller knows two things about: every entry is an integer with |c| <= max_abs, and `minima` holds its

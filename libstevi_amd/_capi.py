@@ -16,7 +16,7 @@ SVH_MAX_DIMS = 4
 OK, EMPTY_RESULT, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY = range(7)
 # svh_memspace / svh_dtype
 HOST, DEVICE = 0, 1
-F32, I32, U32, U8, U64 = 0, 1, 2, 3, 4
+F32, I32, U32, U8, U64, I16, U16 = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/stevi_hip.h declares
 EXPORTS = [

@@ -100,7 +100,7 @@ def matchFuncStrategy(matchFunc):
 
 # ------------------------------------------------------------------------------------------------ plumbing
 _NP_DTYPES = {np.dtype(np.float32): _capi.F32, np.dtype(np.int32): _capi.I32, np.dtype(np.uint32): _capi.U32,
-              np.dtype(np.uint8): _capi.U8, np.dtype(np.uint64): _capi.U64}
+              np.dtype(np.uint8): _capi.U8, np.dtype(np.uint64): _capi.U64, np.dtype(np.int16): _capi.I16, np.dtype(np.uint16): _capi.U16}
 
 
 def _is_torch(x):
@@ -109,8 +109,8 @@ def _is_torch(x):
 
 def _torch_code(t):
     import torch
-    table = {torch.float32: _capi.F32, torch.int32: _capi.I32, torch.uint8: _capi.U8}
-    for name, code in (("uint32", _capi.U32), ("uint64", _capi.U64)):
+    table = {torch.float32: _capi.F32, torch.int32: _capi.I32, torch.uint8: _capi.U8, torch.int16: _capi.I16}
+    for name, code in (("uint32", _capi.U32), ("uint64", _capi.U64), ("uint16", _capi.U16)):
         if hasattr(torch, name):
             table[getattr(torch, name)] = code
     if t.dtype == torch.int64:  # 8-byte keys travel as int64 tensors (torch.distributed has no uint64 reductions)
@@ -202,6 +202,18 @@ def _prep(x, dtype=None):
     if dtype is not None and x.dtype != dtype:
         x = x.astype(dtype)
     return x
+
+
+_VOLUME_DTYPES = (np.float32, np.uint8, np.int16, np.uint16, np.int32, np.uint32)
+
+
+def _prep_volume(x):
+    """sgmCostVolume's T_CV: float32 or an integer type the reference casts to float as it reads (converted on the device);
+    any other numpy dtype is converted to float32 on the host."""
+    if _is_torch(x):
+        return x
+    x = np.asarray(x)
+    return x if x.dtype in [np.dtype(t) for t in _VOLUME_DTYPES] else _prep(x, np.float32)
 
 
 def _prep_image(x):
@@ -361,7 +373,7 @@ def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None
     semantics="textbook" selects the explicit second mode (every direction fully traversed, neighbour penalties in the Cost
     strategy): NOT the reference's result, see svh_sgm_cost_volume_textbook in include/stevi_hip.h."""
     lib = _capi.load()
-    cv = _prep(cv_base, np.float32)
+    cv = _prep_volume(cv_base)
     ctx = context_for(cv)
     m = (margins or Margins()).as_tuple()
     out = _like(cv, tuple(cv.shape), "f32")

@@ -88,6 +88,7 @@ size_t dtype_size(int dtype) {
     switch (dtype) {
     case SVH_F32: case SVH_I32: case SVH_U32: return 4;
     case SVH_U8: return 1;
+    case SVH_I16: case SVH_U16: return 2;
     case SVH_U64: return 8;
     default: return 0;
     }
@@ -122,6 +123,12 @@ int validate(svh_context *ctx, const svh_array *a, const char *what, int dtype, 
     }
     if (num_elements(*a) > 0 && !a->data) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "%s: null data pointer", what);
     return SVH_OK;
+}
+
+int validate_volume(svh_context *ctx, const svh_array *cv, const char *what) {
+    if (cv && (cv->dtype == SVH_U8 || cv->dtype == SVH_I16 || cv->dtype == SVH_U16 || cv->dtype == SVH_I32 || cv->dtype == SVH_U32))
+        return validate(ctx, cv, what, cv->dtype, 3, 3);
+    return validate(ctx, cv, what, SVH_F32, 3, 3);
 }
 
 bool any_host(std::initializer_list<const svh_array *> arrays) {
@@ -268,6 +275,33 @@ int stage_image(svh_context *ctx, Scratch &scr, const svh_array &img, void **dpt
         bytes = aligned;
     }
     SVH_LAUNCH(ctx, "widen_u8", widen_u8_kernel, grid_for((n + 3) / 4, 256, 4096), 256, 0, (const uint8_t *)bytes, wide, n);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+// integer cost volumes (sgmCostVolume's T_CV): one conversion to float on the device, the reference's own static_cast<float>
+template <class T> __global__ void to_float_kernel(const T *__restrict__ in, float *__restrict__ out, int64_t n) {
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) out[q] = static_cast<float>(in[q]);
+}
+
+int stage_volume_as_float(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr) {
+    if (a.dtype == SVH_F32) return stage_in(ctx, scr, a, dptr);
+    if (a.dtype == SVH_U8) return stage_image(ctx, scr, a, dptr);
+    void *raw;
+    SVH_TRY(stage_in(ctx, scr, a, &raw));
+    const int64_t n = num_elements(a);
+    float *wide = scr.get_n<float>((size_t)n);
+    if (!wide) return SVH_ERR_OUT_OF_MEMORY;
+    *dptr = wide;
+    if (n == 0) return SVH_OK;
+    const int grid = grid_for(n, 256, 8192);
+    switch (a.dtype) {
+    case SVH_I16: SVH_LAUNCH(ctx, "to_float", to_float_kernel<int16_t>, grid, 256, 0, (const int16_t *)raw, wide, n); break;
+    case SVH_U16: SVH_LAUNCH(ctx, "to_float", to_float_kernel<uint16_t>, grid, 256, 0, (const uint16_t *)raw, wide, n); break;
+    case SVH_I32: SVH_LAUNCH(ctx, "to_float", to_float_kernel<int32_t>, grid, 256, 0, (const int32_t *)raw, wide, n); break;
+    case SVH_U32: SVH_LAUNCH(ctx, "to_float", to_float_kernel<uint32_t>, grid, 256, 0, (const uint32_t *)raw, wide, n); break;
+    default: return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cost volume: element type %d", a.dtype);
+    }
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

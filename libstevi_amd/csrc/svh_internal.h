@@ -153,6 +153,9 @@ int stage_in(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr);
 // skips (testCorrelationFilters.cpp:1249): SVH_ERR_UNSUPPORTED.  match_func < 0: no function involved (unfold, census).
 int validate_image(svh_context *ctx, const svh_array *img, const char *what, int match_func);
 int stage_image(svh_context *ctx, Scratch &scr, const svh_array &img, void **dptr); // dense float32 device view
+// a cost volume of any element type sgmCostVolume's T_CV may take here (f32, u8, i16, u16, i32, u32) as a dense float32 device view
+int validate_volume(svh_context *ctx, const svh_array *cv, const char *what);
+int stage_volume_as_float(svh_context *ctx, Scratch &scr, const svh_array &cv, void **dptr);
 
 // Device-resident dense buffer to compute an output into; finish() moves it to the user's array when needed.
 struct OutStage {

@@ -773,8 +773,9 @@ using namespace svh;
 static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs, float P1, float P2,
                                 const int32_t margins[4], float Pout, svh_array *out) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
-    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate_volume(ctx, cv, "cv")); // (T_CV: float or an integer type the reference casts to float as it reads, sgm.h:234, :273, :299)
     SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
+    if (minima && cv->dtype != SVH_F32) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "the minima statement goes with a float32 volume");
     if (n_directions == 16)
         return fail(ctx, SVH_ERR_UNSUPPORTED,
                     "16 directions: the reference's overlapping lines race on sgm_cv (sgm.h:299, :336), results are not defined");
@@ -790,7 +791,7 @@ static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy
     Scratch scr(ctx);
     void *dcv;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_volume_as_float(ctx, scr, *cv, &dcv));
     SVH_TRY(stage_out(ctx, scr, *out, &os));
     if (strategy == SVH_COST) {
         CostSource cs;
@@ -831,7 +832,7 @@ extern "C" int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, in
 extern "C" int svh_sgm_cost_volume_textbook(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, float P1, float P2,
                                             const int32_t margins[4], float Pout, svh_array *out) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
-    SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
+    SVH_TRY(validate_volume(ctx, cv, "cv"));
     SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
     if (n_directions != 4 && n_directions != 8) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "n_directions must be 4 or 8");
     if (strategy != SVH_COST && strategy != SVH_SCORE) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "bad strategy");
@@ -845,7 +846,7 @@ extern "C" int svh_sgm_cost_volume_textbook(svh_context *ctx, int n_directions, 
     Scratch scr(ctx);
     void *dcv;
     OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *cv, &dcv));
+    SVH_TRY(stage_volume_as_float(ctx, scr, *cv, &dcv));
     SVH_TRY(stage_out(ctx, scr, *out, &os));
     if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
     SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr, true));

@@ -20,7 +20,7 @@ template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV
 Multidim::Array<float, 3> sgmCostVolume(Multidim::Array<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
     static_assert(nDirections == 4 or nDirections == 8 or nDirections == 16, "SGM can only operate with 4, 8 or 16 directions");
     static_assert(nDirections != 16, "libstevi_hip: the reference's 16-direction lines overlap inside one OpenMP loop; its result is not defined");
-    static_assert(std::is_same_v<T_CV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(HipBridge::sgmVolumeTypeOnGpuPath<T_CV>, "libstevi_hip: T_CV is float or an integer type of up to 32 bits (the reference casts those to float as it reads them; double is not taken)");
     Multidim::Array<float, 3> sgm_cv(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
@@ -35,7 +35,7 @@ template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV
 DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
     static_assert(nDirections == 4 or nDirections == 8 or nDirections == 16, "SGM can only operate with 4, 8 or 16 directions");
     static_assert(nDirections != 16, "libstevi_hip: the reference's 16-direction lines overlap inside one OpenMP loop; its result is not defined");
-    static_assert(std::is_same_v<T_CV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(HipBridge::sgmVolumeTypeOnGpuPath<T_CV>, "libstevi_hip: T_CV is float or an integer type of up to 32 bits (the reference casts those to float as it reads them; double is not taken)");
     DeviceArray<float, 3> sgm_cv(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
@@ -66,7 +66,7 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
 template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV>
 Multidim::Array<float, 3> sgmCostVolumeTextbook(Multidim::Array<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
     static_assert(nDirections == 4 or nDirections == 8, "the textbook mode operates with 4 or 8 directions");
-    static_assert(std::is_same_v<T_CV, float>, "libstevi_hip: cost volumes are float");
+    static_assert(HipBridge::sgmVolumeTypeOnGpuPath<T_CV>, "libstevi_hip: T_CV is float or an integer type of up to 32 bits (the reference casts those to float as it reads them; double is not taken)");
     Multidim::Array<float, 3> sgm_cv(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};

@@ -69,6 +69,13 @@ template <> struct DType<uint8_t> { static constexpr int value = SVH_U8; }; // i
 template <> struct DType<float> { static constexpr int value = SVH_F32; };
 template <> struct DType<int32_t> { static constexpr int value = SVH_I32; };
 template <> struct DType<uint32_t> { static constexpr int value = SVH_U32; };
+template <> struct DType<int16_t> { static constexpr int value = SVH_I16; };  // (cost volumes handed to sgmCostVolume: T_CV)
+template <> struct DType<uint16_t> { static constexpr int value = SVH_U16; };
+// sgmCostVolume<.., T_CV>: the reference casts every cost it reads to float (sgm.h:234, :273, :299), so the integer types go through;
+// double would make it subtract in double (sgm.h:299) and is not taken
+template <class T> inline constexpr bool sgmVolumeTypeOnGpuPath =
+    std::is_same_v<T, float> || std::is_same_v<T, uint8_t> || std::is_same_v<T, int16_t> || std::is_same_v<T, uint16_t> || std::is_same_v<T, int32_t> ||
+    std::is_same_v<T, uint32_t>;
 
 // ---- raw access to a Multidim::Array -------------------------------------------------------------------------------------------
 // The reference never asks an array for a data() pointer.  Where its own code needs the address of the elements it takes

@@ -2,6 +2,7 @@
 // (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294; examples/stereo_refine_test/main.cpp:367-384).
 // usage: dropin_chain <H> <W> <D> <left.f32> <right.f32> <out_prefix>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 #include <thread>
@@ -56,6 +57,17 @@ int main(int argc, char **argv) {
             SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(SC::extractSelectedIndex<strat>(SGM_CV), 0);
         dump(out + "_census_sgm.f32", FE(SGM_CV), SGM_CV.flatLenght());
         dump(out + "_census_disp.i32", FE(disp), disp.flatLenght());
+        { // T_CV = int16_t (sgm.h:360 is a template on the volume's element type; the reference casts what it reads to float): same bits
+            Multidim::Array<int16_t, 3> CV16(CV.shape());
+            for (int i = 0; i < CV.shape()[0]; i++)
+                for (int j = 0; j < CV.shape()[1]; j++)
+                    for (int d = 0; d < CV.shape()[2]; d++) CV16.atUnchecked(i, j, d) = static_cast<int16_t>(CV.valueUnchecked(i, j, d));
+            Multidim::Array<float, 3> SGM16 = SC::sgmCostVolume<8, strat>(CV16, P1, P2, StereoVision::Margins(), Pout);
+            if (SGM16.flatLenght() != SGM_CV.flatLenght() || std::memcmp(FE(SGM16), FE(SGM_CV), sizeof(float) * SGM_CV.flatLenght()) != 0) {
+                std::fprintf(stderr, "sgmCostVolume<int16_t> differs from sgmCostVolume<float>\n");
+                return 3;
+            }
+        }
         // the same chain with the volumes left in GPU memory (HipBridge::DeviceArray): the reference's names, overloads picked by
         // the argument type; images up once, one disparity map down
         auto dCV = SC::unfoldBasedCostVolumeOnDevice<matchFunc>(target, source, h_r, v_r, D);

@@ -644,3 +644,23 @@ def test_cost_branch_on_a_census_volume_skips_the_probe_with_the_same_bits(rng):
         assert_bits(got3, so.sgm(host(cv), n_dir, so.COST, 0.001, 0.01, margins.as_tuple() if margins else (0, 0, 0, 0), 100.0))
     # Score strategy / other functions: no statement
     assert getattr(sv.unfoldBasedCostVolume(MF.SAD, l, r, 2, 2, 16), "_svh_minima", None) is None
+
+
+# ------------------------------------------------------------------------------------------------ sgmCostVolume<.., T_CV>
+@pytest.mark.parametrize("dtype", [np.uint8, np.int16, np.uint16, np.int32, np.uint32])
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+def test_sgm_integer_cost_volume_types(rng, dtype, strategy):
+    """sgmCostVolume is a template on the volume's element type (sgm.h:360); the reference casts every cost it reads to float
+    (:234, :273, :299), so an integer volume gives what its float copy gives -- bit for bit, host and device arrays."""
+    hi = {np.uint8: 255, np.int16: 3000, np.uint16: 60000, np.int32: 1 << 26, np.uint32: 1 << 27}[dtype]
+    lo = -hi if np.issubdtype(dtype, np.signedinteger) else 0
+    cv = rng.integers(lo, hi, (23, 41, 19)).astype(dtype)
+    exp = so.sgm(cv.astype(np.float32), 8, strategy, 0.5, 2.0, (0, 0, 0, 0), 7.0)
+    got = sv.sgmCostVolume(8, strategy, cv, 0.5, 2.0, None, 7.0)
+    assert_bits(got, exp)
+    if dtype in (np.uint8, np.int16, np.int32):  # (torch has device tensors of these)
+        got_d = sv.sgmCostVolume(8, strategy, dev(cv), 0.5, 2.0, None, 7.0)
+        assert_bits(got_d, exp)
+    got_t = sv.sgmCostVolume(4, strategy, cv, 0.5, 2.0, sv.Margins(1, 2, 0, 1), 7.0, semantics="textbook")
+    ref_t = sv.sgmCostVolume(4, strategy, cv.astype(np.float32), 0.5, 2.0, sv.Margins(1, 2, 0, 1), 7.0, semantics="textbook")
+    assert_bits(got_t, host(ref_t))

@@ -218,7 +218,7 @@ int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_dir
                                   int *minima_written);
 
 /* ---- A9  sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout)      correlation/sgm.h:360-404
- * cv (H,W,D) f32 -> out (H,W,D) f32.  n_directions 4 or 8 (16 is a data race in the reference and unsupported).
+ * cv (H,W,D) f32 -> out (H,W,D) f32, D <= 2048.  n_directions 4 or 8 (16 is a data race in the reference and unsupported).
  * margins = {left, top, right, bottom}.  Reproduces the reference as written.
  * T_CV: cv may also be SVH_U8, SVH_I16, SVH_U16, SVH_I32 or SVH_U32 -- the reference casts every cost it reads to float
  * (sgm.h:234, :273, :299; the initial copy :369-377), so the volume is converted once on the device and the float kernels run

@@ -576,7 +576,8 @@ static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &s
     case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate);
     case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate);
     case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate);
-    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
+    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate); // (up to 2048 disparities: 32 per lane)
+    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 2048 disparities (got %d)", a.D);
     }
 }
 
@@ -732,7 +733,8 @@ int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv,
     case 2: return score_line_pass<2>(ctx, a, cv, sgm, pass, delta);
     case 4: return score_line_pass<4>(ctx, a, cv, sgm, pass, delta);
     case 8: return score_line_pass<8>(ctx, a, cv, sgm, pass, delta);
-    default: return score_line_pass<16>(ctx, a, cv, sgm, pass, delta);
+    case 16: return score_line_pass<16>(ctx, a, cv, sgm, pass, delta);
+    default: return score_line_pass<32>(ctx, a, cv, sgm, pass, delta);
     }
 }
 
@@ -742,7 +744,8 @@ int dev_sgm_score_l2r_rows(svh_context *ctx, const SgmArgs &a, const float *cv, 
     case 2: return score_line_pass<2>(ctx, a, cv, sgm, 1, true, r0, rows);
     case 4: return score_line_pass<4>(ctx, a, cv, sgm, 1, true, r0, rows);
     case 8: return score_line_pass<8>(ctx, a, cv, sgm, 1, true, r0, rows);
-    default: return score_line_pass<16>(ctx, a, cv, sgm, 1, true, r0, rows);
+    case 16: return score_line_pass<16>(ctx, a, cv, sgm, 1, true, r0, rows);
+    default: return score_line_pass<32>(ctx, a, cv, sgm, 1, true, r0, rows);
     }
 }
 
@@ -762,7 +765,8 @@ int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const
     case 4: return run_score_branch<4>(ctx, scr, a, cv, out_sgm, textbook);
     case 8: return run_score_branch<8>(ctx, scr, a, cv, out_sgm, textbook);
     case 16: return run_score_branch<16>(ctx, scr, a, cv, out_sgm, textbook);
-    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 1024 disparities (got %d)", a.D);
+    case 32: return run_score_branch<32>(ctx, scr, a, cv, out_sgm, textbook); // (up to 2048 disparities: 32 per lane)
+    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 2048 disparities (got %d)", a.D);
     }
 }
 

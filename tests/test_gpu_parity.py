@@ -208,6 +208,27 @@ def test_sgm_margins_larger_than_image(rng):
         assert_bits(sv.sgmCostVolume(8, strategy, cv, 1, 2, sv.Margins(4, 4), 5.0), so.sgm(cv, 8, strategy, 1, 2, (4, 4, 4, 4), 5.0))
 
 
+@pytest.mark.parametrize("D", [1025, 1500, 2048])
+def test_sgm_more_than_1024_disparities(rng, D):
+    """32 disparities per lane: up to 2048 per call (the reference has no limit, sgm.h:360-404; beyond 2048: SVH_ERR_UNSUPPORTED)."""
+    cv = rng.uniform(-2, 2, (5, 9, D)).astype(np.float32)
+    cv[2, 3, 7] = np.inf
+    cv[1, 1, D - 1] = np.nan
+    for strategy in (so.COST, so.SCORE):
+        for n_dir, margins in ((8, (0, 0, 0, 0)), (4, (1, 0, 2, 1))):
+            exp = so.sgm(cv, n_dir, strategy, 0.3, 0.9, margins, 5.0)
+            got = host(sv.sgmCostVolume(n_dir, strategy, dev(cv), 0.3, 0.9, sv.Margins(*margins), 5.0))
+            assert np.array_equal(np.isnan(got), np.isnan(exp))
+            ok = ~np.isnan(exp)
+            assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+    ci = rng.integers(0, 60, (4, 7, D)).astype(np.float32)  # integer costs: the probe declines D > 1024, the general kernels run
+    assert_bits(sv.sgmCostVolume(8, so.COST, ci, 0.3, 0.9, None, 100.0), so.sgm(ci, 8, so.COST, 0.3, 0.9, (0, 0, 0, 0), 100.0))
+    from libstevi_amd._capi import SvhError, ERR_UNSUPPORTED
+    with pytest.raises(SvhError) as e:
+        sv.sgmCostVolume(8, so.SCORE, np.zeros((2, 2, 2049), np.float32), 1, 2)
+    assert e.value.status == ERR_UNSUPPORTED
+
+
 def test_sgm_rejects_16_directions(rng):
     from libstevi_amd._capi import SvhError, ERR_UNSUPPORTED
     with pytest.raises(SvhError) as e:

@@ -819,14 +819,16 @@ __global__ void __launch_bounds__(256) tile_finalize_kernel(CensusGeom g, ScanGe
     auto ld = [&](const __amdgpu_buffer_rsrc_t &r, int64_t index, bool on) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, on ? (uint32_t)(index * 4) : 0xFFFFFFFFu, 0, 0));
     };
-    // everything the tile needs, requested before anything is used
+    // everything the tile needs, requested before anything is used.  32-bit byte offsets, one add per row; a lane past the last column
+    // starts at 2^31 (out of range for every row of the tile: the maps are below 2^30 bytes), a row past the last row is out of range
+    // by itself: both read zeros
     float gv[TILE_RMAX];
     uint2 kv[TILE_RMAX];
+    const uint32_t g0 = col_in ? (uint32_t)((top * W + c) * 4) : 0x80000000u, k0 = col_in ? (uint32_t)((top * g.Ws + c) * 8) : 0x80000000u;
 #pragma unroll
     for (int k = 0; k < TILE_RMAX; k++) {
-        const bool on = col_in && k < n_r;
-        gv[k] = ld(rg, (int64_t)(top + k) * W + c, on);
-        const auto kk = __builtin_amdgcn_raw_buffer_load_b64(rk, on ? (uint32_t)(((int64_t)(top + k) * g.Ws + c) * 8) : 0xFFFFFFFFu, 0, 0);
+        gv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, g0 + (uint32_t)(k * W * 4), 0, 0));
+        const auto kk = __builtin_amdgcn_raw_buffer_load_b64(rk, k0 + (uint32_t)(k * g.Ws * 8), 0, 0);
         kv[k] = make_uint2(kk[0], kk[1]);
     }
     const int bot = top + n_r - 1;
@@ -873,12 +875,13 @@ __global__ void __launch_bounds__(256) tile_finalize_kernel(CensusGeom g, ScanGe
             s3 = dpp_wave_shl1(s3, 0.0f);
         }
     }
+    const int p0 = top * g.Ws + c; // (pixel index: the image is below 2^28 pixels)
 #pragma unroll
     for (int k = 0; k < TILE_RMAX; k++) {
         if (k < n_r && col_in) {
             const int i = top + k, sdiag = i + c;
-            const int n_vis = 2 + (int)(i >= c) + (int)(c >= i) + (int)(sdiag < Wp) + (int)(sdiag < Hp);
-            finalize_px<NW>(g, out, i, c, (int64_t)i * g.Ws + c, (int)acc[k], n_vis, Pout, kv[k]);
+            const int n_vis = 3 + (int)(i == c) + (int)(sdiag < Wp) + (int)(sdiag < Hp); // passes 0, 1, one of 2 / 3 (both on the corner diagonal), 4, 5
+            finalize_px<NW>(g, out, i, c, p0 + k * g.Ws, (int)acc[k], n_vis, Pout, kv[k]);
         }
     }
 }
@@ -1078,7 +1081,7 @@ bool census_tiles_apply(const svh_context *ctx, const SgmArgs &a) {
     const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0 && a.row_origin == 0 && a.full_H == 0 && a.store_rows == 0;
     const int chunk = scan_chunk(a.H);
     return ctx->census_tiles && whole && a.n_dir >= 8 && a.n_dir != 16 && a.H > 0 && a.W > 0 && chunk <= SCAN_MAXSEG && a.H <= 65535 &&
-           (int64_t)a.H * a.W <= ((int64_t)1 << 28);
+           (int64_t)a.H * a.W <= ((int64_t)1 << 27);
 }
 
 int dev_census_sweep_tiles(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win) {

@@ -89,6 +89,19 @@ def test_tiles_equal_general_kernels_and_oracle(shape):
     assert np.allclose(got[~np.isnan(exp)], exp[~np.isnan(exp)], atol=1e-6)
 
 
+@pytest.mark.parametrize("r,ddir", [(2, "RightToLeft"), (4, "LeftToRight"), (5, "LeftToRight")])
+def test_tiles_other_windows_and_direction(r, ddir):
+    """5 x 5 windows (no census word is written: every cost is 0), 11 x 11 (three words), and the other disparity direction."""
+    H, W, D = 75, 140, 64
+    rng = np.random.default_rng(r)
+    src = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    kw = dict(Pout=100.0, dDir=getattr(sv.dispDirection, ddir))
+    same(run(d_tgt, d_src, r, D, 1, **kw), run(d_tgt, d_src, r, D, 0, **kw), (r, ddir))
+    same(run(d_tgt, d_src, r, D, 1, **kw), run(d_tgt, d_src, r, D, 1, fast=0, **kw), (r, ddir, "general"))
+
+
 def test_tiles_full_hd_rows():
     """1080 rows: sixteen segments of 68 rows (the last one 60), thirty column tiles; against the maps form."""
     src, tgt, _ = parallax_pair(1080, 1920, 320, 320, 380, 8, 64, seed=3)

@@ -399,12 +399,28 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
         const int f = tile_family(a.q), T = a.q == 4 ? 63 : 0, R = FULL ? RF : tm.R;
         const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc((void *)(tm.base + tm.e_off(f)), 0, (int)(tm.e_size() * 4), 0x00020000);
         const int v = a.vwave + a.lane;
-        // tile rows m = 0 .. TILE_SUB - 1 of the segment: the traversal step at which the lines enter them (-1: no such tile row)
-        int ek[TILE_SUB];
-#pragma unroll
-        for (int m = 0; m < TILE_SUB; m++) {
-            if (a.dir > 0) ek[m] = R * m < a.n_u ? R * m : -1;
-            else ek[m] = R * m < a.n_u ? a.n_u - min(R * (m + 1), a.n_u) : -1; // its bottom row: nb + min(R (m + 1), n_u) - 1
+        // (general form) the traversal steps at which a tile row begins, as a bit mask in scalar registers -- the test per step is one
+        // s_bitcmp -- and the tile row of the first of them; every further one is the next tile row in the direction of travel.
+        // Downwards the segment starts on a tile row (nb is a multiple of R): steps 0, R, 2 R, ...; upwards the tile rows' bottom rows
+        // are the steps n_u - R m > 0 and step 0 (the segment's last row, whatever tile row it lies in)
+        unsigned long long em_lo = 0;
+        unsigned em_hi = 0;
+        int ty_next = TILE_SUB * a.seg;
+        if constexpr (!FULL) {
+            int k0 = 0;
+            if (a.dir < 0) {
+                int left = a.n_u - 1;
+                for (; left >= R; left -= R) ty_next++;
+                k0 = left + 1 == R ? 0 : left + 1; // n_u mod R
+                em_lo = 1;
+            }
+            for (int kk = k0; kk < a.n_u; kk += R) {
+                if (kk < 64) em_lo |= 1ull << kk;
+                else em_hi |= 1u << (kk - 64);
+            }
+            em_lo = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(em_lo >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)em_lo);
+            em_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)em_hi);
+            ty_next = __builtin_amdgcn_readfirstlane(ty_next);
         }
         // S: a lane's pixel sits on a tile's side (column = T mod 64) once every 64 rows, at traversal steps khit and khit + 64
         const int row0 = a.dir > 0 ? a.nb : a.nb + a.n_u - 1, sd1 = a.s * a.dir;
@@ -413,18 +429,22 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
 #pragma unroll
         for (int k = 0; k < LEN; k++) {
             const int row = a.dir > 0 ? a.nb + k : a.nb + a.n_u - 1 - k; // (wave uniform)
-            int m = -1;
+            bool edge; // (wave uniform) the first row of a tile row in the direction of travel
+            int ty;
             if constexpr (FULL) {
-                if (k % RF == 0) m = a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF;
+                edge = k % RF == 0;
+                ty = TILE_SUB * a.seg + (a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF);
             } else {
-#pragma unroll
-                for (int mm = 0; mm < TILE_SUB; mm++) m = k == ek[mm] ? mm : m;
+                edge = k < 64 ? (em_lo >> k) & 1 : (em_hi >> (k - 64)) & 1;
+                ty = ty_next;
             }
-            if (m >= 0) { // (wave uniform)
+            if (edge) {
                 const bool on = FULL ? a.lane_off != 0xFFFFFFFFu : (unsigned)(k - a.kb) < (unsigned)a.n;
-                const uint32_t eo = on ? (uint32_t)(((TILE_SUB * a.seg + m) * tm.Wp + v + a.s * row) * 4) : 0xFFFFFFFFu;
+                const uint32_t eo = on ? (uint32_t)((ty * tm.Wp + v + a.s * row) * 4) : 0xFFFFFFFFu;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mp), re, eo, 0, 0);
+                if constexpr (!FULL) ty_next += a.dir;
             }
+
             if (f > 0) {
                 if (k < 64) hit0 = khit == k ? mp : hit0;
                 else hit1 = khit == k - 64 ? mp : hit1;

@@ -547,7 +547,13 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
             }
         }
     }
-    if (!CARRY && chunk <= SCAN_MAXSEG) {
+    if constexpr (CARRY) { // (tiles mode is only launched where scan_lean applies: what arrives here is a segment past the last row)
+        seg_a[seg][lane] = 0.0f; // the identity for the chains that walk over it
+        seg_n[seg][lane] = 0;
+        __syncthreads();
+        return;
+    }
+    if (chunk <= SCAN_MAXSEG) {
         // the whole segment lives in registers: one round of loads (all in flight together), summary, chain, replay
         float gv[SCAN_MAXSEG];
 #pragma unroll
@@ -590,22 +596,6 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         for (int t = 0; t < seg; t++) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
     } else {
         for (int t = SCAN_SEGS - 1; t > seg; t--) mp = seg_a[t][lane] + ((seg_n[t][lane] & 1) ? -mp : mp);
-    }
-    if constexpr (CARRY) {
-        // tiles mode, the waves the lean form does not take (ragged ends of the diagonal passes, the last segment): the values on the
-        // tile edges (TileMaps), pixel by pixel
-        const int f = tile_family(q), T = q == 4 ? 63 : 0, R = tm.R;
-        float *const ep = tm.base + tm.e_off(f), *const sp = f > 0 ? tm.base + tm.s_off(f) : nullptr;
-        int64_t p = p0;
-        int row = first, col = v + cl.s * first;
-        for (int k = 0; k < n; k++, p += step, row += cl.dir, col += cl.s * cl.dir) {
-            const int rm = row % R;
-            const bool edge = cl.dir > 0 ? rm == 0 : (rm == R - 1 || row == sg.Hp - 1);
-            if (edge) ep[(int64_t)(row / R) * tm.Wp + col] = mp;
-            if (sp && (col & 63) == T) sp[(int64_t)(col >> 6) * tm.Hp + row] = mp;
-            mp = gmap[p] - mp;
-        }
-        return;
     }
     {
         int64_t p = p0;

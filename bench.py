@@ -53,9 +53,9 @@ def algorithmic_bytes(kernel, wl):
         "census_sweep": 28.0 * vox,
         "census_sweep_pm": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
-        "sgm_line_scans": 4.0 * px + 6 * 4.0 * px,   # g read + six min_p maps written
+        "sgm_line_scans": (4.0 + 1.6) * px,          # g read + the min_p values on tile edges written (with six maps instead: 4 + 24)
         "sgm_line_carries": 4.0 * px,                # g read (the carries are per line and band: negligible)
-        "census_finalize": (8.0 + 24.0 + 4.0) * px,  # keys + six min_p maps + disparity
+        "census_finalize": (8.0 + 4.0 + 1.6 + 4.0) * px,  # keys + g + tile-edge values + disparity (with six maps instead: 8 + 24 + 4)
         "census_scan_finalize": (4.0 + 8.0 + 4.0) * px,  # g + keys + disparity
     }
     return table.get(kernel)
@@ -475,7 +475,7 @@ def main():
                                    "run is `disparity_split`" if (world > 1 and headline_split == "rows") else
                                    (("svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
                                      "svh_census_shard_keys -> int32 MIN all-reduce -> svh_census_shard_finish, inputs and outputs resident in HBM") +
-                                    ("; SGM line recurrences RUN (sweep -> g -> six line scans -> min_p maps -> finalize)" if args.with_line_scans else
+                                    ("; SGM line recurrences RUN (sweep -> g -> six line scans keeping the min_p values on tile edges -> per-pixel kernel replaying them per tile)" if args.with_line_scans else
                                      "; recurrence-free winner identity (the library's default for disparity-only calls): no line scans")),
                        "sgm_recurrences_timed": bool(args.with_line_scans) and not (world > 1 and headline_split == "rows"),
                        "materialize_volumes": bool(args.materialize),

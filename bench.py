@@ -131,7 +131,7 @@ def api_chain(sv, wl, d_tgt, d_src, reps=5):
     strat = sv.matchFuncStrategy(MF.CENSUS)
 
     def chain():
-        cv = sv.unfoldBasedCostVolume(MF.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"])
+        cv = sv.unfoldBasedCostVolume(MF.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], keep_minima=True)  # as the C++ shims do
         sgm = sv.sgmCostVolume(wl["sgm"], strat, cv, wl["P1"], wl["P2"], None, wl["Pout"])
         return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, sgm), 0)
 

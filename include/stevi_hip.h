@@ -126,13 +126,7 @@ const char *svh_last_error(const svh_context *ctx);
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23
  * instead of 44 bytes per voxel over all passes).  0: one read-modify-write sweep per pass.
  * (3 = 1 with the 16-column strips forced that images narrower than about 3000 columns replace by 8-column ones: for the tests.)
- * Same bits in all of them; the parity tests cross-check them.
- * "sgm_overlap" (default 0 = off; 2..16 = number of row bands): svh_stereo_match with a float matching function followed by the Score
- * branch in the banded form above launches the cost-volume kernel per band of rows and, behind each band's event, the Left2Right
- * contribution of those rows on a second stream of the context (created on first use, non-blocking; the context's stream waits for it
- * before the sweep): the line of row i needs row i's costs and nothing else.  The same kernels on the same rows, hence the same bits
- * (tests/test_gpu_sgm_overlap.py).  Off by default because it measured slower at C4 for every band count (the line kernel's duration
- * is the latency of its per-row chain, which a band does not shorten: DESIGN.md section 4.2a). */
+ * Same bits in all of them; the parity tests cross-check them. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);

@@ -329,9 +329,17 @@ def featureVolume2CostVolume(matchFunc, feature_vol_l, feature_vol_r, searchRang
     return out if st == _capi.OK else _empty_like(l, 3, "f32")
 
 
-def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft):
+def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, keep_minima=False):
     """unfoldBasedCostVolume<matchFunc,...> -- correlation/cross_correlations.h:740-765.
-    disp_width: an int (disp_t overload) or a searchOffset1 / (lower, upper) pair."""
+    disp_width: an int (disp_t overload) or a searchOffset1 / (lower, upper) pair.
+
+    keep_minima (device tensors, CENSUS / HAMMING only; off by default): also keep the volume's per-pixel regional minima with the returned
+    tensor, so that a later sgmCostVolume<Cost> on it skips its probing read of the volume (2.1 GB at 1080p x 256).  The statement is
+    checked against the tensor's storage pointer, shape, strides and version counter, which sees every in-place torch operation on the tensor
+    or on a view of it -- and nothing else.  Writes that torch's version counter does not see make sgmCostVolume trust stale minima and
+    return a wrong volume without notice: through `cv.data` (a tensor with a counter of its own), through another framework's kernel handed
+    `cv.data_ptr()` / a DLPack or __cuda_array_interface__ export, through a raw C-ABI call.  Ask for it only for a volume you do not write
+    to by such routes; `dropMinima(cv)` withdraws it."""
     lib = _capi.load()
     l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
@@ -340,9 +348,9 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
         return _empty_like(l, 3, "f32")
     src = r if int(dDir) == dispDirection.RightToLeft else l
     out = _like(l, (src.shape[0], src.shape[1], D), "f32")
-    if _is_torch(out) and int(matchFunc) in (matchingFunctions.CENSUS, matchingFunctions.HAMMING):
-        # device volume of integer costs: keep what a later sgmCostVolume<Cost> on it would otherwise re-read the volume for
-        # (svh_unfold_cost_volume_minima), tied to this tensor's storage and version counter: any in-place change drops it
+    if keep_minima and _is_torch(out) and int(matchFunc) in (matchingFunctions.CENSUS, matchingFunctions.HAMMING):
+        # device volume of integer costs, at the caller's request: keep what a later sgmCostVolume<Cost> on it would otherwise re-read the
+        # volume for (svh_unfold_cost_volume_minima), tied to this tensor's storage and version counter
         minima = _like(l, (src.shape[0], src.shape[1], 2), "f32")
         written = C.c_int(0)
         st = _check(ctx, lib.svh_unfold_cost_volume_minima(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
@@ -356,9 +364,16 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
     return out if st == _capi.OK else _empty_like(l, 3, "f32")
 
 
+def dropMinima(cv):
+    """Withdraw the statement unfoldBasedCostVolume(..., keep_minima=True) left with `cv` (call it after writing to the volume by a route
+    torch's version counter does not see)."""
+    if getattr(cv, "_svh_minima", None) is not None:
+        cv._svh_minima = None
+
+
 def _volume_minima(cv):
-    """The regional minima unfoldBasedCostVolume left with a device volume, if the tensor is still the one it wrote (same storage,
-    same shape, version counter untouched: no in-place operation since)."""
+    """The regional minima unfoldBasedCostVolume(..., keep_minima=True) left with a device volume, if the tensor is still the one it wrote
+    (same storage, same shape, version counter untouched: no in-place torch operation since).  See that function for what this cannot see."""
     hint = getattr(cv, "_svh_minima", None) if _is_torch(cv) else None
     if hint is None:
         return None

@@ -378,11 +378,6 @@ int svh_context_destroy(svh_context *ctx) {
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : ctx->prof_free_events) (void)hipEventDestroy(e);
-    if (ctx->aux_stream) {
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        (void)hipStreamDestroy(ctx->aux_stream);
-    }
-    for (auto e : ctx->aux_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SVH_OK;
@@ -436,11 +431,6 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         if (value != 0 && value != 1 && value != 3)
             return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows), 3 (bands, 16-column strips forced)");
         ctx->sgm_score_fused = value;
-        return SVH_OK;
-    }
-    if (strcmp(name, "sgm_overlap") == 0) {
-        if (value < 0 || value == 1 || value > 16) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_overlap: 0 (off) or the number of row bands, 2..16");
-        ctx->sgm_overlap = value;
         return SVH_OK;
     }
     return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);

@@ -54,9 +54,6 @@ struct svh_context {
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)
-    int sgm_overlap = 0;               // svh_context_set_option("sgm_overlap") 0 off / 2..16 row bands: svh_stereo_match runs the Left2Right pass of a Score-branch SGM per band of rows on a second stream, under the cost-volume kernel of the later bands
-    hipStream_t aux_stream = nullptr;  // (created on first use, destroyed with the context)
-    std::vector<hipEvent_t> aux_events;
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;
@@ -248,8 +245,6 @@ struct SgmArgs {
     // arrays are the whole image); margins and line geometry refer to the full image; only the local rows
     // [store_row0, store_row0 + store_rows) are written, to an output of store_rows rows
     int row_origin = 0, full_H = 0, store_row0 = 0, store_rows = 0;
-    // Score branch: out_sgm already holds the contribution of the Left2Right pass (dev_sgm_score_l2r_rows over all the rows)
-    bool l2r_done = false;
 };
 // The min_p maps of the six effective passes live in FIVE planes: passes 2 and 3 (the two start loops of UpLeft2DownRight, sgm.h:331-345)
 // partition the margin box along its diagonal -- pass 2 visits ip >= jp, pass 3 jp >= ip -- and the pixels both visit, the diagonal itself,
@@ -294,10 +289,6 @@ int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const
 // "sgm_score_fused" option); *ran = false when the geometry is outside what the sweep covers.  The line kernel for one pass.
 int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran);
 int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta);
-// the Left2Right contribution (delta form) of rows [r0, r0 + rows) only: a row's line needs that row's costs and nothing else
-int dev_sgm_score_l2r_rows(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int r0, int rows);
-// whether dev_sgm_score_branch would take the banded sweep for these arguments (so that its Left2Right pass may be run ahead)
-bool sgm_score_sweep_applies(const svh_context *ctx, const SgmArgs &a, const float *cv, const float *sgm);
 // census specialisation of the Cost branch (svh_census_sgm.hip)
 bool census_lane_kernels_available(int nWw, int D);
 bool census_exact_regime(const SgmArgs &a, int nWw);

@@ -706,13 +706,12 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
 
 // one pass of the whole-image 8-direction aggregation with P2 >= P1 >= 0 (what the fused sweeps leave to the line kernels):
 // delta: write the pass's contribution instead of adding it to sgm
-template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta, int r0 = 0, int rows = -1) {
+template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta) {
     // pixels per register batch (two batches: one in flight, one being walked).  Twice and four times as many measured the same at C4
     // (Left2Right + DownLeft2UpRight 5.57 / 5.57 / 5.60 ms): the passes are not waiting for their loads
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
     const bool vec = aligned16(cv) && aligned16(sgm) && a.D % 4 == 0;
     LineSet ls{pass, pass_lines(pass, a.H, a.W), 0, 0, a.H, a.W};
-    if (rows >= 0) ls = LineSet{1, rows, r0, 0, rows, a.W}; // (Left2Right only: the lines of a band of rows are the rows of a box that starts at r0)
     if (ls.n_lines <= 0) return SVH_OK;
     const int grid = ceil_div(ls.n_lines, 4);
 #define SVH_LINE(DELTAV, VECV) \
@@ -736,25 +735,6 @@ int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv,
     case 16: return score_line_pass<16>(ctx, a, cv, sgm, pass, delta);
     default: return score_line_pass<32>(ctx, a, cv, sgm, pass, delta);
     }
-}
-
-int dev_sgm_score_l2r_rows(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int r0, int rows) {
-    switch (pick_R(a.D)) {
-    case 1: return score_line_pass<1>(ctx, a, cv, sgm, 1, true, r0, rows);
-    case 2: return score_line_pass<2>(ctx, a, cv, sgm, 1, true, r0, rows);
-    case 4: return score_line_pass<4>(ctx, a, cv, sgm, 1, true, r0, rows);
-    case 8: return score_line_pass<8>(ctx, a, cv, sgm, 1, true, r0, rows);
-    case 16: return score_line_pass<16>(ctx, a, cv, sgm, 1, true, r0, rows);
-    default: return score_line_pass<32>(ctx, a, cv, sgm, 1, true, r0, rows);
-    }
-}
-
-bool sgm_score_sweep_applies(const svh_context *ctx, const SgmArgs &a, const float *cv, const float *sgm) {
-    (void)cv;
-    (void)sgm;
-    const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0;
-    const bool far_global = a.P2 >= a.P1 && a.P1 >= 0.0f;
-    return ctx->sgm_score_fused && a.n_dir >= 8 && a.n_dir != 16 && whole && far_global && a.H > 0 && a.W > 0 && a.D > 0 && pick_R(a.D) <= 8;
 }
 
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook) {

@@ -263,7 +263,7 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
         const size_t state_floats = (size_t)3 * a.W * DP;
         float *st[2] = {scr.get_n<float>(state_floats), scr.get_n<float>(state_floats)};
         if (!st[0] || !st[1]) return SVH_ERR_OUT_OF_MEMORY;
-        if (!a.l2r_done) SVH_TRY(dev_sgm_score_line_pass(ctx, a, cv, sgm, 1, true)); // Left2Right: its contribution alone
+        SVH_TRY(dev_sgm_score_line_pass(ctx, a, cv, sgm, 1, true)); // Left2Right: its contribution alone
         const int strips = ceil_div(a.W, WB);
         {
             ProfScope prof(ctx, "sgm_score_bands"); // (one bracket around all the band launches)

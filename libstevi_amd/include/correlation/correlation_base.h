@@ -5,6 +5,7 @@
 
 #include <array>
 #include <cstdint>
+#include <type_traits>
 
 #include "./stevi_hip_bridge.h"
 
@@ -51,12 +52,38 @@ template <typename SearchRangeType> struct searchRangeTypeInfos {};
 template <> struct searchRangeTypeInfos<disp_t> { static const int CostVolumeDims = 3; };
 template <int nDim> struct searchRangeTypeInfos<searchOffset<nDim>> { static const int CostVolumeDims = 2 + nDim; };
 
+// condImgRef<T_L, T_R, dDir, nImDims>, correlation_base.h:824-878: which of the (left, right) pair is the SOURCE (the image whose pixels
+// get a disparity) and which the TARGET (the image searched), with their element types T_S / T_T: the right image is the source when
+// disparities run RightToLeft, the left one otherwise.  Holds references; a helper of the reference's own bodies that callers of
+// aggregateCost-like templates (hierarchical.h:82, cross_correlations.h:199) name.
+template <class T_L, class T_R, dispDirection dDir, int nImDims = 2> class condImgRef {
+    static constexpr bool rightIsSource = dDir == dispDirection::RightToLeft;
+
+  public:
+    typedef std::conditional_t<rightIsSource, T_R, T_L> T_S;
+    typedef std::conditional_t<rightIsSource, T_L, T_R> T_T;
+
+    explicit condImgRef(Multidim::Array<T_L, nImDims> const &im_l, Multidim::Array<T_R, nImDims> const &im_r) : img_l(im_l), img_r(im_r) {}
+
+    Multidim::Array<T_S, nImDims> const &source() const {
+        if constexpr (rightIsSource) return img_r;
+        else return img_l;
+    }
+    Multidim::Array<T_T, nImDims> const &target() const {
+        if constexpr (rightIsSource) return img_l;
+        else return img_r;
+    }
+
+  private:
+    Multidim::Array<T_L, nImDims> const &img_l;
+    Multidim::Array<T_R, nImDims> const &img_r;
+};
+
 // extractSelectedIndex<strategy>, correlation_base.h:427-464
 template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 2> extractSelectedIndex(Multidim::Array<T_CV, 3> const &costVolume) {
     auto s = costVolume.shape();
     Multidim::Array<disp_t, 2> disp(s[0], s[1]);
     if (disp.empty()) return disp;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
     HipBridge::check(svh_extract_selected_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
     return disp;
@@ -68,7 +95,6 @@ Multidim::Array<DT, 2> selectedIndexToDisp(Multidim::Array<DT, 2> const &selecte
     auto s = selectedIndex.shape();
     Multidim::Array<DT, 2> disp(s[0], s[1]);
     if (disp.empty()) return disp;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
     HipBridge::check(svh_selected_index_to_disp(HipBridge::context(), static_cast<int>(dDir), &in, disp_offset, &out));
     return disp;
@@ -79,7 +105,6 @@ template <class T_CV> Multidim::Array<T_CV, 2> selectedCost(Multidim::Array<T_CV
     auto s = costVolume.shape();
     Multidim::Array<T_CV, 2> tcv(s[0], s[1]);
     if (tcv.empty()) return tcv;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
     HipBridge::check(svh_selected_cost(HipBridge::context(), &cv, &idx, &out));
     return tcv;
@@ -92,7 +117,6 @@ Multidim::Array<T_CV, 3> truncatedCostVolume(Multidim::Array<T_CV, 3> const &cos
     auto s = costVolume.shape();
     Multidim::Array<T_CV, 3> tcv(s[0], s[1], (sdir == truncatedCostVolumeDirection::Both) ? cost_vol_radius * 4 + 1 : cost_vol_radius * 2 + 1);
     if (tcv.empty()) return tcv;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
     HipBridge::check(svh_truncated_cost_volume(HipBridge::context(), static_cast<int>(sdir), static_cast<int>(dir), &cv, &idx, h_radius, v_radius,
                                                cost_vol_radius, &out));
@@ -104,7 +128,6 @@ template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 3
     auto s = costVolume.shape();
     Multidim::Array<disp_t, 3> disp(s[0], s[1], 2);
     if (costVolume.empty()) return disp;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
     HipBridge::check(svh_extract_selected_2d_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
     return disp;
@@ -115,7 +138,6 @@ template <typename DT> Multidim::Array<DT, 3> selected2dIndexToDisp(Multidim::Ar
     auto s = selectedIndex.shape();
     Multidim::Array<DT, 3> disp(s[0], s[1], 2);
     if (selectedIndex.empty()) return disp;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
     HipBridge::check(svh_selected_2d_index_to_disp(HipBridge::context(), &in, offset.lowerOffset(0), offset.lowerOffset(1), &out));
     return disp;
@@ -130,7 +152,6 @@ Multidim::Array<T_CV, 4> truncatedBidirectionaCostVolume(Multidim::Array<T_CV, 4
     auto s = costVolume.shape();
     Multidim::Array<T_CV, 4> tcv(s[0], s[1], r0 * 2 + 1, r1 * 2 + 1);
     if (costVolume.empty()) return tcv;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
     HipBridge::check(svh_truncated_bidirectional_cost_volume(HipBridge::context(), &cv, &idx, r0, r1, &out));
     return tcv;
@@ -183,7 +204,6 @@ inline Multidim::Array<T_O, 2> channelsMean(Multidim::Array<T_I, 3, C> const &in
     static_assert(std::is_same_v<std::remove_const_t<T_I>, float> && std::is_same_v<T_O, float>, "libstevi_hip: float feature volumes only");
     Multidim::Array<T_O, 2> mean(in_data.shape()[0], in_data.shape()[1]);
     if (mean.empty()) return mean;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(in_data), out = HipBridge::describe(mean);
     HipBridge::check(svh_channels_mean(HipBridge::context(), &in, &out));
     return mean;

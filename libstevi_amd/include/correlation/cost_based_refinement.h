@@ -3,6 +3,7 @@
 #ifndef STEREOVISION_COST_BASED_REFINEMENT_H
 #define STEREOVISION_COST_BASED_REFINEMENT_H
 
+#include <algorithm>
 #include <cmath>
 
 #include "./correlation_base.h"
@@ -13,6 +14,26 @@ namespace Correlation {
 enum class InterpolationKernel { Equiangular, Parabola, Gaussian }; // cost_based_refinement.h:30-35
 enum class IsotropyHypothesis { Isotropic, Anisotropic };
 
+// refineCostTriplet<kernel>(c(-1), c(0), c(+1)), cost_based_refinement.h:43-69: the sub-sample offset of the extremum of the kernel's
+// curve through three neighbouring costs, as an inline HOST function for callers that hold a triplet themselves (the map-sized
+// refinement below runs the same three formulas on the GPU, svh_select_refine.hip; nothing in this tree routes a map through this one).
+//   Equiangular: (c1 - cm1) / (2 a), a = the larger of |c0 - cm1|, |c1 - c0| carrying the sign of c0 - cm1
+//   Parabola:    (cm1 - c1) / (2 (c1 - 2 c0 + cm1))
+//   Gaussian:    the parabola through the logarithms
+// No guard against a flat triplet: 0/0 gives NaN exactly as in the reference.
+template <InterpolationKernel kernel> inline float refineCostTriplet(float cm1, float c0, float c1) {
+    if constexpr (kernel == InterpolationKernel::Equiangular) {
+        const float rise = c0 - cm1;
+        const float alpha = std::copysign(1.f, rise) * std::max(std::fabs(rise), std::fabs(c1 - c0));
+        return (c1 - cm1) / (2 * alpha);
+    } else if constexpr (kernel == InterpolationKernel::Parabola) {
+        return (cm1 - c1) / (2 * (c1 - 2 * c0 + cm1));
+    } else {
+        const float lm1 = std::log(cm1), l0 = std::log(c0), l1 = std::log(c1);
+        return (lm1 - l1) / (2 * (l1 - 2 * l0 + lm1));
+    }
+}
+
 // refineDispCostInterpolation<kernel>(truncatedCostVolume, rawDisparity), cost_based_refinement.h:128-163
 template <InterpolationKernel kernel>
 Multidim::Array<float, 2> refineDispCostInterpolation(Multidim::Array<float, 3> const &truncatedCostVolume, Multidim::Array<disp_t, 2> const &rawDisparity) {
@@ -22,7 +43,6 @@ Multidim::Array<float, 2> refineDispCostInterpolation(Multidim::Array<float, 3> 
     if (cv_radius < 1 or 2 * cv_radius + 1 != depth) return Multidim::Array<float, 2>(); // :141-143
     Multidim::Array<float, 2> refined(shape);
     if (refined.empty()) return refined;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out)))
         return Multidim::Array<float, 2>();
@@ -51,7 +71,6 @@ Multidim::Array<float, 3> refineDisp2dCostInterpolation(Multidim::Array<float, 4
         return Multidim::Array<float, 3>(); // :180-182
     Multidim::Array<float, 3> refined(rawDisparity.shape());
     if (refined.empty()) return refined;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_2d_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), static_cast<int>(isotropHypothesis), &tcv,
                                                                 &raw, &out)))
@@ -70,7 +89,6 @@ Multidim::Array<float, 3> refineDisp2dCostPatchInterpolation(Multidim::Array<flo
         return Multidim::Array<float, 3>(); // :393-395
     Multidim::Array<float, 3> refined(rawDisparity.shape());
     if (refined.empty()) return refined;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_2d_cost_patch_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out)))
         return Multidim::Array<float, 3>();

@@ -7,6 +7,8 @@
 #include "./matching_costs.h"
 #include "./unfold.h"
 
+#include "../utils/contiguity.h" // as the reference does (cross_correlations.h:29)
+
 namespace StereoVision {
 namespace Correlation {
 
@@ -26,7 +28,6 @@ namespace HipBridge {
 template <class Fn, class... Maps> inline Multidim::Array<float, 2> mapOf(Fn fn, svh_array in, int h, int w, Maps... maps) {
     Multidim::Array<float, 2> out(h, w);
     if (out.empty()) return out;
-    std::lock_guard<std::mutex> g(lock());
     svh_array o = describe(out);
     check(fn(context(), &in, maps..., &o));
     return out;
@@ -34,7 +35,6 @@ template <class Fn, class... Maps> inline Multidim::Array<float, 2> mapOf(Fn fn,
 template <class Fn, class... Maps> inline Multidim::Array<float, 3> volumeOf(Fn fn, svh_array in, int h, int w, int f, Maps... maps) {
     Multidim::Array<float, 3> out(h, w, f);
     if (out.empty()) return out;
-    std::lock_guard<std::mutex> g(lock());
     svh_array o = describe(out);
     check(fn(context(), &in, maps..., &o));
     return out;
@@ -95,7 +95,6 @@ Multidim::Array<FType, 3> getFeatureVolumeForMatchFunc(Multidim::Array<T_I, 3, C
     if (census && shp[2] <= 1) return Multidim::Array<FType, 3>(); // census.h:76-78
     Multidim::Array<FType, 3> out(shp[0], shp[1], census ? (shp[2] - 1) / 32 + 1 : shp[2]);
     if (out.empty()) return out;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(feature_vol), o = HipBridge::describe(out);
     if (!HipBridge::check(svh_feature_volume_for_match_func(HipBridge::context(), static_cast<int>(matchFunc), &in, &o))) return Multidim::Array<FType, 3>();
     return out;
@@ -116,7 +115,6 @@ featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim:
         if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || count <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :209-211
         // aggregateCost's own layout (cross_correlations.h:220) is {w*D, 1, w}; the GPU's native one is dense (row, col, disparity)
         Multidim::Array<TCV, 3> cv(src[0], src[1], count);
-        std::lock_guard<std::mutex> g(HipBridge::lock());
         svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
         if (!HipBridge::check(svh_feature_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, lower, count, &out)))
             return Multidim::Array<TCV, 3>(0, 0, 0);
@@ -126,7 +124,6 @@ featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim:
         const int Dh = searchRange.dimRange(0), Dw = searchRange.dimRange(1);
         if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || Dh <= 0 || Dw <= 0) return Multidim::Array<TCV, 4>(); // :324-326, :338-340
         Multidim::Array<TCV, 4> cv(src[0], src[1], Dh, Dw);
-        std::lock_guard<std::mutex> g(HipBridge::lock());
         svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
         if (!HipBridge::check(svh_feature_cost_volume_2d(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r,
                                                          searchRange.template lowerOffset<0>(), searchRange.template upperOffset<0>(),
@@ -151,7 +148,6 @@ Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const
     if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 3>(0, 0, 0); // :755-759
     auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
     Multidim::Array<TCV, 3> cv(src[0], src[1], disp_width);
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
     if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
                                                  disp_width, &out)))
@@ -244,7 +240,6 @@ Multidim::Array<TCV, 4> unfoldBased2dDisparityCostVolume(Multidim::Array<T_L, nI
     const int Dh = searchWindows.dimRange(0), Dw = searchWindows.dimRange(1);
     if (Dh <= 0 || Dw <= 0) return Multidim::Array<TCV, 4>(); // :338-340
     Multidim::Array<TCV, 4> cv(l_shape[0], l_shape[1], Dh, Dw);
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
     if (!HipBridge::check(svh_unfold_cost_volume_2d(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius,
                                                     searchWindows.lowerOffset(0), searchWindows.upperOffset(0), searchWindows.lowerOffset(1),

@@ -29,7 +29,6 @@ OffsetedCostVolume<TCV> computeGuidedCV(Multidim::Array<T_L, 3> const &feature_v
     if (l_shape[0] != r_shape[0]) return {Multidim::Array<TCV, 3>(), Multidim::Array<disp_t, 2>()}; // :90-92
     auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
     OffsetedCostVolume<TCV> ret = {Multidim::Array<TCV, 3>(src[0], src[1], 2 * upscale_disp_radius + 1), Multidim::Array<disp_t, 2>(src[0], src[1])};
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), gd = HipBridge::describe(disp_guide);
     svh_array tcv = HipBridge::describe(ret.truncated_cost_volume), disp = HipBridge::describe(ret.disp_estimate);
     if (!HipBridge::check(svh_guided_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, &gd, upscale_disp_radius,
@@ -57,7 +56,6 @@ OffsetedCostVolume<TCV> hiearchicalTruncatedCostVolume(Multidim::Array<T_L, nImD
         hr[i] = h_radiuses[i];
         vr[i] = v_radiuses[i];
     }
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r);
     svh_array tcv = HipBridge::describe(ret.truncated_cost_volume), disp = HipBridge::describe(ret.disp_estimate);
     if (!HipBridge::check(svh_hierarchical_truncated_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), depth, &l, &r, hr,

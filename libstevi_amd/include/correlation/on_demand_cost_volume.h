@@ -123,7 +123,6 @@ template <matchingFunctions matchFunc, class T_CV, class F_V_S_T, class F_V_T_T,
         Multidim::Array<T_CV, nCostVolDim> tcv(tshape);
         if (tcv.empty()) return tcv;
         const svh_on_demand_params p = params();
-        std::lock_guard<std::mutex> g(HipBridge::lock());
         svh_array s = HipBridge::describe(_source->array()), t = HipBridge::describe(_target->array()), d = HipBridge::describe(disp), o = HipBridge::describe(tcv);
         if (!HipBridge::check(svh_on_demand_truncated_cost_volume(HipBridge::context(), &p, &s, &t, &d, radius, &o))) return Multidim::Array<T_CV, nCostVolDim>();
         return tcv;

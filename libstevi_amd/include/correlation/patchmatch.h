@@ -54,7 +54,6 @@ Multidim::Array<disp_t, 3> cachelessPatchMatch(T_FV_S const &f_s_p, T_FV_T const
         std::random_device rd;
         seed = (static_cast<uint64_t>(rd()) << 32) | rd();
     }
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array s = HipBridge::describe(f_s_p.array()), t = HipBridge::describe(f_t_p.array()), o = HipBridge::describe(disp);
     if (!HipBridge::check(svh_cacheless_patch_match(HipBridge::context(), &p, &s, &t, nIter, nRandomSearch, seed, &o, nullptr))) return Multidim::Array<disp_t, 3>();
     return disp;

@@ -24,7 +24,6 @@ Multidim::Array<float, 3> sgmCostVolume(Multidim::Array<T_CV, 3> const &cv_base,
     Multidim::Array<float, 3> sgm_cv(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
     HipBridge::check(svh_sgm_cost_volume(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
     return sgm_cv;
@@ -40,10 +39,11 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
-    if (extractionStrategy == dispExtractionStartegy::Cost && cv_base.statement()) {
+    auto known = cv_base.statement(); // one read: the statement is shared by every handle of the memory and may be dropped through another
+    if (extractionStrategy == dispExtractionStartegy::Cost && known) {
         // a volume the library wrote and nobody has touched: its regional minima come with it, the probe pass over the volume is skipped
         svh_array mn{};
-        mn.data = cv_base.statement()->minima.get();
+        mn.data = const_cast<float *>(known->minima.get()); // (svh_array has one pointer type; the call only reads the map)
         mn.ndim = 3;
         mn.dtype = SVH_F32;
         mn.memspace = SVH_DEVICE;
@@ -53,7 +53,7 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
         mn.strides[0] = 2 * static_cast<int64_t>(cv_base.shape()[1]);
         mn.strides[1] = 2;
         mn.strides[2] = 1;
-        HipBridge::check(svh_sgm_cost_volume_minima(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, &mn, cv_base.statement()->max_abs,
+        HipBridge::check(svh_sgm_cost_volume_minima(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, &mn, known->max_abs,
                                                     P1, P2, m, Pout, &out));
         return sgm_cv;
     }
@@ -70,7 +70,6 @@ Multidim::Array<float, 3> sgmCostVolumeTextbook(Multidim::Array<T_CV, 3> const &
     Multidim::Array<float, 3> sgm_cv(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
     HipBridge::check(svh_sgm_cost_volume_textbook(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
     return sgm_cv;

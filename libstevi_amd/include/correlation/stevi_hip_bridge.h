@@ -5,9 +5,9 @@
 #include <MultidimArrays/MultidimArrays.h>
 
 #include <array>
+#include <atomic>
 #include <cstdint>
 #include <memory>
-#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -27,7 +27,6 @@ namespace HipBridge {
 struct ThreadState {
     svh_context *own = nullptr;     // created lazily, owned by the thread
     svh_context *current = nullptr; // what context() hands out: a ContextScope's context, else `own`
-    std::mutex unshared;            // lock() below: kept so that the shims read the same as before; never contended
     ~ThreadState() {
         if (own) svh_context_destroy(own);
     }
@@ -58,8 +57,6 @@ class ContextScope {
   private:
     svh_context *prev;
 };
-
-inline std::mutex &lock() { return thread_state().unshared; }
 
 template <class T> struct DType {
     static_assert(sizeof(T) == 0, "libstevi_hip: this element type has no GPU path (float or uint8 images, float volumes, int32 index "
@@ -175,7 +172,8 @@ template <class T, int N> class DeviceArray {
         // freed by DEVICE, not through the allocating context: the array may outlive the thread (and with it the thread's context) that
         // made it -- a worker returns its result and exits
         const int device = svh_context_get_device(ctx);
-        _mem.reset(static_cast<T *>(p), [device](T *q) { svh_device_free_detached(device, q); });
+        _st = std::make_shared<Storage>();
+        _st->mem.reset(static_cast<T *>(p), [device](T *q) { svh_device_free_detached(device, q); });
     }
     template <Multidim::ArrayDataAccessConstness C> static DeviceArray upload(Multidim::Array<T, N, C> const &host) {
         ShapeBlock s;
@@ -198,7 +196,7 @@ template <class T, int N> class DeviceArray {
             copy = denseCopy(host);
             src = copy->data();
         }
-        check(svh_device_upload(context(), d._mem.get(), src, d.flatLenght() * sizeof(T)));
+        check(svh_device_upload(context(), d._st->mem.get(), src, d.flatLenght() * sizeof(T)));
         return d;
     }
     Multidim::Array<T, N> download() const {
@@ -214,11 +212,11 @@ template <class T, int N> class DeviceArray {
             stride *= host.shape()[k];
         }
         if (dense) {
-            check(svh_device_download(context(), firstElement(host), _mem.get(), flatLenght() * sizeof(T)));
+            check(svh_device_download(context(), firstElement(host), _st->mem.get(), flatLenght() * sizeof(T)));
         } else {
             constexpr Multidim::AccessCheck Nc = Multidim::AccessCheck::Nocheck;
             std::vector<T> tmp(flatLenght());
-            check(svh_device_download(context(), tmp.data(), _mem.get(), flatLenght() * sizeof(T)));
+            check(svh_device_download(context(), tmp.data(), _st->mem.get(), flatLenght() * sizeof(T)));
             std::array<int, N> idx;
             idx.fill(0);
             for (std::size_t e = 0; e < tmp.size(); e++) {
@@ -232,40 +230,52 @@ template <class T, int N> class DeviceArray {
         return host;
     }
     ShapeBlock const &shape() const { return _shape; }
-    bool empty() const { return !_mem || flatLenght() == 0; }
+    bool empty() const { return !_st || flatLenght() == 0; }
     // What the library knows about a volume it wrote itself and that has not been written to since (svh_unfold_cost_volume_minima /
     // svh_sgm_cost_volume_minima in include/stevi_hip.h): the regional minima of a census / Hamming cost volume and the bound on its
-    // integer costs.  Attached by unfoldBasedCostVolumeOnDevice, read by sgmCostVolume<.., Cost>, gone the moment anybody asks for a
-    // pointer the volume could be written through (data() on a non-const array): const access cannot invalidate it.
+    // integer costs.  Attached by unfoldBasedCostVolumeOnDevice, read by sgmCostVolume<.., Cost>.  The statement is about the MEMORY, so
+    // it lives with the memory (the control block every copy of the handle shares), not with one handle: the moment anybody asks any
+    // handle for a pointer the volume could be written through (data() on a non-const array) it is gone for all of them.  const access
+    // cannot invalidate it: data() const and share() hand out pointers to const.  A caller who casts that const away, or who kept a
+    // mutable pointer from before the statement was attached, is outside what the type can see -- dropStatement() is for them.
     struct Statement {
-        std::shared_ptr<float> minima; // device, (H, W, 2)
+        std::shared_ptr<const float> minima; // device, (H, W, 2)
         float max_abs = 0;
     };
-    std::shared_ptr<const Statement> const &statement() const { return _statement; }
-    void attach(std::shared_ptr<const Statement> st) { _statement = std::move(st); }
-    std::shared_ptr<T> share() const { return _mem; } // the memory itself, kept alive by whoever holds the pointer
+    std::shared_ptr<const Statement> statement() const { return _st ? std::atomic_load(&_st->statement) : std::shared_ptr<const Statement>(); }
+    void attach(std::shared_ptr<const Statement> st) {
+        if (_st) std::atomic_store(&_st->statement, std::move(st));
+    }
+    void dropStatement() const {
+        if (_st) std::atomic_store(&_st->statement, std::shared_ptr<const Statement>());
+    }
+    // the memory itself, read-only, kept alive by whoever holds the pointer
+    std::shared_ptr<const T> share() const { return _st ? std::shared_ptr<const T>(_st, _st->mem.get()) : std::shared_ptr<const T>(); }
     std::size_t flatLenght() const { // (sic) as Multidim::Array
         std::size_t n = 1;
         for (int k = 0; k < N; k++) n *= static_cast<std::size_t>(_shape[k] > 0 ? _shape[k] : 0);
         return n;
     }
-    T const *data() const { return _mem.get(); }
+    T const *data() const { return _st ? _st->mem.get() : nullptr; }
     T *data() {
-        _statement.reset(); // the caller may write: whatever was known about the contents is no longer
-        return _mem.get();
+        dropStatement(); // the caller may write: whatever was known about the contents is no longer, through any handle
+        return _st ? _st->mem.get() : nullptr;
     }
 
   private:
     template <class U, int M> friend svh_array describe(DeviceArray<U, M> const &a);
+    struct Storage {
+        std::shared_ptr<T> mem;
+        std::shared_ptr<const Statement> statement;
+    };
     ShapeBlock _shape;
-    std::shared_ptr<T> _mem;
-    std::shared_ptr<const Statement> _statement;
+    std::shared_ptr<Storage> _st;
 };
 
 template <class T, int N> inline svh_array describe(DeviceArray<T, N> const &a) {
     static_assert(N <= SVH_MAX_DIMS, "too many dimensions");
     svh_array d{};
-    d.data = a._mem.get(); // (the shims write results through descriptors of arrays they have just created: nothing is attached yet)
+    d.data = a._st ? a._st->mem.get() : nullptr; // (the shims write results through descriptors of arrays they have just created: nothing is attached yet)
     d.ndim = N;
     d.dtype = DType<std::remove_const_t<T>>::value;
     d.memspace = SVH_DEVICE;

@@ -87,7 +87,6 @@ Multidim::Array<T_O, 3> unfold(uint8_t h_radius, uint8_t v_radius, Multidim::Arr
     if (svh_unfold_shape(&in, h_radius, v_radius, pp, shp) != SVH_OK || shp[0] <= 0 || shp[1] <= 0) return Multidim::Array<T_O, 3>();
     Multidim::Array<float, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2])); // the device writes float samples
     {
-        std::lock_guard<std::mutex> g(HipBridge::lock());
         svh_array o = HipBridge::describe(out);
         if (!HipBridge::check(svh_unfold_oriented(HipBridge::context(), &in, h_radius, v_radius, pp, static_cast<int>(orientation), &o)))
             return Multidim::Array<T_O, 3>();
@@ -111,7 +110,6 @@ Multidim::Array<T_O, 3> unfold(UnFoldCompressor const &compressor, Multidim::Arr
         shp[1] <= 0 || shp[2] <= 0)
         return Multidim::Array<T_O, 3>();
     Multidim::Array<T_O, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2]));
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array o = HipBridge::describe(out);
     if (!HipBridge::check(svh_unfold_compressed(HipBridge::context(), &in, compressor.maskData(), compressor.maskHeight(), compressor.maskWidth(), pp, &o)))
         return Multidim::Array<T_O, 3>();

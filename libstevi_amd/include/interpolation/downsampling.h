@@ -31,7 +31,6 @@ Multidim::Array<T_O, nDim> averagePoolingDownsample(Multidim::Array<T_I, nDim, C
     shape[1] = (shape[1] + (windows.horizontal() - 1)) / windows.horizontal();
     Multidim::Array<T_O, nDim> output(shape);
     if (output.empty()) return output;
-    std::lock_guard<std::mutex> g(HipBridge::lock());
     svh_array in = HipBridge::describe(input), out = HipBridge::describe(output);
     HipBridge::check(svh_average_pooling_downsample(HipBridge::context(), &in, windows.horizontal(), windows.vertical(), &out));
     return output;

@@ -78,12 +78,19 @@ int main(int argc, char **argv) {
             SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(SC::truncatedCostVolume(dSGM, dIdx, h_r, v_r, 1), dIdx).download();
         dump(out + "_census_disp_dev.i32", FE(ddisp), ddisp.flatLenght());
         // dCV came with the library's statement about its contents (regional minima: sgmCostVolume<Cost> skipped its probe pass above); a
-        // pointer the volume could be written through drops it, and the call takes the probing path: the same map either way
+        // pointer the volume could be written through drops it -- for EVERY handle of that memory, the copy the pointer was asked of and the
+        // original alike (the statement is about the storage) -- and the call takes the probing path: the same map either way.  const
+        // access (data() const, share()) keeps it.
         auto dCVt = dCV;
         const bool had = static_cast<bool>(dCVt.statement());
+        auto const &dCVc = dCV;
+        (void)dCVc.data();
+        (void)dCVc.share();
+        const bool kept_by_const_access = static_cast<bool>(dCV.statement());
         (void)dCVt.data();
-        if (!had || dCVt.statement() || !dCV.statement()) {
-            fprintf(stderr, "DeviceArray statement: attached %d, kept after a mutable access %d\n", (int)had, (int)static_cast<bool>(dCVt.statement()));
+        if (!had || !kept_by_const_access || dCVt.statement() || dCV.statement()) {
+            fprintf(stderr, "DeviceArray statement: attached %d, kept by const access %d, after a mutable access through a copy: copy %d original %d\n", (int)had,
+                    (int)kept_by_const_access, (int)static_cast<bool>(dCVt.statement()), (int)static_cast<bool>(dCV.statement()));
             return 5;
         }
         Multidim::Array<SC::disp_t, 2> tdisp = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(

@@ -628,13 +628,15 @@ def test_textbook_sgm_differs_from_the_reference_mode(rng):
 
 
 def test_cost_branch_on_a_census_volume_skips_the_probe_with_the_same_bits(rng):
-    """unfoldBasedCostVolume(CENSUS) on device tensors leaves the volume's regional minima with the tensor (svh_unfold_cost_volume_minima); a
-    sgmCostVolume<Cost> on the untouched tensor uses them instead of probing the volume (svh_sgm_cost_volume_minima): same S bit for bit,
-    no sgm_volume_probe launch.  Any in-place change of the tensor, a copy or a view with other strides drops the statement."""
+    """unfoldBasedCostVolume(CENSUS, keep_minima=True) on device tensors leaves the volume's regional minima with the tensor
+    (svh_unfold_cost_volume_minima); a sgmCostVolume<Cost> on the untouched tensor uses them instead of probing the volume
+    (svh_sgm_cost_volume_minima): same S bit for bit, no sgm_volume_probe launch.  Any in-place change of the tensor, a copy or a view with
+    other strides drops the statement; so does dropMinima; without keep_minima there is none (opt-in: ADVICE r03)."""
     src, tgt, _ = parallax_pair(40, 200, 14, 9, 30, 3, 17, seed=5)
     l, r = dev(tgt), dev(src)
     for D, margins, n_dir in ((64, None, 8), (48, sv.Margins(3, 2, 5, 1), 4), (256, None, 8)):
-        cv = sv.unfoldBasedCostVolume(MF.CENSUS, l, r, 4, 4, D)
+        assert getattr(sv.unfoldBasedCostVolume(MF.CENSUS, l, r, 4, 4, D), "_svh_minima", None) is None
+        cv = sv.unfoldBasedCostVolume(MF.CENSUS, l, r, 4, 4, D, keep_minima=True)
         assert getattr(cv, "_svh_minima", None) is not None
         exp = so.sgm(so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D), n_dir, so.COST, 0.001, 0.01, margins.as_tuple() if margins else (0, 0, 0, 0), 100.0)
         sv.profile_reset(l)
@@ -663,8 +665,17 @@ def test_cost_branch_on_a_census_volume_skips_the_probe_with_the_same_bits(rng):
         sv.profile_enable(l, False)
         assert "gmap_from_minima" not in sv.profile_collect(l)
         assert_bits(got3, so.sgm(host(cv), n_dir, so.COST, 0.001, 0.01, margins.as_tuple() if margins else (0, 0, 0, 0), 100.0))
+    # withdrawn by hand (for writes torch's version counter cannot see): probe path again
+    cv = sv.unfoldBasedCostVolume(MF.CENSUS, l, r, 4, 4, 32, keep_minima=True)
+    sv.dropMinima(cv)
+    sv.profile_reset(l)
+    sv.profile_enable(l, True)
+    got4 = sv.sgmCostVolume(8, so.COST, cv, 0.001, 0.01, None, 100.0)
+    sv.profile_enable(l, False)
+    assert "gmap_from_minima" not in sv.profile_collect(l)
+    assert_bits(got4, so.sgm(host(cv), 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0))
     # Score strategy / other functions: no statement
-    assert getattr(sv.unfoldBasedCostVolume(MF.SAD, l, r, 2, 2, 16), "_svh_minima", None) is None
+    assert getattr(sv.unfoldBasedCostVolume(MF.SAD, l, r, 2, 2, 16, keep_minima=True), "_svh_minima", None) is None
 
 
 # ------------------------------------------------------------------------------------------------ sgmCostVolume<.., T_CV>

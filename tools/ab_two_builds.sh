@@ -7,7 +7,10 @@ set -e
 A=$1; B=$2; shift 2
 ARMS=${@:-census_tiles=1}
 R=$(pwd)
-cp $R/libstevi_amd/libstevi_hip.so /tmp/keep.so
+# the installed library is put back on EVERY way out (a failing step under set -e, a signal), not only after the last arm
+KEEP=$(mktemp /tmp/stevi_keep_XXXXXX.so)
+cp "$R/libstevi_amd/libstevi_hip.so" "$KEEP"
+trap 'cp "$KEEP" "$R/libstevi_amd/libstevi_hip.so"; rm -f "$KEEP"' EXIT
 cd /tmp; export TMPDIR=/tmp
 for arm in A B A B; do
   if [ $arm = A ]; then cp $R/$A $R/libstevi_amd/libstevi_hip.so; else cp $R/$B $R/libstevi_amd/libstevi_hip.so; fi
@@ -25,4 +28,3 @@ PY
 ) $(grep -o 'checksum": [0-9]*' /tmp/ab_$arm.log | head -1)"
   rm -rf /tmp/abl_$arm
 done
-cp /tmp/keep.so $R/libstevi_amd/libstevi_hip.so

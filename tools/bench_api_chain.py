@@ -17,7 +17,7 @@ for name, W, H, D, func, r in cases:
     d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
     strat = sv.matchFuncStrategy(func)
     def chain():
-        cv = sv.unfoldBasedCostVolume(func, d_tgt, d_src, r, r, D)
+        cv = sv.unfoldBasedCostVolume(func, d_tgt, d_src, r, r, D, keep_minima=True)
         sgm = sv.sgmCostVolume(8, strat, cv, 0.001, 0.01, None, 100.0)
         return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, sgm), 0)
     chain(); torch.cuda.synchronize()

@@ -121,6 +121,13 @@ const char *svh_last_error(const svh_context *ctx);
  * of the line recurrences' per-pass minima, only the values on the edges of 9-row x 64-column tiles, and the per-pixel kernel replays
  * the recurrences inside its tile; 0 writes the six per-pass maps and reads them back (round 2's pair of kernels).  Same results bit
  * for bit (tests/test_gpu_census_tiles.py); margins, 4 directions, taller images and row bands take the maps form regardless.
+ * "sgm_cost_two_minima" (default 1): svh_sgm_cost_volume, Cost strategy, on a float volume that is not in the exact-integer regime
+ * reads the volume ONCE for its line recurrences: a probe leaves every pixel's two regional minima (the smallest finite cost among the
+ * disparities that look inside the image, and among those that look past its right border), and the recurrence of sgm.h:257-296 --
+ * whose state is one number per line because of `min_a_cost = c_score` -- runs on those two numbers with the reference's float
+ * operations (the per-disparity step is non-decreasing in the cost, so a region's minimum over d is the step of the region's minimum).
+ * Needs magnitudes that cannot overflow along a line: the probe checks |c| <= 1e30 on the device and otherwise lets the sweeps of the
+ * volume run (a finite |Pout| > 1e30 sends the call there directly).  0: one sweep of the volume per pass (rounds 1-3).  Same bits.
  * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
  * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  1: one sweep of the volume, a launch per band of 16
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23

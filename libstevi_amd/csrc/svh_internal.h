@@ -53,6 +53,7 @@ struct svh_context {
     bool census_tiles = true;          // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
+    bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;

@@ -73,8 +73,8 @@ __device__ __forceinline__ float cost_step_lane_min(const float (&c)[R], int lan
 
 template <class SRC, int R, int B>
 __global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, LineSet ls, int D, int W, float Pout,
-                                                             float *__restrict__ mmap, const int *__restrict__ run_if_nonzero) {
-    if (run_if_nonzero && *run_if_nonzero == 0) return; // the exact-integer route already produced the maps
+                                                             float *__restrict__ mmap, const int *__restrict__ gate, int gate_mask) {
+    if (gate && (*gate & gate_mask) == 0) return; // another route already produced the maps (exact-integer scans / the two-minima recurrences)
     const int lane = threadIdx.x & 63;
     const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (l >= ls.n_lines) return;
@@ -308,48 +308,221 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
     }
 }
 
-// Integer-volume probe.  A float cost volume whose values are all small integers (a Hamming volume handed to the
-// per-function API, say) is in the same exact regime as the census path: every operation of sgm.h:257-300 is exact,
-// the per-pass minima follow mp' = g - mp, and six wave-per-line sweeps of the volume collapse into this one read.
-// The kernel writes g(p) = min_d [c + (c [+ Pout])] and raises `flag` as soon as one value is not an integer in
-// [-limit, limit]; the scan kernels run only if the flag stayed 0 and the line kernels only if it was raised, so no host
-// round trip is needed.
-template <int R>
-__global__ void __launch_bounds__(256) volume_gmin_probe_kernel(SrcVolume src, int64_t npx, int D, int W, float Pout, float limit,
-                                                               float *__restrict__ gmap, int *__restrict__ flag) {
+// Volume probe: ONE read of a float cost volume that replaces the per-pass sweeps of it.
+//  * g(p) = min_d [c + (c [+ Pout])] and bit 0 of `flag`, raised as soon as one value is not an integer in [-limit, limit].  A volume
+//    whose values are all small integers (a Hamming volume handed to the per-function API, say) is in the same exact regime as the
+//    census path: every operation of sgm.h:257-300 is exact, the per-pass minima follow mp' = g - mp, and the scan kernels of
+//    svh_census_sgm.hip produce the min_p maps from g.  (limit < 0: no exact route wanted, bit 0 is always raised.)
+//  * minima(p) = (min of the finite costs with j + d < W, min of the finite costs with j + d >= W; +inf for an empty region) and bit 1
+//    of `flag`, raised when a finite |c| exceeds SGM_SAFE_MAGNITUDE.  These two numbers are ALL the Cost branch's recurrence needs of
+//    a pixel (sgm_cost_minmap_scalar_kernel below), for any float volume whose magnitudes cannot overflow along a line.
+// The scan kernels run only while the flag is 0, the two-minima recurrences when bit 0 is up and bit 1 is not, the wave-per-line
+// sweeps of the volume only when bit 1 is up: a device-side word gates all three, no host round trip.
+constexpr float SGM_SAFE_MAGNITUDE = 1e30f;
+// EXACT: the caller wants the exact-integer route tried (bit 0 is meaningful); otherwise bit 0 is raised unconditionally.
+// g is not computed here any more: in the exact regime it is min(2 m_in, m_out + (m_out + Pout)) (gmap_from_minima_kernel, gated on
+// the flag), one wave reduction less per pixel.  Most pixels have no disparity that looks past the border (j + D <= W, wave-uniform):
+// one reduction instead of two.
+template <int R, bool EXACT>
+__global__ void __launch_bounds__(256) volume_minima_probe_kernel(SrcVolume src, int64_t npx, int D, int W, float limit, float2 *__restrict__ minima,
+                                                                 int *__restrict__ flag) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // (pixel indices are wave-uniform: kept in scalar registers, one 32-bit division per eight pixels -- a 64-bit division per pixel
+    // and lane cost more instructions than the whole reduction)
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int npx32 = (int)npx; // (the host refuses more than 2^31 - 1 pixels)
     bool bad = false;
-    constexpr int PROBE_PB = 4; // pixels per wave iteration, loads issued together
-    for (int64_t p0 = wave * PROBE_PB; p0 < npx; p0 += nwaves * PROBE_PB) {
+    float amax = 0.0f; // largest finite |c| seen by this lane
+    constexpr int PROBE_PB = 8; // pixels per wave iteration, loads issued together
+    for (int p0 = wave * PROBE_PB; p0 < npx32; p0 += nwaves * PROBE_PB) {
         float cb[PROBE_PB][R];
+        const int j0 = (int)((unsigned)p0 % (unsigned)W);
+#pragma unroll
+        for (int u = 0; u < PROBE_PB; u++) src.template load_flat<R>(min(p0 + u, npx32 - 1), lane, cb[u]);
 #pragma unroll
         for (int u = 0; u < PROBE_PB; u++) {
-            const int64_t pu = min(p0 + u, npx - 1);
-            src.template load<R>((int)(pu / W), (int)(pu % W), lane, cb[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < PROBE_PB; u++) {
-            const int64_t p = p0 + u;
-            if (p >= npx) break;
-            const int j = (int)(p % W);
-            float m = INFINITY;
+            const int p = p0 + u;
+            if (p >= npx32) break;
+            int j = j0 + u;
+            while (j >= W) j -= W;
+            float cf[R];
 #pragma unroll
             for (int k = 0; k < R; k++) {
-                const int d = lane * R + k;
-                if (d < D) {
-                    const float c = cb[u][k];
-                    bad = bad || !(fabsf(c) <= limit) || c != rintf(c);
-                    const float t = (j + d >= W) ? c + Pout : c;
-                    m = fminf(m, c + t);
-                }
+                const float c = cb[u][k], ac = fabsf(c);
+                const bool fin = ac < INFINITY && lane * R + k < D;
+                if constexpr (EXACT) bad = bad || (lane * R + k < D && (!(ac <= limit) || c != rintf(c)));
+                amax = fmaxf(amax, fin ? ac : 0.0f);
+                cf[k] = fin ? c : INFINITY;
             }
-            m = wave_min(m);
-            if (lane == 0) gmap[p] = m;
+            float m_in = INFINITY, m_out = INFINITY;
+            if (j + D <= W) { // (wave-uniform) every disparity looks inside the image
+#pragma unroll
+                for (int k = 0; k < R; k++) m_in = fminf(m_in, cf[k]);
+                m_in = wave_min(m_in);
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; k++) {
+                    const bool oob = j + lane * R + k >= W;
+                    m_in = fminf(m_in, oob ? INFINITY : cf[k]);
+                    m_out = fminf(m_out, oob ? cf[k] : INFINITY);
+                }
+                m_in = wave_min(m_in);
+                m_out = wave_min(m_out);
+            }
+            if (lane == 0) minima[p] = make_float2(m_in, m_out);
         }
     }
-    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+    const int raise = ((!EXACT || __any(bad)) ? 1 : 0) | (__any(amax > SGM_SAFE_MAGNITUDE) ? 2 : 0);
+    if (raise && lane == 0) atomicOr(flag, raise);
+}
+
+// g(p) from the probe's minima, exact route only (the scans that read it are gated the same way)
+__global__ void gmap_from_minima_gated_kernel(const float2 *__restrict__ minima, int64_t npx, float Pout, float *__restrict__ gmap, const int *__restrict__ skip_if_nonzero) {
+    if (*skip_if_nonzero != 0) return;
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p < npx) {
+        const float2 m = minima[p];
+        gmap[p] = fminf(m.x + m.x, m.y + (m.y + Pout));
+    }
+}
+
+// ---- Cost branch on any float volume: the per-pass min_p maps from two numbers per pixel ----------------------------------------
+// One step of sgm.h:259-295 at a pixel with previous-line minimum mp is, per disparity (cost_step_lane_min above),
+//     t = c (+ Pout where j + d >= W);   act = (mp finite and t finite) ? c + (t - mp) : c;   mp' = min over the finite act.
+// For fixed mp and Pout, c -> act is a composition of roundings of non-decreasing functions, hence non-decreasing in c within each of
+// the two regions (j + d < W, j + d >= W); a non-finite c gives a non-finite act and never enters the minimum.  As long as nothing
+// overflows -- every finite |c| <= SGM_SAFE_MAGNITUDE, Pout not finite or |Pout| <= SGM_SAFE_MAGNITUDE, lines of at most 10^5 pixels, so
+// that |mp| stays below 10^36 -- finite c give finite act, and the minimum over a region is the step applied to the region's smallest
+// finite cost.  mp' is therefore a function of the pixel's two regional minima alone: the six line recurrences run on an (H, W, 2) map
+// (one lane per line, the reference's float operations in the reference's order, literally the per-disparity step on two values) and
+// the volume is read once, by the probe, instead of once per pass.  The minima themselves are order-free (a minimum of floats is
+// exact).  Outside the regime (bit 1 of the probe's flag, or a huge finite Pout) the wave-per-line kernels above run instead.
+// Lane <-> line mapping: a lane owns a line, and the lanes of a wave touch CONSECUTIVE COLUMNS OF ONE ROW at every step, so that
+// the loads of the minima and the stores of the map are whole cache lines: the wave walks the rows of the margin box (downwards;
+// upwards for DownLeft2UpRight) and a lane is active on the rows its line crosses --
+//     family 0  Up2Down            line l: column l                       every row
+//     family 1  UpLeft2DownRight   line k = j - i in [-(Hp-1), Wp-1]       rows max(0, -k) .. : both start loops of the reference (passes 2
+//                                  and 3 share a plane; the corner line runs twice there with the same values, once here)
+//     family 2  UpRight2DownLeft   line l = i + j in [0, Wp-1]             rows 0 .. l
+//     family 3  DownLeft2UpRight   line l = i + j in [0, Hp-1]             rows l .. 0, upwards
+// -- while Left2Right (family 4) gives a lane a row, whose minima and map entries are contiguous in memory by themselves (eight steps:
+// 64 bytes in, 32 out).  The chains of different lanes are independent, so none of this changes a value.
+struct ScalarLines {
+    int top, left, Hp, Wp;
+    int first[6]; // lanes of family f: [first[f], first[f + 1]), each family padded to whole waves
+    int n_dir;    // 4: families 0 and 4 only
+};
+__device__ __forceinline__ float cost_step_two_minima(float2 m, float Pout, float mp) {
+    const bool mp_fin = finite_f(mp);
+    float next = INFINITY;
+    {
+        const float c = m.x, t = c;
+        float act = c;
+        if (mp_fin && finite_f(t)) act = c + (t - mp);
+        if (finite_f(act)) next = fminf(next, act);
+    }
+    {
+        const float c = m.y, t = c + Pout;
+        float act = c;
+        if (mp_fin && finite_f(t)) act = c + (t - mp);
+        if (finite_f(act)) next = fminf(next, act);
+    }
+    return next;
+}
+__global__ void __launch_bounds__(64) sgm_cost_minmap_scalar_kernel(const float2 *__restrict__ minima, ScalarLines g, int W, int64_t npx, float Pout,
+                                                                    float *__restrict__ mmap, const int *__restrict__ gate) {
+    if (gate) {
+        const int f = *gate;
+        if (f == 0 || (f & 2)) return; // exact-integer scans made the maps / magnitudes outside the regime: the volume sweeps make them
+    }
+    const int gl = blockIdx.x * 64 + threadIdx.x;
+    int fam = 0;
+    while (fam < 4 && gl >= g.first[fam + 1]) fam++; // (block-uniform: families are padded to whole waves)
+    const int l = gl - g.first[fam];
+    // The loads do not depend on the recurrence: two register batches of PF steps alternate, the next batch's minima are in flight
+    // while the chain walks the current one (a lane's chain is ~50 cycles a step; a batch must outlast a memory round trip).
+    constexpr int PF = 24;
+    float mp = 0.0f; // previous_cost[] = 0 -> min over finite = 0 (sgm.h:206-208)
+    if (fam == 4) { // Left2Right: lane = row
+        if (l >= g.Hp) return;
+        const int64_t base = (int64_t)(g.top + l) * W + g.left;
+        float *plane = mmap + (int64_t)min_p_plane(1) * npx + base;
+        const float2 *src = minima + base;
+        auto load = [&](float2 (&m)[PF], int t0) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) m[u] = src[min(t0 + u, g.Wp - 1)];
+        };
+        auto walk = [&](const float2 (&m)[PF], int t0) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                if (t0 + u < g.Wp) {
+                    plane[t0 + u] = mp;
+                    mp = cost_step_two_minima(m[u], Pout, mp);
+                }
+            }
+        };
+        float2 ma[PF], mb[PF];
+        load(ma, 0);
+        for (int t0 = 0; t0 < g.Wp; t0 += 2 * PF) {
+            load(mb, t0 + PF);
+            walk(ma, t0);
+            load(ma, t0 + 2 * PF);
+            walk(mb, t0 + PF);
+        }
+        return;
+    }
+    // row-walking families: column of this lane's line on row r (relative to the margin box), and the rows it crosses
+    const int q = fam == 0 ? 0 : (fam == 1 ? 2 : (fam == 2 ? 4 : 5));
+    float *plane = mmap + (int64_t)min_p_plane(q) * npx;
+    const int k = fam == 1 ? l - (g.Hp - 1) : l; // family 1: k = j - i
+    int r_first, r_last, lines;                  // rows of the line, in walking order r_first -> r_last
+    switch (fam) {
+    case 0: lines = g.Wp; r_first = 0; r_last = g.Hp - 1; break;
+    case 1: lines = g.Hp + g.Wp - 1; r_first = max(0, -k); r_last = min(g.Hp - 1, g.Wp - 1 - k); break;
+    case 2: lines = g.Wp; r_first = 0; r_last = min(g.Hp - 1, l); break;
+    default: lines = g.Hp; r_first = l; r_last = max(0, l - (g.Wp - 1)); break;
+    }
+    const bool mine = l < lines;
+    const int dir = fam == 3 ? -1 : 1;
+    // the wave walks the union of its lanes' rows
+    const int wl0 = l - (int)threadIdx.x, wl1 = min(wl0 + 63, lines - 1); // first / last line of the wave
+    int w_first, w_last;
+    switch (fam) {
+    case 0: w_first = 0; w_last = g.Hp - 1; break;
+    case 1: w_first = max(0, -(wl1 - (g.Hp - 1))); w_last = min(g.Hp - 1, g.Wp - 1 - (wl0 - (g.Hp - 1))); break;
+    case 2: w_first = 0; w_last = min(g.Hp - 1, wl1); break;
+    default: w_first = min(wl1, g.Hp - 1); w_last = max(0, wl0 - (g.Wp - 1)); break;
+    }
+    const int n_rows = (w_last - w_first) * dir + 1;
+    auto column = [&](int r) { return fam == 0 ? l : (fam == 1 ? r + k : l - r); };
+    auto active = [&](int r) { return mine && (r - r_first) * dir >= 0 && (r_last - r) * dir >= 0; };
+    auto load = [&](float2 (&m)[PF], int s0) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int r = w_first + min(s0 + u, n_rows - 1) * dir;
+            const int c = min(max(column(r), 0), g.Wp - 1); // (inactive lanes load a clamped address: every load unconditional, the count of loads in flight stays exact)
+            m[u] = minima[(int64_t)(g.top + r) * W + g.left + c];
+        }
+    };
+    auto walk = [&](const float2 (&m)[PF], int s0) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int r = w_first + (s0 + u) * dir;
+            if (s0 + u < n_rows && active(r)) {
+                plane[(int64_t)(g.top + r) * W + g.left + column(r)] = mp;
+                mp = cost_step_two_minima(m[u], Pout, mp);
+            }
+        }
+    };
+    float2 ma[PF], mb[PF];
+    load(ma, 0);
+    for (int s0 = 0; s0 < n_rows; s0 += 2 * PF) {
+        load(mb, s0 + PF);
+        walk(ma, s0);
+        load(ma, s0 + 2 * PF);
+        walk(mb, s0 + PF);
+    }
 }
 
 // g(p) = min_d [c + (c [+ Pout])] from the two regional minima of the pixel (an empty region holds +inf)
@@ -545,7 +718,7 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
 // phase 1: the per-pass min_p maps (the sequential part); phase 2: rebuild S / pick the winner per pixel
 template <class SRC, int R>
 static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
-                           const int *gate = nullptr) {
+                           const int *gate = nullptr, int gate_mask = ~0) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
@@ -553,7 +726,7 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
         for (int q = 0; q < n_pass; q++) {
             LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
             SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), ceil_div(ls.n_lines, 4), 256, 0, src, ls, a.D, a.W,
-                       a.Pout, mmap + (size_t)min_p_plane(q) * a.H * a.W, gate);
+                       a.Pout, mmap + (size_t)min_p_plane(q) * a.H * a.W, gate, gate_mask);
             SVH_CHECK_LAUNCH(ctx);
         }
     }
@@ -569,14 +742,14 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
 
 template <class SRC>
 static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
-                                const int *gate = nullptr) {
+                                const int *gate = nullptr, int gate_mask = ~0) {
     switch (pick_R(a.D)) {
-    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate);
-    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate);
-    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate);
-    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate);
-    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate);
-    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate); // (up to 2048 disparities: 32 per lane)
+    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
+    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
+    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
+    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
+    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
+    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask); // (up to 2048 disparities: 32 per lane)
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 2048 disparities (got %d)", a.D);
     }
 }
@@ -593,11 +766,14 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
         // largest |c| for which 8 (2 |c| + |Pout|) (L + 2) stays below 2^24 (same bound as census_exact_regime)
         const double L = (double)std::max(a.H, a.W);
         const double limit = std::floor((16777216.0 / (8.0 * (L + 2.0)) - std::fabs((double)a.Pout)) / 2.0) - 1.0;
-        const bool try_exact = ctx->census_fast_path && n_pass > 0 && Hp > 0 && Wp > 0 && std::isfinite(a.Pout) &&
+        const bool try_exact = ctx->census_fast_path && (int64_t)a.H * a.W < (1ll << 31) && n_pass > 0 && Hp > 0 && Wp > 0 && std::isfinite(a.Pout) &&
                                a.Pout == std::nearbyint(a.Pout) && limit >= 1.0 && a.D <= 1024;
-        if (!try_exact) return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
+        // the two-minima recurrences (sgm_cost_minmap_scalar_kernel) need magnitudes that cannot overflow along a line
+        const bool two_minima = ctx->sgm_cost_two_minima && (int64_t)a.H * a.W < (1ll << 31) && n_pass > 0 && Hp > 0 && Wp > 0 && (!std::isfinite(a.Pout) || std::fabs(a.Pout) <= SGM_SAFE_MAGNITUDE) &&
+                                std::max(a.H, a.W) <= 100000 && a.D <= 1024;
+        if (!try_exact && !two_minima) return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
         const int64_t npx = (int64_t)a.H * a.W;
-        if (cs.minima && cs.max_abs <= (float)limit) {
+        if (try_exact && cs.minima && cs.max_abs <= (float)limit) {
             // the caller vouches for what the probe would find (svh_sgm_cost_volume_minima): g from the two regional minima, no read of C
             float *gmap = scr.get_n<float>((size_t)npx);
             if (!gmap) return SVH_ERR_OUT_OF_MEMORY;
@@ -606,12 +782,17 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
             SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, nullptr));
             return dispatch_cost_branch(ctx, a, src, mmap, &out, false);
         }
-        float *gmap = scr.get_n<float>((size_t)npx);
+        float *gmap = try_exact ? scr.get_n<float>((size_t)npx) : nullptr;
+        float2 *minima = scr.get_n<float2>((size_t)npx);
         int *flag = scr.get_n<int>(64);
-        if (!gmap || !flag) return SVH_ERR_OUT_OF_MEMORY;
+        if ((try_exact && !gmap) || !minima || !flag) return SVH_ERR_OUT_OF_MEMORY;
         SVH_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
-        const int grid = grid_for(npx, 4, 256 * 8 * 4);
-#define SVH_PROBE(RV) SVH_LAUNCH(ctx, "sgm_volume_probe", volume_gmin_probe_kernel<RV>, grid, 256, 0, src, npx, a.D, a.W, a.Pout, (float)limit, gmap, flag)
+        const int grid = grid_for(npx, 8 * 4, 256 * 8 * 4);
+#define SVH_PROBE(RV)                                                                                                                                   \
+    do {                                                                                                                                                \
+        if (try_exact) SVH_LAUNCH(ctx, "sgm_volume_probe", (volume_minima_probe_kernel<RV, true>), grid, 256, 0, src, npx, a.D, a.W, (float)limit, minima, flag); \
+        else SVH_LAUNCH(ctx, "sgm_volume_probe", (volume_minima_probe_kernel<RV, false>), grid, 256, 0, src, npx, a.D, a.W, 0.0f, minima, flag);             \
+    } while (0)
         switch (pick_R(a.D)) {
         case 1: SVH_PROBE(1); break;
         case 2: SVH_PROBE(2); break;
@@ -621,7 +802,20 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
         }
 #undef SVH_PROBE
         SVH_CHECK_LAUNCH(ctx);
-        SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, flag)); // run only while the flag is 0
+        if (try_exact) {
+            SVH_LAUNCH(ctx, "gmap_from_probe", gmap_from_minima_gated_kernel, grid_for(npx, 256), 256, 0, minima, npx, a.Pout, gmap, flag);
+            SVH_CHECK_LAUNCH(ctx);
+            SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, flag)); // run only while the flag is 0
+        }
+        if (two_minima) {
+            ScalarLines g{};
+            g.top = a.top, g.left = a.left, g.Hp = Hp, g.Wp = Wp, g.n_dir = a.n_dir;
+            const int fam_lines[5] = {Wp, n_pass > 2 ? Hp + Wp - 1 : 0, n_pass > 2 ? Wp : 0, n_pass > 2 ? Hp : 0, Hp};
+            for (int f = 0; f < 5; f++) g.first[f + 1] = g.first[f] + ceil_div(fam_lines[f], 64) * 64;
+            SVH_LAUNCH(ctx, "sgm_cost_minmap_scalar", sgm_cost_minmap_scalar_kernel, g.first[5] / 64, 64, 0, minima, g, a.W, npx, a.Pout, mmap, flag);
+            SVH_CHECK_LAUNCH(ctx);
+            return dispatch_cost_branch(ctx, a, src, mmap, &out, true, flag, 2); // the sweeps of the volume only when the probe saw magnitudes outside the regime
+        }
         return dispatch_cost_branch(ctx, a, src, mmap, &out, true, flag);   // line kernels run only if it was raised
     }
     SrcCensus src{cs.src_words, cs.tgt_words, cs.nWw, a.W, cs.Wt, cs.sign, cs.disp_lower, a.D};

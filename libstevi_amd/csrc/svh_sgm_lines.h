@@ -94,6 +94,22 @@ struct SrcVolume { // dense (H, W, D) floats
 #pragma unroll
         for (int k = 0; k < R; k++) c[k] = (lane * R + k < D) ? p[k] : 0.0f;
     }
+    // the same by flat pixel index (row * W + column)
+    template <int R> __device__ __forceinline__ void load_flat(int64_t px, int lane, float (&c)[R]) const {
+        const float *p = cv + px * D + lane * R;
+        if constexpr (R % 4 == 0) {
+            if (vec && lane * R + R <= D) {
+#pragma unroll
+                for (int q = 0; q < R / 4; q++) {
+                    float4 v = *reinterpret_cast<const float4 *>(p + 4 * q);
+                    c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) c[k] = (lane * R + k < D) ? p[k] : 0.0f;
+    }
 };
 
 // cross-lane primitives on the DPP path (no LDS round trip): whole-wave shifts by one lane and a max reduction

@@ -550,6 +550,58 @@ def test_sgm_integer_volume_routes_agree(rng):
                 assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
 
 
+def test_sgm_cost_branch_two_minima_route(rng):
+    """The Cost branch on a float volume reads the volume once: a probe leaves every pixel's two regional minima (costs that look inside
+    / past the right border) and the six line recurrences run on those two numbers (monotonicity of the per-disparity step,
+    svh_sgm.hip).  Must equal the oracle and the wave-per-line sweeps of the volume (option off) bit for bit: magnitudes over fifteen
+    decades, negative costs, NaN / +-inf voxels and whole non-finite pixels, an infinite Pout, margins, four directions, D not a
+    multiple of 64; and volumes whose magnitudes could overflow along a line (> 1e30) must fall back to the sweeps by themselves."""
+    H, W, D = 19, 37, 70
+    base = (rng.uniform(-1, 1, (H, W, D)) * 10.0 ** rng.integers(-6, 9, (H, W, 1))).astype(np.float32)
+    holes = base.copy()
+    holes[3, 5, 7] = np.nan
+    holes[0, 0, :] = np.inf           # a pixel without a finite cost: the line's minimum becomes +inf and the next pixel restarts
+    holes[7, 30:, :] = np.nan         # ... several in a row, at the right border
+    holes[11, 2, 5] = -np.inf
+    holes[H - 1, W - 1, D - 1] = np.inf
+    holes[9, W - 2, 1:] = np.nan      # only the in-image disparity is finite
+    huge = base.copy()
+    huge[4, 4, 4] = 3e38              # outside the regime: the probe's second flag bit sends the call to the volume sweeps
+    huge[12, 20, 60] = -2.5e38
+    for name, cv in (("magnitudes", base), ("non-finite", holes), ("huge", huge)):
+        d = dev(cv)
+        for n_dir, margins, Pout in ((8, (0, 0, 0, 0), 100.0), (8, (2, 1, 3, 2), 0.37), (4, (0, 0, 0, 0), -3.5), (8, (0, 0, 0, 0), np.inf), (8, (0, 3, 0, 0), 1e31)):
+            exp = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, margins, Pout, variant=0)  # the literal O(D^2) loops of sgm.h:257-296
+            outs = {}
+            try:
+                for route in (1, 0):
+                    sv.set_option(d, "sgm_cost_two_minima", route)
+                    sv.profile_reset(d)
+                    sv.profile_enable(d, True)
+                    outs[route] = host(sv.sgmCostVolume(n_dir, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout))
+                    sv.profile_enable(d, False)
+                    kernels = sv.profile_collect(d)
+                    if route == 1 and np.isinf(Pout) or route == 1 and abs(Pout) <= 1e30:
+                        assert "sgm_cost_minmap_scalar" in kernels and "sgm_volume_probe" in kernels, (name, kernels.keys())
+                    else:  # option off, or a finite Pout beyond the regime: no probe for the minima, the sweeps run unconditionally
+                        assert "sgm_cost_minmap_scalar" not in kernels
+            finally:
+                sv.set_option(d, "sgm_cost_two_minima", 1)
+            for route, got in outs.items():
+                assert np.array_equal(np.isnan(got), np.isnan(exp)), (name, n_dir, margins, Pout, route)
+                ok = ~np.isnan(exp)
+                assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32)), (name, n_dir, margins, Pout, route)
+    # the winner fused behind it (svh_stereo_match, SAD + SGM: Cost branch on the float volume the cost kernel wrote)
+    src, tgt, _ = parallax_pair(30, 90, 10, 8, 30, 2, 9, seed=77)
+    exp_cv = so.unfold_cost_volume(so.SAD, tgt, src, 2, 2, 40)
+    exp_idx = so.extract_index(so.sgm(exp_cv, 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 5.0), so.COST)
+    got = sv.stereoMatch(MF.SAD, dev(tgt), dev(src), 2, 2, 40, sgmDirections=8, P1=0.01, P2=0.1, Pout=5.0, want_cv=True)
+    if np.array_equal(host(got["cv"]), exp_cv):  # (the column-sum cost kernel agrees to 1e-4, not always to the bit: the map is only comparable on equal volumes)
+        assert np.array_equal(host(got["disp"]), so.index_to_disp(exp_idx))
+    same_cv = so.extract_index(so.sgm(host(got["cv"]), 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 5.0), so.COST)
+    assert np.array_equal(host(got["disp"]), so.index_to_disp(same_cv))
+
+
 # ------------------------------------------------------------------------------------------------ randomised sweep
 def test_random_configurations_against_oracle():
     """Seeded random shapes / windows / ranges / margins / penalties through the fused pipeline and the per-function

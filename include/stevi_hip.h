@@ -128,6 +128,12 @@ const char *svh_last_error(const svh_context *ctx);
  * operations (the per-disparity step is non-decreasing in the cost, so a region's minimum over d is the step of the region's minimum).
  * Needs magnitudes that cannot overflow along a line: the probe checks |c| <= 1e30 on the device and otherwise lets the sweeps of the
  * volume run (a finite |Pout| > 1e30 sends the call there directly).  0: one sweep of the volume per pass (rounds 1-3).  Same bits.
+ * "sgm_score_finish_fused" (default 1): svh_stereo_match with a Score-strategy function and 8-direction SGM in the banded form below
+ * lets the launch that writes a pixel's FINAL aggregated costs emit its winner -- index, disparity, the three truncatedCostVolume<Same>
+ * taps for the refinement: DownLeft2UpRight for the pixels it visits (row + column < rows), the downward sweep for the others (the order
+ * of the passes is fixed by sgm.h:379-389) -- instead of reading S back in extract_index / truncated_cost_volume; and when the caller did
+ * not ask for sgm_cv, only the costs a later pass reads are stored at all.  0: the separate kernels.  Same maps bit for bit
+ * (tests/test_gpu_sgm_score_fused.py).
  * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
  * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  1: one sweep of the volume, a launch per band of 16
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23

@@ -148,9 +148,67 @@ __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, 
     }
 }
 
+// The same statistics of a grey image without zero-mean, from COLUMN SUMS shared by the windows that contain the column (the form
+// cost_volume_colsum_kernel uses for the costs themselves): the sum of squares (norm, SSD's zero-target cost) and the zero-target term
+// (DOT: sum of x * 0, which is 0 or NaN; SAD: sum of |x|) of the 2 v_r + 1 samples of a column are computed once per row and column,
+// and a window adds the 2 h_r + 1 column sums it covers: 2 (v + h) additions per pixel instead of 2 v h.  The terms are the reference's;
+// their ORDER is by column, not by row, so a norm may differ from the literal walk in its last bits -- as the costs of the column-sum
+// kernel that consume it already do (both stay inside the 1e-4 the float cost volumes are held to; tests/test_gpu_parity.py).  The
+// literal kernel above stays for the zero-mean functions (their terms are not separable), multi-channel images, and behind the
+// "cost_volume_colsum" = 0 option.
+template <int CMP>
+__global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a, bool normalized, float *__restrict__ norm, float *__restrict__ zcost) {
+    __shared__ float colA[WS_TP + 2 * 255], colZ[WS_TP + 2 * 255];
+    const int h = 2 * a.h_r + 1, v = 2 * a.v_r + 1;
+    const int i = blockIdx.y, j0 = blockIdx.x * WS_TP;
+    for (int e = threadIdx.x; e < WS_TP + h - 1; e += WS_TP) {
+        const int jj = j0 - a.h_r + e;
+        float A = 0.0f, Z = 0.0f;
+        if (jj >= 0 && jj < a.W) {
+            for (int k = 0; k < v; k++) {
+                const int ii = i - a.v_r + k;
+                const float x = (ii >= 0 && ii < a.H) ? a.img[(int64_t)ii * a.W + jj] : 0.0f;
+                A += x * x;
+                if (CMP == CMP_DOT) Z += x * 0.0f;
+                else if (CMP == CMP_SAD) Z += fabsf(x);
+            }
+        }
+        colA[e] = A;
+        colZ[e] = Z;
+    }
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= a.W) return;
+    const int64_t p = (int64_t)i * a.W + j;
+    float A = 0.0f, Z = 0.0f;
+    for (int l = 0; l < h; l++) {
+        A += colA[threadIdx.x + l];
+        Z += colZ[threadIdx.x + l];
+    }
+    float n = 1.0f;
+    if (normalized) {
+        n = sqrtf(A);
+        norm[p] = n;
+    }
+    if (zcost) {
+        // the literal loop's sum of ((x / n) * 0) [DOT], x * x [SSD], |x| [SAD] over the window (zero-mean off; only DOT is ever normalised)
+        float z = CMP == CMP_SSD ? A : Z;
+        if (CMP == CMP_DOT && normalized && n == 0.0f) z = __uint_as_float(0x7FC00000u); // 0 / 0 (or underflowed squares: x / 0 = inf, inf * 0)
+        zcost[p] = z;
+    }
+}
+
 // image statistics: the LDS-tiled kernel when the tile fits, the per-lane global walk otherwise; cmp only matters for zcost
-inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm, float *mean, float *norm, float *zcost, int cmp) {
+inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm, float *mean, float *norm, float *zcost, int cmp, bool colsum = false) {
     if ((int64_t)a.H * a.W == 0 || (!zm && !nrm && !zcost)) return SVH_OK;
+    if (colsum && !zm && a.C == 1 && a.h_r <= 255 && !(nrm && cmp != CMP_DOT)) {
+        dim3 grid(ceil_div(a.W, WS_TP), a.H);
+        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SSD>, grid, WS_TP, 0, a, nrm, norm, zcost);
+        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SAD>, grid, WS_TP, 0, a, nrm, norm, zcost);
+        else SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_DOT>, grid, WS_TP, 0, a, nrm, norm, zcost);
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
     const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
     if (shmem <= 60 * 1024) {
         dim3 grid(ceil_div(a.W, WS_TP), a.H);

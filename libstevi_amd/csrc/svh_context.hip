@@ -431,6 +431,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->sgm_cost_two_minima = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "sgm_score_finish_fused") == 0) {
+        ctx->sgm_score_finish_fused = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "sgm_score_fused") == 0) {
         if (value != 0 && value != 1 && value != 3)
             return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows), 3 (bands, 16-column strips forced)");

@@ -498,8 +498,10 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
         // means / norms follow the reference literally (channelsMean, channelsNorm, channelsZeroMeanNorm); zc = cost of the source
         // window against the all-zero target vector
         const int cmpk = cmp == T_DOT ? CMP_DOT : cmp == T_SSD ? CMP_SSD : CMP_SAD;
-        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, 1, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk));
-        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, 1, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk));
+        // (without zero-mean the terms are separable: column sums shared between windows, like the cost kernel that reads these maps)
+        const bool sep = ctx->cost_volume_colsum;
+        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, 1, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk, sep));
+        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, 1, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk, sep));
         st.ready = true;
     }
     float *ms = st.ms, *mt = st.mt, *ns = st.ns, *nt = st.nt, *zc = st.zc;

@@ -54,6 +54,7 @@ struct svh_context {
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
+    bool sgm_score_finish_fused = true; // svh_context_set_option("sgm_score_finish_fused"): svh_stereo_match lets the Score branch's last writer of each pixel emit its winner / taps (0: extract_index + truncatedCostVolume read S back)
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
@@ -285,11 +286,26 @@ struct WinnerOut {
 };
 // Cost branch on either source; out_sgm (H, W, D) optional
 int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &src, float *out_sgm, const WinnerOut &win);
-int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook = false);
+// Score branch.  finish (optional): every pixel's winner record -- (the three truncatedCostVolume<Same> taps around the winner, the
+// winner's index as bits): wave_emit_record in svh_sgm_lines.h -- written by whichever launch writes the pixel's FINAL aggregated costs:
+// DownLeft2UpRight for the pixels it visits (i + j < H), the downward sweep for the rest (sgm.h:379-389 fixes the order of the passes; the
+// sweep writes a record for every pixel and the later pass overwrites its own), so that nothing reads S back.  finish->done says whether
+// that happened (whole image, 8 directions, P2 >= P1 >= 0, vector form: otherwise the caller runs the winner kernels as before).
+// finish->store_all == false: out_sgm is scratch, only the costs a later pass reads are stored (the pixels DownLeft2UpRight visits).
+struct ScoreFinish {
+    float *records = nullptr; // (H, W, 4) floats
+    int taps_h_r = 0, taps_v_r = 0;
+    bool store_all = true;
+    bool done = false;
+};
+// records -> index / disparity / refined maps (any of them may be null; refine_kernel < 0: no refinement)
+int dev_finish_records(svh_context *ctx, const float *records, int64_t npx, int refine_kernel, int disp_sign, int disp_offset, int32_t *idx,
+                       int32_t *disp, float *refined);
+int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook = false, ScoreFinish *finish = nullptr);
 // Score branch, whole image, 8 directions, P2 >= P1 >= 0: the four downward passes as one sweep (svh_sgm_sweep.hip; form = the
 // "sgm_score_fused" option); *ran = false when the geometry is outside what the sweep covers.  The line kernel for one pass.
-int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran);
-int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta);
+int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran, ScoreFinish *finish = nullptr);
+int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta, const ScoreFinish *finish = nullptr);
 // census specialisation of the Cost branch (svh_census_sgm.hip)
 bool census_lane_kernels_available(int nWw, int D);
 bool census_exact_regime(const SgmArgs &a, int nWw);

@@ -96,6 +96,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
     if (need_idx && !d_idx) return SVH_ERR_OUT_OF_MEMORY;
     const int disp_sign = r2l ? 1 : -1;
     const int disp_offset = disp_sign * (prm->disp_lower + sb); // selectedIndexToDisp(idx, first searched offset); shards report global indices
+    bool disp_written = false, refined_written = false; // (from the winner records of the Score branch's fused finish)
     WinnerOut win;
     win.idx = d_idx;
     win.disp = (disp && cost_fused) ? (int32_t *)o_disp.dptr : nullptr;
@@ -150,18 +151,39 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, win));
         } else {
             const float *d_final = d_cv;
+            bool winner_done = false;
             if (sgm) {
-                SVH_TRY(dev_sgm_score_branch(ctx, scr, sa, d_cv, d_s));
+                // the winner (index, disparity, refinement taps) rides on the launches that write a pixel's final aggregated costs where the
+                // Score branch can do that; the volume itself is only stored in full when the caller asked for it
+                ScoreFinish fin;
+                const bool try_fused = ctx->sgm_score_finish_fused && (need_idx || disp) && !keys;
+                if (try_fused) {
+                    fin.records = scr.get_n<float>((size_t)npx * 4);
+                    if (!fin.records) return SVH_ERR_OUT_OF_MEMORY;
+                }
+                fin.taps_h_r = prm->refine_h_radius;
+                fin.taps_v_r = prm->refine_v_radius;
+                fin.store_all = sgm_cv != nullptr;
+                SVH_TRY(dev_sgm_score_branch(ctx, scr, sa, d_cv, d_s, false, try_fused ? &fin : nullptr));
+                winner_done = try_fused && fin.done;
+                if (winner_done) {
+                    SVH_TRY(dev_finish_records(ctx, fin.records, npx, want_refine ? prm->refine_kernel : -1, disp_sign, disp_offset, nullptr,
+                                               disp ? (int32_t *)o_disp.dptr : nullptr, want_refine ? (float *)o_ref.dptr : nullptr));
+                    disp_written = disp != nullptr;
+                    refined_written = want_refine;
+                }
                 d_final = d_s;
             }
-            if (need_idx || keys) SVH_TRY(dev_extract_index(ctx, strategy, d_final, npx, D, d_idx, d_keys, sb, Dtot));
-            if (want_refine)
-                SVH_TRY(dev_truncated_cv(ctx, SVH_TCV_SAME, prm->disp_direction, d_final, d_idx, H, Ws, D, prm->refine_h_radius,
-                                         prm->refine_v_radius, 1, d_taps));
+            if (!winner_done) {
+                if (need_idx || keys) SVH_TRY(dev_extract_index(ctx, strategy, d_final, npx, D, d_idx, d_keys, sb, Dtot));
+                if (want_refine)
+                    SVH_TRY(dev_truncated_cv(ctx, SVH_TCV_SAME, prm->disp_direction, d_final, d_idx, H, Ws, D, prm->refine_h_radius,
+                                             prm->refine_v_radius, 1, d_taps));
+            }
         }
     }
-    if (want_refine) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));
-    if (disp && !cost_fused) SVH_TRY(dev_index_to_disp(ctx, prm->disp_direction, d_idx, npx, disp_offset, (int32_t *)o_disp.dptr));
+    if (want_refine && !refined_written) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));
+    if (disp && !cost_fused && !disp_written) SVH_TRY(dev_index_to_disp(ctx, prm->disp_direction, d_idx, npx, disp_offset, (int32_t *)o_disp.dptr));
 
     if (disp) SVH_TRY(finish_out(ctx, o_disp));
     if (refined) SVH_TRY(finish_out(ctx, o_ref));

@@ -192,6 +192,18 @@ __global__ void refine_kernel(int kernel, const float *__restrict__ tcv, const i
     }
 }
 
+// winner records of the Score branch's fused finish (wave_emit_record, svh_sgm_lines.h) -> selectedIndexToDisp / refineDispCostInterpolation
+__global__ void finish_records_kernel(const float4 *__restrict__ rec, int64_t n, int kernel, int sign, int offset, int32_t *__restrict__ idx,
+                                      int32_t *__restrict__ disp, float *__restrict__ refined) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const float4 r = rec[p];
+        const int sel = __float_as_int(r.w);
+        if (idx) idx[p] = sel;
+        if (disp) disp[p] = sign * sel + offset;
+        if (refined) refined[p] = (float)sel + refine_triplet(kernel, r.x, r.y, r.z);
+    }
+}
+
 // flat index over (D1, D2) -> (d1, d2): the row-major '<=' scan of extractSelected2dIndex (correlation_base.h:466-509) is the
 // 1-D scan over the flattened axis
 __global__ void split_index_kernel(const int32_t *__restrict__ flat, int64_t n, int D2, int32_t *__restrict__ out2) {
@@ -369,6 +381,15 @@ int dev_truncated_cv(svh_context *ctx, int sdir, int ddir, const float *cv, cons
     if (n == 0) return SVH_OK;
     SVH_LAUNCH(ctx, "truncated_cost_volume", truncated_cv_kernel, grid_for(n, 256, 16384), 256, 0, sdir, ddir, cv, idx, H, W, D, h_r, v_r,
                r, tcv);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+int dev_finish_records(svh_context *ctx, const float *records, int64_t npx, int refine_kernel, int disp_sign, int disp_offset, int32_t *idx,
+                       int32_t *disp, float *refined) {
+    if (npx == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "finish_records", finish_records_kernel, grid_for(npx, 256, 8192), 256, 0, reinterpret_cast<const float4 *>(records), npx, refine_kernel,
+               disp_sign, disp_offset, idx, disp, refine_kernel >= 0 ? refined : nullptr);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

@@ -545,9 +545,11 @@ __global__ void gmap_from_minima_kernel(const float2 *__restrict__ minima, int64
 // VEC: 16-byte aligned volumes and D = 64 R exactly: every load and store of the main loop is one unconditional vector access, so
 // the compiler's count of outstanding memory operations is exact and consuming a batch does not wait for the loads of the next one
 // (with the generic form's conditional accesses every step ended in s_waitcnt vmcnt(0): the two batches never overlapped).
-template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false, bool VEC = false>
+// FIN (with VEC, FAR_IS_GLOBAL, not NEG / DELTA / FIRST): this pass is the last one to touch the pixels it visits; it writes their
+// winner records (fin.records) and stores the aggregated costs only when somebody wants the volume (fin.store_all).
+template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false, bool VEC = false, bool FIN = false>
 __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
-                                                            int D, int W, float P1, float P2, float Pout, bool vec) {
+                                                            int D, int W, float P1, float P2, float Pout, bool vec, ScoreFinish fin) {
     const int lane = threadIdx.x & 63;
     const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (l >= ls.n_lines) return;
@@ -569,7 +571,8 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
                     outv[k] = DELTA ? act[k] - c_in[k] : base + (act[k] - c_in[k]); // :298-300
                     prev[k] = act[k];
                 }
-                lds_put<R>(sgm + ((int64_t)ii * W + jj) * D + lane * R, outv);
+                if constexpr (FIN) wave_emit_record<false, R>(outv, lane, ii, jj, ls.Hp, W, fin.records, fin.taps_h_r, fin.taps_v_r); // (whole image: ls.Hp = H)
+                if (!FIN || fin.store_all) lds_put<R>(sgm + ((int64_t)ii * W + jj) * D + lane * R, outv);
                 return;
             }
             float c[R];
@@ -847,7 +850,7 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
 }
 
 template <int R>
-static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool textbook = false) {
+static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool textbook = false, ScoreFinish *finish = nullptr) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = textbook ? (a.n_dir >= 8 ? 8 : 4) : (a.n_dir >= 8 ? 6 : 2);
     const int pass0 = textbook ? 6 : 0;
@@ -864,7 +867,7 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
     if (Hp <= 0 || Wp <= 0) return SVH_OK;
     if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) { // svh_sgm_sweep.hip: the four downward passes in one sweep
         bool ran = false;
-        SVH_TRY(dev_sgm_score_sweep(ctx, scr, a, cv, sgm, vec, ctx->sgm_score_fused, &ran));
+        SVH_TRY(dev_sgm_score_sweep(ctx, scr, a, cv, sgm, vec, ctx->sgm_score_fused, &ran, finish));
         if (ran) return SVH_OK;
     }
     for (int q = 0; q < n_pass; q++) {
@@ -873,7 +876,7 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
         const bool first = q == 0 && whole;
 #define SVH_SCORE(FIRSTV, FARV, NEGV)                                                                                                    \
     SVH_LAUNCH(ctx, NEGV ? "sgm_textbook_pass" : "sgm_score_pass", (sgm_score_pass_kernel<R, B, FIRSTV, FARV, NEGV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, \
-               a.P1, a.P2, a.Pout, vec)
+               a.P1, a.P2, a.Pout, vec, ScoreFinish{})
         if (neg) {
             if (far_global) {
                 if (first) SVH_SCORE(true, true, true); else SVH_SCORE(false, true, true);
@@ -883,10 +886,10 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
         } else if (far_global && vec && a.D == 64 * R) { // the usual case: exact prefetch form
             if (first)
                 SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, true, true, false, false, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2,
-                           a.Pout, vec);
+                           a.Pout, vec, ScoreFinish{});
             else
                 SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, false, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2,
-                           a.Pout, vec);
+                           a.Pout, vec, ScoreFinish{});
         } else if (far_global) {
             if (first) SVH_SCORE(true, true, false); else SVH_SCORE(false, true, false);
         } else {
@@ -900,7 +903,7 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
 
 // one pass of the whole-image 8-direction aggregation with P2 >= P1 >= 0 (what the fused sweeps leave to the line kernels):
 // delta: write the pass's contribution instead of adding it to sgm
-template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta) {
+template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta, const ScoreFinish *finish) {
     // pixels per register batch (two batches: one in flight, one being walked).  Twice and four times as many measured the same at C4
     // (Left2Right + DownLeft2UpRight 5.57 / 5.57 / 5.60 ms): the passes are not waiting for their loads
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
@@ -908,38 +911,44 @@ template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, 
     LineSet ls{pass, pass_lines(pass, a.H, a.W), 0, 0, a.H, a.W};
     if (ls.n_lines <= 0) return SVH_OK;
     const int grid = ceil_div(ls.n_lines, 4);
-#define SVH_LINE(DELTAV, VECV) \
-    SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, DELTAV, VECV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout, vec)
+    const ScoreFinish none{};
+#define SVH_LINE(DELTAV, VECV, FINV) \
+    SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, DELTAV, VECV, FINV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout, vec, \
+               FINV ? *finish : none)
     if (vec && a.D == 64 * R) {
-        if (delta) SVH_LINE(true, true); else SVH_LINE(false, true);
+        if (finish && !delta) SVH_LINE(false, true, true);
+        else if (delta) SVH_LINE(true, true, false);
+        else SVH_LINE(false, true, false);
     } else {
-        if (delta) SVH_LINE(true, false); else SVH_LINE(false, false);
+        if (finish) return fail(ctx, SVH_ERR_HIP, "internal: fused winner asked of the generic line pass");
+        if (delta) SVH_LINE(true, false, false); else SVH_LINE(false, false, false);
     }
 #undef SVH_LINE
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
 
-int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta) {
+int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta, const ScoreFinish *finish) {
     switch (pick_R(a.D)) {
-    case 1: return score_line_pass<1>(ctx, a, cv, sgm, pass, delta);
-    case 2: return score_line_pass<2>(ctx, a, cv, sgm, pass, delta);
-    case 4: return score_line_pass<4>(ctx, a, cv, sgm, pass, delta);
-    case 8: return score_line_pass<8>(ctx, a, cv, sgm, pass, delta);
-    case 16: return score_line_pass<16>(ctx, a, cv, sgm, pass, delta);
-    default: return score_line_pass<32>(ctx, a, cv, sgm, pass, delta);
+    case 1: return score_line_pass<1>(ctx, a, cv, sgm, pass, delta, finish);
+    case 2: return score_line_pass<2>(ctx, a, cv, sgm, pass, delta, finish);
+    case 4: return score_line_pass<4>(ctx, a, cv, sgm, pass, delta, finish);
+    case 8: return score_line_pass<8>(ctx, a, cv, sgm, pass, delta, finish);
+    case 16: return score_line_pass<16>(ctx, a, cv, sgm, pass, delta, finish);
+    default: return score_line_pass<32>(ctx, a, cv, sgm, pass, delta, finish);
     }
 }
 
-int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook) {
+int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish) {
+    if (finish) finish->done = false;
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
     switch (pick_R(a.D)) {
-    case 1: return run_score_branch<1>(ctx, scr, a, cv, out_sgm, textbook);
-    case 2: return run_score_branch<2>(ctx, scr, a, cv, out_sgm, textbook);
-    case 4: return run_score_branch<4>(ctx, scr, a, cv, out_sgm, textbook);
-    case 8: return run_score_branch<8>(ctx, scr, a, cv, out_sgm, textbook);
-    case 16: return run_score_branch<16>(ctx, scr, a, cv, out_sgm, textbook);
-    case 32: return run_score_branch<32>(ctx, scr, a, cv, out_sgm, textbook); // (up to 2048 disparities: 32 per lane)
+    case 1: return run_score_branch<1>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 2: return run_score_branch<2>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 4: return run_score_branch<4>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 8: return run_score_branch<8>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 16: return run_score_branch<16>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 32: return run_score_branch<32>(ctx, scr, a, cv, out_sgm, textbook, finish); // (up to 2048 disparities: 32 per lane)
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 2048 disparities (got %d)", a.D);
     }
 }

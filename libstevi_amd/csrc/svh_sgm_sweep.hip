@@ -78,10 +78,13 @@ __device__ __forceinline__ void score_step3_far_global(const float (&prev)[3][R]
 // written: 3 x W vectors of D floats each), the launch boundary is the only synchronisation.  Per band and block this costs
 // (KB - 1) KB / 2 extra single-pass pixels on either side against 3 WB KB pass-pixels of its own (+ 31 % at WB = KB = 16) and the
 // carried states (+ 10 % of the band's bytes); nothing spins.
-template <int R, int WB, int KB, int NCW, bool VEC>
+// FIN (VEC only): the sweep is the last writer of the pixels DownLeft2UpRight does not visit (i + j >= H).  It writes a winner record
+// for EVERY pixel (unconditionally: the later pass overwrites the records of the pixels it visits) and, when nobody wants the volume
+// (fin.store_all false), stores the aggregated costs only where that pass will read them.
+template <int R, int WB, int KB, int NCW, bool VEC, bool FIN = false>
 __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *__restrict__ cv, float *sgm, int H, int W, int D, float P1, float P2,
                                                                   float Pout, int r0, int rows, const float *__restrict__ st_in,
-                                                                  float *__restrict__ st_out) {
+                                                                  float *__restrict__ st_out, ScoreFinish fin) {
     constexpr int DP = 64 * R, CPW = WB / NCW, NL = WB + KB - 1, NH = 2 * (KB - 1), HS = (NH + NCW - 1) / NCW;
     constexpr int NB = R <= 4 ? 3 : 2; // register sets of the row prefetch (4: no faster)
     static_assert(WB % NCW == 0, "cells of a row are dealt evenly to the waves");
@@ -188,7 +191,10 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
                     outv[k] = visA ? S4 : S;
                 }
                 float *o = sgm + ((int64_t)i * W + j) * D + lane * R;
-                if constexpr (VEC) lds_put<R>(o, outv);
+                if constexpr (FIN) {
+                    wave_emit_record<false, R>(outv, lane, i, j, H, W, fin.records, fin.taps_h_r, fin.taps_v_r);
+                    if (fin.store_all || i + j < H) lds_put<R>(o, outv); // (wave-uniform) DownLeft2UpRight visits i + j < H
+                } else if constexpr (VEC) lds_put<R>(o, outv);
                 else {
 #pragma unroll
                     for (int k = 0; k < R; k++)
@@ -246,7 +252,7 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
 
 // The same three stages with the downward sweep as one launch per band of KB rows (sgm_score_band_kernel).
 template <int R, int KB, int WB>
-static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, bool *ran) {
+static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, bool *ran, ScoreFinish *finish) {
     *ran = false;
     if constexpr (R > 8) return SVH_OK;
     else {
@@ -256,6 +262,8 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
         if (!__atomic_load_n(&attr_set[ctx->device & 63], __ATOMIC_ACQUIRE)) {
             SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, true, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, false>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             __atomic_store_n(&attr_set[ctx->device & 63], 1, __ATOMIC_RELEASE);
@@ -263,28 +271,35 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
         const size_t state_floats = (size_t)3 * a.W * DP;
         float *st[2] = {scr.get_n<float>(state_floats), scr.get_n<float>(state_floats)};
         if (!st[0] || !st[1]) return SVH_ERR_OUT_OF_MEMORY;
+        // the winner rides on the last writer of every pixel: the vector form only, and not for cross-shard keys
+        const bool fused_finish = finish && finish->records && vec && a.D == DP && (int64_t)a.H * a.W < (1ll << 29);
+        const ScoreFinish none{};
         SVH_TRY(dev_sgm_score_line_pass(ctx, a, cv, sgm, 1, true)); // Left2Right: its contribution alone
         const int strips = ceil_div(a.W, WB);
         {
             ProfScope prof(ctx, "sgm_score_bands"); // (one bracket around all the band launches)
             for (int r0 = 0, b = 0; r0 < a.H; r0 += KB, b++) {
                 const int rows = std::min(KB, a.H - r0);
-                if (vec && a.D == DP)
+                if (fused_finish)
+                    hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, true, true>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D, a.P1,
+                                       a.P2, a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1], *finish);
+                else if (vec && a.D == DP)
                     hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, true>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D, a.P1, a.P2,
-                                       a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1]);
+                                       a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1], none);
                 else
                     hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, false>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D, a.P1, a.P2,
-                                       a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1]);
+                                       a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1], none);
             }
         }
         SVH_CHECK_LAUNCH(ctx);
-        SVH_TRY(dev_sgm_score_line_pass(ctx, a, cv, sgm, 5, false)); // DownLeft2UpRight: read-modify-write
+        SVH_TRY(dev_sgm_score_line_pass(ctx, a, cv, sgm, 5, false, fused_finish ? finish : nullptr)); // DownLeft2UpRight: read-modify-write
+        if (fused_finish) finish->done = true;
         *ran = true;
         return SVH_OK;
     }
 }
 
-int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran) {
+int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran, ScoreFinish *finish) {
     *ran = false;
     const auto run = [&](auto r_tag) -> int {
         constexpr int R = decltype(r_tag)::value;
@@ -292,8 +307,8 @@ int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
         // without a strip (1080p: 8 / 16 / 32 rows per band 2.56 / 2.78 / 4.05 ms)
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        if (form != 3 && ceil_div(a.W, 16) * 4 < cus * 3) return run_score_branch_bands<R, 8, 8>(ctx, scr, a, cv, sgm, vec, ran);
-        return run_score_branch_bands<R, 16, 16>(ctx, scr, a, cv, sgm, vec, ran);
+        if (form != 3 && ceil_div(a.W, 16) * 4 < cus * 3) return run_score_branch_bands<R, 8, 8>(ctx, scr, a, cv, sgm, vec, ran, finish);
+        return run_score_branch_bands<R, 16, 16>(ctx, scr, a, cv, sgm, vec, ran, finish);
     };
     switch (pick_R(a.D)) {
     case 1: return run(std::integral_constant<int, 1>{});

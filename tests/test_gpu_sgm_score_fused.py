@@ -106,3 +106,94 @@ def test_fused_forms_on_random_geometries(seed):
                 assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32)), what
         finally:
             sv.set_option(d, "sgm_score_fused", 1)
+
+
+# ---- the winner riding on the last writer of each pixel (svh_stereo_match, option "sgm_score_finish_fused") -------------------------------
+@pytest.mark.parametrize("shape_d", [((40, 150), 64), ((150, 40), 64), ((33, 200), 128), ((70, 90), 256), ((9, 300), 64), ((64, 64), 64), ((1, 80), 64),
+                                     ((45, 97), 40)])
+@pytest.mark.parametrize("func_name", ["NCC", "ZNCC", "CC"])
+def test_winner_emitted_by_the_last_writer(rng, shape_d, func_name):
+    """svh_stereo_match with a Score-strategy function + SGM-8: the index, the disparity and the three truncatedCostVolume<Same> taps of a
+    pixel are emitted by the launch that writes its final aggregated costs (DownLeft2UpRight where i + j < H, the downward sweep
+    elsewhere) instead of reading S back; without a request for S only the costs a later pass needs are stored.  Must equal the
+    separate extract_index / truncatedCostVolume kernels bit for bit (disparity map, refined map incl. its NaN mask), with and without
+    the volume requested, every kernel -- and the oracle run on the library's own cost volume.  (D = 40: not the vector form, the fused
+    finish declines and the old path runs.)"""
+    from helpers import parallax_pair
+    (H, W), D = shape_d
+    MF = sv.matchingFunctions
+    func = getattr(MF, func_name)
+    src, tgt, _ = parallax_pair(H, W, max(2, min(H, W) // 4), H // 4, W // 4, 2, 9, seed=H * 1000 + W + D)
+    src, tgt = src[:H, :W].copy(), tgt[:H, :W].copy()
+    l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
+    hr = 2
+
+    def run(fused, kernel, want_sgm_cv):
+        sv.set_option(l, "sgm_score_finish_fused", fused)
+        try:
+            sv.profile_reset(l)
+            sv.profile_enable(l, True)
+            out = sv.stereoMatch(func, l, r, hr, hr, D, sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=kernel, refine_h_radius=hr,
+                                 refine_v_radius=hr, want_sgm_cv=want_sgm_cv, want_cv=True)
+            sv.profile_enable(l, False)
+            return out, sv.profile_collect(l)
+        finally:
+            sv.set_option(l, "sgm_score_finish_fused", 1)
+
+    for kernel in (sv.InterpolationKernel.Parabola, sv.InterpolationKernel.Equiangular, None):
+        for want_sgm_cv in (False, True):
+            a, ka = run(1, kernel, want_sgm_cv)
+            b, kb = run(0, kernel, want_sgm_cv)
+            assert "extract_index" in kb
+            if D % 64 == 0 and H * W > 0:
+                assert "extract_index" not in ka and "truncated_cost_volume" not in ka and "index_to_disp" not in ka, ka.keys()
+            assert torch.equal(a["disp"], b["disp"])
+            if kernel is not None:
+                ra, rb = a["refined"].cpu().numpy(), b["refined"].cpu().numpy()
+                assert np.array_equal(np.isnan(ra), np.isnan(rb))
+                assert np.array_equal(bits(ra[~np.isnan(ra)]), bits(rb[~np.isnan(rb)]))
+            if want_sgm_cv:
+                assert np.array_equal(bits(a["sgm_cv"]), bits(b["sgm_cv"]))
+    # against the oracle, on the cost volume the library made (the column-sum kernel agrees with the oracle's to 1e-4, not to the bit)
+    cvh = a["cv"].cpu().numpy()
+    svol = so.sgm(cvh, 8, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    idx = so.extract_index(svol, so.SCORE)
+    assert np.array_equal(a["disp"].cpu().numpy(), so.index_to_disp(idx))
+    out, _ = run(1, sv.InterpolationKernel.Parabola, False)
+    exp = so.refine_disp(so.truncated_cost_volume(svol, idx, hr, hr, 1), idx, so.PARABOLA)
+    got = out["refined"].cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.max(np.abs(got[ok] - exp[ok]), initial=0.0) <= 1e-4
+
+
+def test_winner_emitted_by_the_last_writer_ties_and_nan(rng):
+    """Few cost levels (ties everywhere: the larger index must win), NaN voxels (never win unless at index 0), whole NaN pixels: the fused
+    finish against the separate kernels on the same call, through CC on crafted images is not possible -- so the Score branch is fed a
+    crafted VOLUME through sgmCostVolume + extractSelectedIndex and compared with the fused pipeline's selection rule in isolation:
+    wave_select_index is also what sgm_cost... no: this test drives the rule through stereoMatch on constant images (all costs equal)."""
+    MF = sv.matchingFunctions
+    H, W, D = 48, 130, 64
+    img = np.full((H, W), 0.5, np.float32)
+    l = torch.from_numpy(img).to(DEV)
+    for fused in (1, 0):
+        sv.set_option(l, "sgm_score_finish_fused", fused)
+        try:
+            out = sv.stereoMatch(MF.CC, l, l, 1, 1, D, sgmDirections=8, P1=0.0, P2=0.0, Pout=0.0)
+        finally:
+            sv.set_option(l, "sgm_score_finish_fused", 1)
+        cv = so.unfold_cost_volume(so.CC, img, img, 1, 1, D)
+        exp = so.index_to_disp(so.extract_index(so.sgm(cv, 8, so.SCORE, 0.0, 0.0, (0, 0, 0, 0), 0.0), so.SCORE))
+        assert np.array_equal(out["disp"].cpu().numpy(), exp), fused
+    # NCC of an all-zero image: every cost NaN (0 / 0): index 0 everywhere, refined NaN or 0 as the separate kernels say
+    z = torch.zeros((H, W), device=DEV)
+    outs = []
+    for fused in (1, 0):
+        sv.set_option(z, "sgm_score_finish_fused", fused)
+        try:
+            outs.append(sv.stereoMatch(MF.NCC, z, z, 1, 1, D, sgmDirections=8, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=1, refine_v_radius=1))
+        finally:
+            sv.set_option(z, "sgm_score_finish_fused", 1)
+    assert torch.equal(outs[0]["disp"], outs[1]["disp"]) and int(outs[0]["disp"].abs().sum()) == 0
+    ra, rb = outs[0]["refined"].cpu().numpy(), outs[1]["refined"].cpu().numpy()
+    assert np.array_equal(np.isnan(ra), np.isnan(rb)) and np.array_equal(ra[~np.isnan(ra)], rb[~np.isnan(rb)])

@@ -232,44 +232,67 @@ template <int R> __device__ __forceinline__ float wave_value_at(const float (&s)
 // kernel's count of memory operations in flight stays exact and its prefetch keeps running (conditional accesses end in
 // s_waitcnt vmcnt(0): DESIGN.md 4.2a).  D = 64 R (the vector form).  finish_records_kernel (svh_select_refine.hip) turns records into
 // index / disparity / refined maps.
+// Instruction budget: the host kernels are bound by instruction issue.  The wave extremum runs as hand-written DPP steps (one
+// instruction per step: the compiler's form is v_mov, v_mov_dpp, a canonicalising v_max and the v_max); NaN never enters it (v_max /
+// v_min return the other operand), a lane finds the largest k whose value EQUALS the extremum (a NaN equals nothing; +-inf do), the
+// highest such lane holds the winner, and every lane builds the record of ITS OWN candidate from its registers and its two
+// neighbours' edge values (two DPP moves): no cross-lane gather, almost no scalar state.  The record is stored by the winning lane.
 template <bool COST, int R>
 __device__ __forceinline__ void wave_emit_record(const float (&s)[R], int lane, int i, int j, int H, int W, float *__restrict__ rec, int h_r, int v_r) {
     constexpr int D = 64 * R;
-    float bv = COST ? INFINITY : -INFINITY;
-    int bk = -1;
+    float A = s[0];
 #pragma unroll
-    for (int k = 0; k < R; k++) {
-        const bool take = !isnan(s[k]) && (bk < 0 || (COST ? s[k] <= bv : s[k] >= bv));
-        bv = take ? s[k] : bv;
-        bk = take ? k : bk;
+    for (int k = 1; k < R; k++) A = COST ? fminf(A, s[k]) : fmaxf(A, s[k]);
+    if constexpr (COST) {
+#define SVH_EXT_DPP(CTRL) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL : "+v"(A))
+        SVH_EXT_DPP("row_shr:1 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_shr:2 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_shr:4 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_shr:8 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+        SVH_EXT_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef SVH_EXT_DPP
+    } else {
+#define SVH_EXT_DPP(CTRL) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL : "+v"(A))
+        SVH_EXT_DPP("row_shr:1 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_shr:2 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_shr:4 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_shr:8 row_mask:0xf bank_mask:0xf");
+        SVH_EXT_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+        SVH_EXT_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef SVH_EXT_DPP
     }
-    const float vv = bk >= 0 ? bv : (COST ? INFINITY : -INFINITY);
-    const float M = COST ? wave_min(vv) : wave_max_dpp(vv);
-    const unsigned long long holders = __builtin_amdgcn_ballot_w64(bk >= 0 && bv == M);
+    asm("s_nop 0" : "+v"(A));
+    const float M = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, A), 63)); // NaN iff every value is NaN
+    int kb = -1;
+#pragma unroll
+    for (int k = 0; k < R; k++) kb = (s[k] == M) ? k : kb; // ties: the larger index (correlation_base.h:441-455)
+    const unsigned long long holders = __builtin_amdgcn_ballot_w64(kb >= 0);
     const unsigned long long nan_at_0 = __builtin_amdgcn_ballot_w64(isnan(s[0])); // bit 0: the value at disparity 0
-    const int top = 63 - __builtin_clzll(holders | 1ull);
-    const int kk = __builtin_amdgcn_readlane(bk, top);
-    const int sel = (holders == 0ull || (nan_at_0 & 1ull)) ? 0 : top * R + kk;
-    const bool px_bad = j < h_r || i < v_r || i + v_r >= H;
-    float tv[3];
+    const bool none = holders == 0ull || (nan_at_0 & 1ull);                         // -> index 0
+    const int writer = none ? 0 : 63 - __builtin_clzll(holders | 1ull);
+    const int c = none ? 0 : kb; // (lanes without a candidate build a record nobody stores)
+    const float prevL = lane_shift_up(s[R - 1], 0.0f), prevR = lane_shift_down(s[0], 0.0f);
+    float t0 = s[0], tm1 = prevL, tp1 = R > 1 ? s[R > 1 ? 1 : 0] : prevR;
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const int pd = sel + t - 1;
-        const bool bad = px_bad || pd < 0 || pd >= D || j + pd + h_r >= W;
-        const int pdc = bad ? 0 : pd;
-        const int kt = pdc & (R - 1);
-        float v = s[0];
-#pragma unroll
-        for (int k = 1; k < R; k++) v = (kt == k) ? s[k] : v;
-        const float x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pdc / R));
-        tv[t] = bad ? __uint_as_float(0x7FC00000u) : x;
+    for (int k = 1; k < R; k++) {
+        const bool here = c == k;
+        t0 = here ? s[k] : t0;
+        tm1 = here ? s[k - 1] : tm1;
+        tp1 = here ? (k + 1 < R ? s[k + 1 < R ? k + 1 : k] : prevR) : tp1;
     }
-    const int slot = lane & 3;
-    float out = __int_as_float(sel);
-    out = slot == 0 ? tv[0] : out;
-    out = slot == 1 ? tv[1] : out;
-    out = slot == 2 ? tv[2] : out;
-    rec[(unsigned)(i * W + j) * 4u + (unsigned)slot] = out;
+    // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613): NaN where the pixel's window, or the window of the shifted
+    // disparity, leaves the image, or the disparity its range
+    const bool px_bad = j < h_r || i < v_r || i + v_r >= H;
+    const int limit = px_bad ? -2 : W - h_r - j; // valid: 0 <= pd < D and pd < limit
+    const int d = lane * R + c;
+    const float nan = __uint_as_float(0x7FC00000u);
+    float4 r;
+    r.x = (d == 0 || d - 1 >= limit) ? nan : tm1;
+    r.y = (d >= limit) ? nan : t0;
+    r.z = (d + 1 >= D || d + 1 >= limit) ? nan : tp1;
+    r.w = __int_as_float(d);
+    if (lane == writer) *reinterpret_cast<float4 *>(rec + (unsigned)(i * W + j) * 4u) = r;
 }
 
 // ---- host helpers

@@ -38,7 +38,11 @@ C3 = dict(name="C3", W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.
 C5 = dict(name="C5", W=8192, H=4320, D=512, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=5, bg=32, sq=256, side=1280, v=1280, h=1520)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # MI355X_MICROARCH.md, matrix cores (dense): BF16 ~2.5 PFLOP/s; int8 runs at twice the BF16 rate, block-scaled FP4 at four times
-MFMA_PEAK_TOPS = {"census_sweep_pm": 10000.0}  # (both FP4 kernels launch under this name)
+FP4_PEAK_TOPS = 10000.0
+MFMA_PEAK_TOPS = {"census_sweep_rl": FP4_PEAK_TOPS, "census_sweep_pm": FP4_PEAK_TOPS}  # the two FP4 sweep kernels (library profile labels)
+# library profile label -> the kernel symbol rocprofv3 prints for it (profiles/*_kernel_stats.csv, profiles/traffic.json)
+KERNEL_SYMBOL = {"census_sweep_rl": "census_sweep_rl_kernel", "census_sweep_pm": "census_sweep_pm_kernel", "census_sweep": "census_sweep_kernel",
+                 "census_transform": "census_grey_kernel", "sgm_line_scans": "scan_cols_kernel", "census_finalize": "tile_finalize_kernel"}
 
 
 def algorithmic_bytes(kernel, wl):
@@ -52,6 +56,7 @@ def algorithmic_bytes(kernel, wl):
     table = {
         "census_sweep": 28.0 * vox,
         "census_sweep_pm": 28.0 * vox,
+        "census_sweep_rl": 28.0 * vox,
         "census_transform": (4.0 + 24.0) * px,      # one image: 4 B read + nW = 3 words written and read back
         "sgm_line_scans": (4.0 + 1.6) * px,          # g read + the min_p values on tile edges written (with six maps instead: 4 + 24)
         "sgm_line_carries": 4.0 * px,                # g read (the carries are per line and band: negligible)
@@ -62,12 +67,13 @@ def algorithmic_bytes(kernel, wl):
 
 
 def load_measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections
-    of MI355X_MICROARCH.md) on this workload; the summary is committed under profiles/ by the round that measured it."""
+    """HBM bytes per launch of `kernel` (library profile label) measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE passes, gfx950
+    corrections of MI355X_MICROARCH.md) on this workload; the summary is committed under profiles/ by the round that measured it, keyed by
+    the kernel symbol rocprofv3 prints."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(KERNEL_SYMBOL.get(kernel, kernel), {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -158,11 +164,183 @@ def api_chain(sv, wl, d_tgt, d_src, reps=5):
             "kernel_ms": {k: round(v[0] / reps, 4) for k, v in prof.items()}}, disp
 
 
+def _time_steps(fn, steps, repeats=3):
+    """median over `repeats` regions of `steps` calls, synchronised on both sides; ms per call"""
+    fn()
+    torch.cuda.synchronize()
+    out = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / steps * 1e3)
+    return float(np.median(out)), r
+
+
+def _kernel_ms(sv, probe, fn, steps):
+    sv.profile_reset(probe)
+    sv.profile_enable(probe, True)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    sv.profile_enable(probe, False)
+    return {k: round(v[0] / steps, 4) for k, v in sv.profile_collect(probe).items()}
+
+
+def other_configs(sv, dev, cpu_legs=True):
+    """BASELINE.json's other configurations on ONE GPU, after the timed headline (they are parity-test cases, not the metric): a few steps
+    each, per-kernel times, a roofline on compulsory bytes, and the result checked against the oracle (whole frame where the oracle
+    finishes in seconds, a band of rows otherwise -- the pixels of the band whose SGM lines lie inside it).  Returns (dict, ok)."""
+    import oracle as so
+    from helpers import parallax_pair
+    MF, IK = sv.matchingFunctions, sv.InterpolationKernel
+    out, ok = {}, True
+
+    def hbm(bytes_, ms, model):
+        ach = bytes_ / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "compulsory_bytes": int(bytes_), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "model": model}
+
+    # ---- C1: 480x360, SAD 5x5, D = 64, argmin: the reference's own CPU-runnable case; the oracle runs it in full (SURVEY.md 8d)
+    t0 = time.perf_counter()
+    W, H, D, r = 480, 360, 64, 2
+    src, tgt, _ = parallax_pair(H, W, 120, 120, 120, 4, 24, 1)
+    d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    fn = lambda: sv.stereoMatch(MF.SAD, d_tgt, d_src, r, r, D)  # noqa: E731
+    ms, res = _time_steps(fn, 50)
+    c = {"workload": "480x360 synthetic pair, SAD 5x5 cost volume, D=64, argmin (BASELINE.json configs[0]; stands in for SimStereo)", "ms": round(ms, 4),
+         "Mdisparities_per_s": round(W * H * D / ms / 1e3, 1), "kernel_ms": _kernel_ms(sv, d_src, fn, 20),
+         "roofline": hbm(8.0 * W * H * D + 12.0 * W * H, ms, "C written and read once as float32 (8 B/voxel) + 12 B/pixel")}
+    if cpu_legs:
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            cv = so.unfold_cost_volume(so.SAD, tgt, src, r, r, D)
+            want = so.index_to_disp(so.extract_index(cv, so.COST))
+        dt = (time.perf_counter() - t1) / reps
+        full = sv.stereoMatch(MF.SAD, d_tgt, d_src, r, r, D, want_cv=True)
+        gcv, gdisp = full["cv"].cpu().numpy(), full["disp"].cpu().numpy()
+        own = so.index_to_disp(so.extract_index(gcv, so.COST))
+        c["cpu_baseline"] = {"value": round(W * H * D / dt / 1e6, 1), "unit": "Mdisparities/s", "cores": so.num_threads(), "kind": "port",
+                             "sample": f"the whole frame, {reps} runs: unfoldBasedCostVolume<SAD> -> extractSelectedIndex -> selectedIndexToDisp, {dt * 1e3:.1f} ms each"}
+        c["end_err"] = {"cost_max_rel_err": float(np.max(np.abs(gcv - cv) / np.maximum(1, np.abs(cv)))), "tolerance": 1e-4,
+                        "pixels_differing_from_oracle_map": int(np.count_nonzero(gdisp != want)), "of": int(want.size),
+                        "pixels_differing_on_the_library_s_own_volume": int(np.count_nonzero(gdisp != own)),
+                        "checked_against": "oracle (port), whole frame; float costs agree to 1e-4, so the map is held to the oracle's argmin of the library's own volume (0) "
+                                           "and compared with the oracle's own map for information (near-ties may flip)"}
+        ok &= c["end_err"]["cost_max_rel_err"] <= 1e-4 and c["end_err"]["pixels_differing_on_the_library_s_own_volume"] == 0
+    c["wall_s"] = round(time.perf_counter() - t0, 2)
+    out["C1"] = c
+
+    # ---- C2: 1920x1080, census 9x9 + Hamming cost volume, D = 128 (the volume is the output)
+    t0 = time.perf_counter()
+    W, H, D, r = 1920, 1080, 128, 4
+    src, tgt, _ = parallax_pair(H, W, 320, 320, 380, 8, 64, 2)
+    d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    fn = lambda: sv.unfoldBasedCostVolume(MF.CENSUS, d_tgt, d_src, r, r, D)  # noqa: E731
+    ms, vol = _time_steps(fn, 20)
+    c = {"workload": "1920x1080 synthetic pair, census 9x9 + Hamming cost volume (float32, the API type), D=128 (BASELINE.json configs[1])", "ms": round(ms, 4),
+         "Mdisparities_per_s": round(W * H * D / ms / 1e3, 1), "kernel_ms": _kernel_ms(sv, d_src, fn, 10),
+         "roofline": hbm(4.0 * W * H * D + 56.0 * W * H, ms, "SURVEY.md 8(d) C2: the volume written once as float32 (4 B/voxel) + 56 B/pixel (images, census words)")}
+    if cpu_legs:
+        band = 40
+        cvb = so.unfold_cost_volume(so.CENSUS, tgt[:band], src[:band], r, r, D)
+        c["end_err"] = {"voxels_differing": int(np.count_nonzero(vol[:band - r].cpu().numpy() != cvb[:band - r])), "of": int((band - r) * W * D),
+                        "checked_against": f"oracle (port), top {band - r} rows of the volume, bit for bit"}
+        ok &= c["end_err"]["voxels_differing"] == 0
+    del vol
+    c["wall_s"] = round(time.perf_counter() - t0, 2)
+    out["C2"] = c
+
+    # ---- C4: 4096x2160, NCC 11x11, D = 256, SGM-8 (Score branch), argmax, truncatedCostVolume(S, idx, 5, 5, 1) + parabola (rule E6)
+    t0 = time.perf_counter()
+    W, H, D, r = 4096, 2160, 256, 5
+    src, tgt, _ = parallax_pair(H, W, 640, 640, 760, 16, 128, 4)
+    d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    kw = dict(sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=IK.Parabola, refine_h_radius=r, refine_v_radius=r)
+    fn = lambda: sv.stereoMatch(MF.NCC, d_tgt, d_src, r, r, D, **kw)  # noqa: E731
+    ms, res = _time_steps(fn, 5)
+    vox = W * H * D
+    c = {"workload": "4096x2160 synthetic pair, NCC 11x11 cost volume + 8-path SGM (Score branch) + argmax + parabola sub-pixel refinement, D=256 (BASELINE.json configs[3])",
+         "ms": round(ms, 3), "Mdisparities_per_s": round(vox / ms / 1e3, 1), "kernel_ms": _kernel_ms(sv, d_src, fn, 3),
+         "roofline": hbm((4.0 + 23.2) * vox + 36.0 * W * H, ms,
+                         "C written once (4 B/voxel) + Score-branch SGM in its fused form 23.2 B/voxel (Left2Right: read C, write its contribution = 8; downward sweep: "
+                         "read C and that contribution, write S = 12; DownLeft2UpRight on the 26 % of the pixels it visits: 12 x 0.264) + 36 B/pixel; SURVEY.md 8(d) "
+                         "prices a pass-per-launch design at 68 B/voxel"),
+         "sgm_store": "S is only stored where a later pass reads it (DownLeft2UpRight's 26 %): the winner records ride on the last writer of each pixel"}
+    if cpu_legs:
+        band = 28
+        full = sv.stereoMatch(MF.NCC, d_tgt, d_src, r, r, D, want_cv=True, want_sgm_cv=True, **kw)
+        torch.cuda.synchronize()
+        same_maps = bool(torch.equal(full["disp"], res["disp"])) and bool(torch.equal(torch.nan_to_num(full["refined"], nan=-7.0), torch.nan_to_num(res["refined"], nan=-7.0)))
+        gcv = full["cv"][:band].cpu().numpy()
+        cvb = so.unfold_cost_volume(so.NCC, tgt[:band + r], src[:band + r], r, r, D)[:band]
+        okc = ~np.isnan(cvb)
+        m = band_check_mask(H, W, band)
+        sb = so.sgm(gcv, 8, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+        gs = full["sgm_cv"][:band].cpu().numpy()
+        a, b = gs[m], sb[m]
+        okv = ~np.isnan(b)
+        idx = so.extract_index(gs, so.SCORE)
+        gdisp = res["disp"][:band].cpu().numpy()
+        ref = so.refine_disp(so.truncated_cost_volume(gs, idx, r, r, 1), idx, so.PARABOLA)
+        gref = res["refined"][:band].cpu().numpy()
+        rows = band - r
+        mm = m[:rows]
+        ra, rb = gref[:rows][mm], ref[:rows][mm]
+        okr = ~np.isnan(rb)
+        c["end_err"] = {"band_rows": band, "cost_max_abs_err": float(np.max(np.abs(gcv[okc] - cvb[okc]))), "cost_nan_mask_equal": bool(np.array_equal(np.isnan(gcv), np.isnan(cvb))),
+                        "sgm_voxels_differing": int(np.count_nonzero(a[okv].view(np.uint32) != b[okv].view(np.uint32))) + int(np.count_nonzero(np.isnan(a) != np.isnan(b))),
+                        "disp_pixels_differing": int(np.count_nonzero(gdisp[m] != so.index_to_disp(idx)[m])), "of_pixels": int(m.sum()),
+                        "refined_max_abs_err": float(np.max(np.abs(ra[okr] - rb[okr]))), "refined_nan_mask_equal": bool(np.array_equal(np.isnan(ra), np.isnan(rb))),
+                        "timed_call_equals_the_call_that_also_returned_the_volumes": same_maps, "tolerance": 1e-4,
+                        "checked_against": f"oracle (port), top {band} rows: NCC costs <= 1e-4; Score-branch SGM of the library's own cost band bit for bit on the pixels whose "
+                                           "lines lie inside the band; arg-max map exact; parabola-refined map <= 1e-4 with the same NaN mask"}
+        e = c["end_err"]
+        ok &= (e["cost_max_abs_err"] <= 1e-4 and e["cost_nan_mask_equal"] and e["sgm_voxels_differing"] == 0 and e["disp_pixels_differing"] == 0 and
+               e["refined_max_abs_err"] <= 1e-4 and e["refined_nan_mask_equal"] and same_maps)
+        del full
+    del res
+    torch.cuda.empty_cache()
+    c["wall_s"] = round(time.perf_counter() - t0, 2)
+    out["C4"] = c
+
+    # ---- C5 on ONE GPU: 8192x4320, census 9x9 + SGM-8, D = 512, the whole range (the N > 1 bench shards it)
+    t0 = time.perf_counter()
+    W, H, D, r = 8192, 4320, 512, 4
+    src, tgt, _ = parallax_pair(H, W, 1280, 1280, 1520, 32, 256, 5)
+    d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    fn = lambda: sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0)  # noqa: E731
+    ms, res = _time_steps(fn, 10)
+    vox = W * H * D
+    ops = 128.0 * vox
+    c = {"workload": "8192x4320 synthetic pair, census 9x9 + 8-path SGM, D=512, argmin, the whole disparity range on one GPU (BASELINE.json configs[4] without the sharding)",
+         "ms": round(ms, 4), "Mdisparities_per_s": round(vox / ms / 1e3, 1), "kernel_ms": _kernel_ms(sv, d_src, fn, 5),
+         "sgm_recurrences_timed": True,
+         "roofline": {"bound": "mfma", "algorithmic_ops": int(ops), "achieved": round(ops / (ms * 1e-3) / 1e12, 1), "peak": FP4_PEAK_TOPS, "unit": "TFLOP/s",
+                      "frac": round(ops / (ms * 1e-3) / 1e12 / FP4_PEAK_TOPS, 4),
+                      "model": "128 operations per voxel (64 census bits as a +-1 dot product) on the FP4 matrix cores, whole step; compulsory HBM traffic is 12 B/pixel: "
+                               f"{12.0 * W * H / (ms * 1e-3) / 1e9:.0f} GB/s"}}
+    if cpu_legs:
+        band = 48
+        want, _ = oracle_disparity(dict(h_r=r, v_r=r, D=D, sgm=8, P1=0.001, P2=0.01, Pout=100.0), src, tgt, band + r, variant=1)
+        c["end_px_err"] = end_px_err(res["disp"].cpu().numpy(), want[:band], f"oracle (port), top {band} rows, pixels whose SGM lines lie inside the band",
+                                     band_check_mask(H, W, band))
+        ok &= c["end_px_err"]["pixels_differing"] == 0
+    c["wall_s"] = round(time.perf_counter() - t0, 2)
+    out["C5_one_gpu"] = c
+    return out, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=7, help="the K-step timed region is run this many times (each bracketed by barrier + synchronize, "
+                    "max over ranks); ms_per_step / value are the MEDIAN region, min and max are in the line (K = 20 is a 1.7 ms window)")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the other BASELINE configurations (C1, C2, C4, one-GPU C5) after the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline and end_px_err)")
     ap.add_argument("--no-api-chain", action="store_true", help="skip the per-function (volume-materialising) chain")
     ap.add_argument("--materialize", action="store_true", help="also write the cost volume and the SGM volume (float32) to HBM")
@@ -211,8 +389,10 @@ def main():
     if wl["D"] > wl["W"]:
         raise SystemExit("refusing a disparity range wider than the image")
     # every rank holds the same pair: with N > 1 the ranks cooperate on ONE problem (disparity shards)
+    t_setup = time.perf_counter()
     src, tgt, _ = parallax_pair(wl["H"], wl["W"], wl["side"], wl["v"], wl["h"], wl["bg"], wl["sq"], wl["seed"])
     d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    wall = {"pair_generation_s": round(time.perf_counter() - t_setup, 2)}  # wall-clock of the untimed legs, for whoever sets a timeout
 
     pipe = None
     if world > 1:
@@ -277,21 +457,25 @@ def main():
     every = max(1, min(10, args.steps // 5))
     sv.profile_reset(d_src)
     sv.profile_enable(d_src, True, only=dom_name, every=every)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    if world > 1:
-        out = drain()  # the last frame's exchange and finish belong to the timed region
-    sync()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY K steps per timed region, barrier + synchronize on both sides, max over ranks -- R regions, the median reported (at the
+    # driver's K = 20 one region of C3 is a 1.7 ms window; `ms_per_step_min` / `_max` say how far single regions scatter)
+    repeats = max(1, args.repeats)
+    regions = []
+    for _ in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        if world > 1:
+            out = drain()  # the last frame's exchange and finish belong to the timed region
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions.append(float(t.item()))
     sv.profile_enable(d_src, False)
     prof = sv.profile_collect(d_src)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = float(np.median(regions))
     disp_dev = out["disp"]
     checksum = int(disp_dev.sum().item())
 
@@ -344,9 +528,11 @@ def main():
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
         ms_rb = float(trb.item()) / args.steps * 1e3
         row_bands = {"ms_per_step": round(ms_rb, 4), "Mdisparities_per_s": round(wl["W"] * wl["H"] * wl["D"] / ms_rb / 1e3, 1),
+                     "sgm_recurrences_timed": False,
                      "rows_per_gpu": rows[1], "collective": None, "result": "rank r holds rows band_range(H, r, N) of the map",
                      "bands_equal_the_replicated_map": bool(same.item()),
-                     "note": "not BASELINE's protocol (that one is `disparity_split`): the disparity range is not sharded, the image rows are, which rests on "
+                     "note": "SECONDARY, never the headline: not BASELINE's protocol (that one is `disparity_split` = `value`) and not the same work (no line "
+                             "recurrence is run): the disparity range is not sharded, the image rows are, which rests on "
                              "the recurrence-free winner identity (the winner of a pixel depends on its own costs and its position only, so no "
                              "line recurrence and no exchange); barrier + synchronize on both sides, max over ranks"}
 
@@ -389,19 +575,14 @@ def main():
     rc = 0
     if rank == 0:
         voxels = wl["W"] * wl["H"] * wl["D"]
+        # The headline is ONE protocol for every N: BASELINE's disparity split with the SGM recurrences run, as at N = 1 (the
+        # exchange-free row split computes the recurrence-free winner identity, different work, and is only ever a secondary entry).
         headline_split = "disparity"
-        if world > 1 and row_bands is not None and row_bands["bands_equal_the_replicated_map"] and row_bands["ms_per_step"] * 1e-3 * args.steps < elapsed:
-            # Both splits were timed the same way (K steps, barrier + synchronize on both sides, max over ranks).  The headline is the better
-            # one; the other stays in the line under its own name.  BASELINE's protocol (disparity shards + RCCL all-reduce) is
-            # `disparity_split`, the exchange-free row split is `row_bands`.
-            headline_split = "rows"
         disparity_split = None
         if world > 1:
             disparity_split = {"ms_per_step": round(elapsed / args.steps * 1e3, 4), "Mdisparities_per_s": round(voxels * args.steps / elapsed / 1e6, 1),
                                "collective": "one int32 MIN all-reduce of the regional winner keys per frame (RCCL), overlapped with the next frame's key kernels",
-                               "result": "every rank holds the whole map"}
-            if headline_split == "rows":
-                elapsed = row_bands["ms_per_step"] * 1e-3 * args.steps
+                               "result": "every rank holds the whole map", "sgm_recurrences_timed": bool(args.with_line_scans)}
         value = voxels * args.steps / elapsed / 1e6
         wl1 = dict(wl, D=wl["D"] if world == 1 else pipe.shard[1])  # what one launch of a kernel processes on one GPU
         ms_per_step = elapsed / args.steps * 1e3
@@ -416,7 +597,7 @@ def main():
         avg_ms_mid = max(avg_raw_ms - 0.5 * pair_ms, 1e-6)
         alg = algorithmic_bytes(dom_name, wl1)
         traffic = load_measured_traffic(dom_name) if world == 1 else None
-        hbm_model = {"bound": "hbm", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
+        hbm_model = {"bound": "hbm", "kernel": KERNEL_SYMBOL.get(dom_name, dom_name), "library_label": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
                      "event_pair_ms": round(pair_ms, 5), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "traffic": traffic, "model": "SURVEY.md 8(d) row C3 prices this launch at 28 B/voxel of volume traffic the fused design never generates"}
         if alg is not None:
@@ -436,7 +617,8 @@ def main():
             fp4 = True
             ops = 2.0 * bits * vox_launch
             ach = ops / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom_name, "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
+            roof = {"bound": "mfma", "kernel": KERNEL_SYMBOL.get(dom_name, dom_name), "library_label": dom_name,
+                    "kernel_is": "the symbol rocprofv3 prints (profiles/r04_bench_kernel_stats.csv, profiles/traffic.json)", "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
                     "event_pair_ms": round(pair_ms, 5), "avg_ms_is": "the event bracket as read (over-reads the kernel by 0 .. one event pair)",
                     "avg_ms_minus_half_pair": round(avg_ms_mid, 5), "frac_minus_half_pair": round(ops / (avg_ms_mid * 1e-3) / 1e12 / peak, 4),
                     "bracketed": f"every {every}. launch inside the timed region", "achieved": round(ach, 1),
@@ -453,36 +635,32 @@ def main():
             cyc = 2 * 2.76 + 2 * 4.58 + 4.46 + 0.5 * 4.55
             peak_vox = 1024 * 2.4e9 / cyc * 64.0
             ach_vox = vox_launch / (avg_ms * 1e-3)
-            issue = {"bound": "valu_issue", "kernel": dom_name, "cycles_per_64_voxels_per_simd": round(cyc, 2), "peak": round(peak_vox / 1e9, 1),
+            issue = {"bound": "valu_issue", "kernel": KERNEL_SYMBOL.get(dom_name, dom_name), "cycles_per_64_voxels_per_simd": round(cyc, 2), "peak": round(peak_vox / 1e9, 1),
                      "achieved": round(ach_vox / 1e9, 1), "unit": "Gvoxels/s", "frac": round(ach_vox / peak_vox, 4),
                      "rates": "measured per-instruction issue rates, tools/ubench_valu.hip"}
         pipeline_alg = 28.0 * voxels + 60.0 * wl["W"] * wl["H"]
         # what no implementation of this step can go below on one GPU: the images in, the disparity map out (HBM), and the
         # Hamming dot products of every voxel on the fastest unit that can do them (matrix cores, FP4)
         compulsory = 12.0 * wl["W"] * wl["H"]
-        lb_us = max(compulsory / (HBM_PEAK_GBPS * 1e9), 2.0 * bits * (voxels / world) / (MFMA_PEAK_TOPS["census_sweep_pm"] * 1e12)) * 1e6
+        lb_us = max(compulsory / (HBM_PEAK_GBPS * 1e9), 2.0 * bits * (voxels / world) / (FP4_PEAK_TOPS * 1e12)) * 1e6
         kernel_ms = {k: round(v[0] / n_warm, 4) for k, v in prof_all.items()}  # warm-up steps, every kernel bracketed (each + one event pair)
         shape = f"{wl['W']}x{wl['H']}"
         line = {
             "metric": f"Mdisparities/s (W*H*D) for census+SGM, {'1080p' if wl['name'] == 'C3' else shape} D={wl['D']}; end-px-err vs ref",
             "value": round(value, 1), "unit": "Mdisparities/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "repeats": repeats, "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+            "timing": f"median of {repeats} timed regions of exactly {args.steps} steps, each bracketed by barrier + torch.cuda.synchronize(), max over ranks",
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "fp4 (e2m1) +-1 census operands on the matrix cores, f32 accumulators holding exact integers (no rounding anywhere on the path)", "data": "synthetic",
             "config": {"workload": f"{shape} synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
                                    f"D={wl['D']}, argmin -> int32 disparity map (BASELINE.json configs[{2 if wl['name'] == 'C3' else 4}])",
-                       "pipeline": "svh_census_band_match on every rank's rows (census transform of the band + halo, sweep writing the disparity map), inputs and "
-                                   "outputs resident in HBM; recurrence-free winner identity (no line scans); the replicated-finish protocol with the recurrences "
-                                   "run is `disparity_split`" if (world > 1 and headline_split == "rows") else
-                                   (("svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
-                                     "svh_census_shard_keys -> int32 MIN all-reduce -> svh_census_shard_finish, inputs and outputs resident in HBM") +
-                                    ("; SGM line recurrences RUN (sweep -> g -> six line scans keeping the min_p values on tile edges -> per-pixel kernel replaying them per tile)" if args.with_line_scans else
-                                     "; recurrence-free winner identity (the library's default for disparity-only calls): no line scans")),
-                       "sgm_recurrences_timed": bool(args.with_line_scans) and not (world > 1 and headline_split == "rows"),
+                       "pipeline": ("svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
+                                    "svh_census_shard_keys -> int32 MIN all-reduce -> svh_census_shard_finish, inputs and outputs resident in HBM") +
+                                   ("; SGM line recurrences RUN (sweep -> g -> six line scans keeping the min_p values on tile edges -> per-pixel kernel replaying them per tile)" if args.with_line_scans else
+                                    "; recurrence-free winner identity (the library's default for disparity-only calls): no line scans"),
+                       "sgm_recurrences_timed": bool(args.with_line_scans),
                        "materialize_volumes": bool(args.materialize),
-                       "parallelism": (f"image rows split over {world} GPUs ({row_bands['rows_per_gpu']} rows each, the whole disparity range on every GPU), no "
-                                       "collective on the data path (svh_census_band_match: the winner of a pixel depends on its own costs and its position "
-                                       "only); BASELINE's disparity split is `disparity_split` in this line") if (world > 1 and headline_split == "rows") else
-                                      (f"disparity axis sharded over {world} GPUs ({pipe.shard[1]} of {wl['D']} disparities per GPU), one RCCL int32 MIN "
+                       "parallelism": (f"disparity axis sharded over {world} GPUs ({pipe.shard[1]} of {wl['D']} disparities per GPU), one RCCL int32 MIN "
                                        "all-reduce of the regional winner keys per frame, overlapped with the next frame's key kernels "
                                        "(one exchange in flight); the finish (" + ("line scans on the reduced keys + finalize" if args.with_line_scans else
                                                                            "winner from the reduced keys") + ") replicated") if world > 1 else "single GPU"},
@@ -511,7 +689,9 @@ def main():
         got = disp_dev.cpu().numpy()
         if not args.no_cpu_baseline:
             if world == 1:
+                t_cpu = time.perf_counter()
                 line["cpu_baseline"], want = cpu_baseline(wl, src, tgt)
+                wall["cpu_baseline_s"] = round(time.perf_counter() - t_cpu, 2)
                 line["end_px_err"] = end_px_err(got, want, "oracle (port), full frame")
             else:  # the oracle on the whole 8K frame would take about a minute: a row band, on the pixels a band decides ...
                 # ... and the WHOLE frame against the map one GPU computes alone on the whole range in this same run (itself oracle-checked
@@ -521,7 +701,8 @@ def main():
                 if diff_one != 0:
                     rc = 3
                 band = 48
-                want, _ = oracle_disparity(wl, src, tgt, band + wl["v_r"], variant=1)
+                want, wall["oracle_band_s"] = oracle_disparity(wl, src, tgt, band + wl["v_r"], variant=1)
+                wall["oracle_band_s"] = round(wall["oracle_band_s"], 2)
                 line["end_px_err"] = end_px_err(got, want[:band], f"oracle (port), top {band} rows, pixels whose SGM lines lie inside the band",
                                                 band_check_mask(wl["H"], wl["W"], band))
             if line["end_px_err"]["pixels_differing"] != 0:
@@ -546,7 +727,7 @@ def main():
                 sv.set_option(d_src, "census_winner_shortcut", 0)
             line["winner_identity"] = {"ms_per_step": round(dt_id * 1e3, 4), "Mdisparities_per_s": round(voxels / dt_id / 1e6, 1),
                                        "same_disparity_map": bool(torch.equal(out_id["disp"], disp_dev)),
-                                       "kernels": "census_transform, census_sweep_pm (writes the disparity map)",
+                                       "kernels": "census_grey_kernel, census_sweep_rl_kernel (writes the disparity map)",
                                        "note": "what svh_stereo_match does by default when only the disparity map is asked for"}
             if not line["winner_identity"]["same_disparity_map"]:
                 rc = 3
@@ -575,6 +756,20 @@ def main():
             line["api_chain"]["pixels_differing_from_fused"] = int((chain_disp != disp_dev).sum().item())
             if line["api_chain"]["pixels_differing_from_fused"] != 0:
                 rc = 3
+        if world == 1 and not args.no_configs:
+            # the other BASELINE configurations, after (and outside) everything the headline times; C3 itself is the headline above
+            torch.cuda.empty_cache()
+            sv.set_option(disp_dev, "census_winner_shortcut", 0)  # as the headline: the SGM recurrences run
+            try:
+                line["configs"], cfg_ok = other_configs(sv, dev, cpu_legs=not args.no_cpu_baseline)
+                line["configs"]["C3"] = "the headline of this line (value, ms_per_step, roofline, cpu_baseline, end_px_err)"
+                if not cfg_ok:
+                    rc = 3
+            except Exception as e:  # noqa: BLE001 -- report, never lose the headline to a secondary leg
+                line["configs"] = {"error": f"{type(e).__name__}: {e}"}
+                rc = 3
+        wall["total_s"] = round(time.perf_counter() - t_setup, 2)
+        line["wall_clock_s"] = wall
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

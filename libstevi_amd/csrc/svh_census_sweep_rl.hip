@@ -468,8 +468,8 @@ template <int NW, int NT, int CT, int BPC = rl_blocks_per_cu(NW, NT, CT)> int la
             return fail(ctx, SVH_ERR_HIP, "census_sweep (fp4, right-to-left): cannot raise the dynamic LDS limit");
         __atomic_store_n(&attr_set[dev], 1, __ATOMIC_RELEASE);
     }
-    if (sw.on()) SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_rl_kernel<NW, NT, CT, true, BPC>), grid, 64 * RL_WAVES, shmem, g, Pout, keys, gmap, plan, sw);
-    else SVH_LAUNCH(ctx, "census_sweep_pm", (census_sweep_rl_kernel<NW, NT, CT, false, BPC>), grid, 64 * RL_WAVES, shmem, g, Pout, keys, gmap, plan, sw);
+    if (sw.on()) SVH_LAUNCH(ctx, "census_sweep_rl", (census_sweep_rl_kernel<NW, NT, CT, true, BPC>), grid, 64 * RL_WAVES, shmem, g, Pout, keys, gmap, plan, sw);
+    else SVH_LAUNCH(ctx, "census_sweep_rl", (census_sweep_rl_kernel<NW, NT, CT, false, BPC>), grid, 64 * RL_WAVES, shmem, g, Pout, keys, gmap, plan, sw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? SVH_OK : fail(ctx, SVH_ERR_HIP, "census_sweep (fp4, right-to-left): %s", hipGetErrorString(e));
 }

@@ -18,7 +18,7 @@ import os
 import re
 import sys
 
-NAMES = {"census_image_tiled_kernel": "census_transform", "census_grey_kernel": "census_transform", "census_image_kernel": "census_transform", "census_sweep_kernel": "census_sweep", "census_sweep_pm_kernel": "census_sweep_pm", "census_sweep_rl_kernel": "census_sweep_pm", "scan_cols_kernel": "sgm_line_scans", "census_finalize_kernel": "census_finalize", "tile_finalize_kernel": "census_finalize"}
+# keys of the summary = the kernel symbols rocprofv3 prints (bench.py's KERNEL_SYMBOL maps the library's profile labels onto them)
 
 
 def collect(directory, counter):
@@ -27,11 +27,11 @@ def collect(directory, counter):
         for r in csv.DictReader(open(path)):
             m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
             if m and "svh" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                name = NAMES.get(m.group(1), m.group(1))
+                name = m.group(1)
                 # the sweep that writes the disparity map itself (template argument WINNER = true: the winner_identity leg of bench.py) is
                 # another kernel as far as bytes go: it writes 4 B / pixel instead of keys + g
-                if name == "census_sweep_pm" and re.search(r"census_sweep_\w+_kernel<[^>]*\btrue\b", r["Kernel_Name"]):
-                    name = "census_sweep_pm_winner"
+                if name in ("census_sweep_pm_kernel", "census_sweep_rl_kernel") and re.search(r"census_sweep_\w+_kernel<[^>]*\btrue\b", r["Kernel_Name"]):
+                    name += ":winner"
                 acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 

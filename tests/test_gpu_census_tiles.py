@@ -102,10 +102,39 @@ def test_tiles_other_windows_and_direction(r, ddir):
     same(run(d_tgt, d_src, r, D, 1, **kw), run(d_tgt, d_src, r, D, 1, fast=0, **kw), (r, ddir, "general"))
 
 
+def oracle_checks(out, vol, r, what):
+    """The values the recurrences produce, against the oracle's aggregated volume: the disparity map, the S value at the winner (upper
+    half of the reduction key: an order-preserving code of the float) and the Gaussian-refined map (it takes logarithms of the three
+    taps, so it sees the sum of the per-pass minima that the disparity map cannot see)."""
+    idx = so.extract_index(vol, so.COST)
+    assert np.array_equal(out["disp"].cpu().numpy(), so.index_to_disp(idx, so.RIGHT_TO_LEFT)), what
+    best = np.take_along_axis(vol, idx[..., None].astype(np.int64), axis=2)[..., 0]
+    u = best.astype(np.float32).view(np.uint32)
+    code = np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64)
+    keys = out["keys"].cpu().numpy().view(np.uint64)
+    assert np.array_equal(keys >> np.uint64(32), code), what
+    taps = so.truncated_cost_volume(vol, idx, r, r, 1)
+    exp = so.refine_disp(taps, idx, so.GAUSSIAN)
+    got = out["refined"].cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), what
+    # Tolerance: the north star's 1e-4 for refined disparities.  (At 1080p the aggregated costs reach a few hundred and neighbouring taps
+    # differ by a few units: the differences of logarithms in (ln cm1 - ln c1) / (2 (ln c1 - 2 ln c0 + ln cm1)) cancel most digits, so the
+    # device's logf against the host's shows as a few 1e-5 here where the small frames above agree to 1e-6.)
+    ok = ~np.isnan(exp)
+    assert float(np.max(np.abs(got[ok] - exp[ok]), initial=0.0)) <= 1e-4, (what, float(np.max(np.abs(got[ok] - exp[ok]))))
+    assert np.median(np.abs(got[ok] - exp[ok])) <= 1e-6, what
+
+
 def test_tiles_full_hd_rows():
-    """1080 rows: sixteen segments of 68 rows (the last one 60), thirty column tiles; against the maps form."""
+    """1080 rows: sixteen segments of 68 rows (the last one 60), thirty column tiles -- the benchmark's frame, 256 disparities.  Against the
+    maps form AND against the oracle's aggregated volume of the whole frame (S at the winner of every pixel, Gaussian-refined map): the
+    headline form is not only compared with another form of itself."""
     src, tgt, _ = parallax_pair(1080, 1920, 320, 320, 380, 8, 64, seed=3)
     d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
     a = run(d_tgt, d_src, 4, 256, 1, Pout=100.0)
     b = run(d_tgt, d_src, 4, 256, 0, Pout=100.0)
     same(a, b, "1080p")
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, 256, so.RIGHT_TO_LEFT)
+    vol = so.sgm(cv, 8, so.COST, 0.3, 0.9, (0, 0, 0, 0), 100.0)
+    del cv
+    oracle_checks(a, vol, 4, "1080p x 256, tiles form")

@@ -101,8 +101,20 @@ def test_c3_census_sgm_1080p(c3_pair):
     cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 4, 4, D)
     vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), Pout)
     want = so.index_to_disp(so.extract_index(vol, so.COST))
-    del cv, vol
+    del cv
     assert int(np.count_nonzero(fast.cpu().numpy() != want)) == 0
+    # the form bench.py times (recurrences run, tile edges + per-tile replay) asked for what depends on the recurrences' VALUES, against
+    # the oracle's volume of the whole frame: S at the winner of every pixel (reduction keys) and the Gaussian-refined map
+    from test_gpu_census_tiles import oracle_checks
+    try:
+        sv.set_option(d_tgt, "census_winner_shortcut", 0)
+        tiles = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, sgmDirections=8, Pout=Pout, want_keys=True, refineKernel=so.GAUSSIAN, refine_h_radius=4,
+                               refine_v_radius=4)
+    finally:
+        sv.set_option(d_tgt, "census_winner_shortcut", 1)
+    assert torch.equal(tiles["disp"], fast)
+    oracle_checks(tiles, vol, 4, "C3, tiles form")
+    del vol, tiles
     # planted disparities are recovered away from borders and occlusions
     disp = fast.cpu().numpy()
     inner = np.zeros((H, W), bool)

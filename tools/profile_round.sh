@@ -3,7 +3,8 @@
 #   gpurun_out/<tag>_line_rocprof.json       the bench line printed under the profiler
 #   gpurun_out/<tag>_traffic.json            HBM bytes per launch and kernel (two --pmc passes, tools/pmc_summary.py)
 #   gpurun_out/<tag>_sq_counters.json        SQ instruction mix and wait breakdown (three --pmc passes, tools/pmc_sq_summary.py)
-#   gpurun_out/<tag>_line.json, _line_two_frames.json   plain bench lines
+#   gpurun_out/<tag>_line.json, _line_driver_flags.json, _line_two_frames.json   plain bench lines (200 steps; the driver's --steps 20 --warmup 5)
+#   gpurun_out/<tag>_c4_kernel_stats.csv     rocprofv3 --kernel-trace --stats of tools/bench_configs.py c4
 #   gpurun_out/<tag>_other_workloads.jsonl   C1 - C5 and the per-function chains
 set -e
 TAG=${1:-r03}
@@ -11,6 +12,7 @@ R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- $B --steps 100 --warmup 10 --no-cpu-baseline --no-configs > $R/gpurun_out/${TAG}_line_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_c4 -- python3 $R/tools/bench_configs.py c4 > $R/gpurun_out/${TAG}_c4_line_rocprof.json 2>> $R/gpurun_out/${TAG}_rocprof.err
 echo "kernel trace done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-api-chain --no-configs > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- $B --steps 5 --warmup 2 --no-cpu-baseline --no-api-chain --no-configs > /dev/null 2>&1
@@ -23,8 +25,10 @@ cd $R
 python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${TAG}_traffic.json > /dev/null
 python3 tools/pmc_sq_summary.py gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3 > gpurun_out/${TAG}_sq_counters.json
 cp $(ls gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -1) gpurun_out/${TAG}_kernel_stats.csv
-rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3
+cp $(ls gpurun_out/prof_${TAG}_c4/*/*kernel_stats.csv | head -1) gpurun_out/${TAG}_c4_kernel_stats.csv
+rm -rf gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_c4 gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 gpurun_out/pmc_sq3
 python3 bench.py --steps 200 --warmup 10 > gpurun_out/${TAG}_line.json 2> gpurun_out/${TAG}_line.err
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_line_driver_flags.json 2>> gpurun_out/${TAG}_line.err
 python3 bench.py --steps 200 --warmup 10 --two-frames --no-cpu-baseline --no-api-chain --no-configs > gpurun_out/${TAG}_line_two_frames.json 2>/dev/null
 echo "bench lines done"
 (python3 tools/bench_configs.py c1 c2 c3 c4 c5slice c5; python3 tools/bench_api_chain.py; python3 tools/bench_l2r.py; python3 tools/sgm_score_probe.py; python3 tools/bench_2d.py; python3 tools/bench_hierarchical.py) 2>/dev/null | grep "^{" > gpurun_out/${TAG}_other_workloads.jsonl || true

@@ -121,6 +121,12 @@ const char *svh_last_error(const svh_context *ctx);
  * of the line recurrences' per-pass minima, only the values on the edges of 9-row x 64-column tiles, and the per-pixel kernel replays
  * the recurrences inside its tile; 0 writes the six per-pass maps and reads them back (round 2's pair of kernels).  Same results bit
  * for bit (tests/test_gpu_census_tiles.py); margins, 4 directions, taller images and row bands take the maps form regardless.
+ * "cost_reduce_fused" (default 1): svh_stereo_match with a float matching function on grey images (windows up to 11 wide, not ZSAD)
+ * lets the cost kernel reduce over the disparity axis while a block's waves hold a pixel's whole range: without SGM, for a call that asks
+ * for the disparity map alone, the winner (extractSelectedIndex's rule: extremum, ties to the larger index, NaN never wins unless at index
+ * 0) -- the volume is then never written and nothing reads it back; with a Cost-strategy SGM the two regional minima its line recurrences
+ * run on (see "sgm_cost_two_minima"), so that the probing read of the volume is gone too.  0: extract_index / the probe read the volume.
+ * Same maps bit for bit (tests/test_gpu_parity.py::test_winner_and_minima_reduced_inside_the_cost_kernel).
  * "sgm_cost_two_minima" (default 1): svh_sgm_cost_volume, Cost strategy, on a float volume that is not in the exact-integer regime
  * reads the volume ONCE for its line recurrences: a probe leaves every pixel's two regional minima (the smallest finite cost among the
  * disparities that look inside the image, and among those that look past its right border), and the recurrence of sgm.h:257-296 --

@@ -427,6 +427,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_winner_shortcut = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "cost_reduce_fused") == 0) {
+        ctx->cost_reduce_fused = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "sgm_cost_two_minima") == 0) {
         ctx->sgm_cost_two_minima = value != 0;
         return SVH_OK;

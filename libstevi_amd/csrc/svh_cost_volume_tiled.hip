@@ -166,12 +166,26 @@ __device__ __forceinline__ float lane_below(float v) { // value of lane - 1 (wav
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
 }
 
-template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
+// what the kernel reduces over the disparity axis besides (or instead of) storing the costs: CostReduce of svh_internal.h as a kernel argument
+struct ColsumReduce {
+    int mode, score, store;
+    int32_t *idx, *disp;
+    int disp_sign, disp_offset;
+    float2 *minima;
+    int *flag;
+    float big;
+};
+
+// RED: 0 none (the kernel of round 3, register for register: 119-126 VGPRs, two blocks of eight waves per CU), 1 winner, 2 regional
+// minima.  A compile-time parameter because the reductions' running state (eight registers live across the whole disparity loop) took
+// the kernel to 150 VGPRs and one block per CU when it was a run-time switch: every plain cost volume paid 0.19 ms of 0.54 for a feature
+// it did not use.  The reducing forms are held to four waves per SIMD as well (second launch bound).
+template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES, int RED>
+__global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
                                                                  int D, int disp_lower, const float *__restrict__ mean_s,
                                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                  const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
-                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0) {
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0, ColsumReduce rd) {
     constexpr int DB = CS_DB, OUT = CS_COLS - 2 * HR;
     extern __shared__ float lds[];
     const int v = 2 * v_r + 1;
@@ -231,6 +245,12 @@ __global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const fl
         inv_ns[e] = NRM ? 1.0f / norm_s[px] : 1.0f;
         zc[e] = zcost[px];
     }
+    // per-pixel reductions over the disparities this wave walks (ColsumReduce): the running winner (value, index; index -1: no candidate
+    // yet) or the two regional minima, and the largest finite magnitude seen
+    const float red0 = (RED == 1 && rd.score) ? -INFINITY : INFINITY;
+    float red_a[2] = {red0, red0}, red_b[2] = {INFINITY, INFINITY}, amax = 0.0f;
+    int red_d[2] = {-1, -1};
+    bool nan_at_0[2] = {false, false};
     for (int db = wave; db < n_blocks; db += WAVES) {
         const int d0 = db * DB;
         // Column sums as register PAIRS (v_pk_fma_f32 takes aligned pairs): the row's target samples t[0 .. DB + 1] arrive as the
@@ -345,6 +365,57 @@ __global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const fl
                 const bool there = trow_in && (unsigned)(jt0 + SIGN * q) < (unsigned)Wt && (whole || d0 + q < D);
                 o_[q] = there ? x : zc[e]; // no target pixel: the cost against the all-zero vector (cross_correlations.h:235)
             }
+            // The reductions must cost next to nothing per voxel (the kernel is bound by vector issue: a first form with explicit NaN and
+            // candidate tests took 7 instructions per voxel and made it 65 % longer).
+            if constexpr (RED == 1) { // winner so far: the sequential scan's rule on this wave's disparities, in increasing order
+                // best starts at +inf (-inf for scores): `x <= best` holds for every non-NaN x until something smaller came, never for a
+                // NaN, and an equal value later in the scan takes over (ties to the larger index): compare, min / max, select -- 3 per voxel.
+                if (!whole) { // (wave uniform; the last block of a range that is no multiple of 16) indices past the range never win
+#pragma unroll
+                    for (int q = 0; q < DB; q++) o_[q] = d0 + q < D ? o_[q] : __uint_as_float(0x7FC00000u);
+                }
+                if (d0 == 0) nan_at_0[e] = isnan(o_[0]);
+                if (rd.score) {
+#pragma unroll
+                    for (int q = 0; q < DB; q++) {
+                        red_d[e] = o_[q] >= red_a[e] ? d0 + q : red_d[e];
+                        red_a[e] = fmaxf(red_a[e], o_[q]);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < DB; q++) {
+                        red_d[e] = o_[q] <= red_a[e] ? d0 + q : red_d[e];
+                        red_a[e] = fminf(red_a[e], o_[q]);
+                    }
+                }
+            } else if constexpr (RED == 2) { // regional minima: j + d < W / j + d >= W (sgm.h:285-289 applies Pout by the INDEX)
+                // v_min ignores NaN and +inf never lowers a minimum; any infinity (the only way to a -inf) drives amax to +inf, which raises
+                // the "outside the regime" bit and sends the aggregation to the kernels that read the volume: no finiteness test per voxel.
+                const int first_oob = Ws - pe[e]; // this pixel's first index that looks past the right border
+                float mn = INFINITY, mx = 0.0f;
+                if (!whole) {
+#pragma unroll
+                    for (int q = 0; q < DB; q++) o_[q] = d0 + q < D ? o_[q] : __uint_as_float(0x7FC00000u);
+                }
+#pragma unroll
+                for (int q = 0; q < DB; q++) mx = fmaxf(mx, fabsf(o_[q]));
+                amax = fmaxf(amax, mx);
+                const bool all_in = __all(d0 + DB <= first_oob || !live[e]), all_out = __all(d0 >= first_oob || !live[e]);
+                if (all_in || all_out) { // (wave uniform) the usual case: one region for the whole block
+#pragma unroll
+                    for (int q = 0; q < DB; q++) mn = fminf(mn, o_[q]);
+                    if (all_in) red_a[e] = fminf(red_a[e], mn);
+                    else red_b[e] = fminf(red_b[e], mn);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < DB; q++) {
+                        const bool oob = d0 + q >= first_oob;
+                        red_a[e] = fminf(red_a[e], oob ? INFINITY : o_[q]);
+                        red_b[e] = fminf(red_b[e], oob ? o_[q] : INFINITY);
+                    }
+                }
+            }
+            if (RED && !rd.store) continue; // (kernel-uniform) nobody wants the volume
             if (whole && ((px_stride | out_off) & 3) == 0) { // (wave uniform)
                 // A lane holds 64 bytes of its pixel's run; stored as they are, every 16-byte piece of a wave's store instruction would go to
                 // a different pixel (1 KB apart): requests of 16 bytes, a quarter of what the memory side takes per request (measured: the
@@ -370,6 +441,47 @@ __global__ void __launch_bounds__(64 * WAVES) cost_volume_colsum_kernel(const fl
             }
         }
     }
+    if constexpr (RED == 0) return;
+    // The waves of the block hold a pixel's range between them (disparity block b belongs to wave b mod WAVES): partial results go
+    // through this wave's transposition area, wave 0 -- which walked block 0 and knows whether the cost at index 0 is NaN -- combines.
+    float *part = xpose; // 64 lanes x 4 floats
+    *reinterpret_cast<float4 *>(part + 4 * u) = RED == 1 ? make_float4(red_a[0], __int_as_float(red_d[0]), red_a[1], __int_as_float(red_d[1]))
+                                                             : make_float4(red_a[0], red_b[0], red_a[1], red_b[1]);
+    if (RED == 2 && rd.flag && __any(amax > rd.big) && u == 0) atomicOr(rd.flag, 2);
+    __syncthreads();
+    if (wave != 0) return;
+    float *base = xpose; // wave 0's own area is the first
+    for (int w = 1; w < WAVES; w++) {
+        const float4 o = *reinterpret_cast<const float4 *>(base + w * (64 * CS_XP) + 4 * u);
+        if (RED == 1) {
+            const float ov[2] = {o.x, o.z};
+            const int od[2] = {__float_as_int(o.y), __float_as_int(o.w)};
+#pragma unroll
+            for (int e = 0; e < 2; e++) { // extremum wins, ties go to the larger index (correlation_base.h:441-455)
+                const bool take = od[e] >= 0 && (red_d[e] < 0 || (rd.score ? (ov[e] > red_a[e] || (ov[e] == red_a[e] && od[e] > red_d[e]))
+                                                                          : (ov[e] < red_a[e] || (ov[e] == red_a[e] && od[e] > red_d[e]))));
+                red_a[e] = take ? ov[e] : red_a[e];
+                red_d[e] = take ? od[e] : red_d[e];
+            }
+        } else {
+            red_a[0] = fminf(red_a[0], o.x);
+            red_b[0] = fminf(red_b[0], o.y);
+            red_a[1] = fminf(red_a[1], o.z);
+            red_b[1] = fminf(red_b[1], o.w);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (!live[e]) continue;
+        const int64_t px = (int64_t)i * Ws + pe[e];
+        if (RED == 1) {
+            const int sel = (nan_at_0[e] || red_d[e] < 0) ? 0 : red_d[e];
+            if (rd.idx) rd.idx[px] = sel;
+            if (rd.disp) rd.disp[px] = rd.disp_sign * sel + rd.disp_offset;
+        } else {
+            rd.minima[px] = make_float2(red_a[e], red_b[e]);
+        }
+    }
 }
 
 // waves per block: eight share a staged tile when there are disparity blocks for all of them (two blocks of eight waves fit a CU's LDS
@@ -383,17 +495,30 @@ inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm) {
 template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                                    const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
     const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM);
+    ColsumReduce rd{};
+    rd.store = 1;
+    if (a.reduce && a.reduce->mode && a.tgt_row_off == 0 && a.out_off == 0 && a.row_count == 0) { // (1-D volumes of whole images)
+        const CostReduce &r = *a.reduce;
+        rd = ColsumReduce{r.mode, r.score ? 1 : 0, r.store ? 1 : 0, r.idx, r.disp, r.disp_sign, r.disp_offset, reinterpret_cast<float2 *>(r.minima), r.flag, r.big};
+        a.reduce->done = true;
+    }
     dim3 grid(ceil_div(a.Ws, CS_COLS - 2 * HR), a.row_count ? a.row_count : a.H);
-#define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
+#define SVH_CS_LAUNCH_R(SG, WV, RD)                                                                                                                 \
     do {                                                                                                                                           \
         static int big_lds[64] = {}; /* (per instantiation and device) more than the default 64 KiB of dynamic LDS */                              \
         if (shmem > 64 * 1024 && !__atomic_load_n(&big_lds[ctx->device & 63], __ATOMIC_ACQUIRE)) {                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV>),                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD>),                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                     \
             __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
         }                                                                                                                                          \
-        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV>), grid, 64 * WV, shmem, src, tgt, a.H, a.Ws,     \
-                   a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin);                    \
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD>), grid, 64 * WV, shmem, src, tgt, a.H, a.Ws, \
+                   a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd);                \
+    } while (0)
+#define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
+    do {                                                                                                                                           \
+        if (rd.mode == 1) SVH_CS_LAUNCH_R(SG, WV, 1);                                                                                              \
+        else if (rd.mode == 2) SVH_CS_LAUNCH_R(SG, WV, 2);                                                                                         \
+        else SVH_CS_LAUNCH_R(SG, WV, 0);                                                                                                           \
     } while (0)
     if (colsum_waves(a.D) == 8) {
         if (sign > 0) SVH_CS_LAUNCH(1, 8);
@@ -403,6 +528,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
         else SVH_CS_LAUNCH(-1, 4);
     }
 #undef SVH_CS_LAUNCH
+#undef SVH_CS_LAUNCH_R
 }
 template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                        const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
@@ -468,6 +594,11 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 }
 
 } // namespace
+
+bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r) {
+    if (a.literal || src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
+    return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func)) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
+}
 
 // Returns SVH_OK when the tiled kernel ran, SVH_ERR_UNSUPPORTED (without touching the context error) when the caller must
 // use the generic kernel (multi-channel images, windows wider than 11, tiles beyond the LDS budget).

@@ -53,6 +53,7 @@ struct svh_context {
     bool census_tiles = true;          // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
+    bool cost_reduce_fused = true;     // svh_context_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
     bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
     bool sgm_score_finish_fused = true; // svh_context_set_option("sgm_score_finish_fused"): svh_stereo_match lets the Score branch's last writer of each pixel emit its winner / taps (0: extract_index + truncatedCostVolume read S back)
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)
@@ -206,6 +207,24 @@ struct WindowStatsCache {
     bool ready = false;
     float *ms = nullptr, *mt = nullptr, *ns = nullptr, *nt = nullptr, *zc = nullptr;
 };
+// Per-pixel reductions over the disparity axis that the float cost kernel computes while it holds the costs (the column-sum kernel of
+// svh_cost_volume_tiled.hip: a block's waves hold a pixel's whole range between them), so that nobody reads the volume back for them:
+//   mode 1  the winner (extractSelectedIndex, correlation_base.h:427-464: extremum, ties to the larger index, NaN never wins unless at
+//           index 0) -> idx and / or disp = disp_sign * idx + disp_offset; with store == false the volume is not written at all
+//   mode 2  the two regional minima a later Cost-branch sgmCostVolume needs (svh_sgm.hip: the smallest finite cost among the disparities
+//           with j + d < W, and among those with j + d >= W) -> minima (H, W) float2; bit 1 of *flag is raised when a finite |c| > big
+// done: set by the launcher when the kernel that ran produced them (other kernels do not: the caller falls back to reading the volume).
+struct CostReduce {
+    int mode = 0;
+    bool score = false;
+    int32_t *idx = nullptr, *disp = nullptr;
+    int disp_sign = 1, disp_offset = 0;
+    float *minima = nullptr;
+    int *flag = nullptr;
+    float big = 1e30f;
+    bool store = true;
+    bool done = false;
+};
 struct CostVolumeArgs {
     int func, ddir;
     int H, Ws, Wt;
@@ -223,6 +242,7 @@ struct CostVolumeArgs {
     // (device, (H, Ws) float2; svh_unfold_cost_volume_minima); *minima_written says whether the kernel that ran produced them
     float *minima = nullptr;
     int *minima_written = nullptr;
+    CostReduce *reduce = nullptr; // float costs of grey images: see CostReduce (ignored by the kernels that cannot do it: check reduce->done)
     // image rows [row_begin, row_begin + row_count) only (row_count 0: all of them; dev_cost_volume_grey_tiled)
     int row_begin = 0, row_count = 0;
     int sign() const { return force_sign ? force_sign : (ddir == SVH_RIGHT_TO_LEFT ? 1 : -1); }
@@ -233,6 +253,8 @@ int dev_cost_volume_from_features(svh_context *ctx, Scratch &scr, const CostVolu
 int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r,
                                 int v_r, float *cv);
 int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv);
+// whether dev_cost_volume_grey_tiled would run the column-sum kernel for these arguments (the one that can serve a CostReduce)
+bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r);
 // Hamming volume from compact census words (src exact, tgt already rounded through float)
 int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *src_words, const uint32_t *tgt_words, int nWw,
                        float *cv);
@@ -258,6 +280,11 @@ __host__ __device__ __forceinline__ int min_p_plane(int q) { return q <= 2 ? q :
 // cost source for the Cost-branch kernels: either a dense float volume or census words evaluated on the fly
 struct CostSource {
     const float *cv = nullptr;       // (H, W, D) dense, or nullptr
+    // float volume the library has just written (CostReduce mode 2): its regional minima (H, W) float2 and the flag word the kernel that
+    // wrote them raised bit 1 of when a finite |c| exceeded 1e30 (bit 0 is set by the host: no exact-integer route is tried); the Cost
+    // branch then needs no probing read of the volume
+    const float *float_minima = nullptr;
+    int *float_flag = nullptr;
     const uint32_t *src_words = nullptr, *tgt_words = nullptr; // compact (H, W*, nWw)
     int nWw = 0, Wt = 0, sign = 1, disp_lower = 0;
     int d_offset = 0; // disparity shards: global index of local disparity 0 (disp_lower already includes it)

@@ -137,6 +137,27 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, win));
         }
     } else {
+        // What the cost kernel can do while it holds a pixel's costs (CostReduce; the column-sum kernel of grey images):
+        //   no SGM, disparity map only: the winner -- the volume is then never written, and nothing reads it back;
+        //   Cost-branch SGM: the two regional minima the line recurrences run on -- no probing read of the volume.
+        CostReduce red;
+        CostVolumeArgs cva_r = cva;
+        const bool colsum = ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, cva, isrc, itgt, prm->h_radius, prm->v_radius);
+        const bool winner_in_cost = colsum && !sgm && !cv && !want_refine && !keys && disp && !sharded;
+        const bool minima_in_cost = colsum && sgm && strategy == SVH_COST && ctx->sgm_cost_two_minima && !sharded;
+        if (winner_in_cost) {
+            red.mode = 1;
+            red.score = strategy != SVH_COST;
+            red.disp = (int32_t *)o_disp.dptr;
+            red.disp_sign = disp_sign;
+            red.disp_offset = disp_offset;
+            red.store = false;
+            cva_r.reduce = &red;
+            SVH_TRY(dev_cost_volume_from_images(ctx, scr, cva_r, isrc, itgt, prm->h_radius, prm->v_radius, nullptr));
+            if (!red.done) return fail(ctx, SVH_ERR_HIP, "internal: the cost kernel that ran does not reduce");
+            SVH_TRY(finish_out(ctx, o_disp));
+            return SVH_OK;
+        }
         float *d_cv = cv ? (float *)o_cv.dptr : scr.get_n<float>(nvox);
         if (!d_cv) return SVH_ERR_OUT_OF_MEMORY;
         float *d_s = nullptr;
@@ -144,10 +165,23 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             d_s = sgm_cv ? (float *)o_sgm.dptr : scr.get_n<float>(nvox);
             if (!d_s) return SVH_ERR_OUT_OF_MEMORY;
         }
-        SVH_TRY(dev_cost_volume_from_images(ctx, scr, cva, isrc, itgt, prm->h_radius, prm->v_radius, d_cv));
+        if (minima_in_cost) {
+            red.mode = 2;
+            red.minima = scr.get_n<float>((size_t)npx * 2);
+            red.flag = scr.get_n<int>(64);
+            if (!red.minima || !red.flag) return SVH_ERR_OUT_OF_MEMORY;
+            const int one = 1; // bit 0: no exact-integer route (the kernel does not test integrality); it raises bit 1 itself
+            SVH_HIP_CHECK(ctx, hipMemcpyAsync(red.flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            cva_r.reduce = &red;
+        }
+        SVH_TRY(dev_cost_volume_from_images(ctx, scr, cva_r, isrc, itgt, prm->h_radius, prm->v_radius, d_cv));
         if (sgm && strategy == SVH_COST) {
             CostSource cs;
             cs.cv = d_cv;
+            if (minima_in_cost && red.done) {
+                cs.float_minima = red.minima;
+                cs.float_flag = red.flag;
+            }
             SVH_TRY(dev_sgm_cost_branch(ctx, scr, sa, cs, sgm_cv ? (float *)o_sgm.dptr : nullptr, win));
         } else {
             const float *d_final = d_cv;

@@ -189,17 +189,26 @@ template <bool COST> __device__ __forceinline__ Winner wave_winner(Winner w) {
 
 // Winner over the non-NaN values of the wave (d = -1 when there is none) and whether the value at local index 0
 // is NaN: the sequential scan of the reference starts from index 0 and never leaves it when that value is NaN.
+// Wave extremum by DPP (v_min / v_max ignore NaN), a ballot of the lanes that hold a value EQUAL to it (a NaN equals nothing), the highest
+// such lane and its largest such k: ties go to the larger index.  (The first form exchanged (value, index) pairs through six
+// ds_bpermute rounds: the fused winner made sgm_cost_apply 35 % longer than the same kernel writing the whole volume.)
 template <bool COST, int R>
 __device__ __forceinline__ Winner wave_select(const float (&s)[R], int lane, int D, bool *first_is_nan) {
-    Winner w{0.0f, -1};
+    float A = COST ? INFINITY : -INFINITY;
 #pragma unroll
     for (int k = 0; k < R; k++) {
-        int d = lane * R + k;
-        if (d < D && !isnan(s[k])) w = better<COST>(w, Winner{s[k], d});
+        const float x = (lane * R + k < D) ? s[k] : __uint_as_float(0x7FC00000u);
+        A = COST ? fminf(A, x) : fmaxf(A, x);
     }
-    w = wave_winner<COST>(w);
-    *first_is_nan = isnan(__shfl(s[0], 0));
-    return w;
+    const float M = COST ? wave_min(A) : wave_max_dpp(A); // +-inf when every value is NaN (then nothing equals it unless a real +-inf does)
+    int kb = -1;
+#pragma unroll
+    for (int k = 0; k < R; k++) kb = (lane * R + k < D && s[k] == M) ? k : kb;
+    const unsigned long long holders = __builtin_amdgcn_ballot_w64(kb >= 0);
+    *first_is_nan = (__builtin_amdgcn_ballot_w64(isnan(s[0])) & 1ull) != 0;
+    if (holders == 0ull) return Winner{0.0f, -1};
+    const int top = 63 - __builtin_clzll(holders);
+    return Winner{M, top * R + __builtin_amdgcn_readlane(kb, top)};
 }
 
 // (ordered value, index) key for a cross-shard min (COST) / max (SCORE) reduction that reproduces the tie rule
@@ -221,9 +230,14 @@ struct ApplyOut {
 template <class SRC, int R>
 __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int W, int D, int top, int left, int Hp, int Wp,
                                                             int n_pass, float Pout, const float *__restrict__ mmap,
-                                                            ApplyOut out) {
+                                                            ApplyOut out, const int *__restrict__ regime_flag) {
     const int lane = threadIdx.x & 63;
     const int64_t npx = (int64_t)H * W;
+    // In the regime the two-minima route established (no finite |c| above 1e30: bit 1 of the flag down) and with a finite Pout (then
+    // |Pout| <= 1e30) `isfinite(t)` is redundant once mp is finite: for a non-finite c the sum c + (t - mp) IS c (same-signed infinities; NaN stays NaN)
+    // and a finite c cannot overflow t.  Four operations per voxel and pass instead of eight: with the winner fused behind it this kernel
+    // is bound by vector issue, not by its one read of the volume.
+    const bool lean = regime_flag && (*regime_flag & 2) == 0 && finite_f(Pout);
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     // APPLY_PB pixels per wave iteration: their cost rows and min_p values are all requested before the first one is used
@@ -253,6 +267,19 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
                 if (q >= n_pass || !pass_visits(q, ip, jp, Hp, Wp)) continue;
                 const float mp = mpb[u][q];
                 const bool mp_fin = finite_f(mp);
+                if (lean && mp_fin) { // (wave uniform)
+                    if (j + D > W) {
+#pragma unroll
+                        for (int k = 0; k < R; k++) {
+                            const float t = (j + lane * R + k >= W) ? c[k] + Pout : c[k];
+                            s[k] += (c[k] + (t - mp)) - c[k];
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < R; k++) s[k] += (c[k] + (c[k] - mp)) - c[k];
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int k = 0; k < R; k++) {
                     int d = lane * R + k;
@@ -721,7 +748,7 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
 // phase 1: the per-pass min_p maps (the sequential part); phase 2: rebuild S / pick the winner per pixel
 template <class SRC, int R>
 static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
-                           const int *gate = nullptr, int gate_mask = ~0) {
+                           const int *gate = nullptr, int gate_mask = ~0, const int *regime_flag = nullptr) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
@@ -737,7 +764,7 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
         const int64_t npx = (int64_t)a.H * a.W;
         int grid = grid_for(npx, 4, 256 * 8 * 4);
         SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
-                   Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out);
+                   Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag);
         SVH_CHECK_LAUNCH(ctx);
     }
     return SVH_OK;
@@ -745,14 +772,14 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
 
 template <class SRC>
 static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
-                                const int *gate = nullptr, int gate_mask = ~0) {
+                                const int *gate = nullptr, int gate_mask = ~0, const int *regime_flag = nullptr) {
     switch (pick_R(a.D)) {
-    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
-    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
-    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
-    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
-    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask);
-    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask); // (up to 2048 disparities: 32 per lane)
+    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
+    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
+    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
+    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
+    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
+    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag); // (up to 2048 disparities: 32 per lane)
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 2048 disparities (got %d)", a.D);
     }
 }
@@ -784,6 +811,17 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
             SVH_CHECK_LAUNCH(ctx);
             SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, nullptr));
             return dispatch_cost_branch(ctx, a, src, mmap, &out, false);
+        }
+        if (two_minima && cs.float_minima && cs.float_flag) {
+            // the kernel that wrote the volume left its regional minima (CostReduce mode 2): no read of C before the apply pass
+            ScalarLines g{};
+            g.top = a.top, g.left = a.left, g.Hp = Hp, g.Wp = Wp, g.n_dir = a.n_dir;
+            const int fam_lines[5] = {Wp, n_pass > 2 ? Hp + Wp - 1 : 0, n_pass > 2 ? Wp : 0, n_pass > 2 ? Hp : 0, Hp};
+            for (int f = 0; f < 5; f++) g.first[f + 1] = g.first[f] + ceil_div(fam_lines[f], 64) * 64;
+            SVH_LAUNCH(ctx, "sgm_cost_minmap_scalar", sgm_cost_minmap_scalar_kernel, g.first[5] / 64, 64, 0, reinterpret_cast<const float2 *>(cs.float_minima), g, a.W, npx,
+                       a.Pout, mmap, cs.float_flag);
+            SVH_CHECK_LAUNCH(ctx);
+            return dispatch_cost_branch(ctx, a, src, mmap, &out, true, cs.float_flag, 2, cs.float_flag);
         }
         float *gmap = try_exact ? scr.get_n<float>((size_t)npx) : nullptr;
         float2 *minima = scr.get_n<float2>((size_t)npx);
@@ -817,7 +855,7 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
             for (int f = 0; f < 5; f++) g.first[f + 1] = g.first[f] + ceil_div(fam_lines[f], 64) * 64;
             SVH_LAUNCH(ctx, "sgm_cost_minmap_scalar", sgm_cost_minmap_scalar_kernel, g.first[5] / 64, 64, 0, minima, g, a.W, npx, a.Pout, mmap, flag);
             SVH_CHECK_LAUNCH(ctx);
-            return dispatch_cost_branch(ctx, a, src, mmap, &out, true, flag, 2); // the sweeps of the volume only when the probe saw magnitudes outside the regime
+            return dispatch_cost_branch(ctx, a, src, mmap, &out, true, flag, 2, flag); // the sweeps of the volume only when the probe saw magnitudes outside the regime
         }
         return dispatch_cost_branch(ctx, a, src, mmap, &out, true, flag);   // line kernels run only if it was raised
     }

@@ -602,6 +602,63 @@ def test_sgm_cost_branch_two_minima_route(rng):
     assert np.array_equal(host(got["disp"]), so.index_to_disp(same_cv))
 
 
+def _with_option(t, name, value, fn):
+    sv.set_option(t, name, value)
+    try:
+        return fn()
+    finally:
+        sv.set_option(t, name, 1)
+
+
+@pytest.mark.parametrize("func", [MF.SAD, MF.SSD, MF.CC, MF.NCC, MF.ZNCC, MF.ZSSD, MF.ZCC])
+def test_winner_and_minima_reduced_inside_the_cost_kernel(func):
+    """svh_stereo_match with a float matching function lets the cost kernel reduce over the disparity axis while it holds a pixel's costs
+    (option "cost_reduce_fused"): without SGM the winner -- the volume is then never written --, with a Cost-branch SGM the two regional
+    minima its recurrences run on (no probing read).  Same maps as the separate kernels (option 0) and as the oracle's selection on the
+    library's own volume: D a multiple of 16 or not, fewer disparity blocks than waves, both directions, ties, NaN costs."""
+    strat = sv.matchFuncStrategy(func)
+    for (H, W), D, r, ddir in (((37, 150), 64, 2, sv.dispDirection.RightToLeft), ((20, 130), 40, 1, sv.dispDirection.LeftToRight), ((9, 121), 200, 3, sv.dispDirection.RightToLeft),
+                               ((64, 64), 16, 2, sv.dispDirection.RightToLeft), ((5, 300), 7, 5, sv.dispDirection.RightToLeft)):
+        src, tgt, _ = parallax_pair(H, W, max(2, min(H, W) // 4), H // 4, W // 4, 2, 9, seed=H + W + D)
+        src, tgt = src[:H, :W].copy(), tgt[:H, :W].copy()
+        l, r_ = dev(tgt), dev(src)
+        run = lambda **kw: sv.stereoMatch(func, l, r_, r, r, D, dDir=ddir, **kw)  # noqa: E731
+        sv.profile_reset(l)
+        sv.profile_enable(l, True)
+        a = run()
+        sv.profile_enable(l, False)
+        kernels = sv.profile_collect(l)
+        b = _with_option(l, "cost_reduce_fused", 0, run)
+        if func != MF.ZSAD and r <= 5:
+            assert "extract_index" not in kernels and "index_to_disp" not in kernels, kernels.keys()
+        assert np.array_equal(host(a["disp"]), host(b["disp"])), (func, H, W, D)
+        full = run(want_cv=True)
+        assert np.array_equal(host(full["disp"]), host(a["disp"]))
+        exp = so.index_to_disp(so.extract_index(host(full["cv"]), strat), int(ddir))
+        assert np.array_equal(host(a["disp"]), exp)
+        if int(strat) == so.COST:  # Cost-branch SGM on the float volume: minima from the cost kernel
+            sgm_on = lambda **kw: sv.stereoMatch(func, l, r_, r, r, D, dDir=ddir, sgmDirections=8, P1=0.01, P2=0.1, Pout=3.5, **kw)  # noqa: E731
+            sv.profile_reset(l)
+            sv.profile_enable(l, True)
+            c = sgm_on(want_sgm_cv=True, want_cv=True)
+            sv.profile_enable(l, False)
+            kernels = sv.profile_collect(l)
+            assert "sgm_volume_probe" not in kernels and "sgm_cost_minmap_scalar" in kernels, kernels.keys()
+            d_ = _with_option(l, "cost_reduce_fused", 0, lambda: sgm_on(want_sgm_cv=True))
+            assert np.array_equal(host(c["disp"]), host(d_["disp"]))
+            assert_bits(c["sgm_cv"], host(d_["sgm_cv"]))
+            assert_bits(c["sgm_cv"], so.sgm(host(c["cv"]), 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 3.5, variant=0))
+    # ties everywhere (constant images: the larger index wins) and NaN costs (NCC of an all-zero image: index 0)
+    flat = dev(np.full((12, 140), 0.25, np.float32))
+    zero = dev(np.zeros((12, 140), np.float32))
+    for img in (flat, zero):
+        a = sv.stereoMatch(func, img, img, 2, 2, 48)
+        b = _with_option(img, "cost_reduce_fused", 0, lambda: sv.stereoMatch(func, img, img, 2, 2, 48))
+        assert np.array_equal(host(a["disp"]), host(b["disp"]))
+        cvh = host(sv.stereoMatch(func, img, img, 2, 2, 48, want_cv=True)["cv"])
+        assert np.array_equal(host(a["disp"]), so.index_to_disp(so.extract_index(cvh, strat)))
+
+
 # ------------------------------------------------------------------------------------------------ randomised sweep
 def test_random_configurations_against_oracle():
     """Seeded random shapes / windows / ranges / margins / penalties through the fused pipeline and the per-function

@@ -27,6 +27,10 @@ CONFIGS = {
     "c4w4000": (4000, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
     "c4w4160": (4160, 2160, 256, MF.NCC, 5, 5, 8, IK.Parabola, (640, 640, 760, 16, 128, 4), {}),
     "c4small": (1024, 540, 256, MF.NCC, 5, 5, 8, IK.Parabola, (160, 160, 190, 4, 32, 4), {}),
+    # float costs through the fused call: winner / regional minima reduced inside the cost kernel (no volume read back)
+    "sad_sgm": (1920, 1080, 256, MF.SAD, 2, 2, 8, None, (320, 320, 380, 8, 64, 3), {}),
+    "ncc_argmax": (1920, 1080, 256, MF.NCC, 5, 5, 0, None, (320, 320, 380, 8, 64, 3), {}),
+    "sad_argmin": (1920, 1080, 256, MF.SAD, 2, 2, 0, None, (320, 320, 380, 8, 64, 3), {}),
     "c5slice": (8192, 4320, 64, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),
     "c5": (8192, 4320, 512, MF.CENSUS, 4, 4, 8, None, (1280, 1280, 1520, 32, 256, 5), {}),  # the whole range on one GPU
 }

@@ -71,12 +71,22 @@ __device__ __forceinline__ float cost_step_lane_min(const float (&c)[R], int lan
     return lm;
 }
 
+// the lines of all the passes of one aggregation in one launch: pass q owns blocks [first_block[q], first_block[q + 1]) (four lines each)
+struct PassSets {
+    LineSet ls[6];
+    int first_block[7];
+    int n_pass;
+};
 template <class SRC, int R, int B>
-__global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, LineSet ls, int D, int W, float Pout,
-                                                             float *__restrict__ mmap, const int *__restrict__ gate, int gate_mask) {
+__global__ void __launch_bounds__(256) sgm_cost_minmap_kernel(SRC src, PassSets sets, int D, int W, int64_t npx, float Pout,
+                                                             float *__restrict__ mmap_base, const int *__restrict__ gate, int gate_mask) {
     if (gate && (*gate & gate_mask) == 0) return; // another route already produced the maps (exact-integer scans / the two-minima recurrences)
     const int lane = threadIdx.x & 63;
-    const int l = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int q = 0;
+    while (q + 1 < sets.n_pass && (int)blockIdx.x >= sets.first_block[q + 1]) q++; // (block uniform)
+    const LineSet ls = sets.ls[q];
+    float *__restrict__ mmap = mmap_base + (int64_t)min_p_plane(q) * npx;
+    const int l = ((int)blockIdx.x - sets.first_block[q]) * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (l >= ls.n_lines) return;
     const Line L = line_of(ls, l);
     float mp = 0.0f; // previous_cost[] = 0 -> min over finite = 0 (sgm.h:206-208)
@@ -440,52 +450,73 @@ struct ScalarLines {
     int first[6]; // lanes of family f: [first[f], first[f + 1]), each family padded to whole waves
     int n_dir;    // 4: families 0 and 4 only
 };
-__device__ __forceinline__ float cost_step_two_minima(float2 m, float Pout, float mp) {
-    const bool mp_fin = finite_f(mp);
-    float next = INFINITY;
-    {
-        const float c = m.x, t = c;
-        float act = c;
-        if (mp_fin && finite_f(t)) act = c + (t - mp);
-        if (finite_f(act)) next = fminf(next, act);
-    }
-    {
-        const float c = m.y, t = c + Pout;
-        float act = c;
-        if (mp_fin && finite_f(t)) act = c + (t - mp);
-        if (finite_f(act)) next = fminf(next, act);
-    }
+// One step on two minima.  The kernel only runs in the regime the probe established (bit 1 of the flag down: every finite |c| <= 1e30, so
+// a minimum is a finite number of that size or +inf for a region without a finite cost -- never NaN, never -inf -- and mp, a minimum of
+// sums of such numbers, is finite or +inf and cannot overflow along a line of 10^5 pixels), which removes most of the per-disparity
+// step's finiteness tests: an infinite minimum yields an infinite sum, which the final minimum ignores by itself.  What remains of
+// sgm.h:259-295: act = (mp finite [and t finite]) ? c + (t - mp) : c, with t = c for the first region and c + Pout for the second
+// (t is finite iff Pout is, for a finite c; for c = +inf either form gives +inf).
+__device__ __forceinline__ float cost_step_two_minima(float2 m, float Pout, bool pout_fin, float mp, bool mp_fin) {
+    const float a_in = mp_fin ? m.x + (m.x - mp) : m.x;
+    const float a_out = (mp_fin && pout_fin) ? m.y + ((m.y + Pout) - mp) : m.y;
+    float next; // (no NaN can reach this minimum: the plain instruction, without the canonicalising v_max pair fminf() puts on the chain)
+    asm("v_min_f32 %0, %1, %2" : "=v"(next) : "v"(a_in), "v"(a_out));
     return next;
 }
 __global__ void __launch_bounds__(64) sgm_cost_minmap_scalar_kernel(const float2 *__restrict__ minima, ScalarLines g, int W, int64_t npx, float Pout,
                                                                     float *__restrict__ mmap, const int *__restrict__ gate) {
-    if (gate) {
+    {
         const int f = *gate;
         if (f == 0 || (f & 2)) return; // exact-integer scans made the maps / magnitudes outside the regime: the volume sweeps make them
     }
-    const int gl = blockIdx.x * 64 + threadIdx.x;
+    // (families are padded to whole waves: the family is a function of the block alone, and written as one -- with the lane in it the
+    // compiler took the buffer resources below for per-lane values and wrapped every access in a waterfall loop)
+    const int block_first = blockIdx.x * 64;
     int fam = 0;
-    while (fam < 4 && gl >= g.first[fam + 1]) fam++; // (block-uniform: families are padded to whole waves)
-    const int l = gl - g.first[fam];
-    // The loads do not depend on the recurrence: two register batches of PF steps alternate, the next batch's minima are in flight
-    // while the chain walks the current one (a lane's chain is ~50 cycles a step; a batch must outlast a memory round trip).
+    while (fam < 4 && block_first >= g.first[fam + 1]) fam++;
+    const int l = block_first - g.first[fam] + (int)threadIdx.x;
+    const bool pout_fin = finite_f(Pout);
+    // Addresses as 32-bit byte offsets into two buffer resources (the host keeps npx * 8 below 2^32): a step is one add per array, a
+    // load past either end returns zeros and a store there is dropped, so a lane that is not on its line yet (or any more) needs no
+    // branch -- its store offset is parked out of range.  The loads do not depend on the recurrence: two register batches of PF steps
+    // alternate, the next batch's minima are in flight while the chain walks the current one.
+    const __amdgpu_buffer_rsrc_t rs_min = __builtin_amdgcn_make_buffer_rsrc((void *)minima, 0, (int)(npx * 8), 0x00020000);
     constexpr int PF = 24;
     float mp = 0.0f; // previous_cost[] = 0 -> min over finite = 0 (sgm.h:206-208)
-    if (fam == 4) { // Left2Right: lane = row
-        if (l >= g.Hp) return;
-        const int64_t base = (int64_t)(g.top + l) * W + g.left;
-        float *plane = mmap + (int64_t)min_p_plane(1) * npx + base;
-        const float2 *src = minima + base;
+    bool mp_fin = true;
+    if (fam == 4) { // Left2Right: lane = row; a lane's minima and map entries are contiguous in memory by themselves
+        const __amdgpu_buffer_rsrc_t rs_map = __builtin_amdgcn_make_buffer_rsrc((void *)(mmap + (int64_t)min_p_plane(1) * npx), 0, (int)(npx * 4), 0x00020000);
+        const bool mine = l < g.Hp;
+        const uint32_t px0 = (uint32_t)((g.top + min(l, g.Hp - 1)) * W + g.left);
+        // (lanes are rows here: every access of the wave touches 64 different cache lines, and the texture path takes them one at a
+        // time -- with one 8-byte load and one 4-byte store per step that, not the recurrence, set the pace (170 cycles a step).  Two
+        // steps per load and four per store: 16-byte accesses.)
         auto load = [&](float2 (&m)[PF], int t0) {
 #pragma unroll
-            for (int u = 0; u < PF; u++) m[u] = src[min(t0 + u, g.Wp - 1)];
+            for (int u = 0; u < PF; u += 2) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_min, (px0 + (uint32_t)(t0 + u)) * 8u, 0, 0); // (past the row: unused; past the map: zeros)
+                m[u] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+                m[u + 1] = make_float2(__uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
         };
         auto walk = [&](const float2 (&m)[PF], int t0) {
 #pragma unroll
-            for (int u = 0; u < PF; u++) {
-                if (t0 + u < g.Wp) {
-                    plane[t0 + u] = mp;
-                    mp = cost_step_two_minima(m[u], Pout, mp);
+            for (int u0 = 0; u0 < PF; u0 += 4) {
+                if (t0 + u0 >= g.Wp) break; // (wave uniform)
+                float out[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    out[u] = mp;
+                    mp = cost_step_two_minima(m[u0 + u], Pout, pout_fin, mp, mp_fin);
+                    mp_fin = mp < INFINITY;
+                }
+                const uint32_t off = mine ? (px0 + (uint32_t)(t0 + u0)) * 4u : 0xFFFFFFFFu;
+                if (t0 + u0 + 4 <= g.Wp) { // (wave uniform)
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 ov = {__float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rs_map, off, 0, 0);
+                } else { // the row's last one to three pixels (the steps past them ran on values nobody uses)
+                    for (int u = 0; t0 + u0 + u < g.Wp; u++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out[u]), rs_map, mine ? off + 4u * u : off, 0, 0);
                 }
             }
         };
@@ -499,9 +530,9 @@ __global__ void __launch_bounds__(64) sgm_cost_minmap_scalar_kernel(const float2
         }
         return;
     }
-    // row-walking families: column of this lane's line on row r (relative to the margin box), and the rows it crosses
+    // row-walking families: the wave walks rows, the lanes sit on consecutive columns of the row (see the table above)
     const int q = fam == 0 ? 0 : (fam == 1 ? 2 : (fam == 2 ? 4 : 5));
-    float *plane = mmap + (int64_t)min_p_plane(q) * npx;
+    const __amdgpu_buffer_rsrc_t rs_map = __builtin_amdgcn_make_buffer_rsrc((void *)(mmap + (int64_t)min_p_plane(q) * npx), 0, (int)(npx * 4), 0x00020000);
     const int k = fam == 1 ? l - (g.Hp - 1) : l; // family 1: k = j - i
     int r_first, r_last, lines;                  // rows of the line, in walking order r_first -> r_last
     switch (fam) {
@@ -522,23 +553,34 @@ __global__ void __launch_bounds__(64) sgm_cost_minmap_scalar_kernel(const float2
     default: w_first = min(wl1, g.Hp - 1); w_last = max(0, wl0 - (g.Wp - 1)); break;
     }
     const int n_rows = (w_last - w_first) * dir + 1;
-    auto column = [&](int r) { return fam == 0 ? l : (fam == 1 ? r + k : l - r); };
-    auto active = [&](int r) { return mine && (r - r_first) * dir >= 0 && (r_last - r) * dir >= 0; };
+    const int col_first = fam == 0 ? l : (fam == 1 ? r_first + k : l - r_first); // the line's column on its first row
+    const int dcol = fam == 0 ? 0 : (fam == 1 ? 1 : (fam == 2 ? -1 : 1));         // and how it moves per step
+    const int stride = dir * W + dcol;                                             // pixel index step of the line
+    const int s_begin = (r_first - w_first) * dir;                                 // the wave step at which this lane's line starts
+    const int len = mine ? (r_last - r_first) * dir + 1 : 0;
+    // pixel index at wave step s: px_first + (s - s_begin) * stride (two's-complement arithmetic: out of range when not on the line)
+    const uint32_t px_at_0 = (uint32_t)((g.top + r_first) * W + g.left + col_first) - (uint32_t)s_begin * (uint32_t)stride;
     auto load = [&](float2 (&m)[PF], int s0) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const int r = w_first + min(s0 + u, n_rows - 1) * dir;
-            const int c = min(max(column(r), 0), g.Wp - 1); // (inactive lanes load a clamped address: every load unconditional, the count of loads in flight stays exact)
-            m[u] = minima[(int64_t)(g.top + r) * W + g.left + c];
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_min, (px_at_0 + (uint32_t)(s0 + u) * (uint32_t)stride) * 8u, 0, 0);
+            m[u] = make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
         }
     };
     auto walk = [&](const float2 (&m)[PF], int s0) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const int r = w_first + (s0 + u) * dir;
-            if (s0 + u < n_rows && active(r)) {
-                plane[(int64_t)(g.top + r) * W + g.left + column(r)] = mp;
-                mp = cost_step_two_minima(m[u], Pout, mp);
+            const int s = s0 + u;
+            if (s < n_rows) { // (wave uniform)
+                const unsigned rel = (unsigned)(s - s_begin);
+                const bool on = rel < (unsigned)len;
+                if (rel == 0u) { // the line's first pixel sees previous_cost[] = 0
+                    mp = 0.0f;
+                    mp_fin = true;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mp), rs_map, on ? (px_at_0 + (uint32_t)s * (uint32_t)stride) * 4u : 0xFFFFFFFFu, 0, 0);
+                mp = cost_step_two_minima(m[u], Pout, pout_fin, mp, mp_fin);
+                mp_fin = mp < INFINITY;
             }
         }
     };
@@ -752,13 +794,17 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
-    if (do_minmaps && Hp > 0 && Wp > 0) {
+    if (do_minmaps && Hp > 0 && Wp > 0 && n_pass > 0) {
+        // one launch for the lines of every pass (they are independent: a pass's map depends on the volume alone)
+        PassSets sets{};
+        sets.n_pass = n_pass;
         for (int q = 0; q < n_pass; q++) {
-            LineSet ls{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
-            SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), ceil_div(ls.n_lines, 4), 256, 0, src, ls, a.D, a.W,
-                       a.Pout, mmap + (size_t)min_p_plane(q) * a.H * a.W, gate, gate_mask);
-            SVH_CHECK_LAUNCH(ctx);
+            sets.ls[q] = LineSet{q, pass_lines(q, Hp, Wp), a.top, a.left, Hp, Wp};
+            sets.first_block[q + 1] = sets.first_block[q] + ceil_div(sets.ls[q].n_lines, 4);
         }
+        SVH_LAUNCH(ctx, "sgm_cost_minmap", (sgm_cost_minmap_kernel<SRC, R, B>), sets.first_block[n_pass], 256, 0, src, sets, a.D, a.W, (int64_t)a.H * a.W, a.Pout, mmap,
+                   gate, gate_mask);
+        SVH_CHECK_LAUNCH(ctx);
     }
     if (out) {
         const int64_t npx = (int64_t)a.H * a.W;
@@ -799,7 +845,7 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
         const bool try_exact = ctx->census_fast_path && (int64_t)a.H * a.W < (1ll << 31) && n_pass > 0 && Hp > 0 && Wp > 0 && std::isfinite(a.Pout) &&
                                a.Pout == std::nearbyint(a.Pout) && limit >= 1.0 && a.D <= 1024;
         // the two-minima recurrences (sgm_cost_minmap_scalar_kernel) need magnitudes that cannot overflow along a line
-        const bool two_minima = ctx->sgm_cost_two_minima && (int64_t)a.H * a.W < (1ll << 31) && n_pass > 0 && Hp > 0 && Wp > 0 && (!std::isfinite(a.Pout) || std::fabs(a.Pout) <= SGM_SAFE_MAGNITUDE) &&
+        const bool two_minima = ctx->sgm_cost_two_minima && (int64_t)a.H * a.W < (1ll << 28) && n_pass > 0 && Hp > 0 && Wp > 0 && (!std::isfinite(a.Pout) || std::fabs(a.Pout) <= SGM_SAFE_MAGNITUDE) &&
                                 std::max(a.H, a.W) <= 100000 && a.D <= 1024;
         if (!try_exact && !two_minima) return dispatch_cost_branch(ctx, a, src, mmap, &out, true);
         const int64_t npx = (int64_t)a.H * a.W;

@@ -211,7 +211,8 @@ def other_configs(sv, dev, cpu_legs=True):
     ms, res = _time_steps(fn, 50)
     c = {"workload": "480x360 synthetic pair, SAD 5x5 cost volume, D=64, argmin (BASELINE.json configs[0]; stands in for SimStereo)", "ms": round(ms, 4),
          "Mdisparities_per_s": round(W * H * D / ms / 1e3, 1), "kernel_ms": _kernel_ms(sv, d_src, fn, 20),
-         "roofline": hbm(8.0 * W * H * D + 12.0 * W * H, ms, "C written and read once as float32 (8 B/voxel) + 12 B/pixel")}
+         "roofline": hbm(12.0 * W * H, ms, "12 B/pixel (two images in, the disparity map out): the winner comes out of the cost kernel, the volume is never written "
+                                           "(SURVEY.md 8(d) has no byte model for C1; a design that materialises C moves 8 B/voxel more)")}
     if cpu_legs:
         t1 = time.perf_counter()
         reps = 5

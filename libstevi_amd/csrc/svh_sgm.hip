@@ -248,17 +248,29 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
     // and a finite c cannot overflow t.  Four operations per voxel and pass instead of eight: with the winner fused behind it this kernel
     // is bound by vector issue, not by its one read of the volume.
     const bool lean = regime_flag && (*regime_flag & 2) == 0 && finite_f(Pout);
-    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // (pixel indices are wave-uniform and fit 32 bits -- the library takes images of fewer than 2^31 pixels: kept scalar, one division per
+    // APPLY_PB pixels instead of two 64-bit ones per pixel and lane)
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int npx32 = (int)npx;
     // APPLY_PB pixels per wave iteration: their cost rows and min_p values are all requested before the first one is used
     // (one pixel at a time leaves a single 1 KiB load in flight per wave and the kernel latency-bound)
     constexpr int APPLY_PB = 4, MAX_PASS = 6;
-    for (int64_t p0 = wave * APPLY_PB; p0 < npx; p0 += nwaves * APPLY_PB) {
+    for (int p0 = wave * APPLY_PB; p0 < npx32; p0 += nwaves * APPLY_PB) {
       float cb[APPLY_PB][R], mpb[APPLY_PB][MAX_PASS];
+      const int i0 = (int)((unsigned)p0 / (unsigned)W), j0 = p0 - i0 * W;
+      int iu[APPLY_PB], ju[APPLY_PB];
 #pragma unroll
       for (int u = 0; u < APPLY_PB; u++) {
-          const int64_t pu = min(p0 + u, npx - 1);
-          src.template load<R>((int)(pu / W), (int)(pu % W), lane, cb[u]);
+          const int pu = min(p0 + u, npx32 - 1);
+          int jj = j0 + (pu - p0), ii = i0;
+          while (jj >= W) { // (an image narrower than APPLY_PB pixels wraps more than once)
+              jj -= W;
+              ii++;
+          }
+          iu[u] = ii;
+          ju[u] = jj;
+          src.template load<R>(ii, jj, lane, cb[u]);
 #pragma unroll
           for (int q = 0; q < MAX_PASS; q++) mpb[u][q] = q < n_pass ? mmap[(int64_t)min_p_plane(q) * npx + pu] : 0.0f;
       }
@@ -266,7 +278,7 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
       for (int u = 0; u < APPLY_PB; u++) {
         const int64_t p = p0 + u;
         if (p >= npx) break;
-        const int j = (int)(p % W), i = (int)(p / W);
+        const int j = ju[u], i = iu[u];
         float c[R], s[R];
 #pragma unroll
         for (int k = 0; k < R; k++) s[k] = c[k] = cb[u][k]; // sgm_cv := cv, sgm.h:371-377

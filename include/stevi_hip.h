@@ -164,6 +164,8 @@ int svh_context_get_device(const svh_context *ctx);
 int svh_device_free_detached(int device, void *ptr);
 int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes);
 int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes);
+/* device -> device, enqueued on the context's stream (no wait) */
+int svh_device_copy(svh_context *ctx, void *device_dst, const void *device_src, size_t bytes);
 
 /* Per-kernel timing with hipEvents on the context's stream.  While enabled, every kernel launch is
  * bracketed by two events; svh_profile_collect() synchronises and folds them into per-kernel totals. */
@@ -247,6 +249,15 @@ int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strategy, const 
  * the tensor's version counter.  Score strategy: minima are ignored. */
 int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
                                float P1, float P2, const int32_t margins[4], float Pout, svh_array *out);
+/* The same (minima may be NULL: then exactly svh_sgm_cost_volume) with a by-product for a later extractSelectedIndex<strategy> on `out`:
+ * winner_idx (H,W) i32 = the index that call would return.  The kernel that writes a pixel's final aggregated costs holds them in one
+ * wave, so its winner costs a few instructions there against a second read of the whole volume (4 bytes per voxel) later.
+ * *winner_written = 1 when the map was produced (Cost strategy: always; Score strategy: when the banded sweep applies -- whole image, 8
+ * directions, P2 >= P1 >= 0, at most 512 disparities, a multiple of 64 --, else 0 and winner_idx is left untouched).  Like the minima it
+ * is a statement about `out` that the caller must not let outlive its contents (DeviceArray keeps it with the storage). */
+int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
+                               float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx,
+                               int *winner_written);
 
 /* "Textbook" semi-global matching -- NOT the reference's behaviour, an explicit second mode:
  * every one of the 4 / 8 directions traverses every line of the margin box once (the reference skips three directions and half of

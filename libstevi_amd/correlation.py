@@ -365,10 +365,12 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
 
 
 def dropMinima(cv):
-    """Withdraw the statement unfoldBasedCostVolume(..., keep_minima=True) left with `cv` (call it after writing to the volume by a route
-    torch's version counter does not see)."""
+    """Withdraw the statements unfoldBasedCostVolume(..., keep_minima=True) / sgmCostVolume(..., keep_winner=True) left with `cv` (call it
+    after writing to the volume by a route torch's version counter does not see)."""
     if getattr(cv, "_svh_minima", None) is not None:
         cv._svh_minima = None
+    if getattr(cv, "_svh_winner", None) is not None:
+        cv._svh_winner = None
 
 
 def _volume_minima(cv):
@@ -383,10 +385,17 @@ def _volume_minima(cv):
     return minima, max_abs
 
 
-def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0, semantics="reference"):
+def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0, semantics="reference", keep_winner=False):
     """sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout) -- correlation/sgm.h:360-404, as written.
     semantics="textbook" selects the explicit second mode (every direction fully traversed, neighbour penalties in the Cost
-    strategy): NOT the reference's result, see svh_sgm_cost_volume_textbook in include/stevi_hip.h."""
+    strategy): NOT the reference's result, see svh_sgm_cost_volume_textbook in include/stevi_hip.h.
+
+    keep_winner (device tensors; off by default): also keep, with the returned tensor, the index map a later
+    extractSelectedIndex(strategy, ...) on it returns -- the kernel that writes a pixel's final aggregated costs picks it while it holds
+    them (svh_sgm_cost_volume_winner) -- so that call hands back a copy of the map instead of reading the volume again.  Like the minima
+    of unfoldBasedCostVolume(keep_minima=True) the statement is checked against the tensor's storage pointer, shape, strides and version
+    counter and cannot see writes that bypass torch's counter (`.data`, other frameworks' kernels on data_ptr(), DLPack, raw C-ABI calls):
+    dropMinima(out) withdraws it."""
     lib = _capi.load()
     cv = _prep_volume(cv_base)
     ctx = context_for(cv)
@@ -395,6 +404,15 @@ def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None
     if semantics not in ("reference", "textbook"):
         raise ValueError("semantics is 'reference' or 'textbook'")
     hint = _volume_minima(cv_base) if (semantics == "reference" and int(extractionStrategy) == dispExtractionStartegy.Cost) else None
+    if semantics == "reference" and keep_winner and _is_torch(out):
+        widx = _like(cv, tuple(cv.shape[:2]), "i32")
+        written = C.c_int(0)
+        _check(ctx, lib.svh_sgm_cost_volume_winner(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)),
+                                                   C.byref(_desc(hint[0])) if hint is not None else None, C.c_float(hint[1] if hint is not None else 0.0), P1, P2,
+                                                   (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out)), C.byref(_desc(widx)), C.byref(written)))
+        if written.value:
+            out._svh_winner = (widx, int(extractionStrategy), out.data_ptr(), out._version, tuple(out.shape))
+        return out
     if hint is not None:  # same bits, one read of the volume less (svh_sgm_cost_volume_minima)
         _check(ctx, lib.svh_sgm_cost_volume_minima(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), C.byref(_desc(hint[0])),
                                                    C.c_float(hint[1]), P1, P2, (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out))))
@@ -407,6 +425,12 @@ def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None
 def extractSelectedIndex(strategy, costVolume):
     """extractSelectedIndex<strategy> -- correlation/correlation_base.h:427-464."""
     lib = _capi.load()
+    hint = getattr(costVolume, "_svh_winner", None) if _is_torch(costVolume) else None
+    if hint is not None:  # the volume came from sgmCostVolume(keep_winner=True) and has not been written to since: its winner travels with it
+        widx, strat, ptr, version, shape = hint
+        if (strat == int(strategy) and costVolume.data_ptr() == ptr and costVolume._version == version and tuple(costVolume.shape) == shape and
+                costVolume.is_contiguous()):
+            return widx.clone()
     cv = _prep(costVolume, np.float32)
     ctx = context_for(cv)
     out = _like(cv, tuple(cv.shape[:2]), "i32")

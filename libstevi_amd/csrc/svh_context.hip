@@ -511,6 +511,13 @@ int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src
     return SVH_OK;
 }
 
+int svh_device_copy(svh_context *ctx, void *device_dst, const void *device_src, size_t bytes) {
+    if (!ctx || (bytes && (!device_dst || !device_src))) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    SVH_HIP_CHECK(ctx, hipMemcpyAsync(device_dst, device_src, bytes, hipMemcpyDeviceToDevice, ctx->stream)); // (stream-ordered like the kernels: no wait)
+    return SVH_OK;
+}
+
 const char *svh_status_string(int status) {
     switch (status) {
     case SVH_OK: return "ok";

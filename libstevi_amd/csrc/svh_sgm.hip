@@ -240,14 +240,15 @@ struct ApplyOut {
 template <class SRC, int R>
 __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int W, int D, int top, int left, int Hp, int Wp,
                                                             int n_pass, float Pout, const float *__restrict__ mmap,
-                                                            ApplyOut out, const int *__restrict__ regime_flag) {
+                                                            ApplyOut out, const int *__restrict__ regime_flag, int regime_vouched) {
     const int lane = threadIdx.x & 63;
     const int64_t npx = (int64_t)H * W;
     // In the regime the two-minima route established (no finite |c| above 1e30: bit 1 of the flag down) and with a finite Pout (then
     // |Pout| <= 1e30) `isfinite(t)` is redundant once mp is finite: for a non-finite c the sum c + (t - mp) IS c (same-signed infinities; NaN stays NaN)
     // and a finite c cannot overflow t.  Four operations per voxel and pass instead of eight: with the winner fused behind it this kernel
     // is bound by vector issue, not by its one read of the volume.
-    const bool lean = regime_flag && (*regime_flag & 2) == 0 && finite_f(Pout);
+    // (regime_vouched: the host knows already -- small integer costs stated by the caller, svh_sgm_cost_volume_minima)
+    const bool lean = (regime_vouched || (regime_flag && (*regime_flag & 2) == 0)) && finite_f(Pout);
     // (pixel indices are wave-uniform and fit 32 bits -- the library takes images of fewer than 2^31 pixels: kept scalar, one division per
     // APPLY_PB pixels instead of two 64-bit ones per pixel and lane)
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -802,7 +803,7 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
 // phase 1: the per-pass min_p maps (the sequential part); phase 2: rebuild S / pick the winner per pixel
 template <class SRC, int R>
 static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
-                           const int *gate = nullptr, int gate_mask = ~0, const int *regime_flag = nullptr) {
+                           const int *gate = nullptr, int gate_mask = ~0, const int *regime_flag = nullptr, bool regime_vouched = false) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
     const int n_pass = a.n_dir >= 8 ? 6 : (a.n_dir >= 4 ? 2 : 0); // n_dir == 0: no aggregation, S = C
     constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
@@ -822,7 +823,7 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
         const int64_t npx = (int64_t)a.H * a.W;
         int grid = grid_for(npx, 4, 256 * 8 * 4);
         SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
-                   Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag);
+                   Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag, regime_vouched ? 1 : 0);
         SVH_CHECK_LAUNCH(ctx);
     }
     return SVH_OK;
@@ -830,14 +831,14 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
 
 template <class SRC>
 static int dispatch_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, float *mmap, const ApplyOut *out, bool do_minmaps,
-                                const int *gate = nullptr, int gate_mask = ~0, const int *regime_flag = nullptr) {
+                                const int *gate = nullptr, int gate_mask = ~0, const int *regime_flag = nullptr, bool regime_vouched = false) {
     switch (pick_R(a.D)) {
-    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
-    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
-    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
-    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
-    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag);
-    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag); // (up to 2048 disparities: 32 per lane)
+    case 1: return run_cost_branch<SRC, 1>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag, regime_vouched);
+    case 2: return run_cost_branch<SRC, 2>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag, regime_vouched);
+    case 4: return run_cost_branch<SRC, 4>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag, regime_vouched);
+    case 8: return run_cost_branch<SRC, 8>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag, regime_vouched);
+    case 16: return run_cost_branch<SRC, 16>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag, regime_vouched);
+    case 32: return run_cost_branch<SRC, 32>(ctx, a, src, mmap, out, do_minmaps, gate, gate_mask, regime_flag, regime_vouched); // (up to 2048 disparities: 32 per lane)
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "SGM supports at most 2048 disparities (got %d)", a.D);
     }
 }
@@ -868,7 +869,7 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
             SVH_LAUNCH(ctx, "gmap_from_minima", gmap_from_minima_kernel, grid_for(npx, 256), 256, 0, reinterpret_cast<const float2 *>(cs.minima), npx, a.Pout, gmap);
             SVH_CHECK_LAUNCH(ctx);
             SVH_TRY(dev_census_scans(ctx, a, nullptr, gmap, true, mmap, nullptr));
-            return dispatch_cost_branch(ctx, a, src, mmap, &out, false);
+            return dispatch_cost_branch(ctx, a, src, mmap, &out, false, nullptr, ~0, nullptr, true); // (small integers: inside the regime by the caller's statement)
         }
         if (two_minima && cs.float_minima && cs.float_flag) {
             // the kernel that wrote the volume left its regional minima (CostReduce mode 2): no read of C before the apply pass
@@ -1054,8 +1055,14 @@ int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const
 using namespace svh;
 
 static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs, float P1, float P2,
-                                const int32_t margins[4], float Pout, svh_array *out) {
+                                const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx = nullptr, int *winner_written = nullptr) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (winner_written) *winner_written = 0;
+    if (winner_idx) {
+        SVH_TRY(validate(ctx, winner_idx, "winner_idx", SVH_I32, 2, 2));
+        if (!winner_written) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "winner_idx needs winner_written");
+        if (winner_idx->shape[0] != cv->shape[0] || winner_idx->shape[1] != cv->shape[1]) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "winner_idx must have shape (H,W)");
+    }
     SVH_TRY(validate_volume(ctx, cv, "cv")); // (T_CV: float or an integer type the reference casts to float as it reads, sgm.h:234, :273, :299)
     SVH_TRY(validate(ctx, out, "out", SVH_F32, 3, 3));
     if (minima && cv->dtype != SVH_F32) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "the minima statement goes with a float32 volume");
@@ -1076,6 +1083,8 @@ static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy
     OutStage os;
     SVH_TRY(stage_volume_as_float(ctx, scr, *cv, &dcv));
     SVH_TRY(stage_out(ctx, scr, *out, &os));
+    OutStage ow;
+    if (winner_idx) SVH_TRY(stage_out(ctx, scr, *winner_idx, &ow));
     if (strategy == SVH_COST) {
         CostSource cs;
         cs.cv = (const float *)dcv;
@@ -1089,11 +1098,26 @@ static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy
             cs.minima = (const float *)dmin;
             cs.max_abs = max_abs;
         }
-        SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, WinnerOut()));
+        // the kernel that writes S holds a pixel's aggregated costs in one wave: its winner is a by-product (extractSelectedIndex's rule)
+        WinnerOut w;
+        if (winner_idx) w.idx = (int32_t *)ow.dptr;
+        SVH_TRY(dev_sgm_cost_branch(ctx, scr, a, cs, (float *)os.dptr, w));
+        if (winner_idx) *winner_written = 1;
     } else {
         if (os.dptr == dcv) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "cv and out must not alias");
-        SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr, false));
+        ScoreFinish fin;
+        if (winner_idx) {
+            fin.records = scr.get_n<float>((size_t)a.H * a.W * 4);
+            if (!fin.records) return SVH_ERR_OUT_OF_MEMORY;
+            fin.store_all = true;
+        }
+        SVH_TRY(dev_sgm_score_branch(ctx, scr, a, (const float *)dcv, (float *)os.dptr, false, winner_idx ? &fin : nullptr));
+        if (winner_idx && fin.done) { // (the banded sweep ran: the last writer of every pixel left a record)
+            SVH_TRY(dev_finish_records(ctx, fin.records, (int64_t)a.H * a.W, -1, 1, 0, (int32_t *)ow.dptr, nullptr, nullptr));
+            *winner_written = 1;
+        }
     }
+    if (winner_idx) SVH_TRY(finish_out(ctx, ow));
     return finish_out(ctx, os);
 }
 
@@ -1105,6 +1129,11 @@ extern "C" int svh_sgm_cost_volume(svh_context *ctx, int n_directions, int strat
 extern "C" int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
                                           float P1, float P2, const int32_t margins[4], float Pout, svh_array *out) {
     return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, minima, max_abs, P1, P2, margins, Pout, out);
+}
+
+extern "C" int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
+                                          float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx, int *winner_written) {
+    return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, minima, max_abs, P1, P2, margins, Pout, out, winner_idx, winner_written);
 }
 
 // "Textbook" semi-global matching: NOT the reference's behaviour -- what correlation/sgm.h

@@ -164,6 +164,15 @@ using HipBridge::DeviceArray;
 template <dispExtractionStartegy strategy, class T_CV> DeviceArray<disp_t, 2> extractSelectedIndex(DeviceArray<T_CV, 3> const &costVolume) {
     DeviceArray<disp_t, 2> disp({costVolume.shape()[0], costVolume.shape()[1]});
     if (disp.empty()) return disp;
+    if constexpr (std::is_same_v<std::remove_const_t<T_CV>, float> && std::is_same_v<disp_t, int32_t>) {
+        // an aggregated volume sgmCostVolume wrote and nobody has touched since carries its winner (stevi_hip_bridge.h: Statement): a copy of
+        // that map (the caller may write to what it gets) instead of a scan of the volume
+        auto known = costVolume.statement();
+        if (known && known->winner && known->winner_strategy == static_cast<int>(strategy)) {
+            HipBridge::check(svh_device_copy(HipBridge::context(), disp.data(), known->winner.get(), disp.flatLenght() * sizeof(disp_t)));
+            return disp;
+        }
+    }
     svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
     HipBridge::check(svh_extract_selected_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
     return disp;

@@ -40,9 +40,10 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
     auto known = cv_base.statement(); // one read: the statement is shared by every handle of the memory and may be dropped through another
-    if (extractionStrategy == dispExtractionStartegy::Cost && known) {
-        // a volume the library wrote and nobody has touched: its regional minima come with it, the probe pass over the volume is skipped
-        svh_array mn{};
+    // a volume the library wrote and nobody has touched: its regional minima come with it, the probe pass over the volume is skipped
+    const bool with_minima = extractionStrategy == dispExtractionStartegy::Cost && known && known->minima;
+    svh_array mn{};
+    if (with_minima) {
         mn.data = const_cast<float *>(known->minima.get()); // (svh_array has one pointer type; the call only reads the map)
         mn.ndim = 3;
         mn.dtype = SVH_F32;
@@ -53,11 +54,20 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
         mn.strides[0] = 2 * static_cast<int64_t>(cv_base.shape()[1]);
         mn.strides[1] = 2;
         mn.strides[2] = 1;
-        HipBridge::check(svh_sgm_cost_volume_minima(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, &mn, known->max_abs,
-                                                    P1, P2, m, Pout, &out));
-        return sgm_cv;
     }
-    HipBridge::check(svh_sgm_cost_volume(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, P1, P2, m, Pout, &out));
+    // ... and the result leaves with a statement of its own: the winner a later extractSelectedIndex<extractionStrategy> would scan the
+    // 4 D bytes of every pixel for, which the kernel that writes a pixel's final costs picks while it holds them
+    DeviceArray<int32_t, 2> winner({cv_base.shape()[0], cv_base.shape()[1]});
+    svh_array wi = HipBridge::describe(winner);
+    int written = 0;
+    HipBridge::check(svh_sgm_cost_volume_winner(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, with_minima ? &mn : nullptr,
+                                                with_minima ? known->max_abs : 0.0f, P1, P2, m, Pout, &out, &wi, &written));
+    if (written) {
+        auto st = std::make_shared<typename DeviceArray<float, 3>::Statement>();
+        st->winner = winner.share();
+        st->winner_strategy = static_cast<int>(extractionStrategy);
+        sgm_cv.attach(st);
+    }
     return sgm_cv;
 }
 

@@ -239,8 +239,12 @@ template <class T, int N> class DeviceArray {
     // cannot invalidate it: data() const and share() hand out pointers to const.  A caller who casts that const away, or who kept a
     // mutable pointer from before the statement was attached, is outside what the type can see -- dropStatement() is for them.
     struct Statement {
-        std::shared_ptr<const float> minima; // device, (H, W, 2)
+        std::shared_ptr<const float> minima; // device, (H, W, 2); null when the statement says nothing about the minima
         float max_abs = 0;
+        // An aggregated volume sgmCostVolume wrote (svh_sgm_cost_volume_winner): the index extractSelectedIndex<winner_strategy> returns
+        // for it, computed by the kernel that wrote the volume; read by extractSelectedIndex instead of the volume.  device, (H, W)
+        std::shared_ptr<const int32_t> winner;
+        int winner_strategy = -1;
     };
     std::shared_ptr<const Statement> statement() const { return _st ? std::atomic_load(&_st->statement) : std::shared_ptr<const Statement>(); }
     void attach(std::shared_ptr<const Statement> st) {

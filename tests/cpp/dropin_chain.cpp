@@ -72,7 +72,26 @@ int main(int argc, char **argv) {
         // the argument type; images up once, one disparity map down
         auto dCV = SC::unfoldBasedCostVolumeOnDevice<matchFunc>(target, source, h_r, v_r, D);
         auto dSGM = SC::sgmCostVolume<8, strat>(dCV, P1, P2, StereoVision::Margins(), Pout);
+        // dSGM left sgmCostVolume with the winner the kernel that wrote it picked on the way (Statement::winner): extractSelectedIndex
+        // returns a copy of that map instead of scanning the volume.  Same indices as the scan, which runs once the statement is gone.
+        if (!dSGM.statement() || !dSGM.statement()->winner) {
+            fprintf(stderr, "sgmCostVolume<Cost> on a DeviceArray left no winner statement\n");
+            return 6;
+        }
         auto dIdx = SC::extractSelectedIndex<strat>(dSGM);
+        {
+            auto dSGMscan = dSGM;
+            Multidim::Array<SC::disp_t, 2> byStatement = dIdx.download();
+            (void)dSGMscan.data(); // a pointer the volume could be written through: the statement is dropped for every handle of the storage
+            if (dSGM.statement()) return 6;
+            Multidim::Array<SC::disp_t, 2> byScan = SC::extractSelectedIndex<strat>(dSGM).download();
+            for (int i = 0; i < byScan.shape()[0]; i++)
+                for (int j = 0; j < byScan.shape()[1]; j++)
+                    if (byScan.valueUnchecked(i, j) != byStatement.valueUnchecked(i, j)) {
+                        fprintf(stderr, "winner statement differs from the scan at (%d, %d): %d vs %d\n", i, j, byStatement.valueUnchecked(i, j), byScan.valueUnchecked(i, j));
+                        return 6;
+                    }
+        }
         Multidim::Array<SC::disp_t, 2> ddisp = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(dIdx, 0).download();
         Multidim::Array<float, 2> dref =
             SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(SC::truncatedCostVolume(dSGM, dIdx, h_r, v_r, 1), dIdx).download();
@@ -165,6 +184,17 @@ int main(int argc, char **argv) {
         dump(out + "_ncc_cv.f32", FE(CV), CV.flatLenght());
         dump(out + "_ncc_idx.i32", FE(rawDisp), rawDisp.flatLenght());
         dump(out + "_ncc_refined.f32", FE(refined), refined.flatLenght());
+        // the same on the device: the Score branch's winner records become the statement when the banded sweep applies (it does not at
+        // this D unless D is a multiple of 64: either way the map must equal the host chain's)
+        auto dCV = SC::DeviceArray<float, 3>::upload(CV);
+        auto dS = SC::sgmCostVolume<8, strat>(dCV, P1, P2, StereoVision::Margins(), Pout);
+        Multidim::Array<SC::disp_t, 2> dRaw = SC::extractSelectedIndex<strat>(dS).download();
+        for (int i = 0; i < dRaw.shape()[0]; i++)
+            for (int j = 0; j < dRaw.shape()[1]; j++)
+                if (dRaw.valueUnchecked(i, j) != rawDisp.valueUnchecked(i, j)) {
+                    fprintf(stderr, "Score-branch device chain differs from the host chain at (%d, %d)\n", i, j);
+                    return 7;
+                }
     }
     { // 2-D disparity volume + winner, as test/unittests/testCorrelation2d.cpp:166-175 chains them
         constexpr auto matchFunc = SC::matchingFunctions::ZNCC;

@@ -659,6 +659,42 @@ def test_winner_and_minima_reduced_inside_the_cost_kernel(func):
         assert np.array_equal(host(a["disp"]), so.index_to_disp(so.extract_index(cvh, strat)))
 
 
+@pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
+def test_winner_travels_with_the_aggregated_volume(rng, strategy):
+    """sgmCostVolume(..., keep_winner=True) on a device tensor keeps, with the volume it returns, the index map extractSelectedIndex would
+    scan it for (svh_sgm_cost_volume_winner: the kernel that writes a pixel's final costs picks it); extractSelectedIndex on the untouched
+    tensor returns a copy of that map -- no extract_index launch -- equal to the scan and to the oracle's; any in-place change, another
+    strategy, dropMinima, or a call without keep_winner and the scan runs."""
+    for shape, n_dir, margins in (((37, 90, 64), 8, None), ((20, 70, 128), 8, None), ((33, 41, 40), 8, None), ((25, 60, 64), 4, None), ((30, 50, 64), 8, sv.Margins(2, 1, 0, 3))):
+        cv = (rng.integers(0, 30, shape) if strategy == so.COST and shape[2] == 128 else rng.uniform(-1, 1, shape)).astype(np.float32)
+        cv[1, 2, 3] = np.nan
+        d = dev(cv)
+        m = margins.as_tuple() if margins else (0, 0, 0, 0)
+        exp_vol = so.sgm(cv, n_dir, strategy, 0.01, 0.1, m, 5.0)
+        exp = so.extract_index(exp_vol, strategy)
+        s = sv.sgmCostVolume(n_dir, strategy, d, 0.01, 0.1, margins, 5.0, keep_winner=True)
+        got_vol = host(s)
+        assert np.array_equal(np.isnan(got_vol), np.isnan(exp_vol)) and np.array_equal(got_vol[~np.isnan(exp_vol)].view(np.uint32), exp_vol[~np.isnan(exp_vol)].view(np.uint32))
+        banded = strategy == so.SCORE and not (n_dir == 8 and margins is None and shape[2] % 64 == 0)
+        assert (getattr(s, "_svh_winner", None) is None) == banded  # (Score: only the banded sweep of whole images leaves records)
+        sv.profile_reset(d)
+        sv.profile_enable(d, True)
+        idx = sv.extractSelectedIndex(strategy, s)
+        sv.profile_enable(d, False)
+        assert ("extract_index" in sv.profile_collect(d)) == banded
+        assert np.array_equal(host(idx), exp)
+        idx += 1  # the caller's copy: the statement's map is untouched
+        assert np.array_equal(host(sv.extractSelectedIndex(strategy, s)), exp)
+        other = so.SCORE if strategy == so.COST else so.COST
+        assert np.array_equal(host(sv.extractSelectedIndex(other, s)), so.extract_index(got_vol, other))
+        s[0, 0, 0] += 1.0  # in-place change: the statement no longer describes the tensor
+        assert np.array_equal(host(sv.extractSelectedIndex(strategy, s)), so.extract_index(host(s), strategy))
+        s2 = sv.sgmCostVolume(n_dir, strategy, d, 0.01, 0.1, margins, 5.0, keep_winner=True)
+        sv.dropMinima(s2)
+        assert getattr(s2, "_svh_winner", None) is None
+        assert getattr(sv.sgmCostVolume(n_dir, strategy, d, 0.01, 0.1, margins, 5.0), "_svh_winner", None) is None
+
+
 # ------------------------------------------------------------------------------------------------ randomised sweep
 def test_random_configurations_against_oracle():
     """Seeded random shapes / windows / ranges / margins / penalties through the fused pipeline and the per-function

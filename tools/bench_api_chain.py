@@ -18,7 +18,7 @@ for name, W, H, D, func, r in cases:
     strat = sv.matchFuncStrategy(func)
     def chain():
         cv = sv.unfoldBasedCostVolume(func, d_tgt, d_src, r, r, D, keep_minima=True)
-        sgm = sv.sgmCostVolume(8, strat, cv, 0.001, 0.01, None, 100.0)
+        sgm = sv.sgmCostVolume(8, strat, cv, 0.001, 0.01, None, 100.0, keep_winner=True)
         return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, sgm), 0)
     chain(); torch.cuda.synchronize()
     sv.profile_reset(d_src); sv.profile_enable(d_src, True)

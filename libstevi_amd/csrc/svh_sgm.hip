@@ -186,17 +186,6 @@ template <bool COST> __device__ __forceinline__ Winner better(Winner a, Winner b
     return b_wins ? b : a;
 }
 
-template <bool COST> __device__ __forceinline__ Winner wave_winner(Winner w) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Winner o;
-        o.v = __shfl_xor(w.v, off);
-        o.d = __shfl_xor(w.d, off);
-        w = better<COST>(w, o);
-    }
-    return w;
-}
-
 // Winner over the non-NaN values of the wave (d = -1 when there is none) and whether the value at local index 0
 // is NaN: the sequential scan of the reference starts from index 0 and never leaves it when that value is NaN.
 // Wave extremum by DPP (v_min / v_max ignore NaN), a ballot of the lanes that hold a value EQUAL to it (a NaN equals nothing), the highest

@@ -197,41 +197,14 @@ __device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], c
 
 // ---- the winner of a pixel from the wave that holds its D aggregated values (R per lane) -------------------------------------------
 // extractSelectedIndex (correlation_base.h:427-464): the sequential scan keeps the extremum, ties go to the LARGER index, a NaN never
-// wins unless it sits at index 0 (then the index stays 0).  Here: per-lane extremum (ties to the larger k), wave extremum by DPP, a
-// ballot of the lanes that hold it, the highest such lane.  Everything after the ballot is scalar.
-template <bool COST, int R, bool TAIL> __device__ __forceinline__ int wave_select_index(const float (&s)[R], int lane, int D) {
-    float bv = COST ? INFINITY : -INFINITY;
-    int bk = -1;
-#pragma unroll
-    for (int k = 0; k < R; k++) {
-        const bool ok = !isnan(s[k]) && (!TAIL || lane * R + k < D);
-        const bool take = ok && (bk < 0 || (COST ? s[k] <= bv : s[k] >= bv));
-        bv = take ? s[k] : bv;
-        bk = take ? k : bk;
-    }
-    const float vv = bk >= 0 ? bv : (COST ? INFINITY : -INFINITY);
-    const float M = COST ? wave_min(vv) : wave_max_dpp(vv);
-    const unsigned long long holders = __builtin_amdgcn_ballot_w64(bk >= 0 && bv == M);
-    const bool first_is_nan = isnan(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s[0]), 0)));
-    if (holders == 0ull || first_is_nan) return 0;
-    const int top = 63 - __builtin_clzll(holders);
-    return top * R + __builtin_amdgcn_readlane(bk, top);
-}
-// value at disparity pd (wave-uniform, 0 <= pd < 64 R) of the same register layout, as a wave-uniform float
-template <int R> __device__ __forceinline__ float wave_value_at(const float (&s)[R], int pd) {
-    const int kt = pd & (R - 1);
-    float v = s[0];
-#pragma unroll
-    for (int k = 1; k < R; k++) v = (kt == k) ? s[k] : v;
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), pd / R));
-}
-// The same as one 16-byte RECORD per pixel -- (tap(-1), tap(0), tap(+1), index as bits): the three truncatedCostVolume<Same>(S, idx, h_r,
+// wins unless it sits at index 0 (then the index stays 0).
+// One 16-byte RECORD per pixel -- (tap(-1), tap(0), tap(+1), index as bits): the three truncatedCostVolume<Same>(S, idx, h_r,
 // v_r, 1) values around the winner (correlation_base.h:579-613: NaN where the window of the shifted disparity leaves the image) and the
-// winner -- written from inside a streaming kernel.  Straight-line code on purpose: no branch, no exec-masked region, ONE unconditional
-// store in which every lane takes part (lane & 3 picks the slot; sixteen lanes write each dword, the same value), so that the host
-// kernel's count of memory operations in flight stays exact and its prefetch keeps running (conditional accesses end in
-// s_waitcnt vmcnt(0): DESIGN.md 4.2a).  D = 64 R (the vector form).  finish_records_kernel (svh_select_refine.hip) turns records into
-// index / disparity / refined maps.
+// winner -- written from inside a streaming kernel whose prefetch depends on the compiler's exact count of memory operations in
+// flight (conditional accesses end in s_waitcnt vmcnt(0): DESIGN.md 4.2a).  A first form with branches and `if (lane == 0)` stores
+// per output array put 32 such waits into the sweep (4 without records) and made it 30 % longer; this one is straight-line code with a
+// single 16-byte store.  D = 64 R (the vector form).  finish_records_kernel (svh_select_refine.hip) turns records into index /
+// disparity / refined maps.
 // Instruction budget: the host kernels are bound by instruction issue.  The wave extremum runs as hand-written DPP steps (one
 // instruction per step: the compiler's form is v_mov, v_mov_dpp, a canonicalising v_max and the v_max); NaN never enters it (v_max /
 // v_min return the other operand), a lane finds the largest k whose value EQUALS the extremum (a NaN equals nothing; +-inf do), the

@@ -226,8 +226,10 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
 
 /* The same with a by-product for a later sgmCostVolume<.., Cost> on the volume: minima (H,Ws,2) f32 = per pixel the smallest cost among
  * the disparities d with j + d < Ws and among those with j + d >= Ws (the ones sgm.h:287-289 charges Pout; +inf where there are none).
- * Census / Hamming only (integer costs <= 32 words): *minima_written = 1 when they were produced, 0 otherwise (the array is then left
- * untouched).  See svh_sgm_cost_volume_minima. */
+ * *minima_written says what was produced: 0 nothing (the array is left untouched); 1 census / Hamming -- integer costs, the minima of ALL
+ * costs; 2 a Cost-strategy float function on grey images through the column-sum kernel (SAD, SSD, ZSSD; windows up to 11 wide) -- the
+ * minima of the FINITE costs, and every finite |c| <= 1e30 (checked on the device; one word comes back to the host, so this form of the
+ * call waits for its kernel).  Pass the kind on to svh_sgm_cost_volume_winner; svh_sgm_cost_volume_minima takes kind 1. */
 int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r,
                                   int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima,
                                   int *minima_written);
@@ -255,8 +257,8 @@ int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, int strategy,
  * *winner_written = 1 when the map was produced (Cost strategy: always; Score strategy: when the banded sweep applies -- whole image, 8
  * directions, P2 >= P1 >= 0, at most 512 disparities, a multiple of 64 --, else 0 and winner_idx is left untouched).  Like the minima it
  * is a statement about `out` that the caller must not let outlive its contents (DeviceArray keeps it with the storage). */
-int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
-                               float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx,
+int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, int minima_kind,
+                               float max_abs, float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx,
                                int *winner_written);
 
 /* "Textbook" semi-global matching -- NOT the reference's behaviour, an explicit second mode:

@@ -128,7 +128,7 @@ def load():
         "svh_sgm_cost_volume_textbook": (C.c_int, [ctx, C.c_int, C.c_int, A, C.c_float, C.c_float, P(i32), C.c_float, A]),
         "svh_unfold_cost_volume_minima": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_int, i32, i32, A, A, P(C.c_int)]),
         "svh_sgm_cost_volume_minima": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_float, C.c_float, C.c_float, P(i32), C.c_float, A]),
-        "svh_sgm_cost_volume_winner": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_float, C.c_float, C.c_float, P(i32), C.c_float, A, A, P(C.c_int)]),
+        "svh_sgm_cost_volume_winner": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_float, C.c_float, C.c_float, P(i32), C.c_float, A, A, P(C.c_int)]),
         "svh_device_copy": (C.c_int, [ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
         "svh_census_exchange_keys": (C.c_int, [ctx, C.c_void_p, A, C.c_int]),
         "svh_context_get_device": (C.c_int, [ctx]),

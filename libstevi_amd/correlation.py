@@ -348,16 +348,16 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
         return _empty_like(l, 3, "f32")
     src = r if int(dDir) == dispDirection.RightToLeft else l
     out = _like(l, (src.shape[0], src.shape[1], D), "f32")
-    if keep_minima and _is_torch(out) and int(matchFunc) in (matchingFunctions.CENSUS, matchingFunctions.HAMMING):
+    if keep_minima and _is_torch(out) and int(matchFuncStrategy(matchFunc)) == dispExtractionStartegy.Cost:
         # device volume of integer costs, at the caller's request: keep what a later sgmCostVolume<Cost> on it would otherwise re-read the
         # volume for (svh_unfold_cost_volume_minima), tied to this tensor's storage and version counter
         minima = _like(l, (src.shape[0], src.shape[1], 2), "f32")
         written = C.c_int(0)
         st = _check(ctx, lib.svh_unfold_cost_volume_minima(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
                                                            lower, D, C.byref(_desc(out)), C.byref(_desc(minima)), C.byref(written)))
-        if st == _capi.OK and written.value:
+        if st == _capi.OK and written.value:  # 1: integer costs (census / Hamming), 2: float costs inside the regime (column-sum kernel)
             nWw = ((2 * h_radius + 1) * (2 * v_radius + 1) * (l.shape[2] if l.ndim == 3 else 1) - 1) // 32
-            out._svh_minima = (minima, float(32 * nWw), out.data_ptr(), out._version, tuple(out.shape))
+            out._svh_minima = (minima, float(32 * nWw) if written.value == 1 else 1e30, out.data_ptr(), out._version, tuple(out.shape), int(written.value))
         return out if st == _capi.OK else _empty_like(l, 3, "f32")
     st = _check(ctx, lib.svh_unfold_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
                                                 lower, D, C.byref(_desc(out))))
@@ -379,10 +379,10 @@ def _volume_minima(cv):
     hint = getattr(cv, "_svh_minima", None) if _is_torch(cv) else None
     if hint is None:
         return None
-    minima, max_abs, ptr, version, shape = hint
+    minima, max_abs, ptr, version, shape, kind = hint
     if cv.data_ptr() != ptr or cv._version != version or tuple(cv.shape) != shape or not cv.is_contiguous():
         return None
-    return minima, max_abs
+    return minima, max_abs, kind
 
 
 def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None, Pout=100.0, semantics="reference", keep_winner=False):
@@ -408,10 +408,15 @@ def sgmCostVolume(nDirections, extractionStrategy, cv_base, P1, P2, margins=None
         widx = _like(cv, tuple(cv.shape[:2]), "i32")
         written = C.c_int(0)
         _check(ctx, lib.svh_sgm_cost_volume_winner(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)),
-                                                   C.byref(_desc(hint[0])) if hint is not None else None, C.c_float(hint[1] if hint is not None else 0.0), P1, P2,
+                                                   C.byref(_desc(hint[0])) if hint is not None else None, hint[2] if hint is not None else 1,
+                                                   C.c_float(hint[1] if hint is not None else 0.0), P1, P2,
                                                    (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out)), C.byref(_desc(widx)), C.byref(written)))
         if written.value:
             out._svh_winner = (widx, int(extractionStrategy), out.data_ptr(), out._version, tuple(out.shape))
+        return out
+    if hint is not None and hint[2] == 2:  # float costs inside the regime: the minima go in through the winner entry point (no map asked for)
+        _check(ctx, lib.svh_sgm_cost_volume_winner(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), C.byref(_desc(hint[0])), 2, C.c_float(hint[1]),
+                                                   P1, P2, (C.c_int32 * 4)(*m), Pout, C.byref(_desc(out)), None, None))
         return out
     if hint is not None:  # same bits, one read of the volume less (svh_sgm_cost_volume_minima)
         _check(ctx, lib.svh_sgm_cost_volume_minima(ctx, int(nDirections), int(extractionStrategy), C.byref(_desc(cv)), C.byref(_desc(hint[0])),

@@ -355,16 +355,36 @@ static int unfold_cost_volume_impl(svh_context *ctx, int match_func, int disp_di
     SVH_TRY(stage_image(ctx, scr, *tgt, &dt));
     SVH_TRY(stage_out(ctx, scr, *cv, &os));
     int written = 0;
-    if (minima && func_census(match_func)) { // (other functions: the hint does not exist; *minima_written stays 0)
+    CostReduce red;
+    const ImageDesc isrc{(const float *)ds, a.H, a.Ws, C}, itgt{(const float *)dt, a.H, a.Wt, C};
+    if (minima) {
         SVH_TRY(validate(ctx, minima, "minima", SVH_F32, 3, 3));
         if (minima->shape[0] != a.H || minima->shape[1] != a.Ws || minima->shape[2] != 2)
             return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima must have shape (%d,%d,2)", a.H, a.Ws);
+    }
+    if (minima && func_census(match_func)) {
         SVH_TRY(stage_out(ctx, scr, *minima, &om));
         a.minima = (float *)om.dptr;
         a.minima_written = &written;
+    } else if (minima && func_strategy(match_func) == SVH_COST && ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) {
+        // float costs of a Cost-strategy function: the column-sum kernel leaves the regional minima (CostReduce mode 2) and says whether a
+        // magnitude left the regime in which the Cost branch's recurrences may run on them alone (svh_sgm.hip)
+        SVH_TRY(stage_out(ctx, scr, *minima, &om));
+        red.mode = 2;
+        red.minima = (float *)om.dptr;
+        red.flag = scr.get_n<int>(64);
+        if (!red.flag) return SVH_ERR_OUT_OF_MEMORY;
+        SVH_HIP_CHECK(ctx, hipMemsetAsync(red.flag, 0, sizeof(int), ctx->stream));
+        a.reduce = &red;
     }
-    SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, {(const float *)ds, a.H, a.Ws, C}, {(const float *)dt, a.H, a.Wt, C}, h_radius,
-                                        v_radius, (float *)os.dptr));
+    SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, isrc, itgt, h_radius, v_radius, (float *)os.dptr));
+    if (red.mode == 2 && red.done) {
+        // one word back to the host: the statement is only made for a volume inside the regime (every finite |c| <= 1e30)
+        int flag = 0;
+        SVH_HIP_CHECK(ctx, hipMemcpyAsync(&flag, red.flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((flag & 2) == 0) written = 2;
+    }
     if (written) SVH_TRY(finish_out(ctx, om));
     if (minima_written) *minima_written = written;
     return finish_out(ctx, os);

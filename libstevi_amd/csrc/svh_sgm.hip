@@ -1044,7 +1044,8 @@ int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const
 using namespace svh;
 
 static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs, float P1, float P2,
-                                const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx = nullptr, int *winner_written = nullptr) {
+                                const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx = nullptr, int *winner_written = nullptr,
+                                int minima_kind = 1) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     if (winner_written) *winner_written = 0;
     if (winner_idx) {
@@ -1082,10 +1083,23 @@ static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy
             if (minima->shape[0] != cv->shape[0] || minima->shape[1] != cv->shape[1] || minima->shape[2] != 2)
                 return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima must have shape (H,W,2)");
             if (!(max_abs >= 0.0f)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "max_abs must be a non-negative number");
+            if (minima_kind != 1 && minima_kind != 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima_kind: 1 (integer costs) or 2 (float costs inside the regime)");
             void *dmin;
             SVH_TRY(stage_in(ctx, scr, *minima, &dmin));
-            cs.minima = (const float *)dmin;
-            cs.max_abs = max_abs;
+            if (minima_kind == 1) {
+                cs.minima = (const float *)dmin;
+                cs.max_abs = max_abs;
+            } else {
+                // float costs the caller knows to lie inside the regime (svh_unfold_cost_volume_minima said 2): no probing read, the line
+                // recurrences run on the minima (bit 0 of the flag word: no exact-integer route; bit 1 stays down)
+                if (!(max_abs <= SGM_SAFE_MAGNITUDE)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima_kind 2 states finite magnitudes up to 1e30");
+                int *flag = scr.get_n<int>(64);
+                if (!flag) return SVH_ERR_OUT_OF_MEMORY;
+                const int one = 1;
+                SVH_HIP_CHECK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                cs.float_minima = (const float *)dmin;
+                cs.float_flag = flag;
+            }
         }
         // the kernel that writes S holds a pixel's aggregated costs in one wave: its winner is a by-product (extractSelectedIndex's rule)
         WinnerOut w;
@@ -1120,9 +1134,10 @@ extern "C" int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, in
     return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, minima, max_abs, P1, P2, margins, Pout, out);
 }
 
-extern "C" int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, float max_abs,
-                                          float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx, int *winner_written) {
-    return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, minima, max_abs, P1, P2, margins, Pout, out, winner_idx, winner_written);
+extern "C" int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, int minima_kind,
+                                          float max_abs, float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx,
+                                          int *winner_written) {
+    return sgm_cost_volume_impl(ctx, n_directions, strategy, cv, minima, max_abs, P1, P2, margins, Pout, out, winner_idx, winner_written, minima ? minima_kind : 1);
 }
 
 // "Textbook" semi-global matching: NOT the reference's behaviour -- what correlation/sgm.h

@@ -173,8 +173,9 @@ DeviceArray<TCV, 3> unfoldBasedCostVolumeOnDevice(Multidim::Array<T_L, nImDim> c
     DeviceArray<TCV, 3> cv({src[0], src[1], static_cast<int>(disp_width)});
     if (cv.empty()) return cv;
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
-    if constexpr (matchFunc == matchingFunctions::CENSUS || matchFunc == matchingFunctions::HAMMING) {
-        // integer costs: also keep the per-pixel regional minima a later sgmCostVolume<.., Cost> would otherwise read the volume for
+    if constexpr (MatchingFunctionTraits<matchFunc>::extractionStrategy == dispExtractionStartegy::Cost) {
+        // a Cost-strategy function: also keep the per-pixel regional minima a later sgmCostVolume<.., Cost> would otherwise read the volume
+        // for.  The library says which kind it could make: 1 integer costs (census / Hamming), 2 float costs inside the regime, 0 none.
         DeviceArray<float, 3> minima({src[0], src[1], 2});
         svh_array mn = HipBridge::describe(minima);
         int written = 0;
@@ -184,8 +185,9 @@ DeviceArray<TCV, 3> unfoldBasedCostVolumeOnDevice(Multidim::Array<T_L, nImDim> c
         if (written) {
             auto st = std::make_shared<typename DeviceArray<TCV, 3>::Statement>();
             st->minima = minima.share();
+            st->minima_kind = written;
             const int channels = nImDim == 3 ? l_shape[nImDim - 1] : 1;
-            st->max_abs = static_cast<float>(32 * (((2 * h_radius + 1) * (2 * v_radius + 1) * channels - 1) / 32));
+            st->max_abs = written == 1 ? static_cast<float>(32 * (((2 * h_radius + 1) * (2 * v_radius + 1) * channels - 1) / 32)) : 1e30f;
             cv.attach(st);
         }
         return cv;

@@ -61,7 +61,7 @@ DeviceArray<float, 3> sgmCostVolume(DeviceArray<T_CV, 3> const &cv_base, float P
     svh_array wi = HipBridge::describe(winner);
     int written = 0;
     HipBridge::check(svh_sgm_cost_volume_winner(HipBridge::context(), nDirections, static_cast<int>(extractionStrategy), &in, with_minima ? &mn : nullptr,
-                                                with_minima ? known->max_abs : 0.0f, P1, P2, m, Pout, &out, &wi, &written));
+                                                with_minima ? known->minima_kind : 1, with_minima ? known->max_abs : 0.0f, P1, P2, m, Pout, &out, &wi, &written));
     if (written) {
         auto st = std::make_shared<typename DeviceArray<float, 3>::Statement>();
         st->winner = winner.share();

@@ -240,6 +240,7 @@ template <class T, int N> class DeviceArray {
     // mutable pointer from before the statement was attached, is outside what the type can see -- dropStatement() is for them.
     struct Statement {
         std::shared_ptr<const float> minima; // device, (H, W, 2); null when the statement says nothing about the minima
+        int minima_kind = 1;                 // 1: integer costs with |c| <= max_abs; 2: float costs, finite magnitudes <= max_abs <= 1e30
         float max_abs = 0;
         // An aggregated volume sgmCostVolume wrote (svh_sgm_cost_volume_winner): the index extractSelectedIndex<winner_strategy> returns
         // for it, computed by the kernel that wrote the volume; read by extractSelectedIndex instead of the volume.  device, (H, W)

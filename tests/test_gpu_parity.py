@@ -819,8 +819,41 @@ def test_cost_branch_on_a_census_volume_skips_the_probe_with_the_same_bits(rng):
     sv.profile_enable(l, False)
     assert "gmap_from_minima" not in sv.profile_collect(l)
     assert_bits(got4, so.sgm(host(cv), 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0))
-    # Score strategy / other functions: no statement
-    assert getattr(sv.unfoldBasedCostVolume(MF.SAD, l, r, 2, 2, 16, keep_minima=True), "_svh_minima", None) is None
+    # Score strategy: no statement (its SGM branch has no use for minima)
+    assert getattr(sv.unfoldBasedCostVolume(MF.NCC, l, r, 2, 2, 16, keep_minima=True), "_svh_minima", None) is None
+    # float costs of a Cost-strategy function: the column-sum kernel leaves the minima of the finite costs and vouches for the regime
+    # (kind 2); sgmCostVolume<Cost> then runs its line recurrences on them without a probing read -- same S as the oracle's literal loops
+    for func, r_ in ((MF.SAD, 2), (MF.SSD, 3), (MF.ZSSD, 2)):
+        cvf = sv.unfoldBasedCostVolume(func, l, r, r_, r_, 48, keep_minima=True)
+        assert cvf._svh_minima[5] == 2
+        sv.profile_reset(l)
+        sv.profile_enable(l, True)
+        got = sv.sgmCostVolume(8, so.COST, cvf, 0.01, 0.1, None, 2.5)
+        sv.profile_enable(l, False)
+        kernels = sv.profile_collect(l)
+        assert "sgm_volume_probe" not in kernels and "sgm_cost_minmap_scalar" in kernels, kernels.keys()
+        assert_bits(got, so.sgm(host(cvf), 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 2.5, variant=0))
+        c = host(cvf)
+        jj, dd = np.meshgrid(np.arange(c.shape[1]), np.arange(48), indexing="ij")
+        pays = (jj + dd >= c.shape[1])[None]
+        mins = cvf._svh_minima[0].cpu().numpy()
+        assert np.array_equal(mins[..., 0], np.where(pays, np.inf, c).min(axis=2)) and np.array_equal(mins[..., 1], np.where(pays, c, np.inf).min(axis=2))
+        cvf[2, 3, 4] = 7.0  # in-place change: probe again
+        sv.profile_reset(l)
+        sv.profile_enable(l, True)
+        got = sv.sgmCostVolume(8, so.COST, cvf, 0.01, 0.1, None, 2.5)
+        sv.profile_enable(l, False)
+        assert "sgm_volume_probe" in sv.profile_collect(l)
+        assert_bits(got, so.sgm(host(cvf), 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 2.5, variant=0))
+    # ZSAD takes the per-window kernel, which makes no minima: nothing is stated
+    assert getattr(sv.unfoldBasedCostVolume(MF.ZSAD, l, r, 2, 2, 16, keep_minima=True), "_svh_minima", None) is None
+    # an image with an infinite sample: a cost leaves the regime, the library states nothing and the probe finds out by itself
+    bad = tgt.copy()
+    bad[10, 50] = np.inf
+    cvb = sv.unfoldBasedCostVolume(MF.SAD, dev(bad), r, 2, 2, 48, keep_minima=True)
+    assert getattr(cvb, "_svh_minima", None) is None
+    gb, eb = host(sv.sgmCostVolume(8, so.COST, cvb, 0.01, 0.1, None, 2.5)), so.sgm(host(cvb), 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 2.5, variant=0)
+    assert np.array_equal(np.isnan(gb), np.isnan(eb)) and np.array_equal(gb[~np.isnan(eb)].view(np.uint32), eb[~np.isnan(eb)].view(np.uint32))
 
 
 # ------------------------------------------------------------------------------------------------ sgmCostVolume<.., T_CV>

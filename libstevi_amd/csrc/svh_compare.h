@@ -96,7 +96,7 @@ constexpr int WS_TP = 256;
 
 template <int CMP>
 __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, bool zero_mean, bool normalized, float *__restrict__ mean,
-                                                                   float *__restrict__ norm, float *__restrict__ zcost) {
+                                                                   float *__restrict__ norm, float *__restrict__ zcost, int *__restrict__ odd_norm_flag) {
     extern __shared__ float ws_tile[];
     const int h = 2 * a.h_r + 1, v = 2 * a.v_r + 1, C = a.C, F = h * v * C;
     const int tw = (WS_TP + h - 1) * C; // floats per tile row
@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, 
             }
         n = sqrtf(acc);
         norm[p] = n;
+        if (odd_norm_flag && !(n > 0.0f && n < INFINITY)) atomicOr(odd_norm_flag, 1); // (FiniteCostsQuery: a zero, infinite or NaN norm)
     }
     if (zcost) {
         float acc = 0.0f;
@@ -157,7 +158,8 @@ __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, 
 // literal kernel above stays for the zero-mean functions (their terms are not separable), multi-channel images, and behind the
 // "cost_volume_colsum" = 0 option.
 template <int CMP>
-__global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a, bool normalized, float *__restrict__ norm, float *__restrict__ zcost) {
+__global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a, bool normalized, float *__restrict__ norm, float *__restrict__ zcost,
+                                                                    int *__restrict__ odd_norm_flag) {
     __shared__ float colA[WS_TP + 2 * 255], colZ[WS_TP + 2 * 255];
     const int h = 2 * a.h_r + 1, v = 2 * a.v_r + 1;
     const int i = blockIdx.y, j0 = blockIdx.x * WS_TP;
@@ -189,6 +191,7 @@ __global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a,
     if (normalized) {
         n = sqrtf(A);
         norm[p] = n;
+        if (odd_norm_flag && !(n > 0.0f && n < INFINITY)) atomicOr(odd_norm_flag, 1); // (FiniteCostsQuery: a zero, infinite or NaN norm)
     }
     if (zcost) {
         // the literal loop's sum of ((x / n) * 0) [DOT], x * x [SSD], |x| [SAD] over the window (zero-mean off; only DOT is ever normalised)
@@ -199,22 +202,23 @@ __global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a,
 }
 
 // image statistics: the LDS-tiled kernel when the tile fits, the per-lane global walk otherwise; cmp only matters for zcost
-inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm, float *mean, float *norm, float *zcost, int cmp, bool colsum = false) {
+inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm, float *mean, float *norm, float *zcost, int cmp, bool colsum = false,
+                               int *odd_norm_flag = nullptr) {
     if ((int64_t)a.H * a.W == 0 || (!zm && !nrm && !zcost)) return SVH_OK;
     if (colsum && !zm && a.C == 1 && a.h_r <= 255 && !(nrm && cmp != CMP_DOT)) {
         dim3 grid(ceil_div(a.W, WS_TP), a.H);
-        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SSD>, grid, WS_TP, 0, a, nrm, norm, zcost);
-        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SAD>, grid, WS_TP, 0, a, nrm, norm, zcost);
-        else SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_DOT>, grid, WS_TP, 0, a, nrm, norm, zcost);
+        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SSD>, grid, WS_TP, 0, a, nrm, norm, zcost, odd_norm_flag);
+        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SAD>, grid, WS_TP, 0, a, nrm, norm, zcost, odd_norm_flag);
+        else SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_DOT>, grid, WS_TP, 0, a, nrm, norm, zcost, odd_norm_flag);
         SVH_CHECK_LAUNCH(ctx);
         return SVH_OK;
     }
     const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
     if (shmem <= 60 * 1024) {
         dim3 grid(ceil_div(a.W, WS_TP), a.H);
-        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SSD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost);
-        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SAD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost);
-        else SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_DOT>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost);
+        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SSD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);
+        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SAD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);
+        else SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_DOT>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);
         SVH_CHECK_LAUNCH(ctx);
         return SVH_OK;
     }

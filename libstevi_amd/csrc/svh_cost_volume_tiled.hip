@@ -631,9 +631,23 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
         const int cmpk = cmp == T_DOT ? CMP_DOT : cmp == T_SSD ? CMP_SSD : CMP_SAD;
         // (without zero-mean the terms are separable: column sums shared between windows, like the cost kernel that reads these maps)
         const bool sep = ctx->cost_volume_colsum;
-        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, 1, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk, sep));
-        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, 1, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk, sep));
+        // FiniteCostsQuery: the costs of a normalised function are finite and of magnitude about one iff every norm is positive and finite
+        int *odd = nullptr;
+        if (a.finite_query && a.finite_query->asked && nrm) {
+            odd = owner.get_n<int>(64);
+            if (!odd) return SVH_ERR_OUT_OF_MEMORY;
+            SVH_HIP_CHECK(ctx, hipMemsetAsync(odd, 0, sizeof(int), ctx->stream));
+        }
+        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, 1, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk, sep, odd));
+        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, 1, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk, sep, odd));
         st.ready = true;
+        if (odd) { // one word back, before the cost kernel is launched: the wait is for the two statistics kernels
+            int h = 1;
+            SVH_HIP_CHECK(ctx, hipMemcpyAsync(&h, odd, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            a.finite_query->known = true;
+            a.finite_query->all_finite = h == 0;
+        }
     }
     float *ms = st.ms, *mt = st.mt, *ns = st.ns, *nt = st.nt, *zc = st.zc;
     const int sign = a.sign();

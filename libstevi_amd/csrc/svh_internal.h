@@ -207,6 +207,13 @@ struct WindowStatsCache {
     bool ready = false;
     float *ms = nullptr, *mt = nullptr, *ns = nullptr, *nt = nullptr, *zc = nullptr;
 };
+// Asked of dev_cost_volume_grey_tiled by a caller that will aggregate the volume with the Score branch: are all its costs finite and of
+// magnitude about one?  True for a normalised function (NCC, ZNCC) exactly when every window norm of both images is a positive finite
+// number; the statistics kernels check that as they write the norms and the answer (one word) is read back BEFORE the cost kernel is
+// launched, so the wait is for the statistics only.  asked: the caller wants it; known: an answer was produced; all_finite: the answer.
+struct FiniteCostsQuery {
+    bool asked = false, known = false, all_finite = false;
+};
 // Per-pixel reductions over the disparity axis that the float cost kernel computes while it holds the costs (the column-sum kernel of
 // svh_cost_volume_tiled.hip: a block's waves hold a pixel's whole range between them), so that nobody reads the volume back for them:
 //   mode 1  the winner (extractSelectedIndex, correlation_base.h:427-464: extremum, ties to the larger index, NaN never wins unless at
@@ -243,6 +250,7 @@ struct CostVolumeArgs {
     float *minima = nullptr;
     int *minima_written = nullptr;
     CostReduce *reduce = nullptr; // float costs of grey images: see CostReduce (ignored by the kernels that cannot do it: check reduce->done)
+    FiniteCostsQuery *finite_query = nullptr;
     // image rows [row_begin, row_begin + row_count) only (row_count 0: all of them; dev_cost_volume_grey_tiled)
     int row_begin = 0, row_count = 0;
     int sign() const { return force_sign ? force_sign : (ddir == SVH_RIGHT_TO_LEFT ? 1 : -1); }
@@ -269,6 +277,9 @@ struct SgmArgs {
     // arrays are the whole image); margins and line geometry refer to the full image; only the local rows
     // [store_row0, store_row0 + store_rows) are written, to an output of store_rows rows
     int row_origin = 0, full_H = 0, store_row0 = 0, store_rows = 0;
+    // Score branch: every cost is a finite number of magnitude about one (FiniteCostsQuery) and Pout is finite -- then every line state
+    // stays finite and the isfinite filters of sgm.h:224, :241, :251 are no-ops: the kernels that are bound by instruction issue drop them
+    bool costs_all_finite = false;
 };
 // The min_p maps of the six effective passes live in FIVE planes: passes 2 and 3 (the two start loops of UpLeft2DownRight, sgm.h:331-345)
 // partition the margin box along its diagonal -- pass 2 visits ip >= jp, pass 3 jp >= ip -- and the pixels both visit, the diagonal itself,

@@ -165,6 +165,14 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             d_s = sgm_cv ? (float *)o_sgm.dptr : scr.get_n<float>(nvox);
             if (!d_s) return SVH_ERR_OUT_OF_MEMORY;
         }
+        // Score-branch SGM behind a normalised function: ask the statistics kernels whether every norm is a positive finite number (then
+        // every cost is finite and the aggregation's finiteness filters are no-ops: SgmArgs::costs_all_finite).  One word and a wait for the
+        // statistics kernels: only for volumes where the aggregation is long enough to notice.
+        FiniteCostsQuery fq;
+        if (sgm && strategy != SVH_COST && func_normalized(func) && ctx->sgm_score_finish_fused && nvox >= ((size_t)1 << 26)) {
+            fq.asked = true;
+            cva_r.finite_query = &fq;
+        }
         if (minima_in_cost) {
             red.mode = 2;
             red.minima = scr.get_n<float>((size_t)npx * 2);
@@ -198,6 +206,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
                 fin.taps_h_r = prm->refine_h_radius;
                 fin.taps_v_r = prm->refine_v_radius;
                 fin.store_all = sgm_cv != nullptr;
+                sa.costs_all_finite = fq.known && fq.all_finite;
                 SVH_TRY(dev_sgm_score_branch(ctx, scr, sa, d_cv, d_s, false, try_fused ? &fin : nullptr));
                 winner_done = try_fused && fin.done;
                 if (winner_done) {

@@ -618,7 +618,7 @@ __global__ void gmap_from_minima_kernel(const float2 *__restrict__ minima, int64
 // (with the generic form's conditional accesses every step ended in s_waitcnt vmcnt(0): the two batches never overlapped).
 // FIN (with VEC, FAR_IS_GLOBAL, not NEG / DELTA / FIRST): this pass is the last one to touch the pixels it visits; it writes their
 // winner records (fin.records) and stores the aggregated costs only when somebody wants the volume (fin.store_all).
-template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false, bool VEC = false, bool FIN = false>
+template <int R, int B, bool FIRST, bool FAR_IS_GLOBAL, bool NEG, bool DELTA = false, bool VEC = false, bool FIN = false, bool LEAN = false>
 __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__restrict__ cv, float *__restrict__ sgm, LineSet ls,
                                                             int D, int W, float P1, float P2, float Pout, bool vec, ScoreFinish fin) {
     const int lane = threadIdx.x & 63;
@@ -634,8 +634,8 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
     auto step = [&](const float (&c_in)[R], const float (&sacc)[R], int ii, int jj) {
             if constexpr (VEC && FAR_IS_GLOBAL && !NEG) { // the branch-free form (svh_sgm_lines.h): a third of the instructions
                 float act[R], outv[R];
-                if (jj + D > W) score_step1_far_global<R, true, false>(prev, c_in, jj, lane, D, W, P1, P2, Pout, act);
-                else score_step1_far_global<R, false, false>(prev, c_in, jj, lane, D, W, P1, P2, Pout, act);
+                if (jj + D > W) score_step1_far_global<R, true, false, LEAN>(prev, c_in, jj, lane, D, W, P1, P2, Pout, act);
+                else score_step1_far_global<R, false, false, LEAN>(prev, c_in, jj, lane, D, W, P1, P2, Pout, act);
 #pragma unroll
                 for (int k = 0; k < R; k++) {
                     const float base = FIRST ? c_in[k] : sacc[k];
@@ -998,18 +998,23 @@ template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, 
     if (ls.n_lines <= 0) return SVH_OK;
     const int grid = ceil_div(ls.n_lines, 4);
     const ScoreFinish none{};
-#define SVH_LINE(DELTAV, VECV, FINV) \
-    SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, DELTAV, VECV, FINV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout, vec, \
-               FINV ? *finish : none)
+#define SVH_LINE_L(DELTAV, VECV, FINV, LEANV) \
+    SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, DELTAV, VECV, FINV, LEANV>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2, a.Pout, \
+               vec, FINV ? *finish : none)
+#define SVH_LINE(DELTAV, VECV, FINV) SVH_LINE_L(DELTAV, VECV, FINV, false)
+    const bool lean = a.costs_all_finite && std::isfinite(a.Pout);
     if (vec && a.D == 64 * R) {
-        if (finish && !delta) SVH_LINE(false, true, true);
-        else if (delta) SVH_LINE(true, true, false);
-        else SVH_LINE(false, true, false);
+        if (finish && !delta) {
+            if (lean) SVH_LINE_L(false, true, true, true); else SVH_LINE(false, true, true);
+        } else if (delta) {
+            if (lean) SVH_LINE_L(true, true, false, true); else SVH_LINE(true, true, false);
+        } else SVH_LINE(false, true, false);
     } else {
         if (finish) return fail(ctx, SVH_ERR_HIP, "internal: fused winner asked of the generic line pass");
         if (delta) SVH_LINE(true, false, false); else SVH_LINE(false, false, false);
     }
 #undef SVH_LINE
+#undef SVH_LINE_L
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

@@ -165,14 +165,16 @@ template <int R> __device__ __forceinline__ void lds_put(float *p, const float (
 // One step of the Score branch's recurrence (sgm.h:218-255) for the R disparities of this lane when P2 >= P1 >= 0 (the far term is
 // max_p - P2: see svh_sgm.hip), written without per-lane branches.  POUT: some disparity of this pixel looks past the image border
 // (wave-uniform; false for most pixels, which skip the term).  TAIL: D < 64 R, the lanes past D are masked.
-template <int R, bool POUT, bool TAIL>
+// LEAN: every cost is finite and of magnitude about one and Pout is finite (SgmArgs::costs_all_finite): then every line state is finite
+// and the isfinite filters of sgm.h:224, :241, :251 change nothing -- left out, a sixth of the step's instructions.
+template <int R, bool POUT, bool TAIL, bool LEAN = false>
 __device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], const float (&c)[R], int jj, int lane, int D, int W, float P1,
                                                        float P2, float Pout, float (&act)[R]) {
     float pf[R];
     float A = -INFINITY;
 #pragma unroll
     for (int k = 0; k < R; k++) {
-        const bool keep = TAIL ? ((lane * R + k < D) & finite_f(prev[k])) : finite_f(prev[k]);
+        const bool keep = TAIL ? ((lane * R + k < D) & (LEAN || finite_f(prev[k]))) : (LEAN || finite_f(prev[k]));
         pf[k] = keep ? prev[k] : -INFINITY;
         A = fmaxf(A, pf[k]);
     }
@@ -191,7 +193,7 @@ __device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], c
             a = (jj + lane * R + k >= W) ? a_out : a;
         }
         const float moved = c[k] + (a - max_p);
-        act[k] = (maxp_fin & finite_f(a)) ? moved : c[k];
+        act[k] = (LEAN || (maxp_fin & finite_f(a))) ? moved : c[k];
     }
 }
 

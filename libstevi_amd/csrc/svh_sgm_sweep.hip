@@ -26,7 +26,7 @@ namespace svh {
 // TAIL: D < 64 R, the lanes past D are masked.
 #define SVH_MAX3_DPP(CTRL)                                                                                                        \
     asm("v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\tv_max_f32_dpp %2, %2, %2 " CTRL : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]))
-template <int R, bool POUT, bool TAIL>
+template <int R, bool POUT, bool TAIL, bool LEAN = false>
 __device__ __forceinline__ void score_step3_far_global(const float (&prev)[3][R], const float (&c)[R], int jj, int lane, int D, int W, float P1,
                                                        float P2, float Pout, float (&act)[3][R]) {
     float pf[3][R], A[3];
@@ -35,7 +35,7 @@ __device__ __forceinline__ void score_step3_far_global(const float (&prev)[3][R]
         A[s] = -INFINITY;
 #pragma unroll
         for (int k = 0; k < R; k++) {
-            const bool keep = TAIL ? ((lane * R + k < D) & finite_f(prev[s][k])) : finite_f(prev[s][k]); // isfinite filters of sgm.h:224, :241
+            const bool keep = TAIL ? ((lane * R + k < D) & (LEAN || finite_f(prev[s][k]))) : (LEAN || finite_f(prev[s][k])); // isfinite filters of sgm.h:224, :241
             pf[s][k] = keep ? prev[s][k] : -INFINITY;
             A[s] = fmaxf(A[s], pf[s][k]);
         }
@@ -65,7 +65,7 @@ __device__ __forceinline__ void score_step3_far_global(const float (&prev)[3][R]
                 a = (jj + lane * R + k >= W) ? a_out : a;
             }
             const float moved = c[k] + (a - max_p);                                // :251-254
-            act[s][k] = (maxp_fin & finite_f(a)) ? moved : c[k];
+            act[s][k] = (LEAN || (maxp_fin & finite_f(a))) ? moved : c[k];
         }
     }
 }
@@ -81,7 +81,8 @@ __device__ __forceinline__ void score_step3_far_global(const float (&prev)[3][R]
 // FIN (VEC only): the sweep is the last writer of the pixels DownLeft2UpRight does not visit (i + j >= H).  It writes a winner record
 // for EVERY pixel (unconditionally: the later pass overwrites the records of the pixels it visits) and, when nobody wants the volume
 // (fin.store_all false), stores the aggregated costs only where that pass will read them.
-template <int R, int WB, int KB, int NCW, bool VEC, bool FIN = false>
+// LEAN (with FIN, VEC): all costs finite (SgmArgs::costs_all_finite), the finiteness filters of the steps are left out.
+template <int R, int WB, int KB, int NCW, bool VEC, bool FIN = false, bool LEAN = false>
 __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *__restrict__ cv, float *sgm, int H, int W, int D, float P1, float P2,
                                                                   float Pout, int r0, int rows, const float *__restrict__ st_in,
                                                                   float *__restrict__ st_out, ScoreFinish fin) {
@@ -175,7 +176,7 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
                         if (i == 0) prev[0][k] = prev[2][k] = 0.0f;
                     }
                 }
-                score_step3_far_global<R, POUT, !VEC>(prev, c[q], j, lane, D, W, P1, P2, Pout, act);
+                score_step3_far_global<R, POUT, !VEC, LEAN>(prev, c[q], j, lane, D, W, P1, P2, Pout, act);
                 lds_put<R>(pv, act[0]);
                 lds_put<R>(pd, act[1]);
                 if (visA) lds_put<R>(pa, act[2]);
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
 #pragma unroll
                     for (int k = 0; k < R; k++) prev[k] = 0.0f;
                 }
-                score_step1_far_global<R, POUT, !VEC>(prev, hc[q], j, lane, D, W, P1, P2, Pout, act);
+                score_step1_far_global<R, POUT, !VEC, LEAN>(prev, hc[q], j, lane, D, W, P1, P2, Pout, act);
                 lds_put<R>(ps, act);
             }
             row_end();
@@ -264,6 +265,8 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, true, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, true, true, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             SVH_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&sgm_score_band_kernel<R, WB, KB, NCW, false>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             __atomic_store_n(&attr_set[ctx->device & 63], 1, __ATOMIC_RELEASE);
@@ -274,13 +277,17 @@ static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs 
         // the winner rides on the last writer of every pixel: the vector form only, and not for cross-shard keys
         const bool fused_finish = finish && finish->records && vec && a.D == DP && (int64_t)a.H * a.W < (1ll << 29);
         const ScoreFinish none{};
+        const bool lean = fused_finish && a.costs_all_finite && std::isfinite(a.Pout); // (the fused call's volumes: SgmArgs::costs_all_finite)
         SVH_TRY(dev_sgm_score_line_pass(ctx, a, cv, sgm, 1, true)); // Left2Right: its contribution alone
         const int strips = ceil_div(a.W, WB);
         {
             ProfScope prof(ctx, "sgm_score_bands"); // (one bracket around all the band launches)
             for (int r0 = 0, b = 0; r0 < a.H; r0 += KB, b++) {
                 const int rows = std::min(KB, a.H - r0);
-                if (fused_finish)
+                if (fused_finish && lean)
+                    hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, true, true, true>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D,
+                                       a.P1, a.P2, a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1], *finish);
+                else if (fused_finish)
                     hipLaunchKernelGGL((sgm_score_band_kernel<R, WB, KB, NCW, true, true>), strips, NCW * 64, shmem, ctx->stream, cv, sgm, a.H, a.W, a.D, a.P1,
                                        a.P2, a.Pout, r0, rows, st[b & 1], st[(b + 1) & 1], *finish);
                 else if (vec && a.D == DP)

@@ -197,3 +197,51 @@ def test_winner_emitted_by_the_last_writer_ties_and_nan(rng):
     assert torch.equal(outs[0]["disp"], outs[1]["disp"]) and int(outs[0]["disp"].abs().sum()) == 0
     ra, rb = outs[0]["refined"].cpu().numpy(), outs[1]["refined"].cpu().numpy()
     assert np.array_equal(np.isnan(ra), np.isnan(rb)) and np.array_equal(ra[~np.isnan(ra)], rb[~np.isnan(rb)])
+
+
+@pytest.mark.parametrize("flat_patch", [False, True])
+@pytest.mark.parametrize("func_name", ["NCC", "ZNCC"])
+def test_all_finite_regime_drops_the_filters_and_nothing_else(func_name, flat_patch):
+    """svh_stereo_match, normalised function + SGM-8 on a volume of 2^26 voxels or more: the statistics kernels report whether every window
+    norm is a positive finite number; if so every cost is finite and the Score-branch kernels run without the isfinite filters of
+    sgm.h:224, :241, :251 (SgmArgs::costs_all_finite), else (a flat patch: zero norms, NaN costs) with them.  Either way the maps must equal
+    the separate-kernel path's (no query there) bit for bit, and the oracle's on a band of the library's own volume."""
+    from helpers import parallax_pair
+    MF = sv.matchingFunctions
+    func = getattr(MF, func_name)
+    H, W, D, hr = 512, 1024, 128, 2
+    src, tgt, _ = parallax_pair(H, W, 128, 100, 300, 3, 21, seed=17)
+    if flat_patch:
+        src[200:230, 400:470] = 0.0 if func_name == "NCC" else 0.375  # zero norm (NCC) / zero sigma (ZNCC): 0 / 0 costs
+        tgt[40:60, 100:140] = 0.0 if func_name == "NCC" else -0.5
+    l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
+    kw = dict(sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=hr, refine_v_radius=hr)
+    a = sv.stereoMatch(func, l, r, hr, hr, D, want_cv=True, want_sgm_cv=True, **kw)
+    sv.set_option(l, "sgm_score_finish_fused", 0)
+    try:
+        b = sv.stereoMatch(func, l, r, hr, hr, D, want_sgm_cv=True, **kw)
+    finally:
+        sv.set_option(l, "sgm_score_finish_fused", 1)
+    assert torch.equal(a["disp"], b["disp"])
+    sa, sb = a["sgm_cv"].cpu().numpy(), b["sgm_cv"].cpu().numpy()
+    assert np.array_equal(np.isnan(sa), np.isnan(sb)) and np.array_equal(sa[~np.isnan(sa)].view(np.uint32), sb[~np.isnan(sb)].view(np.uint32))
+    ra, rb = a["refined"].cpu().numpy(), b["refined"].cpu().numpy()
+    assert np.array_equal(np.isnan(ra), np.isnan(rb)) and np.array_equal(bits(ra[~np.isnan(ra)]), bits(rb[~np.isnan(rb)]))
+    cvh = a["cv"].cpu().numpy()
+    assert bool(np.isnan(cvh).any()) == flat_patch
+    del sb, b
+    # oracle on the top band of the library's own volume (pixels whose lines lie inside the band)
+    band = 24
+    ii, jj = np.meshgrid(np.arange(band), np.arange(W), indexing="ij")
+    m = (ii + jj < band) | (ii + jj >= H)
+    ob = so.sgm(cvh[:band], 8, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    x, y = sa[:band][m], ob[m]
+    assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(y)].view(np.uint32), y[~np.isnan(y)].view(np.uint32))
+    # ... and a band that contains the flat patch of the source image, against the oracle's aggregation of the rows above it
+    if flat_patch:
+        rows = 240
+        ob = so.sgm(cvh[:rows], 8, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+        ii, jj = np.meshgrid(np.arange(rows), np.arange(W), indexing="ij")
+        m = (ii + jj < rows) | (ii + jj >= H)
+        x, y = sa[:rows][m], ob[m]
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(y)].view(np.uint32), y[~np.isnan(y)].view(np.uint32))

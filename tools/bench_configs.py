@@ -45,28 +45,51 @@ def main():
         d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
 
         def step():
+            if name == "c2":  # BASELINE configs[1] is the cost volume itself: the per-function entry point, as bench.py times it
+                return {"disp": sv.unfoldBasedCostVolume(func, d_tgt, d_src, hr, vr, D)}
             return sv.stereoMatch(func, d_tgt, d_src, hr, vr, D, sgmDirections=sgm, refineKernel=refine, refine_h_radius=hr, refine_v_radius=vr,
                                   **extra)
 
-        steps = 5 if W * H * D > 1e9 else 20
-        for _ in range(2):  # warm-up: workspace pool and allocator reach their steady state
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):  # timed without the per-kernel events
-            out = step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        sv.profile_reset(d_src)
-        sv.profile_enable(d_src, True)
-        for _ in range(steps):  # per-kernel breakdown (hipEvents around every launch)
-            out = step()
-        torch.cuda.synchronize()
-        sv.profile_enable(d_src, False)
-        prof = sv.profile_collect(d_src)
+        # timed the way bench.py times its `configs` entries: median of three regions, synchronised on both sides; census + SGM with the
+        # line recurrences run (as the headline), the library's default (winner identity) beside it
+        steps = 5 if W * H * D > 1e9 else (50 if W * H * D < 1e8 else 20)
+        census_sgm = func == MF.CENSUS and sgm > 0
+
+        def timed():
+            for _ in range(2):  # warm-up: workspace pool and allocator reach their steady state
+                step()
+            regions = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    o = step()
+                torch.cuda.synchronize()
+                regions.append((time.perf_counter() - t0) / steps)
+            return sorted(regions)[1], o
+
+        dt_default = None
+        if census_sgm:
+            dt_default, out = timed()
+            sv.set_option(d_src, "census_winner_shortcut", 0)
+        try:
+            dt, out = timed()
+            sv.profile_reset(d_src)
+            sv.profile_enable(d_src, True)
+            for _ in range(steps):  # per-kernel breakdown (hipEvents around every launch)
+                out = step()
+            torch.cuda.synchronize()
+            sv.profile_enable(d_src, False)
+            prof = sv.profile_collect(d_src)
+        finally:
+            if census_sgm:
+                sv.set_option(d_src, "census_winner_shortcut", 1)
         line = {"config": name, "shape": [W, H, D], "func": func.name, "sgm": sgm, "ms": round(dt * 1e3, 3),
                 "Mdisp_per_s": round(W * H * D / dt / 1e6, 1), "kernel_ms": {k: round(v[0] / steps, 3) for k, v in prof.items()},
-                "checksum": int(out["disp"].sum().item())}
+                "checksum": int(out["disp"].double().sum().item())}
+        if census_sgm:
+            line["sgm_recurrences_timed"] = True
+            line["ms_library_default"] = round(dt_default * 1e3, 3)
         if name.startswith("c4"):
             # HBM roofline of the Score-branch SGM, the dominant kernel of this configuration.  SURVEY.md 8(d) prices C4 at 68 B/voxel
             # (C written 4 + five passes x (C read 4 + S read-modify-write 8) + final S read 4).  The reference's five effective passes

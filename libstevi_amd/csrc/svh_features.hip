@@ -160,10 +160,22 @@ __device__ __forceinline__ void shift_in_greater(uint32_t &word, float ref, floa
 // word = 2 word + (ref > sample) is v_sub_f32 + v_alignbit_b32 -- 5.5 issue cycles per pair instead of 8.8 for v_cmp + v_addc
 // (tools/ubench_valu.hip).  Not for NaN or infinities: inf - inf is a NEGATIVE NaN on this hardware and a NaN operand keeps or
 // flips its sign; tiles that hold any take the compare form.
-__device__ __forceinline__ void shift_in_sign(uint32_t &word, float ref, float sample) {
-    float d; // (asm: left to itself the compiler packs pairs of these into v_pk_add_f32 and pays two v_mov per pair to do it)
-    asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(sample), "v"(ref));
-    word = __builtin_amdgcn_alignbit(word, __float_as_uint(d), 31);
+// Eight bits per asm statement: left to itself the compiler packs pairs of the subtractions into v_pk_add_f32 and pays two v_mov per pair
+// to do it, hence asm -- and behind an asm statement whose result the next instruction touches it puts an s_nop (it cannot see that a
+// plain VALU result needs none): with one subtraction per statement that was one nop per three bits, 963 of the kernel's 4 000 issue
+// slots; with eight bits per statement it is one per sixteen instructions.
+__device__ __forceinline__ void shift_in_sign8(uint32_t &word, float ref, float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7) {
+    float d;
+    asm("v_sub_f32 %1, %3, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %4, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %5, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %6, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %7, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %8, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %9, %2\n\tv_alignbit_b32 %0, %0, %1, 31\n\t"
+        "v_sub_f32 %1, %10, %2\n\tv_alignbit_b32 %0, %0, %1, 31"
+        : "+v"(word), "=&v"(d)
+        : "v"(ref), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7));
 }
 
 // ROWS output rows per block: the (2 VR + ROWS) x (512 + 2 HR) tile is staged once and every lane keeps its
@@ -240,11 +252,14 @@ __global__ void __launch_bounds__(TJN) census_grey_kernel(CensusJob job0, Census
 #pragma unroll
             for (int w = 0; w < NWRITTEN; w++) {
 #pragma unroll
-                for (int b = 31; b >= 0; b--) {
-                    const int c = 32 * w + b + 1; // channel index (unfold.h:180) behind bit b of word w (census.h:98-108)
-                    const int k = c / h, l = c % h;
-                    shift_in_sign(dA[w], refA, smp[rr + k][l]);
-                    shift_in_sign(dB[w], refB, smp[rr + k][l + 1]);
+                for (int b = 31; b >= 0; b -= 8) {
+                    // channel index c = 32 w + b + 1 (unfold.h:180) behind bit b of word w (census.h:98-108): window row c / h, column c % h
+#define SVH_SMP(BIT, SHIFT) smp[rr + (32 * w + (BIT) + 1) / h][(32 * w + (BIT) + 1) % h + (SHIFT)]
+                    shift_in_sign8(dA[w], refA, SVH_SMP(b, 0), SVH_SMP(b - 1, 0), SVH_SMP(b - 2, 0), SVH_SMP(b - 3, 0), SVH_SMP(b - 4, 0), SVH_SMP(b - 5, 0),
+                                   SVH_SMP(b - 6, 0), SVH_SMP(b - 7, 0));
+                    shift_in_sign8(dB[w], refB, SVH_SMP(b, 1), SVH_SMP(b - 1, 1), SVH_SMP(b - 2, 1), SVH_SMP(b - 3, 1), SVH_SMP(b - 4, 1), SVH_SMP(b - 5, 1),
+                                   SVH_SMP(b - 6, 1), SVH_SMP(b - 7, 1));
+#undef SVH_SMP
                 }
             }
         } else {

@@ -178,8 +178,9 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             red.minima = scr.get_n<float>((size_t)npx * 2);
             red.flag = scr.get_n<int>(64);
             if (!red.minima || !red.flag) return SVH_ERR_OUT_OF_MEMORY;
-            const int one = 1; // bit 0: no exact-integer route (the kernel does not test integrality); it raises bit 1 itself
-            SVH_HIP_CHECK(ctx, hipMemcpyAsync(red.flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            // bit 0: no exact-integer route (the kernel does not test integrality); it raises bit 1 itself.  (A device-side fill: an
+            // asynchronous copy from a stack variable may be read after the variable is gone.)
+            SVH_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)red.flag, 1, 1, ctx->stream));
             cva_r.reduce = &red;
         }
         SVH_TRY(dev_cost_volume_from_images(ctx, scr, cva_r, isrc, itgt, prm->h_radius, prm->v_radius, d_cv));

@@ -1100,8 +1100,7 @@ static int sgm_cost_volume_impl(svh_context *ctx, int n_directions, int strategy
                 if (!(max_abs <= SGM_SAFE_MAGNITUDE)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "minima_kind 2 states finite magnitudes up to 1e30");
                 int *flag = scr.get_n<int>(64);
                 if (!flag) return SVH_ERR_OUT_OF_MEMORY;
-                const int one = 1;
-                SVH_HIP_CHECK(ctx, hipMemcpyAsync(flag, &one, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                SVH_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)flag, 1, 1, ctx->stream)); // (a device-side fill, not a copy from the stack)
                 cs.float_minima = (const float *)dmin;
                 cs.float_flag = flag;
             }

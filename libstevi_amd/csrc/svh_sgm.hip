@@ -193,16 +193,27 @@ template <bool COST> __device__ __forceinline__ Winner better(Winner a, Winner b
 // ds_bpermute rounds: the fused winner made sgm_cost_apply 35 % longer than the same kernel writing the whole volume.)
 template <bool COST, int R>
 __device__ __forceinline__ Winner wave_select(const float (&s)[R], int lane, int D, bool *first_is_nan) {
+    const bool full = D == 64 * R; // (wave-uniform) every lane's R values exist: no per-value guard
     float A = COST ? INFINITY : -INFINITY;
+    if (full) {
 #pragma unroll
-    for (int k = 0; k < R; k++) {
-        const float x = (lane * R + k < D) ? s[k] : __uint_as_float(0x7FC00000u);
-        A = COST ? fminf(A, x) : fmaxf(A, x);
+        for (int k = 0; k < R; k++) A = COST ? fminf(A, s[k]) : fmaxf(A, s[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const float x = (lane * R + k < D) ? s[k] : __uint_as_float(0x7FC00000u);
+            A = COST ? fminf(A, x) : fmaxf(A, x);
+        }
     }
     const float M = COST ? wave_min(A) : wave_max_dpp(A); // +-inf when every value is NaN (then nothing equals it unless a real +-inf does)
     int kb = -1;
+    if (full) {
 #pragma unroll
-    for (int k = 0; k < R; k++) kb = (lane * R + k < D && s[k] == M) ? k : kb;
+        for (int k = 0; k < R; k++) kb = (s[k] == M) ? k : kb;
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; k++) kb = (lane * R + k < D && s[k] == M) ? k : kb;
+    }
     const unsigned long long holders = __builtin_amdgcn_ballot_w64(kb >= 0);
     *first_is_nan = (__builtin_amdgcn_ballot_w64(isnan(s[0])) & 1ull) != 0;
     if (holders == 0ull) return Winner{0.0f, -1};
@@ -218,6 +229,21 @@ __device__ __forceinline__ unsigned long long winner_key(Winner w, bool first_is
     if (w.d < 0) return COST ? ~0ull : 0ull; // nothing comparable in this shard
     const uint32_t gd = (uint32_t)(key_offset + w.d);
     return ((unsigned long long)float_order_key(w.v) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+}
+
+// Stores the compiler does not count.  Its s_waitcnt bookkeeping treats a store under a branch as "maybe outstanding" and answers with
+// vmcnt(0) at the next use of a load -- which also waits for the loads of the NEXT batch that were issued on purpose.  These outputs are never
+// read back by the kernel, and an uncounted store only makes a counted wait more conservative (vmcnt counts stores too on gfx9).
+__device__ __forceinline__ void store_uncounted(float *p, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v)); }
+__device__ __forceinline__ void store_uncounted(int *p, int v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v)); }
+__device__ __forceinline__ void store_uncounted(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v)); }
+__device__ __forceinline__ void store_uncounted(float4 *p, float4 v) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 r = {v.x, v.y, v.z, v.w};
+    // (a store of more than 64 bits must not be followed at once by a VALU write of its data registers -- one wait state on gfx9, two on
+    // gfx94x/95x; the compiler pads its own stores and knows nothing of this one: without the s_nop a few lanes stored the next address
+    // computation instead of their four values)
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(r));
 }
 
 struct ApplyOut {
@@ -243,13 +269,26 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
     const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int nwaves = gridDim.x * (blockDim.x >> 6);
     const int npx32 = (int)npx;
+    // The min_p values of a pixel are wave-uniform.  Loaded as scalars (24 of them per iteration, with the output descriptor and the pixels'
+    // coordinates) they spilled 67 SGPRs, 440 v_readlane per iteration; and the loop over the passes, unrolled over 4 pixels x 6 passes x
+    // {general, lean, lean at the border}, was 60 KB of code with some 110 scalar branches per pixel on its hot path.  Now LANE q of one
+    // vector register per pixel holds the min_p of pass q (one dword load per pixel), the pass loop is a runtime loop that fetches its
+    // min_p with v_readlane, and the body exists once per prefetched pixel.
+    const int lq = min(lane, max(n_pass, 1) - 1);
+    const float *__restrict__ mp_of_lane = mmap + (int64_t)min_p_plane(lq) * npx;
+    const unsigned pass_mask = (1u << n_pass) - 1u;
     // APPLY_PB pixels per wave iteration: their cost rows and min_p values are all requested before the first one is used
-    // (one pixel at a time leaves a single 1 KiB load in flight per wave and the kernel latency-bound)
-    constexpr int APPLY_PB = 4, MAX_PASS = 6;
-    for (int p0 = wave * APPLY_PB; p0 < npx32; p0 += nwaves * APPLY_PB) {
-      float cb[APPLY_PB][R], mpb[APPLY_PB][MAX_PASS];
+    // (one pixel at a time leaves a single 1 KiB load in flight per wave and the kernel latency-bound).  Two such batches alternate, but the
+    // loads of this general form sit under branches (the guarded tail of a row, the census source), so the compiler waits with vmcnt(0) and the
+    // alternation buys nothing here: sgm_cost_apply_piped_kernel below is the form for aligned dense volumes.
+    constexpr int APPLY_PB = R <= 4 ? 4 : R <= 8 ? 2 : 1;
+    struct Batch {
+        float cb[APPLY_PB][R], mpl[APPLY_PB];
+    };
+    const int64_t stride = (int64_t)nwaves * APPLY_PB;
+    auto load_batch = [&](Batch &B, int64_t q0) {
+      const int p0 = (int)min(q0, (int64_t)npx32 - 1); // (past the end: the last pixel again, unused)
       const int i0 = (int)((unsigned)p0 / (unsigned)W), j0 = p0 - i0 * W;
-      int iu[APPLY_PB], ju[APPLY_PB];
 #pragma unroll
       for (int u = 0; u < APPLY_PB; u++) {
           const int pu = min(p0 + u, npx32 - 1);
@@ -258,48 +297,87 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
               jj -= W;
               ii++;
           }
-          iu[u] = ii;
-          ju[u] = jj;
-          src.template load<R>(ii, jj, lane, cb[u]);
-#pragma unroll
-          for (int q = 0; q < MAX_PASS; q++) mpb[u][q] = q < n_pass ? mmap[(int64_t)min_p_plane(q) * npx + pu] : 0.0f;
+          src.template load<R>(ii, jj, lane, B.cb[u]);
+          B.mpl[u] = n_pass > 0 ? mp_of_lane[pu] : 0.0f;
       }
+    };
+    auto run_batch = [&](const Batch &B, int64_t q0) {
+      if (q0 >= npx) return;
+      const int p0 = (int)q0;
+      const int i0 = (int)((unsigned)p0 / (unsigned)W), j0 = p0 - i0 * W;
+      const auto &cb = B.cb;
+      const auto &mpl = B.mpl;
 #pragma unroll
       for (int u = 0; u < APPLY_PB; u++) {
-        const int64_t p = p0 + u;
+        const int64_t p = (int64_t)p0 + u;
         if (p >= npx) break;
-        const int j = ju[u], i = iu[u];
+        int j = j0 + u, i = i0;
+        while (j >= W) {
+            j -= W;
+            i++;
+        }
         float c[R], s[R];
 #pragma unroll
         for (int k = 0; k < R; k++) s[k] = c[k] = cb[u][k]; // sgm_cv := cv, sgm.h:371-377
         const int ip = i - top, jp = j - left;
-        if (ip >= 0 && ip < Hp && jp >= 0 && jp < Wp) {
+        unsigned visits = 0u; // bit q: pass q visits this pixel (pass_visits(), svh_sgm_lines.h)
+        if (ip >= 0 && ip < Hp && jp >= 0 && jp < Wp)
+            visits = (3u | (ip >= jp ? 4u : 0u) | (jp >= ip ? 8u : 0u) | (ip + jp < Wp ? 16u : 0u) | (ip + jp < Hp ? 32u : 0u)) & pass_mask;
+        const bool at_border = j + D > W;
+        // The common pixel -- every disparity looks inside the image, the min_p of the passes that visit it finite, the lean regime -- takes the
+        // passes that visit it (four on average: two always, one of the two diagonal halves, one or both anti-diagonal ones) in order, four packed
+        // operations per pass and pair of disparities, with no other decision inside the loop.  (The one loop that decided regime, border and
+        // finiteness per pass came out at 15 vector instructions and 17 scalar ones per pass, and the kernel was bound by them, not by its read.)
+        unsigned todo = visits;
+        if constexpr (R % 2 == 0) {
+            const unsigned fin = (unsigned)__builtin_amdgcn_ballot_w64(finite_f(mpl[u])); // bit q: min_p of pass q finite (lane q holds it)
+            if (lean && !at_border && (visits & ~fin) == 0u) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 c2[R / 2], s2[R / 2];
 #pragma unroll
-            for (int q = 0; q < MAX_PASS; q++) {
-                if (q >= n_pass || !pass_visits(q, ip, jp, Hp, Wp)) continue;
-                const float mp = mpb[u][q];
-                const bool mp_fin = finite_f(mp);
-                if (lean && mp_fin) { // (wave uniform)
-                    if (j + D > W) {
+                for (int h = 0; h < R / 2; h++) {
+                    c2[h] = f32x2{c[2 * h], c[2 * h + 1]};
+                    s2[h] = c2[h];
+                }
+                while (todo) {
+                    const int q = __builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    const float mp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mpl[u]), q));
+                    const f32x2 mp2 = {mp, mp};
 #pragma unroll
-                        for (int k = 0; k < R; k++) {
-                            const float t = (j + lane * R + k >= W) ? c[k] + Pout : c[k];
-                            s[k] += (c[k] + (t - mp)) - c[k];
-                        }
-                    } else {
+                    for (int h = 0; h < R / 2; h++) s2[h] += (c2[h] + (c2[h] - mp2)) - c2[h]; // sgm.h:291-300 with t = c, both terms finite
+                }
 #pragma unroll
-                        for (int k = 0; k < R; k++) s[k] += (c[k] + (c[k] - mp)) - c[k];
+                for (int h = 0; h < R / 2; h++) {
+                    s[2 * h] = s2[h][0];
+                    s[2 * h + 1] = s2[h][1];
+                }
+            }
+        }
+        for (int q = 0; q < n_pass; q++) { // (every condition in this loop is wave-uniform)
+            if (!((todo >> q) & 1u)) continue;
+            const float mp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mpl[u]), q));
+            const bool mp_fin = finite_f(mp);
+            if (lean && mp_fin) {
+                if (at_border) {
+#pragma unroll
+                    for (int k = 0; k < R; k++) {
+                        const float t = (j + lane * R + k >= W) ? c[k] + Pout : c[k];
+                        s[k] += (c[k] + (t - mp)) - c[k];
                     }
-                    continue;
-                }
+                } else {
 #pragma unroll
-                for (int k = 0; k < R; k++) {
-                    int d = lane * R + k;
-                    float t = (j + d >= W) ? c[k] + Pout : c[k];
-                    float act = c[k];
-                    if (mp_fin && finite_f(t)) act = c[k] + (t - mp);
-                    s[k] += act - c[k]; // sgm.h:298-300
+                    for (int k = 0; k < R; k++) s[k] += (c[k] + (c[k] - mp)) - c[k];
                 }
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                int d = lane * R + k;
+                float t = (j + d >= W) ? c[k] + Pout : c[k];
+                float act = c[k];
+                if (mp_fin && finite_f(t)) act = c[k] + (t - mp);
+                s[k] += act - c[k]; // sgm.h:298-300
             }
         }
         if (out.sgm) {
@@ -308,14 +386,14 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
             if constexpr (R % 4 == 0) {
                 if (out.vec_store && lane * R + R <= D) {
 #pragma unroll
-                    for (int q = 0; q < R / 4; q++) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
+                    for (int q = 0; q < R / 4; q++) store_uncounted(reinterpret_cast<float4 *>(o + 4 * q), make_float4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]));
                     stored = true;
                 }
             }
             if (!stored) {
 #pragma unroll
                 for (int k = 0; k < R; k++)
-                    if (lane * R + k < D) o[k] = s[k];
+                    if (lane * R + k < D) store_uncounted(o + k, s[k]);
             }
         }
         const WinnerOut &wo = out.w;
@@ -323,9 +401,9 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
             bool first_nan;
             const Winner w = wave_select<true, R>(s, lane, D, &first_nan);
             const int sel = (first_nan || w.d < 0) ? 0 : w.d;
-            if (wo.idx && lane == 0) wo.idx[p] = sel;
-            if (wo.disp && lane == 0) wo.disp[p] = wo.disp_sign * sel + wo.disp_offset;
-            if (wo.keys && lane == 0) wo.keys[p] = winner_key<true>(w, first_nan, wo.key_offset, wo.key_total);
+            if (wo.idx && lane == 0) store_uncounted(wo.idx + p, sel);
+            if (wo.disp && lane == 0) store_uncounted(wo.disp + p, wo.disp_sign * sel + wo.disp_offset);
+            if (wo.keys && lane == 0) store_uncounted(wo.keys + p, winner_key<true>(w, first_nan, wo.key_offset, wo.key_total));
             if (wo.taps) {
                 // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613)
                 const bool px_bad = j < wo.taps_h_r || i < wo.taps_v_r || i + wo.taps_v_r >= H;
@@ -334,16 +412,244 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_kernel(SRC src, int H, int
                     const int pd = sel + t - 1;
                     const bool bad = px_bad || pd < 0 || pd >= D || j + pd + wo.taps_h_r >= W;
                     if (bad) {
-                        if (lane == 0) wo.taps[p * 3 + t] = __uint_as_float(0x7FC00000u);
+                        if (lane == 0) store_uncounted(wo.taps + p * 3 + t, __uint_as_float(0x7FC00000u));
                     } else {
 #pragma unroll
                         for (int k = 0; k < R; k++)
-                            if (lane * R + k == pd) wo.taps[p * 3 + t] = s[k];
+                            if (lane * R + k == pd) store_uncounted(wo.taps + p * 3 + t, s[k]);
                     }
                 }
             }
         }
       }
+    };
+    Batch A, B;
+    load_batch(A, (int64_t)wave * APPLY_PB);
+    for (int64_t q0 = (int64_t)wave * APPLY_PB; q0 < npx; q0 += 2 * stride) {
+        load_batch(B, q0 + stride);
+        run_batch(A, q0);
+        load_batch(A, q0 + 2 * stride);
+        run_batch(B, q0 + stride);
+    }
+}
+
+// ---- the same for a dense volume with 16-byte aligned rows and D % 4 == 0 (R % 4 == 0): software-pipelined, scalar-lean --------------
+// Counters of the general kernel above at 1920 x 1080 x 256 (rocprofv3 --pmc, per pixel): 105 vector, 136 scalar and 39 branch instructions.
+// A CU issues one scalar instruction per cycle for its four SIMDs, so 136 scalar instructions per pixel are 0.46 ms of scalar issue alone
+// -- more than the kernel's one read of the volume (0.42 ms); and every wait was an s_waitcnt vmcnt(0) (loads under a branch, stores under
+// `if (lane == 0)`), so a wave had nothing in flight while it worked.  This form
+//  * loads rows through buffer descriptors that cover exactly one pixel's row (a lane past D reads zeros, what the guarded loads give it):
+//    every load is unconditional, the compiler's count of loads in flight is exact, and two batches alternate for real;
+//  * issues its stores as inline asm the compiler does not count (they are never read back), addressed from a scalar base;
+//  * computes what depends on the pixel's coordinates (which passes visit it, whether a disparity looks past the border, the limit of the
+//    refinement taps) in the LANES of one register per batch -- lane u for pixel u -- next to the loads, and fetches it with one v_readlane;
+//  * collects the winners of a batch in lanes and stores each output array once per batch, not once per pixel under its own exec mask.
+template <int OFF> __device__ __forceinline__ void store_row_b128(const float *sbase, int voff, float a, float b, float c, float d) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 r = {a, b, c, d};
+    // (the s_nop: see store_uncounted(float4 *, float4))
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(r), "s"(sbase), "n"(OFF));
+}
+template <int R, int Q = 0> __device__ __forceinline__ void store_row(const float *sbase, int voff, const float (&s)[R], int lane, int D, bool full) {
+    if constexpr (Q < R / 4) {
+        if (full || lane * R + 4 * Q + 4 <= D) store_row_b128<16 * Q>(sbase, voff, s[4 * Q], s[4 * Q + 1], s[4 * Q + 2], s[4 * Q + 3]);
+        store_row<R, Q + 1>(sbase, voff, s, lane, D, full);
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) sgm_cost_apply_piped_kernel(const float *__restrict__ cv, int H, int W, int D, int top, int left, int Hp, int Wp,
+                                                                  int n_pass, float Pout, const float *__restrict__ mmap, ApplyOut out,
+                                                                  const int *__restrict__ regime_flag, int regime_vouched) {
+    static_assert(R % 4 == 0, "");
+    const int lane = threadIdx.x & 63;
+    const int64_t npx = (int64_t)H * W;
+    const int npx32 = (int)npx;
+    const bool lean = (regime_vouched || (regime_flag && (*regime_flag & 2) == 0)) && finite_f(Pout); // (see sgm_cost_apply_kernel)
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int lq = min(lane, max(n_pass, 1) - 1);
+    const float *__restrict__ mp_of_lane = mmap + (int64_t)min_p_plane(lq) * npx; // lane q: the plane of pass q
+    const unsigned pass_mask = (1u << n_pass) - 1u;
+    const bool full = D == 64 * R;
+    const WinnerOut &wo = out.w;
+    const bool want_winner = wo.idx || wo.disp || wo.taps || wo.keys;
+    constexpr int PB = R <= 4 ? 4 : R <= 8 ? 2 : 1;
+    constexpr unsigned BORDER = 64u;
+    struct Batch {
+        float cb[PB][R], mpl[PB];
+        unsigned info; // lane u: bits 0..5 the passes that visit pixel u of the batch (pass_visits(), svh_sgm_lines.h), bit 6: j + D > W
+        int j, limit;  // lane u: the pixel's column; the first disparity whose refinement tap is outside (truncatedCostVolume<Same>), -2: all are
+    };
+    const int64_t stride = (int64_t)nwaves * PB;
+    auto load_batch = [&](Batch &B, int64_t q0) {
+        const int p0 = (int)min(q0, (int64_t)npx32 - 1); // (past the end: the last pixel again, unused)
+        const int i0 = (int)((unsigned)p0 / (unsigned)W), j0 = p0 - i0 * W;
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            const int pu = min(p0 + u, npx32 - 1);
+            const __amdgpu_buffer_rsrc_t row = __builtin_amdgcn_make_buffer_rsrc((void *)(cv + (int64_t)pu * D), 0, D * 4, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < R / 4; q++) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(row, (lane * R + 4 * q) * 4, 0, 0);
+                // (through named words: __builtin_bit_cast applied to a vector element reads element 0 whatever the subscript)
+                const uint32_t w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3];
+                B.cb[u][4 * q] = __uint_as_float(w0);
+                B.cb[u][4 * q + 1] = __uint_as_float(w1);
+                B.cb[u][4 * q + 2] = __uint_as_float(w2);
+                B.cb[u][4 * q + 3] = __uint_as_float(w3);
+            }
+            B.mpl[u] = mp_of_lane[pu]; // (the scratch always holds every plane)
+        }
+        int jj = j0 + min(lane, PB - 1), ii = i0; // lane u: pixel p0 + u (past the last pixel of the image: a row that does not exist, unused)
+        while (jj >= W) {                       // (an image narrower than PB pixels wraps more than once)
+            jj -= W;
+            ii++;
+        }
+        const int ip = ii - top, jp = jj - left;
+        unsigned vis = 0u;
+        if (ip >= 0 && ip < Hp && jp >= 0 && jp < Wp)
+            vis = (3u | (ip >= jp ? 4u : 0u) | (jp >= ip ? 8u : 0u) | (ip + jp < Wp ? 16u : 0u) | (ip + jp < Hp ? 32u : 0u)) & pass_mask;
+        B.info = vis | (jj + D > W ? BORDER : 0u);
+        B.j = jj;
+        const bool px_bad = jj < wo.taps_h_r || ii < wo.taps_v_r || ii + wo.taps_v_r >= H;
+        B.limit = px_bad ? -2 : W - wo.taps_h_r - jj;
+    };
+    auto run_batch = [&](const Batch &B, int64_t q0) {
+        if (q0 >= npx) return;
+        const int p0 = (int)q0;
+        const int nvalid = min(PB, npx32 - p0);
+        // the winners of the batch, lane u for pixel u: extremum, local index (-1: none), "the value at index 0 is NaN"; lanes 3u .. 3u + 2: the taps
+        int Mv = 0, dv = 0, fnv = 0;
+        float tapv = 0.0f;
+#pragma unroll
+        for (int u = 0; u < PB; u++) {
+            if (u >= nvalid) break;
+            const unsigned info = (unsigned)__builtin_amdgcn_readlane((int)B.info, u);
+            float c[R], s[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) s[k] = c[k] = B.cb[u][k]; // sgm_cv := cv, sgm.h:371-377
+            const unsigned visits = info & 63u;
+            const unsigned fin = (unsigned)__builtin_amdgcn_ballot_w64(finite_f(B.mpl[u])); // bit q: min_p of pass q finite (lane q holds it)
+            unsigned todo = visits;
+            if (lean && (info & BORDER) == 0u && (visits & ~fin) == 0u) {
+                // the common pixel: every disparity looks inside the image, finite min_p, the lean regime -- the passes that visit it in order,
+                // four packed operations per pass and pair of disparities (sgm.h:291-300 with t = c and both terms finite)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 c2[R / 2], s2[R / 2];
+#pragma unroll
+                for (int h = 0; h < R / 2; h++) {
+                    c2[h] = f32x2{c[2 * h], c[2 * h + 1]};
+                    s2[h] = c2[h];
+                }
+                while (todo) {
+                    const int q = __builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    const float mp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, B.mpl[u]), q));
+                    const f32x2 mp2 = {mp, mp};
+#pragma unroll
+                    for (int h = 0; h < R / 2; h++) s2[h] += (c2[h] + (c2[h] - mp2)) - c2[h];
+                }
+#pragma unroll
+                for (int h = 0; h < R / 2; h++) {
+                    s[2 * h] = s2[h][0];
+                    s[2 * h + 1] = s2[h][1];
+                }
+            }
+            if (todo) { // a pixel at the border, a non-finite min_p, or not the lean regime: the step as written
+                const int j = __builtin_amdgcn_readlane(B.j, u);
+                for (int q = 0; q < n_pass; q++) { // (every condition in this loop is wave-uniform)
+                    if (!((todo >> q) & 1u)) continue;
+                    const float mp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, B.mpl[u]), q));
+                    const bool mp_fin = finite_f(mp);
+                    if (lean && mp_fin) {
+#pragma unroll
+                        for (int k = 0; k < R; k++) {
+                            const float t = (j + lane * R + k >= W) ? c[k] + Pout : c[k];
+                            s[k] += (c[k] + (t - mp)) - c[k];
+                        }
+                        continue;
+                    }
+#pragma unroll
+                    for (int k = 0; k < R; k++) {
+                        const int d = lane * R + k;
+                        const float t = (j + d >= W) ? c[k] + Pout : c[k];
+                        float act = c[k];
+                        if (mp_fin && finite_f(t)) act = c[k] + (t - mp);
+                        s[k] += act - c[k]; // sgm.h:298-300
+                    }
+                }
+            }
+            if (out.sgm) store_row<R>(out.sgm + (int64_t)(p0 + u) * D, lane * R * 4, s, lane, D, full);
+            if (!want_winner) continue;
+            // extractSelectedIndex (correlation_base.h:441-455): the extremum over the non-NaN values, ties to the larger index -- the wave
+            // extremum by DPP, a ballot of the lanes holding a value EQUAL to it, the highest such lane and its largest such k
+            float A = INFINITY;
+            int kb = -1;
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < R; k++) A = fminf(A, s[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; k++) A = fminf(A, (lane * R + k < D) ? s[k] : INFINITY);
+            }
+            const float M = wave_min(A); // +inf when every value is NaN (then nothing equals it unless a real +inf does)
+            if (full) {
+#pragma unroll
+                for (int k = 0; k < R; k++) kb = (s[k] == M) ? k : kb;
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; k++) kb = (lane * R + k < D && s[k] == M) ? k : kb;
+            }
+            const unsigned long long holders = __builtin_amdgcn_ballot_w64(kb >= 0);
+            const int first_nan = (int)(__builtin_amdgcn_ballot_w64(isnan(s[0])) & 1ull);
+            const int wl = holders ? 63 - __builtin_clzll(holders) : 0; // the winning lane
+            const int wd = holders ? wl * R + __builtin_amdgcn_readlane(kb, wl) : -1;
+            Mv = lane == u ? __builtin_bit_cast(int, M) : Mv;
+            dv = lane == u ? wd : dv;
+            fnv = lane == u ? first_nan : fnv;
+            if (wo.taps) {
+                // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613) around the selected index: every lane builds the triple of ITS
+                // candidate from its own registers and its neighbours' edge values (two DPP moves); the lane that holds the selected index is read
+                const int sel = (first_nan || wd < 0) ? 0 : wd;
+                const int sl = sel / R, sk = sel % R; // (R is a power of two)
+                const float prevL = lane_shift_up(s[R - 1], 0.0f), nextR = lane_shift_down(s[0], 0.0f);
+                float t0 = s[0], tm1 = prevL, tp1 = R > 1 ? s[R > 1 ? 1 : 0] : nextR;
+#pragma unroll
+                for (int k = 1; k < R; k++) {
+                    const bool here = sk == k;
+                    t0 = here ? s[k] : t0;
+                    tm1 = here ? s[k - 1] : tm1;
+                    tp1 = here ? (k + 1 < R ? s[k + 1 < R ? k + 1 : k] : nextR) : tp1;
+                }
+                const int limit = __builtin_amdgcn_readlane(B.limit, u); // valid: 0 <= pd < D and pd < limit
+                const float nan = __uint_as_float(0x7FC00000u);
+                const float r0 = (sel == 0 || sel - 1 >= limit) ? nan : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tm1), sl));
+                const float r1 = (sel >= limit) ? nan : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t0), sl));
+                const float r2 = (sel + 1 >= D || sel + 1 >= limit) ? nan : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tp1), sl));
+                tapv = lane == 3 * u ? r0 : tapv;
+                tapv = lane == 3 * u + 1 ? r1 : tapv;
+                tapv = lane == 3 * u + 2 ? r2 : tapv;
+            }
+        }
+        if (!want_winner) return;
+        if (lane < nvalid) {
+            const int64_t p = (int64_t)p0 + lane;
+            const Winner w{__builtin_bit_cast(float, Mv), dv};
+            const int sel = (fnv || dv < 0) ? 0 : dv;
+            if (wo.idx) store_uncounted(wo.idx + p, sel);
+            if (wo.disp) store_uncounted(wo.disp + p, wo.disp_sign * sel + wo.disp_offset);
+            if (wo.keys) store_uncounted(wo.keys + p, winner_key<true>(w, fnv != 0, wo.key_offset, wo.key_total));
+        }
+        if (wo.taps && lane < 3 * nvalid) store_uncounted(wo.taps + (int64_t)p0 * 3 + lane, tapv);
+    };
+    Batch A, B;
+    load_batch(A, (int64_t)wave * PB);
+    for (int64_t q0 = (int64_t)wave * PB; q0 < npx; q0 += 2 * stride) {
+        load_batch(B, q0 + stride);
+        run_batch(A, q0);
+        load_batch(A, q0 + 2 * stride);
+        run_batch(B, q0 + stride);
     }
 }
 
@@ -811,8 +1117,17 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
     if (out) {
         const int64_t npx = (int64_t)a.H * a.W;
         int grid = grid_for(npx, 4, 256 * 8 * 4);
-        SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
-                   Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag, regime_vouched ? 1 : 0);
+        bool piped = false;
+        if constexpr (std::is_same<SRC, SrcVolume>::value && R % 4 == 0) {
+            if (src.vec && (!out->sgm || out->vec_store)) {
+                piped = true;
+                SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_piped_kernel<R>), grid, 256, 0, src.cv, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
+                           Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag, regime_vouched ? 1 : 0);
+            }
+        }
+        if (!piped)
+            SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_kernel<SRC, R>), grid, 256, 0, src, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
+                       Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag, regime_vouched ? 1 : 0);
         SVH_CHECK_LAUNCH(ctx);
     }
     return SVH_OK;

@@ -57,17 +57,26 @@ __device__ __forceinline__ bool pass_visits(int q, int ip, int jp, int Hp, int W
 
 __device__ __forceinline__ bool finite_f(float x) { return fabsf(x) < INFINITY; } // false for NaN and +-inf
 
-__device__ __forceinline__ float wave_min(float v) { // DPP: row_shr 1,2,4,8, row_bcast:15, row_bcast:31, result in lane 63
-#define SVH_DPP_MIN(CTRL, RM) v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0x7F800000, __builtin_bit_cast(int, v), CTRL, RM, 0xF, false)))
-    SVH_DPP_MIN(0x111, 0xF);
-    SVH_DPP_MIN(0x112, 0xF);
-    SVH_DPP_MIN(0x114, 0xF);
-    SVH_DPP_MIN(0x118, 0xF);
-    SVH_DPP_MIN(0x142, 0xA);
-    SVH_DPP_MIN(0x143, 0xC);
-#undef SVH_DPP_MIN
+// Wave extremum, result in every lane's return value (read from lane 63): row_shr 1,2,4,8, row_bcast:15, row_bcast:31 as hand-written DPP steps, one
+// instruction each -- the compiler's form of `v = fminf(v, update_dpp(inf, v, ...))` is a v_mov of the fill value, the v_mov_dpp, a canonicalising
+// v_max and the v_min, and the kernels that reduce per pixel are bound by instruction issue.  A lane whose DPP source does not exist is not
+// written and keeps its value (what the +-inf fill gave); a quiet NaN operand yields the other operand, as fminf / fmaxf do.  The operand
+// must not be a signalling NaN (every caller passes the result of an fminf / fmaxf chain, which is canonical).
+template <bool MIN> __device__ __forceinline__ float wave_extremum_dpp(float v) {
+#define SVH_EXT_DPP(CTRL)                                                                  \
+    if constexpr (MIN) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL : "+v"(v));     \
+    else asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL : "+v"(v))
+    SVH_EXT_DPP("row_shr:1 row_mask:0xf bank_mask:0xf");
+    SVH_EXT_DPP("row_shr:2 row_mask:0xf bank_mask:0xf");
+    SVH_EXT_DPP("row_shr:4 row_mask:0xf bank_mask:0xf");
+    SVH_EXT_DPP("row_shr:8 row_mask:0xf bank_mask:0xf");
+    SVH_EXT_DPP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    SVH_EXT_DPP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef SVH_EXT_DPP
+    asm("s_nop 0" : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+__device__ __forceinline__ float wave_min(float v) { return wave_extremum_dpp<true>(v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
@@ -130,9 +139,7 @@ __device__ __forceinline__ float wave_prefix_max(float v) {
     v = fmaxf(v, dpp_move<0x143, 0xC>(-INFINITY, v));
     return v;
 }
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_prefix_max(v)), 63));
-}
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_extremum_dpp<false>(v); }
 
 // R consecutive floats of a lane as 16 / 8 / 4-byte accesses (any address space)
 template <int R> __device__ __forceinline__ void lds_get(const float *p, float (&v)[R]) {

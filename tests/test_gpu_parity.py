@@ -695,6 +695,68 @@ def test_winner_travels_with_the_aggregated_volume(rng, strategy):
         assert getattr(sv.sgmCostVolume(n_dir, strategy, d, 0.01, 0.1, margins, 5.0), "_svh_winner", None) is None
 
 
+def _order_code(v):
+    u = np.where(v == 0, np.float32(0), v).astype(np.float32).view(np.uint32)
+    return np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64)
+
+
+@pytest.mark.parametrize("D", [132, 256, 260, 300, 512, 516, 1028])
+def test_cost_apply_pipelined_form(rng, D):
+    """Aligned dense volumes with D % 4 == 0 and more than 128 disparities take sgm_cost_apply_piped_kernel (rows through buffer descriptors,
+    two batches in flight, per-batch winner stores, uncounted stores): the aggregated volume and the winner it leaves, bit for bit against
+    the oracle -- rows that are no multiple of 64 R (lanes past D), images narrower than a batch of pixels, pixels whose every disparity
+    looks past the border, NaN / +-inf voxels, whole non-finite pixels (a non-finite min_p for the next one), magnitudes outside the lean
+    regime, an infinite Pout, margins (also margins that leave no pixel to aggregate), four directions."""
+    for H, W in ((7, 11), (3, 2), (4, 1), (1, 5), (2, 3)) if D < 1000 else ((3, 5), (2, 1)):
+        base = (rng.uniform(-1, 1, (H, W, D)) * 10.0 ** rng.integers(-3, 4, (H, W, 1))).astype(np.float32)
+        ints = rng.integers(0, 65, (H, W, D)).astype(np.float32)
+        holes = base.copy()
+        holes[0, 0, :] = np.inf
+        holes[H // 2, W // 2, 1] = -np.inf
+        holes[H - 1, W - 1, D - 1] = np.nan
+        holes[H - 1, 0, 0] = np.nan  # "the value at index 0 is NaN": index 0 wins
+        holes[0, W - 1, : D - 3] = np.nan
+        huge = base.copy()
+        huge[H // 2, 0, 5] = 3e38
+        for name, cv in (("ints", ints), ("magnitudes", base), ("non-finite", holes), ("huge", huge)):
+            d = dev(cv)
+            for n_dir, margins, Pout in ((8, (0, 0, 0, 0), 100.0), (8, (1, 0, 1, 0), 0.37), (4, (0, 0, 0, 0), -3.5), (8, (0, 0, 0, 0), np.inf), (8, (5, 0, 9, 0), 1.0)):
+                exp = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, margins, Pout)
+                sv.profile_reset(d)
+                sv.profile_enable(d, True)
+                got_t = sv.sgmCostVolume(n_dir, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout, keep_winner=True)
+                sv.profile_enable(d, False)
+                assert "sgm_cost_apply" in sv.profile_collect(d)
+                got = host(got_t)
+                what = (name, (H, W, D), n_dir, margins, Pout)
+                assert np.array_equal(np.isnan(got), np.isnan(exp)), what
+                ok = ~np.isnan(exp)
+                assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32)), what
+                assert getattr(got_t, "_svh_winner", None) is not None
+                assert np.array_equal(host(sv.extractSelectedIndex(so.COST, got_t)), so.extract_index(exp, so.COST)), what
+
+
+@pytest.mark.parametrize("func,D,W", [(MF.SAD, 132, 150), (MF.SAD, 256, 300), (MF.SSD, 300, 310), (MF.SAD, 260, 64)])
+def test_cost_apply_pipelined_form_winner_outputs(func, D, W):
+    """... and every per-pixel output of the fused call (disparity, reduction keys, the three refinement taps through the refined map) from
+    that kernel, with and without the aggregated volume written beside them, against the oracle run on the GPU's own cost volume."""
+    H = 9
+    src, tgt, _ = parallax_pair(H, W, 5, 2, W // 3, 2, min(W // 4, 40), seed=D + W)
+    kw = dict(sgmDirections=8, P1=0.01, P2=0.1, Pout=5.0, refineKernel=so.PARABOLA, refine_h_radius=2, refine_v_radius=2, want_keys=True)
+    full = sv.stereoMatch(func, dev(tgt), dev(src), 2, 2, D, want_cv=True, want_sgm_cv=True, **kw)
+    vol = so.sgm(host(full["cv"]), 8, so.COST, 0.01, 0.1, (0, 0, 0, 0), 5.0)
+    assert_bits(full["sgm_cv"], vol)
+    idx = so.extract_index(vol, so.COST)
+    exp_refined = so.refine_disp(so.truncated_cost_volume(vol, idx, 2, 2, 1), idx, so.PARABOLA)
+    best = np.take_along_axis(vol, idx[..., None].astype(np.int64), axis=2)[..., 0]
+    for res in (full, sv.stereoMatch(func, dev(tgt), dev(src), 2, 2, D, **kw)):
+        assert np.array_equal(host(res["disp"]), so.index_to_disp(idx))
+        keys = host(res["keys"]).view(np.uint64)
+        assert np.array_equal(keys >> np.uint64(32), _order_code(best))
+        assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.int64), D - 1 - idx.astype(np.int64))
+        assert_close(res["refined"], exp_refined, 1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ randomised sweep
 def test_random_configurations_against_oracle():
     """Seeded random shapes / windows / ranges / margins / penalties through the fused pipeline and the per-function

@@ -653,6 +653,202 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_piped_kernel(const float *
     }
 }
 
+// ---- ... and for 128 disparities or fewer: several pixels per wave ----------------------------------------------------------------------
+// With one or two disparities per lane a wave-per-pixel kernel issues a pixel's whole instruction stream for 64 or 128 costs: at 1080p the
+// general kernel takes 0.56 ms for D = 64 and 0.57 ms for D = 128 -- the same as for 256 -- where the volume's read is 0.10 / 0.21 ms.
+// Here a lane holds FOUR disparities of one pixel (a 16-byte load) and a pixel takes LPP = 16 (D <= 64) or 32 (D <= 128) lanes, so a wave
+// works on four or two neighbouring pixels at once.  What was wave-uniform scalar state per pixel (coordinates, visiting passes, min_p) is
+// per-lane vector state now; the common case -- the lean regime, no disparity past the border, every lane's pixel visited by the same
+// passes with finite min_p -- is detected per group with one ballot and runs the same packed pass loop; everything else takes the step as
+// written with per-lane predicates.  Reductions stay inside a pixel's lanes: row_ror DPP steps (an all-reduce within a row of 16) and one
+// v_permlane16_swap for the two rows of a 32-lane pixel.  The lane that holds the winner writes the pixel's outputs.
+template <bool MIN> __device__ __forceinline__ float row_allreduce_f32(float v) { // every lane: the extremum of its row of 16
+#define SVH_ROR_DPP(CTRL)                                                                                                   \
+    if constexpr (MIN) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v));          \
+    else asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+    SVH_ROR_DPP("row_ror:1");
+    SVH_ROR_DPP("row_ror:2");
+    SVH_ROR_DPP("row_ror:4");
+    SVH_ROR_DPP("row_ror:8");
+#undef SVH_ROR_DPP
+    asm("s_nop 0" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int row_allreduce_max_i32(int v) {
+#define SVH_ROR_DPP(CTRL) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+    SVH_ROR_DPP("row_ror:1");
+    SVH_ROR_DPP("row_ror:2");
+    SVH_ROR_DPP("row_ror:4");
+    SVH_ROR_DPP("row_ror:8");
+#undef SVH_ROR_DPP
+    asm("s_nop 0" : "+v"(v));
+    return v;
+}
+// all-reduce over the LPP lanes of a pixel (LPP = 32: both rows of the pair hold both rows' values after the swap)
+template <int LPP> __device__ __forceinline__ float pixel_allreduce_min(float v) {
+    v = row_allreduce_f32<true>(v);
+    if constexpr (LPP == 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const uint32_t a = r[0], b = r[1];
+        v = fminf(__uint_as_float(a), __uint_as_float(b));
+    }
+    return v;
+}
+template <int LPP> __device__ __forceinline__ int pixel_allreduce_max(int v) {
+    v = row_allreduce_max_i32(v);
+    if constexpr (LPP == 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        const uint32_t a = r[0], b = r[1];
+        v = max((int)a, (int)b);
+    }
+    return v;
+}
+
+template <int LPP>
+__global__ void __launch_bounds__(256) sgm_cost_apply_packed_kernel(const float *__restrict__ cv, int H, int W, int D, int top, int left, int Hp, int Wp,
+                                                                   int n_pass, float Pout, const float *__restrict__ mmap, ApplyOut out,
+                                                                   const int *__restrict__ regime_flag, int regime_vouched) {
+    static_assert(LPP == 16 || LPP == 32, "");
+    constexpr int PPW = 64 / LPP, G = 2, PB = G * PPW; // pixels per wave and group; groups, pixels per batch
+    const int lane = threadIdx.x & 63, sub = lane / LPP, dl = lane % LPP, d0 = dl * 4;
+    const int64_t npx = (int64_t)H * W;
+    const int npx32 = (int)npx;
+    const bool lean = (regime_vouched || (regime_flag && (*regime_flag & 2) == 0)) && finite_f(Pout); // (see sgm_cost_apply_kernel)
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const unsigned pass_mask = (1u << n_pass) - 1u;
+    const bool lane_on = d0 < D; // (D % 4 == 0: a lane's four disparities exist or none does)
+    const WinnerOut &wo = out.w;
+    const bool want_winner = wo.idx || wo.disp || wo.taps || wo.keys;
+    // "the value at index 0 is NaN" makes index 0 the winner (correlation_base.h:441-455) but enters a reduction key only in the shard that
+    // holds disparity 0 (winner_key): folded into the one integer reduction below when the two agree -- the host sends the other case
+    // (keys of a later shard together with an index map) to the general kernel
+    const bool fold_first_nan = !wo.keys || wo.key_offset == 0;
+    struct Batch {
+        float c[G][4], mp[G][MIN_P_PLANES];
+    };
+    const int64_t stride = (int64_t)nwaves * PB;
+    auto load_batch = [&](Batch &B, int64_t q0) {
+        const int p0 = (int)min(q0, (int64_t)npx32 - 1); // (past the end: the last pixel again, unused)
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int p = min(p0 + g * PPW + sub, npx32 - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(cv + (int64_t)p * D + (lane_on ? d0 : 0)); // (a lane past D: the row's first costs, unused)
+            B.c[g][0] = v.x; B.c[g][1] = v.y; B.c[g][2] = v.z; B.c[g][3] = v.w;
+#pragma unroll
+            for (int pl = 0; pl < MIN_P_PLANES; pl++) B.mp[g][pl] = mmap[(int64_t)pl * npx + p]; // (the scratch always holds every plane)
+        }
+    };
+    auto run_batch = [&](const Batch &B, int64_t q0) {
+        if (q0 >= npx) return;
+        const int p0 = (int)q0;
+        const int i0 = (int)((unsigned)p0 / (unsigned)W), j0 = p0 - i0 * W;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (p0 + g * PPW >= npx32) break; // (wave-uniform) no pixel of this group exists
+            const int p = p0 + g * PPW + sub;
+            const bool active = lane_on && p < npx32;
+            int j = j0 + g * PPW + sub, i = i0;
+            while (j >= W) { // (an image narrower than a batch wraps more than once)
+                j -= W;
+                i++;
+            }
+            const int ip = i - top, jp = j - left;
+            unsigned vis = 0u; // bit q: pass q visits this lane's pixel (pass_visits(), svh_sgm_lines.h)
+            if (ip >= 0 && ip < Hp && jp >= 0 && jp < Wp)
+                vis = (3u | (ip >= jp ? 4u : 0u) | (jp >= ip ? 8u : 0u) | (ip + jp < Wp ? 16u : 0u) | (ip + jp < Hp ? 32u : 0u)) & pass_mask;
+            float c[4], s[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) s[k] = c[k] = B.c[g][k]; // sgm_cv := cv, sgm.h:371-377
+            // the largest |min_p| among the passes that visit the pixel (the plane of a pass that does not holds whatever the scratch held)
+            float m = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 6; q++) m = fmaxf(m, ((vis >> q) & 1u) ? fabsf(B.mp[g][min_p_plane(q)]) : 0.0f);
+            const unsigned vis0 = (unsigned)__builtin_amdgcn_readfirstlane((int)vis);
+            const bool odd = active && (j + D > W || vis != vis0 || !(m < INFINITY));
+            if (lean && __builtin_amdgcn_ballot_w64(odd) == 0ull) {
+                // every pixel of the group: inside the image for every disparity, the same visiting passes, finite min_p, the lean regime --
+                // four operations per pass and cost (sgm.h:291-300 with t = c and both terms finite)
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    if (!((vis0 >> q) & 1u)) continue; // (wave-uniform)
+                    const float mp = B.mp[g][min_p_plane(q)];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) s[k] += (c[k] + (c[k] - mp)) - c[k];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    if (q >= n_pass) break;
+                    const bool visits = (vis >> q) & 1u;
+                    const float mp = B.mp[g][min_p_plane(q)];
+                    const bool mp_fin = finite_f(mp);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float t = (j + d0 + k >= W) ? c[k] + Pout : c[k];
+                        float act = c[k];
+                        if (mp_fin && finite_f(t)) act = c[k] + (t - mp);
+                        const float sum = s[k] + (act - c[k]); // sgm.h:298-300
+                        s[k] = visits ? sum : s[k];
+                    }
+                }
+            }
+            if (out.sgm && active) store_uncounted(reinterpret_cast<float4 *>(out.sgm + (int64_t)p * D + d0), make_float4(s[0], s[1], s[2], s[3]));
+            if (!want_winner) continue;
+            // extractSelectedIndex (correlation_base.h:441-455) inside the pixel's lanes: the extremum over the non-NaN values, the largest
+            // index that holds it, index 0 when the value there is NaN or nothing compares
+            float A = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; k++) A = fminf(A, s[k]);
+            const float M = pixel_allreduce_min<LPP>(lane_on ? A : INFINITY);
+            int kb = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) kb = (s[k] == M) ? k : kb;
+            constexpr int FIRST_NAN = 1 << 20;
+            int key = (lane_on && kb >= 0) ? d0 + kb + 1 : 0; // 0: this lane holds no candidate
+            const bool first_nan_here = dl == 0 && isnan(s[0]);
+            if (fold_first_nan && first_nan_here) key = FIRST_NAN;
+            const int best = pixel_allreduce_max<LPP>(key);
+            const bool writer = active && (best == 0 ? dl == 0 : key == best);
+            if (writer) {
+                const bool first_nan = key == FIRST_NAN || (!fold_first_nan && first_nan_here);
+                const int wd = (best == 0 || best == FIRST_NAN) ? -1 : best - 1; // (FIRST_NAN: unused by winner_key and by sel below)
+                const int sel = (best == 0 || best == FIRST_NAN) ? 0 : best - 1;
+                if (wo.idx) store_uncounted(wo.idx + p, sel);
+                if (wo.disp) store_uncounted(wo.disp + p, wo.disp_sign * sel + wo.disp_offset);
+                if (wo.keys) store_uncounted(wo.keys + p, winner_key<true>(Winner{M, wd}, first_nan, wo.key_offset, wo.key_total));
+            }
+            if (wo.taps) {
+                // truncatedCostVolume<Same>, radius 1 (correlation_base.h:601-613) around the selected index, from the writer's own registers
+                // and its neighbours' edge values (two DPP moves, executed by every lane)
+                const float prevL = lane_shift_up(s[3], 0.0f), nextR = lane_shift_down(s[0], 0.0f);
+                if (writer) {
+                    const int ck = (best == 0 || best == FIRST_NAN) ? 0 : kb; // the writer's candidate (index 0: lane 0 of the pixel, k = 0)
+                    const int sel = d0 + ck;
+                    const float t0 = ck == 0 ? s[0] : ck == 1 ? s[1] : ck == 2 ? s[2] : s[3];
+                    const float tm1 = ck == 0 ? prevL : ck == 1 ? s[0] : ck == 2 ? s[1] : s[2];
+                    const float tp1 = ck == 0 ? s[1] : ck == 1 ? s[2] : ck == 2 ? s[3] : nextR;
+                    const bool px_bad = j < wo.taps_h_r || i < wo.taps_v_r || i + wo.taps_v_r >= H;
+                    const int limit = px_bad ? -2 : W - wo.taps_h_r - j; // valid: 0 <= pd < D and pd < limit
+                    const float nan = __uint_as_float(0x7FC00000u);
+                    float *o = wo.taps + (int64_t)p * 3;
+                    store_uncounted(o, (sel == 0 || sel - 1 >= limit) ? nan : tm1);
+                    store_uncounted(o + 1, (sel >= limit) ? nan : t0);
+                    store_uncounted(o + 2, (sel + 1 >= D || sel + 1 >= limit) ? nan : tp1);
+                }
+            }
+        }
+    };
+    Batch A, B;
+    load_batch(A, (int64_t)wave * PB);
+    for (int64_t q0 = (int64_t)wave * PB; q0 < npx; q0 += 2 * stride) {
+        load_batch(B, q0 + stride);
+        run_batch(A, q0);
+        load_batch(A, q0 + 2 * stride);
+        run_batch(B, q0 + stride);
+    }
+}
+
 // Volume probe: ONE read of a float cost volume that replaces the per-pass sweeps of it.
 //  * g(p) = min_d [c + (c [+ Pout])] and bit 0 of `flag`, raised as soon as one value is not an integer in [-limit, limit].  A volume
 //    whose values are all small integers (a Hamming volume handed to the per-function API, say) is in the same exact regime as the
@@ -1118,6 +1314,22 @@ static int run_cost_branch(svh_context *ctx, const SgmArgs &a, const SRC &src, f
         const int64_t npx = (int64_t)a.H * a.W;
         int grid = grid_for(npx, 4, 256 * 8 * 4);
         bool piped = false;
+        if constexpr (std::is_same<SRC, SrcVolume>::value && R <= 2) {
+            // 128 disparities or fewer on an aligned dense volume: several pixels per wave.  (Not for reduction keys of a later shard together with
+            // an index map: the first-NaN rule enters the two differently, see the kernel.)
+            const bool keys_and_map = out->w.keys && out->w.key_offset != 0 && (out->w.idx || out->w.disp || out->w.taps);
+            if (src.vec && (!out->sgm || out->vec_store) && a.D >= 4 && !keys_and_map) {
+                piped = true;
+                const int pb = a.D <= 64 ? 8 : 4; // pixels per wave and batch
+                const int grid_p = grid_for(npx, 4 * pb, 256 * 8 * 4);
+                if (a.D <= 64)
+                    SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_packed_kernel<16>), grid_p, 256, 0, src.cv, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
+                               Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag, regime_vouched ? 1 : 0);
+                else
+                    SVH_LAUNCH(ctx, "sgm_cost_apply", (sgm_cost_apply_packed_kernel<32>), grid_p, 256, 0, src.cv, a.H, a.W, a.D, a.top, a.left, Hp > 0 ? Hp : 0,
+                               Wp > 0 ? Wp : 0, (Hp > 0 && Wp > 0) ? n_pass : 0, a.Pout, mmap, *out, regime_flag, regime_vouched ? 1 : 0);
+            }
+        }
         if constexpr (std::is_same<SRC, SrcVolume>::value && R % 4 == 0) {
             if (src.vec && (!out->sgm || out->vec_store)) {
                 piped = true;

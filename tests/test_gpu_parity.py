@@ -700,10 +700,11 @@ def _order_code(v):
     return np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64)
 
 
-@pytest.mark.parametrize("D", [132, 256, 260, 300, 512, 516, 1028])
+@pytest.mark.parametrize("D", [4, 8, 40, 64, 68, 128, 132, 256, 260, 300, 512, 516, 1028])
 def test_cost_apply_pipelined_form(rng, D):
-    """Aligned dense volumes with D % 4 == 0 and more than 128 disparities take sgm_cost_apply_piped_kernel (rows through buffer descriptors,
-    two batches in flight, per-batch winner stores, uncounted stores): the aggregated volume and the winner it leaves, bit for bit against
+    """Aligned dense volumes with D % 4 == 0 take sgm_cost_apply_piped_kernel (more than 128 disparities: rows through buffer descriptors,
+    two batches in flight, per-batch winner stores, uncounted stores) or sgm_cost_apply_packed_kernel (128 or fewer: four disparities per
+    lane, two or four pixels per wave, reductions inside a pixel's lanes): the aggregated volume and the winner it leaves, bit for bit against
     the oracle -- rows that are no multiple of 64 R (lanes past D), images narrower than a batch of pixels, pixels whose every disparity
     looks past the border, NaN / +-inf voxels, whole non-finite pixels (a non-finite min_p for the next one), magnitudes outside the lean
     regime, an infinite Pout, margins (also margins that leave no pixel to aggregate), four directions."""
@@ -717,7 +718,7 @@ def test_cost_apply_pipelined_form(rng, D):
         holes[H - 1, 0, 0] = np.nan  # "the value at index 0 is NaN": index 0 wins
         holes[0, W - 1, : D - 3] = np.nan
         huge = base.copy()
-        huge[H // 2, 0, 5] = 3e38
+        huge[H // 2, 0, min(5, D - 1)] = 3e38
         for name, cv in (("ints", ints), ("magnitudes", base), ("non-finite", holes), ("huge", huge)):
             d = dev(cv)
             for n_dir, margins, Pout in ((8, (0, 0, 0, 0), 100.0), (8, (1, 0, 1, 0), 0.37), (4, (0, 0, 0, 0), -3.5), (8, (0, 0, 0, 0), np.inf), (8, (5, 0, 9, 0), 1.0)):
@@ -736,7 +737,8 @@ def test_cost_apply_pipelined_form(rng, D):
                 assert np.array_equal(host(sv.extractSelectedIndex(so.COST, got_t)), so.extract_index(exp, so.COST)), what
 
 
-@pytest.mark.parametrize("func,D,W", [(MF.SAD, 132, 150), (MF.SAD, 256, 300), (MF.SSD, 300, 310), (MF.SAD, 260, 64)])
+@pytest.mark.parametrize("func,D,W", [(MF.SAD, 132, 150), (MF.SAD, 256, 300), (MF.SSD, 300, 310), (MF.SAD, 260, 64), (MF.SAD, 64, 100), (MF.SAD, 128, 140),
+                                      (MF.SSD, 40, 30), (MF.SAD, 8, 21)])
 def test_cost_apply_pipelined_form_winner_outputs(func, D, W):
     """... and every per-pixel output of the fused call (disparity, reduction keys, the three refinement taps through the refined map) from
     that kernel, with and without the aggregated volume written beside them, against the oracle run on the GPU's own cost volume."""

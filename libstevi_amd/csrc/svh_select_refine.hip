@@ -1,6 +1,7 @@
 // Winner extraction (A10), index -> disparity, selected cost, truncated volume (A11) and cost-based
 // sub-pixel refinement (A12).
 #include "svh_internal.h"
+#include "svh_sgm_lines.h"
 
 namespace svh {
 
@@ -94,6 +95,66 @@ __global__ void __launch_bounds__(256) extract_index_kernel(const float *__restr
                         key = ((unsigned long long)order_key(bv) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
                     }
                     keys[p] = key;
+                }
+            }
+        }
+    }
+}
+
+// The same for rows of at most 256 costs, a multiple of four: a pixel takes LPP = 16 / 32 / 64 lanes (four costs per lane, one 16-byte load), a
+// wave works on four, two or one pixels at a time, and the combine is not six rounds of (value, index) exchanges but two all-reduces inside
+// the pixel's lanes (DPP row rotations, v_permlane16/32_swap): the extremum, then the largest index among the lanes that hold a value EQUAL
+// to it.  "The value at index 0 is NaN" (index 0 wins: every comparison with it is false) enters the index reduction as a key above every
+// index.  The wave-per-pixel kernel took 0.44 ms at 1080p for 64, 128 and 256 costs alike -- the time of its instruction stream, not of its
+// bytes.
+template <bool COST, int LPP>
+__global__ void __launch_bounds__(256) extract_index_packed_kernel(const float *__restrict__ cv, int64_t npx, int D, int32_t *__restrict__ idx,
+                                                                  unsigned long long *__restrict__ keys, int key_offset, int key_total) {
+    constexpr int PPW = 64 / LPP, G = 4, PB = G * PPW;
+    const int lane = threadIdx.x & 63, sub = lane / LPP, dl = lane % LPP, d0 = dl * 4;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const bool lane_on = d0 < D;
+    const bool fold_first_nan = !keys || key_offset == 0; // (a later shard's key ignores the rule, its index map does not: reduced separately then)
+    constexpr int FIRST_NAN = 1 << 20;
+    for (int64_t p0 = wave * PB; p0 < npx; p0 += nwaves * PB) {
+        Costs4 v[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int64_t p = min(p0 + g * PPW + sub, npx - 1);
+            v[g] = *reinterpret_cast<const Costs4 *>(cv + p * D + (lane_on ? d0 : 0)); // (a lane past D: the row's first costs, unused)
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (p0 + g * PPW >= npx) break; // (wave-uniform)
+            const int64_t p = p0 + g * PPW + sub;
+            const float s[4] = {v[g].x, v[g].y, v[g].z, v[g].w};
+            float A = COST ? INFINITY : -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; k++) A = COST ? fminf(A, s[k]) : fmaxf(A, s[k]); // (a NaN never enters)
+            const float M = pixel_allreduce_f32<LPP, COST>(lane_on ? A : (COST ? INFINITY : -INFINITY));
+            int kb = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) kb = (s[k] == M) ? k : kb; // ties: the larger index
+            int key = (lane_on && kb >= 0) ? d0 + kb + 1 : 0;
+            const bool first_nan_here = dl == 0 && isnan(s[0]);
+            if (fold_first_nan && first_nan_here) key = FIRST_NAN;
+            const int best = pixel_allreduce_max<LPP>(key);
+            int first_nan = best == FIRST_NAN;
+            if (!fold_first_nan) first_nan = pixel_allreduce_max<LPP>(first_nan_here ? 1 : 0); // (wave-uniform branch)
+            const bool writer = lane_on && p < npx && (best == 0 || best == FIRST_NAN ? dl == 0 : key == best);
+            if (writer) {
+                const int bd = (best == 0 || best == FIRST_NAN) ? -1 : best - 1;
+                if (idx) idx[p] = (first_nan || bd < 0) ? 0 : bd;
+                if (keys) {
+                    unsigned long long kk;
+                    if (key_offset == 0 && first_nan) kk = COST ? (unsigned long long)(uint32_t)(key_total - 1) : (0xFFFFFFFFull << 32);
+                    else if (bd < 0) kk = COST ? ~0ull : 0ull;
+                    else {
+                        const uint32_t gd = (uint32_t)(key_offset + bd);
+                        kk = ((unsigned long long)order_key(M) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+                    }
+                    keys[p] = kk;
                 }
             }
         }
@@ -343,6 +404,23 @@ __global__ void refine_2d_patch_kernel(int kernel, const float *__restrict__ tcv
 int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n_pixels, int D, int32_t *idx,
                       unsigned long long *keys, int key_index_offset, int key_total_D) {
     if (n_pixels == 0) return SVH_OK;
+    if (D % 4 == 0 && D >= 4 && D <= 256) { // several pixels per wave (rows need no more than the 4-byte alignment every cost has)
+        const int lpp = D <= 64 ? 16 : D <= 128 ? 32 : 64;
+        const int gridp = grid_for(ceil_div(n_pixels, 4 * (64 / lpp)), 4, 256 * 8 * 4);
+#define SVH_EXTRACT_P(C, L) SVH_LAUNCH(ctx, "extract_index", (extract_index_packed_kernel<C, L>), gridp, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D)
+        if (strategy == SVH_COST) {
+            if (lpp == 16) SVH_EXTRACT_P(true, 16);
+            else if (lpp == 32) SVH_EXTRACT_P(true, 32);
+            else SVH_EXTRACT_P(true, 64);
+        } else {
+            if (lpp == 16) SVH_EXTRACT_P(false, 16);
+            else if (lpp == 32) SVH_EXTRACT_P(false, 32);
+            else SVH_EXTRACT_P(false, 64);
+        }
+#undef SVH_EXTRACT_P
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
     int grid = grid_for(ceil_div(n_pixels, EXTRACT_PB), 4, 256 * 8 * 4);
 #define SVH_EXTRACT(C) SVH_LAUNCH(ctx, "extract_index", (extract_index_kernel<C>), grid, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D)
     if (strategy == SVH_COST) SVH_EXTRACT(true);

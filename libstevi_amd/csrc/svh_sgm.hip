@@ -662,48 +662,6 @@ __global__ void __launch_bounds__(256) sgm_cost_apply_piped_kernel(const float *
 // passes with finite min_p -- is detected per group with one ballot and runs the same packed pass loop; everything else takes the step as
 // written with per-lane predicates.  Reductions stay inside a pixel's lanes: row_ror DPP steps (an all-reduce within a row of 16) and one
 // v_permlane16_swap for the two rows of a 32-lane pixel.  The lane that holds the winner writes the pixel's outputs.
-template <bool MIN> __device__ __forceinline__ float row_allreduce_f32(float v) { // every lane: the extremum of its row of 16
-#define SVH_ROR_DPP(CTRL)                                                                                                   \
-    if constexpr (MIN) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v));          \
-    else asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
-    SVH_ROR_DPP("row_ror:1");
-    SVH_ROR_DPP("row_ror:2");
-    SVH_ROR_DPP("row_ror:4");
-    SVH_ROR_DPP("row_ror:8");
-#undef SVH_ROR_DPP
-    asm("s_nop 0" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ int row_allreduce_max_i32(int v) {
-#define SVH_ROR_DPP(CTRL) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
-    SVH_ROR_DPP("row_ror:1");
-    SVH_ROR_DPP("row_ror:2");
-    SVH_ROR_DPP("row_ror:4");
-    SVH_ROR_DPP("row_ror:8");
-#undef SVH_ROR_DPP
-    asm("s_nop 0" : "+v"(v));
-    return v;
-}
-// all-reduce over the LPP lanes of a pixel (LPP = 32: both rows of the pair hold both rows' values after the swap)
-template <int LPP> __device__ __forceinline__ float pixel_allreduce_min(float v) {
-    v = row_allreduce_f32<true>(v);
-    if constexpr (LPP == 32) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        const uint32_t a = r[0], b = r[1];
-        v = fminf(__uint_as_float(a), __uint_as_float(b));
-    }
-    return v;
-}
-template <int LPP> __device__ __forceinline__ int pixel_allreduce_max(int v) {
-    v = row_allreduce_max_i32(v);
-    if constexpr (LPP == 32) {
-        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-        const uint32_t a = r[0], b = r[1];
-        v = max((int)a, (int)b);
-    }
-    return v;
-}
-
 template <int LPP>
 __global__ void __launch_bounds__(256) sgm_cost_apply_packed_kernel(const float *__restrict__ cv, int H, int W, int D, int top, int left, int Hp, int Wp,
                                                                    int n_pass, float Pout, const float *__restrict__ mmap, ApplyOut out,

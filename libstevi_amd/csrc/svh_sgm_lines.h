@@ -277,6 +277,62 @@ __device__ __forceinline__ void wave_emit_record(const float (&s)[R], int lane, 
     if (lane == writer) *reinterpret_cast<float4 *>(rec + (unsigned)(i * W + j) * 4u) = r;
 }
 
+// ---- reductions inside the lanes of one pixel (several pixels per wave: svh_sgm.hip's packed apply kernel, svh_select_refine.hip) ----------
+template <bool MIN> __device__ __forceinline__ float row_allreduce_f32(float v) { // every lane: the extremum of its row of 16
+#define SVH_ROR_DPP(CTRL)                                                                                                   \
+    if constexpr (MIN) asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v));          \
+    else asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+    SVH_ROR_DPP("row_ror:1");
+    SVH_ROR_DPP("row_ror:2");
+    SVH_ROR_DPP("row_ror:4");
+    SVH_ROR_DPP("row_ror:8");
+#undef SVH_ROR_DPP
+    asm("s_nop 0" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int row_allreduce_max_i32(int v) {
+#define SVH_ROR_DPP(CTRL) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(v))
+    SVH_ROR_DPP("row_ror:1");
+    SVH_ROR_DPP("row_ror:2");
+    SVH_ROR_DPP("row_ror:4");
+    SVH_ROR_DPP("row_ror:8");
+#undef SVH_ROR_DPP
+    asm("s_nop 0" : "+v"(v));
+    return v;
+}
+// all-reduce over the LPP = 16 / 32 / 64 lanes of a pixel: after v_permlane16_swap of a register with itself every lane of a row pair holds
+// both rows' values (one in each result), after v_permlane32_swap every lane both halves' (through named words: see the note on
+// __builtin_bit_cast of vector elements in svh_sgm.hip)
+template <int LPP, bool MIN> __device__ __forceinline__ float pixel_allreduce_f32(float v) {
+    v = row_allreduce_f32<MIN>(v);
+    if constexpr (LPP >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const uint32_t a = r[0], b = r[1];
+        v = MIN ? fminf(__uint_as_float(a), __uint_as_float(b)) : fmaxf(__uint_as_float(a), __uint_as_float(b));
+    }
+    if constexpr (LPP == 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        const uint32_t a = r[0], b = r[1];
+        v = MIN ? fminf(__uint_as_float(a), __uint_as_float(b)) : fmaxf(__uint_as_float(a), __uint_as_float(b));
+    }
+    return v;
+}
+template <int LPP> __device__ __forceinline__ float pixel_allreduce_min(float v) { return pixel_allreduce_f32<LPP, true>(v); }
+template <int LPP> __device__ __forceinline__ int pixel_allreduce_max(int v) {
+    v = row_allreduce_max_i32(v);
+    if constexpr (LPP >= 32) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        const uint32_t a = r[0], b = r[1];
+        v = max((int)a, (int)b);
+    }
+    if constexpr (LPP == 64) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        const uint32_t a = r[0], b = r[1];
+        v = max((int)a, (int)b);
+    }
+    return v;
+}
+
 // ---- host helpers
 inline int pass_lines(int q, int Hp, int Wp) {
     if (q >= 10) return Hp + Wp - 1;

@@ -237,8 +237,9 @@ def test_sgm_rejects_16_directions(rng):
 
 
 # ------------------------------------------------------------------------------------------------ A10-A12
-@pytest.mark.parametrize("D", [1, 2, 63, 64, 65, 200, 513])
+@pytest.mark.parametrize("D", [1, 2, 4, 8, 60, 63, 64, 65, 128, 132, 200, 256, 260, 513])
 def test_extract_index(rng, D):
+    """(rows of 4 ... 256 costs, a multiple of four, take the kernel that packs several pixels into a wave: extract_index_packed_kernel)"""
     cv = rng.integers(0, 6, (11, 14, D)).astype(np.float32)  # few levels -> many ties
     cv[0, 0, 0] = np.nan
     if D > 2:
@@ -246,6 +247,15 @@ def test_extract_index(rng, D):
         cv[2, 2, :] = np.nan
         cv[3, 3, D - 1] = -0.0
         cv[3, 3, 0] = 0.0
+        cv[4, 4, :] = np.inf            # every value the same infinity: the last index
+        cv[4, 5, :] = -np.inf
+        cv[5, 5, 1:] = np.nan           # only index 0 compares
+        cv[5, 6, : D - 1] = np.nan      # only the last index compares
+        cv[6, 6, D // 2] = -np.inf
+        cv[6, 7, D // 2] = np.inf
+        cv[7, 7, 0] = np.nan            # a NaN at index 0 beside ...
+        cv[7, 7, D - 1] = -np.inf       # ... an unbeatable value: index 0 stays (E5)
+        cv[10, 13, :] = rng.uniform(-1, 1, D)  # the last pixel of the volume: no ties
     for strategy in (so.COST, so.SCORE):
         exp = so.extract_index(cv, strategy)
         assert_bits(sv.extractSelectedIndex(strategy, cv), exp)
@@ -364,6 +374,19 @@ def test_disparity_shards_reduce_to_full_argmin(rng):
             keys = k if keys is None else red(keys, k)
         idx = sv.keysToIndex(sv.matchFuncStrategy(func), keys, D)
         assert_bits(idx, host(full["disp"]))
+    # NaN costs at a shard's local index 0 (a window of zeros in the target has norm 0): the first-NaN rule belongs to global index 0 only
+    tgt2 = tgt.copy()
+    tgt2[:, 12:23] = 0.0
+    full = sv.stereoMatch(MF.NCC, dev(tgt2), dev(src), 4, 4, D, want_cv=True)
+    assert np.isnan(host(full["cv"])).any() and not np.isnan(host(full["cv"])).all()
+    assert_bits(full["disp"], so.index_to_disp(so.extract_index(host(full["cv"]), so.SCORE)))
+    keys = None
+    for (b, n) in ((0, 8), (8, 4), (12, 12)):
+        part = sv.stereoMatch(MF.NCC, dev(tgt2), dev(src), 4, 4, D, want_keys=True, want_cv=True, shard=(b, n))
+        assert np.isnan(host(part["cv"])[:, :, 0]).any()
+        k = host(part["keys"]).view(np.uint64)
+        keys = k if keys is None else np.maximum(keys, k)
+    assert_bits(sv.keysToIndex(so.SCORE, keys, D), host(full["disp"]))
 
 
 def test_non_dense_device_output(rng):

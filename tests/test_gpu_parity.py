@@ -549,11 +549,12 @@ def test_census_shards_equal_single_gpu(ddir):
     assert e.value.status == ERR_UNSUPPORTED
 
 
-def test_sgm_integer_volume_routes_agree(rng):
+@pytest.mark.parametrize("D", [70, 64, 128])
+def test_sgm_integer_volume_routes_agree(rng, D):
     """svh_sgm_cost_volume on an integer-valued float volume takes the probe + scan route; it must equal the
     wave-per-line route (option off) and the oracle bit for bit, also when a single voxel breaks integrality."""
-    cv = rng.integers(0, 65, (23, 31, 70)).astype(np.float32)
-    for breaker in (None, (5, 7, 3, 0.5), (0, 0, 0, np.inf), (22, 30, 69, 1e6)):
+    cv = rng.integers(0, 65, (23, 31, D)).astype(np.float32)
+    for breaker in (None, (5, 7, 3, 0.5), (0, 0, 0, np.inf), (22, 30, D - 1, 1e6)):
         v = cv.copy()
         if breaker is not None:
             v[breaker[0], breaker[1], breaker[2]] = breaker[3]
@@ -573,13 +574,15 @@ def test_sgm_integer_volume_routes_agree(rng):
                 assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
 
 
-def test_sgm_cost_branch_two_minima_route(rng):
+@pytest.mark.parametrize("D", [70, 40, 72, 128])
+def test_sgm_cost_branch_two_minima_route(rng, D):
     """The Cost branch on a float volume reads the volume once: a probe leaves every pixel's two regional minima (costs that look inside
     / past the right border) and the six line recurrences run on those two numbers (monotonicity of the per-disparity step,
     svh_sgm.hip).  Must equal the oracle and the wave-per-line sweeps of the volume (option off) bit for bit: magnitudes over fifteen
     decades, negative costs, NaN / +-inf voxels and whole non-finite pixels, an infinite Pout, margins, four directions, D not a
-    multiple of 64; and volumes whose magnitudes could overflow along a line (> 1e30) must fall back to the sweeps by themselves."""
-    H, W, D = 19, 37, 70
+    multiple of 64 (a multiple of four up to 128: the probe and the apply kernel that pack several pixels into a wave); and volumes whose
+    magnitudes could overflow along a line (> 1e30) must fall back to the sweeps by themselves."""
+    H, W = 19, 37
     base = (rng.uniform(-1, 1, (H, W, D)) * 10.0 ** rng.integers(-6, 9, (H, W, 1))).astype(np.float32)
     holes = base.copy()
     holes[3, 5, 7] = np.nan
@@ -590,7 +593,7 @@ def test_sgm_cost_branch_two_minima_route(rng):
     holes[9, W - 2, 1:] = np.nan      # only the in-image disparity is finite
     huge = base.copy()
     huge[4, 4, 4] = 3e38              # outside the regime: the probe's second flag bit sends the call to the volume sweeps
-    huge[12, 20, 60] = -2.5e38
+    huge[12, 20, D - 10] = -2.5e38
     for name, cv in (("magnitudes", base), ("non-finite", holes), ("huge", huge)):
         d = dev(cv)
         for n_dir, margins, Pout in ((8, (0, 0, 0, 0), 100.0), (8, (2, 1, 3, 2), 0.37), (4, (0, 0, 0, 0), -3.5), (8, (0, 0, 0, 0), np.inf), (8, (0, 3, 0, 0), 1e31)):

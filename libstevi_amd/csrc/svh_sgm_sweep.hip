@@ -122,14 +122,6 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
         }
     }
     row_end();
-    auto load_px = [&](const float *vol, int i, int j, float (&v)[R]) {
-        const float *p = vol + ((int64_t)i * W + j) * D + lane * R;
-        if constexpr (VEC) lds_get<R>(p, v);
-        else {
-#pragma unroll
-            for (int k = 0; k < R; k++) v[k] = (lane * R + k < D) ? p[k] : 0.0f;
-        }
-    };
     // halo slot hs of row r: the pixel, the line slot and whether it is needed (left: diagonal lines, right: anti-diagonal lines)
     auto halo_of = [&](int hs, int r, int &j, int &slot, bool &left) {
         left = hs < KB - 1;
@@ -140,22 +132,38 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
     };
     auto run = [&](auto full_tag, auto pout_tag) {
         constexpr bool FULL = decltype(full_tag)::value, POUT = decltype(pout_tag)::value; // FULL: the whole strip is inside the image
+        // A cell's column does not change from row to row: its offset inside a row of the volume (32 bits: W D < 2^31, checked by the host) is
+        // computed once, and a row costs one 64-bit scalar product for the row's base.  (Per load the sweep spent some fourteen scalar
+        // instructions on ((i W + j) D + lane R) in 64 bits: 70 of the 116 scalar instructions a wave issued per row, in a kernel bound by
+        // instruction issue -- profiles/r04d_sq_counters_c4.jsonl.)
+        unsigned own_off[CPW], halo_off[HS];
+#pragma unroll
+        for (int q = 0; q < CPW; q++) own_off[q] = (unsigned)((FULL ? j0 + wave + q * NCW : min(j0 + wave + q * NCW, W - 1)) * D + lane * R);
+#pragma unroll
+        for (int q = 0; q < HS; q++) {
+            int j, slot;
+            bool left;
+            (void)halo_of(wave + q * NCW, 0, j, slot, left); // (the column of a halo slot does not depend on the row)
+            halo_off[q] = (unsigned)(min(max(j, 0), W - 1) * D + lane * R);
+        }
+        auto load_at = [&](const float *row, unsigned off, float (&v)[R]) {
+            if constexpr (VEC) lds_get<R>(row + off, v);
+            else {
+#pragma unroll
+                for (int k = 0; k < R; k++) v[k] = (lane * R + k < D) ? row[off + k] : 0.0f;
+            }
+        };
         auto load_row = [&](float (&c)[CPW][R], float (&d1)[CPW][R], float (&hc)[HS][R], int r) {
             r = min(r, rows - 1); // (past the band: the last row again, unused)
-            const int i = r0 + r;
+            const int64_t row_off = (int64_t)(r0 + r) * W * D;
+            const float *crow = cv + row_off, *srow = sgm + row_off;
 #pragma unroll
             for (int q = 0; q < CPW; q++) {
-                const int j = FULL ? j0 + wave + q * NCW : min(j0 + wave + q * NCW, W - 1);
-                load_px(cv, i, j, c[q]);
-                load_px(sgm, i, j, d1[q]);
+                load_at(crow, own_off[q], c[q]);
+                load_at(srow, own_off[q], d1[q]);
             }
 #pragma unroll
-            for (int q = 0; q < HS; q++) {
-                int j, slot;
-                bool left;
-                (void)halo_of(wave + q * NCW, r, j, slot, left);
-                load_px(cv, i, min(max(j, 0), W - 1), hc[q]); // (every slot loads, needed or not: the count of loads in flight stays exact)
-            }
+            for (int q = 0; q < HS; q++) load_at(crow, halo_off[q], hc[q]); // (every slot loads, needed or not: the count of loads in flight stays exact)
         };
         auto run_row = [&](const float (&c)[CPW][R], const float (&d1)[CPW][R], const float (&hc)[HS][R], int r) {
             const int i = r0 + r;
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
                     const float S4 = S + (act[2][k] - c[q][k]);
                     outv[k] = visA ? S4 : S;
                 }
-                float *o = sgm + ((int64_t)i * W + j) * D + lane * R;
+                float *o = sgm + (int64_t)i * W * D + own_off[q]; // (own_off: the cell's column, see load_row)
                 if constexpr (FIN) {
                     wave_emit_record<false, R>(outv, lane, i, j, H, W, fin.records, fin.taps_h_r, fin.taps_v_r);
                     if (fin.store_all || i + j < H) lds_put<R>(o, outv); // (wave-uniform) DownLeft2UpRight visits i + j < H
@@ -256,6 +264,7 @@ template <int R, int KB, int WB>
 static int run_score_branch_bands(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, bool *ran, ScoreFinish *finish) {
     *ran = false;
     if constexpr (R > 8) return SVH_OK;
+    else if ((int64_t)a.W * a.D >= (1ll << 31)) return SVH_OK; // (a cell's offset inside a row of the volume is kept in 32 bits: a launch per pass then)
     else {
         constexpr int NCW = WB, DP = 64 * R; // a wave per own pixel (8 waves for 16 pixels: 13.8 ms at C4, 16 waves: 13.0)
         const size_t shmem = (size_t)(WB + 2 * (WB + KB - 1)) * DP * sizeof(float);

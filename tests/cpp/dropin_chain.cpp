@@ -184,8 +184,8 @@ int main(int argc, char **argv) {
         dump(out + "_ncc_cv.f32", FE(CV), CV.flatLenght());
         dump(out + "_ncc_idx.i32", FE(rawDisp), rawDisp.flatLenght());
         dump(out + "_ncc_refined.f32", FE(refined), refined.flatLenght());
-        // the same on the device: the Score branch's winner records become the statement when the banded sweep applies (it does not at
-        // this D unless D is a multiple of 64: either way the map must equal the host chain's)
+        // the same on the device: the Score branch's winner (records of the banded sweep from 256 disparities on, a scan of the volume the call
+        // has just written below that) becomes the statement: the map must equal the host chain's
         auto dCV = SC::DeviceArray<float, 3>::upload(CV);
         auto dS = SC::sgmCostVolume<8, strat>(dCV, P1, P2, StereoVision::Margins(), Pout);
         Multidim::Array<SC::disp_t, 2> dRaw = SC::extractSelectedIndex<strat>(dS).download();

@@ -353,6 +353,11 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
             const int jt0 = pe[e] + SIGN * (disp_lower + d0); // target column of the block's first disparity
             const bool whole = d0 + DB <= D;                    // (wave uniform)
             float o_[DB];
+            // Nearly every block lies inside the target image for all of its sixteen disparities and every pixel of the wave (wave uniform):
+            // then no cost is the one against the all-zero vector and the test per voxel -- a compare, a select and the mask arithmetic, a
+            // third of the block's vector instructions outside the window sums -- is one ballot per block.
+            const int jt_last = jt0 + SIGN * (DB - 1);
+            const bool interior = trow_in && whole && __all(!live[e] || ((unsigned)jt0 < (unsigned)Wt && (unsigned)jt_last < (unsigned)Wt));
 #pragma unroll
             for (int q = 0; q < DB; q++) {
                 float x = r[e][q];
@@ -362,8 +367,14 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                     x -= Ff * dm * dm;
                 }
                 if (NRM) x *= inv_ns[e] * tinv[zc0 + q];
-                const bool there = trow_in && (unsigned)(jt0 + SIGN * q) < (unsigned)Wt && (whole || d0 + q < D);
-                o_[q] = there ? x : zc[e]; // no target pixel: the cost against the all-zero vector (cross_correlations.h:235)
+                o_[q] = x;
+            }
+            if (!interior) {
+#pragma unroll
+                for (int q = 0; q < DB; q++) {
+                    const bool there = trow_in && (unsigned)(jt0 + SIGN * q) < (unsigned)Wt && (whole || d0 + q < D);
+                    o_[q] = there ? o_[q] : zc[e]; // no target pixel: the cost against the all-zero vector (cross_correlations.h:235)
+                }
             }
             // The reductions must cost next to nothing per voxel (the kernel is bound by vector issue: a first form with explicit NaN and
             // candidate tests took 7 instructions per voxel and made it 65 % longer).

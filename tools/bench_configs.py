@@ -29,6 +29,7 @@ CONFIGS = {
     "c4small": (1024, 540, 256, MF.NCC, 5, 5, 8, IK.Parabola, (160, 160, 190, 4, 32, 4), {}),
     # float costs through the fused call: winner / regional minima reduced inside the cost kernel (no volume read back)
     "sad_sgm": (1920, 1080, 256, MF.SAD, 2, 2, 8, None, (320, 320, 380, 8, 64, 3), {}),
+    "ncc_sgm": (1920, 1080, 256, MF.NCC, 5, 5, 8, IK.Parabola, (320, 320, 380, 8, 64, 3), {}),
     "sad_sgm_d128": (1920, 1080, 128, MF.SAD, 2, 2, 8, None, (320, 320, 380, 8, 64, 3), {}),
     "sad_sgm_d64": (1920, 1080, 64, MF.SAD, 2, 2, 8, None, (320, 320, 380, 8, 32, 3), {}),
     "ncc_argmax": (1920, 1080, 256, MF.NCC, 5, 5, 0, None, (320, 320, 380, 8, 64, 3), {}),

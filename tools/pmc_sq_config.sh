@@ -31,6 +31,13 @@ for k, cs in sorted(acc.items()):
             out[c.replace("SQ_INSTS", "per_wave").lower()] = round(avg[c] / w, 1)
     if "SQ_BUSY_CYCLES" in avg:
         out["busy_cycles"] = int(avg["SQ_BUSY_CYCLES"])
+    # wave-cycle accounting (SQ_WAVE_CYCLES counts in units of four cycles per resident wave): what share of a wave's life it waited on anything /
+    # on an instruction's operands, and the share it had a vector instruction executing
+    if "SQ_WAVE_CYCLES" in avg:
+        wc = avg["SQ_WAVE_CYCLES"] or 1
+        for c in ("SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+            if c in avg:
+                out[c.lower() + "_share"] = round(avg[c] / wc, 3)
     print(json.dumps({k: out}))
 PY
 rm -rf /tmp/sqc1 /tmp/sqc2

@@ -254,9 +254,10 @@ int svh_sgm_cost_volume_minima(svh_context *ctx, int n_directions, int strategy,
 /* The same (minima may be NULL: then exactly svh_sgm_cost_volume) with a by-product for a later extractSelectedIndex<strategy> on `out`:
  * winner_idx (H,W) i32 = the index that call would return.  The kernel that writes a pixel's final aggregated costs holds them in one
  * wave, so its winner costs a few instructions there against a second read of the whole volume (4 bytes per voxel) later.
- * *winner_written = 1 when the map was produced (Cost strategy: always; Score strategy: when the banded sweep applies -- whole image, 8
- * directions, P2 >= P1 >= 0, at most 512 disparities, a multiple of 64 --, else 0 and winner_idx is left untouched).  Like the minima it
- * is a statement about `out` that the caller must not let outlive its contents (DeviceArray keeps it with the storage). */
+ * *winner_written = 1 when the map was produced: always, when winner_idx is given.  (Score strategy: the records of the banded sweep from
+ * 256 disparities on -- whole image, 8 directions, P2 >= P1 >= 0, at most 512 disparities, a multiple of 64 --, otherwise a scan of the
+ * volume the call has just written, which below 256 disparities is also the faster of the two.)  Like the minima it is a statement about
+ * `out` that the caller must not let outlive its contents (DeviceArray keeps it with the storage). */
 int svh_sgm_cost_volume_winner(svh_context *ctx, int n_directions, int strategy, const svh_array *cv, const svh_array *minima, int minima_kind,
                                float max_abs, float P1, float P2, const int32_t margins[4], float Pout, svh_array *out, svh_array *winner_idx,
                                int *winner_written);

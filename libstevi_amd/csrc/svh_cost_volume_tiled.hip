@@ -47,6 +47,13 @@ __device__ __forceinline__ float image_or_zero1(const float *__restrict__ img, i
 // samples broadcast by v_readlane: 2.45 ms for 1080p x 256 NCC 11x11 against 1.79 ms for this form.)
 constexpr int PL_TPX = 64;
 
+// four consecutive costs with only the 4-byte alignment every cost has: global_store_dwordx4 needs no more on gfx950, so the pieces of rows
+// of any length (2-D volumes: 9 x 33 offsets make rows of 297 costs) are stored 16 bytes per lane like those of aligned rows.  (With the
+// 16-byte alignment test the 2-D volumes took the store-per-cost path for every block: 3.4 ms for 1080p x 297 ZNCC 7x7.)
+struct __attribute__((packed, aligned(4))) CostPiece4 {
+    float x, y, z, w;
+};
+
 template <int CMP, bool ZM, int HR, int DB, int SIGN>
 __global__ void __launch_bounds__(256) cost_volume_pxlane_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
                                                                  int D, int disp_lower, const float *__restrict__ mean_s,
@@ -139,9 +146,9 @@ __global__ void __launch_bounds__(256) cost_volume_pxlane_kernel(const float *__
             }
         }
         float *o = cv + px * px_stride + out_off + d0;
-        if (d0 + DB <= D && (((px * px_stride + out_off + d0) & 3) == 0)) {
+        if (d0 + DB <= D) {
 #pragma unroll
-            for (int q = 0; q < DB; q += 4) *reinterpret_cast<float4 *>(o + q) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
+            for (int q = 0; q < DB; q += 4) *reinterpret_cast<CostPiece4 *>(o + q) = CostPiece4{r[q], r[q + 1], r[q + 2], r[q + 3]};
         } else {
 #pragma unroll
             for (int q = 0; q < DB; q++)
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                 }
             }
             if (RED && !rd.store) continue; // (kernel-uniform) nobody wants the volume
-            if (whole && ((px_stride | out_off) & 3) == 0) { // (wave uniform)
+            if (whole) { // (wave uniform)
                 // A lane holds 64 bytes of its pixel's run; stored as they are, every 16-byte piece of a wave's store instruction would go to
                 // a different pixel (1 KB apart): requests of 16 bytes, a quarter of what the memory side takes per request (measured: the
                 // kernel then runs at 2.4 TB/s whatever the window).  Through LDS instead: lanes 4 a .. 4 a + 3 store the four pieces of
@@ -441,7 +448,7 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                     const int uu = 16 * j + a;                                 // the lane whose pixel this is
                     const int pp = p0 + 2 * (uu - HR) + e;                     // that pixel
                     const float4 piece = *reinterpret_cast<const float4 *>(xpose + uu * CS_XP + 4 * c);
-                    if (uu >= HR && pp < Ws) *reinterpret_cast<float4 *>(cv + ((int64_t)i * Ws + pp) * px_stride + out_off + d0 + 4 * c) = piece;
+                    if (uu >= HR && pp < Ws) *reinterpret_cast<CostPiece4 *>(cv + ((int64_t)i * Ws + pp) * px_stride + out_off + d0 + 4 * c) = CostPiece4{piece.x, piece.y, piece.z, piece.w};
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (read before the next round overwrites it)
             } else if (live[e]) {

@@ -35,5 +35,5 @@ for name, W, H, D, func, r in cases:
     dt = (time.perf_counter() - t0) / n
     sv.profile_enable(d_src, False)
     prof = sv.profile_collect(d_src)
-    print(json.dumps({"chain": name, "ms": round(dt * 1e3, 3), "Mdisp_per_s": round(W * H * D / dt / 1e6), "kernel_ms": {k: round(v[0] / n, 3) for k, v in prof.items()},
+    print(json.dumps({"chain": name + ("" if keep else " (no statements carried between the calls)"), "ms": round(dt * 1e3, 3), "Mdisp_per_s": round(W * H * D / dt / 1e6), "kernel_ms": {k: round(v[0] / n, 3) for k, v in prof.items()},
                       "checksum": int(disp.sum().item())}), flush=True)

@@ -835,6 +835,56 @@ def test_random_configurations_against_oracle():
         assert np.array_equal(host(lean["disp"]), host(res["disp"])), tag
 
 
+def test_random_volumes_through_the_packed_and_pipelined_kernels():
+    """Seeded random volumes whose rows are a multiple of four costs -- the forms that put several pixels into a wave (<= 128 costs), one pixel
+    on 64 lanes (<= 256) or pipeline their loads (> 128) -- through sgmCostVolume (both branches, with and without the winner kept), the
+    probe route (no statement) and extractSelectedIndex: shapes down to one pixel, rows of 4 ... 640 costs, margins, penalties of either
+    sign, an infinite Pout, NaN / +-inf voxels and pixels, integer and real costs, magnitudes on either side of the regime."""
+    r = np.random.default_rng(20261004)
+    for case in range(36):
+        H, W = int(r.integers(1, 24)), int(r.integers(1, 70))
+        D = 4 * int(r.integers(1, 33)) if case % 4 else 4 * int(r.integers(33, 161))
+        kind = case % 5
+        if kind == 0:
+            cv = r.integers(0, 40, (H, W, D)).astype(np.float32)
+        else:
+            cv = (r.uniform(-1, 1, (H, W, D)) * 10.0 ** r.integers(-2, 3, (H, W, 1))).astype(np.float32)
+        if kind >= 2:  # holes
+            for _ in range(1 + H * W // 6):
+                i, j = int(r.integers(0, H)), int(r.integers(0, W))
+                what = int(r.integers(0, 5))
+                if what == 0:
+                    cv[i, j, int(r.integers(0, D))] = np.nan
+                elif what == 1:
+                    cv[i, j, :] = np.inf
+                elif what == 2:
+                    cv[i, j, 0] = np.nan
+                elif what == 3:
+                    cv[i, j, int(r.integers(0, D))] = -np.inf
+                else:
+                    cv[i, j, : int(r.integers(0, D))] = np.nan
+        if kind == 4:
+            cv[int(r.integers(0, H)), int(r.integers(0, W)), int(r.integers(0, D))] = 2.5e38  # outside the regime: the volume sweeps
+        n_dir = int(r.choice([4, 8, 8, 8]))
+        margins = tuple(int(x) for x in r.integers(0, 3, 4)) if case % 3 == 0 else (0, 0, 0, 0)
+        Pout = float(r.choice([100.0, 7.0, 0.0, 2.5, -3.0, np.inf]))
+        P1 = float(r.uniform(0, 2))
+        P2 = P1 + float(r.uniform(0, 3))
+        d = dev(cv)
+        tag = f"case {case}: {H}x{W}xD{D} kind {kind} dirs {n_dir} margins {margins} Pout {Pout}"
+        for strategy in (so.COST, so.SCORE):
+            exp = so.sgm(cv, n_dir, strategy, P1, P2, margins, Pout)
+            exp_idx = so.extract_index(exp, strategy)
+            for keep in (False, True):
+                got_t = sv.sgmCostVolume(n_dir, strategy, d, P1, P2, sv.Margins(*margins), Pout, keep_winner=keep)
+                got = host(got_t)
+                assert np.array_equal(np.isnan(got), np.isnan(exp)), (tag, strategy, keep)
+                ok = ~np.isnan(exp)
+                assert np.array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32)), (tag, strategy, keep)
+                assert np.array_equal(host(sv.extractSelectedIndex(strategy, got_t)), exp_idx), (tag, strategy, keep)
+            assert np.array_equal(host(sv.extractSelectedIndex(strategy, d)), so.extract_index(cv, strategy)), (tag, strategy)
+
+
 # ------------------------------------------------------------------------------------------------ textbook SGM (explicit second mode)
 @pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
 @pytest.mark.parametrize("D", [1, 5, 64, 70, 130, 256, 300])

@@ -111,6 +111,9 @@ const char *svh_last_error(const svh_context *ctx);
  * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
  * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
  * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
+ * "fold_2d_offsets" (default 1): svh_unfold_cost_volume_2d on grey images with a function the column-sum kernel takes stages the
+ * v + Dh - 1 target rows of all vertical offsets once per block and walks the (dh, dw) blocks in one launch (as many offsets as the
+ * tile holds); 0 = one launch per vertical offset.  Same bits (tests/test_gpu_2d.py).
  * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
  * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one.
  * "census_winner_shortcut" (default 1): in the integer-exact regime of the census + SGM Cost-branch pipeline the winning disparity of a

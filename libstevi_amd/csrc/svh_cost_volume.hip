@@ -464,7 +464,19 @@ extern "C" int svh_unfold_cost_volume_2d(svh_context *ctx, int match_func, int d
         WindowStatsCache stats; // means / norms / zero-target costs do not depend on the offset: computed by the first pass
         stats.scr = &scr;
         a.stats = &stats;
-        for (int dh = 0; dh < Dh; dh++) {
+        // as many vertical offsets per launch as the column-sum kernel's tile holds (grey images, separable terms); one otherwise
+        int group = 1;
+        if (ctx->fold_2d_offsets) {
+            for (int g = Dh; g > 1; g--) {
+                a.n_dh = g;
+                if (cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) {
+                    group = g;
+                    break;
+                }
+            }
+        }
+        for (int dh = 0; dh < Dh; dh += group) {
+            a.n_dh = std::min(group, Dh - dh);
             a.tgt_row_off = lower0 + dh;
             a.out_off = (int64_t)dh * Dw;
             Scratch inner(ctx); // the per-offset statistics maps are released after each pass

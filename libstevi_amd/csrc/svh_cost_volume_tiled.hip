@@ -187,19 +187,33 @@ struct ColsumReduce {
 // minima.  A compile-time parameter because the reductions' running state (eight registers live across the whole disparity loop) took
 // the kernel to 150 VGPRs and one block per CU when it was a run-time switch: every plain cost volume paid 0.19 ms of 0.54 for a feature
 // it did not use.  The reducing forms are held to four waves per SIMD as well (second launch bound).
-template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES, int RED>
+// FOLD (2-D disparity volumes, round 4f): the launch takes n_dh consecutive vertical offsets at once.  The target tile holds v + n_dh - 1
+// rows; disparity block b belongs to vertical offset b / (blocks per offset) and reads the v rows that start at that offset.  One launch
+// per vertical offset staged the v source rows once per offset for two or three blocks of work and left a wave of four without any.
+// Search ranges are symmetric as a rule -- 2 r + 1 offsets, 17, 33, 65 -- so the last block of an offset would hold ONE disparity.
+// The row loads of a block already bring the target samples of a seventeenth (the pairs t[16], t[17] of the last 8-byte read), so the
+// last block of an ODD range is seventeen wide: two more single multiply-adds per window row instead of a block (16 k + 1 offsets
+// run k blocks).  And the last block of a range that is no multiple of 16 (17 for odd ranges) starts early, at Dw - 16 (Dw - 17),
+// instead of ending late: it recomputes what the block before it stores -- the same terms in the same order, the same bits -- and
+// every block of a range of 16 or more takes the 64-byte store path.  Both starts are even: an odd start makes every 8-byte LDS read
+// of the block misaligned (9 x 33 offsets with the last block at 17: 1.96 ms, against 1.27 for 9 x 34 with it at 18; a partial last
+// block instead of the early start: 1.41).  Ranges shorter than 16 are one partial block per offset.
+template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES, int RED, bool FOLD = false>
 __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
                                                                  int D, int disp_lower, const float *__restrict__ mean_s,
                                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                  const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
-                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0, ColsumReduce rd) {
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0, ColsumReduce rd, int n_dh) {
     constexpr int DB = CS_DB, OUT = CS_COLS - 2 * HR;
     extern __shared__ float lds[];
     const int v = 2 * v_r + 1;
-    const int n_blocks = (D + DB - 1) / DB;
-    const int tw = CS_COLS + n_blocks * DB; // target tile columns (even: 8-byte aligned pairs)
-    float *stile = lds, *ttile = lds + v * CS_COLS, *tmean = ttile + v * tw, *tinv = tmean + (ZM ? tw : 0); // (tmean / tinv: ZM / NRM only)
-    float *xpose = tinv + (NRM ? tw : 0) + (threadIdx.x >> 6) * (64 * CS_XP); // this wave's area for turning 64 pixels x DB costs around
+    const bool ext = FOLD && D > DB && (D & 1);       // the last block of an offset is seventeen wide
+    const int nbw = (D - (ext ? 1 : 0) + DB - 1) / DB; // blocks of one vertical offset
+    const int n_blocks = FOLD ? nbw * n_dh : nbw;
+    const int n_off = FOLD ? n_dh : 1, tv = v + n_off - 1; // vertical offsets of the launch, target rows staged
+    const int tw = CS_COLS + nbw * DB; // target tile columns (even: 8-byte aligned pairs)
+    float *stile = lds, *ttile = lds + v * CS_COLS, *tmean = ttile + tv * tw, *tinv = tmean + (ZM ? n_off * tw : 0); // (tmean / tinv: ZM / NRM only)
+    float *xpose = tinv + (NRM ? n_off * tw : 0) + (threadIdx.x >> 6) * (64 * CS_XP); // this wave's area for turning 64 pixels x DB costs around
     const int i = row0 + blockIdx.y, p0 = blockIdx.x * OUT, xb = p0 - HR; // first output pixel, first column of the tile
     const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(p0, Ws - 1)] : 0.0f; // keeps the zero-mean dot products small
     const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
@@ -217,24 +231,26 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
         float *dst = is_src ? stile + xc : ttile + (xc - CS_COLS);
         const int pitch = is_src ? CS_COLS : tw;
         const bool col_in = col >= 0 && col < Wi;
-        for (int k0 = 0; k0 < v; k0 += 4) {
+        const int nr = (FOLD && !is_src) ? tv : v;
+        for (int k0 = 0; k0 < nr; k0 += 4) {
             float val[4];
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const int rr = r0 + k0 + kk;
-                val[kk] = (k0 + kk < v && col_in && rr >= 0 && rr < H) ? img[(int64_t)rr * Wi + col] : 0.0f;
+                val[kk] = (k0 + kk < nr && col_in && rr >= 0 && rr < H) ? img[(int64_t)rr * Wi + col] : 0.0f;
             }
 #pragma unroll
             for (int kk = 0; kk < 4; kk++)
-                if (k0 + kk < v) dst[(k0 + kk) * pitch] = val[kk] - c0;
+                if (k0 + kk < nr) dst[(k0 + kk) * pitch] = val[kk] - c0;
         }
     }
-    if (ZM || NRM) { // per target pixel: mean and 1 / norm at the window CENTRE column tcol(z)
-        for (int z = threadIdx.x; z < tw; z += blockDim.x) {
-            const int jt = tcol(z);
-            const bool in = trow_in && jt >= 0 && jt < Wt;
-            if (ZM) tmean[z] = in ? mean_t[(int64_t)it * Wt + jt] : 0.0f;
-            if (NRM) tinv[z] = in ? 1.0f / norm_t[(int64_t)it * Wt + jt] : 0.0f;
+    if (ZM || NRM) { // per target pixel: mean and 1 / norm at the window CENTRE column tcol(z) (FOLD: one row of them per vertical offset)
+        for (int zz = threadIdx.x; zz < n_off * tw; zz += blockDim.x) {
+            const int dh = FOLD ? zz / tw : 0, z = zz - dh * tw;
+            const int jt = tcol(z), itd = it + dh;
+            const bool in = itd >= 0 && itd < H && jt >= 0 && jt < Wt;
+            if (ZM) tmean[zz] = in ? mean_t[(int64_t)itd * Wt + jt] : 0.0f;
+            if (NRM) tinv[zz] = in ? 1.0f / norm_t[(int64_t)itd * Wt + jt] : 0.0f;
         }
     }
     __syncthreads();
@@ -259,13 +275,26 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
     int red_d[2] = {-1, -1};
     bool nan_at_0[2] = {false, false};
     for (int db = wave; db < n_blocks; db += WAVES) {
-        const int d0 = db * DB;
+        int d0 = db * DB, dh = 0;
+        bool ext_b = false; // (wave uniform) this block carries the seventeenth disparity
+        if constexpr (FOLD) {
+            dh = db / nbw;
+            d0 = (db - dh * nbw) * DB;
+            if (D > DB && d0 + DB + (ext ? 1 : 0) >= D) { // the last block of the offset: it ends with the range
+                d0 = D - DB - (ext ? 1 : 0);
+                ext_b = ext;
+            }
+        }
+        const float *ttile_b = FOLD ? ttile + dh * tw : ttile, *tmean_b = FOLD ? tmean + dh * tw : tmean, *tinv_b = FOLD ? tinv + dh * tw : tinv;
+        const bool trow_in_b = FOLD ? (it + dh >= 0 && it + dh < H) : trow_in;
+        const int64_t out_b = FOLD ? out_off + (int64_t)dh * D : out_off;
         // Column sums as register PAIRS (v_pk_fma_f32 takes aligned pairs): the row's target samples t[0 .. DB + 1] arrive as the
         // pairs (t[2 m], t[2 m + 1]).  The column that meets t[q] pairs its disparities (2 m, 2 m + 1); the one that meets t[q + 1]
         // pairs (2 m + 1, 2 m + 2) -- the same register pairs, one to the right -- and keeps disparities 0 and DB - 1 as singles.
         using v2f = float __attribute__((ext_vector_type(2)));
         v2f A[DB / 2], Bp[DB / 2 - 1];
         float b_first = 0.0f, b_last = 0.0f;
+        float x17a = 0.0f, x17b = 0.0f; // FOLD: disparity d0 + 16 of the even / the odd column (accumulated by every block, used by the last)
 #pragma unroll
         for (int m = 0; m < DB / 2; m++) A[m] = (v2f){0.0f, 0.0f};
 #pragma unroll
@@ -278,7 +307,7 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
         auto load_row = [&](Row &rw, int k) {
             const float2 sv = *reinterpret_cast<const float2 *>(stile + k * CS_COLS + 2 * u);
             rw.s = (v2f){sv.x, sv.y};
-            const float2 *trow = reinterpret_cast<const float2 *>(ttile + k * tw + zb);
+            const float2 *trow = reinterpret_cast<const float2 *>(ttile_b + k * tw + zb);
 #pragma unroll
             for (int m = 0; m < DB / 2 + 1; m++) {
                 const float2 tt = trow[m];
@@ -309,6 +338,11 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
             for (int m = 0; m < DB / 2 - 1; m++) term2(Bp[m], sb, rw.t[m + 1]);
             term1(b_first, sb, rw.t[0].y);
             term1(b_last, sb, rw.t[DB / 2].x);
+            if constexpr (FOLD) {
+                static_assert(!FOLD || SIGN > 0, "2-D volumes walk the target to the right");
+                term1(x17a, sa, rw.t[DB / 2].x);
+                term1(x17b, sb, rw.t[DB / 2].y);
+            }
         };
         // two rows in flight: the LDS reads of the next row are issued before the arithmetic of the current one (the scheduling
         // barriers keep the compiler from sinking each read to its first use, which made every read a round trip of its own)
@@ -351,6 +385,21 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
             r[0][q] = P0 + lane_below(P1m);
             r[1][q] = P1 + P0m;
         }
+        float r17[2] = {0.0f, 0.0f};
+        if (FOLD && ext_b) {
+            float P0 = x17a, P1 = x17b, P0m = P0, P1m = P1;
+#pragma unroll
+            for (int l = 1; l <= HR; l++) {
+                if (l == HR) {
+                    P0m = P0;
+                    P1m = P1;
+                }
+                P0 = x17a + lane_below(P0);
+                P1 = x17b + lane_below(P1);
+            }
+            r17[0] = P0 + lane_below(P1m);
+            r17[1] = P1 + P0m;
+        }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             // (every lane goes through the exchange below; lanes without a pixel carry values nobody stores)
@@ -363,23 +412,23 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
             // Nearly every block lies inside the target image for all of its sixteen disparities and every pixel of the wave (wave uniform):
             // then no cost is the one against the all-zero vector and the test per voxel -- a compare, a select and the mask arithmetic, a
             // third of the block's vector instructions outside the window sums -- is one ballot per block.
-            const int jt_last = jt0 + SIGN * (DB - 1);
-            const bool interior = trow_in && whole && __all(!live[e] || ((unsigned)jt0 < (unsigned)Wt && (unsigned)jt_last < (unsigned)Wt));
+            const int jt_last = jt0 + SIGN * (DB - 1 + ((FOLD && ext_b) ? 1 : 0));
+            const bool interior = trow_in_b && whole && __all(!live[e] || ((unsigned)jt0 < (unsigned)Wt && (unsigned)jt_last < (unsigned)Wt));
 #pragma unroll
             for (int q = 0; q < DB; q++) {
                 float x = r[e][q];
-                if (ZM && CMP == T_DOT) x -= Ff * (ms[e] - c0) * (tmean[zc0 + q] - c0);
+                if (ZM && CMP == T_DOT) x -= Ff * (ms[e] - c0) * (tmean_b[zc0 + q] - c0);
                 if (ZM && CMP == T_SSD) {
-                    const float dm = ms[e] - tmean[zc0 + q];
+                    const float dm = ms[e] - tmean_b[zc0 + q];
                     x -= Ff * dm * dm;
                 }
-                if (NRM) x *= inv_ns[e] * tinv[zc0 + q];
+                if (NRM) x *= inv_ns[e] * tinv_b[zc0 + q];
                 o_[q] = x;
             }
             if (!interior) {
 #pragma unroll
                 for (int q = 0; q < DB; q++) {
-                    const bool there = trow_in && (unsigned)(jt0 + SIGN * q) < (unsigned)Wt && (whole || d0 + q < D);
+                    const bool there = trow_in_b && (unsigned)(jt0 + SIGN * q) < (unsigned)Wt && (whole || d0 + q < D);
                     o_[q] = there ? o_[q] : zc[e]; // no target pixel: the cost against the all-zero vector (cross_correlations.h:235)
                 }
             }
@@ -433,8 +482,19 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                     }
                 }
             }
+            if (FOLD && ext_b && live[e]) { // the seventeenth cost: the lane's own pixel, one dword
+                float x = r17[e];
+                if (ZM && CMP == T_DOT) x -= Ff * (ms[e] - c0) * (tmean_b[zc0 + DB] - c0);
+                if (ZM && CMP == T_SSD) {
+                    const float dm = ms[e] - tmean_b[zc0 + DB];
+                    x -= Ff * dm * dm;
+                }
+                if (NRM) x *= inv_ns[e] * tinv_b[zc0 + DB];
+                const bool there = trow_in_b && (unsigned)(jt0 + DB) < (unsigned)Wt;
+                cv[((int64_t)i * Ws + pe[e]) * px_stride + out_b + d0 + DB] = there ? x : zc[e];
+            }
             if (RED && !rd.store) continue; // (kernel-uniform) nobody wants the volume
-            if (whole) { // (wave uniform)
+            if (whole || FOLD) { // (wave uniform)
                 // A lane holds 64 bytes of its pixel's run; stored as they are, every 16-byte piece of a wave's store instruction would go to
                 // a different pixel (1 KB apart): requests of 16 bytes, a quarter of what the memory side takes per request (measured: the
                 // kernel then runs at 2.4 TB/s whatever the window).  Through LDS instead: lanes 4 a .. 4 a + 3 store the four pieces of
@@ -448,11 +508,20 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                     const int uu = 16 * j + a;                                 // the lane whose pixel this is
                     const int pp = p0 + 2 * (uu - HR) + e;                     // that pixel
                     const float4 piece = *reinterpret_cast<const float4 *>(xpose + uu * CS_XP + 4 * c);
-                    if (uu >= HR && pp < Ws) *reinterpret_cast<CostPiece4 *>(cv + ((int64_t)i * Ws + pp) * px_stride + out_off + d0 + 4 * c) = CostPiece4{piece.x, piece.y, piece.z, piece.w};
+                    float *dst = cv + ((int64_t)i * Ws + pp) * px_stride + out_b + d0 + 4 * c;
+                    if (uu >= HR && pp < Ws) {
+                        if (whole || d0 + 4 * c + 4 <= D) { // (FOLD: a partial block stores its whole pieces the same way)
+                            *reinterpret_cast<CostPiece4 *>(dst) = CostPiece4{piece.x, piece.y, piece.z, piece.w};
+                        } else {
+                            if (d0 + 4 * c < D) dst[0] = piece.x;
+                            if (d0 + 4 * c + 1 < D) dst[1] = piece.y;
+                            if (d0 + 4 * c + 2 < D) dst[2] = piece.z;
+                        }
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (read before the next round overwrites it)
             } else if (live[e]) {
-                float *o = cv + ((int64_t)i * Ws + pe[e]) * px_stride + out_off + d0;
+                float *o = cv + ((int64_t)i * Ws + pe[e]) * px_stride + out_b + d0;
 #pragma unroll
                 for (int q = 0; q < DB; q++)
                     if (d0 + q < D) o[q] = o_[q];
@@ -505,14 +574,15 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
 // waves per block: eight share a staged tile when there are disparity blocks for all of them (two blocks of eight waves fit a CU's LDS
 // where three of four would: 16 instead of 12 waves per CU), four otherwise
 inline int colsum_waves(int D) { return (D + CS_DB - 1) / CS_DB >= 16 ? 8 : 4; }
-inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm) {
+inline int colsum_waves(int D, int n_dh) { return n_dh * ((D + CS_DB - 1) / CS_DB) >= 16 ? 8 : 4; }
+inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm, int n_dh = 1) {
     const int v = 2 * v_r + 1, nb = (D + CS_DB - 1) / CS_DB, tw = CS_COLS + nb * CS_DB;
-    return (size_t)(v * (CS_COLS + tw) + (zm ? tw : 0) + (nrm ? tw : 0) + colsum_waves(D) * 64 * CS_XP) * sizeof(float);
+    return (size_t)(v * CS_COLS + (v + n_dh - 1) * tw + (zm ? n_dh * tw : 0) + (nrm ? n_dh * tw : 0) + colsum_waves(D, n_dh) * 64 * CS_XP) * sizeof(float);
 }
 
 template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                                    const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
-    const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM);
+    const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM, a.n_dh);
     ColsumReduce rd{};
     rd.store = 1;
     if (a.reduce && a.reduce->mode && a.tgt_row_off == 0 && a.out_off == 0 && a.row_count == 0) { // (1-D volumes of whole images)
@@ -521,24 +591,28 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
         a.reduce->done = true;
     }
     dim3 grid(ceil_div(a.Ws, CS_COLS - 2 * HR), a.row_count ? a.row_count : a.H);
-#define SVH_CS_LAUNCH_R(SG, WV, RD)                                                                                                                 \
+#define SVH_CS_LAUNCH_RF(SG, WV, RD, FD)                                                                                                            \
     do {                                                                                                                                           \
         static int big_lds[64] = {}; /* (per instantiation and device) more than the default 64 KiB of dynamic LDS */                              \
         if (shmem > 64 * 1024 && !__atomic_load_n(&big_lds[ctx->device & 63], __ATOMIC_ACQUIRE)) {                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD>),                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD>),                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                     \
             __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
         }                                                                                                                                          \
-        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD>), grid, 64 * WV, shmem, src, tgt, a.H, a.Ws, \
-                   a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd);                \
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD>), grid, 64 * WV, shmem, src, tgt, a.H,   \
+                   a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, a.n_dh); \
     } while (0)
+#define SVH_CS_LAUNCH_R(SG, WV, RD) SVH_CS_LAUNCH_RF(SG, WV, RD, false)
 #define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
     do {                                                                                                                                           \
         if (rd.mode == 1) SVH_CS_LAUNCH_R(SG, WV, 1);                                                                                              \
         else if (rd.mode == 2) SVH_CS_LAUNCH_R(SG, WV, 2);                                                                                         \
         else SVH_CS_LAUNCH_R(SG, WV, 0);                                                                                                           \
     } while (0)
-    if (colsum_waves(a.D) == 8) {
+    if (a.n_dh > 1) { // several vertical offsets of a 2-D volume in one launch (sign +1 there, no reductions)
+        if (colsum_waves(a.D, a.n_dh) == 8) SVH_CS_LAUNCH_RF(1, 8, 0, true);
+        else SVH_CS_LAUNCH_RF(1, 4, 0, true);
+    } else if (colsum_waves(a.D) == 8) {
         if (sign > 0) SVH_CS_LAUNCH(1, 8);
         else SVH_CS_LAUNCH(-1, 8);
     } else {
@@ -547,6 +621,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
     }
 #undef SVH_CS_LAUNCH
 #undef SVH_CS_LAUNCH_R
+#undef SVH_CS_LAUNCH_RF
 }
 template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                        const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
@@ -589,7 +664,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
                                              const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv,
                                              size_t shmem) {
     if constexpr (!(ZM && CMP == T_SAD)) { // separable terms: column sums shared by the windows that contain the column
-        if (ctx->cost_volume_colsum && colsum_shmem(v_r, a.D, ZM, ns != nullptr) <= 78 * 1024) {
+        if (ctx->cost_volume_colsum && colsum_shmem(v_r, a.D, ZM, ns != nullptr, a.n_dh) <= 78 * 1024) {
             switch (h_r) {
             case 1: launch_colsum<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
             case 2: launch_colsum<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
@@ -600,7 +675,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
             }
         }
     }
-    if (shmem > 60 * 1024) return false;
+    if (shmem > 60 * 1024 || a.n_dh > 1) return false; // (only the column-sum kernel folds vertical offsets: cost_volume_colsum_applies)
     switch (h_r) {
     case 1: launch_pxlane<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
     case 2: launch_pxlane<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
@@ -615,7 +690,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 
 bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r) {
     if (a.literal || src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
-    return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func)) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
+    return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func), a.n_dh) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
 }
 
 // Returns SVH_OK when the tiled kernel ran, SVH_ERR_UNSUPPORTED (without touching the context error) when the caller must
@@ -624,7 +699,8 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
     if (src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func)) return SVH_ERR_UNSUPPORTED;
     const size_t shmem = pxlane_shmem(h_r, v_r, a.D);
     const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
-    if (shmem > 60 * 1024 && (a.func == SVH_ZSAD || !ctx->cost_volume_colsum || colsum_shmem(v_r, a.D, zm, nrm) > 78 * 1024)) return SVH_ERR_UNSUPPORTED;
+    if (a.n_dh > 1 && !cost_volume_colsum_applies(ctx, a, src, tgt, h_r, v_r)) return SVH_ERR_UNSUPPORTED;
+    if (shmem > 60 * 1024 && (a.func == SVH_ZSAD || !ctx->cost_volume_colsum || colsum_shmem(v_r, a.D, zm, nrm, a.n_dh) > 78 * 1024)) return SVH_ERR_UNSUPPORTED;
     if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
     const int cmp = (a.func == SVH_SSD || a.func == SVH_ZSSD) ? T_SSD : (a.func == SVH_SAD || a.func == SVH_ZSAD) ? T_SAD : T_DOT;
     const size_t ns_px = (size_t)a.H * a.Ws, nt_px = (size_t)a.H * a.Wt;

@@ -52,6 +52,7 @@ struct svh_context {
     int census_sweep_rl = 1;       // svh_context_set_option("census_sweep_rl"): the FP4 engine may use its RightToLeft specialisation (svh_census_sweep_rl.hip)
     bool census_tiles = true;          // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
+    bool fold_2d_offsets = true;       // svh_context_set_option("fold_2d_offsets"): 2-D disparity volumes of grey images take as many vertical offsets per launch of the column-sum kernel as its tile holds (0: a launch per vertical offset)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     bool cost_reduce_fused = true;     // svh_context_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
     bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
@@ -243,6 +244,9 @@ struct CostVolumeArgs {
     int force_sign = 0;          // 0: +1 for RightToLeft, -1 for LeftToRight
     int64_t out_px_stride = 0;   // 0: D
     int64_t out_off = 0;
+    // n_dh > 1: one launch takes the vertical offsets tgt_row_off .. tgt_row_off + n_dh - 1 (offset dh at out_off + dh D); only where
+    // cost_volume_colsum_applies says the column-sum kernel runs
+    int n_dh = 1;
     bool literal = false;        // skip the register-blocked kernel: the reference's operations in the reference's order
     WindowStatsCache *stats = nullptr; // optional: statistics maps shared by several passes over the same image pair
     // census / Hamming volumes: per pixel the smallest cost among the disparities that do not / do pay Pout in a later sgmCostVolume

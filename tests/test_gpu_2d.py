@@ -201,3 +201,36 @@ def test_feature_volume_2d_matches_oracle(rng, func):
                 else:
                     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))  # the per-voxel kernel follows the reference's operation order
     assert sv.featureVolume2CostVolume(MF.SAD, fl, fr[:10], sv.searchOffset2(0, 1, 0, 1)).size == 0
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.SSD, MF.ZSSD, MF.SAD, MF.CC, MF.ZCC])
+def test_2d_volume_folded_offsets_same_bits(rng, func):
+    """fold_2d_offsets (one launch of the column-sum kernel for as many vertical offsets as its tile holds, the last block of an offset
+    starting at Dw - 16) against a launch per vertical offset: the same bits; and against the oracle within the float tolerance.  Ranges
+    that are / are not multiples of 16, shorter than 16, offsets that leave the image on every side, more offsets than one tile holds."""
+    cases = [((31, 300), 3, 3, (-4, 4), (-16, 16)),   # 9 x 33: two whole blocks + the shifted one
+             ((23, 150), 2, 2, (-8, 8), (-8, 8)),     # 17 x 17
+             ((17, 140), 1, 2, (-1, 1), (0, 15)),     # exactly one block per offset
+             ((12, 130), 2, 1, (-3, 2), (-4, 4)),     # shorter than a block: the per-cost store path
+             ((40, 131), 5, 5, (-30, 29), (-3, 40)),  # 60 offsets of 44: several groups; rows far outside the image
+             ((9, 64), 4, 4, (2, 4), (-70, -40)),     # (31) every target column left of the image for most pixels
+             ((20, 129), 2, 2, (-2, 2), (-17, 17)),   # 35: an odd range that is not 16 k + 1 (last block seventeen wide, starting early)
+             ((14, 140), 1, 1, (0, 2), (-9, 8)),      # 18: even, the last block starts at 2
+             ((11, 127), 3, 1, (-1, 0), (-9, 9))]     # 19
+    for (shape, h_r, v_r, r0, r1) in cases:
+        left = rng.uniform(-1, 1, shape).astype(np.float32)
+        right = rng.uniform(-1, 1, shape).astype(np.float32)
+        dl, dr = dev(left), dev(right)
+        off = sv.searchOffset2(r0[0], r0[1], r1[0], r1[1])
+        sv.set_option(dl, "fold_2d_offsets", 0)
+        try:
+            per_offset = host(sv.unfoldBased2dDisparityCostVolume(func, dl, dr, h_r, v_r, off))
+        finally:
+            sv.set_option(dl, "fold_2d_offsets", 1)
+        folded = host(sv.unfoldBased2dDisparityCostVolume(func, dl, dr, h_r, v_r, off))
+        assert folded.shape == per_offset.shape == (shape[0], shape[1], r0[1] - r0[0] + 1, r1[1] - r1[0] + 1)
+        assert np.array_equal(folded.view(np.uint32), per_offset.view(np.uint32)), (shape, h_r, v_r, r0, r1)
+        exp = so.unfold_cost_volume_2d(int(func), left, right, h_r, v_r, r0, r1)
+        assert np.array_equal(np.isnan(folded), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.all(np.abs(folded[ok] - exp[ok]) <= 1e-4 * np.maximum(1, np.abs(exp[ok])))

@@ -274,10 +274,31 @@ struct ScanGeom {
 // lanes of a wave (64 neighbouring lines) touch 64 consecutive pixels: every access is a coalesced 256-byte row
 // segment.  The rows are cut into SCAN_SEGS chunks handled by the threadIdx.y slices of the block.
 constexpr int SCAN_SEGS = 16;
-constexpr int SCAN_MAXSEG = 72; // segments up to this many rows are kept in registers (images up to 1152 rows)
+constexpr int SCAN_MAXSEG = 72; // segments up to this many rows are kept in registers (a launch covers up to 1152 rows)
 constexpr int TILE_SUB = 8;     // tile rows per segment (tiles mode: TileMaps, tile_finalize_kernel)
 // rows per segment: a multiple of TILE_SUB (and of four: the lean form's lengths)
 __host__ __device__ __forceinline__ int scan_chunk(int Hp) { return ((Hp + SCAN_SEGS - 1) / SCAN_SEGS + TILE_SUB - 1) / TILE_SUB * TILE_SUB; }
+// Tiles mode on images taller than one launch covers (round 4f): the rows are cut into BANDS of SCAN_SEGS segments, one launch per band,
+// and a line's min_p crosses from band to band through one float per line and pass (ScanBands::carry: the affine maps of the bands
+// compose like those of the segments).  The downward passes take the bands top to bottom, pass 5 bottom to top, so launch k holds band k
+// of the former and band n - 1 - k of the latter.
+struct ScanBands {
+    int n = 1, chunk = 0; // bands, rows per segment (every band: SCAN_SEGS * chunk rows, the last one what is left)
+    // n > 1: 5 x stride floats each; a launch reads what the one before it wrote (zeros for the first) and writes the other array --
+    // two arrays, so that no wave's read of an entry can meet the write of the block's last slice
+    const float *carry_in = nullptr;
+    float *carry_out = nullptr;
+    int stride = 0;
+    int band_dn = 0, band_up = 0; // the bands of this launch
+    __host__ __device__ int rows() const { return SCAN_SEGS * chunk; }
+};
+inline ScanBands scan_bands_for(int Hp) {
+    ScanBands b;
+    b.n = (Hp + SCAN_SEGS * SCAN_MAXSEG - 1) / (SCAN_SEGS * SCAN_MAXSEG);
+    if (b.n < 1) b.n = 1;
+    b.chunk = ((Hp + SCAN_SEGS * b.n - 1) / (SCAN_SEGS * b.n) + TILE_SUB - 1) / TILE_SUB * TILE_SUB;
+    return b;
+}
 
 struct ColLines {
     int s, v_lo, n_lines, dir;
@@ -349,13 +370,19 @@ struct LeanArgs {
     int q, s, vwave, nb, n_u; // pass, column step per row, line of lane 0, first row and row count of the segment
     int v_lo, n_lines;        // the pass's lines
     int kb;                   // first traversal step of this lane's line in the segment (its steps: [kb, kb + n))
+    int ty0;                  // tile row of the band's first row
+    const float *carry_in;    // several bands: this lane's entries of ScanBands::carry_in / carry_out (nullptr: one band, lines start from 0)
+    float *carry_out;
 };
 // FULL: every lane's line crosses all LEN rows of the segment or none (and, in tiles mode, LEN = TILE_SUB R: a whole segment)
 template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], const TileMaps &tm) {
     static_assert(CARRY || FULL, "the maps mode has its own general form");
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gmap, 0, (int)(a.npx * 4), 0x00020000);
     float gv[LEN];
-    float mp = 0.0f;
+    float mp = 0.0f, carry_in = 0.0f;
+    if constexpr (CARRY) {
+        if (a.carry_in) carry_in = *a.carry_in; // (kernel uniform) what the bands before this one leave on this lane's line
+    }
     // traversal step k is the segment's row k (downwards) or n_u - 1 - k (pass 5, upwards)
     if constexpr (FULL) {
         const uint32_t s0 = a.dir > 0 ? 0u : (uint32_t)(LEN - 1) * a.st4, sd = a.dir > 0 ? a.st4 : 0u - a.st4;
@@ -384,13 +411,17 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
     seg_a[a.seg][a.lane] = mp;
     seg_n[a.seg][a.lane] = a.n;
     __syncthreads();
-    mp = 0.0f;
+    mp = carry_in;
     if (a.dir > 0) {
         for (int t = 0; t < a.seg; t++) mp = seg_a[t][a.lane] + ((seg_n[t][a.lane] & 1) ? -mp : mp);
     } else {
         for (int t = SCAN_SEGS - 1; t > a.seg; t--) mp = seg_a[t][a.lane] + ((seg_n[t][a.lane] & 1) ? -mp : mp);
     }
     if constexpr (CARRY) {
+        if (a.carry_out && a.seg == (a.dir > 0 ? SCAN_SEGS - 1 : 0)) { // the last segment in traversal order: the whole band's map, for the next band
+            const float out_c = seg_a[a.seg][a.lane] + ((seg_n[a.seg][a.lane] & 1) ? -mp : mp);
+            if (a.v_lo + a.n_lines > a.vwave + a.lane) *a.carry_out = out_c;
+        }
         // The replay keeps what lies on tile edges: E at the first row of every tile row in the direction of travel (a full-wave
         // store), S where a lane's pixel sits on a tile's side: once every 64 rows, at steps known beforehand -- a compare and a
         // select per row park the value, one store per lane at the end writes it.  (A line that has not started yet carries 0
@@ -405,7 +436,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
         // are the steps n_u - R m > 0 and step 0 (the segment's last row, whatever tile row it lies in)
         unsigned long long em_lo = 0;
         unsigned em_hi = 0;
-        int ty_next = TILE_SUB * a.seg;
+        int ty_next = a.ty0 + TILE_SUB * a.seg;
         if constexpr (!FULL) {
             int k0 = 0;
             if (a.dir < 0) {
@@ -433,7 +464,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
             int ty;
             if constexpr (FULL) {
                 edge = k % RF == 0;
-                ty = TILE_SUB * a.seg + (a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF);
+                ty = a.ty0 + TILE_SUB * a.seg + (a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF);
             } else {
                 edge = k < 64 ? (em_lo >> k) & 1 : (em_hi >> (k - 64)) & 1;
                 ty = ty_next;
@@ -477,7 +508,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
 
 template <bool CARRY>
 __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
-                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero, TileMaps tm) {
+                                                                   float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero, TileMaps tm, ScanBands bands) {
     if (skip_if_nonzero && *skip_if_nonzero != 0) return; // the integer-volume probe failed: the line kernels make the maps
     // slice (which pass) and block within the slice: blockIdx.y / blockIdx.x of a two-dimensional grid whose slices are as wide as the
     // widest (blocks past a pass's lines leave at once), or -- tiles mode -- a one-dimensional grid of exactly the blocks that have
@@ -485,7 +516,8 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     int by = blockIdx.y, bx = blockIdx.x;
     if (CARRY && gridDim.y == 1) {
         const int cw = (sg.Wp + 63) / 64, ch = (sg.Hp + 63) / 64;
-        const int count[6] = {ch, cw, cw, ch, cw, (sg.Hp + SCAN_SEGS - 1) / SCAN_SEGS}, slice[6] = {1, 2, 3, 4, 0, 5};
+        const int band_rows = min(bands.rows(), sg.Hp - bands.band_dn * bands.rows()); // (pass 1: the rows of this launch's downward band)
+        const int count[6] = {ch, cw, cw, ch, cw, (band_rows + SCAN_SEGS - 1) / SCAN_SEGS}, slice[6] = {1, 2, 3, 4, 0, 5};
         int rem = blockIdx.x;
         by = -1;
 #pragma unroll
@@ -499,7 +531,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         if (by < 0) return;
     }
     if (by == (n_pass <= 2 ? 1 : 5)) { // last slice of the grid: pass 1, one wave per row
-        scan_one_row<CARRY>(gmap, sg, npx, mmap, bx * SCAN_SEGS + threadIdx.y, threadIdx.x, tm);
+        scan_one_row<CARRY>(gmap, sg, npx, mmap, (CARRY ? bands.band_dn * bands.rows() : 0) + bx * SCAN_SEGS + threadIdx.y, threadIdx.x, tm);
         return;
     }
     __shared__ float seg_a[SCAN_SEGS][64];
@@ -511,8 +543,9 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     if (bx * 64 >= cl.n_lines) return; // whole block out of range (uniform)
     int r0 = 0, r1 = 0;
     if (v < cl.v_lo + cl.n_lines) col_line_rows(q, v, sg, r0, r1);
-    const int chunk = scan_chunk(sg.Hp);
-    const int b = max(r0, seg * chunk), e = min(r1, (seg + 1) * chunk);
+    const int chunk = CARRY ? bands.chunk : scan_chunk(sg.Hp);
+    const int band0 = CARRY ? (q == 5 ? bands.band_up : bands.band_dn) * bands.rows() : 0; // first row of this launch's band of the pass
+    const int b = max(r0, band0 + seg * chunk), e = min(r1, band0 + (seg + 1) * chunk);
     const int n = max(e - b, 0);
     // pixel index of relative row r on this line: (top + r) * W + left + v + s r, advanced by dir * (W + s) per step
     const int first = cl.dir > 0 ? b : e - 1;
@@ -524,14 +557,16 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         // LEAN FORM (scan_lean below) for the waves whose 64 lines all cross every row of the segment or none of it -- all but the
         // waves at the ragged ends of the diagonal passes -- when the segment's row count is one of the compile-time lengths
         const int segu = __builtin_amdgcn_readfirstlane(seg);
-        const int nb = segu * chunk, ne = min(sg.Hp, nb + chunk), n_u = ne - nb; // rows [nb, ne) of the margin box
+        const int nb = band0 + segu * chunk, ne = min(sg.Hp, nb + chunk), n_u = ne - nb; // rows [nb, ne) of the margin box
         const bool ragged = n != 0 && (b != nb || e != ne);
         const bool full = n_u > 0 && (n_u & 3) == 0 && (!CARRY || n_u == chunk) && __builtin_amdgcn_ballot_w64(ragged) == 0;
         if (full || CARRY) {
             // lane_off: the lane's pixel in row nb (in the general form possibly not a pixel of its line: only used inside its steps)
             const uint32_t lane_off = (full && n == 0) ? 0xFFFFFFFFu : (uint32_t)(((int64_t)(sg.top + nb) * sg.W + sg.left + v + cl.s * nb) * 4);
             const LeanArgs la{gmap, out, npx, (uint32_t)(sg.W + cl.s) * 4u, lane_off, cl.dir, segu, lane, n,
-                              q, cl.s, cl.v_lo + bx * 64, nb, n_u, cl.v_lo, cl.n_lines, cl.dir > 0 ? b - nb : ne - e};
+                              q, cl.s, cl.v_lo + bx * 64, nb, n_u, cl.v_lo, cl.n_lines, cl.dir > 0 ? b - nb : ne - e, band0 / max(tm.R, 1),
+                              bands.carry_in ? bands.carry_in + (int64_t)by * bands.stride + min(bx * 64 + lane, bands.stride - 1) : nullptr,
+                              bands.carry_out ? bands.carry_out + (int64_t)by * bands.stride + min(bx * 64 + lane, bands.stride - 1) : nullptr};
             if (n_u > 0) {
                 switch ((n_u + 3) >> 2) {
 #define SVH_LEAN(Q)                                                     \
@@ -1073,7 +1108,7 @@ int dev_census_scans(svh_context *ctx, const SgmArgs &a, const uint2 *keys, floa
     ScanGeom sg{a.top, a.left, Hp, Wp, a.W};
     // one launch: grid slices 0..4 (or 0) are the passes that cross the rows, the last slice is pass 1 (one wave per row)
     dim3 cgrid(std::max(ceil_div(std::max(Hp, Wp), 64), ceil_div(Hp, SCAN_SEGS)), (n_pass == 6 ? 5 : 1) + 1), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<false>, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero, TileMaps{});
+    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<false>, cgrid, cblock, 0, gmap, sg, npx, n_pass, mmap, skip_if_nonzero, TileMaps{}, ScanBands{});
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -1089,34 +1124,60 @@ static int launch_tile_finalize(svh_context *ctx, dim3 tgrid, const CensusGeom &
 // sweep -> tile-edge values of the line scans -> replay + per-pixel kernel, no min_p maps (tile_finalize_kernel): whether the geometry allows it
 bool census_tiles_apply(const svh_context *ctx, const SgmArgs &a) {
     const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0 && a.row_origin == 0 && a.full_H == 0 && a.store_rows == 0;
-    const int chunk = scan_chunk(a.H);
-    return ctx->census_tiles && whole && a.n_dir >= 8 && a.n_dir != 16 && a.H > 0 && a.W > 0 && chunk <= SCAN_MAXSEG && a.H <= 65535 &&
-           (int64_t)a.H * a.W <= ((int64_t)1 << 27);
+    // (taller than one launch's 1152 rows: bands of rows, ScanBands; tile_finalize_kernel addresses keys with 32-bit byte offsets)
+    return ctx->census_tiles && whole && a.n_dir >= 8 && a.n_dir != 16 && a.H > 0 && a.W > 0 && a.H <= 65535 && (int64_t)a.H * a.W <= ((int64_t)1 << 27);
+}
+
+// keys (and g, unless the caller has it already) -> tile-edge values of the line scans -> replay + per-pixel kernel
+int dev_census_tiles_from_keys(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const uint2 *keys, float *gmap, bool gmap_ready,
+                               const WinnerOut &win) {
+    const int64_t npx = (int64_t)a.H * a.W;
+    ScanBands bands = scan_bands_for(a.H);
+    TileMaps tm;
+    tm.Hp = a.H;
+    tm.Wp = a.W;
+    tm.R = bands.chunk / TILE_SUB;
+    tm.base = scr.get_n<float>((size_t)tm.total());
+    if (!tm.base) return SVH_ERR_OUT_OF_MEMORY;
+    if (!gmap_ready) {
+        SVH_LAUNCH(ctx, "gmap_from_keys", gmap_from_keys_kernel, grid_for(npx, 256), 256, 0, keys, npx, a.Pout, gmap);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    float *carry[2] = {nullptr, nullptr};
+    if (bands.n > 1) {
+        bands.stride = ceil_div(std::max(a.H, a.W), 64) * 64;
+        carry[0] = scr.get_n<float>((size_t)10 * bands.stride);
+        if (!carry[0]) return SVH_ERR_OUT_OF_MEMORY;
+        carry[1] = carry[0] + (size_t)5 * bands.stride;
+        SVH_HIP_CHECK(ctx, hipMemsetAsync(carry[0], 0, (size_t)5 * bands.stride * sizeof(float), ctx->stream));
+    }
+    ScanGeom sg{0, 0, a.H, a.W, a.W};
+    // one block per 64 lines of a pass (3 x over the columns, 2 x over the rows) and per 16 rows of the row pass, nothing else
+    // (against six slices as wide as the widest, 408 blocks of which 216 leave at once: 16.4 -> 16.2 us, rocprofv3, same box)
+    for (int k = 0; k < bands.n; k++) {
+        bands.band_dn = k;
+        bands.band_up = bands.n - 1 - k;
+        bands.carry_in = carry[k & 1];
+        bands.carry_out = carry[(k + 1) & 1];
+        const int band_rows = std::min(bands.rows(), a.H - k * bands.rows());
+        dim3 cgrid(3 * ceil_div(a.W, 64) + 2 * ceil_div(a.H, 64) + ceil_div(band_rows, SCAN_SEGS)), cblock(64, SCAN_SEGS);
+        SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm, bands);
+        SVH_CHECK_LAUNCH(ctx);
+    }
+    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
+    dim3 tgrid(tm.tx(), ceil_div(tm.ny(), 4));
+#define CALL(N) launch_tile_finalize<N>(ctx, tgrid, g, sg, a.Pout, gmap, tm, keys, win)
+    SVH_NW_DISPATCH(cs.nWw, CALL)
+#undef CALL
 }
 
 int dev_census_sweep_tiles(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win) {
     const int64_t npx = (int64_t)a.H * a.W;
     uint2 *keys = scr.get_n<uint2>((size_t)npx);
     float *gmap = scr.get_n<float>((size_t)npx);
-    const int chunk = scan_chunk(a.H);
-    TileMaps tm;
-    tm.Hp = a.H;
-    tm.Wp = a.W;
-    tm.R = chunk / TILE_SUB;
-    tm.base = scr.get_n<float>((size_t)tm.total());
-    if (!keys || !gmap || !tm.base) return SVH_ERR_OUT_OF_MEMORY;
+    if (!keys || !gmap) return SVH_ERR_OUT_OF_MEMORY;
     SVH_TRY(dev_census_sweep(ctx, a, cs, keys, gmap));
-    ScanGeom sg{0, 0, a.H, a.W, a.W};
-    // one block per 64 lines of a pass (3 x over the columns, 2 x over the rows) and per 16 rows of the row pass, nothing else
-    // (against six slices as wide as the widest, 408 blocks of which 216 leave at once: 16.4 -> 16.2 us, rocprofv3, same box)
-    dim3 cgrid(3 * ceil_div(a.W, 64) + 2 * ceil_div(a.H, 64) + ceil_div(a.H, SCAN_SEGS)), cblock(64, SCAN_SEGS);
-    SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm);
-    SVH_CHECK_LAUNCH(ctx);
-    CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};
-    dim3 tgrid(tm.tx(), ceil_div(tm.ny(), 4));
-#define CALL(N) launch_tile_finalize<N>(ctx, tgrid, g, sg, a.Pout, gmap, tm, keys, win)
-    SVH_NW_DISPATCH(cs.nWw, CALL)
-#undef CALL
+    return dev_census_tiles_from_keys(ctx, scr, a, cs, keys, gmap, true, win);
 }
 
 int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out) {

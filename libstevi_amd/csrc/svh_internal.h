@@ -354,6 +354,8 @@ bool census_exact_regime(const SgmArgs &a, int nWw);
 // exact regime: one sweep (regional winner keys + g map), then the min_p maps by parallel line scans
 bool census_tiles_apply(const svh_context *ctx, const SgmArgs &a);
 int dev_census_sweep_tiles(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const WinnerOut &win);
+int dev_census_tiles_from_keys(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, const uint2 *keys, float *gmap, bool gmap_ready,
+                               const WinnerOut &win);
 int dev_census_sweep_and_scans(svh_context *ctx, Scratch &scr, const SgmArgs &a, const CostSource &cs, float *mmap, uint2 **keys_out);
 int dev_census_sweep(svh_context *ctx, const SgmArgs &a, const CostSource &cs, uint2 *keys, float *gmap /* may be null */);
 // exact regime, index / disparity maps only (win.taps and win.keys null): no g map, no line scans, no min_p maps

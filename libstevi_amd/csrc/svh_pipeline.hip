@@ -425,12 +425,17 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
     // the disparity map alone does not depend on the min_p maps (census_finalize_kernel): no scans then
     const bool shift_ok = want_refine && (prm->refine_kernel == SVH_PARABOLA || prm->refine_kernel == SVH_EQUIANGULAR);
     const bool winner_only = ctx->census_winner_shortcut && (!want_refine || shift_ok);
-    float *mmap = nullptr;
+    float *mmap = nullptr, *gmap = nullptr;
+    // (the recurrences run) tile-edge values + replay where the geometry allows it, as in the one-GPU call; else the six min_p maps
+    const bool tiles = !winner_only && census_tiles_apply(ctx, sa);
     if (!winner_only) {
-        mmap = scr.get_n<float>((size_t)MIN_P_PLANES * npx);
-        float *gmap = scr.get_n<float>((size_t)npx);
-        if (!mmap || !gmap) return SVH_ERR_OUT_OF_MEMORY;
-        SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap, nullptr));
+        gmap = scr.get_n<float>((size_t)npx);
+        if (!gmap) return SVH_ERR_OUT_OF_MEMORY;
+        if (!tiles) {
+            mmap = scr.get_n<float>((size_t)MIN_P_PLANES * npx);
+            if (!mmap) return SVH_ERR_OUT_OF_MEMORY;
+            SVH_TRY(dev_census_scans(ctx, sa, (const uint2 *)dkeys, gmap, false, mmap, nullptr));
+        }
     }
     CostSource cs;
     cs.nWw = s.nWw;
@@ -464,7 +469,8 @@ extern "C" int svh_census_shard_finish(svh_context *ctx, const svh_stereo_params
         win.taps_v_r = prm->refine_v_radius;
         win.taps_up_to_shift = shift_ok;
     }
-    SVH_TRY(dev_census_finalize(ctx, sa, cs, mmap, (const uint2 *)dkeys, win));
+    if (tiles) SVH_TRY(dev_census_tiles_from_keys(ctx, scr, sa, cs, (const uint2 *)dkeys, gmap, false, win));
+    else SVH_TRY(dev_census_finalize(ctx, sa, cs, mmap, (const uint2 *)dkeys, win));
     if (want_refine) SVH_TRY(dev_refine(ctx, prm->refine_kernel, d_taps, d_idx, npx, 3, (float *)o_ref.dptr));
     if (disp) SVH_TRY(finish_out(ctx, o_disp));
     if (refined) SVH_TRY(finish_out(ctx, o_ref));

@@ -138,3 +138,48 @@ def test_tiles_full_hd_rows():
     vol = so.sgm(cv, 8, so.COST, 0.3, 0.9, (0, 0, 0, 0), 100.0)
     del cv
     oracle_checks(a, vol, 4, "1080p x 256, tiles form")
+
+
+# taller than one launch of the scans covers (1152 rows): bands of rows, a line's min_p handed from band to band (ScanBands).  Heights
+# just past one band, two bands with a short second one, three and four bands, a last band of a single segment, wider than tall by far
+TALL = [(1153, 70), (1300, 100), (2304, 64), (2305, 130), (2400, 257), (3500, 90), (4320, 200), (1160, 1500)]
+
+
+@pytest.mark.parametrize("shape", TALL)
+def test_tiles_tall_images_equal_maps(shape):
+    H, W = shape
+    D, r = 32, 4
+    rng = np.random.default_rng(H * 7 + W)
+    src = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    for Pout in (100.0, 3.0):
+        a = run(d_tgt, d_src, r, D, 1, Pout=Pout)
+        b = run(d_tgt, d_src, r, D, 0, Pout=Pout)
+        same(a, b, (shape, Pout))
+
+
+@pytest.mark.parametrize("shape", [(130, 200), (1300, 100), (2500, 70)])
+def test_shard_finish_replays_tiles_like_the_single_call(shape):
+    """svh_census_shard_finish with the recurrences' values in use (Gaussian refinement): tile-edge values + replay from reduced keys,
+    against the six-map form and the one-GPU call."""
+    H, W = shape
+    D, r = 64, 4
+    src, tgt, _ = parallax_pair(H, W, max(min(H, W) // 3, 1), H // 4, W // 4, 2, 9, seed=H + W)
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    kw = dict(sgmDirections=8, P1=0.3, P2=0.9, Pout=100.0)
+    single = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, refineKernel=so.GAUSSIAN, refine_h_radius=r, refine_v_radius=r, **kw)
+    keys = torch.minimum(sv.censusShardKeys(d_tgt, d_src, r, r, D, (0, 32), **kw), sv.censusShardKeys(d_tgt, d_src, r, r, D, (32, 32), **kw))
+    outs = []
+    for tiles in (1, 0):
+        sv.set_option(d_tgt, "census_tiles", tiles)
+        try:
+            outs.append(sv.censusShardFinish(d_tgt, d_src, keys, r, r, D, refineKernel=so.GAUSSIAN, refine_h_radius=r, refine_v_radius=r, **kw))
+        finally:
+            sv.set_option(d_tgt, "census_tiles", 1)
+    for o in outs:
+        assert torch.equal(o["disp"], single["disp"])
+        ra, rb = o["refined"].cpu().numpy(), single["refined"].cpu().numpy()
+        assert np.array_equal(np.isnan(ra), np.isnan(rb))
+        ok = ~np.isnan(ra)
+        assert np.array_equal(ra[ok].view(np.uint32), rb[ok].view(np.uint32))

@@ -1489,7 +1489,7 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
     const int n_pass = textbook ? (a.n_dir >= 8 ? 8 : 4) : (a.n_dir >= 8 ? 6 : 2);
     const int pass0 = textbook ? 6 : 0;
     const bool neg = textbook && a.strategy == SVH_COST;
-    constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
+    constexpr int B = (R <= 4) ? 4 : (R <= 8 ? 2 : 1);
     const bool vec = aligned16(cv) && aligned16(sgm) && a.D % 4 == 0;
     const bool whole = a.top == 0 && a.left == 0 && a.bottom == 0 && a.right == 0;
     const bool far_global = a.P2 >= a.P1 && a.P1 >= 0.0f; // also false for NaN penalties
@@ -1540,7 +1540,7 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
 template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta, const ScoreFinish *finish) {
     // pixels per register batch (two batches: one in flight, one being walked).  Twice and four times as many measured the same at C4
     // (Left2Right + DownLeft2UpRight 5.57 / 5.57 / 5.60 ms): the passes are not waiting for their loads
-    constexpr int B = (R <= 4) ? 4 : (R == 8 ? 2 : 1);
+    constexpr int B = (R <= 4) ? 4 : (R <= 8 ? 2 : 1);
     const bool vec = aligned16(cv) && aligned16(sgm) && a.D % 4 == 0;
     LineSet ls{pass, pass_lines(pass, a.H, a.W), 0, 0, a.H, a.W};
     if (ls.n_lines <= 0) return SVH_OK;
@@ -1568,10 +1568,14 @@ template <int R> static int score_line_pass(svh_context *ctx, const SgmArgs &a, 
 }
 
 int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv, float *sgm, int pass, bool delta, const ScoreFinish *finish) {
-    switch (pick_R(a.D)) {
+    switch (pick_R_score(a.D)) {
     case 1: return score_line_pass<1>(ctx, a, cv, sgm, pass, delta, finish);
     case 2: return score_line_pass<2>(ctx, a, cv, sgm, pass, delta, finish);
+    case 3: return score_line_pass<3>(ctx, a, cv, sgm, pass, delta, finish);
     case 4: return score_line_pass<4>(ctx, a, cv, sgm, pass, delta, finish);
+    case 5: return score_line_pass<5>(ctx, a, cv, sgm, pass, delta, finish);
+    case 6: return score_line_pass<6>(ctx, a, cv, sgm, pass, delta, finish);
+    case 7: return score_line_pass<7>(ctx, a, cv, sgm, pass, delta, finish);
     case 8: return score_line_pass<8>(ctx, a, cv, sgm, pass, delta, finish);
     case 16: return score_line_pass<16>(ctx, a, cv, sgm, pass, delta, finish);
     default: return score_line_pass<32>(ctx, a, cv, sgm, pass, delta, finish);
@@ -1581,10 +1585,14 @@ int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv,
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish) {
     if (finish) finish->done = false;
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
-    switch (pick_R(a.D)) {
+    switch (pick_R_score(a.D)) {
     case 1: return run_score_branch<1>(ctx, scr, a, cv, out_sgm, textbook, finish);
     case 2: return run_score_branch<2>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 3: return run_score_branch<3>(ctx, scr, a, cv, out_sgm, textbook, finish);
     case 4: return run_score_branch<4>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 5: return run_score_branch<5>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 6: return run_score_branch<6>(ctx, scr, a, cv, out_sgm, textbook, finish);
+    case 7: return run_score_branch<7>(ctx, scr, a, cv, out_sgm, textbook, finish);
     case 8: return run_score_branch<8>(ctx, scr, a, cv, out_sgm, textbook, finish);
     case 16: return run_score_branch<16>(ctx, scr, a, cv, out_sgm, textbook, finish);
     case 32: return run_score_branch<32>(ctx, scr, a, cv, out_sgm, textbook, finish); // (up to 2048 disparities: 32 per lane)

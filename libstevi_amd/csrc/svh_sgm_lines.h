@@ -141,7 +141,15 @@ __device__ __forceinline__ float wave_prefix_max(float v) {
 }
 __device__ __forceinline__ float wave_max_dpp(float v) { return wave_extremum_dpp<false>(v); }
 
-// R consecutive floats of a lane as 16 / 8 / 4-byte accesses (any address space)
+// R consecutive floats of a lane as 16 / 8 / 4-byte accesses (any address space).  R = 3, 5, 6, 7 (192, 320, 384, 448 disparities: a lane's
+// run starts at a multiple of 4 R bytes, not of 16): pieces of four / two floats that claim only the 4-byte alignment every float has --
+// global memory takes a dwordx4 at any dword (as the cost kernels' CostPiece4 stores), LDS accesses are split as the alignment demands.
+struct __attribute__((packed, aligned(4))) LanePiece4 {
+    float x, y, z, w;
+};
+struct __attribute__((packed, aligned(4))) LanePiece2 {
+    float x, y;
+};
 template <int R> __device__ __forceinline__ void lds_get(const float *p, float (&v)[R]) {
     if constexpr (R % 4 == 0) {
 #pragma unroll
@@ -153,8 +161,17 @@ template <int R> __device__ __forceinline__ void lds_get(const float *p, float (
         const float2 x = *reinterpret_cast<const float2 *>(p);
         v[0] = x.x; v[1] = x.y;
     } else {
+        constexpr int R4 = R / 4 * 4;
 #pragma unroll
-        for (int k = 0; k < R; k++) v[k] = p[k];
+        for (int q = 0; q < R4; q += 4) {
+            const LanePiece4 x = *reinterpret_cast<const LanePiece4 *>(p + q);
+            v[q] = x.x; v[q + 1] = x.y; v[q + 2] = x.z; v[q + 3] = x.w;
+        }
+        if constexpr (R - R4 >= 2) {
+            const LanePiece2 x = *reinterpret_cast<const LanePiece2 *>(p + R4);
+            v[R4] = x.x; v[R4 + 1] = x.y;
+        }
+        if constexpr ((R - R4) & 1) v[R - 1] = p[R - 1];
     }
 }
 template <int R> __device__ __forceinline__ void lds_put(float *p, const float (&v)[R]) {
@@ -164,8 +181,11 @@ template <int R> __device__ __forceinline__ void lds_put(float *p, const float (
     } else if constexpr (R == 2) {
         *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
     } else {
+        constexpr int R4 = R / 4 * 4;
 #pragma unroll
-        for (int k = 0; k < R; k++) p[k] = v[k];
+        for (int q = 0; q < R4; q += 4) *reinterpret_cast<LanePiece4 *>(p + q) = LanePiece4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+        if constexpr (R - R4 >= 2) *reinterpret_cast<LanePiece2 *>(p + R4) = LanePiece2{v[R4], v[R4 + 1]};
+        if constexpr ((R - R4) & 1) p[R - 1] = v[R - 1];
     }
 }
 
@@ -345,6 +365,9 @@ inline int pick_R(int D) {
     while (64 * R < D) R <<= 1;
     return R;
 }
+// Score branch: every count up to eight per lane (192, 320, 384, 448 disparities run the vector forms at full width instead of the masked
+// forms of the next power of two: the reference's own benchmark rows use 160 and 320); powers of two beyond
+inline int pick_R_score(int D) { return D <= 512 ? (D + 63) / 64 : pick_R(D); }
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 

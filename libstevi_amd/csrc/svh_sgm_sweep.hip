@@ -326,10 +326,14 @@ int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
         if (form != 3 && ceil_div(a.W, 16) * 4 < cus * 3) return run_score_branch_bands<R, 8, 8>(ctx, scr, a, cv, sgm, vec, ran, finish);
         return run_score_branch_bands<R, 16, 16>(ctx, scr, a, cv, sgm, vec, ran, finish);
     };
-    switch (pick_R(a.D)) {
+    switch (pick_R_score(a.D)) {
     case 1: return run(std::integral_constant<int, 1>{});
     case 2: return run(std::integral_constant<int, 2>{});
+    case 3: return run(std::integral_constant<int, 3>{});
     case 4: return run(std::integral_constant<int, 4>{});
+    case 5: return run(std::integral_constant<int, 5>{});
+    case 6: return run(std::integral_constant<int, 6>{});
+    case 7: return run(std::integral_constant<int, 7>{});
     case 8: return run(std::integral_constant<int, 8>{});
     default: return SVH_OK; // more than 512 disparities: a launch per pass
     }

@@ -170,7 +170,7 @@ SGM_PARAMS = [(0.001, 0.01, 100.0), (2.0, 7.0, 3.0), (5.0, 1.0, 0.5), (0.0, 0.0,
 
 
 @pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
-@pytest.mark.parametrize("D", [1, 5, 64, 70, 130, 256, 300])
+@pytest.mark.parametrize("D", [1, 5, 64, 70, 130, 160, 192, 256, 300, 320, 384, 430, 448])
 def test_sgm_bit_exact(rng, strategy, D):
     H, W = 9, 12
     for integer in (True, False):

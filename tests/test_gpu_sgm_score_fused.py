@@ -41,7 +41,9 @@ def both_forms(cv, P1, P2, Pout, form):
 # shapes that put several strips of 16 skewed columns side by side, wider than tall and taller than wide, one row, one column;
 # disparity counts on each lane layout (1, 2, 4, 8 per lane), multiples of four or not
 @pytest.mark.parametrize("shape", [(37, 90, 40), (90, 37, 40), (64, 64, 17), (50, 70, 100), (33, 47, 256), (20, 35, 300), (1, 50, 8), (50, 1, 8),
-                                   (130, 16, 5), (16, 130, 64)])
+                                   (130, 16, 5), (16, 130, 64),
+                                   # 3, 5, 6, 7 disparities per lane: whole lanes (192, 320, 384, 448) and the masked forms (160, 330, 400)
+                                   (21, 40, 192), (18, 33, 320), (17, 20, 384), (19, 18, 448), (23, 37, 160), (12, 35, 330), (9, 21, 400)])
 @pytest.mark.parametrize("form", FORMS)
 def test_fused_equals_per_pass_and_oracle(rng, shape, form):
     cv = rng.uniform(-1, 1, shape).astype(np.float32)
@@ -110,7 +112,7 @@ def test_fused_forms_on_random_geometries(seed):
 
 # ---- the winner riding on the last writer of each pixel (svh_stereo_match, option "sgm_score_finish_fused") -------------------------------
 @pytest.mark.parametrize("shape_d", [((40, 150), 64), ((150, 40), 64), ((33, 200), 128), ((70, 90), 256), ((9, 300), 64), ((64, 64), 64), ((1, 80), 64),
-                                     ((45, 97), 40)])
+                                     ((45, 97), 40), ((30, 260), 192), ((40, 400), 320), ((25, 470), 448), ((33, 300), 160)])
 @pytest.mark.parametrize("func_name", ["NCC", "ZNCC", "CC"])
 def test_winner_emitted_by_the_last_writer(rng, shape_d, func_name):
     """svh_stereo_match with a Score-strategy function + SGM-8: the index, the disparity and the three truncatedCostVolume<Same> taps of a

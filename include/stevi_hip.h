@@ -111,6 +111,10 @@ const char *svh_last_error(const svh_context *ctx);
  * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
  * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
  * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
+ * "sgm_score_pad" (default 1): svh_sgm_cost_volume / svh_stereo_match, Score strategy, on 65 .. 511 disparities that are no multiple of 64
+ * (the reference's own benchmark uses 160) aggregate a copy of the volume whose rows are padded to the next multiple of 64 with -inf
+ * -- a pad never enters a maximum, and cost + anything stays -inf along every line -- so that the vector kernels, the banded sweep and
+ * the winner records apply; the result is copied back without the pads.  0: the masked kernels on the caller's layout.  Same bits.
  * "fold_2d_offsets" (default 1): svh_unfold_cost_volume_2d on grey images with a function the column-sum kernel takes stages the
  * v + Dh - 1 target rows of all vertical offsets once per block and walks the (dh, dw) blocks in one launch (as many offsets as the
  * tile holds); 0 = one launch per vertical offset.  Same bits (tests/test_gpu_2d.py).

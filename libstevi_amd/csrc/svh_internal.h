@@ -53,6 +53,7 @@ struct svh_context {
     bool census_tiles = true;          // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
     bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
     bool fold_2d_offsets = true;       // svh_context_set_option("fold_2d_offsets"): 2-D disparity volumes of grey images take as many vertical offsets per launch of the column-sum kernel as its tile holds (0: a launch per vertical offset)
+    bool sgm_score_pad = true;         // svh_context_set_option("sgm_score_pad"): Score-branch SGM on 65 .. 511 disparities that are no multiple of 64 runs on copies padded to the next multiple (pads -inf: inert), so that the vector kernels apply (0: the masked forms)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     bool cost_reduce_fused = true;     // svh_context_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
     bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
@@ -339,6 +340,7 @@ struct ScoreFinish {
     int taps_h_r = 0, taps_v_r = 0;
     bool store_all = true;
     bool done = false;
+    int d_valid = 0; // > 0: the rows are padded to a whole number of lanes and only the first d_valid costs exist (dev_sgm_score_branch)
 };
 // records -> index / disparity / refined maps (any of them may be null; refine_kernel < 0: no refinement)
 int dev_finish_records(svh_context *ctx, const float *records, int64_t npx, int refine_kernel, int disp_sign, int disp_offset, int32_t *idx,

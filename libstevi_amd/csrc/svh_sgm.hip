@@ -1154,7 +1154,7 @@ __global__ void __launch_bounds__(256) sgm_score_pass_kernel(const float *__rest
                     outv[k] = DELTA ? act[k] - c_in[k] : base + (act[k] - c_in[k]); // :298-300
                     prev[k] = act[k];
                 }
-                if constexpr (FIN) wave_emit_record<false, R>(outv, lane, ii, jj, ls.Hp, W, fin.records, fin.taps_h_r, fin.taps_v_r); // (whole image: ls.Hp = H)
+                if constexpr (FIN) wave_emit_record<false, R>(outv, lane, ii, jj, ls.Hp, W, fin.records, fin.taps_h_r, fin.taps_v_r, fin.d_valid > 0 ? fin.d_valid : 64 * R); // (whole image: ls.Hp = H)
                 if (!FIN || fin.store_all) lds_put<R>(sgm + ((int64_t)ii * W + jj) * D + lane * R, outv);
                 return;
             }
@@ -1517,6 +1517,18 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
             } else {
                 if (first) SVH_SCORE(true, false, true); else SVH_SCORE(false, false, true);
             }
+        } else if (far_global && vec && a.D == 64 * R && !textbook && n_pass == 2 && q == 1 && whole && finish && finish->records &&
+                   (int64_t)a.H * a.W < (1ll << 29)) {
+            // four directions: Left2Right is the last pass and visits every pixel of a whole-image aggregation -- the last writer of every
+            // pixel: it emits the winner records (and stores the volume only when somebody wants it)
+            const bool lean = a.costs_all_finite && std::isfinite(a.Pout);
+            if (lean)
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, false, true, true, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1,
+                           a.P2, a.Pout, vec, *finish);
+            else
+                SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, false, true, false, false, true, true, false>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1,
+                           a.P2, a.Pout, vec, *finish);
+            finish->done = true;
         } else if (far_global && vec && a.D == 64 * R) { // the usual case: exact prefetch form
             if (first)
                 SVH_LAUNCH(ctx, "sgm_score_pass", (sgm_score_pass_kernel<R, B, true, true, false, false, true>), grid, 256, 0, cv, sgm, ls, a.D, a.W, a.P1, a.P2,
@@ -1582,9 +1594,55 @@ int dev_sgm_score_line_pass(svh_context *ctx, const SgmArgs &a, const float *cv,
     }
 }
 
+// rows of `count` floats at a pitch of `in_pitch` -> rows at a pitch of `out_pitch` floats, what lies past `count` filled with `fill`.  A block
+// takes REPITCH_ROWS rows as one flat run of output elements: every store instruction of a wave is 256 contiguous bytes, every thread has
+// a dozen independent loads in flight (a wave per row had three, and ran at 0.7 TB/s).
+constexpr int REPITCH_ROWS = 16;
+__global__ void __launch_bounds__(256) repitch_rows_kernel(const float *__restrict__ in, int64_t n_rows, int in_pitch, int count, float *__restrict__ out,
+                                                          int out_pitch, float fill) {
+    const int64_t r0 = (int64_t)blockIdx.x * REPITCH_ROWS;
+    const int rows = (int)(n_rows - r0 < REPITCH_ROWS ? n_rows - r0 : REPITCH_ROWS), n = rows * out_pitch;
+    const float *src = in + r0 * in_pitch;
+    float *dst = out + r0 * out_pitch;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int r = e / out_pitch, d = e - r * out_pitch;
+        dst[e] = d < count ? src[r * in_pitch + d] : fill;
+    }
+}
+
+static int score_branch_dispatch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish);
+
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish) {
     if (finish) finish->done = false;
     if ((int64_t)a.H * a.W * a.D == 0) return SVH_OK;
+    // 65 .. 511 disparities, no multiple of 64 (the reference's own benchmark rows use 160): the vector kernels -- unconditional 16-byte
+    // accesses, the banded sweep, the winner records -- need rows of whole lanes.  Aggregate a copy padded to the next multiple of 64 with
+    // -inf instead: a pad never enters a maximum (the isfinite filters of sgm.h:224, :241; v_max ignores it in the filter-free forms), its
+    // own value stays cost + (a - max_p) = -inf along every line, and at a line's first pixel, where every previous score is 0, it only
+    // repeats values the real neighbours already contribute.  Two more streaming passes (pad in, copy out) for a 1.5 x faster aggregation.
+    const int DP = (a.D + 63) / 64 * 64;
+    if (!textbook && ctx->sgm_score_pad && a.D > 64 && a.D < 512 && DP != a.D) {
+        const int64_t npx = (int64_t)a.H * a.W;
+        float *cvp = scr.get_n<float>((size_t)npx * DP), *sgp = scr.get_n<float>((size_t)npx * DP);
+        if (!cvp || !sgp) return SVH_ERR_OUT_OF_MEMORY;
+        const int grid = (int)((npx + REPITCH_ROWS - 1) / REPITCH_ROWS);
+        SVH_LAUNCH(ctx, "sgm_pad_rows", repitch_rows_kernel, grid, 256, 0, cv, npx, a.D, a.D, cvp, DP, -INFINITY);
+        SVH_CHECK_LAUNCH(ctx);
+        SgmArgs ap = a;
+        ap.D = DP;
+        if (finish) finish->d_valid = a.D;
+        SVH_TRY(score_branch_dispatch(ctx, scr, ap, cvp, sgp, false, finish));
+        if (!finish || finish->store_all || !finish->done) { // somebody reads the aggregated volume
+            SVH_LAUNCH(ctx, "sgm_pad_rows", repitch_rows_kernel, grid, 256, 0, sgp, npx, DP, a.D, out_sgm, a.D, 0.0f);
+            SVH_CHECK_LAUNCH(ctx);
+        }
+        return SVH_OK;
+    }
+    return score_branch_dispatch(ctx, scr, a, cv, out_sgm, textbook, finish);
+}
+
+static int score_branch_dispatch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish) {
     switch (pick_R_score(a.D)) {
     case 1: return run_score_branch<1>(ctx, scr, a, cv, out_sgm, textbook, finish);
     case 2: return run_score_branch<2>(ctx, scr, a, cv, out_sgm, textbook, finish);

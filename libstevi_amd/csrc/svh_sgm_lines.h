@@ -239,8 +239,11 @@ __device__ __forceinline__ void score_step1_far_global(const float (&prev)[R], c
 // v_min return the other operand), a lane finds the largest k whose value EQUALS the extremum (a NaN equals nothing; +-inf do), the
 // highest such lane holds the winner, and every lane builds the record of ITS OWN candidate from its registers and its two
 // neighbours' edge values (two DPP moves): no cross-lane gather, almost no scalar state.  The record is stored by the winning lane.
+// Dv <= 64 R: rows padded to a whole number of lanes (dev_sgm_score_branch; Score: the pads hold -inf and stay -inf along every line):
+// only the first Dv values exist for the caller.
 template <bool COST, int R>
-__device__ __forceinline__ void wave_emit_record(const float (&s)[R], int lane, int i, int j, int H, int W, float *__restrict__ rec, int h_r, int v_r) {
+__device__ __forceinline__ void wave_emit_record(const float (&s)[R], int lane, int i, int j, int H, int W, float *__restrict__ rec, int h_r, int v_r,
+                                                 int Dv = 64 * R) {
     constexpr int D = 64 * R;
     float A = s[0];
 #pragma unroll
@@ -269,6 +272,11 @@ __device__ __forceinline__ void wave_emit_record(const float (&s)[R], int lane, 
     int kb = -1;
 #pragma unroll
     for (int k = 0; k < R; k++) kb = (s[k] == M) ? k : kb; // ties: the larger index (correlation_base.h:441-455)
+    if (Dv < D && M == (COST ? INFINITY : -INFINITY)) { // (wave uniform, no memory operation inside) a pad equals the extremum only when every real value is infinite or NaN
+        kb = -1;
+#pragma unroll
+        for (int k = 0; k < R; k++) kb = (s[k] == M && lane * R + k < Dv) ? k : kb;
+    }
     const unsigned long long holders = __builtin_amdgcn_ballot_w64(kb >= 0);
     const unsigned long long nan_at_0 = __builtin_amdgcn_ballot_w64(isnan(s[0])); // bit 0: the value at disparity 0
     const bool none = holders == 0ull || (nan_at_0 & 1ull);                         // -> index 0
@@ -292,7 +300,7 @@ __device__ __forceinline__ void wave_emit_record(const float (&s)[R], int lane, 
     float4 r;
     r.x = (d == 0 || d - 1 >= limit) ? nan : tm1;
     r.y = (d >= limit) ? nan : t0;
-    r.z = (d + 1 >= D || d + 1 >= limit) ? nan : tp1;
+    r.z = (d + 1 >= Dv || d + 1 >= limit) ? nan : tp1;
     r.w = __int_as_float(d);
     if (lane == writer) *reinterpret_cast<float4 *>(rec + (unsigned)(i * W + j) * 4u) = r;
 }

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(NCW * 64) sgm_score_band_kernel(const float *_
                 }
                 float *o = sgm + (int64_t)i * W * D + own_off[q]; // (own_off: the cell's column, see load_row)
                 if constexpr (FIN) {
-                    wave_emit_record<false, R>(outv, lane, i, j, H, W, fin.records, fin.taps_h_r, fin.taps_v_r);
+                    wave_emit_record<false, R>(outv, lane, i, j, H, W, fin.records, fin.taps_h_r, fin.taps_v_r, fin.d_valid > 0 ? fin.d_valid : 64 * R);
                     if (fin.store_all || i + j < H) lds_put<R>(o, outv); // (wave-uniform) DownLeft2UpRight visits i + j < H
                 } else if constexpr (VEC) lds_put<R>(o, outv);
                 else {

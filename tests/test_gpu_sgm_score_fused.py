@@ -147,7 +147,7 @@ def test_winner_emitted_by_the_last_writer(rng, shape_d, func_name):
             a, ka = run(1, kernel, want_sgm_cv)
             b, kb = run(0, kernel, want_sgm_cv)
             assert "extract_index" in kb
-            if D % 64 == 0 and H * W > 0:
+            if (D % 64 == 0 or 64 < D < 512) and H * W > 0:  # (rows padded to whole lanes take the records route too)
                 assert "extract_index" not in ka and "truncated_cost_volume" not in ka and "index_to_disp" not in ka, ka.keys()
             assert torch.equal(a["disp"], b["disp"])
             if kernel is not None:
@@ -247,3 +247,80 @@ def test_all_finite_regime_drops_the_filters_and_nothing_else(func_name, flat_pa
         m = (ii + jj < rows) | (ii + jj >= H)
         x, y = sa[:rows][m], ob[m]
         assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(y)].view(np.uint32), y[~np.isnan(y)].view(np.uint32))
+
+
+@pytest.mark.parametrize("D", [70, 100, 160, 330, 500, 511])
+def test_rows_padded_to_whole_lanes_equal_the_masked_forms(rng, D):
+    """Option "sgm_score_pad" (default): Score-branch SGM on a disparity count that is no multiple of 64 aggregates a copy whose rows are
+    padded with -inf to the next multiple, so that the vector kernels, the banded sweep and the winner records apply.  Same bits as the
+    masked kernels on the caller's layout and as the oracle: whole image, margins, four directions, P1 > P2, non-finite costs, pixels
+    whose every cost is -inf or NaN (where a pad equals the extremum), and the winner that travels with the volume."""
+    H, W = 21, 37
+    cv = rng.uniform(-1, 1, (H, W, D)).astype(np.float32)
+    cv[3, 4, :] = -np.inf          # every real value equals the pads
+    cv[5, 6, :] = np.nan           # nothing equals anything: index 0
+    cv[7, 8, 1:] = -np.inf         # NaN at index 0 beside infinities
+    cv[7, 8, 0] = np.nan
+    cv[9, 10, D - 1] = np.inf      # the last real disparity wins: its right tap does not exist
+    cv[11, 12, 5] = np.nan
+    cv[2, 30, :D // 2] = -np.inf
+    d = torch.from_numpy(cv).to(DEV)
+    for n_dir, margins, (P1, P2, Pout) in [(8, None, (0.001, 0.01, 100.0)), (8, sv.Margins(1, 2, 3, 1), (0.3, 0.9, 3.0)), (4, None, (0.2, 0.7, 0.5)),
+                                           (8, None, (0.9, 0.3, 1.0))]:
+        m = (0, 0, 0, 0) if margins is None else (1, 2, 3, 1)
+        exp = so.sgm(cv, n_dir, so.SCORE, P1, P2, m, Pout)
+        outs = []
+        for pad in (1, 0):
+            sv.set_option(d, "sgm_score_pad", pad)
+            try:
+                vol = sv.sgmCostVolume(n_dir, so.SCORE, d, P1, P2, margins, Pout, keep_winner=True)
+                idx = sv.extractSelectedIndex(so.SCORE, vol)
+            finally:
+                sv.set_option(d, "sgm_score_pad", 1)
+            outs.append((vol.cpu().numpy(), idx.cpu().numpy()))
+        for vol, idx in outs:
+            assert np.array_equal(np.isnan(vol), np.isnan(exp))
+            ok = ~np.isnan(exp)
+            assert np.array_equal(vol[ok].view(np.uint32), exp[ok].view(np.uint32)), (D, n_dir, P1)
+            assert np.array_equal(idx, so.extract_index(exp, so.SCORE)), (D, n_dir, P1)
+
+
+@pytest.mark.parametrize("shape_d", [((40, 150), 64), ((33, 200), 128), ((30, 260), 192), ((25, 300), 160), ((1, 80), 64), ((50, 1), 64)])
+@pytest.mark.parametrize("func_name", ["NCC", "ZNCC"])
+def test_winner_emitted_by_left2right_with_four_directions(rng, shape_d, func_name):
+    """Four directions (sgm.h:379-383: Up2Down, Left2Right): the second pass visits every pixel and is the last writer of each, so it emits
+    the winner records; the volume is stored only on request.  Equal to the separate extract_index / truncatedCostVolume kernels and to the
+    oracle on the library's own cost volume."""
+    from helpers import parallax_pair
+    (H, W), D = shape_d
+    func = getattr(sv.matchingFunctions, func_name)
+    src, tgt, _ = parallax_pair(H, W, max(2, min(H, W) // 4), H // 4, W // 4, 2, 9, seed=H * 1000 + W + D)
+    l, r = torch.from_numpy(tgt[:H, :W].copy()).to(DEV), torch.from_numpy(src[:H, :W].copy()).to(DEV)
+    hr = 2
+
+    def run(fused, kernel, want_sgm_cv):
+        sv.set_option(l, "sgm_score_finish_fused", fused)
+        try:
+            sv.profile_reset(l)
+            sv.profile_enable(l, True)
+            out = sv.stereoMatch(func, l, r, hr, hr, D, sgmDirections=4, P1=0.001, P2=0.01, Pout=100.0, refineKernel=kernel, refine_h_radius=hr,
+                                 refine_v_radius=hr, want_sgm_cv=want_sgm_cv, want_cv=True)
+            sv.profile_enable(l, False)
+            return out, sv.profile_collect(l)
+        finally:
+            sv.set_option(l, "sgm_score_finish_fused", 1)
+
+    for kernel in (sv.InterpolationKernel.Parabola, None):
+        for want_sgm_cv in (False, True):
+            a, ka = run(1, kernel, want_sgm_cv)
+            b, kb = run(0, kernel, want_sgm_cv)
+            assert "extract_index" in kb and "extract_index" not in ka and "finish_records" in ka, (ka.keys(), kb.keys())
+            assert torch.equal(a["disp"], b["disp"])
+            if kernel is not None:
+                ra, rb = a["refined"].cpu().numpy(), b["refined"].cpu().numpy()
+                assert np.array_equal(np.isnan(ra), np.isnan(rb))
+                assert np.array_equal(bits(ra[~np.isnan(ra)]), bits(rb[~np.isnan(rb)]))
+            if want_sgm_cv:
+                assert np.array_equal(bits(a["sgm_cv"]), bits(b["sgm_cv"]))
+    svol = so.sgm(a["cv"].cpu().numpy(), 4, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    assert np.array_equal(a["disp"].cpu().numpy(), so.index_to_disp(so.extract_index(svol, so.SCORE)))

@@ -111,6 +111,10 @@ const char *svh_last_error(const svh_context *ctx);
  * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
  * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
  * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
+ * "guided_shared" (default 1): svh_compute_guided_cv / svh_hierarchical_truncated_cost_volume on grey images with a search radius of at most
+ * 3: a block of 256 pixels stages the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of
+ * the target windows its pixels look at in LDS once, instead of every pixel processing every sample of every offset again; 0: the
+ * per-pixel walk.  Same bits (tests/test_gpu_hierarchical.py).
  * "sgm_score_pad" (default 1): svh_sgm_cost_volume / svh_stereo_match, Score strategy, on 65 .. 511 disparities that are no multiple of 64
  * (the reference's own benchmark uses 160) aggregate a copy of the volume whose rows are padded to the next multiple of 64 with -inf
  * -- a pad never enters a maximum, and cost + anything stays -inf along every line -- so that the vector kernels, the banded sweep and

@@ -419,6 +419,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->cost_volume_colsum = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "guided_shared") == 0) {
+        ctx->guided_shared = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "sgm_score_pad") == 0) {
         ctx->sgm_score_pad = value != 0;
         return SVH_OK;

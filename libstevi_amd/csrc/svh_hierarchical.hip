@@ -12,6 +12,7 @@
 // words and larger radii take two: a lane per pixel picks d_r (`guided_select`), then a lane per (pixel, dd) fills the volume
 // (`guided_volume`).  All of them accumulate the terms of the literal comparison of svh_compare.h in the same order, so equal
 // inputs give bit-equal costs and the strict '<' / '>' winner rule sees exactly the values the volume holds.
+#include <climits>
 #include <type_traits>
 
 #include "svh_compare.h"
@@ -151,83 +152,253 @@ __global__ void guided_volume_words_kernel(WordVolume src, WordVolume tgt, int H
 // the winner is searched over the middle 2R + 1 (strict comparison in increasing offset, as the reference does), and the
 // re-centred volume d_r - R .. d_r + R always lies inside the evaluated span.  The per-offset sums see exactly the terms, in
 // exactly the order, of compare_features, so the result equals the two-pass form bit for bit.
+// one pixel of the one-pass form, everything from global memory (the per-lane walk; also what a block of guided_shared_kernel falls back
+// to when its pixels' guides point too far apart for the staged target features)
 template <int CMP, bool ZM, bool NORM, int R>
-__global__ void __launch_bounds__(256) guided_fused_kernel(FeatImage src, FeatImage tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
-                                                           const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
-                                                           GuideArgs g, int32_t *__restrict__ disp, float *__restrict__ tcv) {
+__device__ __forceinline__ void guided_fused_px(const FeatImage &src, const FeatImage &tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
+                                                const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt, const GuideArgs &g,
+                                                int32_t *__restrict__ disp, float *__restrict__ tcv, int64_t p, int i, int j, int d0) {
     constexpr int NC = 4 * R + 1, T = 2 * R + 1;
-    const int64_t npx = (int64_t)H * Ws;
     const int C = src.C, h = 2 * src.h_r + 1, v = 2 * src.v_r + 1;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)(p % Ws), i = (int)(p / Ws);
-        const int d0 = guided_base_disp(g.guide, g.Hg, g.Wg, H, Ws, i, j, g.dirSign);
-        const float ms = ZM ? mean_s[p] : 0.0f, ns = NORM ? norm_s[p] : 1.0f;
-        float mt[NC], nt[NC], acc[NC];
-        bool tin[NC];
+    const float ms = ZM ? mean_s[p] : 0.0f, ns = NORM ? norm_s[p] : 1.0f;
+    float mt[NC], nt[NC], acc[NC];
+    bool tin[NC];
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const int jt = j + d0 + c - 2 * R;
-            tin[c] = jt >= 0 && jt < Wt;
-            const int64_t pt = (int64_t)i * Wt + (tin[c] ? jt : 0);
-            mt[c] = (ZM && tin[c]) ? mean_t[pt] : 0.0f;
-            nt[c] = (NORM && tin[c]) ? norm_t[pt] : 1.0f;
-            acc[c] = 0.0f;
-        }
-        for (int k = 0; k < v; k++) {
-            const int ii = i - src.v_r + k;
-            const bool row_in = ii >= 0 && ii < H;
-            for (int l = 0; l < h; l++) {
-                const int jj = j - src.h_r + l;
-                for (int ch = 0; ch < C; ch++) {
-                    float s = (row_in && jj >= 0 && jj < Ws) ? src.img[((int64_t)ii * Ws + jj) * C + ch] : 0.0f;
-                    if (ZM) s = s - ms;
-                    if (NORM) s = s / ns;
+    for (int c = 0; c < NC; c++) {
+        const int jt = j + d0 + c - 2 * R;
+        tin[c] = jt >= 0 && jt < Wt;
+        const int64_t pt = (int64_t)i * Wt + (tin[c] ? jt : 0);
+        mt[c] = (ZM && tin[c]) ? mean_t[pt] : 0.0f;
+        nt[c] = (NORM && tin[c]) ? norm_t[pt] : 1.0f;
+        acc[c] = 0.0f;
+    }
+    for (int k = 0; k < v; k++) {
+        const int ii = i - src.v_r + k;
+        const bool row_in = ii >= 0 && ii < H;
+        for (int l = 0; l < h; l++) {
+            const int jj = j - src.h_r + l;
+            for (int ch = 0; ch < C; ch++) {
+                float s = (row_in && jj >= 0 && jj < Ws) ? src.img[((int64_t)ii * Ws + jj) * C + ch] : 0.0f;
+                if (ZM) s = s - ms;
+                if (NORM) s = s / ns;
 #pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const int jc = jj + d0 + c - 2 * R;
-                        float t = 0.0f;
-                        if (tin[c]) {
-                            t = (row_in && jc >= 0 && jc < Wt) ? tgt.img[((int64_t)ii * Wt + jc) * C + ch] : 0.0f;
-                            if (ZM) t = t - mt[c];
-                            if (NORM) t = t / nt[c];
-                        }
-                        if (CMP == CMP_DOT) {
-                            acc[c] += s * t;
-                        } else if (CMP == CMP_SSD) {
-                            const float tmp = s - t;
-                            acc[c] += tmp * tmp;
-                        } else {
-                            acc[c] += fabsf(s - t);
-                        }
+                for (int c = 0; c < NC; c++) {
+                    const int jc = jj + d0 + c - 2 * R;
+                    float t = 0.0f;
+                    if (tin[c]) {
+                        t = (row_in && jc >= 0 && jc < Wt) ? tgt.img[((int64_t)ii * Wt + jc) * C + ch] : 0.0f;
+                        if (ZM) t = t - mt[c];
+                        if (NORM) t = t / nt[c];
+                    }
+                    if (CMP == CMP_DOT) {
+                        acc[c] += s * t;
+                    } else if (CMP == CMP_SSD) {
+                        const float tmp = s - t;
+                        acc[c] += tmp * tmp;
+                    } else {
+                        acc[c] += fabsf(s - t);
                     }
                 }
             }
         }
-        float score = g.cost ? INFINITY : -INFINITY;
-        int best = 0; // offset of the winner relative to d0
+    }
+    float score = g.cost ? INFINITY : -INFINITY;
+    int best = 0; // offset of the winner relative to d0
 #pragma unroll
-        for (int c = R; c <= 3 * R; c++) {
-            if (g.cost ? (acc[c] < score) : (acc[c] > score)) {
-                score = acc[c];
-                best = c - 2 * R;
+    for (int c = R; c <= 3 * R; c++) {
+        if (g.cost ? (acc[c] < score) : (acc[c] > score)) {
+            score = acc[c];
+            best = c - 2 * R;
+        }
+    }
+    disp[p] = g.dirSign * (d0 + best);
+#pragma unroll
+    for (int dd = 0; dd < T; dd++) {
+        const int want = best + g.dirSign * (dd - R) + 2 * R;
+        float val = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (c == want) val = acc[c];
+        tcv[p * T + dd] = val;
+    }
+}
+
+template <int CMP, bool ZM, bool NORM, int R>
+__global__ void __launch_bounds__(256) guided_fused_kernel(FeatImage src, FeatImage tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
+                                                           const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
+                                                           GuideArgs g, int32_t *__restrict__ disp, float *__restrict__ tcv) {
+    const int64_t npx = (int64_t)H * Ws;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(p % Ws), i = (int)(p / Ws);
+        const int d0 = guided_base_disp(g.guide, g.Hg, g.Wg, H, Ws, i, j, g.dirSign);
+        guided_fused_px<CMP, ZM, NORM, R>(src, tgt, mean_s, norm_s, mean_t, norm_t, H, Ws, Wt, g, disp, tcv, p, i, j, d0);
+    }
+}
+
+// The same for grey images with the processed target features SHARED by a block (round 4f).  The per-lane walk divides every target sample by
+// its window's norm once per (pixel, offset) -- 4R + 1 times more often than the samples exist, and the true division the reference's
+// normalised features ask for (cross_correlations.h:540) is ten instructions -- and waits for a global load per window sample: 0.82 of the
+// 1.27 ms of the reference's own 1080p benchmark row.  A block owns 256 consecutive pixels of a row; the target windows its pixels look at
+// are centred in one span of columns (the guide is smooth nearly everywhere).  The raw window rows of both images are staged in LDS once;
+// then, window row by window row, every centre of the span has its 2 h_r + 1 samples processed ONCE (mean subtracted, divided by the norm)
+// into a double-buffered strip, and a lane's 4R + 1 sums read them from there.  Same operations on the same operands in the same order
+// as the per-lane walk: same bits.  A block whose guides spread wider than the staged span takes the per-lane walk.
+// (First form: all F processed samples of a centre staged at once, 60 KB per block, samples straight from global memory: two blocks per CU
+// waiting on a load per sample -- 0.93 ms, slower than the walk it replaced.)
+template <int CMP, bool ZM, bool NORM, int R, int HR>
+__global__ void __launch_bounds__(256) guided_shared_kernel(FeatImage src, FeatImage tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
+                                                            const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
+                                                            GuideArgs g, int32_t *__restrict__ disp, float *__restrict__ tcv, int span_max) {
+    constexpr int NC = 4 * R + 1, T = 2 * R + 1, h = 2 * HR + 1, SW = 256 + h - 1;
+    extern __shared__ float lds[];
+    __shared__ int red_lo[4], red_hi[4];
+    const int i = blockIdx.y, j0 = blockIdx.x * 256, j = j0 + threadIdx.x;
+    const int v = 2 * src.v_r + 1, TW = span_max + h - 1;
+    float *stile = lds, *ttile = stile + v * SW, *feat = ttile + v * TW; // raw rows of both images; processed strip, two buffers of span_max x h
+    const bool px = j < Ws;
+    const int64_t p = (int64_t)i * Ws + (px ? j : Ws - 1);
+    const int d0 = px ? guided_base_disp(g.guide, g.Hg, g.Wg, H, Ws, i, j, g.dirSign) : 0;
+    // the span of target centres the block's pixels look at: [lo, hi]
+    int lo = px ? j + d0 - 2 * R : INT_MAX, hi = px ? j + d0 + 2 * R : INT_MIN;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red_lo[threadIdx.x >> 6] = lo;
+        red_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = min(min(red_lo[0], red_lo[1]), min(red_lo[2], red_lo[3]));
+    hi = max(max(red_hi[0], red_hi[1]), max(red_hi[2], red_hi[3]));
+    const int64_t span64 = (int64_t)hi - lo + 1;
+    if (span64 > span_max) { // (block uniform)
+        if (px) guided_fused_px<CMP, ZM, NORM, R>(src, tgt, mean_s, norm_s, mean_t, norm_t, H, Ws, Wt, g, disp, tcv, p, i, j, d0);
+        return;
+    }
+    const int span = (int)span64;
+    // raw rows: a sample outside its image is 0 (before it is processed)
+    for (int k = 0; k < v; k++) {
+        const int ii = i - src.v_r + k;
+        const bool row_in = ii >= 0 && ii < H;
+        for (int x = threadIdx.x; x < SW; x += 256) {
+            const int jj = j0 - HR + x;
+            stile[k * SW + x] = (row_in && jj >= 0 && jj < Ws) ? src.img[(int64_t)ii * Ws + jj] : 0.0f;
+        }
+        for (int x = threadIdx.x; x < span + h - 1; x += 256) {
+            const int jc = lo - HR + x;
+            ttile[k * TW + x] = (row_in && jc >= 0 && jc < Wt) ? tgt.img[(int64_t)ii * Wt + jc] : 0.0f;
+        }
+    }
+    // the centres this thread processes (span_max <= 512): a centre outside the image is the all-zero vector (hierarchical.h:175-178)
+    float mt[2], nt[2];
+    bool tin[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int jt = lo + threadIdx.x + 256 * u;
+        tin[u] = (int)threadIdx.x + 256 * u < span && jt >= 0 && jt < Wt;
+        const int64_t pt = (int64_t)i * Wt + (tin[u] ? jt : 0);
+        mt[u] = (ZM && tin[u]) ? mean_t[pt] : 0.0f;
+        nt[u] = (NORM && tin[u]) ? norm_t[pt] : 1.0f;
+    }
+    const float ms = ZM ? mean_s[p] : 0.0f, ns = NORM ? norm_s[p] : 1.0f;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = 0.0f;
+    const int qb = px ? j + d0 - 2 * R - lo : 0; // this pixel's first centre in the span
+    __syncthreads();
+    for (int k = 0; k < v; k++) {
+        float *buf = feat + (k & 1) * span_max * h;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int q = threadIdx.x + 256 * u;
+            if (q < span) {
+#pragma unroll
+                for (int l = 0; l < h; l++) {
+                    float t = 0.0f;
+                    if (tin[u]) {
+                        t = ttile[k * TW + q + l];
+                        if (ZM) t = t - mt[u];
+                        if (NORM) t = t / nt[u];
+                    }
+                    buf[q * h + l] = t;
+                }
             }
         }
-        disp[p] = g.dirSign * (d0 + best);
+        __syncthreads(); // (the strip of row k is complete; the other buffer was last read before the previous barrier)
 #pragma unroll
-        for (int dd = 0; dd < T; dd++) {
-            const int want = best + g.dirSign * (dd - R) + 2 * R;
-            float val = 0.0f;
+        for (int l = 0; l < h; l++) {
+            float s = stile[k * SW + threadIdx.x + l];
+            if (ZM) s = s - ms;
+            if (NORM) s = s / ns;
 #pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (c == want) val = acc[c];
-            tcv[p * T + dd] = val;
+            for (int c = 0; c < NC; c++) {
+                const float t = buf[(qb + c) * h + l];
+                if (CMP == CMP_DOT) {
+                    acc[c] += s * t;
+                } else if (CMP == CMP_SSD) {
+                    const float tmp = s - t;
+                    acc[c] += tmp * tmp;
+                } else {
+                    acc[c] += fabsf(s - t);
+                }
+            }
         }
+    }
+    if (!px) return;
+    float score = g.cost ? INFINITY : -INFINITY;
+    int best = 0;
+#pragma unroll
+    for (int c = R; c <= 3 * R; c++) {
+        if (g.cost ? (acc[c] < score) : (acc[c] > score)) {
+            score = acc[c];
+            best = c - 2 * R;
+        }
+    }
+    disp[p] = g.dirSign * (d0 + best);
+#pragma unroll
+    for (int dd = 0; dd < T; dd++) {
+        const int want = best + g.dirSign * (dd - R) + 2 * R;
+        float val = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+            if (c == want) val = acc[c];
+        tcv[p * T + dd] = val;
+    }
+}
+
+template <int CMP, bool ZM, bool NORM, int HR>
+bool launch_guided_shared(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws,
+                          int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
+    // the staged span: a block's 256 pixels + the offsets + room for the guide to move (at most 512 centres: two per thread)
+    constexpr int h = 2 * HR + 1, span_max = 384;
+    const int v = 2 * src.v_r + 1;
+    const size_t shmem = (size_t)(v * (256 + h - 1) + v * (span_max + h - 1) + 2 * span_max * h) * sizeof(float);
+    if (shmem > 60 * 1024) return false;
+    const dim3 grid(ceil_div(Ws, 256), H);
+    switch (g.radius) {
+    case 1: SVH_LAUNCH(ctx, "guided_fused", (guided_shared_kernel<CMP, ZM, NORM, 1, HR>), grid, 256, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv, span_max); return true;
+    case 2: SVH_LAUNCH(ctx, "guided_fused", (guided_shared_kernel<CMP, ZM, NORM, 2, HR>), grid, 256, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv, span_max); return true;
+    case 3: SVH_LAUNCH(ctx, "guided_fused", (guided_shared_kernel<CMP, ZM, NORM, 3, HR>), grid, 256, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv, span_max); return true;
+    default: return false;
     }
 }
 
 template <int CMP, bool ZM, bool NORM>
 bool launch_guided_fused(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws,
                          int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
+    // grey images, windows up to 7 wide: the processed target features shared by a block; otherwise every lane on its own
+    if (ctx->guided_shared && src.C == 1 && tgt.C == 1 && H <= 65535 && src.h_r == tgt.h_r && src.v_r == tgt.v_r) {
+        bool ran = false;
+        switch (src.h_r) {
+        case 1: ran = launch_guided_shared<CMP, ZM, NORM, 1>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); break;
+        case 2: ran = launch_guided_shared<CMP, ZM, NORM, 2>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); break;
+        case 3: ran = launch_guided_shared<CMP, ZM, NORM, 3>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); break;
+        default: break;
+        }
+        if (ran) return true;
+    }
     const int grid = grid_for((int64_t)H * Ws, 256, 16384);
     switch (g.radius) {
     case 1: SVH_LAUNCH(ctx, "guided_fused", (guided_fused_kernel<CMP, ZM, NORM, 1>), grid, 256, 0, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;

@@ -131,3 +131,26 @@ def test_reference_testMatchingFilter_on_gpu(depth):
     disp = host(res.disp_estimate)
     assert disp.shape == sc["source"].shape and tuple(res.truncated_cost_volume.shape) == sc["source"].shape + (5,)
     hierarchical_acceptance(sc, depth, disp, host(rev.disp_estimate))
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.CC, MF.SSD, MF.ZSSD, MF.SAD, MF.ZSAD])
+def test_guided_shared_features_same_bits_as_the_per_pixel_walk(func):
+    """Option "guided_shared" (default): a block of 256 pixels stages the processed target feature vectors its pixels look at in LDS;
+    0: every pixel processes every sample of every offset itself.  Same estimates and costs bit for bit: images wider than a block,
+    a last block that is not full, search radii 1 - 3, windows 3x3 - 9x9 (the last too wide for the staged form), both directions, a
+    foreground square whose parallax differs from the background's by more than the staged span holds (blocks that fall back), guides
+    that point outside the image."""
+    for (H, W, r, radius, bg, sq) in [(40, 700, 3, 2, 4, 12), (33, 530, 2, 3, 2, 300), (21, 300, 1, 1, 0, 40), (18, 600, 4, 2, 3, 9), (9, 257, 3, 3, 120, 5)]:
+        src, tgt, _ = parallax_pair(H, W, max(H // 2, 2), H // 4, W // 3, bg, sq, seed=H + W)
+        d_src, d_tgt = dev(src), dev(tgt)
+        for ddir in (R2L, L2R):
+            outs = []
+            for shared in (1, 0):
+                sv.set_option(d_src, "guided_shared", shared)
+                try:
+                    res = sv.hiearchicalTruncatedCostVolume(func, 2, d_tgt, d_src, r, r, 2 * max(bg, sq) + 8, radius, ddir)
+                finally:
+                    sv.set_option(d_src, "guided_shared", 1)
+                outs.append((host(res.disp_estimate), host(res.truncated_cost_volume)))
+            assert np.array_equal(outs[0][0], outs[1][0]), (H, W, r, radius)
+            assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)), (H, W, r, radius)

@@ -60,3 +60,19 @@ for res, (H, W, r, D) in RES.items():
             line["cpu_threads"] = so.num_threads()
             line["pixels_equal_to_oracle"] = round(float((disp_f.cpu().numpy() == want).mean()), 6)
         print(json.dumps(line), flush=True)
+    # benchmarkLocalAlgorithmWithCompressor (:461-531): ZNCC on the 17 superpixel features of the GrPix17R3 / GrPix17R4 masks
+    for gen in ("GrPix17R3Filter", "GrPix17R4Filter"):
+        comp = sv.UnFoldCompressor(getattr(sv.CompressorGenerators, gen)())
+        def chain():
+            cv = sv.unfoldBasedCostVolumeCompressed(MF.ZNCC, d_tgt, d_src, comp, D)
+            return sv.selectedIndexToDisp(sv.extractSelectedIndex(sv.matchFuncStrategy(MF.ZNCC), cv), 0)
+        t_chain, disp_c = timed(chain, n)
+        line = {"row": f"{res} {H}x{W} - {gen[:-6]} windows - disp {D} - zncc", "benchmark": "benchmarkLocalAlgorithmWithCompressor",
+                "ms_per_function_calls": round(t_chain * 1e3, 4), "Mdisparities_per_s": round(W * H * D / t_chain / 1e6, 1)}
+        print(json.dumps(line), flush=True)
+    # benchmarkHierarchicalAlgorithm (:362-402): ZNCC, depth 1 - 3, truncation radius 2 (tools/bench_hierarchical.py has the kernel breakdown)
+    if H >= 100:
+        for depth in (1, 2, 3):
+            t_h, _ = timed(lambda: sv.hiearchicalTruncatedCostVolume(MF.ZNCC, depth, d_tgt, d_src, r, r, D, 2), n)
+            print(json.dumps({"row": f"{res} {H}x{W} - {2 * r + 1}x{2 * r + 1} windows - disp {D} - depth {depth} - zncc", "benchmark": "benchmarkHierarchicalAlgorithm",
+                              "ms": round(t_h * 1e3, 4), "Mdisparities_per_s": round(W * H * D / t_h / 1e6, 1)}), flush=True)

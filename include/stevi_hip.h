@@ -111,6 +111,9 @@ const char *svh_last_error(const svh_context *ctx);
  * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
  * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
  * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
+ * "feature_volume_tiled" (default 1): svh_feature_cost_volume(_2d) with a float matching function processes the two feature volumes once
+ * (mean subtracted, divided by the norm: the values of the reference's normalised volumes) and compares 64 pixels of a row with their
+ * target records from LDS; 0: the per-voxel kernel processes both vectors of every voxel.  Same bits.
  * "guided_shared" (default 1): svh_compute_guided_cv / svh_hierarchical_truncated_cost_volume on grey images with a search radius of at most
  * 3: a block of 256 pixels stages the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of
  * the target windows its pixels look at in LDS once, instead of every pixel processing every sample of every offset again; 0: the

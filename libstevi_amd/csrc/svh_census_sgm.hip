@@ -375,14 +375,14 @@ struct LeanArgs {
     float *carry_out;
 };
 // FULL: every lane's line crosses all LEN rows of the segment or none (and, in tiles mode, LEN = TILE_SUB R: a whole segment)
-template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], const TileMaps &tm) {
+// BANDS: the image is taller than one launch covers (ScanBands): lines start from what the band before left and leave their own
+template <int LEN, bool CARRY, bool FULL, bool BANDS = false>
+__device__ __forceinline__ void scan_lean(const LeanArgs &a, float (*seg_a)[64], int (*seg_n)[64], const TileMaps &tm) {
     static_assert(CARRY || FULL, "the maps mode has its own general form");
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)a.gmap, 0, (int)(a.npx * 4), 0x00020000);
     float gv[LEN];
     float mp = 0.0f, carry_in = 0.0f;
-    if constexpr (CARRY) {
-        if (a.carry_in) carry_in = *a.carry_in; // (kernel uniform) what the bands before this one leave on this lane's line
-    }
+    if constexpr (BANDS) carry_in = *a.carry_in; // what the bands before this one leave on this lane's line
     // traversal step k is the segment's row k (downwards) or n_u - 1 - k (pass 5, upwards)
     if constexpr (FULL) {
         const uint32_t s0 = a.dir > 0 ? 0u : (uint32_t)(LEN - 1) * a.st4, sd = a.dir > 0 ? a.st4 : 0u - a.st4;
@@ -418,7 +418,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
         for (int t = SCAN_SEGS - 1; t > a.seg; t--) mp = seg_a[t][a.lane] + ((seg_n[t][a.lane] & 1) ? -mp : mp);
     }
     if constexpr (CARRY) {
-        if (a.carry_out && a.seg == (a.dir > 0 ? SCAN_SEGS - 1 : 0)) { // the last segment in traversal order: the whole band's map, for the next band
+        if (BANDS && a.seg == (a.dir > 0 ? SCAN_SEGS - 1 : 0)) { // the last segment in traversal order: the whole band's map, for the next band
             const float out_c = seg_a[a.seg][a.lane] + ((seg_n[a.seg][a.lane] & 1) ? -mp : mp);
             if (a.v_lo + a.n_lines > a.vwave + a.lane) *a.carry_out = out_c;
         }
@@ -436,7 +436,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
         // are the steps n_u - R m > 0 and step 0 (the segment's last row, whatever tile row it lies in)
         unsigned long long em_lo = 0;
         unsigned em_hi = 0;
-        int ty_next = a.ty0 + TILE_SUB * a.seg;
+        int ty_next = (BANDS ? a.ty0 : 0) + TILE_SUB * a.seg;
         if constexpr (!FULL) {
             int k0 = 0;
             if (a.dir < 0) {
@@ -464,7 +464,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
             int ty;
             if constexpr (FULL) {
                 edge = k % RF == 0;
-                ty = a.ty0 + TILE_SUB * a.seg + (a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF);
+                ty = (BANDS ? a.ty0 : 0) + TILE_SUB * a.seg + (a.dir > 0 ? k / RF : TILE_SUB - 1 - k / RF);
             } else {
                 edge = k < 64 ? (em_lo >> k) & 1 : (em_hi >> (k - 64)) & 1;
                 ty = ty_next;
@@ -506,7 +506,7 @@ template <int LEN, bool CARRY, bool FULL> __device__ __forceinline__ void scan_l
     }
 }
 
-template <bool CARRY>
+template <bool CARRY, bool BANDS = false>
 __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *__restrict__ gmap, ScanGeom sg, int64_t npx, int n_pass,
                                                                    float *__restrict__ mmap, const int *__restrict__ skip_if_nonzero, TileMaps tm, ScanBands bands) {
     if (skip_if_nonzero && *skip_if_nonzero != 0) return; // the integer-volume probe failed: the line kernels make the maps
@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     int by = blockIdx.y, bx = blockIdx.x;
     if (CARRY && gridDim.y == 1) {
         const int cw = (sg.Wp + 63) / 64, ch = (sg.Hp + 63) / 64;
-        const int band_rows = min(bands.rows(), sg.Hp - bands.band_dn * bands.rows()); // (pass 1: the rows of this launch's downward band)
+        const int band_rows = BANDS ? min(bands.rows(), sg.Hp - bands.band_dn * bands.rows()) : sg.Hp; // (pass 1: the rows of this launch's downward band)
         const int count[6] = {ch, cw, cw, ch, cw, (band_rows + SCAN_SEGS - 1) / SCAN_SEGS}, slice[6] = {1, 2, 3, 4, 0, 5};
         int rem = blockIdx.x;
         by = -1;
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
         if (by < 0) return;
     }
     if (by == (n_pass <= 2 ? 1 : 5)) { // last slice of the grid: pass 1, one wave per row
-        scan_one_row<CARRY>(gmap, sg, npx, mmap, (CARRY ? bands.band_dn * bands.rows() : 0) + bx * SCAN_SEGS + threadIdx.y, threadIdx.x, tm);
+        scan_one_row<CARRY>(gmap, sg, npx, mmap, (BANDS ? bands.band_dn * bands.rows() : 0) + bx * SCAN_SEGS + threadIdx.y, threadIdx.x, tm);
         return;
     }
     __shared__ float seg_a[SCAN_SEGS][64];
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
     int r0 = 0, r1 = 0;
     if (v < cl.v_lo + cl.n_lines) col_line_rows(q, v, sg, r0, r1);
     const int chunk = CARRY ? bands.chunk : scan_chunk(sg.Hp);
-    const int band0 = CARRY ? (q == 5 ? bands.band_up : bands.band_dn) * bands.rows() : 0; // first row of this launch's band of the pass
+    const int band0 = BANDS ? (q == 5 ? bands.band_up : bands.band_dn) * bands.rows() : 0; // first row of this launch's band of the pass
     const int b = max(r0, band0 + seg * chunk), e = min(r1, band0 + (seg + 1) * chunk);
     const int n = max(e - b, 0);
     // pixel index of relative row r on this line: (top + r) * W + left + v + s r, advanced by dir * (W + s) per step
@@ -564,15 +564,15 @@ __global__ void __launch_bounds__(64 * SCAN_SEGS) scan_cols_kernel(const float *
             // lane_off: the lane's pixel in row nb (in the general form possibly not a pixel of its line: only used inside its steps)
             const uint32_t lane_off = (full && n == 0) ? 0xFFFFFFFFu : (uint32_t)(((int64_t)(sg.top + nb) * sg.W + sg.left + v + cl.s * nb) * 4);
             const LeanArgs la{gmap, out, npx, (uint32_t)(sg.W + cl.s) * 4u, lane_off, cl.dir, segu, lane, n,
-                              q, cl.s, cl.v_lo + bx * 64, nb, n_u, cl.v_lo, cl.n_lines, cl.dir > 0 ? b - nb : ne - e, band0 / max(tm.R, 1),
-                              bands.carry_in ? bands.carry_in + (int64_t)by * bands.stride + min(bx * 64 + lane, bands.stride - 1) : nullptr,
-                              bands.carry_out ? bands.carry_out + (int64_t)by * bands.stride + min(bx * 64 + lane, bands.stride - 1) : nullptr};
+                              q, cl.s, cl.v_lo + bx * 64, nb, n_u, cl.v_lo, cl.n_lines, cl.dir > 0 ? b - nb : ne - e, BANDS ? band0 / max(tm.R, 1) : 0,
+                              BANDS ? bands.carry_in + (int64_t)by * bands.stride + min(bx * 64 + lane, bands.stride - 1) : nullptr,
+                              BANDS ? bands.carry_out + (int64_t)by * bands.stride + min(bx * 64 + lane, bands.stride - 1) : nullptr};
             if (n_u > 0) {
                 switch ((n_u + 3) >> 2) {
 #define SVH_LEAN(Q)                                                     \
     case Q:                                                             \
-        if (full) scan_lean<4 * Q, CARRY, true>(la, seg_a, seg_n, tm);  \
-        else if constexpr (CARRY) scan_lean<4 * Q, true, false>(la, seg_a, seg_n, tm); \
+        if (full) scan_lean<4 * Q, CARRY, true, BANDS>(la, seg_a, seg_n, tm);  \
+        else if constexpr (CARRY) scan_lean<4 * Q, true, false, BANDS>(la, seg_a, seg_n, tm); \
         return;
                     SVH_LEAN(1) SVH_LEAN(2) SVH_LEAN(3) SVH_LEAN(4) SVH_LEAN(5) SVH_LEAN(6) SVH_LEAN(7) SVH_LEAN(8) SVH_LEAN(9)
                     SVH_LEAN(10) SVH_LEAN(11) SVH_LEAN(12) SVH_LEAN(13) SVH_LEAN(14) SVH_LEAN(15) SVH_LEAN(16) SVH_LEAN(17) SVH_LEAN(18)
@@ -1161,7 +1161,8 @@ int dev_census_tiles_from_keys(svh_context *ctx, Scratch &scr, const SgmArgs &a,
         bands.carry_out = carry[(k + 1) & 1];
         const int band_rows = std::min(bands.rows(), a.H - k * bands.rows());
         dim3 cgrid(3 * ceil_div(a.W, 64) + 2 * ceil_div(a.H, 64) + ceil_div(band_rows, SCAN_SEGS)), cblock(64, SCAN_SEGS);
-        SVH_LAUNCH(ctx, "sgm_line_scans", scan_cols_kernel<true>, cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm, bands);
+        if (bands.n > 1) SVH_LAUNCH(ctx, "sgm_line_scans", (scan_cols_kernel<true, true>), cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm, bands);
+        else SVH_LAUNCH(ctx, "sgm_line_scans", (scan_cols_kernel<true, false>), cgrid, cblock, 0, gmap, sg, npx, 6, nullptr, nullptr, tm, bands);
         SVH_CHECK_LAUNCH(ctx);
     }
     CensusGeom g{cs.src_words, cs.tgt_words, cs.nWw, a.H, a.W, cs.Wt, a.D, cs.sign, cs.disp_lower, cs.d_offset, cs.region1_global_last};

@@ -419,6 +419,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->cost_volume_colsum = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "feature_volume_tiled") == 0) {
+        ctx->feature_volume_tiled = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "guided_shared") == 0) {
         ctx->guided_shared = value != 0;
         return SVH_OK;

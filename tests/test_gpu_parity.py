@@ -1016,3 +1016,36 @@ def test_sgm_integer_cost_volume_types(rng, dtype, strategy):
     got_t = sv.sgmCostVolume(4, strategy, cv, 0.5, 2.0, sv.Margins(1, 2, 0, 1), 7.0, semantics="textbook")
     ref_t = sv.sgmCostVolume(4, strategy, cv.astype(np.float32), 0.5, 2.0, sv.Margins(1, 2, 0, 1), 7.0, semantics="textbook")
     assert_bits(got_t, host(ref_t))
+
+
+@pytest.mark.parametrize("func", [MF.NCC, MF.ZNCC, MF.CC, MF.ZCC, MF.SSD, MF.ZSSD, MF.SAD, MF.ZSAD])
+def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
+    """Option "feature_volume_tiled" (default): the feature volumes are processed once and compared from LDS; 0: the per-voxel kernel.
+    Same bits, and the oracle within the float tolerance: feature counts odd / even / one, both directions, target narrower and wider
+    than the source, rows wider than a block, disparity ranges that leave the image, the reference's compressor chain (17 features)."""
+    for (H, Ws, Wt, F, D, ddir) in [(9, 150, 150, 17, 40, sv.dispDirection.RightToLeft), (7, 130, 100, 16, 33, sv.dispDirection.LeftToRight),
+                                     (5, 70, 90, 1, 70, sv.dispDirection.RightToLeft), (6, 200, 200, 25, 128, sv.dispDirection.LeftToRight)]:
+        fl = rng.uniform(-1, 1, (H, Wt if ddir == sv.dispDirection.RightToLeft else Ws, F)).astype(np.float32)
+        fr = rng.uniform(-1, 1, (H, Ws if ddir == sv.dispDirection.RightToLeft else Wt, F)).astype(np.float32)
+        dl, dr = dev(fl), dev(fr)
+        outs = []
+        for tiled in (1, 0):
+            sv.set_option(dl, "feature_volume_tiled", tiled)
+            try:
+                outs.append(host(sv.featureVolume2CostVolume(func, dl, dr, D, ddir)))
+            finally:
+                sv.set_option(dl, "feature_volume_tiled", 1)
+        assert np.array_equal(np.isnan(outs[0]), np.isnan(outs[1]))
+        ok = ~np.isnan(outs[0])
+        assert np.array_equal(outs[0][ok].view(np.uint32), outs[1][ok].view(np.uint32)), (H, Ws, Wt, F, D)
+        assert_close(outs[0], so.feature_cost_volume(int(func), fl, fr, D, int(ddir)))
+    img_l = rng.uniform(-1, 1, (20, 140)).astype(np.float32)
+    img_r = rng.uniform(-1, 1, (20, 140)).astype(np.float32)
+    comp = sv.UnFoldCompressor(sv.CompressorGenerators.GrPix17R3Filter())
+    a = host(sv.unfoldBasedCostVolumeCompressed(func, dev(img_l), dev(img_r), comp, 24))
+    sv.set_option(dev(img_l), "feature_volume_tiled", 0)
+    try:
+        b = host(sv.unfoldBasedCostVolumeCompressed(func, dev(img_l), dev(img_r), comp, 24))
+    finally:
+        sv.set_option(dev(img_l), "feature_volume_tiled", 1)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))

@@ -337,6 +337,52 @@ def other_configs(sv, dev, cpu_legs=True):
     return out, ok
 
 
+def reference_benchmark_rows(sv, dev, cpu_legs=True):
+    """The rows of the reference's OWN benchmark program (test/benchmarks/benchmarkCrossCorrelationAlgorithms.cpp: local matching :433-459,
+    with a compressor :461-531, SGM :533-550 -- the 1080p rows are the ones it comments out as "too slow" --, hierarchical :362-402), ZNCC as
+    there, at its 480x640 / 160-disparity and 1080x1920 / 320-disparity sizes, through the per-function entry points on device arrays (the
+    benchmark's own call sequence; volumes in HBM between the calls).  A few steps each; the 480x640 SGM row is checked against the oracle
+    on the whole frame.  tools/bench_reference_rows.py has all of them."""
+    import oracle as so
+    from helpers import parallax_pair
+    MF = sv.matchingFunctions
+    strat = sv.matchFuncStrategy(MF.ZNCC)
+    out, ok = {}, True
+    t0 = time.perf_counter()
+    for res, (H, W, r, D, steps) in {"480x640_5x5_disp160": (480, 640, 2, 160, 10), "1080x1920_7x7_disp320": (1080, 1920, 3, 320, 3)}.items():
+        src, tgt, _ = parallax_pair(H, W, H // 3, H // 3, W // 3, D // 16, D // 4, 11)
+        d_src, d_tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+
+        def chain(ndir):
+            cv = sv.unfoldBasedCostVolume(MF.ZNCC, d_tgt, d_src, r, r, D)
+            if ndir:
+                cv = sv.sgmCostVolume(ndir, strat, cv, 0.001, 0.01, None, 100.0)
+            return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, cv), 0)
+
+        comp = sv.UnFoldCompressor(sv.CompressorGenerators.GrPix17R3Filter())
+        rows = {}
+        rows["local_zncc_ms"] = round(_time_steps(lambda: chain(0), steps)[0], 4)
+        rows["sgm4_zncc_ms"] = round(_time_steps(lambda: chain(4), steps)[0], 4)
+        ms8, disp8 = _time_steps(lambda: chain(8), steps)
+        rows["sgm8_zncc_ms"] = round(ms8, 4)
+        rows["sgm8_zncc_Mdisparities_per_s"] = round(W * H * D / ms8 / 1e3, 1)
+        rows["compressor_GrPix17R3_zncc_ms"] = round(_time_steps(lambda: sv.selectedIndexToDisp(sv.extractSelectedIndex(
+            strat, sv.unfoldBasedCostVolumeCompressed(MF.ZNCC, d_tgt, d_src, comp, D)), 0), steps)[0], 4)
+        rows["hierarchical_depth2_zncc_ms"] = round(_time_steps(lambda: sv.hiearchicalTruncatedCostVolume(MF.ZNCC, 2, d_tgt, d_src, r, r, D, 2), steps)[0], 4)
+        if cpu_legs and H < 1000:
+            tc = time.perf_counter()
+            cvh = sv.unfoldBasedCostVolume(MF.ZNCC, d_tgt, d_src, r, r, D).cpu().numpy()  # (float costs agree with the oracle's to 1e-4: the maps are compared on the library's own volume)
+            want = so.index_to_disp(so.extract_index(so.sgm(cvh, 8, int(strat), 0.001, 0.01, (0, 0, 0, 0), 100.0), int(strat)), so.RIGHT_TO_LEFT)
+            rows["sgm8_end_px_err"] = end_px_err(disp8.cpu().numpy(), want, "oracle (port) SGM + argmax on the library's cost volume, whole frame")
+            rows["sgm8_oracle_ms"] = round((time.perf_counter() - tc) * 1e3, 1)
+            ok &= rows["sgm8_end_px_err"]["pixels_differing"] == 0
+        out[res] = rows
+        del d_src, d_tgt
+        torch.cuda.empty_cache()
+    out["wall_s"] = round(time.perf_counter() - t0, 2)
+    return out, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -771,6 +817,13 @@ def main():
                     rc = 3
             except Exception as e:  # noqa: BLE001 -- report, never lose the headline to a secondary leg
                 line["configs"] = {"error": f"{type(e).__name__}: {e}"}
+                rc = 3
+            try:
+                line["reference_benchmark_rows"], rows_ok = reference_benchmark_rows(sv, dev, cpu_legs=not args.no_cpu_baseline)
+                if not rows_ok:
+                    rc = 3
+            except Exception as e:  # noqa: BLE001
+                line["reference_benchmark_rows"] = {"error": f"{type(e).__name__}: {e}"}
                 rc = 3
         wall["total_s"] = round(time.perf_counter() - t_setup, 2)
         line["wall_clock_s"] = wall

@@ -176,6 +176,11 @@ int svh_device_free(svh_context *ctx, void *ptr);
  * array frees it by device number.  Waits for the device to go idle first (nothing still running may use the memory). */
 int svh_context_get_device(const svh_context *ctx);
 int svh_device_free_detached(int device, void *ptr);
+/* Blocks released through svh_device_free / svh_device_free_detached are kept per device and handed out again by svh_device_alloc (best
+ * fit, at most twice the request): a chain written with the reference's names allocates and releases a volume per call, and hipMalloc /
+ * hipFree of 2 GB cost tens of milliseconds each.  The cache holds at most SVH_DEVICE_CACHE_MB (environment, default 65536) and is
+ * returned to the device by this call and by svh_context_trim. */
+int svh_device_cache_trim(int device);
 int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes);
 int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes);
 /* device -> device, enqueued on the context's stream (no wait) */

@@ -1,5 +1,8 @@
 // Context, workspace pool, profiling and array marshalling for libstevi_hip.so.
 #include <cstdarg>
+#include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "svh_internal.h"
 
@@ -481,14 +484,73 @@ int svh_context_trim(svh_context *ctx) {
         else if (b.ptr) (void)hipFree(b.ptr);
     }
     ctx->pool.swap(keep);
+    return svh_device_cache_trim(ctx->device);
+}
+
+// ---- memory behind HipBridge::DeviceArray: a per-device cache of released blocks -------------------------------------------------------
+// A chain written with the reference's names allocates and releases a volume per call (2.1 GB each at 1080p x 256), and hipMalloc /
+// hipFree of that size cost tens of milliseconds each: the C3 chain through the drop-in headers took 128 ms for 1.4 ms of kernels.
+// Released blocks are kept (best fit, at most twice the request) and handed out again; hipFree only when the cache passes its cap
+// (SVH_DEVICE_CACHE_MB, default 65536) or on svh_context_trim / svh_device_cache_trim.  A block is only cached after the wait its release
+// always did (the device idle, or the context's stream drained), so whoever gets it next may use it on any stream.
+namespace {
+struct DeviceCache {
+    std::mutex m;
+    std::multimap<size_t, void *> free_blocks; // size -> block
+    std::map<void *, size_t> sizes;            // every live block of svh_device_alloc
+    size_t cached = 0;
+};
+DeviceCache g_device_cache[64];
+size_t device_cache_cap() {
+    static const size_t cap = [] {
+        const char *e = getenv("SVH_DEVICE_CACHE_MB");
+        const long long mb = e ? atoll(e) : 65536;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return cap;
+}
+// (lock held) hipFree cached blocks, largest first, until at most `keep` bytes stay cached
+void device_cache_shrink(DeviceCache &c, size_t keep) {
+    while (c.cached > keep && !c.free_blocks.empty()) {
+        auto it = std::prev(c.free_blocks.end());
+        (void)hipFree(it->second);
+        c.sizes.erase(it->second);
+        c.cached -= it->first;
+        c.free_blocks.erase(it);
+    }
+}
+int device_release(int device, void *ptr) { // after the caller's wait
+    DeviceCache &c = g_device_cache[device & 63];
+    std::lock_guard<std::mutex> lock(c.m);
+    auto it = c.sizes.find(ptr);
+    if (it == c.sizes.end()) return hipFree(ptr) == hipSuccess ? SVH_OK : SVH_ERR_HIP; // (not from svh_device_alloc)
+    c.free_blocks.emplace(it->second, ptr);
+    c.cached += it->second;
+    device_cache_shrink(c, device_cache_cap());
     return SVH_OK;
 }
+} // namespace
 
 int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr) {
     if (!ctx || !ptr) return SVH_ERR_INVALID_ARGUMENT;
     *ptr = nullptr;
     DeviceGuard guard(ctx->device);
-    SVH_HIP_CHECK(ctx, hipMalloc(ptr, bytes ? bytes : 16));
+    const size_t want = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
+    DeviceCache &c = g_device_cache[ctx->device & 63];
+    std::lock_guard<std::mutex> lock(c.m);
+    auto it = c.free_blocks.lower_bound(want);
+    if (it != c.free_blocks.end() && it->first <= 2 * want + (1u << 20)) {
+        *ptr = it->second;
+        c.cached -= it->first;
+        c.free_blocks.erase(it);
+        return SVH_OK;
+    }
+    if (hipMalloc(ptr, want) != hipSuccess) { // out of memory: give the cached blocks back and try once more
+        (void)hipGetLastError();
+        device_cache_shrink(c, 0);
+        SVH_HIP_CHECK(ctx, hipMalloc(ptr, want));
+    }
+    c.sizes[*ptr] = want;
     return SVH_OK;
 }
 
@@ -499,7 +561,7 @@ int svh_device_free_detached(int device, void *ptr) {
     if (device < 0) return SVH_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(device);
     if (hipDeviceSynchronize() != hipSuccess) return SVH_ERR_HIP; // any stream of any context may still be using it
-    return hipFree(ptr) == hipSuccess ? SVH_OK : SVH_ERR_HIP;
+    return device_release(device, ptr);
 }
 
 int svh_device_free(svh_context *ctx, void *ptr) {
@@ -507,7 +569,17 @@ int svh_device_free(svh_context *ctx, void *ptr) {
     if (!ptr) return SVH_OK;
     DeviceGuard guard(ctx->device);
     SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // nothing enqueued on this context still uses it
-    SVH_HIP_CHECK(ctx, hipFree(ptr));
+    // (another context's stream may: the block is handed out again to any stream, so wait for the device like the detached release)
+    SVH_HIP_CHECK(ctx, hipDeviceSynchronize());
+    return device_release(ctx->device, ptr);
+}
+
+int svh_device_cache_trim(int device) {
+    if (device < 0) return SVH_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(device);
+    DeviceCache &c = g_device_cache[device & 63];
+    std::lock_guard<std::mutex> lock(c.m);
+    device_cache_shrink(c, 0);
     return SVH_OK;
 }
 

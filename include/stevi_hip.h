@@ -111,6 +111,10 @@ const char *svh_last_error(const svh_context *ctx);
  * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
  * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
  * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
+ * "patchmatch_pred_costs" (default 1): svh_cacheless_patch_match evaluates, before each propagation sweep and for every pixel in parallel,
+ * the cost of the pixel against its predecessor's solution; the sweep uses it wherever the predecessor kept that solution (most pixels
+ * after the first iterations) and evaluates a cost on the spot only behind an accepted candidate.  0: every step of a sweep evaluates
+ * its cost.  Same result.
  * "feature_volume_tiled" (default 1): svh_feature_cost_volume(_2d) with a float matching function processes the two feature volumes once
  * (mean subtracted, divided by the norm: the values of the reference's normalised volumes) and compares 64 pixels of a row with their
  * target records from LDS; 0: the per-voxel kernel processes both vectors of every voxel.  Same bits.

@@ -422,6 +422,10 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->cost_volume_colsum = value != 0;
         return SVH_OK;
     }
+    if (strcmp(name, "patchmatch_pred_costs") == 0) {
+        ctx->patchmatch_pred_costs = value != 0;
+        return SVH_OK;
+    }
     if (strcmp(name, "feature_volume_tiled") == 0) {
         ctx->feature_volume_tiled = value != 0;
         return SVH_OK;

@@ -267,6 +267,131 @@ __global__ void __launch_bounds__(64) pm_cols_kernel(OdVolume o, int inc, PmStat
     if (n && threadIdx.x == 0) atomicAdd(changes, n);
 }
 
+// ---- the sweeps without a cost evaluation on most steps (round 4f) -----------------------------------------------------------------------
+// A pixel of a sweep is tested with the running candidate: the solution of its predecessor as the sweep left it.  When the predecessor
+// KEPT its own solution -- most pixels, once the first iterations are over -- that is the solution the predecessor had before the sweep
+// started, and the cost of the pixel against it depends on nothing the sweep does: pm_pred_cost_kernel evaluates it for every pixel in
+// parallel beforehand (the same wave_cost: the same number).  The sweep then carries 64 pixels' worth of (that cost, the pixel's own
+// cost, both "has a value" flags, the pixel's own solution) in the lanes of a few registers, loaded 64 pixels at a time, and a step whose
+// predecessor kept its solution is a handful of v_readlane and a compare; only a step behind an ACCEPTED candidate (the running
+// candidate travels on) evaluates a cost on the spot, as every step used to (1.1 - 1.8 us each: the candidate decides which target
+// vector is loaded, so nothing of it can be fetched ahead).  Same tests in the same order on the same values: same result.
+// axis 0: row sweep (predecessor (i, j - inc)), 1: column sweep ((i - inc, j))
+__global__ void __launch_bounds__(64) pm_pred_cost_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int64_t npx = (int64_t)o.Hs * o.Ws;
+    for (int64_t p = blockIdx.x; p < npx; p += gridDim.x) {
+        const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+        const int pi = axis ? i - inc : i, pj = axis ? j : j - inc;
+        float c = 0.0f;
+        bool ok = false;
+        if (pi >= 0 && pi < o.Hs && pj >= 0 && pj < o.Ws) { // (wave uniform)
+            const int64_t pp = (int64_t)pi * o.Ws + pj;
+            const int c0 = st.sol[pp * o.nd], c1 = o.nd == 2 ? st.sol[pp * o.nd + 1] : 0;
+            if (c0 == st.sol[p * o.nd] && (o.nd < 2 || c1 == st.sol[p * o.nd + 1])) { // the pixel's own solution: its own cost (the same evaluation)
+                c = st.cost[p];
+                ok = st.valid[p] != 0;
+            } else {
+                ok = wave_cost(o, i, j, c0, c1, pm_buf, &c);
+            }
+        }
+        if (threadIdx.x == 0) {
+            pcost[p] = c;
+            pvalid[p] = ok ? 1 : 0;
+        }
+    }
+}
+
+__device__ __forceinline__ int pm_lane_i(int v, int k) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(k)); }
+__device__ __forceinline__ float pm_lane_f(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(k))); }
+
+// one sweep line: `len` pixels at p = first + t * step (t = 0 is the line's first pixel, which is not tested); (i, j) of pixel t: (i0 + t di, j0 + t dj)
+__device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
+                                             int64_t first, int64_t step, int i0, int j0, int di, int dj, int t_end, float *buf) {
+    const int lane = threadIdx.x;
+    int n = 0;
+    int p0 = st.sol[first * o.nd], p1 = o.nd == 2 ? st.sol[first * o.nd + 1] : 0; // solution of the line's first pixel (it has no predecessor)
+    bool fresh = true; // the running candidate is the predecessor's solution of before the sweep
+    float r_pc = 0.0f, r_oc = 0.0f;
+    int r_flags = 0, r_s0 = 0, r_s1 = 0;
+    for (int t = 1; t < t_end; t++) {
+        const int k = (t - 1) & 63;
+        if (k == 0) { // the next 64 pixels of the line, one per lane (their entries are only written at their own steps, which come later)
+            const int tt = t + lane;
+            const bool in = tt < t_end;
+            const int64_t p = first + (int64_t)(in ? tt : t) * step;
+            r_pc = pcost[p];
+            r_oc = st.cost[p];
+            r_flags = (pvalid[p] ? 1 : 0) | (st.valid[p] ? 2 : 0);
+            r_s0 = st.sol[p * o.nd];
+            r_s1 = o.nd == 2 ? st.sol[p * o.nd + 1] : 0;
+        }
+        const int i = i0 + t * di, j = j0 + t * dj;
+        const int flags = pm_lane_i(r_flags, k);
+        float c_new;
+        bool has_new;
+        if (fresh) {
+            c_new = pm_lane_f(r_pc, k);
+            has_new = (flags & 1) != 0;
+        } else if (p0 == pm_lane_i(r_s0, k) && (o.nd < 2 || p1 == pm_lane_i(r_s1, k))) {
+            // a travelling candidate that equals the pixel's own solution (a region that agrees already): the cost is the pixel's own cost,
+            // the same evaluation of the same two vectors
+            c_new = pm_lane_f(r_oc, k);
+            has_new = (flags & 2) != 0;
+        } else {
+            has_new = wave_cost(o, i, j, p0, p1, buf, &c_new);
+        }
+        int kept = 0;
+        if (has_new) { // patchMatchTestCost, patchmatch.h:162-224 (a candidate without a value is dropped)
+            const bool has_old = (flags & 2) != 0;
+            const float c_old = pm_lane_f(r_oc, k);
+            bool keep;
+            if (o.score) keep = has_old ? (c_new >= c_old) : true;
+            else keep = has_old ? (c_new <= c_old) : false;
+            if (keep) {
+                if (lane == 0) {
+                    const int64_t p = first + (int64_t)t * step;
+                    st.sol[p * o.nd] = p0;
+                    if (o.nd == 2) st.sol[p * o.nd + 1] = p1;
+                    st.cost[p] = c_new;
+                    st.valid[p] = 1;
+                }
+                kept = 1;
+            }
+        }
+        n += kept;
+        if (!kept) { // the next pixel's candidate is this pixel's own (unchanged) solution
+            p0 = pm_lane_i(r_s0, k);
+            p1 = pm_lane_i(r_s1, k);
+            fresh = true;
+        } else {
+            fresh = false;
+        }
+    }
+    return n;
+}
+
+__global__ void __launch_bounds__(64) pm_rows_fast_kernel(OdVolume o, int inc, PmState st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
+                                                          int *__restrict__ changes) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int i = blockIdx.x;
+    const int jfirst = inc > 0 ? 0 : o.Ws - 1;
+    // going right: pixels 1 .. Ws - 1; going left: Ws - 2 .. 1 (`j != final` stops before column 0)
+    const int t_end = inc > 0 ? o.Ws : o.Ws - 1;
+    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)i * o.Ws + jfirst, inc, i, jfirst, 0, inc, t_end, pm_buf);
+    if (n && threadIdx.x == 0) atomicAdd(changes, n);
+}
+
+__global__ void __launch_bounds__(64) pm_cols_fast_kernel(OdVolume o, int inc, PmState st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
+                                                          int *__restrict__ changes) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int j = blockIdx.x;
+    const int ifirst = inc > 0 ? 0 : o.Hs - 1;
+    const int t_end = inc > 0 ? o.Hs : o.Hs - 1;
+    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)ifirst * o.Ws + j, (int64_t)inc * o.Ws, ifirst, j, inc, 0, t_end, pm_buf);
+    if (n && threadIdx.x == 0) atomicAdd(changes, n);
+}
+
 // patchMatchSearch, :226-363: a wave per pixel
 __global__ void __launch_bounds__(64) pm_search_kernel(OdVolume o, uint64_t seed, uint32_t iter, int n_random, PmState st, int *__restrict__ changes) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
@@ -620,14 +745,28 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
         if (!changes || !st.cost || !st.valid) return SVH_ERR_OUT_OF_MEMORY;
         const size_t shmem = (size_t)((o.nF + 3) & ~3) * sizeof(float);
         const int px_grid = (int)std::min<int64_t>(npx, 256 * 64); // a wave per pixel, grid-stride
+        float *pcost = nullptr;
+        uint8_t *pvalid = nullptr;
+        if (ctx->patchmatch_pred_costs) {
+            pcost = scr.get_n<float>((size_t)npx);
+            pvalid = scr.get_n<uint8_t>((size_t)npx);
+            if (!pcost || !pvalid) return SVH_ERR_OUT_OF_MEMORY;
+        }
         SVH_LAUNCH(ctx, "patchmatch_init", pm_init_kernel, px_grid, 64, shmem, o, seed, st);
         for (; it < n_iter; it++) {
             SVH_HIP_CHECK(ctx, hipMemsetAsync(changes, 0, sizeof(int), ctx->stream));
             const int inc0 = (it % 4) < 2 ? 1 : -1, inc1 = (it % 2) == 0 ? 1 : -1; // propagation_direction.h:64-86, patchmatch.h:462-479
             // (prefetching the next pixel's vectors under both outcomes of the current test was tried: no gain -- with one wave per
             // SIMD a step is bound by its ~150 dependent additions and the instructions around them, not by the loads)
-            SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
-            SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);
+            if (pcost) { // the cost of every pixel against its predecessor's solution, in parallel; then the sweep (pm_pred_cost_kernel)
+                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost, pvalid);
+                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, shmem, o, inc1, st, pcost, pvalid, changes);
+                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost, pvalid);
+                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, shmem, o, inc0, st, pcost, pvalid, changes);
+            } else {
+                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
+                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);
+            }
             // batched search when at least one pixel's candidates fit a wave and an LDS table of 60 KB
             const int pitch = o.nF | 1;
             int E = std::min<int>(64, (int)(16 * 1024 / (pitch * sizeof(float)))); // table of at most 16 KB: ten waves per CU keep loads in flight

@@ -113,3 +113,23 @@ def test_patch_match_argument_rules(rng):
     assert sv.cachelessPatchMatch(MF.ZNCC, a, a[:7].copy(), 1, sv.searchOffset2(-1, 1, -1, 1)).shape == (8, 9, 2)  # flow does not
     with pytest.raises(Exception):
         sv.cachelessPatchMatch(MF.CENSUS, a, a, 1, sv.searchOffset1(-1, 1))
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SAD])
+@pytest.mark.parametrize("nd", [1, 2])
+def test_patch_match_sweeps_with_predecessor_costs_same_result(rng, func, nd):
+    """Option "patchmatch_pred_costs" (default): the sweeps take a pixel's cost against its predecessor's unchanged solution from a
+    parallel pre-pass and against its own solution from its own cost; 0: every step evaluates its cost.  Same solutions, same iteration
+    counts: lines longer than the 64 pixels a register chunk holds, both sweep directions (iterations 0 - 3), grey and colour."""
+    for (H, W, C, n_iter, n_random) in [(70, 150, 1, 5, 4), (90, 67, 3, 4, 2), (3, 200, 1, 4, 0), (130, 5, 1, 4, 3)]:
+        src, tgt = shifted_pair(rng, H, W, C, 0 if nd == 1 else 1, -2)
+        off = sv.searchOffset2(-3, 3, -6, 6) if nd == 2 else sv.searchOffset1(-6, 6)
+        d_src, d_tgt = dev(src), dev(tgt)
+        outs = []
+        for opt in (1, 0):
+            sv.set_option(d_src, "patchmatch_pred_costs", opt)
+            try:
+                outs.append(sv.cachelessPatchMatch(func, d_src, d_tgt, 2, off, n_iter, n_random, 77, return_iterations=True))
+            finally:
+                sv.set_option(d_src, "patchmatch_pred_costs", 1)
+        assert np.array_equal(host(outs[0][0]), host(outs[1][0])) and outs[0][1] == outs[1][1], (H, W, C)

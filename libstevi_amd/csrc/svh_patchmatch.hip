@@ -38,39 +38,63 @@ struct OdVolume {
     bool score;
 };
 
-__global__ void on_demand_features_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, bool zm, bool nrm,
-                                          float *__restrict__ out) {
-    const int64_t npx = (int64_t)H * W;
-    const int nF = (2 * v_r + 1) * (2 * h_r + 1) * C;
-    auto sample = [&](int i, int j, int f) {
-        const int c = f % C, dj = (f / C) % (2 * h_r + 1) - h_r, di = f / (C * (2 * h_r + 1)) - v_r;
-        const int ii = min(H - 1, max(0, i + di)), jj = min(W - 1, max(0, j + dj)); // constant border condition, features_volume.h:128-133
-        return img[((int64_t)ii * W + jj) * C + c];
-    };
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npx; p += (int64_t)gridDim.x * blockDim.x) {
+// A block takes 256 consecutive pixels: a thread per pixel walks its window once or twice for the mean and the norm (nested loops in the
+// order of the feature index: no division per sample), then the block writes the 256 x nF decorated features as one flat, coalesced run --
+// a thread per pixel storing its nF floats nF * 4 bytes apart, with three divisions per sample and pass, took 5.2 ms for two 1080p RGB
+// images and 7x7 windows (2.4 GB at 0.47 TB/s).  Same operations in the same order.
+constexpr int ODF_PX = 256;
+__global__ void __launch_bounds__(256) on_demand_features_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, bool zm, bool nrm,
+                                                                 float *__restrict__ out) {
+    __shared__ float s_mean[ODF_PX], s_norm[ODF_PX];
+    const int64_t npx = (int64_t)H * W, p0 = (int64_t)blockIdx.x * ODF_PX;
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1, nF = v * h * C;
+    const int n_px = (int)(npx - p0 < ODF_PX ? npx - p0 : ODF_PX);
+    if ((int)threadIdx.x < n_px) {
+        const int64_t p = p0 + threadIdx.x;
         const int j = (int)(p % W), i = (int)(p / W);
         float mean = 0.0f, norm = 1.0f;
         if (zm) { // :183-192
-            for (int f = 0; f < nF; f++) mean += sample(i, j, f);
+            for (int k = 0; k < v; k++) {
+                const int ii = min(H - 1, max(0, i + k - v_r)); // constant border condition, features_volume.h:128-133
+                for (int l = 0; l < h; l++) {
+                    const float *px = img + ((int64_t)ii * W + min(W - 1, max(0, j + l - h_r))) * C;
+                    for (int c = 0; c < C; c++) mean += px[c];
+                }
+            }
             mean /= (float)nF;
         }
         if (nrm) { // :194-207
             float acc = 0.0f;
-            for (int f = 0; f < nF; f++) {
-                float v = sample(i, j, f);
-                if (zm) v -= mean;
-                acc += v * v;
+            for (int k = 0; k < v; k++) {
+                const int ii = min(H - 1, max(0, i + k - v_r));
+                for (int l = 0; l < h; l++) {
+                    const float *px = img + ((int64_t)ii * W + min(W - 1, max(0, j + l - h_r))) * C;
+                    for (int c = 0; c < C; c++) {
+                        float x = px[c];
+                        if (zm) x -= mean;
+                        acc += x * x;
+                    }
+                }
             }
             acc /= (float)nF;
             norm = sqrtf(acc);
         }
-        float *o = out + p * nF;
-        for (int f = 0; f < nF; f++) {
-            float v = sample(i, j, f);
-            if (zm) v -= mean;
-            if (nrm) v /= norm;
-            o[f] = v;
-        }
+        s_mean[threadIdx.x] = mean;
+        s_norm[threadIdx.x] = norm;
+    }
+    __syncthreads();
+    float *o = out + p0 * nF;
+    const int hc = h * C;
+    for (int e = threadIdx.x; e < n_px * nF; e += 256) {
+        const int q = e / nF, f = e - q * nF;
+        const int k = f / hc, r = f - k * hc, l = r / C, c = r - l * C;
+        const int64_t p = p0 + q;
+        const int j = (int)(p % W), i = (int)(p / W);
+        const int ii = min(H - 1, max(0, i + k - v_r)), jj = min(W - 1, max(0, j + l - h_r));
+        float x = img[((int64_t)ii * W + jj) * C + c];
+        if (zm) x -= s_mean[q];
+        if (nrm) x /= s_norm[q];
+        o[e] = x;
     }
 }
 
@@ -637,7 +661,7 @@ int check_params(svh_context *ctx, const svh_on_demand_params *p, const svh_arra
 int dev_on_demand_features(svh_context *ctx, int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out) {
     const int64_t npx = (int64_t)H * W;
     if (npx == 0) return SVH_OK;
-    SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_kernel, grid_for(npx, 256, 16384), 256, 0, img, H, W, C, h_r, v_r, func_zero_mean(func),
+    SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_kernel, (int)((npx + ODF_PX - 1) / ODF_PX), 256, 0, img, H, W, C, h_r, v_r, func_zero_mean(func),
                func_normalized(func), out);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;

@@ -83,18 +83,43 @@ __global__ void __launch_bounds__(256) on_demand_features_kernel(const float *__
         s_norm[threadIdx.x] = norm;
     }
     __syncthreads();
-    float *o = out + p0 * nF;
-    const int hc = h * C;
-    for (int e = threadIdx.x; e < n_px * nF; e += 256) {
-        const int q = e / nF, f = e - q * nF;
-        const int k = f / hc, r = f - k * hc, l = r / C, c = r - l * C;
-        const int64_t p = p0 + q;
-        const int j = (int)(p % W), i = (int)(p / W);
-        const int ii = min(H - 1, max(0, i + k - v_r)), jj = min(W - 1, max(0, j + l - h_r));
-        float x = img[((int64_t)ii * W + jj) * C + c];
-        if (zm) x -= s_mean[q];
-        if (nrm) x /= s_norm[q];
-        o[e] = x;
+    // a wave per pixel, the lanes over the feature index (a pixel's nF floats are one contiguous run): which window sample a lane's
+    // features are is the same for every pixel -- decoded once (three divisions per feature made this loop the whole kernel)
+    const int hc = h * C, j_blk = (int)(p0 % W), i_blk = (int)(p0 / W);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int MAXCH = 4;
+    int dk[MAXCH], dl[MAXCH], dc[MAXCH];
+#pragma unroll
+    for (int m = 0; m < MAXCH; m++) {
+        const int f = min(lane + 64 * m, nF - 1);
+        const int k = f / hc, r = f - k * hc, l = r / C;
+        dk[m] = k - v_r;
+        dl[m] = l - h_r;
+        dc[m] = r - l * C;
+    }
+    for (int q = wave; q < n_px; q += 4) {
+        const int t = j_blk + q, i = i_blk + t / W, j = t - (t / W) * W; // (wave uniform)
+        const float mean = s_mean[q], norm = s_norm[q];
+        float *o = out + (p0 + q) * nF;
+#pragma unroll
+        for (int m = 0; m < MAXCH; m++) {
+            const int f = lane + 64 * m;
+            if (f < nF) {
+                const int ii = min(H - 1, max(0, i + dk[m])), jj = min(W - 1, max(0, j + dl[m]));
+                float x = img[((int64_t)ii * W + jj) * C + dc[m]];
+                if (zm) x -= mean;
+                if (nrm) x /= norm;
+                o[f] = x;
+            }
+        }
+        for (int f = lane + 64 * MAXCH; f < nF; f += 64) { // (more than 256 features: decoded on the spot)
+            const int k = f / hc, r = f - k * hc, l = r / C, c = r - l * C;
+            const int ii = min(H - 1, max(0, i + k - v_r)), jj = min(W - 1, max(0, j + l - h_r));
+            float x = img[((int64_t)ii * W + jj) * C + c];
+            if (zm) x -= mean;
+            if (nrm) x /= norm;
+            o[f] = x;
+        }
     }
 }
 

@@ -504,7 +504,8 @@ struct DeviceCache {
     std::map<void *, size_t> sizes;            // every live block of svh_device_alloc
     size_t cached = 0;
 };
-DeviceCache g_device_cache[64];
+// (never destroyed: an array released by a static object's destructor after this library's own statics are gone must still find it)
+DeviceCache *const g_device_cache = new DeviceCache[64];
 size_t device_cache_cap() {
     static const size_t cap = [] {
         const char *e = getenv("SVH_DEVICE_CACHE_MB");

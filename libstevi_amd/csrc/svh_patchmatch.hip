@@ -86,6 +86,20 @@ __global__ void __launch_bounds__(256) on_demand_features_kernel(const float *__
     // a wave per pixel, the lanes over the feature index (a pixel's nF floats are one contiguous run): which window sample a lane's
     // features are is the same for every pixel -- decoded once (three divisions per feature made this loop the whole kernel)
     const int hc = h * C, j_blk = (int)(p0 % W), i_blk = (int)(p0 / W);
+    if (nF < 48) { // short vectors would leave most of a wave's lanes idle: one flat run of elements instead (a few divisions per element)
+        float *o = out + p0 * nF;
+        for (int e = threadIdx.x; e < n_px * nF; e += 256) {
+            const int q = e / nF, f = e - q * nF;
+            const int k = f / hc, r = f - k * hc, l = r / C, c = r - l * C;
+            const int t = j_blk + q, i = i_blk + t / W, j = t - (t / W) * W;
+            const int ii = min(H - 1, max(0, i + k - v_r)), jj = min(W - 1, max(0, j + l - h_r));
+            float x = img[((int64_t)ii * W + jj) * C + c];
+            if (zm) x -= s_mean[q];
+            if (nrm) x /= s_norm[q];
+            o[e] = x;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int MAXCH = 4;
     int dk[MAXCH], dl[MAXCH], dc[MAXCH];

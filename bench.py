@@ -362,6 +362,9 @@ def reference_benchmark_rows(sv, dev, cpu_legs=True):
         comp = sv.UnFoldCompressor(sv.CompressorGenerators.GrPix17R3Filter())
         rows = {}
         rows["local_zncc_ms"] = round(_time_steps(lambda: chain(0), steps)[0], 4)
+        # (the volume carries its winner to extractSelectedIndex: what the C++ drop-in headers do on DeviceArray for Score-strategy functions)
+        rows["local_zncc_winner_carried_ms"] = round(_time_steps(lambda: sv.selectedIndexToDisp(sv.extractSelectedIndex(
+            strat, sv.unfoldBasedCostVolume(MF.ZNCC, d_tgt, d_src, r, r, D, keep_winner=True)), 0), steps)[0], 4)
         rows["sgm4_zncc_ms"] = round(_time_steps(lambda: chain(4), steps)[0], 4)
         ms8, disp8 = _time_steps(lambda: chain(8), steps)
         rows["sgm8_zncc_ms"] = round(ms8, 4)

@@ -256,6 +256,13 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
 int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r,
                                   int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima,
                                   int *minima_written);
+/* The same with the by-product a later extractSelectedIndex<strategy of match_func> on the volume would scan it for (the reference
+ * benchmark's own sequence, benchmarkCrossCorrelationAlgorithms.cpp:92-96): winner (H,Ws) i32 = that index map, picked by the kernel that
+ * writes the volume while it holds a pixel's costs.  *winner_written: 1 when it was produced (a float function on grey images through the
+ * column-sum kernel: windows up to 11 wide, not ZSAD), 0 when not (the array is left untouched; scan the volume). */
+int svh_unfold_cost_volume_winner(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r,
+                                  int h_radius, int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *winner,
+                                  int *winner_written);
 
 /* ---- A9  sgmCostVolume<nDirections, strategy>(cv, P1, P2, margins, Pout)      correlation/sgm.h:360-404
  * cv (H,W,D) f32 -> out (H,W,D) f32, D <= 2048.  n_directions 4 or 8 (16 is a data race in the reference and unsupported).

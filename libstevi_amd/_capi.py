@@ -24,7 +24,7 @@ EXPORTS = [
     "svh_status_string", "svh_last_error", "svh_device_available", "svh_device_alloc", "svh_device_free", "svh_device_free_detached", "svh_device_cache_trim", "svh_context_get_device", "svh_device_upload", "svh_device_download", "svh_device_copy",
     "svh_profile_enable", "svh_profile_filter", "svh_profile_sampling", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_oriented", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
-    "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_unfold_cost_volume_minima", "svh_sgm_cost_volume", "svh_sgm_cost_volume_minima", "svh_sgm_cost_volume_winner", "svh_sgm_cost_volume_textbook",
+    "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_unfold_cost_volume_minima", "svh_unfold_cost_volume_winner", "svh_sgm_cost_volume", "svh_sgm_cost_volume_minima", "svh_sgm_cost_volume_winner", "svh_sgm_cost_volume_textbook",
     "svh_extract_selected_index", "svh_selected_index_to_disp", "svh_selected_cost", "svh_truncated_cost_volume",
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_census_exchange_keys", "svh_census_band_match", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
@@ -127,6 +127,7 @@ def load():
         "svh_sgm_cost_volume": (C.c_int, [ctx, C.c_int, C.c_int, A, C.c_float, C.c_float, P(i32), C.c_float, A]),
         "svh_sgm_cost_volume_textbook": (C.c_int, [ctx, C.c_int, C.c_int, A, C.c_float, C.c_float, P(i32), C.c_float, A]),
         "svh_unfold_cost_volume_minima": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_int, i32, i32, A, A, P(C.c_int)]),
+        "svh_unfold_cost_volume_winner": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_int, i32, i32, A, A, P(C.c_int)]),
         "svh_sgm_cost_volume_minima": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_float, C.c_float, C.c_float, P(i32), C.c_float, A]),
         "svh_sgm_cost_volume_winner": (C.c_int, [ctx, C.c_int, C.c_int, A, A, C.c_int, C.c_float, C.c_float, C.c_float, P(i32), C.c_float, A, A, P(C.c_int)]),
         "svh_device_copy": (C.c_int, [ctx, C.c_void_p, C.c_void_p, C.c_size_t]),

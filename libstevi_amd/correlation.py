@@ -329,7 +329,7 @@ def featureVolume2CostVolume(matchFunc, feature_vol_l, feature_vol_r, searchRang
     return out if st == _capi.OK else _empty_like(l, 3, "f32")
 
 
-def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, keep_minima=False):
+def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_width, dDir=dispDirection.RightToLeft, keep_minima=False, keep_winner=False):
     """unfoldBasedCostVolume<matchFunc,...> -- correlation/cross_correlations.h:740-765.
     disp_width: an int (disp_t overload) or a searchOffset1 / (lower, upper) pair.
 
@@ -339,7 +339,11 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
     or on a view of it -- and nothing else.  Writes that torch's version counter does not see make sgmCostVolume trust stale minima and
     return a wrong volume without notice: through `cv.data` (a tensor with a counter of its own), through another framework's kernel handed
     `cv.data_ptr()` / a DLPack or __cuda_array_interface__ export, through a raw C-ABI call.  Ask for it only for a volume you do not write
-    to by such routes; `dropMinima(cv)` withdraws it."""
+    to by such routes; `dropMinima(cv)` withdraws it.
+
+    keep_winner (device tensors; off by default; the same conditions): keep the index map a later extractSelectedIndex<strategy of
+    matchFunc> on the untouched tensor would scan the volume for (svh_unfold_cost_volume_winner: the reference benchmark's own sequence
+    is unfoldBasedCostVolume -> extractSelectedIndex): that call then returns a copy of the map."""
     lib = _capi.load()
     l, r = _prep_image(img_l), _prep_image(img_r)
     ctx = context_for(l)
@@ -358,6 +362,14 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
         if st == _capi.OK and written.value:  # 1: integer costs (census / Hamming), 2: float costs inside the regime (column-sum kernel)
             nWw = ((2 * h_radius + 1) * (2 * v_radius + 1) * (l.shape[2] if l.ndim == 3 else 1) - 1) // 32
             out._svh_minima = (minima, float(32 * nWw) if written.value == 1 else 1e30, out.data_ptr(), out._version, tuple(out.shape), int(written.value))
+        return out if st == _capi.OK else _empty_like(l, 3, "f32")
+    if keep_winner and _is_torch(out):
+        widx = _like(l, (src.shape[0], src.shape[1]), "i32")
+        written = C.c_int(0)
+        st = _check(ctx, lib.svh_unfold_cost_volume_winner(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
+                                                           lower, D, C.byref(_desc(out)), C.byref(_desc(widx)), C.byref(written)))
+        if st == _capi.OK and written.value:
+            out._svh_winner = (widx, int(matchFuncStrategy(matchFunc)), out.data_ptr(), out._version, tuple(out.shape))
         return out if st == _capi.OK else _empty_like(l, 3, "f32")
     st = _check(ctx, lib.svh_unfold_cost_volume(ctx, int(matchFunc), int(dDir), C.byref(_desc(l)), C.byref(_desc(r)), h_radius, v_radius,
                                                 lower, D, C.byref(_desc(out))))

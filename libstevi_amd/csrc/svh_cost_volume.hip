@@ -483,9 +483,11 @@ int svh_feature_cost_volume(svh_context *ctx, int match_func, int disp_direction
 } // extern "C"
 
 static int unfold_cost_volume_impl(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r, int h_radius,
-                                   int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima, int *minima_written) {
+                                   int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima, int *minima_written,
+                                   svh_array *winner = nullptr, int *winner_written = nullptr) {
     if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
     if (minima_written) *minima_written = 0;
+    if (winner_written) *winner_written = 0;
     SVH_TRY(validate_image(ctx, img_l, "img_l", match_func));
     SVH_TRY(validate_image(ctx, img_r, "img_r", match_func));
     SVH_TRY(validate(ctx, cv, "cv", SVH_F32, 3, 3));
@@ -536,7 +538,24 @@ static int unfold_cost_volume_impl(svh_context *ctx, int match_func, int disp_di
         SVH_HIP_CHECK(ctx, hipMemsetAsync(red.flag, 0, sizeof(int), ctx->stream));
         a.reduce = &red;
     }
+    OutStage ow;
+    if (winner) { // the column-sum kernel picks extractSelectedIndex's index while it holds a pixel's costs (CostReduce mode 1) and stores the volume too
+        SVH_TRY(validate(ctx, winner, "winner", SVH_I32, 2, 2));
+        if (winner->shape[0] != a.H || winner->shape[1] != a.Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "winner must have shape (%d,%d)", a.H, a.Ws);
+        if (!func_census(match_func) && ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) {
+            SVH_TRY(stage_out(ctx, scr, *winner, &ow));
+            red.mode = 1;
+            red.score = func_strategy(match_func) != SVH_COST;
+            red.idx = (int32_t *)ow.dptr;
+            red.store = true;
+            a.reduce = &red;
+        }
+    }
     SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, isrc, itgt, h_radius, v_radius, (float *)os.dptr));
+    if (red.mode == 1 && red.done) {
+        SVH_TRY(finish_out(ctx, ow));
+        if (winner_written) *winner_written = 1;
+    }
     if (red.mode == 2 && red.done) {
         // one word back to the host: the statement is only made for a volume inside the regime (every finite |c| <= 1e30)
         int flag = 0;
@@ -559,6 +578,12 @@ int svh_unfold_cost_volume(svh_context *ctx, int match_func, int disp_direction,
 int svh_unfold_cost_volume_minima(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r, int h_radius,
                                   int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *minima, int *minima_written) {
     return unfold_cost_volume_impl(ctx, match_func, disp_direction, img_l, img_r, h_radius, v_radius, disp_lower, disp_count, cv, minima, minima_written);
+}
+
+int svh_unfold_cost_volume_winner(svh_context *ctx, int match_func, int disp_direction, const svh_array *img_l, const svh_array *img_r, int h_radius,
+                                  int v_radius, int32_t disp_lower, int32_t disp_count, svh_array *cv, svh_array *winner, int *winner_written) {
+    return unfold_cost_volume_impl(ctx, match_func, disp_direction, img_l, img_r, h_radius, v_radius, disp_lower, disp_count, cv, nullptr, nullptr, winner,
+                                   winner_written);
 }
 
 } // extern "C"

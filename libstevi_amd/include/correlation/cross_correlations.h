@@ -192,9 +192,21 @@ DeviceArray<TCV, 3> unfoldBasedCostVolumeOnDevice(Multidim::Array<T_L, nImDim> c
         }
         return cv;
     } else {
-        if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
-                                                     disp_width, &out)))
+        // a Score-strategy function (no regional minima to keep: the Score branch of sgmCostVolume has no use for them): keep the index a
+        // later extractSelectedIndex<Score> on the untouched volume would scan it for -- the reference benchmark's own sequence
+        // (benchmarkCrossCorrelationAlgorithms.cpp:92-96).  The library says whether the kernel that ran could pick it.
+        DeviceArray<int32_t, 2> winner({src[0], src[1]});
+        svh_array wi = HipBridge::describe(winner);
+        int written = 0;
+        if (!HipBridge::check(svh_unfold_cost_volume_winner(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius,
+                                                            0, disp_width, &out, &wi, &written)))
             return DeviceArray<TCV, 3>();
+        if (written) {
+            auto st = std::make_shared<typename DeviceArray<TCV, 3>::Statement>();
+            st->winner = winner.share();
+            st->winner_strategy = static_cast<int>(MatchingFunctionTraits<matchFunc>::extractionStrategy);
+            cv.attach(st);
+        }
         return cv;
     }
 }

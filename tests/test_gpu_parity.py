@@ -1049,3 +1049,27 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
     finally:
         sv.set_option(dev(img_l), "feature_volume_tiled", 1)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
+
+
+@pytest.mark.parametrize("func", [MF.NCC, MF.ZNCC, MF.CC, MF.ZCC, MF.SSD, MF.ZSSD, MF.SAD, MF.ZSAD, MF.CENSUS])
+def test_cost_volume_carries_its_winner(rng, func):
+    """unfoldBasedCostVolume(..., keep_winner=True): the kernel that writes the volume picks extractSelectedIndex's index while it holds a
+    pixel's costs (svh_unfold_cost_volume_winner), and extractSelectedIndex on the untouched tensor returns that map.  Equal to the scan
+    of the same volume (ties, both strategies, both directions, ranges that are no multiple of 16); functions without that kernel (ZSAD,
+    census) leave no statement and the scan runs; an in-place write withdraws it."""
+    strat = sv.matchFuncStrategy(func)
+    for (H, W, r, D, ddir) in [(23, 150, 2, 40, sv.dispDirection.RightToLeft), (17, 131, 3, 33, sv.dispDirection.LeftToRight), (9, 64, 1, 70, sv.dispDirection.RightToLeft)]:
+        left = np.round(rng.uniform(-2, 2, (H, W)) * 4).astype(np.float32) / 4  # (a coarse grid: ties between disparities)
+        right = np.round(rng.uniform(-2, 2, (H, W)) * 4).astype(np.float32) / 4
+        dl, dr = dev(left), dev(right)
+        plain = sv.unfoldBasedCostVolume(func, dl, dr, r, r, D, ddir)
+        kept = sv.unfoldBasedCostVolume(func, dl, dr, r, r, D, ddir, keep_winner=True)
+        assert_bits(kept, host(plain))
+        has = getattr(kept, "_svh_winner", None) is not None
+        assert has == (func not in (MF.ZSAD, MF.CENSUS))
+        want = host(sv.extractSelectedIndex(strat, plain))
+        assert np.array_equal(host(sv.extractSelectedIndex(strat, kept)), want)
+        assert np.array_equal(want, so.extract_index(host(plain), int(strat)))
+        if has:
+            kept.add_(1.0)  # an in-place write: the statement no longer describes the tensor
+            assert np.array_equal(host(sv.extractSelectedIndex(strat, kept)), so.extract_index(host(kept), int(strat)))

@@ -47,9 +47,17 @@ for res, (H, W, r, D) in RES.items():
             return sv.stereoMatch(func, d_tgt, d_src, r, r, D, sgmDirections=ndir, P1=0.001, P2=0.01, Pout=100.0)["disp"]
         t_chain, disp_c = timed(chain, n)
         t_fused, disp_f = timed(fused, n)
+        t_stmt = None
+        if not ndir:  # the volume carries its winner to extractSelectedIndex (what the C++ drop-in headers do for Score-strategy functions on DeviceArray; opt-in here)
+            def chain_stmt():
+                cv = sv.unfoldBasedCostVolume(func, d_tgt, d_src, r, r, D, keep_winner=True)
+                return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, cv), 0)
+            t_stmt, disp_s = timed(chain_stmt, n)
+            assert torch.equal(disp_s, disp_c)
         line = {"row": f"{res} {H}x{W} - {2 * r + 1}x{2 * r + 1} windows - disp {D}" + (f" - {ndir} directions" if ndir else "") + f" - {func.name.lower()}",
                 "benchmark": "benchmarkSemiGlobalAlgorithm" if ndir else "benchmarkLocalAlgorithm",
-                "ms_per_function_calls": round(t_chain * 1e3, 4), "ms_fused_call": round(t_fused * 1e3, 4),
+                "ms_per_function_calls": round(t_chain * 1e3, 4), "ms_per_function_calls_winner_carried": None if t_stmt is None else round(t_stmt * 1e3, 4),
+                "ms_fused_call": round(t_fused * 1e3, 4),
                 "Mdisparities_per_s_fused": round(W * H * D / t_fused / 1e6, 1), "maps_equal": bool(torch.equal(disp_c, disp_f))}
         if H < 1000:  # the oracle on the host threads (the whole frame)
             t0 = time.perf_counter()

@@ -288,6 +288,9 @@ struct SgmArgs {
     // Score branch: every cost is a finite number of magnitude about one (FiniteCostsQuery) and Pout is finite -- then every line state
     // stays finite and the isfinite filters of sgm.h:224, :241, :251 are no-ops: the kernels that are bound by instruction issue drop them
     bool costs_all_finite = false;
+    // Score branch: the cost volume's rows already have this pitch (the next multiple of 64 above D) with -inf behind the D costs
+    // (svh_stereo_match lets the cost kernel write that layout: dev_sgm_score_branch then skips its pad-in copy)
+    int cv_pitch = 0;
 };
 // The min_p maps of the six effective passes live in FIVE planes: passes 2 and 3 (the two start loops of UpLeft2DownRight, sgm.h:331-345)
 // partition the margin box along its diagonal -- pass 2 visits ip >= jp, pass 3 jp >= ip -- and the pixels both visit, the diagonal itself,
@@ -349,6 +352,8 @@ struct ScoreFinish {
 int dev_finish_records(svh_context *ctx, const float *records, int64_t npx, int refine_kernel, int disp_sign, int disp_offset, int32_t *idx,
                        int32_t *disp, float *refined);
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook = false, ScoreFinish *finish = nullptr);
+// -inf into the pads [D, pitch) of every row of a volume whose rows were written at that pitch
+int dev_sgm_fill_pads(svh_context *ctx, float *cv, int64_t n_rows, int D, int pitch);
 // Score branch, whole image, 8 directions, P2 >= P1 >= 0: the four downward passes as one sweep (svh_sgm_sweep.hip; form = the
 // "sgm_score_fused" option); *ran = false when the geometry is outside what the sweep covers.  The line kernel for one pass.
 int dev_sgm_score_sweep(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool vec, int form, bool *ran, ScoreFinish *finish = nullptr);

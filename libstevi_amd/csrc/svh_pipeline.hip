@@ -158,8 +158,13 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
             SVH_TRY(finish_out(ctx, o_disp));
             return SVH_OK;
         }
-        float *d_cv = cv ? (float *)o_cv.dptr : scr.get_n<float>(nvox);
+        // Score-branch SGM on a disparity count that is no multiple of 64 aggregates rows padded to whole lanes (dev_sgm_score_branch): when
+        // nobody wants the cost volume itself the cost kernel writes that layout directly (its output pitch) and only the pads are filled
+        const int DP = (D + 63) / 64 * 64;
+        const bool padded_cv = sgm && strategy != SVH_COST && !cv && ctx->sgm_score_pad && D > 64 && D < 512 && DP != D;
+        float *d_cv = cv ? (float *)o_cv.dptr : scr.get_n<float>(padded_cv ? (size_t)npx * DP : nvox);
         if (!d_cv) return SVH_ERR_OUT_OF_MEMORY;
+        if (padded_cv) cva_r.out_px_stride = DP;
         float *d_s = nullptr;
         if (sgm && strategy != SVH_COST) {
             d_s = sgm_cv ? (float *)o_sgm.dptr : scr.get_n<float>(nvox);
@@ -208,6 +213,10 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
                 fin.taps_v_r = prm->refine_v_radius;
                 fin.store_all = sgm_cv != nullptr;
                 sa.costs_all_finite = fq.known && fq.all_finite;
+                if (padded_cv) {
+                    SVH_TRY(dev_sgm_fill_pads(ctx, d_cv, npx, D, DP));
+                    sa.cv_pitch = DP;
+                }
                 SVH_TRY(dev_sgm_score_branch(ctx, scr, sa, d_cv, d_s, false, try_fused ? &fin : nullptr));
                 winner_done = try_fused && fin.done;
                 if (winner_done) {

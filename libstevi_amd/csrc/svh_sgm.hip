@@ -1611,6 +1611,23 @@ __global__ void __launch_bounds__(256) repitch_rows_kernel(const float *__restri
     }
 }
 
+__global__ void __launch_bounds__(256) fill_pads_kernel(float *__restrict__ cv, int64_t n_rows, int D, int pitch, float fill) {
+    const int pads = pitch - D;
+    const int64_t r0 = (int64_t)blockIdx.x * REPITCH_ROWS;
+    const int rows = (int)(n_rows - r0 < REPITCH_ROWS ? n_rows - r0 : REPITCH_ROWS);
+    for (int e = threadIdx.x; e < rows * pads; e += 256) {
+        const int r = e / pads;
+        cv[(r0 + r) * pitch + D + (e - r * pads)] = fill;
+    }
+}
+
+int dev_sgm_fill_pads(svh_context *ctx, float *cv, int64_t n_rows, int D, int pitch) {
+    if (n_rows <= 0 || pitch <= D) return SVH_OK;
+    SVH_LAUNCH(ctx, "sgm_pad_rows", fill_pads_kernel, (int)((n_rows + REPITCH_ROWS - 1) / REPITCH_ROWS), 256, 0, cv, n_rows, D, pitch, -INFINITY);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
 static int score_branch_dispatch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish);
 
 int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *out_sgm, bool textbook, ScoreFinish *finish) {
@@ -1624,15 +1641,19 @@ int dev_sgm_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const
     const int DP = (a.D + 63) / 64 * 64;
     if (!textbook && ctx->sgm_score_pad && a.D > 64 && a.D < 512 && DP != a.D) {
         const int64_t npx = (int64_t)a.H * a.W;
-        float *cvp = scr.get_n<float>((size_t)npx * DP), *sgp = scr.get_n<float>((size_t)npx * DP);
-        if (!cvp || !sgp) return SVH_ERR_OUT_OF_MEMORY;
+        const bool prepadded = a.cv_pitch == DP; // (the caller's cost kernel wrote the padded layout and filled the pads)
+        float *cvp = prepadded ? nullptr : scr.get_n<float>((size_t)npx * DP), *sgp = scr.get_n<float>((size_t)npx * DP);
+        if ((!prepadded && !cvp) || !sgp) return SVH_ERR_OUT_OF_MEMORY;
         const int grid = (int)((npx + REPITCH_ROWS - 1) / REPITCH_ROWS);
-        SVH_LAUNCH(ctx, "sgm_pad_rows", repitch_rows_kernel, grid, 256, 0, cv, npx, a.D, a.D, cvp, DP, -INFINITY);
-        SVH_CHECK_LAUNCH(ctx);
+        if (!prepadded) {
+            SVH_LAUNCH(ctx, "sgm_pad_rows", repitch_rows_kernel, grid, 256, 0, cv, npx, a.D, a.D, cvp, DP, -INFINITY);
+            SVH_CHECK_LAUNCH(ctx);
+        }
         SgmArgs ap = a;
         ap.D = DP;
+        ap.cv_pitch = 0;
         if (finish) finish->d_valid = a.D;
-        SVH_TRY(score_branch_dispatch(ctx, scr, ap, cvp, sgp, false, finish));
+        SVH_TRY(score_branch_dispatch(ctx, scr, ap, prepadded ? cv : cvp, sgp, false, finish));
         if (!finish || finish->store_all || !finish->done) { // somebody reads the aggregated volume
             SVH_LAUNCH(ctx, "sgm_pad_rows", repitch_rows_kernel, grid, 256, 0, sgp, npx, DP, a.D, out_sgm, a.D, 0.0f);
             SVH_CHECK_LAUNCH(ctx);

@@ -324,3 +324,30 @@ def test_winner_emitted_by_left2right_with_four_directions(rng, shape_d, func_na
                 assert np.array_equal(bits(a["sgm_cv"]), bits(b["sgm_cv"]))
     svol = so.sgm(a["cv"].cpu().numpy(), 4, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
     assert np.array_equal(a["disp"].cpu().numpy(), so.index_to_disp(so.extract_index(svol, so.SCORE)))
+
+
+@pytest.mark.parametrize("D", [100, 160, 330])
+@pytest.mark.parametrize("n_dir", [4, 8])
+def test_fused_call_writes_padded_rows_directly(rng, D, n_dir):
+    """svh_stereo_match, Score strategy, a disparity count that is no multiple of 64, nobody asking for the cost volume: the cost kernel
+    writes rows of the padded pitch itself and only the pads are filled (no pad-in copy).  Same disparity and refined maps as the call
+    that also returns the volumes (which aggregates a padded copy), and as the masked kernels."""
+    from helpers import parallax_pair
+    H, W = 37, 400
+    src, tgt, _ = parallax_pair(H, W, 12, 9, 100, 2, 9, seed=D + n_dir)
+    l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
+    kw = dict(sgmDirections=n_dir, P1=0.001, P2=0.01, Pout=100.0, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=2, refine_v_radius=2)
+    a = sv.stereoMatch(sv.matchingFunctions.ZNCC, l, r, 2, 2, D, **kw)
+    b = sv.stereoMatch(sv.matchingFunctions.ZNCC, l, r, 2, 2, D, want_cv=True, want_sgm_cv=True, **kw)
+    sv.set_option(l, "sgm_score_pad", 0)
+    try:
+        c = sv.stereoMatch(sv.matchingFunctions.ZNCC, l, r, 2, 2, D, **kw)
+    finally:
+        sv.set_option(l, "sgm_score_pad", 1)
+    for other in (b, c):
+        assert torch.equal(a["disp"], other["disp"])
+        ra, rb = a["refined"].cpu().numpy(), other["refined"].cpu().numpy()
+        assert np.array_equal(np.isnan(ra), np.isnan(rb)) and np.array_equal(bits(ra[~np.isnan(ra)]), bits(rb[~np.isnan(rb)]))
+    svol = so.sgm(b["cv"].cpu().numpy(), n_dir, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    assert np.array_equal(bits(b["sgm_cv"]), bits(svol))
+    assert np.array_equal(a["disp"].cpu().numpy(), so.index_to_disp(so.extract_index(svol, so.SCORE)))

@@ -340,24 +340,40 @@ __global__ void __launch_bounds__(64) pm_cols_kernel(OdVolume o, int inc, PmStat
 // candidate travels on) evaluates a cost on the spot, as every step used to (1.1 - 1.8 us each: the candidate decides which target
 // vector is loaded, so nothing of it can be fetched ahead).  Same tests in the same order on the same values: same result.
 // axis 0: row sweep (predecessor (i, j - inc)), 1: column sweep ((i - inc, j))
-__global__ void __launch_bounds__(64) pm_pred_cost_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid) {
+// Two launches: a thread per pixel settles the pixels whose predecessor holds the pixel's own solution (the cost is the pixel's own: most
+// pixels once regions agree) and lists the others; a wave per listed pixel evaluates its cost.  (A wave per pixel for both: 75 us per
+// pre-pass at 640x480 whatever the state of the solution -- two 64-bit divisions and three dependent loads per pixel before anything else.)
+__global__ void __launch_bounds__(256) pm_pred_classify_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid,
+                                                               int32_t *__restrict__ work, int *__restrict__ n_work) {
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= o.Ws) return;
+    const int64_t p = (int64_t)i * o.Ws + j;
+    const int pi = axis ? i - inc : i, pj = axis ? j : j - inc;
+    if (pi < 0 || pi >= o.Hs || pj < 0 || pj >= o.Ws) { // (no predecessor: never tested)
+        pcost[p] = 0.0f;
+        pvalid[p] = 0;
+        return;
+    }
+    const int64_t pp = (int64_t)pi * o.Ws + pj;
+    const int c0 = st.sol[pp * o.nd], c1 = o.nd == 2 ? st.sol[pp * o.nd + 1] : 0;
+    if (c0 == st.sol[p * o.nd] && (o.nd < 2 || c1 == st.sol[p * o.nd + 1])) { // the pixel's own solution: its own cost (the same evaluation)
+        pcost[p] = st.cost[p];
+        pvalid[p] = st.valid[p];
+    } else {
+        work[atomicAdd(n_work, 1)] = (int32_t)p; // (pixels < 2^31: checked by the host)
+    }
+}
+
+__global__ void __launch_bounds__(64) pm_pred_cost_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid,
+                                                          const int32_t *__restrict__ work, const int *__restrict__ n_work) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
-    const int64_t npx = (int64_t)o.Hs * o.Ws;
-    for (int64_t p = blockIdx.x; p < npx; p += gridDim.x) {
-        const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
-        const int pi = axis ? i - inc : i, pj = axis ? j : j - inc;
+    const int n = *n_work;
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int p = work[w];
+        const int j = p % o.Ws, i = p / o.Ws;
+        const int64_t pp = (int64_t)(axis ? i - inc : i) * o.Ws + (axis ? j : j - inc);
         float c = 0.0f;
-        bool ok = false;
-        if (pi >= 0 && pi < o.Hs && pj >= 0 && pj < o.Ws) { // (wave uniform)
-            const int64_t pp = (int64_t)pi * o.Ws + pj;
-            const int c0 = st.sol[pp * o.nd], c1 = o.nd == 2 ? st.sol[pp * o.nd + 1] : 0;
-            if (c0 == st.sol[p * o.nd] && (o.nd < 2 || c1 == st.sol[p * o.nd + 1])) { // the pixel's own solution: its own cost (the same evaluation)
-                c = st.cost[p];
-                ok = st.valid[p] != 0;
-            } else {
-                ok = wave_cost(o, i, j, c0, c1, pm_buf, &c);
-            }
-        }
+        const bool ok = wave_cost(o, i, j, st.sol[pp * o.nd], o.nd == 2 ? st.sol[pp * o.nd + 1] : 0, pm_buf, &c);
         if (threadIdx.x == 0) {
             pcost[p] = c;
             pvalid[p] = ok ? 1 : 0;
@@ -810,10 +826,14 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
         const int px_grid = (int)std::min<int64_t>(npx, 256 * 64); // a wave per pixel, grid-stride
         float *pcost = nullptr;
         uint8_t *pvalid = nullptr;
-        if (ctx->patchmatch_pred_costs) {
+        int32_t *work = nullptr;
+        int *n_work = nullptr;
+        if (ctx->patchmatch_pred_costs && npx < (1ll << 31) && in.H <= 65535) {
             pcost = scr.get_n<float>((size_t)npx);
             pvalid = scr.get_n<uint8_t>((size_t)npx);
-            if (!pcost || !pvalid) return SVH_ERR_OUT_OF_MEMORY;
+            work = scr.get_n<int32_t>((size_t)npx);
+            n_work = scr.get_n<int>(2);
+            if (!pcost || !pvalid || !work || !n_work) return SVH_ERR_OUT_OF_MEMORY;
         }
         SVH_LAUNCH(ctx, "patchmatch_init", pm_init_kernel, px_grid, 64, shmem, o, seed, st);
         for (; it < n_iter; it++) {
@@ -822,9 +842,13 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
             // (prefetching the next pixel's vectors under both outcomes of the current test was tried: no gain -- with one wave per
             // SIMD a step is bound by its ~150 dependent additions and the instructions around them, not by the loads)
             if (pcost) { // the cost of every pixel against its predecessor's solution, in parallel; then the sweep (pm_pred_cost_kernel)
-                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost, pvalid);
+                const dim3 cgrid(ceil_div(in.Ws, 256), in.H);
+                SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work, 0, 2 * sizeof(int), ctx->stream));
+                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 0, inc1, st, pcost, pvalid, work, n_work);
+                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost, pvalid, work, n_work);
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, shmem, o, inc1, st, pcost, pvalid, changes);
-                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost, pvalid);
+                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 1, inc0, st, pcost, pvalid, work, n_work + 1);
+                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost, pvalid, work, n_work + 1);
                 SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, shmem, o, inc0, st, pcost, pvalid, changes);
             } else {
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);

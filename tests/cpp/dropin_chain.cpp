@@ -92,6 +92,25 @@ int main(int argc, char **argv) {
                         return 6;
                     }
         }
+        { // a Score-strategy cost volume leaves unfoldBasedCostVolumeOnDevice with ITS winner (svh_unfold_cost_volume_winner): the reference
+          // benchmark's own sequence, unfoldBasedCostVolume -> extractSelectedIndex, returns a copy of that map; the scan gives the same indices
+            constexpr auto ncc = SC::matchingFunctions::NCC;
+            constexpr auto nstrat = SC::MatchingFunctionTraits<ncc>::extractionStrategy;
+            auto dN = SC::unfoldBasedCostVolumeOnDevice<ncc>(target, source, h_r, v_r, D);
+            if (!dN.statement() || !dN.statement()->winner) {
+                fprintf(stderr, "unfoldBasedCostVolumeOnDevice<NCC> left no winner statement\n");
+                return 7;
+            }
+            Multidim::Array<SC::disp_t, 2> byStatement = SC::extractSelectedIndex<nstrat>(dN).download();
+            dN.dropStatement();
+            Multidim::Array<SC::disp_t, 2> byScan = SC::extractSelectedIndex<nstrat>(dN).download();
+            for (int i = 0; i < byScan.shape()[0]; i++)
+                for (int j = 0; j < byScan.shape()[1]; j++)
+                    if (byScan.valueUnchecked(i, j) != byStatement.valueUnchecked(i, j)) {
+                        fprintf(stderr, "cost-volume winner statement differs from the scan at (%d, %d)\n", i, j);
+                        return 7;
+                    }
+        }
         Multidim::Array<SC::disp_t, 2> ddisp = SC::selectedIndexToDisp<SC::disp_t, SC::dispDirection::RightToLeft>(dIdx, 0).download();
         Multidim::Array<float, 2> dref =
             SC::refineDispCostInterpolation<SC::InterpolationKernel::Parabola>(SC::truncatedCostVolume(dSGM, dIdx, h_r, v_r, 1), dIdx).download();

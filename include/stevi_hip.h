@@ -159,10 +159,12 @@ const char *svh_last_error(const svh_context *ctx);
  * not ask for sgm_cv, only the costs a later pass reads are stored at all.  0: the separate kernels.  Same maps bit for bit
  * (tests/test_gpu_sgm_score_fused.py).
  * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
- * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  1: one sweep of the volume, a launch per band of 16
+ * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  2: one sweep of the volume, a launch per band of 16
  * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23
- * instead of 44 bytes per voxel over all passes).  0: one read-modify-write sweep per pass.
- * (3 = 1 with the 16-column strips forced that images narrower than about 3000 columns replace by 8-column ones: for the tests.)
+ * instead of 44 bytes per voxel over all passes).  0: one read-modify-write sweep per pass.  1 (default): whichever a model of the two
+ * predicts faster -- the bands walk the rows one dependent step after the other, so images of up to about a megapixel at moderate ranges
+ * (the reference's own 480x640 x 160 benchmark rows) run faster pass by pass; large volumes in bands.
+ * (3 = 2 with the 16-column strips forced that images narrower than about 3000 columns replace by 8-column ones: for the tests.)
  * Same bits in all of them; the parity tests cross-check them. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */

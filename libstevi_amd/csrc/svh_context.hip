@@ -463,8 +463,8 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         return SVH_OK;
     }
     if (strcmp(name, "sgm_score_fused") == 0) {
-        if (value != 0 && value != 1 && value != 3)
-            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (bands of rows), 3 (bands, 16-column strips forced)");
+        if (value < 0 || value > 3)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (automatic), 2 (bands of rows), 3 (bands, 16-column strips forced)");
         ctx->sgm_score_fused = value;
         return SVH_OK;
     }

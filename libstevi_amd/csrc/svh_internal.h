@@ -61,7 +61,7 @@ struct svh_context {
     bool cost_reduce_fused = true;     // svh_context_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
     bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
     bool sgm_score_finish_fused = true; // svh_context_set_option("sgm_score_finish_fused"): svh_stereo_match lets the Score branch's last writer of each pixel emit its winner / taps (0: extract_index + truncatedCostVolume read S back)
-    int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (1 bands, 3 bands with 16-column strips forced; 0: a launch per pass)
+    int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (2 bands, 3 bands with 16-column strips forced; 0: a launch per pass; 1: the faster of the two by a model)
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;
     std::map<std::string, svh::ProfStat> prof_stats;

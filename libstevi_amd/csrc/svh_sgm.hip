@@ -1499,7 +1499,21 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
         SVH_HIP_CHECK(ctx, hipMemcpyAsync(sgm, cv, (size_t)a.H * a.W * a.D * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (Hp <= 0 || Wp <= 0) return SVH_OK;
-    if (ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global) { // svh_sgm_sweep.hip: the four downward passes in one sweep
+    // The banded sweep moves 23 instead of 44 bytes per voxel but walks the rows one dependent step after the other (1.8 us + 10.5 ns per
+    // disparity and row, whatever the width, until the strips outnumber the CUs); a launch per pass keeps every line of a pass in flight and
+    // runs at what its bytes take (11.5 ns per thousand voxels) above a floor of 0.45 ms.  Images of up to about a megapixel at moderate
+    // ranges are faster pass by pass -- the reference's own SGM benchmark rows (480x640 x 160: 1.49 -> 0.97 ms), 720p x 128 1.96 -> 1.50,
+    // 1080p x 64 2.68 -> 2.05 -- larger volumes in bands (1080p x 256 4.9 against 6.4, C4).  The model picks (measured on 26 shapes; ties
+    // go to the bands, which also carry the winner records).  Option "sgm_score_fused" 3 forces the bands, 0 the passes.
+    bool bands = ctx->sgm_score_fused && !textbook && n_pass == 6 && whole && far_global;
+    if (bands && ctx->sgm_score_fused == 1 && a.D >= 64 && (int64_t)a.H * a.W >= 20000) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int strip = ceil_div(a.W, 16) * 4 < cus * 3 ? 8 : 16, rounds = ceil_div(ceil_div(a.W, strip), cus);
+        const double t_bands = (double)a.H * (1.8 + 0.0105 * a.D) * 1e-3 * rounds, t_passes = (double)a.H * a.W * a.D * 11.5e-9 + 0.45;
+        if (t_passes < 0.95 * t_bands) bands = false;
+    }
+    if (bands) { // svh_sgm_sweep.hip: the four downward passes in one sweep
         bool ran = false;
         SVH_TRY(dev_sgm_score_sweep(ctx, scr, a, cv, sgm, vec, ctx->sgm_score_fused, &ran, finish));
         if (ran) return SVH_OK;

@@ -22,7 +22,7 @@ def bits(x):
     return np.ascontiguousarray(x, np.float32).view(np.uint32)
 
 
-FORMS = [1, 3]  # 1: a launch per band of 16 rows (halos recomputed; 8-column strips at these widths), 3: the same with the 16-column
+FORMS = [2, 3]  # (1, the default, lets a model choose between 0 and 2) 2: a launch per band of 16 rows (halos recomputed; 8-column strips at these widths), 3: the same with the 16-column
 # strips of wide images
 
 
@@ -100,7 +100,7 @@ def test_fused_forms_on_random_geometries(seed):
         ok = ~np.isnan(exp)
         d = torch.from_numpy(cv).to(DEV)
         try:
-            for form in (0, 1, 3):
+            for form in (0, 1, 2, 3):
                 sv.set_option(d, "sgm_score_fused", form)
                 got = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout).cpu().numpy()
                 what = f"case {case} form {form}: {H}x{W}x{D} P1={P1} P2={P2} Pout={Pout}"
@@ -218,12 +218,16 @@ def test_all_finite_regime_drops_the_filters_and_nothing_else(func_name, flat_pa
         tgt[40:60, 100:140] = 0.0 if func_name == "NCC" else -0.5
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     kw = dict(sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=hr, refine_v_radius=hr)
-    a = sv.stereoMatch(func, l, r, hr, hr, D, want_cv=True, want_sgm_cv=True, **kw)
-    sv.set_option(l, "sgm_score_finish_fused", 0)
+    sv.set_option(l, "sgm_score_fused", 2)  # (the bands: the automatic choice runs a volume of this size pass by pass)
     try:
+        a = sv.stereoMatch(func, l, r, hr, hr, D, want_cv=True, want_sgm_cv=True, **kw)
+        sv.set_option(l, "sgm_score_finish_fused", 0)
         b = sv.stereoMatch(func, l, r, hr, hr, D, want_sgm_cv=True, **kw)
     finally:
         sv.set_option(l, "sgm_score_finish_fused", 1)
+        sv.set_option(l, "sgm_score_fused", 1)
+    auto = sv.stereoMatch(func, l, r, hr, hr, D, **kw)  # the default choice: the same maps
+    assert torch.equal(a["disp"], auto["disp"])
     assert torch.equal(a["disp"], b["disp"])
     sa, sb = a["sgm_cv"].cpu().numpy(), b["sgm_cv"].cpu().numpy()
     assert np.array_equal(np.isnan(sa), np.isnan(sb)) and np.array_equal(sa[~np.isnan(sa)].view(np.uint32), sb[~np.isnan(sb)].view(np.uint32))

@@ -1483,6 +1483,20 @@ int dev_sgm_cost_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const 
     return SVH_OK;
 }
 
+// winner records from a finished aggregated volume (rows of 64 R floats): what the launch-per-pass form leaves to do when no pass is the last
+// writer of every pixel (eight directions) -- one read of S instead of extract_index + truncatedCostVolume (+ the copy out of padded rows)
+template <int R>
+__global__ void __launch_bounds__(256) score_records_kernel(const float *__restrict__ sgm, int H, int W, ScoreFinish fin) {
+    const int lane = threadIdx.x & 63;
+    const int64_t npx = (int64_t)H * W;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < npx; p += (int64_t)gridDim.x * 4) {
+        float s[R];
+        lds_get<R>(sgm + p * (64 * R) + lane * R, s);
+        const int i = (int)(p / W), j = (int)(p - (int64_t)i * W);
+        wave_emit_record<false, R>(s, lane, i, j, H, W, fin.records, fin.taps_h_r, fin.taps_v_r, fin.d_valid > 0 ? fin.d_valid : 64 * R);
+    }
+}
+
 template <int R>
 static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, const float *cv, float *sgm, bool textbook = false, ScoreFinish *finish = nullptr) {
     const int Hp = a.H - a.top - a.bottom, Wp = a.W - a.left - a.right;
@@ -1557,6 +1571,13 @@ static int run_score_branch(svh_context *ctx, Scratch &scr, const SgmArgs &a, co
         }
 #undef SVH_SCORE
         SVH_CHECK_LAUNCH(ctx);
+    }
+    if constexpr (R <= 8) {
+        if (finish && finish->records && !finish->done && !textbook && whole && vec && a.D == 64 * R && (int64_t)a.H * a.W < (1ll << 29)) {
+            SVH_LAUNCH(ctx, "sgm_score_records", score_records_kernel<R>, grid_for((int64_t)a.H * a.W, 4, 65536), 256, 0, sgm, a.H, a.W, *finish);
+            SVH_CHECK_LAUNCH(ctx);
+            finish->done = true;
+        }
     }
     return SVH_OK;
 }

@@ -355,3 +355,48 @@ def test_fused_call_writes_padded_rows_directly(rng, D, n_dir):
     svol = so.sgm(b["cv"].cpu().numpy(), n_dir, so.SCORE, 0.001, 0.01, (0, 0, 0, 0), 100.0)
     assert np.array_equal(bits(b["sgm_cv"]), bits(svol))
     assert np.array_equal(a["disp"].cpu().numpy(), so.index_to_disp(so.extract_index(svol, so.SCORE)))
+
+
+@pytest.mark.parametrize("shape_d", [((40, 150), 64), ((33, 200), 128), ((30, 260), 192), ((25, 300), 160), ((21, 310), 100), ((1, 80), 64), ((50, 1), 64)])
+@pytest.mark.parametrize("func_name", ["NCC", "ZNCC"])
+def test_winner_records_from_the_volume_when_the_passes_ran(rng, shape_d, func_name):
+    """A launch per pass with eight directions (option "sgm_score_fused" 0; what the default picks for small volumes): no pass is the last
+    writer of every pixel, so one kernel reads the finished volume (padded rows included) and emits the winner records.  Equal to the
+    separate extract_index / truncatedCostVolume kernels, with and without the volume requested, and to the banded form."""
+    from helpers import parallax_pair
+    (H, W), D = shape_d
+    func = getattr(sv.matchingFunctions, func_name)
+    src, tgt, _ = parallax_pair(H, W, max(2, min(H, W) // 4), H // 4, W // 4, 2, 9, seed=H * 1000 + W + D)
+    l, r = torch.from_numpy(tgt[:H, :W].copy()).to(DEV), torch.from_numpy(src[:H, :W].copy()).to(DEV)
+    hr = 2
+
+    def run(form, fused, kernel, want_sgm_cv):
+        sv.set_option(l, "sgm_score_fused", form)
+        sv.set_option(l, "sgm_score_finish_fused", fused)
+        try:
+            sv.profile_reset(l)
+            sv.profile_enable(l, True)
+            out = sv.stereoMatch(func, l, r, hr, hr, D, sgmDirections=8, P1=0.001, P2=0.01, Pout=100.0, refineKernel=kernel, refine_h_radius=hr,
+                                 refine_v_radius=hr, want_sgm_cv=want_sgm_cv)
+            sv.profile_enable(l, False)
+            return out, sv.profile_collect(l)
+        finally:
+            sv.set_option(l, "sgm_score_fused", 1)
+            sv.set_option(l, "sgm_score_finish_fused", 1)
+
+    for kernel in (sv.InterpolationKernel.Parabola, None):
+        for want_sgm_cv in (False, True):
+            a, ka = run(0, 1, kernel, want_sgm_cv)
+            b, kb = run(0, 0, kernel, want_sgm_cv)
+            c, _ = run(2, 1, kernel, want_sgm_cv)
+            if D > 64 or D % 64 == 0:
+                assert "sgm_score_records" in ka and "extract_index" not in ka, ka.keys()
+            assert "extract_index" in kb
+            for other in (b, c):
+                assert torch.equal(a["disp"], other["disp"])
+                if kernel is not None:
+                    ra, rb = a["refined"].cpu().numpy(), other["refined"].cpu().numpy()
+                    assert np.array_equal(np.isnan(ra), np.isnan(rb))
+                    assert np.array_equal(bits(ra[~np.isnan(ra)]), bits(rb[~np.isnan(rb)]))
+                if want_sgm_cv:
+                    assert np.array_equal(bits(a["sgm_cv"]), bits(other["sgm_cv"]))

@@ -440,6 +440,35 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
     // grey images with windows up to 11x11: LDS-tiled, register-blocked kernel (svh_cost_volume_tiled.hip)
     const int st = a.literal ? SVH_ERR_UNSUPPORTED : dev_cost_volume_grey_tiled(ctx, scr, a, src, tgt, h_r, v_r, cv);
     if (st != SVH_ERR_UNSUPPORTED) return st;
+    // colour images whose tile (window rows x channels x the whole disparity range) is over the LDS budget: the same kernel on chunks of the
+    // range (the per-voxel kernel below walks and, for normalised functions, divides every sample of both windows of every voxel:
+    // 50 ms where this takes about one)
+    if (!a.literal && src.C > 1 && src.C <= 4 && src.C == tgt.C && a.n_dh == 1 && a.row_count == 0) {
+        CostVolumeArgs ac = a;
+        ac.reduce = nullptr;
+        int chunk = 0;
+        for (int dc = (a.D - 1) / 16 * 16; dc >= 16; dc -= 16) {
+            ac.D = dc;
+            if (cost_volume_colsum_applies(ctx, ac, src, tgt, h_r, v_r)) {
+                chunk = dc;
+                break;
+            }
+        }
+        if (chunk > 0) {
+            WindowStatsCache stats; // means / norms / zero-target costs do not depend on the chunk: computed by the first
+            stats.scr = &scr;
+            if (!ac.stats) ac.stats = &stats;
+            ac.out_px_stride = a.px_stride();
+            for (int d0 = 0; d0 < a.D; d0 += chunk) {
+                ac.D = std::min(chunk, a.D - d0);
+                ac.disp_lower = a.disp_lower + d0;
+                ac.out_off = a.out_off + d0;
+                const int sc = dev_cost_volume_grey_tiled(ctx, scr, ac, src, tgt, h_r, v_r, cv);
+                if (sc != SVH_OK) return sc == SVH_ERR_UNSUPPORTED ? fail(ctx, SVH_ERR_HIP, "internal: a chunk of the disparity range left the tiled kernel") : sc;
+            }
+            return SVH_OK;
+        }
+    }
     return cost_volume_generic(ctx, scr, a, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r},
                                FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, cv);
 }
@@ -527,7 +556,7 @@ static int unfold_cost_volume_impl(svh_context *ctx, int match_func, int disp_di
         SVH_TRY(stage_out(ctx, scr, *minima, &om));
         a.minima = (float *)om.dptr;
         a.minima_written = &written;
-    } else if (minima && func_strategy(match_func) == SVH_COST && ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) {
+    } else if (minima && func_strategy(match_func) == SVH_COST && ctx->cost_reduce_fused && C == 1 && cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) {
         // float costs of a Cost-strategy function: the column-sum kernel leaves the regional minima (CostReduce mode 2) and says whether a
         // magnitude left the regime in which the Cost branch's recurrences may run on them alone (svh_sgm.hip)
         SVH_TRY(stage_out(ctx, scr, *minima, &om));
@@ -542,7 +571,7 @@ static int unfold_cost_volume_impl(svh_context *ctx, int match_func, int disp_di
     if (winner) { // the column-sum kernel picks extractSelectedIndex's index while it holds a pixel's costs (CostReduce mode 1) and stores the volume too
         SVH_TRY(validate(ctx, winner, "winner", SVH_I32, 2, 2));
         if (winner->shape[0] != a.H || winner->shape[1] != a.Ws) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "winner must have shape (%d,%d)", a.H, a.Ws);
-        if (!func_census(match_func) && ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) {
+        if (!func_census(match_func) && ctx->cost_reduce_fused && C == 1 && cost_volume_colsum_applies(ctx, a, isrc, itgt, h_radius, v_radius)) { // (grey images: the reducing forms)
             SVH_TRY(stage_out(ctx, scr, *winner, &ow));
             red.mode = 1;
             red.score = func_strategy(match_func) != SVH_COST;

@@ -198,15 +198,19 @@ struct ColsumReduce {
 // every block of a range of 16 or more takes the 64-byte store path.  Both starts are even: an odd start makes every 8-byte LDS read
 // of the block misaligned (9 x 33 offsets with the last block at 17: 1.96 ms, against 1.27 for 9 x 34 with it at 18; a partial last
 // block instead of the early start: 1.41).  Ranges shorter than 16 are one partial block per offset.
-template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES, int RED, bool FOLD = false>
+// MC (round 4f): images of C interleaved channels (RGB).  A window's terms are the sum over its rows AND channels of the same per-column
+// terms, so the channels are staged as rows of their own -- tile row k C + c holds channel c of window row k -- and the kernel walks
+// (2 v_r + 1) C rows.  (Colour images took the per-voxel kernel: NCC 7x7 at 1080p x 128 52.7 ms where the grey image takes 0.4.)
+template <int CMP, bool ZM, bool NRM, int HR, int SIGN, int WAVES, int RED, bool FOLD = false, bool MC = false>
 __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_kernel(const float *__restrict__ src, const float *__restrict__ tgt, int H, int Ws, int Wt, int v_r,
                                                                  int D, int disp_lower, const float *__restrict__ mean_s,
                                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                  const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
-                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0, ColsumReduce rd, int n_dh) {
+                                                                 int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0, ColsumReduce rd, int n_dh, int C) {
+    static_assert(!(MC && FOLD), "colour images build 2-D volumes one vertical offset at a time");
     constexpr int DB = CS_DB, OUT = CS_COLS - 2 * HR;
     extern __shared__ float lds[];
-    const int v = 2 * v_r + 1;
+    const int v = MC ? (2 * v_r + 1) * C : 2 * v_r + 1; // rows the kernel walks (window rows x channels)
     const bool ext = FOLD && D > DB && (D & 1);       // the last block of an offset is seventeen wide
     const int nbw = (D - (ext ? 1 : 0) + DB - 1) / DB; // blocks of one vertical offset
     const int n_blocks = FOLD ? nbw * n_dh : nbw;
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
     float *stile = lds, *ttile = lds + v * CS_COLS, *tmean = ttile + tv * tw, *tinv = tmean + (ZM ? n_off * tw : 0); // (tmean / tinv: ZM / NRM only)
     float *xpose = tinv + (NRM ? n_off * tw : 0) + (threadIdx.x >> 6) * (64 * CS_XP); // this wave's area for turning 64 pixels x DB costs around
     const int i = row0 + blockIdx.y, p0 = blockIdx.x * OUT, xb = p0 - HR; // first output pixel, first column of the tile
-    const float c0 = (ZM && CMP == T_DOT) ? src[(int64_t)i * Ws + min(p0, Ws - 1)] : 0.0f; // keeps the zero-mean dot products small
+    const float c0 = (ZM && CMP == T_DOT) ? src[((int64_t)i * Ws + min(p0, Ws - 1)) * (MC ? C : 1)] : 0.0f; // keeps the zero-mean dot products small
     const int it = i + row_off; // target row (2-D disparity volumes); outside the image the target vector is zero
     const bool trow_in = it >= 0 && it < H;
     // tile index z of the target tile <-> image column: the index grows with the disparity in both directions
@@ -236,8 +240,9 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
             float val[4];
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const int rr = r0 + k0 + kk;
-                val[kk] = (k0 + kk < nr && col_in && rr >= 0 && rr < H) ? img[(int64_t)rr * Wi + col] : 0.0f;
+                const int wrow = MC ? (k0 + kk) / C : k0 + kk, ch = MC ? (k0 + kk) - wrow * C : 0; // (window row, channel) of tile row k0 + kk
+                const int rr = r0 + wrow;
+                val[kk] = (k0 + kk < nr && col_in && rr >= 0 && rr < H) ? img[MC ? ((int64_t)rr * Wi + col) * C + ch : (int64_t)rr * Wi + col] : 0.0f;
             }
 #pragma unroll
             for (int kk = 0; kk < 4; kk++)
@@ -575,17 +580,17 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
 // where three of four would: 16 instead of 12 waves per CU), four otherwise
 inline int colsum_waves(int D) { return (D + CS_DB - 1) / CS_DB >= 16 ? 8 : 4; }
 inline int colsum_waves(int D, int n_dh) { return n_dh * ((D + CS_DB - 1) / CS_DB) >= 16 ? 8 : 4; }
-inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm, int n_dh = 1) {
-    const int v = 2 * v_r + 1, nb = (D + CS_DB - 1) / CS_DB, tw = CS_COLS + nb * CS_DB;
+inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm, int n_dh = 1, int C = 1) {
+    const int v = (2 * v_r + 1) * C, nb = (D + CS_DB - 1) / CS_DB, tw = CS_COLS + nb * CS_DB;
     return (size_t)(v * CS_COLS + (v + n_dh - 1) * tw + (zm ? n_dh * tw : 0) + (nrm ? n_dh * tw : 0) + colsum_waves(D, n_dh) * 64 * CS_XP) * sizeof(float);
 }
 
 template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                                    const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
-    const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM, a.n_dh);
+    const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM, a.n_dh, a.C);
     ColsumReduce rd{};
     rd.store = 1;
-    if (a.reduce && a.reduce->mode && a.tgt_row_off == 0 && a.out_off == 0 && a.row_count == 0) { // (1-D volumes of whole images)
+    if (a.C == 1 && a.reduce && a.reduce->mode && a.tgt_row_off == 0 && a.out_off == 0 && a.row_count == 0) { // (1-D volumes of whole grey images)
         const CostReduce &r = *a.reduce;
         rd = ColsumReduce{r.mode, r.score ? 1 : 0, r.store ? 1 : 0, r.idx, r.disp, r.disp_sign, r.disp_offset, reinterpret_cast<float2 *>(r.minima), r.flag, r.big};
         a.reduce->done = true;
@@ -600,7 +605,19 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
             __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
         }                                                                                                                                          \
         SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD>), grid, 64 * WV, shmem, src, tgt, a.H,   \
-                   a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, a.n_dh); \
+                   a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, a.n_dh, 1); \
+    } while (0)
+#define SVH_CS_LAUNCH_MC(SG, WV)                                                                                                                    \
+    do {                                                                                                                                           \
+        static int big_lds[64] = {};                                                                                                               \
+        if (shmem > 64 * 1024 && !__atomic_load_n(&big_lds[ctx->device & 63], __ATOMIC_ACQUIRE)) {                                                 \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, false, true>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                     \
+            __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
+        }                                                                                                                                          \
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, false, true>), grid, 64 * WV, shmem, src, tgt, \
+                   a.H, a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, 1,   \
+                   a.C);                                                                                                                           \
     } while (0)
 #define SVH_CS_LAUNCH_R(SG, WV, RD) SVH_CS_LAUNCH_RF(SG, WV, RD, false)
 #define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
@@ -609,7 +626,15 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
         else if (rd.mode == 2) SVH_CS_LAUNCH_R(SG, WV, 2);                                                                                         \
         else SVH_CS_LAUNCH_R(SG, WV, 0);                                                                                                           \
     } while (0)
-    if (a.n_dh > 1) { // several vertical offsets of a 2-D volume in one launch (sign +1 there, no reductions)
+    if (a.C > 1) { // interleaved channels: their own instantiations (the grey kernels stay as they are, register for register)
+        if (colsum_waves(a.D) == 8) {
+            if (sign > 0) SVH_CS_LAUNCH_MC(1, 8);
+            else SVH_CS_LAUNCH_MC(-1, 8);
+        } else {
+            if (sign > 0) SVH_CS_LAUNCH_MC(1, 4);
+            else SVH_CS_LAUNCH_MC(-1, 4);
+        }
+    } else if (a.n_dh > 1) { // several vertical offsets of a 2-D volume in one launch (sign +1 there, no reductions)
         if (colsum_waves(a.D, a.n_dh) == 8) SVH_CS_LAUNCH_RF(1, 8, 0, true);
         else SVH_CS_LAUNCH_RF(1, 4, 0, true);
     } else if (colsum_waves(a.D) == 8) {
@@ -622,6 +647,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
 #undef SVH_CS_LAUNCH
 #undef SVH_CS_LAUNCH_R
 #undef SVH_CS_LAUNCH_RF
+#undef SVH_CS_LAUNCH_MC
 }
 template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                        const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
@@ -664,7 +690,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
                                              const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv,
                                              size_t shmem) {
     if constexpr (!(ZM && CMP == T_SAD)) { // separable terms: column sums shared by the windows that contain the column
-        if (ctx->cost_volume_colsum && colsum_shmem(v_r, a.D, ZM, ns != nullptr, a.n_dh) <= 78 * 1024) {
+        if (ctx->cost_volume_colsum && colsum_shmem(v_r, a.D, ZM, ns != nullptr, a.n_dh, a.C) <= 78 * 1024) {
             switch (h_r) {
             case 1: launch_colsum<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
             case 2: launch_colsum<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
@@ -675,7 +701,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
             }
         }
     }
-    if (shmem > 60 * 1024 || a.n_dh > 1) return false; // (only the column-sum kernel folds vertical offsets: cost_volume_colsum_applies)
+    if (shmem > 60 * 1024 || a.n_dh > 1 || a.C > 1) return false; // (only the column-sum kernel folds vertical offsets / takes channels: cost_volume_colsum_applies)
     switch (h_r) {
     case 1: launch_pxlane<CMP, ZM, 1>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
     case 2: launch_pxlane<CMP, ZM, 2>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
@@ -689,18 +715,24 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 } // namespace
 
 bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r) {
-    if (a.literal || src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
-    return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func), a.n_dh) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
+    if (a.literal || src.C != tgt.C || src.C < 1 || src.C > 4 || h_r < 1 || h_r > 5 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
+    if (src.C > 1 && a.n_dh > 1) return false; // (colour images: one vertical offset per launch)
+    return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func), a.n_dh, src.C) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
 }
 
 // Returns SVH_OK when the tiled kernel ran, SVH_ERR_UNSUPPORTED (without touching the context error) when the caller must
 // use the generic kernel (multi-channel images, windows wider than 11, tiles beyond the LDS budget).
-int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
-    if (src.C != 1 || tgt.C != 1 || h_r < 1 || h_r > 5 || func_census(a.func)) return SVH_ERR_UNSUPPORTED;
+int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a_in, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
+    if (h_r < 1 || h_r > 5 || func_census(a_in.func)) return SVH_ERR_UNSUPPORTED;
+    CostVolumeArgs a = a_in; // (+ the channel count: colour images take the column-sum kernel with the channels as rows, or nothing here)
+    a.C = src.C;
+    if (src.C != 1 || tgt.C != 1) {
+        if (!cost_volume_colsum_applies(ctx, a, src, tgt, h_r, v_r)) return SVH_ERR_UNSUPPORTED;
+    }
     const size_t shmem = pxlane_shmem(h_r, v_r, a.D);
     const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
     if (a.n_dh > 1 && !cost_volume_colsum_applies(ctx, a, src, tgt, h_r, v_r)) return SVH_ERR_UNSUPPORTED;
-    if (shmem > 60 * 1024 && (a.func == SVH_ZSAD || !ctx->cost_volume_colsum || colsum_shmem(v_r, a.D, zm, nrm, a.n_dh) > 78 * 1024)) return SVH_ERR_UNSUPPORTED;
+    if (shmem > 60 * 1024 && (a.func == SVH_ZSAD || !ctx->cost_volume_colsum || colsum_shmem(v_r, a.D, zm, nrm, a.n_dh, a.C) > 78 * 1024)) return SVH_ERR_UNSUPPORTED;
     if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
     const int cmp = (a.func == SVH_SSD || a.func == SVH_ZSSD) ? T_SSD : (a.func == SVH_SAD || a.func == SVH_ZSAD) ? T_SAD : T_DOT;
     const size_t ns_px = (size_t)a.H * a.Ws, nt_px = (size_t)a.H * a.Wt;
@@ -732,8 +764,8 @@ int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeA
             if (!odd) return SVH_ERR_OUT_OF_MEMORY;
             SVH_HIP_CHECK(ctx, hipMemsetAsync(odd, 0, sizeof(int), ctx->stream));
         }
-        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, 1, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk, sep, odd));
-        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, 1, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk, sep, odd));
+        SVH_TRY(launch_window_stats(ctx, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r}, zm, nrm, st.ms, st.ns, st.zc, cmpk, sep, odd));
+        if (zm || nrm) SVH_TRY(launch_window_stats(ctx, FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, zm, nrm, st.mt, st.nt, nullptr, cmpk, sep, odd));
         st.ready = true;
         if (odd) { // one word back, before the cost kernel is launched: the wait is for the two statistics kernels
             int h = 1;

@@ -251,6 +251,7 @@ struct CostVolumeArgs {
     // n_dh > 1: one launch takes the vertical offsets tgt_row_off .. tgt_row_off + n_dh - 1 (offset dh at out_off + dh D); only where
     // cost_volume_colsum_applies says the column-sum kernel runs
     int n_dh = 1;
+    int C = 1;                   // interleaved channels of the images (set by dev_cost_volume_grey_tiled)
     bool literal = false;        // skip the register-blocked kernel: the reference's operations in the reference's order
     WindowStatsCache *stats = nullptr; // optional: statistics maps shared by several passes over the same image pair
     // census / Hamming volumes: per pixel the smallest cost among the disparities that do not / do pay Pout in a later sgmCostVolume
@@ -270,6 +271,7 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
                                 int v_r, float *cv);
 int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv);
 // whether dev_cost_volume_grey_tiled would run the column-sum kernel for these arguments (the one that can serve a CostReduce)
+// (whether it can also serve a CostReduce: grey images only -- callers that hand it one check src.C == 1 themselves)
 bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r);
 // Hamming volume from compact census words (src exact, tgt already rounded through float)
 int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *src_words, const uint32_t *tgt_words, int nWw,

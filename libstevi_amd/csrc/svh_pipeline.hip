@@ -142,7 +142,7 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
         //   Cost-branch SGM: the two regional minima the line recurrences run on -- no probing read of the volume.
         CostReduce red;
         CostVolumeArgs cva_r = cva;
-        const bool colsum = ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, cva, isrc, itgt, prm->h_radius, prm->v_radius);
+        const bool colsum = ctx->cost_reduce_fused && isrc.C == 1 && cost_volume_colsum_applies(ctx, cva, isrc, itgt, prm->h_radius, prm->v_radius); // (the reducing forms of the kernel take grey images)
         const bool winner_in_cost = colsum && !sgm && !cv && !want_refine && !keys && disp && !sharded;
         const bool minima_in_cost = colsum && sgm && strategy == SVH_COST && ctx->sgm_cost_two_minima && !sharded;
         if (winner_in_cost) {

@@ -1073,3 +1073,31 @@ def test_cost_volume_carries_its_winner(rng, func):
         if has:
             kept.add_(1.0)  # an in-place write: the statement no longer describes the tensor
             assert np.array_equal(host(sv.extractSelectedIndex(strat, kept)), so.extract_index(host(kept), int(strat)))
+
+
+@pytest.mark.parametrize("func", [MF.NCC, MF.ZNCC, MF.CC, MF.ZCC, MF.SSD, MF.ZSSD, MF.SAD])
+def test_colour_images_through_the_column_sum_kernel(rng, func):
+    """Images of 2 - 4 interleaved channels (the reference's unfold takes nImDim = 3: unfold.h:292-344): the column-sum kernel stages the
+    channels as window rows of their own; ranges whose tile is over the LDS budget run in chunks.  Against the oracle (1e-4) and the
+    per-voxel kernel (option cost_volume_colsum 0): both directions, images wider than a tile, 3x3 - 7x7 windows, a chunked range,
+    disparities that leave the image, and the fused call's winner."""
+    for (H, W, C, r, D, ddir) in [(9, 150, 3, 2, 40, sv.dispDirection.RightToLeft), (7, 131, 3, 3, 70, sv.dispDirection.LeftToRight),
+                                   (6, 140, 2, 1, 33, sv.dispDirection.RightToLeft), (5, 129, 4, 2, 17, sv.dispDirection.LeftToRight),
+                                   (4, 300, 3, 3, 300, sv.dispDirection.RightToLeft)]:
+        left = rng.uniform(-1, 1, (H, W, C)).astype(np.float32)
+        right = rng.uniform(-1, 1, (H, W, C)).astype(np.float32)
+        dl, dr = dev(left), dev(right)
+        exp = so.unfold_cost_volume(int(func), left, right, r, r, D, int(ddir))
+        got = host(sv.unfoldBasedCostVolume(func, dl, dr, r, r, D, ddir))
+        sv.set_option(dl, "cost_volume_colsum", 0)
+        try:
+            per_voxel = host(sv.unfoldBasedCostVolume(func, dl, dr, r, r, D, ddir))
+        finally:
+            sv.set_option(dl, "cost_volume_colsum", 1)
+        for other in (exp, per_voxel):
+            assert np.array_equal(np.isnan(got), np.isnan(other)), (H, W, C, r, D)
+            ok = ~np.isnan(other)
+            assert np.all(np.abs(got[ok] - other[ok]) <= 1e-4 * np.maximum(1, np.abs(other[ok]))), (H, W, C, r, D)
+        strat = sv.matchFuncStrategy(func)
+        fused = sv.stereoMatch(func, dl, dr, r, r, D, dDir=ddir)["disp"]
+        assert np.array_equal(host(fused), so.index_to_disp(so.extract_index(got, int(strat)), int(ddir)))

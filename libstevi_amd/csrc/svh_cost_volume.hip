@@ -437,17 +437,15 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
         SVH_TRY(dev_census_pair_compact(ctx, src, tgt, h_r, v_r, nWw, sw, tw));
         return dev_hamming_volume(ctx, a, sw, tw, nWw, cv);
     }
-    // grey images with windows up to 11x11: LDS-tiled, register-blocked kernel (svh_cost_volume_tiled.hip)
-    const int st = a.literal ? SVH_ERR_UNSUPPORTED : dev_cost_volume_grey_tiled(ctx, scr, a, src, tgt, h_r, v_r, cv);
-    if (st != SVH_ERR_UNSUPPORTED) return st;
-    // colour images whose tile (window rows x channels x the whole disparity range) is over the LDS budget: the same kernel on chunks of the
-    // range (the per-voxel kernel below walks and, for normalised functions, divides every sample of both windows of every voxel:
-    // 50 ms where this takes about one)
-    if (!a.literal && src.C > 1 && src.C <= 4 && src.C == tgt.C && a.n_dh == 1 && a.row_count == 0) {
+    // Windows up to 15 wide on images of up to four channels: the column-sum kernel.  When its tile (window rows x channels x the whole
+    // disparity range) is over the LDS budget it runs on chunks of the range -- sooner than the per-window kernel (grey images, at half
+    // the rate) or the per-voxel kernel below (which walks and, for normalised functions, divides every sample of both windows of every
+    // voxel: 50 - 80 ms where the chunks take about one).
+    if (!a.literal && a.n_dh == 1 && a.row_count == 0 && !(a.reduce && a.reduce->mode) && !cost_volume_colsum_applies(ctx, a, src, tgt, h_r, v_r)) {
         CostVolumeArgs ac = a;
         ac.reduce = nullptr;
         int chunk = 0;
-        for (int dc = (a.D - 1) / 16 * 16; dc >= 16; dc -= 16) {
+        for (int dc = (a.D - 1) / 16 * 16; dc >= 64; dc -= 16) {
             ac.D = dc;
             if (cost_volume_colsum_applies(ctx, ac, src, tgt, h_r, v_r)) {
                 chunk = dc;
@@ -459,8 +457,9 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
             stats.scr = &scr;
             if (!ac.stats) ac.stats = &stats;
             ac.out_px_stride = a.px_stride();
-            for (int d0 = 0; d0 < a.D; d0 += chunk) {
-                ac.D = std::min(chunk, a.D - d0);
+            const int n_chunks = ceil_div(a.D, chunk), even = ceil_div(ceil_div(a.D, n_chunks), 16) * 16; // (chunks of about equal length)
+            for (int d0 = 0; d0 < a.D; d0 += even) {
+                ac.D = std::min(even, a.D - d0);
                 ac.disp_lower = a.disp_lower + d0;
                 ac.out_off = a.out_off + d0;
                 const int sc = dev_cost_volume_grey_tiled(ctx, scr, ac, src, tgt, h_r, v_r, cv);
@@ -469,6 +468,9 @@ int dev_cost_volume_from_images(svh_context *ctx, Scratch &scr, const CostVolume
             return SVH_OK;
         }
     }
+    // grey images with windows up to 11x11: LDS-tiled, register-blocked kernels (svh_cost_volume_tiled.hip)
+    const int st = a.literal ? SVH_ERR_UNSUPPORTED : dev_cost_volume_grey_tiled(ctx, scr, a, src, tgt, h_r, v_r, cv);
+    if (st != SVH_ERR_UNSUPPORTED) return st;
     return cost_volume_generic(ctx, scr, a, FeatImage{src.data, src.H, src.W, src.C, h_r, v_r},
                                FeatImage{tgt.data, tgt.H, tgt.W, tgt.C, h_r, v_r}, cv);
 }

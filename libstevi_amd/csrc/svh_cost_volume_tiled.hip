@@ -697,6 +697,8 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
             case 3: launch_colsum<CMP, ZM, 3>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
             case 4: launch_colsum<CMP, ZM, 4>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
             case 5: launch_colsum<CMP, ZM, 5>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true;
+            case 6: launch_colsum<CMP, ZM, 6>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true; // (13 and 15 wide: the per-voxel
+            case 7: launch_colsum<CMP, ZM, 7>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv); return true; //  kernel took 60 - 80 ms at 1080p x 128)
             default: return false;
             }
         }
@@ -708,6 +710,18 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
     case 3: launch_pxlane<CMP, ZM, 3>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
     case 4: launch_pxlane<CMP, ZM, 4>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
     case 5: launch_pxlane<CMP, ZM, 5>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem); return true;
+    case 6: // (13 and 15 wide: only ZSAD, which has no column-sum form, comes here with these)
+        if constexpr (ZM && CMP == T_SAD) {
+            launch_pxlane<CMP, ZM, 6>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
+            return true;
+        }
+        return false;
+    case 7:
+        if constexpr (ZM && CMP == T_SAD) {
+            launch_pxlane<CMP, ZM, 7>(ctx, a, src, tgt, v_r, sign, ms, mt, ns, nt, zc, cv, shmem);
+            return true;
+        }
+        return false;
     default: return false;
     }
 }
@@ -715,7 +729,7 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 } // namespace
 
 bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r) {
-    if (a.literal || src.C != tgt.C || src.C < 1 || src.C > 4 || h_r < 1 || h_r > 5 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
+    if (a.literal || src.C != tgt.C || src.C < 1 || src.C > 4 || h_r < 1 || h_r > 7 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
     if (src.C > 1 && a.n_dh > 1) return false; // (colour images: one vertical offset per launch)
     return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func), a.n_dh, src.C) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
 }
@@ -723,10 +737,10 @@ bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a,
 // Returns SVH_OK when the tiled kernel ran, SVH_ERR_UNSUPPORTED (without touching the context error) when the caller must
 // use the generic kernel (multi-channel images, windows wider than 11, tiles beyond the LDS budget).
 int dev_cost_volume_grey_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a_in, ImageDesc src, ImageDesc tgt, int h_r, int v_r, float *cv) {
-    if (h_r < 1 || h_r > 5 || func_census(a_in.func)) return SVH_ERR_UNSUPPORTED;
+    if (h_r < 1 || h_r > 7 || func_census(a_in.func)) return SVH_ERR_UNSUPPORTED;
     CostVolumeArgs a = a_in; // (+ the channel count: colour images take the column-sum kernel with the channels as rows, or nothing here)
     a.C = src.C;
-    if (src.C != 1 || tgt.C != 1) {
+    if (src.C != 1 || tgt.C != 1 || (h_r > 5 && a.func != SVH_ZSAD)) { // (colour images, windows 13 or 15 wide: the column-sum kernel or nothing here; ZSAD on grey images: the per-window kernel)
         if (!cost_volume_colsum_applies(ctx, a, src, tgt, h_r, v_r)) return SVH_ERR_UNSUPPORTED;
     }
     const size_t shmem = pxlane_shmem(h_r, v_r, a.D);

@@ -1101,3 +1101,24 @@ def test_colour_images_through_the_column_sum_kernel(rng, func):
         strat = sv.matchFuncStrategy(func)
         fused = sv.stereoMatch(func, dl, dr, r, r, D, dDir=ddir)["disp"]
         assert np.array_equal(host(fused), so.index_to_disp(so.extract_index(got, int(strat)), int(ddir)))
+
+
+@pytest.mark.parametrize("func", [MF.NCC, MF.ZNCC, MF.SSD, MF.ZSSD, MF.SAD, MF.ZSAD])
+def test_wide_windows_and_chunked_ranges_through_the_column_sum_kernel(rng, func):
+    """Windows 13 and 15 wide (h_radius 6, 7) and disparity ranges whose tile is over the LDS budget (run in chunks of the range) take
+    the column-sum kernel instead of the per-voxel one.  Against the oracle within 1e-4, both directions, non-square windows."""
+    for (H, W, h_r, v_r, D, ddir) in [(8, 150, 6, 6, 20, sv.dispDirection.RightToLeft), (9, 140, 7, 7, 33, sv.dispDirection.LeftToRight),
+                                       (7, 131, 7, 2, 17, sv.dispDirection.RightToLeft), (3, 260, 3, 3, 1100, sv.dispDirection.RightToLeft),
+                                       (4, 300, 5, 5, 700, sv.dispDirection.LeftToRight)]:
+        left = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+        right = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+        exp = so.unfold_cost_volume(int(func), left, right, h_r, v_r, D, int(ddir))
+        dl = dev(left)
+        sv.profile_reset(dl)
+        sv.profile_enable(dl, True)
+        got = host(sv.unfoldBasedCostVolume(func, dl, dev(right), h_r, v_r, D, ddir))
+        sv.profile_enable(dl, False)
+        assert "cost_volume_tiled" in sv.profile_collect(dl), (h_r, v_r, D)
+        assert np.array_equal(np.isnan(got), np.isnan(exp)), (H, W, h_r, v_r, D)
+        ok = ~np.isnan(exp)
+        assert np.all(np.abs(got[ok] - exp[ok]) <= 1e-4 * np.maximum(1, np.abs(exp[ok]))), (H, W, h_r, v_r, D)

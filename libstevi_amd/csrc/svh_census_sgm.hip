@@ -1026,7 +1026,9 @@ int launch_apply_select(svh_context *ctx, const CensusGeom &g, const ScanGeom &s
 
 } // namespace
 
-// largest nWw the pixel-per-lane kernels are instantiated for (11x11 windows and smaller; 9x9 -> 2 words)
+// largest nWw the pixel-per-lane kernels are instantiated for (11x11 windows and smaller; 9x9 -> 2 words).  Not more: the kernels pack a
+// cost into seven bits beside the index (costs <= 128 = 32 x 4 words); five words (13x13: costs up to 160) were tried in round 4f -- the
+// disparity map still agreed with the oracle on the test pair, the aggregated values did not -- and stay on the general kernels.
 static constexpr int kMaxWords = 4;
 
 // LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), at most 1024 disparities per

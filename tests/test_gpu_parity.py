@@ -1122,3 +1122,21 @@ def test_wide_windows_and_chunked_ranges_through_the_column_sum_kernel(rng, func
         assert np.array_equal(np.isnan(got), np.isnan(exp)), (H, W, h_r, v_r, D)
         ok = ~np.isnan(exp)
         assert np.all(np.abs(got[ok] - exp[ok]) <= 1e-4 * np.maximum(1, np.abs(exp[ok]))), (H, W, h_r, v_r, D)
+
+
+@pytest.mark.parametrize("h_r,v_r", [(6, 6), (6, 5), (7, 5)])
+def test_census_windows_of_five_words(rng, h_r, v_r):
+    """Census windows of five written words (13x13: 168 comparisons): the Hamming volume through the tiled kernel, and the census + SGM
+    pipeline -- on the general kernels there: the pixel-per-lane kernels pack costs of at most 128 -- against the oracle, bit for bit."""
+    from helpers import parallax_pair
+    H, W, D = 40, 150, 40
+    src, tgt, _ = parallax_pair(H, W, 12, 10, 40, 2, 9, seed=h_r * 10 + v_r)
+    dl, dr = dev(tgt), dev(src)
+    cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, v_r, D)
+    assert_bits(sv.unfoldBasedCostVolume(MF.CENSUS, dl, dr, h_r, v_r, D), cv)
+    for n_dir in (8, 4):
+        vol = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, (0, 0, 0, 0), 100.0)
+        want = so.index_to_disp(so.extract_index(vol, so.COST))
+        a = sv.stereoMatch(MF.CENSUS, dl, dr, h_r, v_r, D, sgmDirections=n_dir, P1=0.3, P2=0.9, want_sgm_cv=True)
+        assert np.array_equal(host(a["disp"]), want)
+        assert_bits(a["sgm_cv"], vol)

@@ -213,11 +213,11 @@ static int launch_cv(svh_context *ctx, bool zm, bool nrm, A src, A tgt, const fl
 // processed values, and the block stores them flat again.  (A thread per pixel reading its 17 floats straight from global memory, then a
 // second kernel: 0.34 + 0.11 ms for two 1080p x 17 volumes.)
 template <bool ZM, bool NORM>
-__global__ void __launch_bounds__(256) process_features_kernel(const float *__restrict__ f, int64_t npx, int F, float *__restrict__ out) {
+__global__ void __launch_bounds__(256) process_features_kernel(const float *__restrict__ f, int64_t npx, int F, float *__restrict__ out, int ppb) {
     extern __shared__ float pf_lds[];
     const int FS = F | 1;
-    const int64_t p0 = (int64_t)blockIdx.x * 256;
-    const int n_px = (int)(npx - p0 < 256 ? npx - p0 : 256), n = n_px * F;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb; // ppb <= 256 pixels per block: what the LDS budget holds of vectors this long
+    const int n_px = (int)(npx - p0 < ppb ? npx - p0 : ppb), n = n_px * F;
     const float *src = f + p0 * F;
     float *dst = out + p0 * F;
     for (int e = threadIdx.x; e < n; e += 256) {
@@ -314,8 +314,14 @@ __global__ void __launch_bounds__(256) feature_volume_tiled_kernel(const float *
 
 // SVH_ERR_UNSUPPORTED (nothing launched): the records do not fit the LDS budget
 static int cost_volume_features_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, const float *feat_src, const float *feat_tgt, int F, float *cv) {
-    const size_t shmem = ((size_t)(HV_TP + a.D - 1) * (F | 1) + (size_t)HV_TP * F) * sizeof(float);
-    if (!ctx->feature_volume_tiled || shmem > 60 * 1024 || (size_t)256 * (F | 1) * sizeof(float) > 60 * 1024 || a.H > 65535) return SVH_ERR_UNSUPPORTED;
+    if (!ctx->feature_volume_tiled || a.H > 65535 || F < 1) return SVH_ERR_UNSUPPORTED;
+    // the disparity range in chunks when the records of the whole range do not fit (long vectors: 9x9 unfolded features and more)
+    const size_t rec = (size_t)(F | 1) * sizeof(float), budget = 60 * 1024;
+    const int64_t max_rec = (int64_t)((budget - (size_t)HV_TP * F * sizeof(float)) / rec) - (HV_TP - 1); // disparities whose records fit beside the source vectors
+    if ((size_t)HV_TP * F * sizeof(float) >= budget || max_rec < 16) return SVH_ERR_UNSUPPORTED;
+    const int chunk = (int)std::min<int64_t>(a.D, max_rec >= 64 ? max_rec / 64 * 64 : max_rec);
+    const int ppb = (int)std::min<size_t>(256, budget / rec);
+    if (ppb < 32) return SVH_ERR_UNSUPPORTED;
     if ((int64_t)a.H * a.Ws * a.D == 0) return SVH_OK;
     const bool zm = func_zero_mean(a.func), nrm = func_normalized(a.func);
     const float *ps = feat_src, *pt = feat_tgt;
@@ -323,11 +329,11 @@ static int cost_volume_features_tiled(svh_context *ctx, Scratch &scr, const Cost
         const int64_t ns_px = (int64_t)a.H * a.Ws, nt_px = (int64_t)a.H * a.Wt;
         float *os = scr.get_n<float>((size_t)ns_px * F), *ot = scr.get_n<float>((size_t)nt_px * F);
         if (!os || !ot) return SVH_ERR_OUT_OF_MEMORY;
-        const size_t pshmem = (size_t)256 * (F | 1) * sizeof(float);
-#define SVH_PROCESS(ZMV, NRMV)                                                                                                                     \
-    do {                                                                                                                                           \
-        SVH_LAUNCH(ctx, "process_features", (process_features_kernel<ZMV, NRMV>), (int)((ns_px + 255) / 256), 256, pshmem, feat_src, ns_px, F, os); \
-        SVH_LAUNCH(ctx, "process_features", (process_features_kernel<ZMV, NRMV>), (int)((nt_px + 255) / 256), 256, pshmem, feat_tgt, nt_px, F, ot); \
+        const size_t pshmem = (size_t)ppb * rec;
+#define SVH_PROCESS(ZMV, NRMV)                                                                                                                          \
+    do {                                                                                                                                                \
+        SVH_LAUNCH(ctx, "process_features", (process_features_kernel<ZMV, NRMV>), (int)((ns_px + ppb - 1) / ppb), 256, pshmem, feat_src, ns_px, F, os, ppb); \
+        SVH_LAUNCH(ctx, "process_features", (process_features_kernel<ZMV, NRMV>), (int)((nt_px + ppb - 1) / ppb), 256, pshmem, feat_tgt, nt_px, F, ot, ppb); \
     } while (0)
         if (zm && nrm) SVH_PROCESS(true, true);
         else if (zm) SVH_PROCESS(true, false);
@@ -338,20 +344,25 @@ static int cost_volume_features_tiled(svh_context *ctx, Scratch &scr, const Cost
     }
     const dim3 grid(ceil_div(a.Ws, HV_TP), a.H);
     const int sign = a.sign();
-    switch (a.func) {
-    case SVH_CC: case SVH_NCC: case SVH_ZCC: case SVH_ZNCC:
-        SVH_LAUNCH(ctx, "feature_volume_tiled", feature_volume_tiled_kernel<CMP_DOT>, grid, 256, shmem, ps, pt, a.H, a.Ws, a.Wt, F, a.D, sign, a.disp_lower,
-                   a.tgt_row_off, a.px_stride(), a.out_off, cv);
-        break;
-    case SVH_SSD: case SVH_ZSSD:
-        SVH_LAUNCH(ctx, "feature_volume_tiled", feature_volume_tiled_kernel<CMP_SSD>, grid, 256, shmem, ps, pt, a.H, a.Ws, a.Wt, F, a.D, sign, a.disp_lower,
-                   a.tgt_row_off, a.px_stride(), a.out_off, cv);
-        break;
-    case SVH_SAD: case SVH_ZSAD:
-        SVH_LAUNCH(ctx, "feature_volume_tiled", feature_volume_tiled_kernel<CMP_SAD>, grid, 256, shmem, ps, pt, a.H, a.Ws, a.Wt, F, a.D, sign,
-                   a.disp_lower, a.tgt_row_off, a.px_stride(), a.out_off, cv);
-        break;
-    default: return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d is not available on the GPU path", a.func);
+    for (int d0 = 0; d0 < a.D; d0 += chunk) {
+        const int Dc = std::min(chunk, a.D - d0), lower = a.disp_lower + d0;
+        const int64_t off = a.out_off + d0;
+        const size_t shmem = ((size_t)(HV_TP + Dc - 1) * (F | 1) + (size_t)HV_TP * F) * sizeof(float);
+        switch (a.func) {
+        case SVH_CC: case SVH_NCC: case SVH_ZCC: case SVH_ZNCC:
+            SVH_LAUNCH(ctx, "feature_volume_tiled", feature_volume_tiled_kernel<CMP_DOT>, grid, 256, shmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off,
+                       a.px_stride(), off, cv);
+            break;
+        case SVH_SSD: case SVH_ZSSD:
+            SVH_LAUNCH(ctx, "feature_volume_tiled", feature_volume_tiled_kernel<CMP_SSD>, grid, 256, shmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off,
+                       a.px_stride(), off, cv);
+            break;
+        case SVH_SAD: case SVH_ZSAD:
+            SVH_LAUNCH(ctx, "feature_volume_tiled", feature_volume_tiled_kernel<CMP_SAD>, grid, 256, shmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off,
+                       a.px_stride(), off, cv);
+            break;
+        default: return fail(ctx, SVH_ERR_UNSUPPORTED, "matching function %d is not available on the GPU path", a.func);
+        }
     }
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;

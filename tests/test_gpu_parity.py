@@ -1024,7 +1024,10 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
     Same bits, and the oracle within the float tolerance: feature counts odd / even / one, both directions, target narrower and wider
     than the source, rows wider than a block, disparity ranges that leave the image, the reference's compressor chain (17 features)."""
     for (H, Ws, Wt, F, D, ddir) in [(9, 150, 150, 17, 40, sv.dispDirection.RightToLeft), (7, 130, 100, 16, 33, sv.dispDirection.LeftToRight),
-                                     (5, 70, 90, 1, 70, sv.dispDirection.RightToLeft), (6, 200, 200, 25, 128, sv.dispDirection.LeftToRight)]:
+                                     (5, 70, 90, 1, 70, sv.dispDirection.RightToLeft), (6, 200, 200, 25, 128, sv.dispDirection.LeftToRight),
+                                     # long vectors (9x9, 11x11 unfolded and more): the range in chunks, fewer pixels per processing block
+                                     (5, 100, 100, 81, 140, sv.dispDirection.RightToLeft), (4, 90, 80, 121, 70, sv.dispDirection.LeftToRight),
+                                     (3, 70, 70, 200, 33, sv.dispDirection.RightToLeft)]:
         fl = rng.uniform(-1, 1, (H, Wt if ddir == sv.dispDirection.RightToLeft else Ws, F)).astype(np.float32)
         fr = rng.uniform(-1, 1, (H, Ws if ddir == sv.dispDirection.RightToLeft else Wt, F)).astype(np.float32)
         dl, dr = dev(fl), dev(fr)

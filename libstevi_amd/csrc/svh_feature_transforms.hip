@@ -77,9 +77,14 @@ int channel_statistic(svh_context *ctx, int which, const svh_array *feat, const 
         } else if (which == 1) {
             SVH_TRY(launch_stats(ctx, fv, H, W, false, true, (float *)nullptr, (float *)os.dptr));
         } else if (dm) {
-            SVH_LAUNCH(ctx, "window_stats", channels_norm_given_kernel, grid_for(npx, 256, 16384), 256, 0, (const float *)df, (const float *)dm, npx, F,
-                       (float *)os.dptr);
-            SVH_CHECK_LAUNCH(ctx);
+            const int st = launch_stats(ctx, fv, H, W, false, true, (float *)nullptr, (float *)os.dptr, (const float *)dm); // (the mean is given)
+            if (st == SVH_ERR_UNSUPPORTED) {
+                SVH_LAUNCH(ctx, "window_stats", channels_norm_given_kernel, grid_for(npx, 256, 16384), 256, 0, (const float *)df, (const float *)dm, npx, F,
+                           (float *)os.dptr);
+                SVH_CHECK_LAUNCH(ctx);
+            } else if (st != SVH_OK) {
+                return st;
+            }
         } else {
             float *m = scr.get_n<float>((size_t)npx);
             if (!m) return SVH_ERR_OUT_OF_MEMORY;

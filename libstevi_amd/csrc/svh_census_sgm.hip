@@ -126,6 +126,17 @@ template <int NW> __device__ __forceinline__ void load_pair(const uint32_t *lds,
         const uint2 a = *reinterpret_cast<const uint2 *>(lds + 6 * m), b = *reinterpret_cast<const uint2 *>(lds + 6 * m + 2),
                     c = *reinterpret_cast<const uint2 *>(lds + 6 * m + 4);
         lo.w[0] = a.x; lo.w[1] = a.y; lo.w[2] = b.x; hi.w[0] = b.y; hi.w[1] = c.x; hi.w[2] = c.y;
+    } else if constexpr (NW > 4) {
+        // pairs of 2 NW words start on 8-byte boundaries: NW reads of two words
+        const uint2 *p = reinterpret_cast<const uint2 *>(lds + 2 * NW * m);
+        uint32_t t[2 * NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const uint2 q = p[w];
+            t[2 * w] = q.x; t[2 * w + 1] = q.y;
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) { lo.w[w] = t[w]; hi.w[w] = t[NW + w]; }
     } else {
         lo.w[0] = 0; hi.w[0] = 0;
     }
@@ -1026,10 +1037,9 @@ int launch_apply_select(svh_context *ctx, const CensusGeom &g, const ScanGeom &s
 
 } // namespace
 
-// largest nWw the pixel-per-lane kernels are instantiated for (11x11 windows and smaller; 9x9 -> 2 words).  Not more: the kernels pack a
-// cost into seven bits beside the index (costs <= 128 = 32 x 4 words); five words (13x13: costs up to 160) were tried in round 4f -- the
-// disparity map still agreed with the oracle on the test pair, the aggregated values did not -- and stay on the general kernels.
-static constexpr int kMaxWords = 4;
+// largest nWw the pixel-per-lane kernels are instantiated for (15x15 windows and smaller; 9x9 -> 2 words, 13x13 -> 5, 15x15 -> 7: costs
+// up to 256 sit in the keys' 19 cost bits).  Five words and more run the VALU sweep (the matrix-core sweeps stop at four words).
+static constexpr int kMaxWords = 8;
 
 // LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), at most 1024 disparities per
 // call, 4096 over all shards (12 index bits in the winner key), costs <= 128
@@ -1052,6 +1062,10 @@ bool census_exact_regime(const SgmArgs &a, int nWw) {
     case 2: return CALL(2);                                                                     \
     case 3: return CALL(3);                                                                     \
     case 4: return CALL(4);                                                                     \
+    case 5: return CALL(5);                                                                     \
+    case 6: return CALL(6);                                                                     \
+    case 7: return CALL(7);                                                                     \
+    case 8: return CALL(8);                                                                     \
     default: return fail(ctx, SVH_ERR_UNSUPPORTED, "census lane kernels: %d words", nWw);       \
     }
 

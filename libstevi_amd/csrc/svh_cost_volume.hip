@@ -404,13 +404,16 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
     int64_t n = (int64_t)a.H * a.Ws * a.D;
     if (n == 0) return SVH_OK;
     int sign = a.sign();
-    if (nWw >= 1 && nWw <= 5 && (size_t)nWw * (2 * HV_TP + a.D - 1) * sizeof(uint32_t) <= 60 * 1024) {
+    if (nWw >= 1 && nWw <= 8 && (size_t)nWw * (2 * HV_TP + a.D - 1) * sizeof(uint32_t) <= 60 * 1024) {
         switch (nWw) {
         case 1: launch_hamming_tiled<1>(ctx, a, src_words, tgt_words, sign, cv); break;
         case 2: launch_hamming_tiled<2>(ctx, a, src_words, tgt_words, sign, cv); break;
         case 3: launch_hamming_tiled<3>(ctx, a, src_words, tgt_words, sign, cv); break;
         case 4: launch_hamming_tiled<4>(ctx, a, src_words, tgt_words, sign, cv); break;
-        default: launch_hamming_tiled<5>(ctx, a, src_words, tgt_words, sign, cv); break;
+        case 5: launch_hamming_tiled<5>(ctx, a, src_words, tgt_words, sign, cv); break;
+        case 6: launch_hamming_tiled<6>(ctx, a, src_words, tgt_words, sign, cv); break;
+        case 7: launch_hamming_tiled<7>(ctx, a, src_words, tgt_words, sign, cv); break;
+        default: launch_hamming_tiled<8>(ctx, a, src_words, tgt_words, sign, cv); break;
         }
         SVH_CHECK_LAUNCH(ctx);
         if (a.minima_written) *a.minima_written = a.minima != nullptr;

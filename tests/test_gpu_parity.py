@@ -1127,10 +1127,11 @@ def test_wide_windows_and_chunked_ranges_through_the_column_sum_kernel(rng, func
         assert np.all(np.abs(got[ok] - exp[ok]) <= 1e-4 * np.maximum(1, np.abs(exp[ok]))), (H, W, h_r, v_r, D)
 
 
-@pytest.mark.parametrize("h_r,v_r", [(6, 6), (6, 5), (7, 5)])
+@pytest.mark.parametrize("h_r,v_r", [(6, 6), (6, 5), (7, 5), (7, 6), (7, 7), (9, 7), (8, 8)])
 def test_census_windows_of_five_words(rng, h_r, v_r):
-    """Census windows of five written words (13x13: 168 comparisons): the Hamming volume through the tiled kernel, and the census + SGM
-    pipeline -- on the general kernels there: the pixel-per-lane kernels pack costs of at most 128 -- against the oracle, bit for bit."""
+    """Census windows of five to eight written words (13x13: 168 comparisons, 15x15: 224, 19x15: 284) and one of nine (17x17, the general
+    kernels): the Hamming volume through the tiled kernel, and the census + SGM pipeline (the pixel-per-lane kernels with long records;
+    float and integer penalties) against the oracle, bit for bit."""
     from helpers import parallax_pair
     H, W, D = 40, 150, 40
     src, tgt, _ = parallax_pair(H, W, 12, 10, 40, 2, 9, seed=h_r * 10 + v_r)
@@ -1143,3 +1144,9 @@ def test_census_windows_of_five_words(rng, h_r, v_r):
         a = sv.stereoMatch(MF.CENSUS, dl, dr, h_r, v_r, D, sgmDirections=n_dir, P1=0.3, P2=0.9, want_sgm_cv=True)
         assert np.array_equal(host(a["disp"]), want)
         assert_bits(a["sgm_cv"], vol)
+        vol = so.sgm(cv, n_dir, so.COST, 3.0, 17.0, (0, 0, 0, 0), 100.0)
+        want = so.index_to_disp(so.extract_index(vol, so.COST))
+        a = sv.stereoMatch(MF.CENSUS, dl, dr, h_r, v_r, D, sgmDirections=n_dir, P1=3.0, P2=17.0, want_sgm_cv=True)
+        assert np.array_equal(host(a["disp"]), want)
+        assert_bits(a["sgm_cv"], vol)
+        assert np.array_equal(host(sv.stereoMatch(MF.CENSUS, dl, dr, h_r, v_r, D, sgmDirections=n_dir, P1=3.0, P2=17.0)["disp"]), want)

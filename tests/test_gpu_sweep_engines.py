@@ -145,3 +145,38 @@ def test_geometries_outside_the_matrix_core_kernel_still_run():
     for bad in (2, 4):  # (2 was round 1's int8 matrix-core engine: removed)
         with pytest.raises(sv._capi.SvhError):
             sv.set_option(l, "census_sweep", bad)
+
+
+@pytest.mark.parametrize("D", [33, 50, 100, 250, 333])
+@pytest.mark.parametrize("W", [97, 420])
+def test_ranges_that_are_no_multiple_of_32(D, W):
+    """The matrix cores take the leading multiple of 32 disparities, the vector ALU the rest as a second disparity shard whose keys are
+    MIN-merged into the first part's (launch_sweep): the same keys as the vector ALU alone over the whole range, both directions, whole
+    ranges, shards and ranges that start below zero; the oracle's disparities."""
+    src, tgt, _ = parallax_pair(11, W, 9, 3, min(40, W // 3), 2, 13, seed=5 * D + W)
+    l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
+    for h_r, n_dir, Pout in ((4, 8, 100.0), (3, 4, 7.0), (5, 8, 100.0)):
+        for shard in ((0, D), (7, D - 7)):
+            keys = both_engines(lambda: sv.censusShardKeys(l, r, h_r, h_r, D, shard, sgmDirections=n_dir, Pout=Pout).cpu().numpy(), l)
+            assert all(np.array_equal(keys[0], k) for k in keys[1:]), (h_r, n_dir, shard)
+        res = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, h_r, h_r, D, sgmDirections=n_dir, Pout=Pout, want_sgm_cv=D <= 100), l)
+        assert all(torch.equal(res[0]["disp"], o["disp"]) for o in res[1:])
+        if W <= 97 or D <= 100:
+            cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, h_r, D, so.RIGHT_TO_LEFT, 0)
+            vol = so.sgm(cv, n_dir, so.COST, 0.001, 0.01, (0, 0, 0, 0), Pout)
+            assert np.array_equal(res[-1]["disp"].cpu().numpy(), so.extract_index(vol, so.COST))
+            if D <= 100:
+                assert np.array_equal(res[-1]["sgm_cv"].cpu().numpy().view(np.uint32), vol.view(np.uint32))
+    rng_ = sv.searchOffset1(-17, D - 18)
+    keys = both_engines(lambda: sv.censusShardKeys(l, r, 4, 4, rng_, (0, D), sgmDirections=8).cpu().numpy(), l)
+    assert all(np.array_equal(keys[0], k) for k in keys[1:])
+    # LeftToRight (roles swapped: the left image is the source)
+    L2R = sv.dispDirection.LeftToRight
+    keys = both_engines(lambda: sv.censusShardKeys(r, l, 4, 4, D, (0, D), dDir=L2R, sgmDirections=8).cpu().numpy(), l)
+    assert all(np.array_equal(keys[0], k) for k in keys[1:])
+    disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, r, l, 4, 4, D, dDir=L2R, sgmDirections=8)["disp"].cpu().numpy(), l)
+    assert all(np.array_equal(disp[0], d) for d in disp[1:])
+    if W <= 97 or D <= 100:
+        cv = so.unfold_cost_volume(so.CENSUS, src, tgt, 4, 4, D, so.LEFT_TO_RIGHT)
+        vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+        assert np.array_equal(disp[-1], so.index_to_disp(so.extract_index(vol, so.COST), so.LEFT_TO_RIGHT))

@@ -18,3 +18,14 @@ for r in (4, 5, 6, 7):
         torch.cuda.synchronize()
         print(json.dumps({"r": r, "shortcut": short, "ms": round((time.perf_counter() - t0) * 100, 3), "sum": int(o["disp"].double().sum().item())}), flush=True)
 sv.set_option(ds, "census_winner_shortcut", 1)
+# disparity counts that are no multiple of 32 (the matrix cores take the leading multiple, the vector ALU the rest)
+for D in (256, 250, 200, 128, 120, 100):
+    for short in (1, 0):
+        sv.set_option(ds, "census_winner_shortcut", short)
+        f = lambda: sv.stereoMatch(MF.CENSUS, dt_, ds, 4, 4, D, sgmDirections=8)
+        f(); f(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10): o = f()
+        torch.cuda.synchronize()
+        print(json.dumps({"D": D, "shortcut": short, "ms": round((time.perf_counter() - t0) * 100, 3), "sum": int(o["disp"].double().sum().item())}), flush=True)
+sv.set_option(ds, "census_winner_shortcut", 1)

@@ -1028,7 +1028,7 @@ template <int NW> int launch_sweep(svh_context *ctx, const CensusGeom &g, float 
         if (launch_sweep_pm(ctx, g, Pout, keys, gmap, &status)) return status;
         // a disparity count that is no multiple of 32: the matrix cores take the leading multiple, the vector ALU the D % 32 disparities
         // behind it as a second disparity shard (global indices in the keys, MIN-merged into the first part's: D = 250 at 1080p 0.13 -> 0.09 ms)
-        const int D32 = g.D & ~31;
+        const int D32 = std::min(g.D & ~31, 992); // (also ranges longer than the matrix-core sweep's 992)
         if (D32 >= 32 && D32 < g.D) {
             CensusGeom ga = g;
             ga.D = D32;

@@ -99,8 +99,8 @@ const char *svh_last_error(const svh_context *ctx);
  * for census costs too (same results, used by the parity tests to cross-check the two implementations).
  * "census_sweep" (default 0 = automatic): engine of the voxel sweep of the fused census pipeline, 1 = the vector-ALU kernel
  * (xor + popcount), 3 = the matrix-core kernels with FP4 operands (Hamming distance as a dot product; at most 4 census words,
- * disp_count a multiple of 32 up to 992 -- anything else runs the vector-ALU kernel); automatic = 3 where it applies.  Same keys bit
- * for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
+ * disp_count a multiple of 32 up to 992 -- of any other count they take the leading multiple and the vector-ALU kernel the rest, merged
+ * by MIN; five to eight census words run the vector-ALU kernel alone); automatic = 3 where it applies.  Same keys bit for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
  * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
  * (64 / 128 / 256 / 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
  * (Development A/Bs of that kernel, same keys again: 2 = column-major tile order everywhere; 3 = neighbouring column tiles per wave also
@@ -468,7 +468,7 @@ int svh_stereo_match(svh_context *ctx, const svh_stereo_params *params, const sv
  *   (half the bytes; reducing both is still correct)
  *   svh_census_shard_finish -> SGM line recurrences from the reduced keys + winner: disp (H,W) i32 [, refined (H,W) f32]
  * The result is bit-identical to the single-GPU svh_stereo_match.  Census / Hamming costs in the integer-exact regime
- * only (integer Pout, window <= 11x11, <= 1024 disparities per shard, <= 4096 in total); otherwise SVH_ERR_UNSUPPORTED:
+ * only (integer Pout, window <= 15x15 = at most 8 census words, <= 1024 disparities per shard, <= 4096 in total); otherwise SVH_ERR_UNSUPPORTED:
  * the Score branch and non-integer costs couple the disparities along every path step and do not shard. */
 int svh_census_shard_keys(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                           svh_array *keys);

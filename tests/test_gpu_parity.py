@@ -1150,3 +1150,11 @@ def test_census_windows_of_five_words(rng, h_r, v_r):
         assert np.array_equal(host(a["disp"]), want)
         assert_bits(a["sgm_cv"], vol)
         assert np.array_equal(host(sv.stereoMatch(MF.CENSUS, dl, dr, h_r, v_r, D, sgmDirections=n_dir, P1=3.0, P2=17.0)["disp"]), want)
+    if (2 * h_r + 1) * (2 * v_r + 1) - 1 < 9 * 32:  # disparity shards (uneven, one of them no multiple of 32): keys merged by MIN, then the finish
+        kw = dict(sgmDirections=8, P1=3.0, P2=17.0)
+        keys = None
+        for b, n in ((0, 17), (17, D - 17)):
+            k = sv.censusShardKeys(dl, dr, h_r, v_r, D, (b, n), **kw)
+            keys = k if keys is None else torch.minimum(keys, k)
+        vol = so.sgm(cv, 8, so.COST, 3.0, 17.0, (0, 0, 0, 0), 100.0)
+        assert np.array_equal(host(sv.censusShardFinish(dl, dr, keys, h_r, v_r, D, **kw)["disp"]), so.index_to_disp(so.extract_index(vol, so.COST)))

@@ -125,6 +125,35 @@ def test_c3_census_sgm_1080p(c3_pair):
     assert (disp[inner] == gt[inner]).mean() > 0.6
 
 
+@pytest.mark.parametrize("h_r,D", [(4, 250), (4, 1000), (6, 256), (7, 100)])
+def test_census_sgm_1080p_ranges_and_windows_off_the_benchmark_shape(c3_pair, h_r, D):
+    """1080p with disparity counts that are no multiple of 32 (the range split between the matrix cores and the vector ALU), beyond 992,
+    and windows of five / seven census words (pixel-per-lane kernels with long records): the winner-identity form, the form with the
+    recurrences run and the vector-ALU sweep alone give one disparity map and the same reduction keys; where the oracle finishes in seconds
+    (D <= 256) the map, S at the winner and the Gaussian-refined map agree with its aggregated volume of the whole frame."""
+    src, tgt, _ = c3_pair
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    fast = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, h_r, D, sgmDirections=8)["disp"]
+    try:
+        sv.set_option(d_tgt, "census_winner_shortcut", 0)
+        run = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, h_r, D, sgmDirections=8, want_keys=True, refineKernel=so.GAUSSIAN, refine_h_radius=h_r,
+                             refine_v_radius=h_r)
+        sv.set_option(d_tgt, "census_sweep", 1)  # the vector ALU alone over the whole range
+        valu = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, h_r, D, sgmDirections=8, want_keys=True)
+    finally:
+        sv.set_option(d_tgt, "census_winner_shortcut", 1)
+        sv.set_option(d_tgt, "census_sweep", 0)
+    assert torch.equal(run["disp"], fast) and torch.equal(valu["disp"], fast)
+    assert torch.equal(run["keys"], valu["keys"])
+    if D <= 256:
+        from test_gpu_census_tiles import oracle_checks
+        cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, h_r, D)
+        vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+        del cv
+        assert int(np.count_nonzero(fast.cpu().numpy() != so.index_to_disp(so.extract_index(vol, so.COST)))) == 0
+        oracle_checks(run, vol, h_r, f"1080p, {2 * h_r + 1} wide, D = {D}")
+
+
 def test_c1_sad_480x360_full_vs_oracle():
     """Config 1 (480x360, SAD 5x5, D=64) is small enough to run the oracle in full."""
     src, tgt, gt = parallax_pair(360, 480, 120, 120, 120, 4, 24, seed=1)

@@ -106,6 +106,36 @@ def test_census_transform_special_values(rng, h_r):
     assert_bits(res["cv"], cv)
 
 
+@pytest.mark.parametrize("h_r,channels", [(2, 3), (3, 3), (4, 3), (6, 1), (7, 1)])
+def test_census_transform_fixed_windows(rng, h_r, channels):
+    """Colour images (5x5, 7x7, 9x9 RGB) and grey windows 13 / 15 wide take census_fixed_kernel (four output rows per block from one staged
+    tile, a compare per bit): special values, explicit padding, images narrower and shorter than a block, and the fused pipeline with both
+    images in one launch -- bit for bit against the oracle."""
+    H, W = 23, 530
+    shape = (H, W, channels) if channels > 1 else (H, W)
+    img = rng.uniform(-1, 1, shape).astype(np.float32)
+    img[:, 50:120] = np.round(img[:, 50:120] * 2) / 2
+    img[5:9, 70:90] = np.float32(-0.0)
+    img[9:12, 70:90] = np.float32(0.0)
+    img[12:20, 300:330] = np.inf
+    img[14:16, 310:315] = -np.inf
+    img[3, 333] = np.nan
+    img[2, 520] = -np.nan
+    exp = so.census_transform(img, h_r, h_r)
+    assert_bits(sv.censusTransform2D(dev(img), h_r, h_r), exp)
+    assert_bits(sv.censusTransform2D(img, h_r, h_r), exp)
+    assert_bits(sv.censusTransform2D(dev(img), h_r, h_r, sv.PaddingMargins(2, 1, 0, 3)), so.census_transform(img, h_r, h_r, (2, 1, 0, 3)))
+    small = np.ascontiguousarray(img[:3, :7])
+    assert_bits(sv.censusTransform2D(dev(small), h_r, h_r), so.census_transform(small, h_r, h_r))
+    other = np.roll(img, 7, axis=1)[:, :500].copy()  # another width: the launch's grid covers the larger image
+    cv = so.unfold_cost_volume(so.CENSUS, img, other, h_r, h_r, 32)
+    res = sv.stereoMatch(MF.CENSUS, dev(img), dev(other), h_r, h_r, 32, sgmDirections=0, want_cv=True)
+    assert_bits(res["cv"], cv)
+    vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
+    assert np.array_equal(host(sv.stereoMatch(MF.CENSUS, dev(img), dev(other), h_r, h_r, 32, sgmDirections=8)["disp"]),
+                          so.index_to_disp(so.extract_index(vol, so.COST)))
+
+
 def test_census_single_channel_is_empty():
     assert sv.censusFeatures(np.zeros((3, 3, 1), np.float32)).size == 0
     assert sv.censusTransform2D(np.zeros((3, 3), np.float32), 0, 0).size == 0

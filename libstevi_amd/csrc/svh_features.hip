@@ -312,7 +312,7 @@ static bool census_grey_dispatch(svh_context *ctx, int h_r, int v_r, const Censu
 // Compile-time windows the register-blocked grey kernel does not take -- colour images (the channels of a window row are the next
 // floats of the image row: unfold.h:180) and grey windows 13 / 15 wide: ROWS output rows per block from one staged tile of
 // (2 VR + ROWS) rows, a pixel per lane (lanes C floats apart: conflict free for C = 1 and 3), every LDS read at an immediate offset, one
-// v_cmp + v_addc per bit.  (The general tiled kernel below stages a whole window of rows per output row and spends six instructions of
+// v_cmp + v_addc per bit, a tile row read once for all the output rows it serves.  (The general tiled kernel below stages a whole window of rows per output row and spends six instructions of
 // bookkeeping per bit: RGB 5x5 / 7x7 / 9x9 at 1080p, both images: 0.109 / 0.165 / 0.265 ms.)
 template <int HR, int VR, int C, int ROWS>
 __global__ void __launch_bounds__(256) census_fixed_kernel(CensusJob job0, CensusJob job1, int pl, int pt, int n_out) {
@@ -327,37 +327,70 @@ __global__ void __launch_bounds__(256) census_fixed_kernel(CensusJob job0, Censu
     __shared__ float tile[TR * TW];
     const int i0 = blockIdx.y * ROWS, j0 = blockIdx.x * 256, tj = threadIdx.x;
     if (i0 >= Ho || j0 >= Wo) return; // the grid covers the larger image
-#pragma unroll 2
-    for (int k = 0; k < TR; k++) {
-        const int ii = i0 - pt + k;
-        const bool row_in = ii >= 0 && ii < H;
-        const float *row = img + ((int64_t)ii * W + (j0 - pl)) * C;
-        for (int e = tj; e < TW; e += 256) {
-            const int jj = j0 - pl + e / C;
-            tile[k * TW + e] = (row_in && jj >= 0 && jj < W) ? row[e] : 0.0f;
+    // stage the tile: every load of the thread is issued before the first LDS write (a block pays one memory latency)
+    constexpr int PER_ROW = (TW + 255) / 256;
+    {
+        float r[TR][PER_ROW];
+#pragma unroll
+        for (int k = 0; k < TR; k++) {
+            const int ii = i0 - pt + k;
+            const bool row_in = ii >= 0 && ii < H;
+            const float *row = img + ((int64_t)ii * W + (j0 - pl)) * C;
+#pragma unroll
+            for (int q = 0; q < PER_ROW; q++) {
+                const int e = tj + q * 256, jj = j0 - pl + e / C;
+                r[k][q] = (row_in && e < TW && jj >= 0 && jj < W) ? row[e] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TR; k++) {
+#pragma unroll
+            for (int q = 0; q < PER_ROW; q++) {
+                const int e = tj + q * 256;
+                if (e < TW) tile[k * TW + e] = r[k][q];
+            }
         }
     }
     __syncthreads();
     const int j = j0 + tj;
     if (j >= Wo) return;
     const float *tp = tile + tj * C;
+    // The ROWS output rows advance together over the tile rows, from the bottom one up: a tile row's h C samples are read once and serve
+    // every output row whose window holds it (four times fewer LDS reads than a walk per output row).  Bottom-up and right-to-left is the
+    // channel index descending -- the order in which word = 2 word + bit fills a word from bit 31 down (census.h:98-108: channel
+    // c = 32 w + b + 1 sits behind bit b of word w; window row c / (h C), then column, then channel; channel 0 is the reference sample).
+    float ref[ROWS];
+    uint32_t d[ROWS][NWRITTEN];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; rr++) {
+        ref[rr] = tp[rr * TW]; // the window's top-left sample, channel 0 (finding F6)
+#pragma unroll
+        for (int w = 0; w < NWRITTEN; w++) d[rr][w] = 0;
+    }
+#pragma unroll
+    for (int k = TR - 1; k >= 0; k--) {
+        float smp[HC];
+#pragma unroll
+        for (int q = 0; q < HC; q++) smp[q] = tp[k * TW + q];
+#pragma unroll
+        for (int rr = 0; rr < ROWS; rr++) {
+            const int wr = k - rr; // the window row of output row rr that tile row k is
+            if (wr >= 0 && wr < v) {
+#pragma unroll
+                for (int rem = HC - 1; rem >= 0; rem--) {
+                    const int c = wr * HC + rem;
+                    if (c >= 1 && c <= 32 * NWRITTEN) shift_in_greater(d[rr][(c - 1) / 32], ref[rr], smp[rem]);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int rr = 0; rr < ROWS; rr++) {
         const int i = i0 + rr;
         if (i >= Ho) break;
-        const float ref = tp[rr * TW]; // the window's top-left sample, channel 0 (finding F6)
-        uint32_t d[NWRITTEN] = {};
-#pragma unroll
-        for (int w = 0; w < NWRITTEN; w++) {
-#pragma unroll
-            for (int b = 31; b >= 0; b--) {
-                const int c = 32 * w + b + 1; // channel index behind bit b of word w (census.h:98-108): window row c / (h C), then column, then channel
-                shift_in_greater(d[w], ref, tp[(rr + c / HC) * TW + c % HC]);
-            }
-        }
         uint32_t *o = words + ((int64_t)i * Wo + j) * n_out;
 #pragma unroll
-        for (int w = 0; w < NWRITTEN; w++) o[w] = round_target ? round_word_through_float(d[w], round_target) : d[w];
+        for (int w = 0; w < NWRITTEN; w++) o[w] = round_target ? round_word_through_float(d[rr][w], round_target) : d[rr][w];
         for (int w = NWRITTEN; w < n_out; w++) o[w] = 0; // rule E1
     }
 }

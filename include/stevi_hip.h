@@ -98,9 +98,9 @@ const char *svh_last_error(const svh_context *ctx);
 /* Tuning / test switches.  "census_fast_path" (default 1): 0 forces the general wave-per-line SGM kernels
  * for census costs too (same results, used by the parity tests to cross-check the two implementations).
  * "census_sweep" (default 0 = automatic): engine of the voxel sweep of the fused census pipeline, 1 = the vector-ALU kernel
- * (xor + popcount), 3 = the matrix-core kernels with FP4 operands (Hamming distance as a dot product; at most 4 census words,
+ * (xor + popcount), 3 = the matrix-core kernels with FP4 operands (Hamming distance as a dot product; at most 8 census words,
  * disp_count a multiple of 32 up to 992 -- of any other count they take the leading multiple and the vector-ALU kernel the rest, merged
- * by MIN; five to eight census words run the vector-ALU kernel alone); automatic = 3 where it applies.  Same keys bit for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
+ * by MIN); automatic = 3 where it applies.  Same keys bit for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
  * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
  * (64 / 128 / 256 / 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
  * (Development A/Bs of that kernel, same keys again: 2 = column-major tile order everywhere; 3 = neighbouring column tiles per wave also

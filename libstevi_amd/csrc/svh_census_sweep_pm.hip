@@ -542,7 +542,8 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
     // item width (4 waves x CT column tiles of 32 pixels): the one that pads the row least, the wider on a tie
     int best_ct = 0;
     int64_t best_pad = 0;
-    for (int ct = 4; ct >= 2; ct--) {
+    // (five to eight census words: three or four MFMAs' worth of fragments per column tile -- two column tiles per wave keep them in registers)
+    for (int ct = NW > 4 ? 2 : 4; ct >= 2; ct--) {
         const int pxb = 4 * ct * 32;
         if (pm_lds_bytes(NW, 4, ct, g.D, 1) > 160 * 1024) continue;
         const int64_t pad = (int64_t)ceil_div(g.Ws, pxb) * pxb;
@@ -552,10 +553,14 @@ template <int NW> bool launch_for_words(svh_context *ctx, const CensusGeom &g, f
         }
     }
     if (!best_ct) return false;
-    switch (best_ct) {
-    case 4: *status = launch_config<NW, 4, 4>(ctx, g, Pout, keys, gmap, sw); break;
-    case 3: *status = launch_config<NW, 4, 3>(ctx, g, Pout, keys, gmap, sw); break;
-    default: *status = launch_config<NW, 4, 2>(ctx, g, Pout, keys, gmap, sw); break;
+    if constexpr (NW > 4) {
+        *status = launch_config<NW, 4, 2>(ctx, g, Pout, keys, gmap, sw);
+    } else {
+        switch (best_ct) {
+        case 4: *status = launch_config<NW, 4, 4>(ctx, g, Pout, keys, gmap, sw); break;
+        case 3: *status = launch_config<NW, 4, 3>(ctx, g, Pout, keys, gmap, sw); break;
+        default: *status = launch_config<NW, 4, 2>(ctx, g, Pout, keys, gmap, sw); break;
+        }
     }
     return true;
 }
@@ -568,7 +573,7 @@ bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *k
     if (ctx->census_sweep_rl && launch_sweep_rl(ctx, g, Pout, keys, gmap, status, winner)) return true;
     const SweepWinner sw = winner ? *winner : SweepWinner();
     if (sw.on() && g.region1_global_last >= 0) return false; // (disparity shards exchange keys)
-    if (g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 4) return false;
+    if (g.D < 32 || (g.D & 31) != 0 || g.D > 992 || g.nWw < 1 || g.nWw > 8) return false;
     // the staging DMA addresses the word maps with byte offsets held in 32-bit-safe ranges
     if ((int64_t)g.H * g.Wt * g.nWw * 4 >= (int64_t)1 << 31 || (int64_t)g.H * g.Ws * g.nWw * 4 >= (int64_t)1 << 31) return false;
     if ((int64_t)g.H * g.Wt * g.nWw * 4 < 16 || (int64_t)g.H * g.Ws * g.nWw * 4 < 16) return false;
@@ -576,7 +581,11 @@ bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *k
     case 1: return launch_for_words<1>(ctx, g, Pout, keys, gmap, status, sw);
     case 2: return launch_for_words<2>(ctx, g, Pout, keys, gmap, status, sw);
     case 3: return launch_for_words<3>(ctx, g, Pout, keys, gmap, status, sw);
-    default: return launch_for_words<4>(ctx, g, Pout, keys, gmap, status, sw);
+    case 4: return launch_for_words<4>(ctx, g, Pout, keys, gmap, status, sw);
+    case 5: return launch_for_words<5>(ctx, g, Pout, keys, gmap, status, sw);
+    case 6: return launch_for_words<6>(ctx, g, Pout, keys, gmap, status, sw);
+    case 7: return launch_for_words<7>(ctx, g, Pout, keys, gmap, status, sw);
+    default: return launch_for_words<8>(ctx, g, Pout, keys, gmap, status, sw);
     }
 }
 #endif

@@ -2,8 +2,8 @@
 distance as a dot product: svh_census_sweep_pm.hip for any geometry, svh_census_sweep_rl.hip for RightToLeft ranges that end at the
 image edge with 64 / 128 / 256 / 512 disparities) -- must give the same regional winner keys bit for bit, and all the oracle's
 disparities.  svh_context_set_option("census_sweep", 1 | 3) selects the engine and "census_sweep_rl" 0 keeps the FP4 engine on its
-general kernel; 0 (default) takes the matrix cores wherever they apply (1..4 census words, D a multiple of 32 up to 992) and the
-vector ALU elsewhere."""
+general kernel; 0 (default) takes the matrix cores wherever they apply (1..8 census words; the leading multiple of 32 disparities up to
+992) and the vector ALU elsewhere."""
 import numpy as np
 import pytest
 
@@ -134,8 +134,8 @@ def test_shards_offsets_and_margins():
 
 
 def test_geometries_outside_the_matrix_core_kernel_still_run():
-    """D not a multiple of 32, D > 992, 13x13 windows (5 words): the options fall back to the vector ALU kernel; LeftToRight stays on
-    the general FP4 kernel."""
+    """D not a multiple of 32 and D > 992 (the range is split between the engines), 13x13 windows (5 words: the general FP4 kernel);
+    LeftToRight stays on the general FP4 kernel."""
     src, tgt, _ = parallax_pair(9, 260, 8, 3, 30, 2, 9, seed=5)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for kw in (dict(D=64, dDir=sv.dispDirection.LeftToRight, h=4), dict(D=70, dDir=sv.dispDirection.RightToLeft, h=4),
@@ -180,3 +180,25 @@ def test_ranges_that_are_no_multiple_of_32(D, W):
         cv = so.unfold_cost_volume(so.CENSUS, src, tgt, 4, 4, D, so.LEFT_TO_RIGHT)
         vol = so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0)
         assert np.array_equal(disp[-1], so.index_to_disp(so.extract_index(vol, so.COST), so.LEFT_TO_RIGHT))
+
+
+@pytest.mark.parametrize("h_r,v_r", [(6, 6), (7, 6), (7, 7), (9, 7)])
+@pytest.mark.parametrize("W", [97, 420, 700])
+def test_five_to_eight_census_words(h_r, v_r, W):
+    """13x13 ... 19x15 windows (5, 6, 7, 8 census words: three or four MFMAs per tile, costs up to 256): the matrix-core kernel gives the
+    vector-ALU kernel's keys, whole ranges and shards, both directions, ranges that are no multiple of 32; the oracle's disparities."""
+    src, tgt, _ = parallax_pair(23, W, 9, 3, min(40, W // 3), 2, 13, seed=h_r * 100 + v_r + W)
+    l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
+    for D, n_dir, Pout in ((64, 8, 100.0), (96, 4, 7.0), (256, 8, 100.0), (70, 8, 100.0)):
+        for shard in ((0, D), (32, D - 32)):
+            keys = both_engines(lambda: sv.censusShardKeys(l, r, h_r, v_r, D, shard, sgmDirections=n_dir, Pout=Pout).cpu().numpy(), l)
+            assert all(np.array_equal(keys[0], k) for k in keys[1:]), (D, n_dir, shard)
+        disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, h_r, v_r, D, sgmDirections=n_dir, Pout=Pout)["disp"].cpu().numpy(), l)
+        assert all(np.array_equal(disp[0], d) for d in disp[1:])
+        if W <= 420 and D <= 96:
+            cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, v_r, D, so.RIGHT_TO_LEFT, 0)
+            vol = so.sgm(cv, n_dir, so.COST, 0.001, 0.01, (0, 0, 0, 0), Pout)
+            assert np.array_equal(disp[-1], so.extract_index(vol, so.COST))
+    L2R = sv.dispDirection.LeftToRight
+    keys = both_engines(lambda: sv.censusShardKeys(r, l, h_r, v_r, 64, (0, 64), dDir=L2R, sgmDirections=8).cpu().numpy(), l)
+    assert all(np.array_equal(keys[0], k) for k in keys[1:])

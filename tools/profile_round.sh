@@ -31,7 +31,7 @@ python3 bench.py --steps 200 --warmup 10 > gpurun_out/${TAG}_line.json 2> gpurun
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_line_driver_flags.json 2>> gpurun_out/${TAG}_line.err
 python3 bench.py --steps 200 --warmup 10 --two-frames --no-cpu-baseline --no-api-chain --no-configs > gpurun_out/${TAG}_line_two_frames.json 2>/dev/null
 echo "bench lines done"
-(python3 tools/bench_configs.py c1 c2 c3 c4 c5slice c5 sad_sgm sad_sgm_d128 sad_sgm_d64 ncc_argmax sad_argmin; python3 tools/bench_api_chain.py; python3 tools/bench_api_chain.py 128 64; SVH_CHAIN_PLAIN=1 python3 tools/bench_api_chain.py 256 128 64; python3 tools/bench_l2r.py; python3 tools/sgm_score_probe.py; python3 tools/bench_2d.py; python3 tools/bench_hierarchical.py; python3 tools/bench_reference_rows.py) 2>/dev/null | grep "^{" > gpurun_out/${TAG}_other_workloads.jsonl || true
+(python3 tools/bench_configs.py c1 c2 c3 c4 c5slice c5 sad_sgm sad_sgm_d128 sad_sgm_d64 ncc_argmax sad_argmin; python3 tools/bench_api_chain.py; python3 tools/bench_api_chain.py 128 64; SVH_CHAIN_PLAIN=1 python3 tools/bench_api_chain.py 256 128 64; python3 tools/bench_l2r.py; python3 tools/sgm_score_probe.py; python3 tools/bench_2d.py; python3 tools/bench_hierarchical.py; python3 tools/bench_reference_rows.py; python3 tools/bench_census_windows.py; python3 tools/bench_census_colour.py) 2>/dev/null | grep "^{" > gpurun_out/${TAG}_other_workloads.jsonl || true
 head -8 gpurun_out/${TAG}_kernel_stats.csv
 python3 -c "
 import json; d=json.load(open('gpurun_out/${TAG}_line.json')); print(d['value'], d['ms_per_step'], d['roofline']['avg_ms'], d['roofline']['frac'], d['roofline'].get('frac_minus_half_pair'), d['end_px_err'], d['cpu_baseline']['value'], d['winner_identity']['ms_per_step'], d['api_chain']['ms'])"

@@ -301,7 +301,7 @@ int shard_setup(svh_context *ctx, const svh_stereo_params *prm, const svh_array 
                prm->margins[3]};
     if (!census_lane_kernels_available(s->nWw, per_shard_kernels ? s->D : 1) || !census_exact_regime(sa, s->nWw))
         return fail(ctx, SVH_ERR_UNSUPPORTED,
-                    "disparity sharding needs the integer-exact regime (integer Pout, window up to 11x11, <= 1024 disparities per shard)");
+                    "disparity sharding needs the integer-exact regime (integer Pout, at most 8 census words = windows up to 15x15, <= 1024 disparities per shard)");
     return SVH_OK;
 }
 

@@ -102,7 +102,7 @@ const char *svh_last_error(const svh_context *ctx);
  * disp_count a multiple of 32 up to 992 -- of any other count they take the leading multiple and the vector-ALU kernel the rest, merged
  * by MIN); automatic = 3 where it applies.  Same keys bit for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
  * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
- * (64 / 128 / 256 / 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
+ * (a multiple of 32 from 64 to 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
  * (Development A/Bs of that kernel, same keys again: 2 = column-major tile order everywhere; 3 = neighbouring column tiles per wave also
  * in the items at the right image border, where the default deals them out in serpentine order.)
  * "census_float_overflow" (default 0): what becomes of a target census word that rounds to 2^32 on its way through `float`

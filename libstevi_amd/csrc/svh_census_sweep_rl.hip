@@ -21,8 +21,8 @@
 //     the expansion writes the FP4 records of the window; LDS holds the two window buffers and nothing else;
 //   * the two lane halves merge with v_permlane32_swap instead of a ds_bpermute round trip.
 //
-// Geometries outside this (LeftToRight, a search range that does not end at the image edge, other disparity counts, four census
-// words) keep svh_census_sweep_pm.hip; tests/test_gpu_sweep_engines.py holds the two kernels and the vector-ALU sweep to the same keys.
+// Geometries outside this (LeftToRight, a search range that does not end at the image edge, disparity counts that are no multiple of 32
+// from 64 to 512, four census words and more) keep svh_census_sweep_pm.hip; tests/test_gpu_sweep_engines.py holds the two kernels and the vector-ALU sweep to the same keys.
 #include <type_traits>
 
 #include <cstddef>
@@ -484,10 +484,21 @@ template <int NW, int NT> int launch_rl_width(svh_context *ctx, const CensusGeom
 }
 
 template <int NW> bool launch_rl_words(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner &sw) {
-    switch (g.D) {
+    switch (g.D) { // every multiple of 32 from 64 to 512: the row tiles of a column tile are straight-line code (NT = D / 32 + 1)
     case 64: *status = launch_rl_width<NW, 3>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 96: *status = launch_rl_width<NW, 4>(ctx, g, Pout, keys, gmap, sw); return true;
     case 128: *status = launch_rl_width<NW, 5>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 160: *status = launch_rl_width<NW, 6>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 192: *status = launch_rl_width<NW, 7>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 224: *status = launch_rl_width<NW, 8>(ctx, g, Pout, keys, gmap, sw); return true;
     case 256: *status = launch_rl_width<NW, 9>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 288: *status = launch_rl_width<NW, 10>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 320: *status = launch_rl_width<NW, 11>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 352: *status = launch_rl_width<NW, 12>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 384: *status = launch_rl_width<NW, 13>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 416: *status = launch_rl_width<NW, 14>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 448: *status = launch_rl_width<NW, 15>(ctx, g, Pout, keys, gmap, sw); return true;
+    case 480: *status = launch_rl_width<NW, 16>(ctx, g, Pout, keys, gmap, sw); return true;
     case 512: *status = launch_rl_width<NW, 17>(ctx, g, Pout, keys, gmap, sw); return true;
     default: return false;
     }

@@ -1,6 +1,6 @@
 """The engines of census_sweep -- the vector-ALU kernel (xor + popcount) and the two matrix-core kernels with FP4 operands (Hamming
 distance as a dot product: svh_census_sweep_pm.hip for any geometry, svh_census_sweep_rl.hip for RightToLeft ranges that end at the
-image edge with 64 / 128 / 256 / 512 disparities) -- must give the same regional winner keys bit for bit, and all the oracle's
+image edge with a multiple of 32 from 64 to 512 disparities) -- must give the same regional winner keys bit for bit, and all the oracle's
 disparities.  svh_context_set_option("census_sweep", 1 | 3) selects the engine and "census_sweep_rl" 0 keeps the FP4 engine on its
 general kernel; 0 (default) takes the matrix cores wherever they apply (1..8 census words; the leading multiple of 32 disparities up to
 992) and the vector ALU elsewhere."""
@@ -42,7 +42,7 @@ def oracle_disp(tgt, src, h_r, D, n_dir, Pout, margins=(0, 0, 0, 0), lower=0):
     return so.extract_index(vol, so.COST)
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 128, 256, 480, 512, 992])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 160, 192, 224, 256, 288, 320, 352, 384, 416, 448, 480, 512, 992])
 @pytest.mark.parametrize("W", [97, 384, 700, 1100])
 def test_keys_and_disparities_agree(D, W):
     src, tgt, _ = parallax_pair(11, W, 9, 3, min(40, W // 3), 2, 13, seed=D + W)

@@ -63,8 +63,8 @@ __device__ __forceinline__ int winner_index(uint32_t k0, uint32_t k1, int n_vis,
 // outside what the kernel covers (the caller then runs the vector-ALU sweep)
 // (winner: write the index / disparity maps instead of keys and g)
 bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner = nullptr);
-// the same for RightToLeft geometries whose Pout region is "target column outside the image", 64 / 128 / 256 / 512 disparities, up
-// to three census words (svh_census_sweep_rl.hip); launch_sweep_pm tries it first unless the "census_sweep_rl" option is 0
+// the same for RightToLeft geometries whose Pout region is "target column outside the image", a multiple of 32 from 64 to 512
+// disparities, up to four census words (svh_census_sweep_rl.hip); launch_sweep_pm tries it first unless the "census_sweep_rl" option is 0
 bool launch_sweep_rl(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner);
 
 } // namespace svh

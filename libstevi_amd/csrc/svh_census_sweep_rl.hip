@@ -22,7 +22,7 @@
 //   * the two lane halves merge with v_permlane32_swap instead of a ds_bpermute round trip.
 //
 // Geometries outside this (LeftToRight, a search range that does not end at the image edge, disparity counts that are no multiple of 32
-// from 64 to 512, four census words and more) keep svh_census_sweep_pm.hip; tests/test_gpu_sweep_engines.py holds the two kernels and the vector-ALU sweep to the same keys.
+// from 64 to 512, five census words and more) keep svh_census_sweep_pm.hip; tests/test_gpu_sweep_engines.py holds the two kernels and the vector-ALU sweep to the same keys.
 #include <type_traits>
 
 #include <cstddef>
@@ -519,6 +519,7 @@ bool launch_sweep_rl(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *k
     case 1: return launch_rl_words<1>(ctx, g, Pout, keys, gmap, status, sw);
     case 2: return launch_rl_words<2>(ctx, g, Pout, keys, gmap, status, sw);
     case 3: return launch_rl_words<3>(ctx, g, Pout, keys, gmap, status, sw);
+    case 4: return launch_rl_words<4>(ctx, g, Pout, keys, gmap, status, sw);
     default: return false;
     }
 }

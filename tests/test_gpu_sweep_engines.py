@@ -80,17 +80,19 @@ def test_left_to_right(D, W):
 
 
 def test_four_census_words():
-    """13 x 11 windows: 142 census bits = four written words, the most the matrix-core kernels take (two MFMAs per tile with FP4
-    operands)."""
-    src, tgt, _ = parallax_pair(15, 200, 9, 3, 40, 2, 11, seed=31)
-    l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
-    for D in (64, 160):
-        keys = both_engines(lambda: sv.censusShardKeys(l, r, 6, 5, D, (0, D), sgmDirections=8, Pout=100.0).cpu().numpy(), l)
-        assert all(np.array_equal(keys[0], k) for k in keys[1:])
-        disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, 6, 5, D, sgmDirections=8, Pout=100.0)["disp"].cpu().numpy(), l)
-        assert all(np.array_equal(disp[0], d) for d in disp[1:])
-        cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 6, 5, D)
-        assert np.array_equal(disp[-1], so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
+    """13 x 11 windows: 142 census bits = four written words (two MFMAs per tile with FP4 operands), the most the RightToLeft
+    specialisation takes."""
+    for W in (200, 700):
+        src, tgt, _ = parallax_pair(15, W, 9, 3, 40, 2, 11, seed=31 + W)
+        l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
+        for D in (64, 160, 256, 512):
+            keys = both_engines(lambda: sv.censusShardKeys(l, r, 6, 5, D, (0, D), sgmDirections=8, Pout=100.0).cpu().numpy(), l)
+            assert all(np.array_equal(keys[0], k) for k in keys[1:])
+            disp = both_engines(lambda: sv.stereoMatch(MF.CENSUS, l, r, 6, 5, D, sgmDirections=8, Pout=100.0)["disp"].cpu().numpy(), l)
+            assert all(np.array_equal(disp[0], d) for d in disp[1:])
+            if W == 200 and D <= 160:
+                cv = so.unfold_cost_volume(so.CENSUS, tgt, src, 6, 5, D)
+                assert np.array_equal(disp[-1], so.extract_index(so.sgm(cv, 8, so.COST, 0.001, 0.01, (0, 0, 0, 0), 100.0), so.COST))
 
 
 def test_ties_everywhere():

@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+torch = None  # imported by main(): the self-launching parent of a bare `--gpus N` run (launch_ranks) must never load it, let alone touch HIP
 
 # C3 = 1920x1080, D=256, census 9x9, SGM-8 (P1=0.001, P2=0.01, Pout=100), seed 3; C5 = 8192x4320, D=512, seed 5
 C3 = dict(name="C3", W=1920, H=1080, D=256, h_r=4, v_r=4, sgm=8, P1=0.001, P2=0.01, Pout=100.0, seed=3, bg=8, sq=64, side=320, v=320, h=380)
@@ -386,6 +387,40 @@ def reference_benchmark_rows(sv, dev, cpu_legs=True):
     return out, ok
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(argv, gpus, port):
+    """The command line the driver's documented N > 1 form spells out, for `gpus` ranks of this script with the caller's own flags."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_launch(gpus, environ):
+    """A bare `python bench.py --gpus N` (N > 1, no rank environment) starts its own ranks; a rank started by torch.distributed.run
+    (RANK / WORLD_SIZE set) never does."""
+    return gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def launch_ranks(argv, gpus):
+    """Parent of a bare N > 1 run.  It makes NO torch.cuda / HIP call (torch is not even imported here): the N ranks are fresh child
+    processes of `python -m torch.distributed.run`, nothing that has touched the GPU is ever re-exec'd.  The children's stderr passes
+    through as it comes; their stdout is relayed line by line, and the exit code is the launcher's (non-zero when any rank failed)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))  # the oracle legs of rank 0 (torchrun would pin 1)
+    proc = subprocess.Popen(launch_command(argv, gpus, free_port()), stdout=subprocess.PIPE, env=env, text=True)
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,13 +443,15 @@ def main():
                     "describe the single-stream kernels)")
     args = ap.parse_args()
 
+    if needs_launch(args.gpus, os.environ):
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
+    global torch
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                             "--master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
@@ -590,12 +627,29 @@ def main():
                              "line recurrence and no exchange); barrier + synchronize on both sides, max over ranks"}
 
     # ---- N > 1: the whole frame on ONE GPU (rank 0), outside the timed regions: the reference map of the full-frame end_px_err below
-    one_gpu = None
+    # ... and, timed the same way (K steps between synchronisations, the other ranks idle at the barrier), the one-GPU time of the SAME
+    # workload: the N = 1 bench line is C3, so a scaling point needs its own one-GPU denominator
+    one_gpu, one_gpu_ms, rccl = None, None, None
     if world > 1:
         if rank == 0:
-            one_gpu = sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"],
-                                     P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"])["disp"]
+            def one():
+                return sv.stereoMatch(sv.matchingFunctions.CENSUS, d_tgt, d_src, wl["h_r"], wl["v_r"], wl["D"], sgmDirections=wl["sgm"],
+                                      P1=wl["P1"], P2=wl["P2"], Pout=wl["Pout"])["disp"]
+            one_gpu = one()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_gpu = one()
+            torch.cuda.synchronize()
+            one_gpu_ms = (time.perf_counter() - t1) / args.steps * 1e3
         sync()
+        # the communicator as the backend itself reports it: a SUM all-reduce of ones counts the ranks that took part
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        devs = [None] * world
+        dist.all_gather_object(devs, f"{torch.cuda.get_device_name(dev_index)} #{dev_index}")
+        rccl = {"backend": dist.get_backend(), "ranks_in_all_reduce": int(ones.item()), "world_size": dist.get_world_size(),
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None, "devices": devs}
 
     # ---- N > 1, opt-in: the exchange through the C ABI on a communicator of our own (the C++ host's path)
     c_abi = None
@@ -704,7 +758,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "repeats": repeats, "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4), "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
             "timing": f"median of {repeats} timed regions of exactly {args.steps} steps, each bracketed by barrier + torch.cuda.synchronize(), max over ranks",
-            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "fp4 (e2m1) +-1 census operands on the matrix cores, f32 accumulators holding exact integers (no rounding anywhere on the path)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "fp4 (e2m1) +-1 census operands on the matrix cores, f32 accumulators holding exact integers (no rounding anywhere on the path)", "data": "synthetic",
             "config": {"workload": f"{shape} synthetic parallax pair, census 9x9 + Hamming, 8-path SGM (P1=0.001,P2=0.01,Pout=100), "
                                    f"D={wl['D']}, argmin -> int32 disparity map (BASELINE.json configs[{2 if wl['name'] == 'C3' else 4}])",
                        "pipeline": ("svh_stereo_match fused, inputs and outputs resident in HBM" if world == 1 else
@@ -728,6 +782,13 @@ def main():
             "kernel_ms_per_step_warmup": kernel_ms,
             "disp_checksum": checksum,
         }
+        if world > 1:
+            line["rccl_ranks"] = rccl
+            line["one_gpu_same_workload_ms"] = round(one_gpu_ms, 4)
+            line["speedup"] = round(one_gpu_ms / ms_per_step, 4)
+            line["efficiency"] = round(one_gpu_ms / ms_per_step / world, 4)
+            line["scaling_note"] = ("speedup = one_gpu_same_workload_ms / ms_per_step: svh_stereo_match on rank 0 alone, whole disparity range of this same frame, same K "
+                                    "steps, same run (the N = 1 bench line is BASELINE's C3, a different frame; do not draw a curve through both)")
         if phases is not None:
             line["frame_phases"] = phases
         if disparity_split is not None:

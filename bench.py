@@ -413,7 +413,6 @@ def launch_ranks(argv, gpus):
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))  # the oracle legs of rank 0 (torchrun would pin 1)
     proc = subprocess.Popen(launch_command(argv, gpus, free_port()), stdout=subprocess.PIPE, env=env, text=True)
     for ln in proc.stdout:
         sys.stdout.write(ln)
@@ -802,6 +801,8 @@ def main():
                 rc = 3
         got = disp_dev.cpu().numpy()
         if not args.no_cpu_baseline:
+            import oracle as so
+            so.set_num_threads(so.granted_cpus())  # the CPUs the cgroup grants (torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks)
             if world == 1:
                 t_cpu = time.perf_counter()
                 line["cpu_baseline"], want = cpu_baseline(wl, src, tgt)

@@ -37,11 +37,36 @@ def build(force=False):
 _lib = None
 
 
+def granted_cpus():
+    """Host CPUs this process may really use: the scheduler affinity, cut down to the cgroup's CPU quota (cpu.max).  The GPU boxes show
+    256 CPUs and grant 16: an OpenMP region on 128 threads runs into CFS throttling there, which also stalls whatever the process times
+    next by one 25 - 100 ms period (tools/stall_probe.py, profiles/r05a_stall_probe.jsonl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = fields[0], int(fields[1])
+            else:
+                quota = fields[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+            if quota not in ("max", "-1") and int(quota) > 0 and period > 0:
+                n = min(n, max(1, int(quota) // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
         _lib = C.CDLL(_LIB_PATH)
+        if "OMP_NUM_THREADS" not in os.environ:  # (an explicit request stands)
+            _lib.so_set_num_threads(min(int(_lib.so_num_threads()), granted_cpus()))
         _lib.so_round_word_through_float.restype = C.c_uint32
         _lib.so_round_word_through_float.argtypes = [C.c_uint32]
         _lib.so_refine_triplet.restype = C.c_float

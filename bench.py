@@ -168,6 +168,39 @@ def api_chain(sv, wl, d_tgt, d_src, reps=5):
             "kernel_ms": {k: round(v[0] / reps, 4) for k, v in prof.items()}}, disp
 
 
+def host_chain(sv, wl, src, tgt, reps=3):
+    """The reference benchmark's chain exactly as its callers write it (benchmarkCrossCorrelationAlgorithms.cpp:92-96, :288-294): HOST arrays in,
+    host arrays out of every function, so each float32 volume crosses PCIe down and up again -- SURVEY.md 8(d)'s "host API end-to-end
+    (H2D + D2H) reported separately".  numpy arrays here; the C++ drop-in headers on Multidim::Array run the same C entry points
+    (tools/bench_cpp_chain.cpp).  The results are allocated by the library's mirror in page-locked memory (svh_host_alloc), the images are
+    the caller's pageable arrays."""
+    MF = sv.matchingFunctions
+    strat = sv.matchFuncStrategy(MF.CENSUS)
+
+    def chain():
+        cv = sv.unfoldBasedCostVolume(MF.CENSUS, tgt, src, wl["h_r"], wl["v_r"], wl["D"])
+        sgm = sv.sgmCostVolume(wl["sgm"], strat, cv, wl["P1"], wl["P2"], None, wl["Pout"])
+        return sv.selectedIndexToDisp(sv.extractSelectedIndex(strat, sgm), 0)
+
+    t0 = time.perf_counter()
+    disp = chain()  # first call: page-locks the result blocks (kept in the library's cache afterwards)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        disp = chain()
+        times.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.median(times))
+    px, vox = wl["W"] * wl["H"], wl["W"] * wl["H"] * wl["D"]
+    pcie = 4.0 * vox * 4 + 8.0 * px + 3 * 4.0 * px  # C down, C up, S down, S up; two images up; index down, index up, disparity down
+    assert isinstance(disp, np.ndarray)
+    return {"ms": round(ms, 2), "ms_all": [round(t, 2) for t in times], "first_call_ms": round(first_ms, 1), "Mdisparities_per_s": round(vox / ms / 1e3, 1),
+            "pcie_bytes": int(pcie), "pcie_GBps": round(pcie / (ms * 1e-3) / 1e9, 1),
+            "calls": "unfoldBasedCostVolume -> sgmCostVolume<8,Cost> -> extractSelectedIndex -> selectedIndexToDisp on numpy arrays (host memory in, host memory out of every call)",
+            "note": "four 2.1 GB crossings of the link per chain are what the reference's own call sequence asks for with host arrays; the kernels take 1.4 ms of it "
+                    "(api_chain).  Results live in page-locked blocks (svh_host_alloc) that the DMA engines address directly; first_call_ms includes page-locking them"}, disp
+
+
 def _time_steps(fn, steps, repeats=3):
     """median over `repeats` regions of `steps` calls, synchronised on both sides; ms per call"""
     fn()
@@ -430,6 +463,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the other BASELINE configurations (C1, C2, C4, one-GPU C5) after the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline and end_px_err)")
     ap.add_argument("--no-api-chain", action="store_true", help="skip the per-function (volume-materialising) chain")
+    ap.add_argument("--no-host-chain", action="store_true", help="skip the per-function chain on HOST arrays (numpy in, numpy out of every call: 8.5 GB over PCIe)")
     ap.add_argument("--materialize", action="store_true", help="also write the cost volume and the SGM volume (float32) to HBM")
     ap.add_argument("--winner-identity", action="store_true", help="time the product's default path instead: in the exact regime the winner of a "
                     "pixel does not depend on the per-pass minima, so disparity-only calls run no line recurrence at all (DESIGN.md 4.1); the "
@@ -871,6 +905,18 @@ def main():
             line["api_chain"]["pixels_differing_from_fused"] = int((chain_disp != disp_dev).sum().item())
             if line["api_chain"]["pixels_differing_from_fused"] != 0:
                 rc = 3
+        if world == 1 and not args.no_host_chain:
+            t_h = time.perf_counter()
+            try:
+                line["host_chain"], host_disp = host_chain(sv, wl, src, tgt)
+                line["host_chain"]["pixels_differing_from_fused"] = int(np.count_nonzero(host_disp != got))
+                if line["host_chain"]["pixels_differing_from_fused"] != 0:
+                    rc = 3
+                del host_disp
+            except Exception as e:  # noqa: BLE001 -- report, never lose the headline to a secondary leg
+                line["host_chain"] = {"error": f"{type(e).__name__}: {e}"}
+                rc = 3
+            wall["host_chain_s"] = round(time.perf_counter() - t_h, 2)
         if world == 1 and not args.no_configs:
             # the other BASELINE configurations, after (and outside) everything the headline times; C3 itself is the headline above
             torch.cuda.empty_cache()

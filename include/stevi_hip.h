@@ -184,11 +184,28 @@ int svh_context_get_device(const svh_context *ctx);
 int svh_device_free_detached(int device, void *ptr);
 /* Blocks released through svh_device_free / svh_device_free_detached are kept per device and handed out again by svh_device_alloc (best
  * fit, at most twice the request): a chain written with the reference's names allocates and releases a volume per call, and hipMalloc /
- * hipFree of 2 GB cost tens of milliseconds each.  The cache holds at most SVH_DEVICE_CACHE_MB (environment, default 65536) and is
- * returned to the device by this call and by svh_context_trim. */
+ * hipFree of 2 GB cost tens of milliseconds each.  The cache holds at most SVH_DEVICE_CACHE_MB (environment; default: a quarter of the device's
+ * memory) and is returned to the device by this call, by svh_context_trim and by every allocation of the library that would otherwise
+ * fail for lack of memory.  Releasing a block twice returns SVH_ERR_INVALID_ARGUMENT. */
 int svh_device_cache_trim(int device);
 int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes);
 int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes);
+
+/* Page-locked host memory for the arrays that cross PCIe.  Every function of the reference takes host arrays and returns a fresh host
+ * array (cross_correlations.h:741-745, sgm.h:361-365; its benchmark chain benchmarkCrossCorrelationAlgorithms.cpp:288-294 hands each
+ * 2.1 GB volume to the next function), so a chain written with its names moves each volume over the link twice.  A host array in a
+ * block from svh_host_alloc is written and read by the DMA engines directly, at the link's rate; the drop-in headers and the Python
+ * mirror allocate the results they return there (>= 1 MB), so that the volumes of such a chain never pass through pageable memory.
+ * Host arrays in any other memory still work: large ones are copied in chunks through a page-locked ring by a few host threads
+ * (SVH_COPY_THREADS, default 4) while the DMA engines move the previous chunks.  Nothing is cached by content: each call transfers
+ * what the caller's array holds.  Released blocks are kept page-locked (best fit, at most twice the request) up to SVH_HOST_CACHE_MB
+ * (default 8192); svh_host_cache_trim gives them back.  svh_host_free returns SVH_ERR_INVALID_ARGUMENT for a pointer that did not
+ * come from svh_host_alloc or was released already.  The reference has no counterpart (Multidim::Array allocates with new[]). */
+int svh_host_alloc(size_t bytes, void **ptr);
+int svh_host_free(void *ptr);
+int svh_host_cache_trim(void);
+/* 1 when [ptr, ptr + bytes) lies in page-locked memory (a block of svh_host_alloc, or any memory the HIP runtime has registered) */
+int svh_host_is_pinned(const void *ptr, size_t bytes);
 /* device -> device, enqueued on the context's stream (no wait) */
 int svh_device_copy(svh_context *ctx, void *device_dst, const void *device_src, size_t bytes);
 

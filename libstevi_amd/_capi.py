@@ -22,6 +22,7 @@ F32, I32, U32, U8, U64, I16, U16 = 0, 1, 2, 3, 4, 5, 6
 EXPORTS = [
     "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_set_option", "svh_context_synchronize", "svh_context_trim",
     "svh_status_string", "svh_last_error", "svh_device_available", "svh_device_alloc", "svh_device_free", "svh_device_free_detached", "svh_device_cache_trim", "svh_context_get_device", "svh_device_upload", "svh_device_download", "svh_device_copy",
+    "svh_host_alloc", "svh_host_free", "svh_host_cache_trim", "svh_host_is_pinned",
     "svh_profile_enable", "svh_profile_filter", "svh_profile_sampling", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_oriented", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_unfold_cost_volume_minima", "svh_unfold_cost_volume_winner", "svh_sgm_cost_volume", "svh_sgm_cost_volume_minima", "svh_sgm_cost_volume_winner", "svh_sgm_cost_volume_textbook",
@@ -135,6 +136,12 @@ def load():
         "svh_context_get_device": (C.c_int, [ctx]),
         "svh_device_free_detached": (C.c_int, [C.c_int, C.c_void_p]),
         "svh_device_cache_trim": (C.c_int, [C.c_int]),
+        "svh_device_alloc": (C.c_int, [ctx, C.c_size_t, P(C.c_void_p)]),
+        "svh_device_free": (C.c_int, [ctx, C.c_void_p]),
+        "svh_host_alloc": (C.c_int, [C.c_size_t, P(C.c_void_p)]),
+        "svh_host_free": (C.c_int, [C.c_void_p]),
+        "svh_host_cache_trim": (C.c_int, []),
+        "svh_host_is_pinned": (C.c_int, [C.c_void_p, C.c_size_t]),
         "svh_extract_selected_index": (C.c_int, [ctx, C.c_int, A, A]),
         "svh_selected_index_to_disp": (C.c_int, [ctx, C.c_int, A, i32, A]),
         "svh_selected_cost": (C.c_int, [ctx, A, A, A]),

@@ -187,7 +187,44 @@ def _like(x, shape, dtype):
         td = {"f32": torch.float32, "i32": torch.int32, "u32": getattr(torch, "uint32", torch.int32), "u64": torch.int64}[dtype]
         return torch.empty(shape, dtype=td, device=x.device)
     nd = {"f32": np.float32, "i32": np.int32, "u32": np.uint32, "u64": np.uint64}[dtype]
-    return np.empty(shape, nd)
+    return host_empty(shape, nd)
+
+
+class _PinnedBlock:
+    """A block of svh_host_alloc (page-locked host memory) that a numpy array is laid over; released with the last view of it."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        st = _capi.load().svh_host_alloc(nbytes, C.byref(p))
+        if st != _capi.OK or not p.value:
+            raise MemoryError(f"svh_host_alloc({nbytes})")
+        self.ptr = p.value
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _capi.load().svh_host_free(C.c_void_p(self.ptr))
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+PINNED_RESULTS_FROM = 1 << 20  # bytes
+
+
+def host_empty(shape, dtype):
+    """np.empty for the host arrays this module returns: arrays of a megabyte and more are laid over page-locked memory
+    (svh_host_alloc), which the DMA engines write at the link's rate -- and read at that rate when the array is passed to the next
+    function of a chain (unfoldBasedCostVolume -> sgmCostVolume -> extractSelectedIndex on numpy arrays moves 8.5 GB at 1080p x 256).
+    An ordinary numpy array in every other respect (the block goes back to the library's cache with the last view of it)."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if n < PINNED_RESULTS_FROM:
+        return np.empty(shape, dtype)
+    try:
+        block = _PinnedBlock(n)
+    except (MemoryError, ImportError):
+        return np.empty(shape, dtype)
+    return np.asarray(block)[:n].view(dtype).reshape(shape)
 
 
 def _empty_like(x, ndim, dtype):

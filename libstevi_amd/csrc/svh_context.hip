@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <set>
 
 #include "svh_internal.h"
 
@@ -23,6 +24,15 @@ Scratch::~Scratch() {
     for (size_t k : taken) ctx->pool[k].in_use = false;
 }
 
+static void drop_free_pool_blocks(svh_context *ctx) {
+    for (auto &b : ctx->pool)
+        if (!b.in_use && b.ptr) {
+            (void)hipFree(b.ptr);
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+}
+
 void *Scratch::get(size_t bytes) {
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~size_t(255);
@@ -40,13 +50,10 @@ void *Scratch::get(size_t bytes) {
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
-        // drop every cached free block and retry once
-        for (auto &b : ctx->pool)
-            if (!b.in_use && b.ptr) {
-                (void)hipFree(b.ptr);
-                b.ptr = nullptr;
-                b.bytes = 0;
-            }
+        // drop every cached free block -- this context's workspace and the device's cache of released svh_device_alloc blocks -- and retry once
+        (void)hipGetLastError();
+        drop_free_pool_blocks(ctx);
+        device_cache_release_all(ctx->device);
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             fail(ctx, SVH_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -226,17 +233,10 @@ int stage_in(svh_context *ctx, Scratch &scr, const svh_array &a, void **dptr) {
     *dptr = buf;
     if (n == 0) return SVH_OK;
     if (a.memspace == SVH_DEVICE) return launch_relayout(ctx, a.data, buf, make_layout(a, true), n, es);
-    if (dense) {
-        SVH_HIP_CHECK(ctx, hipMemcpyAsync(buf, a.data, (size_t)n * es, hipMemcpyHostToDevice, ctx->stream));
-        // the source may be pageable and reused by the caller right after we return
-        SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        return SVH_OK;
-    }
+    if (dense) return copy_h2d(ctx, buf, a.data, (size_t)n * es); // (returns when the caller may reuse the source)
     std::vector<uint8_t> packed((size_t)n * es);
     host_copy(a.data, packed.data(), make_layout(a, true), es);
-    SVH_HIP_CHECK(ctx, hipMemcpyAsync(buf, packed.data(), (size_t)n * es, hipMemcpyHostToDevice, ctx->stream));
-    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return SVH_OK;
+    return copy_h2d(ctx, buf, packed.data(), (size_t)n * es);
 }
 
 int validate_image(svh_context *ctx, const svh_array *img, const char *what, int match_func) {
@@ -330,14 +330,9 @@ int finish_out(svh_context *ctx, const OutStage &st) {
     size_t es = dtype_size(a.dtype);
     if (n == 0) return SVH_OK;
     if (a.memspace == SVH_DEVICE) return launch_relayout(ctx, st.dptr, a.data, make_layout(a, false), n, es);
-    if (is_dense(a)) {
-        SVH_HIP_CHECK(ctx, hipMemcpyAsync(a.data, st.dptr, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
-        SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        return SVH_OK;
-    }
+    if (is_dense(a)) return copy_d2h(ctx, a.data, st.dptr, (size_t)n * es);
     std::vector<uint8_t> packed((size_t)n * es);
-    SVH_HIP_CHECK(ctx, hipMemcpyAsync(packed.data(), st.dptr, (size_t)n * es, hipMemcpyDeviceToHost, ctx->stream));
-    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SVH_TRY(copy_d2h(ctx, packed.data(), st.dptr, (size_t)n * es));
     host_copy(packed.data(), a.data, make_layout(a, false), es);
     return SVH_OK;
 }
@@ -374,6 +369,7 @@ int svh_context_destroy(svh_context *ctx) {
     if (!ctx) return SVH_OK;
     DeviceGuard guard(ctx->device); // (holds the device number, not the context)
     (void)hipStreamSynchronize(ctx->stream);
+    staging_destroy(ctx);
     for (auto &b : ctx->pool)
         if (b.ptr) (void)hipFree(b.ptr);
     for (auto &p : ctx->prof_pending) {
@@ -495,24 +491,36 @@ int svh_context_trim(svh_context *ctx) {
 // A chain written with the reference's names allocates and releases a volume per call (2.1 GB each at 1080p x 256), and hipMalloc /
 // hipFree of that size cost tens of milliseconds each: the C3 chain through the drop-in headers took 128 ms for 1.4 ms of kernels.
 // Released blocks are kept (best fit, at most twice the request) and handed out again; hipFree only when the cache passes its cap
-// (SVH_DEVICE_CACHE_MB, default 65536) or on svh_context_trim / svh_device_cache_trim.  A block is only cached after the wait its release
+// (SVH_DEVICE_CACHE_MB, default a quarter of the device's memory) or on svh_context_trim / svh_device_cache_trim.  A block is only cached after the wait its release
 // always did (the device idle, or the context's stream drained), so whoever gets it next may use it on any stream.
 namespace {
 struct DeviceCache {
     std::mutex m;
     std::multimap<size_t, void *> free_blocks; // size -> block
     std::map<void *, size_t> sizes;            // every live block of svh_device_alloc
+    std::set<void *> is_cached;                // the blocks of `sizes` that sit in free_blocks (a second release of one is an error, not a second entry)
     size_t cached = 0;
+    size_t cap = SIZE_MAX;                     // SIZE_MAX: not looked up yet
 };
 // (never destroyed: an array released by a static object's destructor after this library's own statics are gone must still find it)
 DeviceCache *const g_device_cache = new DeviceCache[64];
-size_t device_cache_cap() {
-    static const size_t cap = [] {
-        const char *e = getenv("SVH_DEVICE_CACHE_MB");
-        const long long mb = e ? atoll(e) : 65536;
-        return (size_t)(mb < 0 ? 0 : mb) << 20;
-    }();
-    return cap;
+// (lock held, the cache's device current) SVH_DEVICE_CACHE_MB when set, else a quarter of the device's memory: idle blocks must not be what
+// makes somebody else's allocation (torch, RCCL, a workspace) fail
+size_t device_cache_cap(DeviceCache &c) {
+    if (c.cap != SIZE_MAX) return c.cap;
+    const char *e = getenv("SVH_DEVICE_CACHE_MB");
+    if (e) {
+        const long long mb = atoll(e);
+        c.cap = (size_t)(mb < 0 ? 0 : mb) << 20;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            total_b = size_t(64) << 30;
+        }
+        c.cap = total_b / 4;
+    }
+    return c.cap;
 }
 // (lock held) hipFree cached blocks, largest first, until at most `keep` bytes stay cached
 void device_cache_shrink(DeviceCache &c, size_t keep) {
@@ -520,6 +528,7 @@ void device_cache_shrink(DeviceCache &c, size_t keep) {
         auto it = std::prev(c.free_blocks.end());
         (void)hipFree(it->second);
         c.sizes.erase(it->second);
+        c.is_cached.erase(it->second);
         c.cached -= it->first;
         c.free_blocks.erase(it);
     }
@@ -529,12 +538,23 @@ int device_release(int device, void *ptr) { // after the caller's wait
     std::lock_guard<std::mutex> lock(c.m);
     auto it = c.sizes.find(ptr);
     if (it == c.sizes.end()) return hipFree(ptr) == hipSuccess ? SVH_OK : SVH_ERR_HIP; // (not from svh_device_alloc)
+    if (!c.is_cached.insert(ptr).second) return SVH_ERR_INVALID_ARGUMENT;             // released twice: it must not be handed out twice
     c.free_blocks.emplace(it->second, ptr);
     c.cached += it->second;
-    device_cache_shrink(c, device_cache_cap());
+    device_cache_shrink(c, device_cache_cap(c));
     return SVH_OK;
 }
 } // namespace
+
+extern "C++" {
+namespace svh {
+void device_cache_release_all(int device) { // (the device is current: called from an allocator's out-of-memory path)
+    DeviceCache &c = g_device_cache[device & 63];
+    std::lock_guard<std::mutex> lock(c.m);
+    device_cache_shrink(c, 0);
+}
+} // namespace svh
+} // extern "C++"
 
 int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr) {
     if (!ctx || !ptr) return SVH_ERR_INVALID_ARGUMENT;
@@ -547,13 +567,20 @@ int svh_device_alloc(svh_context *ctx, size_t bytes, void **ptr) {
     if (it != c.free_blocks.end() && it->first <= 2 * want + (1u << 20)) {
         *ptr = it->second;
         c.cached -= it->first;
+        c.is_cached.erase(it->second);
         c.free_blocks.erase(it);
         return SVH_OK;
     }
-    if (hipMalloc(ptr, want) != hipSuccess) { // out of memory: give the cached blocks back and try once more
+    if (hipMalloc(ptr, want) != hipSuccess) { // out of memory: give the cached blocks and this context's idle workspace back and try once more
         (void)hipGetLastError();
         device_cache_shrink(c, 0);
-        SVH_HIP_CHECK(ctx, hipMalloc(ptr, want));
+        drop_free_pool_blocks(ctx);
+        const hipError_t e = hipMalloc(ptr, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            *ptr = nullptr;
+            return fail(ctx, SVH_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
     }
     c.sizes[*ptr] = want;
     return SVH_OK;
@@ -591,17 +618,13 @@ int svh_device_cache_trim(int device) {
 int svh_device_upload(svh_context *ctx, void *device_dst, const void *host_src, size_t bytes) {
     if (!ctx || (bytes && (!device_dst || !host_src))) return SVH_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(ctx->device);
-    SVH_HIP_CHECK(ctx, hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return SVH_OK;
+    return copy_h2d(ctx, device_dst, host_src, bytes);
 }
 
 int svh_device_download(svh_context *ctx, void *host_dst, const void *device_src, size_t bytes) {
     if (!ctx || (bytes && (!host_dst || !device_src))) return SVH_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(ctx->device);
-    SVH_HIP_CHECK(ctx, hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return SVH_OK;
+    return copy_d2h(ctx, host_dst, device_src, bytes);
 }
 
 int svh_device_copy(svh_context *ctx, void *device_dst, const void *device_src, size_t bytes) {

@@ -33,6 +33,8 @@ struct ProfStat {
     int64_t launches = 0;
 };
 
+struct Staging; // page-locked ring, copy streams and events of a context's host <-> device transfers (svh_transfer.hip)
+
 } // namespace svh
 
 struct svh_context {
@@ -41,6 +43,7 @@ struct svh_context {
     bool own_stream = false;
     std::string last_error;
     std::vector<svh::PoolBlock> pool;
+    svh::Staging *staging = nullptr; // created by the first large transfer from or to pageable host memory
     bool profiling = false;
     std::string prof_filter; // when not empty only launches of this kernel are bracketed by events
     int prof_every = 1;      // svh_profile_sampling: bracket every n-th eligible launch
@@ -168,6 +171,14 @@ struct OutStage {
     bool direct = false;
     const svh_array *dst = nullptr;
 };
+// host <-> device copies (svh_transfer.hip): direct DMA for page-locked host memory, chunks through a page-locked ring on two copy
+// streams for large pageable arrays.  copy_h2d returns when `src` may be reused, with the data ordered before everything enqueued on the
+// context's stream afterwards; copy_d2h returns when `dst` holds what the context's stream had produced at the call.
+int copy_h2d(svh_context *ctx, void *dst, const void *src, size_t bytes);
+int copy_d2h(svh_context *ctx, void *dst, const void *src, size_t bytes);
+void staging_destroy(svh_context *ctx);
+// (svh_context.hip) give the device's cache of released svh_device_alloc blocks back to the device: the out-of-memory retry of every allocator
+void device_cache_release_all(int device);
 int stage_out(svh_context *ctx, Scratch &scr, const svh_array &a, OutStage *st);
 int finish_out(svh_context *ctx, const OutStage &st);
 // true when any host array took part (the call must synchronise before returning)

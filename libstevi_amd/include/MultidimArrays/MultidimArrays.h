@@ -28,7 +28,40 @@
 #include <stdexcept>
 #include <type_traits>
 
+#define STEVI_HIP_MULTIDIM_COMPAT 1 // (the shims' bridge asks: is this the compatibility header, with its result-memory hook?)
+
 namespace Multidim {
+
+namespace detail {
+// Where the arrays the drop-in shims RETURN get their memory.  Every function of the reference returns a fresh owning array that it has
+// written completely; the shims construct those inside a ResultAllocationScope, and while one is open on the calling thread an
+// allocation of `from_bytes` and more comes from `alloc` (libstevi_hip's page-locked blocks, installed by stevi_hip_bridge.h) and is not
+// cleared first.  Arrays constructed anywhere else are value-initialised new[] memory, as before.  Unset (the default): new[] always.
+struct ResultMemory {
+    void *(*alloc)(std::size_t bytes) = nullptr;
+    void (*release)(void *) = nullptr;
+    std::size_t from_bytes = std::size_t(1) << 20;
+};
+inline ResultMemory &result_memory() {
+    static ResultMemory m;
+    return m;
+}
+inline int &result_scope_depth() {
+    static thread_local int depth = 0;
+    return depth;
+}
+struct ResultAllocationScope {
+    ResultAllocationScope() { ++result_scope_depth(); }
+    ~ResultAllocationScope() { --result_scope_depth(); }
+    ResultAllocationScope(ResultAllocationScope const &) = delete;
+    ResultAllocationScope &operator=(ResultAllocationScope const &) = delete;
+};
+// what the copies and views of one allocation share besides the memory
+struct Control {
+    bool released = false;            // takePointer() handed the memory to the caller
+    void (*release)(void *) = nullptr; // not new[] memory: given back through this
+};
+} // namespace detail
 
 enum class AccessCheck { Check, Nocheck };
 enum ArrayDataAccessConstness { NonConstView, ConstView };
@@ -131,7 +164,13 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
         T *p = _data;
         if (_owner) {
             if (_owner.use_count() != 1) throw std::logic_error("Multidim::Array::takePointer on shared memory");
-            *_released = true;
+            if (_released->release) { // result memory of the shims: the caller is promised new[] memory, so it gets a copy
+                const std::size_t span = memorySpan();
+                p = new T[span];
+                for (std::size_t e = 0; e < span; e++) p[e] = _data[e];
+            } else {
+                _released->released = true;
+            }
         }
         _owner.reset();
         _released.reset();
@@ -244,16 +283,32 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
             _data = nullptr;
             return;
         }
-        // the extent in memory may exceed the element count for non-dense strides
-        std::size_t span = 1;
-        for (int k = 0; k < nDim; k++) span += static_cast<std::size_t>(_shape[k] - 1) * static_cast<std::size_t>(_strides[k]);
+        const std::size_t span = memorySpan();
         // the memory is released with the last array or view of it, unless takePointer() handed it to the caller first
-        auto released = std::make_shared<bool>(false);
+        auto released = std::make_shared<detail::Control>();
         _released = released;
+        if constexpr (std::is_trivially_copyable_v<T> && std::is_trivially_destructible_v<T>) {
+            detail::ResultMemory const &rm = detail::result_memory();
+            if (detail::result_scope_depth() > 0 && rm.alloc && rm.release && span * sizeof(T) >= rm.from_bytes) {
+                if (void *block = rm.alloc(span * sizeof(T))) {
+                    released->release = rm.release;
+                    _owner.reset(static_cast<T *>(block), [released](T *p) { released->release(p); });
+                    _data = _owner.get();
+                    return;
+                }
+            }
+        }
         _owner.reset(new T[span](), [released](T *p) {
-            if (!*released) delete[] p;
+            if (!released->released) delete[] p;
         });
         _data = _owner.get();
+    }
+
+    // the extent in memory may exceed the element count for non-dense strides
+    std::size_t memorySpan() const {
+        std::size_t span = 1;
+        for (int k = 0; k < nDim; k++) span += static_cast<std::size_t>(_shape[k] - 1) * static_cast<std::size_t>(_strides[k]);
+        return span;
     }
 
     template <typename... Is> std::array<array_size_t, nDim> padded(Is... idx) const {
@@ -291,7 +346,7 @@ template <class T, int nDim, ArrayDataAccessConstness viewConstness = NonConstVi
     ShapeBlock _shape, _strides;
     T *_data;
     std::shared_ptr<T> _owner;
-    std::shared_ptr<bool> _released;
+    std::shared_ptr<detail::Control> _released;
 };
 
 // Enumerates the indices of a shape by a flat number (on_demand_cost_volume.h:208-213: one loop, parallel over i, instead of nDim

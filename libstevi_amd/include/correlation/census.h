@@ -13,7 +13,7 @@ namespace Correlation {
 template <typename T_I, Multidim::ArrayDataAccessConstness C> Multidim::Array<census_data_t, 3> censusFeatures(Multidim::Array<T_I, 3, C> const &baseFeatures) {
     auto s = baseFeatures.shape();
     if (s[2] <= 1) return Multidim::Array<census_data_t, 3>(); // census.h:76-78
-    Multidim::Array<census_data_t, 3> census(s[0], s[1], (s[2] - 1) / 32 + 1);
+    auto census = HipBridge::makeResult<Multidim::Array<census_data_t, 3>>(s[0], s[1], (s[2] - 1) / 32 + 1);
     svh_array in = HipBridge::describe(baseFeatures), out = HipBridge::describe(census);
     if (!HipBridge::check(svh_census_features(HipBridge::context(), &in, &out))) return Multidim::Array<census_data_t, 3>();
     return census;
@@ -30,7 +30,7 @@ Multidim::Array<census_data_t, 3> censusTransform2D(Multidim::Array<T_I, nDim> c
     int64_t shp[3];
     if (svh_unfold_shape(&in, h_radius, v_radius, pp, shp) != SVH_OK || shp[0] <= 0 || shp[1] <= 0 || shp[2] <= 1)
         return Multidim::Array<census_data_t, 3>();
-    Multidim::Array<census_data_t, 3> census(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>((shp[2] - 1) / 32 + 1));
+    auto census = HipBridge::makeResult<Multidim::Array<census_data_t, 3>>(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>((shp[2] - 1) / 32 + 1));
     svh_array out = HipBridge::describe(census);
     if (!HipBridge::check(svh_census_transform(HipBridge::context(), &in, h_radius, v_radius, pp, &out))) return Multidim::Array<census_data_t, 3>();
     return census;

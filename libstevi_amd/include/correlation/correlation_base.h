@@ -82,7 +82,7 @@ template <class T_L, class T_R, dispDirection dDir, int nImDims = 2> class condI
 // extractSelectedIndex<strategy>, correlation_base.h:427-464
 template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 2> extractSelectedIndex(Multidim::Array<T_CV, 3> const &costVolume) {
     auto s = costVolume.shape();
-    Multidim::Array<disp_t, 2> disp(s[0], s[1]);
+    auto disp = HipBridge::makeResult<Multidim::Array<disp_t, 2>>(s[0], s[1]);
     if (disp.empty()) return disp;
     svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
     HipBridge::check(svh_extract_selected_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
@@ -93,7 +93,7 @@ template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 2
 template <typename DT, dispDirection dDir = dispDirection::RightToLeft>
 Multidim::Array<DT, 2> selectedIndexToDisp(Multidim::Array<DT, 2> const &selectedIndex, disp_t disp_offset = 0) {
     auto s = selectedIndex.shape();
-    Multidim::Array<DT, 2> disp(s[0], s[1]);
+    auto disp = HipBridge::makeResult<Multidim::Array<DT, 2>>(s[0], s[1]);
     if (disp.empty()) return disp;
     svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
     HipBridge::check(svh_selected_index_to_disp(HipBridge::context(), static_cast<int>(dDir), &in, disp_offset, &out));
@@ -103,7 +103,7 @@ Multidim::Array<DT, 2> selectedIndexToDisp(Multidim::Array<DT, 2> const &selecte
 // selectedCost, correlation_base.h:557-577
 template <class T_CV> Multidim::Array<T_CV, 2> selectedCost(Multidim::Array<T_CV, 3> const &costVolume, Multidim::Array<disp_t, 2> const &selectedIndex) {
     auto s = costVolume.shape();
-    Multidim::Array<T_CV, 2> tcv(s[0], s[1]);
+    auto tcv = HipBridge::makeResult<Multidim::Array<T_CV, 2>>(s[0], s[1]);
     if (tcv.empty()) return tcv;
     svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
     HipBridge::check(svh_selected_cost(HipBridge::context(), &cv, &idx, &out));
@@ -115,7 +115,7 @@ template <class T_CV, dispDirection dir = dispDirection::RightToLeft, truncatedC
 Multidim::Array<T_CV, 3> truncatedCostVolume(Multidim::Array<T_CV, 3> const &costVolume, Multidim::Array<disp_t, 2> const &selectedIndex,
                                              uint8_t h_radius, uint8_t v_radius, uint8_t cost_vol_radius) {
     auto s = costVolume.shape();
-    Multidim::Array<T_CV, 3> tcv(s[0], s[1], (sdir == truncatedCostVolumeDirection::Both) ? cost_vol_radius * 4 + 1 : cost_vol_radius * 2 + 1);
+    auto tcv = HipBridge::makeResult<Multidim::Array<T_CV, 3>>(s[0], s[1], (sdir == truncatedCostVolumeDirection::Both) ? cost_vol_radius * 4 + 1 : cost_vol_radius * 2 + 1);
     if (tcv.empty()) return tcv;
     svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
     HipBridge::check(svh_truncated_cost_volume(HipBridge::context(), static_cast<int>(sdir), static_cast<int>(dir), &cv, &idx, h_radius, v_radius,
@@ -126,7 +126,7 @@ Multidim::Array<T_CV, 3> truncatedCostVolume(Multidim::Array<T_CV, 3> const &cos
 // extractSelected2dIndex<strategy>, correlation_base.h:466-509
 template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 3> extractSelected2dIndex(Multidim::Array<T_CV, 4> const &costVolume) {
     auto s = costVolume.shape();
-    Multidim::Array<disp_t, 3> disp(s[0], s[1], 2);
+    auto disp = HipBridge::makeResult<Multidim::Array<disp_t, 3>>(s[0], s[1], 2);
     if (costVolume.empty()) return disp;
     svh_array cv = HipBridge::describe(costVolume), out = HipBridge::describe(disp);
     HipBridge::check(svh_extract_selected_2d_index(HipBridge::context(), static_cast<int>(strategy), &cv, &out));
@@ -136,7 +136,7 @@ template <dispExtractionStartegy strategy, class T_CV> Multidim::Array<disp_t, 3
 // selected2dIndexToDisp(selectedIndex, searchOffset<2>), correlation_base.h:534-555
 template <typename DT> Multidim::Array<DT, 3> selected2dIndexToDisp(Multidim::Array<DT, 3> const &selectedIndex, searchOffset<2> const &offset) {
     auto s = selectedIndex.shape();
-    Multidim::Array<DT, 3> disp(s[0], s[1], 2);
+    auto disp = HipBridge::makeResult<Multidim::Array<DT, 3>>(s[0], s[1], 2);
     if (selectedIndex.empty()) return disp;
     svh_array in = HipBridge::describe(selectedIndex), out = HipBridge::describe(disp);
     HipBridge::check(svh_selected_2d_index_to_disp(HipBridge::context(), &in, offset.lowerOffset(0), offset.lowerOffset(1), &out));
@@ -150,7 +150,7 @@ Multidim::Array<T_CV, 4> truncatedBidirectionaCostVolume(Multidim::Array<T_CV, 4
                                                          uint8_t cost_vol_radius0, uint8_t cost_vol_radius1) {
     uint8_t r0 = cost_vol_radius0 < 1 ? 1 : cost_vol_radius0, r1 = cost_vol_radius1 < 1 ? r0 : cost_vol_radius1; // :690-696
     auto s = costVolume.shape();
-    Multidim::Array<T_CV, 4> tcv(s[0], s[1], r0 * 2 + 1, r1 * 2 + 1);
+    auto tcv = HipBridge::makeResult<Multidim::Array<T_CV, 4>>(s[0], s[1], r0 * 2 + 1, r1 * 2 + 1);
     if (costVolume.empty()) return tcv;
     svh_array cv = HipBridge::describe(costVolume), idx = HipBridge::describe(selectedIndex), out = HipBridge::describe(tcv);
     HipBridge::check(svh_truncated_bidirectional_cost_volume(HipBridge::context(), &cv, &idx, r0, r1, &out));
@@ -211,7 +211,7 @@ DeviceArray<T_CV, 3> truncatedCostVolume(DeviceArray<T_CV, 3> const &costVolume,
 template <class T_I, class T_O = float, Multidim::ArrayDataAccessConstness C>
 inline Multidim::Array<T_O, 2> channelsMean(Multidim::Array<T_I, 3, C> const &in_data) {
     static_assert(std::is_same_v<std::remove_const_t<T_I>, float> && std::is_same_v<T_O, float>, "libstevi_hip: float feature volumes only");
-    Multidim::Array<T_O, 2> mean(in_data.shape()[0], in_data.shape()[1]);
+    auto mean = HipBridge::makeResult<Multidim::Array<T_O, 2>>(in_data.shape()[0], in_data.shape()[1]);
     if (mean.empty()) return mean;
     svh_array in = HipBridge::describe(in_data), out = HipBridge::describe(mean);
     HipBridge::check(svh_channels_mean(HipBridge::context(), &in, &out));

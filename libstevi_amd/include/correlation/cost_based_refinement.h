@@ -41,7 +41,7 @@ Multidim::Array<float, 2> refineDispCostInterpolation(Multidim::Array<float, 3> 
     int depth = truncatedCostVolume.shape()[2];
     int cv_radius = (depth - 1) / 2;
     if (cv_radius < 1 or 2 * cv_radius + 1 != depth) return Multidim::Array<float, 2>(); // :141-143
-    Multidim::Array<float, 2> refined(shape);
+    auto refined = HipBridge::makeResult<Multidim::Array<float, 2>>(shape);
     if (refined.empty()) return refined;
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out)))
@@ -69,7 +69,7 @@ Multidim::Array<float, 3> refineDisp2dCostInterpolation(Multidim::Array<float, 4
     int cv_radius0 = (cv_shape[2] - 1) / 2, cv_radius1 = (cv_shape[3] - 1) / 2;
     if (cv_radius0 < 1 or cv_radius1 < 1 or 2 * cv_radius0 + 1 != cv_shape[2] or 2 * cv_radius1 + 1 != cv_shape[3])
         return Multidim::Array<float, 3>(); // :180-182
-    Multidim::Array<float, 3> refined(rawDisparity.shape());
+    auto refined = HipBridge::makeResult<Multidim::Array<float, 3>>(rawDisparity.shape());
     if (refined.empty()) return refined;
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_2d_cost_interpolation(HipBridge::context(), static_cast<int>(kernel), static_cast<int>(isotropHypothesis), &tcv,
@@ -87,7 +87,7 @@ Multidim::Array<float, 3> refineDisp2dCostPatchInterpolation(Multidim::Array<flo
     int cv_radius0 = (cv_shape[2] - 1) / 2, cv_radius1 = (cv_shape[3] - 1) / 2;
     if (cv_radius0 < 1 or cv_radius1 < 1 or 2 * cv_radius0 + 1 != cv_shape[2] or 2 * cv_radius1 + 1 != cv_shape[3])
         return Multidim::Array<float, 3>(); // :393-395
-    Multidim::Array<float, 3> refined(rawDisparity.shape());
+    auto refined = HipBridge::makeResult<Multidim::Array<float, 3>>(rawDisparity.shape());
     if (refined.empty()) return refined;
     svh_array tcv = HipBridge::describe(truncatedCostVolume), raw = HipBridge::describe(rawDisparity), out = HipBridge::describe(refined);
     if (!HipBridge::check(svh_refine_disp_2d_cost_patch_interpolation(HipBridge::context(), static_cast<int>(kernel), &tcv, &raw, &out)))

@@ -26,14 +26,14 @@ inline void rangeOf(searchOffset<1> const &r, int32_t &lower, int32_t &count) {
 // ---- per-pixel statistics and feature-volume transforms (rows A7 / A8), float volumes ------------------------------------
 namespace HipBridge {
 template <class Fn, class... Maps> inline Multidim::Array<float, 2> mapOf(Fn fn, svh_array in, int h, int w, Maps... maps) {
-    Multidim::Array<float, 2> out(h, w);
+    auto out = HipBridge::makeResult<Multidim::Array<float, 2>>(h, w);
     if (out.empty()) return out;
     svh_array o = describe(out);
     check(fn(context(), &in, maps..., &o));
     return out;
 }
 template <class Fn, class... Maps> inline Multidim::Array<float, 3> volumeOf(Fn fn, svh_array in, int h, int w, int f, Maps... maps) {
-    Multidim::Array<float, 3> out(h, w, f);
+    auto out = HipBridge::makeResult<Multidim::Array<float, 3>>(h, w, f);
     if (out.empty()) return out;
     svh_array o = describe(out);
     check(fn(context(), &in, maps..., &o));
@@ -93,7 +93,7 @@ Multidim::Array<FType, 3> getFeatureVolumeForMatchFunc(Multidim::Array<T_I, 3, C
     auto shp = feature_vol.shape();
     constexpr bool census = MatchingFunctionTraits<matchFunc>::isCensusBased;
     if (census && shp[2] <= 1) return Multidim::Array<FType, 3>(); // census.h:76-78
-    Multidim::Array<FType, 3> out(shp[0], shp[1], census ? (shp[2] - 1) / 32 + 1 : shp[2]);
+    auto out = HipBridge::makeResult<Multidim::Array<FType, 3>>(shp[0], shp[1], census ? (shp[2] - 1) / 32 + 1 : shp[2]);
     if (out.empty()) return out;
     svh_array in = HipBridge::describe(feature_vol), o = HipBridge::describe(out);
     if (!HipBridge::check(svh_feature_volume_for_match_func(HipBridge::context(), static_cast<int>(matchFunc), &in, &o))) return Multidim::Array<FType, 3>();
@@ -114,7 +114,7 @@ featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim:
         HipBridge::rangeOf(searchRange, lower, count);
         if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || count <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :209-211
         // aggregateCost's own layout (cross_correlations.h:220) is {w*D, 1, w}; the GPU's native one is dense (row, col, disparity)
-        Multidim::Array<TCV, 3> cv(src[0], src[1], count);
+        auto cv = HipBridge::makeResult<Multidim::Array<TCV, 3>>(src[0], src[1], count);
         svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
         if (!HipBridge::check(svh_feature_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, lower, count, &out)))
             return Multidim::Array<TCV, 3>(0, 0, 0);
@@ -123,7 +123,7 @@ featureVolume2CostVolume(Multidim::Array<T_L, 3> const &feature_vol_l, Multidim:
         static_assert(nCvDims == 4, "libstevi_hip: disp_t, searchOffset<1> or searchOffset<2>");
         const int Dh = searchRange.dimRange(0), Dw = searchRange.dimRange(1);
         if (feature_vol_l.shape()[0] != feature_vol_r.shape()[0] || Dh <= 0 || Dw <= 0) return Multidim::Array<TCV, 4>(); // :324-326, :338-340
-        Multidim::Array<TCV, 4> cv(src[0], src[1], Dh, Dw);
+        auto cv = HipBridge::makeResult<Multidim::Array<TCV, 4>>(src[0], src[1], Dh, Dw);
         svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), out = HipBridge::describe(cv);
         if (!HipBridge::check(svh_feature_cost_volume_2d(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r,
                                                          searchRange.template lowerOffset<0>(), searchRange.template upperOffset<0>(),
@@ -147,7 +147,7 @@ Multidim::Array<TCV, 3> unfoldBasedCostVolume(Multidim::Array<T_L, nImDim> const
     if (l_shape[0] != r_shape[0] || disp_width <= 0) return Multidim::Array<TCV, 3>(0, 0, 0); // :751-753
     if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 3>(0, 0, 0); // :755-759
     auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
-    Multidim::Array<TCV, 3> cv(src[0], src[1], disp_width);
+    auto cv = HipBridge::makeResult<Multidim::Array<TCV, 3>>(src[0], src[1], disp_width);
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
     if (!HipBridge::check(svh_unfold_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius, 0,
                                                  disp_width, &out)))
@@ -253,7 +253,7 @@ Multidim::Array<TCV, 4> unfoldBased2dDisparityCostVolume(Multidim::Array<T_L, nI
     if (nImDim == 3 && l_shape[nImDim - 1] != r_shape[nImDim - 1]) return Multidim::Array<TCV, 4>();
     const int Dh = searchWindows.dimRange(0), Dw = searchWindows.dimRange(1);
     if (Dh <= 0 || Dw <= 0) return Multidim::Array<TCV, 4>(); // :338-340
-    Multidim::Array<TCV, 4> cv(l_shape[0], l_shape[1], Dh, Dw);
+    auto cv = HipBridge::makeResult<Multidim::Array<TCV, 4>>(l_shape[0], l_shape[1], Dh, Dw);
     svh_array l = HipBridge::describe(img_l), r = HipBridge::describe(img_r), out = HipBridge::describe(cv);
     if (!HipBridge::check(svh_unfold_cost_volume_2d(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, h_radius, v_radius,
                                                     searchWindows.lowerOffset(0), searchWindows.upperOffset(0), searchWindows.lowerOffset(1),

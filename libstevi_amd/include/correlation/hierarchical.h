@@ -28,7 +28,7 @@ OffsetedCostVolume<TCV> computeGuidedCV(Multidim::Array<T_L, 3> const &feature_v
     auto r_shape = feature_vol_r.shape();
     if (l_shape[0] != r_shape[0]) return {Multidim::Array<TCV, 3>(), Multidim::Array<disp_t, 2>()}; // :90-92
     auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
-    OffsetedCostVolume<TCV> ret = {Multidim::Array<TCV, 3>(src[0], src[1], 2 * upscale_disp_radius + 1), Multidim::Array<disp_t, 2>(src[0], src[1])};
+    OffsetedCostVolume<TCV> ret = {HipBridge::makeResult<Multidim::Array<TCV, 3>>(src[0], src[1], 2 * upscale_disp_radius + 1), HipBridge::makeResult<Multidim::Array<disp_t, 2>>(src[0], src[1])};
     svh_array l = HipBridge::describe(feature_vol_l), r = HipBridge::describe(feature_vol_r), gd = HipBridge::describe(disp_guide);
     svh_array tcv = HipBridge::describe(ret.truncated_cost_volume), disp = HipBridge::describe(ret.disp_estimate);
     if (!HipBridge::check(svh_guided_cost_volume(HipBridge::context(), static_cast<int>(matchFunc), static_cast<int>(dDir), &l, &r, &gd, upscale_disp_radius,
@@ -50,7 +50,7 @@ OffsetedCostVolume<TCV> hiearchicalTruncatedCostVolume(Multidim::Array<T_L, nImD
     auto r_shape = img_r.shape();
     if (l_shape[0] != r_shape[0]) return {Multidim::Array<TCV, 3>(), Multidim::Array<disp_t, 2>()};
     auto const &src = (dDir == dispDirection::RightToLeft) ? r_shape : l_shape;
-    OffsetedCostVolume<TCV> ret = {Multidim::Array<TCV, 3>(src[0], src[1], 2 * upscale_disp_radius + 1), Multidim::Array<disp_t, 2>(src[0], src[1])};
+    OffsetedCostVolume<TCV> ret = {HipBridge::makeResult<Multidim::Array<TCV, 3>>(src[0], src[1], 2 * upscale_disp_radius + 1), HipBridge::makeResult<Multidim::Array<disp_t, 2>>(src[0], src[1])};
     int32_t hr[depth + 1], vr[depth + 1];
     for (int i = 0; i < depth + 1; i++) {
         hr[i] = h_radiuses[i];

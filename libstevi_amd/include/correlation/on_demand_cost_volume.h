@@ -120,7 +120,7 @@ template <matchingFunctions matchFunc, class T_CV, class F_V_S_T, class F_V_T_T,
         tshape[0] = _source->shape()[0];
         tshape[1] = _source->shape()[1];
         for (int i = 0; i < nSearchDim; i++) tshape[2 + i] = 2 * radius + 1;
-        Multidim::Array<T_CV, nCostVolDim> tcv(tshape);
+        auto tcv = HipBridge::makeResult<Multidim::Array<T_CV, nCostVolDim>>(tshape);
         if (tcv.empty()) return tcv;
         const svh_on_demand_params p = params();
         svh_array s = HipBridge::describe(_source->array()), t = HipBridge::describe(_target->array()), d = HipBridge::describe(disp), o = HipBridge::describe(tcv);

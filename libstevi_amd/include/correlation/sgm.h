@@ -21,7 +21,7 @@ Multidim::Array<float, 3> sgmCostVolume(Multidim::Array<T_CV, 3> const &cv_base,
     static_assert(nDirections == 4 or nDirections == 8 or nDirections == 16, "SGM can only operate with 4, 8 or 16 directions");
     static_assert(nDirections != 16, "libstevi_hip: the reference's 16-direction lines overlap inside one OpenMP loop; its result is not defined");
     static_assert(HipBridge::sgmVolumeTypeOnGpuPath<T_CV>, "libstevi_hip: T_CV is float or an integer type of up to 32 bits (the reference casts those to float as it reads them; double is not taken)");
-    Multidim::Array<float, 3> sgm_cv(cv_base.shape());
+    auto sgm_cv = HipBridge::makeResult<Multidim::Array<float, 3>>(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);
@@ -77,7 +77,7 @@ template <int nDirections, dispExtractionStartegy extractionStrategy, class T_CV
 Multidim::Array<float, 3> sgmCostVolumeTextbook(Multidim::Array<T_CV, 3> const &cv_base, float P1, float P2, Margins const &margins, float Pout = 100) {
     static_assert(nDirections == 4 or nDirections == 8, "the textbook mode operates with 4 or 8 directions");
     static_assert(HipBridge::sgmVolumeTypeOnGpuPath<T_CV>, "libstevi_hip: T_CV is float or an integer type of up to 32 bits (the reference casts those to float as it reads them; double is not taken)");
-    Multidim::Array<float, 3> sgm_cv(cv_base.shape());
+    auto sgm_cv = HipBridge::makeResult<Multidim::Array<float, 3>>(cv_base.shape());
     if (sgm_cv.empty()) return sgm_cv;
     const int32_t m[4] = {margins.left(), margins.top(), margins.right(), margins.bottom()};
     svh_array in = HipBridge::describe(cv_base), out = HipBridge::describe(sgm_cv);

@@ -36,6 +36,38 @@ inline ThreadState &thread_state() {
     return ts;
 }
 
+// Result arrays of a megabyte and more live in page-locked host memory (svh_host_alloc): the DMA engines write them, and read them when
+// the caller passes them to the next function of a chain, at the link's rate.  With this tree's MultidimArrays compatibility header the
+// shims construct their results inside a ResultScope; with the real MultidimArrays (whose arrays allocate as they see fit) ResultScope is
+// empty and the library stages the transfers of pageable memory itself (svh_transfer.hip).
+#ifdef STEVI_HIP_MULTIDIM_COMPAT
+inline void install_result_memory() {
+    static const bool once = [] {
+        Multidim::detail::ResultMemory &rm = Multidim::detail::result_memory();
+        rm.alloc = [](std::size_t bytes) -> void * {
+            void *p = nullptr;
+            return svh_host_alloc(bytes, &p) == SVH_OK ? p : nullptr;
+        };
+        rm.release = [](void *p) { (void)svh_host_free(p); };
+        return true;
+    }();
+    (void)once;
+}
+struct ResultScope {
+    ResultScope() { install_result_memory(); }
+    Multidim::detail::ResultAllocationScope scope;
+};
+#else
+struct ResultScope {};
+#endif
+
+// an array a shim is about to have the library fill and then return
+template <class A, class... Args> inline A makeResult(Args &&...args) {
+    ResultScope scope;
+    (void)scope;
+    return A(std::forward<Args>(args)...);
+}
+
 inline svh_context *context() {
     ThreadState &ts = thread_state();
     if (ts.current) return ts.current;
@@ -202,7 +234,7 @@ template <class T, int N> class DeviceArray {
     Multidim::Array<T, N> download() const {
         typename Multidim::Array<T, N>::ShapeBlock s;
         for (int k = 0; k < N; k++) s[k] = _shape[k];
-        Multidim::Array<T, N> host(s);
+        auto host = makeResult<Multidim::Array<T, N>>(s);
         if (empty()) return host;
         // Array(shape) lays its elements out as it sees fit: straight into it when that is dense last-index-fastest, else scattered
         bool dense = true;

@@ -85,7 +85,7 @@ Multidim::Array<T_O, 3> unfold(uint8_t h_radius, uint8_t v_radius, Multidim::Arr
     svh_array in = HipBridge::describe(in_data);
     int64_t shp[3];
     if (svh_unfold_shape(&in, h_radius, v_radius, pp, shp) != SVH_OK || shp[0] <= 0 || shp[1] <= 0) return Multidim::Array<T_O, 3>();
-    Multidim::Array<float, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2])); // the device writes float samples
+    auto out = HipBridge::makeResult<Multidim::Array<float, 3>>(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2])); // the device writes float samples
     {
         svh_array o = HipBridge::describe(out);
         if (!HipBridge::check(svh_unfold_oriented(HipBridge::context(), &in, h_radius, v_radius, pp, static_cast<int>(orientation), &o)))
@@ -109,7 +109,7 @@ Multidim::Array<T_O, 3> unfold(UnFoldCompressor const &compressor, Multidim::Arr
     if (svh_unfold_compressed_shape(&in, compressor.maskData(), compressor.maskHeight(), compressor.maskWidth(), pp, shp) != SVH_OK || shp[0] <= 0 ||
         shp[1] <= 0 || shp[2] <= 0)
         return Multidim::Array<T_O, 3>();
-    Multidim::Array<T_O, 3> out(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2]));
+    auto out = HipBridge::makeResult<Multidim::Array<T_O, 3>>(static_cast<int>(shp[0]), static_cast<int>(shp[1]), static_cast<int>(shp[2]));
     svh_array o = HipBridge::describe(out);
     if (!HipBridge::check(svh_unfold_compressed(HipBridge::context(), &in, compressor.maskData(), compressor.maskHeight(), compressor.maskWidth(), pp, &o)))
         return Multidim::Array<T_O, 3>();
@@ -120,7 +120,7 @@ namespace CompressorGenerators { // unfold.h:475-693: the two 17-superpixel wind
 
 namespace detail {
 template <int N> inline Multidim::Array<int, 2> maskFromRows(const int (&rows)[N][N]) {
-    Multidim::Array<int, 2> out(N, N);
+    auto out = HipBridge::makeResult<Multidim::Array<int, 2>>(N, N);
     for (int i = 0; i < N; i++)
         for (int j = 0; j < N; j++) out.atUnchecked(i, j) = rows[i][j];
     return out;

@@ -29,7 +29,7 @@ Multidim::Array<T_O, nDim> averagePoolingDownsample(Multidim::Array<T_I, nDim, C
     auto shape = input.shape();
     shape[0] = (shape[0] + (windows.vertical() - 1)) / windows.vertical(); // :79-80
     shape[1] = (shape[1] + (windows.horizontal() - 1)) / windows.horizontal();
-    Multidim::Array<T_O, nDim> output(shape);
+    auto output = StereoVision::Correlation::HipBridge::makeResult<Multidim::Array<T_O, nDim>>(shape);
     if (output.empty()) return output;
     svh_array in = HipBridge::describe(input), out = HipBridge::describe(output);
     HipBridge::check(svh_average_pooling_downsample(HipBridge::context(), &in, windows.horizontal(), windows.vertical(), &out));

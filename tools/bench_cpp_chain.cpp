@@ -47,8 +47,24 @@ int main() {
     auto b = device_chain();
     long diff = 0;
     for (size_t e = 0; e < a.flatLenght(); e++) diff += FE(a)[e] != FE(b)[e];
-    const double th = time_ms(host_chain, 2), td = time_ms(device_chain, 10);
+    const double th = time_ms(host_chain, 3), td = time_ms(device_chain, 10);
+    // the host chain call by call (one more run): where the time of a chain on host arrays goes
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now();
+    auto cv = SC::unfoldBasedCostVolume<f>(l, r, 4, 4, D);
+    auto t1 = now();
+    auto s = SC::sgmCostVolume<8, strat>(cv, 0.001f, 0.01f, StereoVision::Margins(), 100);
+    auto t2 = now();
+    auto idx = SC::extractSelectedIndex<strat>(s);
+    auto t3 = now();
+    auto dsp = SC::selectedIndexToDisp<SC::disp_t>(idx, 0);
+    auto t4 = now();
+    const double pcie = 4.0 * 4.0 * H * W * D + (8.0 + 12.0) * H * W;
     printf("{\"chain\": \"unfoldBasedCostVolume -> sgmCostVolume<8> -> extractSelectedIndex -> selectedIndexToDisp (C++ drop-in headers), 1920x1080 D=256 census 9x9\", "
-           "\"host_arrays_ms\": %.1f, \"device_arrays_ms\": %.2f, \"pixels_differing\": %ld}\n", th, td, diff);
+           "\"host_arrays_ms\": %.1f, \"device_arrays_ms\": %.2f, \"pixels_differing\": %ld, \"host_pcie_bytes\": %.0f, \"host_pcie_GBps\": %.1f, "
+           "\"host_call_ms\": {\"unfoldBasedCostVolume\": %.1f, \"sgmCostVolume\": %.1f, \"extractSelectedIndex\": %.1f, \"selectedIndexToDisp\": %.2f}, "
+           "\"results_page_locked\": %d}\n",
+           th, td, diff, pcie, pcie / th / 1e6, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), svh_host_is_pinned(FE(cv), cv.flatLenght() * sizeof(float)));
     return diff != 0;
 }

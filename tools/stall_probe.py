@@ -64,6 +64,7 @@ def oracle_call():
 
 leg("quiet process")
 full = 128  # what the oracle took by default until round 5 (omp_get_max_threads on a 256-CPU host)
+so.set_num_threads(full)
 leg(f"right after an oracle call on {full} threads", oracle_call)
 leg("quiet again")
 so.set_num_threads(16)

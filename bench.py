@@ -90,7 +90,7 @@ def oracle_disparity(wl, src, tgt, rows=None, variant=1):
     return disp, time.perf_counter() - t0
 
 
-def cpu_baseline(wl, src, tgt, budget_s=18.0):
+def cpu_baseline(wl, src, tgt, budget_s=10.0):
     """Oracle (CPU restatement of the reference) timed on a bounded sample of the workload: the literal O(D^2) loops on a row
     band, and the O(D) restatement (bitwise identical) on the whole frame -- whose disparity map is the `end_px_err` check."""
     import oracle as so
@@ -111,6 +111,50 @@ def cpu_baseline(wl, src, tgt, budget_s=18.0):
         "linear_sgm_sample": f"all {wl['H']} rows, O(D) SGM restatement (bitwise identical), {dt_lin:.1f} s",
     }
     return base, full_disp
+
+
+def cpu_band_baseline(func, strategy, src, tgt, r, D, sgm_dirs, rows=64, cols=None, refine=False):
+    """BASELINE.md section 2 for the configurations whose literal port cannot run whole: the oracle (CPU restatement of the reference) on a
+    band of `rows` image rows (plus the window's halo) [and the first `cols` columns] of the same pair: cost volume, then -- when the
+    configuration aggregates -- SGM with the literal O(D^2) loops of sgm.h:269-295 and with the O(D) restatement (bitwise identical), winner
+    [, truncated volume + parabola].  Measured band throughput, and the linear-in-pixels extrapolation to the whole frame, labelled as such."""
+    import oracle as so
+    H, W = src.shape
+    s, t = src[:rows + 2 * r], tgt[:rows + 2 * r]
+    if cols is not None and cols < W:
+        s, t = s[:, :cols], t[:, :cols]
+    s, t = np.ascontiguousarray(s), np.ascontiguousarray(t)
+    bh, bw = s.shape
+    vox = bh * bw * D
+    t0 = time.perf_counter()
+    cv = so.unfold_cost_volume(func, t, s, r, r, D)
+    t_cv = time.perf_counter() - t0
+    out = {"unit": "Mdisparities/s", "cores": so.num_threads(), "kind": "port",
+           "cost_volume_Mdisparities_per_s": round(vox / t_cv / 1e6, 2), "cost_volume_s": round(t_cv, 2)}
+    frame_scale = (H * W) / float(bh * bw)
+    what = f"rows 0..{bh - 1}" + (f", columns 0..{bw - 1}" if bw < W else "") + f" of the same {W}x{H} pair, D={D}"
+    if not sgm_dirs:
+        out.update({"value": out["cost_volume_Mdisparities_per_s"], "sample": f"{what}: the cost volume (the configuration's whole output), {t_cv:.2f} s",
+                    "extrapolated_full_frame_s": round(t_cv * frame_scale, 2), "extrapolation": "linear in pixels (the volume's voxels are independent)"})
+        return out
+    legs = {}
+    for variant, name in ((0, "literal"), (1, "linear")):
+        t0 = time.perf_counter()
+        vol = so.sgm(cv, sgm_dirs, strategy, 0.001, 0.01, (0, 0, 0, 0), 100.0, variant=variant)
+        idx = so.extract_index(vol, strategy)
+        if refine:
+            so.refine_disp(so.truncated_cost_volume(vol, idx, r, r, 1), idx, so.PARABOLA)
+        else:
+            so.index_to_disp(idx)
+        legs[name] = time.perf_counter() - t0
+    lit, lin = t_cv + legs["literal"], t_cv + legs["linear"]
+    out.update({"value": round(vox / lit / 1e6, 3),
+                "sample": f"{what}: cost volume {t_cv:.2f} s + SGM-{sgm_dirs} with the literal O(D^2) loops of sgm.h:269-295 + winner" + (" + truncated volume + parabola" if refine else "") +
+                          f" {legs['literal']:.2f} s, OpenMP over rows / lines",
+                "extrapolated_full_frame_s": round(lit * frame_scale, 1), "extrapolation": "band time x (frame pixels / band pixels): LINEAR-IN-H EXTRAPOLATION, not measured",
+                "linear_sgm_value": round(vox / lin / 1e6, 2), "linear_sgm_sample": f"the same band, O(D) SGM restatement (bitwise identical), {legs['linear']:.2f} s after the cost volume",
+                "linear_sgm_extrapolated_full_frame_s": round(lin * frame_scale, 1)})
+    return out
 
 
 def band_check_mask(H, W, band):
@@ -287,6 +331,11 @@ def other_configs(sv, dev, cpu_legs=True):
         c["end_err"] = {"voxels_differing": int(np.count_nonzero(vol[:band - r].cpu().numpy() != cvb[:band - r])), "of": int((band - r) * W * D),
                         "checked_against": f"oracle (port), top {band - r} rows of the volume, bit for bit"}
         ok &= c["end_err"]["voxels_differing"] == 0
+        t1 = time.perf_counter()
+        so.unfold_cost_volume(so.CENSUS, tgt, src, r, r, D)
+        dt = time.perf_counter() - t1
+        c["cpu_baseline"] = {"value": round(W * H * D / dt / 1e6, 1), "unit": "Mdisparities/s", "cores": so.num_threads(), "kind": "port",
+                             "sample": f"the whole frame, one run: unfoldBasedCostVolume<CENSUS> 9x9, D={D} (census words of both images + the per-voxel Hamming loop), {dt:.2f} s"}
     del vol
     c["wall_s"] = round(time.perf_counter() - t0, 2)
     out["C2"] = c
@@ -339,6 +388,19 @@ def other_configs(sv, dev, cpu_legs=True):
         ok &= (e["cost_max_abs_err"] <= 1e-4 and e["cost_nan_mask_equal"] and e["sgm_voxels_differing"] == 0 and e["disp_pixels_differing"] == 0 and
                e["refined_max_abs_err"] <= 1e-4 and e["refined_nan_mask_equal"] and same_maps)
         del full
+        # the oracle band covers the first rows only: the WHOLE maps against the pass-per-launch form of the Score branch (sgm_score_fused = 0)
+        sv.set_option(d_src, "sgm_score_fused", 0)
+        try:
+            alt = fn()
+        finally:
+            sv.set_option(d_src, "sgm_score_fused", 1)
+        c["whole_map_vs_pass_per_launch_form"] = {
+            "disp_pixels_differing": int((alt["disp"] != res["disp"]).sum().item()), "of": int(alt["disp"].numel()),
+            "refined_bits_differing": int((torch.nan_to_num(alt["refined"], nan=-7.0) != torch.nan_to_num(res["refined"], nan=-7.0)).sum().item()),
+            "checked_against": "the same call with sgm_score_fused = 0 (one read-modify-write sweep per pass), whole frame"}
+        ok &= c["whole_map_vs_pass_per_launch_form"]["disp_pixels_differing"] == 0 and c["whole_map_vs_pass_per_launch_form"]["refined_bits_differing"] == 0
+        del alt
+        c["cpu_baseline"] = cpu_band_baseline(so.NCC, so.SCORE, src, tgt, r, D, 8, rows=64, cols=2048, refine=True)
     del res
     torch.cuda.empty_cache()
     c["wall_s"] = round(time.perf_counter() - t0, 2)
@@ -366,6 +428,18 @@ def other_configs(sv, dev, cpu_legs=True):
         c["end_px_err"] = end_px_err(res["disp"].cpu().numpy(), want[:band], f"oracle (port), top {band} rows, pixels whose SGM lines lie inside the band",
                                      band_check_mask(H, W, band))
         ok &= c["end_px_err"]["pixels_differing"] == 0
+        # the oracle band lies in the first band of the line scans (ScanBands: 1152 rows): the WHOLE map against the form that keeps the six min_p maps
+        # instead of carries between bands and per-tile replays (census_tiles = 0, itself held to the oracle by tests/test_gpu_census_tiles.py)
+        sv.set_option(d_src, "census_tiles", 0)
+        try:
+            maps_form = fn()["disp"]
+        finally:
+            sv.set_option(d_src, "census_tiles", 1)
+        c["whole_map_vs_maps_form"] = {"pixels_differing": int((maps_form != res["disp"]).sum().item()), "of": int(maps_form.numel()),
+                                       "checked_against": "the same call with census_tiles = 0 (six min_p maps, no band-to-band carries), every row band of the frame"}
+        ok &= c["whole_map_vs_maps_form"]["pixels_differing"] == 0
+        del maps_form
+        c["cpu_baseline"] = cpu_band_baseline(so.CENSUS, so.COST, src, tgt, r, D, 8, rows=64, cols=1024)
     c["wall_s"] = round(time.perf_counter() - t0, 2)
     out["C5_one_gpu"] = c
     return out, ok
@@ -785,6 +859,17 @@ def main():
         lb_us = max(compulsory / (HBM_PEAK_GBPS * 1e9), 2.0 * bits * (voxels / world) / (FP4_PEAK_TOPS * 1e12)) * 1e6
         kernel_ms = {k: round(v[0] / n_warm, 4) for k, v in prof_all.items()}  # warm-up steps, every kernel bracketed (each + one event pair)
         shape = f"{wl['W']}x{wl['H']}"
+        # The step a user sees, next to its dominant kernel: the step's time against the floor no implementation can go
+        # below, and the HBM bytes the step's four kernels really move (the PMC passes under profiles/) against the compulsory 12 B/pixel
+        step_traffic = None
+        if world == 1 and args.with_line_scans:
+            per_kernel = {k: load_measured_traffic(k) for k in ("census_transform", dom_name, "sgm_line_scans", "census_finalize")}
+            if all(v is not None for v in per_kernel.values()):
+                step_traffic = int(sum(per_kernel.values()))
+        roof.update({"step_ms": round(ms_per_step, 4), "step_lower_bound_us": round(lb_us, 2), "frac_of_step_floor": round(lb_us / (ms_per_step * 1e3), 4),
+                     "step_floor_model": "max(12 B/pixel of compulsory HBM traffic at 8 TB/s, 128 ops/voxel on the FP4 matrix cores at 10 POP/s)",
+                     "hbm_bytes_per_step": step_traffic, "compulsory_bytes_per_step": int(compulsory),
+                     "hbm_bytes_per_step_source": "profiles/traffic.json, the four kernels of the step (census words, keys, the g map and tile edges are written by one kernel and read by the next)"})
         line = {
             "metric": f"Mdisparities/s (W*H*D) for census+SGM, {'1080p' if wl['name'] == 'C3' else shape} D={wl['D']}; end-px-err vs ref",
             "value": round(value, 1), "unit": "Mdisparities/s",
@@ -923,6 +1008,10 @@ def main():
             sv.set_option(disp_dev, "census_winner_shortcut", 0)  # as the headline: the SGM recurrences run
             try:
                 line["configs"], cfg_ok = other_configs(sv, dev, cpu_legs=not args.no_cpu_baseline)
+                if isinstance(line.get("cpu_baseline"), dict):  # the other configurations' CPU legs, next to the headline's
+                    line["cpu_baseline"]["other_configs"] = {k: {kk: v["cpu_baseline"][kk] for kk in ("value", "unit", "cores", "sample", "linear_sgm_value", "extrapolated_full_frame_s")
+                                                                 if kk in v["cpu_baseline"]} | {"gpu_Mdisparities_per_s": v.get("Mdisparities_per_s")}
+                                                             for k, v in line["configs"].items() if isinstance(v, dict) and "cpu_baseline" in v}
                 line["configs"]["C3"] = "the headline of this line (value, ms_per_step, roofline, cpu_baseline, end_px_err)"
                 if not cfg_ok:
                     rc = 3

@@ -430,11 +430,11 @@ def other_configs(sv, dev, cpu_legs=True):
         ok &= c["end_px_err"]["pixels_differing"] == 0
         # the oracle band lies in the first band of the line scans (ScanBands: 1152 rows): the WHOLE map against the form that keeps the six min_p maps
         # instead of carries between bands and per-tile replays (census_tiles = 0, itself held to the oracle by tests/test_gpu_census_tiles.py)
-        sv.set_option(d_src, "census_tiles", 0)
+        sv.set_test_option(d_src, "census_tiles", 0)
         try:
             maps_form = fn()["disp"]
         finally:
-            sv.set_option(d_src, "census_tiles", 1)
+            sv.set_test_option(d_src, "census_tiles", 1)
         c["whole_map_vs_maps_form"] = {"pixels_differing": int((maps_form != res["disp"]).sum().item()), "of": int(maps_form.numel()),
                                        "checked_against": "the same call with census_tiles = 0 (six min_p maps, no band-to-band carries), every row band of the frame"}
         ok &= c["whole_map_vs_maps_form"]["pixels_differing"] == 0

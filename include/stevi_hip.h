@@ -95,77 +95,27 @@ int svh_context_trim(svh_context *ctx);
 const char *svh_status_string(int status);
 /* message of the last failing call on this context ("" if none) */
 const char *svh_last_error(const svh_context *ctx);
-/* Tuning / test switches.  "census_fast_path" (default 1): 0 forces the general wave-per-line SGM kernels
- * for census costs too (same results, used by the parity tests to cross-check the two implementations).
- * "census_sweep" (default 0 = automatic): engine of the voxel sweep of the fused census pipeline, 1 = the vector-ALU kernel
- * (xor + popcount), 3 = the matrix-core kernels with FP4 operands (Hamming distance as a dot product; at most 8 census words,
- * disp_count a multiple of 32 up to 992 -- of any other count they take the leading multiple and the vector-ALU kernel the rest, merged
- * by MIN); automatic = 3 where it applies.  Same keys bit for bit.  (Round 1's int8 matrix-core form, value 2, lost to the FP4 form and has been removed.)
- * "census_sweep_rl" (default 1): 0 keeps the FP4 engine on its general kernel where the RightToLeft specialisation
- * (a multiple of 32 from 64 to 512 disparities, the search range ending at the target image's right edge) would run.  Same keys.
- * (Development A/Bs of that kernel, same keys again: 2 = column-major tile order everywhere; 3 = neighbouring column tiles per wave also
- * in the items at the right image border, where the default deals them out in serpentine order.)
+/* Options of a context: the five choices a caller has a reason to make.  (Every other switch of the library exists so that the parity
+ * tests can run both sides of an A/B; those live behind svh_test_set_option in include/stevi_hip_test.h and are no part of the product
+ * surface.)  Unknown names and values return SVH_ERR_INVALID_ARGUMENT.
  * "census_float_overflow" (default 0): what becomes of a target census word that rounds to 2^32 on its way through `float`
- * (cross_correlations.h:235-236; words >= 0xFFFFFF80; undefined in C++): 0 = 0xFFFFFFFF, what the reference's Release build gives on
- * a host with AVX-512 and what the GPU's own conversion does; 1 = 0, what x86-64 code generation without AVX-512 gives (the reference's
- * -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
- * "cost_volume_colsum" (default 1): float cost volumes of grey images (all functions but ZSAD) share the per-column sums of
- * neighbouring windows; 0 evaluates every window on its own (round 1's kernel).  Same results within rounding (1e-4 tolerance).
- * "patchmatch_pred_costs" (default 1): svh_cacheless_patch_match evaluates, before each propagation sweep and for every pixel in parallel,
- * the cost of the pixel against its predecessor's solution; the sweep uses it wherever the predecessor kept that solution (most pixels
- * after the first iterations) and evaluates a cost on the spot only behind an accepted candidate.  0: every step of a sweep evaluates
- * its cost.  Same result.
- * "feature_volume_tiled" (default 1): svh_feature_cost_volume(_2d) with a float matching function processes the two feature volumes once
- * (mean subtracted, divided by the norm: the values of the reference's normalised volumes) and compares 64 pixels of a row with their
- * target records from LDS; 0: the per-voxel kernel processes both vectors of every voxel.  Same bits.
- * "guided_shared" (default 1): svh_compute_guided_cv / svh_hierarchical_truncated_cost_volume on grey images with a search radius of at most
- * 3: a block of 256 pixels stages the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of
- * the target windows its pixels look at in LDS once, instead of every pixel processing every sample of every offset again; 0: the
- * per-pixel walk.  Same bits (tests/test_gpu_hierarchical.py).
- * "sgm_score_pad" (default 1): svh_sgm_cost_volume / svh_stereo_match, Score strategy, on 65 .. 511 disparities that are no multiple of 64
- * (the reference's own benchmark uses 160) aggregate a copy of the volume whose rows are padded to the next multiple of 64 with -inf
- * -- a pad never enters a maximum, and cost + anything stays -inf along every line -- so that the vector kernels, the banded sweep and
- * the winner records apply; the result is copied back without the pads.  0: the masked kernels on the caller's layout.  Same bits.
- * "fold_2d_offsets" (default 1): svh_unfold_cost_volume_2d on grey images with a function the column-sum kernel takes stages the
- * v + Dh - 1 target rows of all vertical offsets once per block and walks the (dh, dw) blocks in one launch (as many offsets as the
- * tile holds); 0 = one launch per vertical offset.  Same bits (tests/test_gpu_2d.py).
- * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with
- * the per-voxel kernel (the reference's operations in the reference's order) instead of the register-blocked one.
+ *   (cross_correlations.h:235-236; words >= 0xFFFFFF80; undefined in C++): 0 = 0xFFFFFFFF, what the reference's Release build gives on
+ *   a host with AVX-512 and what the GPU's own conversion does; 1 = 0, what x86-64 code generation without AVX-512 gives (the reference's
+ *   -mavx -mavx2 -mfma flags, every Debug build).  Smooth image gradients produce such words; random textures almost never.
  * "census_winner_shortcut" (default 1): in the integer-exact regime of the census + SGM Cost-branch pipeline the winning disparity of a
- * pixel does not depend on the per-pass minima the reference hands along its lines (they shift every disparity of the pixel alike), so
- * calls that ask for index / disparity maps only skip the line scans; 0 runs them regardless (same maps; the parity tests compare).
- * "census_tiles" (default 1): census + SGM calls that need the aggregated values (reduction keys, refinement taps that are not only
- * subtracted from one another; or any call with "census_winner_shortcut" 0) on a whole image of up to 1152 rows with 8 directions keep,
- * of the line recurrences' per-pass minima, only the values on the edges of 9-row x 64-column tiles, and the per-pixel kernel replays
- * the recurrences inside its tile; 0 writes the six per-pass maps and reads them back (round 2's pair of kernels).  Same results bit
- * for bit (tests/test_gpu_census_tiles.py); margins, 4 directions, taller images and row bands take the maps form regardless.
- * "cost_reduce_fused" (default 1): svh_stereo_match with a float matching function on grey images (windows up to 11 wide, not ZSAD)
- * lets the cost kernel reduce over the disparity axis while a block's waves hold a pixel's whole range: without SGM, for a call that asks
- * for the disparity map alone, the winner (extractSelectedIndex's rule: extremum, ties to the larger index, NaN never wins unless at index
- * 0) -- the volume is then never written and nothing reads it back; with a Cost-strategy SGM the two regional minima its line recurrences
- * run on (see "sgm_cost_two_minima"), so that the probing read of the volume is gone too.  0: extract_index / the probe read the volume.
- * Same maps bit for bit (tests/test_gpu_parity.py::test_winner_and_minima_reduced_inside_the_cost_kernel).
- * "sgm_cost_two_minima" (default 1): svh_sgm_cost_volume, Cost strategy, on a float volume that is not in the exact-integer regime
- * reads the volume ONCE for its line recurrences: a probe leaves every pixel's two regional minima (the smallest finite cost among the
- * disparities that look inside the image, and among those that look past its right border), and the recurrence of sgm.h:257-296 --
- * whose state is one number per line because of `min_a_cost = c_score` -- runs on those two numbers with the reference's float
- * operations (the per-disparity step is non-decreasing in the cost, so a region's minimum over d is the step of the region's minimum).
- * Needs magnitudes that cannot overflow along a line: the probe checks |c| <= 1e30 on the device and otherwise lets the sweeps of the
- * volume run (a finite |Pout| > 1e30 sends the call there directly).  0: one sweep of the volume per pass (rounds 1-3).  Same bits.
- * "sgm_score_finish_fused" (default 1): svh_stereo_match with a Score-strategy function and 8-direction SGM in the banded form below
- * lets the launch that writes a pixel's FINAL aggregated costs emit its winner -- index, disparity, the three truncatedCostVolume<Same>
- * taps for the refinement: DownLeft2UpRight for the pixels it visits (row + column < rows), the downward sweep for the others (the order
- * of the passes is fixed by sgm.h:379-389) -- instead of reading S back in extract_index / truncated_cost_volume; and when the caller did
- * not ask for sgm_cv, only the costs a later pass reads are stored at all.  0: the separate kernels.  Same maps bit for bit
- * (tests/test_gpu_sgm_score_fused.py).
+ *   pixel does not depend on the per-pass minima the reference hands along its lines (they shift every disparity of the pixel alike), so
+ *   calls that ask for index / disparity maps only skip the line scans; 0 runs them regardless (same maps; bench.py times that form).
+ * "census_sweep" (default 0 = automatic): engine of the voxel sweep of the fused census pipeline, 1 = the vector-ALU kernel
+ *   (xor + popcount), 3 = the matrix-core kernels with FP4 operands (Hamming distance as a dot product; at most 8 census words,
+ *   up to 992 disparities); automatic = 3 where it applies.  Same keys bit for bit.
  * "sgm_score_fused" (default 1): how the Score branch of svh_sgm_cost_volume runs its four downward passes (8 directions, whole image,
- * P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  2: one sweep of the volume, a launch per band of 16
- * rows, each block recomputing the lines that enter its strip of columns (read c and the Left2Right contribution, write S: 23
- * instead of 44 bytes per voxel over all passes).  0: one read-modify-write sweep per pass.  1 (default): whichever a model of the two
- * predicts faster -- the bands walk the rows one dependent step after the other, so images of up to about a megapixel at moderate ranges
- * (the reference's own 480x640 x 160 benchmark rows) run faster pass by pass; large volumes in bands.
- * (3 = 2 with the 16-column strips forced that images narrower than about 3000 columns replace by 8-column ones: for the tests.)
- * Same bits in all of them; the parity tests cross-check them. */
+ *   P2 >= P1 >= 0, up to 512 disparities; anything else takes a launch per pass).  2: one sweep of the volume, a launch per band of
+ *   rows, each block recomputing the lines that enter its strip of columns (23 instead of 44 bytes per voxel over all passes).
+ *   0: one read-modify-write sweep per pass.  1: whichever a model of the two predicts faster (small images at moderate ranges run
+ *   faster pass by pass, large volumes in bands).  Same bits in all of them.
+ * "literal_cost_volumes" (default 0): 1 makes svh_hierarchical_truncated_cost_volume build its coarsest cost volume with the per-voxel
+ *   kernel (the reference's operations in the reference's order) instead of the register-blocked one: estimates bit-identical to the
+ *   reference's own arithmetic instead of within its 1e-4. */
 int svh_context_set_option(svh_context *ctx, const char *name, int value);
 /* 1 when a HIP device is visible, 0 otherwise; never fails */
 int svh_device_available(void);

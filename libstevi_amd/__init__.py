@@ -9,5 +9,5 @@ stevimg.py       the reference's .stevimg array files (io/image_io.h), the data 
 from . import _capi  # noqa: F401
 from .correlation import *  # noqa: F401,F403
 from .correlation import (Margins, PaddingMargins, searchOffset1, searchOffset2, matchFuncStrategy, context_for, profile_enable,  # noqa: F401
-                          profile_reset, profile_collect, set_option)
+                          profile_reset, profile_collect, set_option, set_test_option)
 from .stevimg import read_flo, read_stevimg, write_flo, write_stevimg  # noqa: F401,E402

@@ -23,6 +23,7 @@ EXPORTS = [
     "svh_context_create", "svh_context_destroy", "svh_context_set_stream", "svh_context_set_option", "svh_context_synchronize", "svh_context_trim",
     "svh_status_string", "svh_last_error", "svh_device_available", "svh_device_alloc", "svh_device_free", "svh_device_free_detached", "svh_device_cache_trim", "svh_context_get_device", "svh_device_upload", "svh_device_download", "svh_device_copy",
     "svh_host_alloc", "svh_host_free", "svh_host_cache_trim", "svh_host_is_pinned",
+    "svh_test_set_option",  # include/stevi_hip_test.h
     "svh_profile_enable", "svh_profile_filter", "svh_profile_sampling", "svh_profile_reset", "svh_profile_collect", "svh_profile_count", "svh_profile_get",
     "svh_unfold", "svh_unfold_oriented", "svh_unfold_shape", "svh_census_features", "svh_census_transform",
     "svh_feature_cost_volume", "svh_unfold_cost_volume", "svh_unfold_cost_volume_minima", "svh_unfold_cost_volume_winner", "svh_sgm_cost_volume", "svh_sgm_cost_volume_minima", "svh_sgm_cost_volume_winner", "svh_sgm_cost_volume_textbook",
@@ -107,6 +108,7 @@ def load():
         "svh_context_destroy": (C.c_int, [ctx]),
         "svh_context_set_stream": (C.c_int, [ctx, C.c_void_p]),
         "svh_context_set_option": (C.c_int, [ctx, C.c_char_p, C.c_int]),
+        "svh_test_set_option": (C.c_int, [ctx, C.c_char_p, C.c_int]),
         "svh_context_synchronize": (C.c_int, [ctx]),
         "svh_context_trim": (C.c_int, [ctx]),
         "svh_status_string": (C.c_char_p, [C.c_int]),

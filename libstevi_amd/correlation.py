@@ -1000,9 +1000,16 @@ def onDemandTruncatedCostVolume(matchFunc, img_source, img_target, radius, searc
 
 
 def set_option(x, name, value):
-    """svh_context_set_option on the context used for array x (e.g. "census_fast_path", 0/1)."""
+    """svh_context_set_option on the context used for array x: "census_float_overflow", "census_winner_shortcut", "census_sweep",
+    "sgm_score_fused", "literal_cost_volumes" (include/stevi_hip.h)."""
     ctx = context_for(x)
     _check(ctx, _capi.load().svh_context_set_option(ctx, name.encode(), int(value)))
+
+
+def set_test_option(x, name, value):
+    """svh_test_set_option (include/stevi_hip_test.h): the A/B switches the parity tests cross-check -- no part of the product surface."""
+    ctx = context_for(x)
+    _check(ctx, _capi.load().svh_test_set_option(ctx, name.encode(), int(value)))
 
 
 # ------------------------------------------------------------------------------------------------ profiling

@@ -6,6 +6,7 @@
 #include <set>
 
 #include "svh_internal.h"
+#include "../../include/stevi_hip_test.h"
 
 namespace svh {
 
@@ -390,10 +391,16 @@ int svh_context_set_stream(svh_context *ctx, void *stream) {
     return SVH_OK;
 }
 
-int svh_context_set_option(svh_context *ctx, const char *name, int value) {
-    if (!ctx || !name) return SVH_ERR_INVALID_ARGUMENT;
-    if (strcmp(name, "census_fast_path") == 0) {
-        ctx->census_fast_path = value != 0;
+// the five options of the product surface (include/stevi_hip.h); everything else is a test switch (include/stevi_hip_test.h)
+static int set_public_option(svh_context *ctx, const char *name, int value, bool *known) {
+    *known = true;
+    if (strcmp(name, "census_float_overflow") == 0) {
+        if (value != 0 && value != 1) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_float_overflow: 0 (a target word that rounds to 2^32 becomes 0xFFFFFFFF) or 1 (becomes 0)");
+        ctx->census_float_overflow = value;
+        return SVH_OK;
+    }
+    if (strcmp(name, "census_winner_shortcut") == 0) {
+        ctx->census_winner_shortcut = value != 0;
         return SVH_OK;
     }
     if (strcmp(name, "census_sweep") == 0) {
@@ -401,67 +408,61 @@ int svh_context_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_sweep_mode = (int)value;
         return SVH_OK;
     }
-    if (strcmp(name, "census_float_overflow") == 0) {
-        if (value != 0 && value != 1) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "census_float_overflow: 0 (a target word that rounds to 2^32 becomes 0xFFFFFFFF) or 1 (becomes 0)");
-        ctx->census_float_overflow = value;
-        return SVH_OK;
-    }
-    if (strcmp(name, "census_sweep_rl") == 0) {
-        ctx->census_sweep_rl = value;
-        return SVH_OK;
-    }
-    if (strcmp(name, "census_tiles") == 0) {
-        ctx->census_tiles = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "cost_volume_colsum") == 0) {
-        ctx->cost_volume_colsum = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "patchmatch_pred_costs") == 0) {
-        ctx->patchmatch_pred_costs = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "feature_volume_tiled") == 0) {
-        ctx->feature_volume_tiled = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "guided_shared") == 0) {
-        ctx->guided_shared = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "sgm_score_pad") == 0) {
-        ctx->sgm_score_pad = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "fold_2d_offsets") == 0) {
-        ctx->fold_2d_offsets = value != 0;
+    if (strcmp(name, "sgm_score_fused") == 0) {
+        if (value < 0 || value > 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (automatic) or 2 (bands of rows)");
+        ctx->sgm_score_fused = value;
         return SVH_OK;
     }
     if (strcmp(name, "literal_cost_volumes") == 0) {
         ctx->literal_cost_volumes = value != 0;
         return SVH_OK;
     }
-    if (strcmp(name, "census_winner_shortcut") == 0) {
-        ctx->census_winner_shortcut = value != 0;
+    *known = false;
+    return SVH_OK;
+}
+
+int svh_context_set_option(svh_context *ctx, const char *name, int value) {
+    if (!ctx || !name) return SVH_ERR_INVALID_ARGUMENT;
+    bool known = false;
+    const int st = set_public_option(ctx, name, value, &known);
+    if (known) return st;
+    return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);
+}
+
+// include/stevi_hip_test.h: both sides of the library's A/Bs, for the parity tests
+int svh_test_set_option(svh_context *ctx, const char *name, int value) {
+    if (!ctx || !name) return SVH_ERR_INVALID_ARGUMENT;
+    if (strcmp(name, "sgm_score_fused") == 0 && value == 3) { // the bands with 16-column strips forced
+        ctx->sgm_score_fused = 3;
         return SVH_OK;
     }
-    if (strcmp(name, "cost_reduce_fused") == 0) {
-        ctx->cost_reduce_fused = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "sgm_cost_two_minima") == 0) {
-        ctx->sgm_cost_two_minima = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "sgm_score_finish_fused") == 0) {
-        ctx->sgm_score_finish_fused = value != 0;
-        return SVH_OK;
-    }
-    if (strcmp(name, "sgm_score_fused") == 0) {
-        if (value < 0 || value > 3)
-            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "sgm_score_fused: 0 (a launch per pass), 1 (automatic), 2 (bands of rows), 3 (bands, 16-column strips forced)");
-        ctx->sgm_score_fused = value;
+    bool known = false;
+    const int st = set_public_option(ctx, name, value, &known);
+    if (known) return st;
+    struct Switch {
+        const char *name;
+        bool svh_context::*flag;
+    };
+    static const Switch switches[] = {
+        {"census_fast_path", &svh_context::census_fast_path},
+        {"census_tiles", &svh_context::census_tiles},
+        {"cost_volume_colsum", &svh_context::cost_volume_colsum},
+        {"patchmatch_pred_costs", &svh_context::patchmatch_pred_costs},
+        {"feature_volume_tiled", &svh_context::feature_volume_tiled},
+        {"guided_shared", &svh_context::guided_shared},
+        {"sgm_score_pad", &svh_context::sgm_score_pad},
+        {"fold_2d_offsets", &svh_context::fold_2d_offsets},
+        {"cost_reduce_fused", &svh_context::cost_reduce_fused},
+        {"sgm_cost_two_minima", &svh_context::sgm_cost_two_minima},
+        {"sgm_score_finish_fused", &svh_context::sgm_score_finish_fused},
+    };
+    for (const Switch &sw : switches)
+        if (strcmp(name, sw.name) == 0) {
+            ctx->*(sw.flag) = value != 0;
+            return SVH_OK;
+        }
+    if (strcmp(name, "census_sweep_rl") == 0) {
+        ctx->census_sweep_rl = value;
         return SVH_OK;
     }
     return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);

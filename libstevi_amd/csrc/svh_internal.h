@@ -48,22 +48,22 @@ struct svh_context {
     std::string prof_filter; // when not empty only launches of this kernel are bracketed by events
     int prof_every = 1;      // svh_profile_sampling: bracket every n-th eligible launch
     int64_t prof_seen = 0;
-    bool census_fast_path = true; // svh_context_set_option("census_fast_path")
+    bool census_fast_path = true; // svh_test_set_option("census_fast_path")
     bool census_winner_shortcut = true; // svh_context_set_option("census_winner_shortcut"): index / disparity maps without the line scans
     int census_sweep_mode = 0;         // svh_context_set_option("census_sweep"): 0 auto, 1 vector-ALU kernel, 3 FP4 matrix-core kernels
     int census_float_overflow = 0;     // svh_context_set_option("census_float_overflow"): rule E2 when a target word rounds to 2^32: 0 saturate (0xFFFFFFFF), 1 zero
-    int census_sweep_rl = 1;       // svh_context_set_option("census_sweep_rl"): the FP4 engine may use its RightToLeft specialisation (svh_census_sweep_rl.hip)
-    bool census_tiles = true;          // svh_context_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
-    bool cost_volume_colsum = true;    // svh_context_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
-    bool fold_2d_offsets = true;       // svh_context_set_option("fold_2d_offsets"): 2-D disparity volumes of grey images take as many vertical offsets per launch of the column-sum kernel as its tile holds (0: a launch per vertical offset)
-    bool sgm_score_pad = true;         // svh_context_set_option("sgm_score_pad"): Score-branch SGM on 65 .. 511 disparities that are no multiple of 64 runs on copies padded to the next multiple (pads -inf: inert), so that the vector kernels apply (0: the masked forms)
-    bool guided_shared = true;         // svh_context_set_option("guided_shared"): computeGuidedCV on grey images stages a block's processed target features in LDS (each sample subtracted / divided once) instead of once per pixel and offset
-    bool feature_volume_tiled = true;  // svh_context_set_option("feature_volume_tiled"): cost volumes of float feature volumes process the features once and compare from LDS (0: the per-voxel kernel processes both vectors of every voxel)
-    bool patchmatch_pred_costs = true; // svh_context_set_option("patchmatch_pred_costs"): PatchMatch sweeps take the cost of a pixel against its predecessor's unchanged solution from a parallel pre-pass (0: every step evaluates its cost)
+    int census_sweep_rl = 1;       // svh_test_set_option("census_sweep_rl"): the FP4 engine may use its RightToLeft specialisation (svh_census_sweep_rl.hip)
+    bool census_tiles = true;          // svh_test_set_option("census_tiles"): census + SGM with the recurrences run keeps only the carries of the line scans and replays them per tile in the per-pixel kernel (0: six min_p maps, round 2's pair of kernels)
+    bool cost_volume_colsum = true;    // svh_test_set_option("cost_volume_colsum"): float cost volumes of grey images share column sums between windows (0: every window on its own, round 1's kernel)
+    bool fold_2d_offsets = true;       // svh_test_set_option("fold_2d_offsets"): 2-D disparity volumes of grey images take as many vertical offsets per launch of the column-sum kernel as its tile holds (0: a launch per vertical offset)
+    bool sgm_score_pad = true;         // svh_test_set_option("sgm_score_pad"): Score-branch SGM on 65 .. 511 disparities that are no multiple of 64 runs on copies padded to the next multiple (pads -inf: inert), so that the vector kernels apply (0: the masked forms)
+    bool guided_shared = true;         // svh_test_set_option("guided_shared"): computeGuidedCV on grey images stages a block's processed target features in LDS (each sample subtracted / divided once) instead of once per pixel and offset
+    bool feature_volume_tiled = true;  // svh_test_set_option("feature_volume_tiled"): cost volumes of float feature volumes process the features once and compare from LDS (0: the per-voxel kernel processes both vectors of every voxel)
+    bool patchmatch_pred_costs = true; // svh_test_set_option("patchmatch_pred_costs"): PatchMatch sweeps take the cost of a pixel against its predecessor's unchanged solution from a parallel pre-pass (0: every step evaluates its cost)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
-    bool cost_reduce_fused = true;     // svh_context_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
-    bool sgm_cost_two_minima = true;   // svh_context_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
-    bool sgm_score_finish_fused = true; // svh_context_set_option("sgm_score_finish_fused"): svh_stereo_match lets the Score branch's last writer of each pixel emit its winner / taps (0: extract_index + truncatedCostVolume read S back)
+    bool cost_reduce_fused = true;     // svh_test_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
+    bool sgm_cost_two_minima = true;   // svh_test_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass
+    bool sgm_score_finish_fused = true; // svh_test_set_option("sgm_score_finish_fused"): svh_stereo_match lets the Score branch's last writer of each pixel emit its winner / taps (0: extract_index + truncatedCostVolume read S back)
     int sgm_score_fused = 1;           // svh_context_set_option("sgm_score_fused"): the four downward Score-branch passes in one sweep (2 bands, 3 bands with 16-column strips forced; 0: a launch per pass; 1: the faster of the two by a model)
     std::vector<svh::ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_free_events;

@@ -12,10 +12,27 @@ from libstevi_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
+def header_functions(names=("stevi_hip.h", "stevi_hip_test.h")):
+    """every function any header under include/ declares (stevi_hip.h: the product surface; stevi_hip_test.h: the tests' A/B switches)"""
+    found = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        found |= set(re.findall(r"\b(svh_[a-z0-9_]+)\s*\(", text))
+    return sorted(found)
+
+
+def test_headers_under_include_are_the_ones_checked():
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["stevi_hip.h", "stevi_hip_test.h"]
+
+
+def test_public_header_documents_at_most_eight_options():
+    """the product surface carries the options a caller chooses between; the tests' A/B switches live elsewhere"""
     text = open(os.path.join(ROOT, "include", "stevi_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(svh_[a-z0-9_]+)\s*\(", text)))
+    doc = text[text.index("/* Options of a context"):text.index("int svh_context_set_option")]
+    options = re.findall(r'^ \* "([a-z_0-9]+)" \(default', doc, flags=re.M)
+    assert 1 <= len(options) <= 8, options
+    assert "svh_test_set_option" not in header_functions(("stevi_hip.h",))
 
 
 def test_library_exports_every_declared_symbol():

@@ -222,11 +222,11 @@ def test_2d_volume_folded_offsets_same_bits(rng, func):
         right = rng.uniform(-1, 1, shape).astype(np.float32)
         dl, dr = dev(left), dev(right)
         off = sv.searchOffset2(r0[0], r0[1], r1[0], r1[1])
-        sv.set_option(dl, "fold_2d_offsets", 0)
+        sv.set_test_option(dl, "fold_2d_offsets", 0)
         try:
             per_offset = host(sv.unfoldBased2dDisparityCostVolume(func, dl, dr, h_r, v_r, off))
         finally:
-            sv.set_option(dl, "fold_2d_offsets", 1)
+            sv.set_test_option(dl, "fold_2d_offsets", 1)
         folded = host(sv.unfoldBased2dDisparityCostVolume(func, dl, dr, h_r, v_r, off))
         assert folded.shape == per_offset.shape == (shape[0], shape[1], r0[1] - r0[0] + 1, r1[1] - r1[0] + 1)
         assert np.array_equal(folded.view(np.uint32), per_offset.view(np.uint32)), (shape, h_r, v_r, r0, r1)

@@ -22,15 +22,15 @@ DEV = torch.device("cuda:0")
 
 
 def run(d_tgt, d_src, r, D, tiles, fast=1, **kw):
-    sv.set_option(d_tgt, "census_tiles", tiles)
-    sv.set_option(d_tgt, "census_fast_path", fast)
+    sv.set_test_option(d_tgt, "census_tiles", tiles)
+    sv.set_test_option(d_tgt, "census_fast_path", fast)
     sv.set_option(d_tgt, "census_winner_shortcut", 0)
     try:
         return sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, sgmDirections=8, P1=0.3, P2=0.9, want_keys=True, refineKernel=so.GAUSSIAN,
                               refine_h_radius=r, refine_v_radius=r, **kw)
     finally:
-        sv.set_option(d_tgt, "census_tiles", 1)
-        sv.set_option(d_tgt, "census_fast_path", 1)
+        sv.set_test_option(d_tgt, "census_tiles", 1)
+        sv.set_test_option(d_tgt, "census_fast_path", 1)
         sv.set_option(d_tgt, "census_winner_shortcut", 1)
 
 
@@ -172,11 +172,11 @@ def test_shard_finish_replays_tiles_like_the_single_call(shape):
     keys = torch.minimum(sv.censusShardKeys(d_tgt, d_src, r, r, D, (0, 32), **kw), sv.censusShardKeys(d_tgt, d_src, r, r, D, (32, 32), **kw))
     outs = []
     for tiles in (1, 0):
-        sv.set_option(d_tgt, "census_tiles", tiles)
+        sv.set_test_option(d_tgt, "census_tiles", tiles)
         try:
             outs.append(sv.censusShardFinish(d_tgt, d_src, keys, r, r, D, refineKernel=so.GAUSSIAN, refine_h_radius=r, refine_v_radius=r, **kw))
         finally:
-            sv.set_option(d_tgt, "census_tiles", 1)
+            sv.set_test_option(d_tgt, "census_tiles", 1)
     for o in outs:
         assert torch.equal(o["disp"], single["disp"])
         ra, rb = o["refined"].cpu().numpy(), single["refined"].cpu().numpy()

@@ -41,7 +41,7 @@ def modes():
     yield set_mode
     set_mode(False)
     sv.set_option(probe, "census_sweep", 0)
-    sv.set_option(probe, "census_sweep_rl", 1)
+    sv.set_test_option(probe, "census_sweep_rl", 1)
 
 
 def test_fixture_reaches_the_overflowing_words():
@@ -79,7 +79,7 @@ def test_census_sgm_every_engine_both_modes(modes, D, W):
         keys = []
         for mode, rl in ((1, 1), (3, 0), (3, 1)):
             sv.set_option(l, "census_sweep", mode)
-            sv.set_option(l, "census_sweep_rl", rl)
+            sv.set_test_option(l, "census_sweep_rl", rl)
             keys.append(sv.censusShardKeys(l, r, 4, 4, D, (0, D), sgmDirections=8, Pout=100.0).cpu().numpy())
             for shortcut in (0, 1):
                 sv.set_option(l, "census_winner_shortcut", shortcut)

@@ -75,10 +75,10 @@ def test_c3_census_sgm_1080p(c3_pair):
     d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
     fast = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, sgmDirections=8, Pout=Pout)["disp"]
     try:
-        sv.set_option(d_tgt, "census_fast_path", 0)
+        sv.set_test_option(d_tgt, "census_fast_path", 0)
         gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, sgmDirections=8, Pout=Pout, want_cv=True, want_sgm_cv=True)
     finally:
-        sv.set_option(d_tgt, "census_fast_path", 1)
+        sv.set_test_option(d_tgt, "census_fast_path", 1)
     assert torch.equal(fast, gen["disp"])
     # identity (integer costs): S - [(1+n) C + n Pout oob] is the same for every d; its argmin is the argmin of S
     H, W = 1080, 1920
@@ -194,10 +194,10 @@ def test_c5_shards_8k_fullsize():
     assert torch.equal(sharded, single)
     del keys, sharded
     try:  # the general wave-per-line kernels + literal float evaluation per voxel
-        sv.set_option(d_tgt, "census_fast_path", 0)
+        sv.set_test_option(d_tgt, "census_fast_path", 0)
         gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, **kw)["disp"]
     finally:
-        sv.set_option(d_tgt, "census_fast_path", 1)
+        sv.set_test_option(d_tgt, "census_fast_path", 1)
     assert torch.equal(gen, single)
     del gen
     try:  # the vector-ALU sweep
@@ -226,11 +226,11 @@ def test_census_sgm_wide_short_images_vs_oracle(W):
     for engine, rl in ((0, 1), (1, 1), (3, 0)):
         try:
             sv.set_option(d_tgt, "census_sweep", engine)
-            sv.set_option(d_tgt, "census_sweep_rl", rl)
+            sv.set_test_option(d_tgt, "census_sweep_rl", rl)
             got = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, D, sgmDirections=8, Pout=100.0)["disp"].cpu().numpy()
         finally:
             sv.set_option(d_tgt, "census_sweep", 0)
-            sv.set_option(d_tgt, "census_sweep_rl", 1)
+            sv.set_test_option(d_tgt, "census_sweep_rl", 1)
         assert np.array_equal(got, want), (engine, rl)
 
 

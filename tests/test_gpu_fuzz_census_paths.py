@@ -40,11 +40,11 @@ def test_census_paths_agree_on_random_geometries(seed):
             default = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, **kw)["disp"].cpu().numpy()
             sv.set_option(d_tgt, "census_winner_shortcut", 0)
             scans = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, **kw)["disp"].cpu().numpy()
-            sv.set_option(d_tgt, "census_fast_path", 0)
+            sv.set_test_option(d_tgt, "census_fast_path", 0)
             general = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, r, r, D, **kw)["disp"].cpu().numpy()
         finally:
             sv.set_option(d_tgt, "census_winner_shortcut", 1)
-            sv.set_option(d_tgt, "census_fast_path", 1)
+            sv.set_test_option(d_tgt, "census_fast_path", 1)
         cv = so.unfold_cost_volume(so.CENSUS, tgt, src, r, r, D, int(ddir))
         vol = so.sgm(cv, n_dir, so.COST, 0.3, 0.9, margins, Pout) if n_dir else cv
         exp = so.index_to_disp(so.extract_index(vol, so.COST), int(ddir))

@@ -146,11 +146,11 @@ def test_guided_shared_features_same_bits_as_the_per_pixel_walk(func):
         for ddir in (R2L, L2R):
             outs = []
             for shared in (1, 0):
-                sv.set_option(d_src, "guided_shared", shared)
+                sv.set_test_option(d_src, "guided_shared", shared)
                 try:
                     res = sv.hiearchicalTruncatedCostVolume(func, 2, d_tgt, d_src, r, r, 2 * max(bg, sq) + 8, radius, ddir)
                 finally:
-                    sv.set_option(d_src, "guided_shared", 1)
+                    sv.set_test_option(d_src, "guided_shared", 1)
                 outs.append((host(res.disp_estimate), host(res.truncated_cost_volume)))
             assert np.array_equal(outs[0][0], outs[1][0]), (H, W, r, radius)
             assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)), (H, W, r, radius)

@@ -442,12 +442,12 @@ def test_census_fast_path_equals_general_and_oracle(D, ddir):
                   refine_h_radius=h_r, refine_v_radius=v_r, want_keys=True)
         d_tgt, d_src = dev(tgt), dev(src)
         try:
-            sv.set_option(d_tgt, "census_fast_path", 1)
+            sv.set_test_option(d_tgt, "census_fast_path", 1)
             fast = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
-            sv.set_option(d_tgt, "census_fast_path", 0)
+            sv.set_test_option(d_tgt, "census_fast_path", 0)
             gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
         finally:
-            sv.set_option(d_tgt, "census_fast_path", 1)
+            sv.set_test_option(d_tgt, "census_fast_path", 1)
         for k in ("disp", "keys"):
             assert_bits(fast[k], host(gen[k]))
         assert_close(fast["refined"], host(gen["refined"]), 0.0)
@@ -474,11 +474,11 @@ def test_census_winner_without_line_scans(D, ddir):
             short = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
             sv.set_option(d_tgt, "census_winner_shortcut", 0)
             scans = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
-            sv.set_option(d_tgt, "census_fast_path", 0)
+            sv.set_test_option(d_tgt, "census_fast_path", 0)
             gen = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, h_r, v_r, D, **kw)
         finally:
             sv.set_option(d_tgt, "census_winner_shortcut", 1)
-            sv.set_option(d_tgt, "census_fast_path", 1)
+            sv.set_test_option(d_tgt, "census_fast_path", 1)
         assert_bits(short["disp"], host(scans["disp"]))
         assert_bits(short["disp"], host(gen["disp"]))
         cv = so.unfold_cost_volume(so.CENSUS, tgt, src, h_r, v_r, D, int(ddir))
@@ -592,12 +592,12 @@ def test_sgm_integer_volume_routes_agree(rng, D):
         for margins, Pout in (((0, 0, 0, 0), 100.0), ((2, 1, 0, 3), 7.0)):
             exp = so.sgm(v, 8, so.COST, 0.3, 0.9, margins, Pout)
             try:
-                sv.set_option(d, "census_fast_path", 1)
+                sv.set_test_option(d, "census_fast_path", 1)
                 a = host(sv.sgmCostVolume(8, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout))
-                sv.set_option(d, "census_fast_path", 0)
+                sv.set_test_option(d, "census_fast_path", 0)
                 b = host(sv.sgmCostVolume(8, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout))
             finally:
-                sv.set_option(d, "census_fast_path", 1)
+                sv.set_test_option(d, "census_fast_path", 1)
             for got in (a, b):
                 assert np.array_equal(np.isnan(got), np.isnan(exp))
                 ok = ~np.isnan(exp)
@@ -631,7 +631,7 @@ def test_sgm_cost_branch_two_minima_route(rng, D):
             outs = {}
             try:
                 for route in (1, 0):
-                    sv.set_option(d, "sgm_cost_two_minima", route)
+                    sv.set_test_option(d, "sgm_cost_two_minima", route)
                     sv.profile_reset(d)
                     sv.profile_enable(d, True)
                     outs[route] = host(sv.sgmCostVolume(n_dir, so.COST, d, 0.3, 0.9, sv.Margins(*margins), Pout))
@@ -642,7 +642,7 @@ def test_sgm_cost_branch_two_minima_route(rng, D):
                     else:  # option off, or a finite Pout beyond the regime: no probe for the minima, the sweeps run unconditionally
                         assert "sgm_cost_minmap_scalar" not in kernels
             finally:
-                sv.set_option(d, "sgm_cost_two_minima", 1)
+                sv.set_test_option(d, "sgm_cost_two_minima", 1)
             for route, got in outs.items():
                 assert np.array_equal(np.isnan(got), np.isnan(exp)), (name, n_dir, margins, Pout, route)
                 ok = ~np.isnan(exp)
@@ -659,11 +659,11 @@ def test_sgm_cost_branch_two_minima_route(rng, D):
 
 
 def _with_option(t, name, value, fn):
-    sv.set_option(t, name, value)
+    sv.set_test_option(t, name, value)
     try:
         return fn()
     finally:
-        sv.set_option(t, name, 1)
+        sv.set_test_option(t, name, 1)
 
 
 @pytest.mark.parametrize("func", [MF.SAD, MF.SSD, MF.CC, MF.NCC, MF.ZNCC, MF.ZSSD, MF.ZCC])
@@ -1063,11 +1063,11 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
         dl, dr = dev(fl), dev(fr)
         outs = []
         for tiled in (1, 0):
-            sv.set_option(dl, "feature_volume_tiled", tiled)
+            sv.set_test_option(dl, "feature_volume_tiled", tiled)
             try:
                 outs.append(host(sv.featureVolume2CostVolume(func, dl, dr, D, ddir)))
             finally:
-                sv.set_option(dl, "feature_volume_tiled", 1)
+                sv.set_test_option(dl, "feature_volume_tiled", 1)
         assert np.array_equal(np.isnan(outs[0]), np.isnan(outs[1]))
         ok = ~np.isnan(outs[0])
         assert np.array_equal(outs[0][ok].view(np.uint32), outs[1][ok].view(np.uint32)), (H, Ws, Wt, F, D)
@@ -1076,11 +1076,11 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
     img_r = rng.uniform(-1, 1, (20, 140)).astype(np.float32)
     comp = sv.UnFoldCompressor(sv.CompressorGenerators.GrPix17R3Filter())
     a = host(sv.unfoldBasedCostVolumeCompressed(func, dev(img_l), dev(img_r), comp, 24))
-    sv.set_option(dev(img_l), "feature_volume_tiled", 0)
+    sv.set_test_option(dev(img_l), "feature_volume_tiled", 0)
     try:
         b = host(sv.unfoldBasedCostVolumeCompressed(func, dev(img_l), dev(img_r), comp, 24))
     finally:
-        sv.set_option(dev(img_l), "feature_volume_tiled", 1)
+        sv.set_test_option(dev(img_l), "feature_volume_tiled", 1)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32))
 
 
@@ -1122,11 +1122,11 @@ def test_colour_images_through_the_column_sum_kernel(rng, func):
         dl, dr = dev(left), dev(right)
         exp = so.unfold_cost_volume(int(func), left, right, r, r, D, int(ddir))
         got = host(sv.unfoldBasedCostVolume(func, dl, dr, r, r, D, ddir))
-        sv.set_option(dl, "cost_volume_colsum", 0)
+        sv.set_test_option(dl, "cost_volume_colsum", 0)
         try:
             per_voxel = host(sv.unfoldBasedCostVolume(func, dl, dr, r, r, D, ddir))
         finally:
-            sv.set_option(dl, "cost_volume_colsum", 1)
+            sv.set_test_option(dl, "cost_volume_colsum", 1)
         for other in (exp, per_voxel):
             assert np.array_equal(np.isnan(got), np.isnan(other)), (H, W, C, r, D)
             ok = ~np.isnan(other)

@@ -127,9 +127,9 @@ def test_patch_match_sweeps_with_predecessor_costs_same_result(rng, func, nd):
         d_src, d_tgt = dev(src), dev(tgt)
         outs = []
         for opt in (1, 0):
-            sv.set_option(d_src, "patchmatch_pred_costs", opt)
+            sv.set_test_option(d_src, "patchmatch_pred_costs", opt)
             try:
                 outs.append(sv.cachelessPatchMatch(func, d_src, d_tgt, 2, off, n_iter, n_random, 77, return_iterations=True))
             finally:
-                sv.set_option(d_src, "patchmatch_pred_costs", 1)
+                sv.set_test_option(d_src, "patchmatch_pred_costs", 1)
         assert np.array_equal(host(outs[0][0]), host(outs[1][0])) and outs[0][1] == outs[1][1], (H, W, C)

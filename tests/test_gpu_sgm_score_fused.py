@@ -131,7 +131,7 @@ def test_winner_emitted_by_the_last_writer(rng, shape_d, func_name):
     hr = 2
 
     def run(fused, kernel, want_sgm_cv):
-        sv.set_option(l, "sgm_score_finish_fused", fused)
+        sv.set_test_option(l, "sgm_score_finish_fused", fused)
         try:
             sv.profile_reset(l)
             sv.profile_enable(l, True)
@@ -140,7 +140,7 @@ def test_winner_emitted_by_the_last_writer(rng, shape_d, func_name):
             sv.profile_enable(l, False)
             return out, sv.profile_collect(l)
         finally:
-            sv.set_option(l, "sgm_score_finish_fused", 1)
+            sv.set_test_option(l, "sgm_score_finish_fused", 1)
 
     for kernel in (sv.InterpolationKernel.Parabola, sv.InterpolationKernel.Equiangular, None):
         for want_sgm_cv in (False, True):
@@ -179,11 +179,11 @@ def test_winner_emitted_by_the_last_writer_ties_and_nan(rng):
     img = np.full((H, W), 0.5, np.float32)
     l = torch.from_numpy(img).to(DEV)
     for fused in (1, 0):
-        sv.set_option(l, "sgm_score_finish_fused", fused)
+        sv.set_test_option(l, "sgm_score_finish_fused", fused)
         try:
             out = sv.stereoMatch(MF.CC, l, l, 1, 1, D, sgmDirections=8, P1=0.0, P2=0.0, Pout=0.0)
         finally:
-            sv.set_option(l, "sgm_score_finish_fused", 1)
+            sv.set_test_option(l, "sgm_score_finish_fused", 1)
         cv = so.unfold_cost_volume(so.CC, img, img, 1, 1, D)
         exp = so.index_to_disp(so.extract_index(so.sgm(cv, 8, so.SCORE, 0.0, 0.0, (0, 0, 0, 0), 0.0), so.SCORE))
         assert np.array_equal(out["disp"].cpu().numpy(), exp), fused
@@ -191,11 +191,11 @@ def test_winner_emitted_by_the_last_writer_ties_and_nan(rng):
     z = torch.zeros((H, W), device=DEV)
     outs = []
     for fused in (1, 0):
-        sv.set_option(z, "sgm_score_finish_fused", fused)
+        sv.set_test_option(z, "sgm_score_finish_fused", fused)
         try:
             outs.append(sv.stereoMatch(MF.NCC, z, z, 1, 1, D, sgmDirections=8, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=1, refine_v_radius=1))
         finally:
-            sv.set_option(z, "sgm_score_finish_fused", 1)
+            sv.set_test_option(z, "sgm_score_finish_fused", 1)
     assert torch.equal(outs[0]["disp"], outs[1]["disp"]) and int(outs[0]["disp"].abs().sum()) == 0
     ra, rb = outs[0]["refined"].cpu().numpy(), outs[1]["refined"].cpu().numpy()
     assert np.array_equal(np.isnan(ra), np.isnan(rb)) and np.array_equal(ra[~np.isnan(ra)], rb[~np.isnan(rb)])
@@ -221,10 +221,10 @@ def test_all_finite_regime_drops_the_filters_and_nothing_else(func_name, flat_pa
     sv.set_option(l, "sgm_score_fused", 2)  # (the bands: the automatic choice runs a volume of this size pass by pass)
     try:
         a = sv.stereoMatch(func, l, r, hr, hr, D, want_cv=True, want_sgm_cv=True, **kw)
-        sv.set_option(l, "sgm_score_finish_fused", 0)
+        sv.set_test_option(l, "sgm_score_finish_fused", 0)
         b = sv.stereoMatch(func, l, r, hr, hr, D, want_sgm_cv=True, **kw)
     finally:
-        sv.set_option(l, "sgm_score_finish_fused", 1)
+        sv.set_test_option(l, "sgm_score_finish_fused", 1)
         sv.set_option(l, "sgm_score_fused", 1)
     auto = sv.stereoMatch(func, l, r, hr, hr, D, **kw)  # the default choice: the same maps
     assert torch.equal(a["disp"], auto["disp"])
@@ -275,12 +275,12 @@ def test_rows_padded_to_whole_lanes_equal_the_masked_forms(rng, D):
         exp = so.sgm(cv, n_dir, so.SCORE, P1, P2, m, Pout)
         outs = []
         for pad in (1, 0):
-            sv.set_option(d, "sgm_score_pad", pad)
+            sv.set_test_option(d, "sgm_score_pad", pad)
             try:
                 vol = sv.sgmCostVolume(n_dir, so.SCORE, d, P1, P2, margins, Pout, keep_winner=True)
                 idx = sv.extractSelectedIndex(so.SCORE, vol)
             finally:
-                sv.set_option(d, "sgm_score_pad", 1)
+                sv.set_test_option(d, "sgm_score_pad", 1)
             outs.append((vol.cpu().numpy(), idx.cpu().numpy()))
         for vol, idx in outs:
             assert np.array_equal(np.isnan(vol), np.isnan(exp))
@@ -303,7 +303,7 @@ def test_winner_emitted_by_left2right_with_four_directions(rng, shape_d, func_na
     hr = 2
 
     def run(fused, kernel, want_sgm_cv):
-        sv.set_option(l, "sgm_score_finish_fused", fused)
+        sv.set_test_option(l, "sgm_score_finish_fused", fused)
         try:
             sv.profile_reset(l)
             sv.profile_enable(l, True)
@@ -312,7 +312,7 @@ def test_winner_emitted_by_left2right_with_four_directions(rng, shape_d, func_na
             sv.profile_enable(l, False)
             return out, sv.profile_collect(l)
         finally:
-            sv.set_option(l, "sgm_score_finish_fused", 1)
+            sv.set_test_option(l, "sgm_score_finish_fused", 1)
 
     for kernel in (sv.InterpolationKernel.Parabola, None):
         for want_sgm_cv in (False, True):
@@ -343,11 +343,11 @@ def test_fused_call_writes_padded_rows_directly(rng, D, n_dir):
     kw = dict(sgmDirections=n_dir, P1=0.001, P2=0.01, Pout=100.0, refineKernel=sv.InterpolationKernel.Parabola, refine_h_radius=2, refine_v_radius=2)
     a = sv.stereoMatch(sv.matchingFunctions.ZNCC, l, r, 2, 2, D, **kw)
     b = sv.stereoMatch(sv.matchingFunctions.ZNCC, l, r, 2, 2, D, want_cv=True, want_sgm_cv=True, **kw)
-    sv.set_option(l, "sgm_score_pad", 0)
+    sv.set_test_option(l, "sgm_score_pad", 0)
     try:
         c = sv.stereoMatch(sv.matchingFunctions.ZNCC, l, r, 2, 2, D, **kw)
     finally:
-        sv.set_option(l, "sgm_score_pad", 1)
+        sv.set_test_option(l, "sgm_score_pad", 1)
     for other in (b, c):
         assert torch.equal(a["disp"], other["disp"])
         ra, rb = a["refined"].cpu().numpy(), other["refined"].cpu().numpy()
@@ -372,7 +372,7 @@ def test_winner_records_from_the_volume_when_the_passes_ran(rng, shape_d, func_n
 
     def run(form, fused, kernel, want_sgm_cv):
         sv.set_option(l, "sgm_score_fused", form)
-        sv.set_option(l, "sgm_score_finish_fused", fused)
+        sv.set_test_option(l, "sgm_score_finish_fused", fused)
         try:
             sv.profile_reset(l)
             sv.profile_enable(l, True)
@@ -382,7 +382,7 @@ def test_winner_records_from_the_volume_when_the_passes_ran(rng, shape_d, func_n
             return out, sv.profile_collect(l)
         finally:
             sv.set_option(l, "sgm_score_fused", 1)
-            sv.set_option(l, "sgm_score_finish_fused", 1)
+            sv.set_test_option(l, "sgm_score_finish_fused", 1)
 
     for kernel in (sv.InterpolationKernel.Parabola, None):
         for want_sgm_cv in (False, True):

@@ -28,11 +28,11 @@ def both_engines(fn, probe):
     try:
         for mode, rl in ((1, 1), (3, 0), (3, 1)):
             sv.set_option(probe, "census_sweep", mode)
-            sv.set_option(probe, "census_sweep_rl", rl)
+            sv.set_test_option(probe, "census_sweep_rl", rl)
             out.append(fn())
     finally:
         sv.set_option(probe, "census_sweep", 0)
-        sv.set_option(probe, "census_sweep_rl", 1)
+        sv.set_test_option(probe, "census_sweep_rl", 1)
     return out
 
 

@@ -18,7 +18,7 @@ for k in range(0, len(args), 4):
     off = sv.searchOffset2(-(Dh // 2), Dh - 1 - Dh // 2, -(Dw // 2), Dw - 1 - Dw // 2)
     out = {"func": args[k], "window": 2 * r + 1, "Dh": Dh, "Dw": Dw, "Mvoxels": W * H * Dh * Dw / 1e6}
     for fold in (0, 1):
-        sv.set_option(d_src, "fold_2d_offsets", fold)
+        sv.set_test_option(d_src, "fold_2d_offsets", fold)
         cv = sv.unfoldBased2dDisparityCostVolume(func, d_tgt, d_src, r, r, off); torch.cuda.synchronize()
         sv.profile_reset(d_src); sv.profile_enable(d_src, True)
         n = 5
@@ -29,5 +29,5 @@ for k in range(0, len(args), 4):
         ms = prof["cost_volume_tiled"][0] / n
         out["fold" if fold else "per_offset"] = {"ms": round(ms, 3), "TB_per_s_written": round(W * H * Dh * Dw * 4 / ms / 1e9, 2)}
         del cv
-    sv.set_option(d_src, "fold_2d_offsets", 1)
+    sv.set_test_option(d_src, "fold_2d_offsets", 1)
     print(json.dumps(out), flush=True)

@@ -13,7 +13,7 @@ ds, dt_ = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
 sv.set_option(ds, "census_winner_shortcut", 0)
 for D in [int(a) for a in sys.argv[1:]] or [64, 96, 128, 160, 192, 256, 320, 512]:
     for rl in (1, 0):
-        sv.set_option(ds, "census_sweep_rl", rl)
+        sv.set_test_option(ds, "census_sweep_rl", rl)
         f = lambda: sv.stereoMatch(MF.CENSUS, dt_, ds, 4, 4, D, sgmDirections=8)
         f(); f(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -26,4 +26,4 @@ for D in [int(a) for a in sys.argv[1:]] or [64, 96, 128, 160, 192, 256, 320, 512
         sv.profile_enable(ds, False)
         prof = sv.profile_collect(ds)
         print(json.dumps({"D": D, "census_sweep_rl": rl, "ms": round(dt * 1e3, 4), "kernel_ms": {k: round(v[0] / 5, 4) for k, v in prof.items() if "sweep" in k}}), flush=True)
-sv.set_option(ds, "census_sweep_rl", 1); sv.set_option(ds, "census_winner_shortcut", 1)
+sv.set_test_option(ds, "census_sweep_rl", 1); sv.set_option(ds, "census_winner_shortcut", 1)

@@ -46,7 +46,7 @@ def main():
         for arm in args.arms:
             opts = [kv.split("=") for kv in arm.split(",") if kv]
             for k, v in opts:
-                sv.set_option(d_src, k, int(v))
+                sv.set_test_option(d_src, k, int(v))
                 touched.add(k)
             for _ in range(5):
                 out = step()

@@ -66,5 +66,7 @@ bool launch_sweep_pm(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *k
 // the same for RightToLeft geometries whose Pout region is "target column outside the image", a multiple of 32 from 64 to 512
 // disparities, up to four census words (svh_census_sweep_rl.hip); launch_sweep_pm tries it first unless the "census_sweep_rl" option is 0
 bool launch_sweep_rl(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner *winner);
+// (svh_census_sweep_rl_wide.hip) the same specialisation for records of five to eight words, geometry already checked
+bool launch_sweep_rl_wide(svh_context *ctx, const CensusGeom &g, float Pout, uint2 *keys, float *gmap, int *status, const SweepWinner &sw);
 
 } // namespace svh

@@ -28,7 +28,7 @@ FORMS = [2, 3]  # (1, the default, lets a model choose between 0 and 2) 2: a lau
 
 def both_forms(cv, P1, P2, Pout, form):
     d = torch.from_numpy(cv).to(DEV)
-    sv.set_option(d, "sgm_score_fused", form)
+    sv.set_test_option(d, "sgm_score_fused", form)
     try:
         fused = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout)
         sv.set_option(d, "sgm_score_fused", 0)
@@ -101,7 +101,7 @@ def test_fused_forms_on_random_geometries(seed):
         d = torch.from_numpy(cv).to(DEV)
         try:
             for form in (0, 1, 2, 3):
-                sv.set_option(d, "sgm_score_fused", form)
+                sv.set_test_option(d, "sgm_score_fused", form)
                 got = sv.sgmCostVolume(8, so.SCORE, d, P1, P2, None, Pout).cpu().numpy()
                 what = f"case {case} form {form}: {H}x{W}x{D} P1={P1} P2={P2} Pout={Pout}"
                 assert np.array_equal(np.isnan(got), np.isnan(exp)), what
@@ -371,7 +371,7 @@ def test_winner_records_from_the_volume_when_the_passes_ran(rng, shape_d, func_n
     hr = 2
 
     def run(form, fused, kernel, want_sgm_cv):
-        sv.set_option(l, "sgm_score_fused", form)
+        sv.set_test_option(l, "sgm_score_fused", form)
         sv.set_test_option(l, "sgm_score_finish_fused", fused)
         try:
             sv.profile_reset(l)

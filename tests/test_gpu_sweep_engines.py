@@ -152,9 +152,11 @@ def test_geometries_outside_the_matrix_core_kernel_still_run():
 @pytest.mark.parametrize("D", [33, 50, 100, 250, 333])
 @pytest.mark.parametrize("W", [97, 420])
 def test_ranges_that_are_no_multiple_of_32(D, W):
-    """The matrix cores take the leading multiple of 32 disparities, the vector ALU the rest as a second disparity shard whose keys are
-    MIN-merged into the first part's (launch_sweep): the same keys as the vector ALU alone over the whole range, both directions, whole
-    ranges, shards and ranges that start below zero; the oracle's disparities."""
+    """RightToLeft ranges that end at the image edge: one launch of the RAGGED form of the specialised kernel (the cells past the range are
+    masked by the start patterns of the last two row tiles, round 5).  Other geometries: the matrix cores take the leading multiple of 32
+    disparities, the vector ALU the rest as a second disparity shard whose keys are MIN-merged into the first part's (launch_sweep).  The
+    same keys as the vector ALU alone over the whole range, both directions, whole ranges, shards and ranges that start below zero; the
+    oracle's disparities."""
     src, tgt, _ = parallax_pair(11, W, 9, 3, min(40, W // 3), 2, 13, seed=5 * D + W)
     l, r = torch.from_numpy(tgt).to(DEV), torch.from_numpy(src).to(DEV)
     for h_r, n_dir, Pout in ((4, 8, 100.0), (3, 4, 7.0), (5, 8, 100.0)):

@@ -19,7 +19,7 @@ cv = torch.rand((H, W, D), device=dev, generator=g) * 2 - 1
 res = {"shape": [W, H, D]}
 outs = {}
 for fused in (0, 2):
-    sv.set_option(cv, "sgm_score_fused", fused)
+    sv.set_test_option(cv, "sgm_score_fused", fused)
     for it in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -62,6 +62,12 @@ extern "C" {
  * of the passes is fixed by sgm.h:379-389) -- instead of reading S back in extract_index / truncated_cost_volume; and when the caller did
  * not ask for sgm_cv, only the costs a later pass reads are stored at all.  0: the separate kernels.  Same maps bit for bit
  * (tests/test_gpu_sgm_score_fused.py).
+ * "patchmatch_search_form" (default 1): the random search of svh_cacheless_patch_match.  1: 64 candidates per wave, their vectors fetched
+ *   coalesced 32 features at a time into a 9 KB LDS table of terms, lane e adding up row e in the reference's order.  0: round 4's kernel
+ *   (a table row of nF floats per candidate, 24 candidates per wave at 1080p RGB 7x7).  2 / 3: a lane per candidate and no LDS, the lane
+ *   fetching its candidate's target features itself (2) or forming them again from the target image and the decorator's (mean, norm) of
+ *   the target pixel (3) -- experiments that lost at long vectors (the texture addresser serialises their scattered accesses) and are
+ *   kept for the cross-check.  Same result in all four.
  * "sgm_score_fused" 3 (the public option takes 0 .. 2): the banded form with the 16-column strips forced that images narrower than about
  *   3000 columns replace by 8-column ones.
  * "census_sweep_rl" 2 / 3: development A/Bs of the RightToLeft sweep (2 = column-major tile order everywhere; 3 = neighbouring column

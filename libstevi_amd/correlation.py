@@ -378,11 +378,20 @@ def unfoldBasedCostVolume(matchFunc, img_l, img_r, h_radius, v_radius, disp_widt
     `cv.data_ptr()` / a DLPack or __cuda_array_interface__ export, through a raw C-ABI call.  Ask for it only for a volume you do not write
     to by such routes; `dropMinima(cv)` withdraws it.
 
+    Exactly ONE statement is attached: with both flags a Cost-strategy function keeps the minima, a Score-strategy one the winner (what
+    the C++ drop-in headers do on DeviceArray); either flag with host (numpy) images raises TypeError.
+
     keep_winner (device tensors; off by default; the same conditions): keep the index map a later extractSelectedIndex<strategy of
     matchFunc> on the untouched tensor would scan the volume for (svh_unfold_cost_volume_winner: the reference benchmark's own sequence
     is unfoldBasedCostVolume -> extractSelectedIndex): that call then returns a copy of the map."""
     lib = _capi.load()
     l, r = _prep_image(img_l), _prep_image(img_r)
+    if (keep_minima or keep_winner) and not _is_torch(l):
+        raise TypeError("keep_minima / keep_winner attach a statement to a device tensor; host (numpy) volumes carry none")
+    if keep_minima and keep_winner and int(matchFuncStrategy(matchFunc)) != dispExtractionStartegy.Cost:
+        keep_minima = False  # exactly ONE statement travels with the volume, chosen by the function's strategy (the C++ headers do the same):
+    elif keep_minima and keep_winner:  # Cost-strategy functions keep the minima (for sgmCostVolume), Score-strategy ones the winner
+        keep_winner = False
     ctx = context_for(l)
     lower, D = _search_range(disp_width)
     if l.shape[0] != r.shape[0] or (l.ndim == 3 and l.shape[2] != r.shape[2]):

@@ -100,7 +100,7 @@ template <int NW, class F> __device__ __forceinline__ void for_each_disparity(co
 // cost with the reference's tie rule (last index) built in.  From them
 //   g(p) = min_d [ c + (c [+ Pout]) ] = min(2 c0, 2 c1 + Pout)          (first-pixel actual cost, min_p = 0)
 // feeds the line recurrences, and census_finalize_kernel picks the winner once the min_p maps exist.
-// Keys are positive int32 values (cost <= 128 needs 8 bits, the index 12), so an int32 MIN all-reduce across
+// Keys are positive int32 values (cost <= 32 nWw <= 256 needs 9 bits, the index 12), so an int32 MIN all-reduce across
 // disparity shards is the cross-GPU winner reduction.  The index part holds the GLOBAL disparity index.
 // Two neighbouring pixels per lane.  With the records stored as 2-record pairs P_m = (rec 2m, rec 2m+1), the "even"
 // pixel E of a lane (record base 2 m0) and its "odd" neighbour O (base 2 m0 + 1) need, for the disparity pair (2e, 2e+1),
@@ -1068,12 +1068,15 @@ int launch_apply_select(svh_context *ctx, const CensusGeom &g, const ScanGeom &s
 
 } // namespace
 
-// largest nWw the pixel-per-lane kernels are instantiated for (15x15 windows and smaller; 9x9 -> 2 words, 13x13 -> 5, 15x15 -> 7: costs
-// up to 256 sit in the keys' 19 cost bits).  Five words and more run the VALU sweep (the matrix-core sweeps stop at four words).
+// largest nWw the pixel-per-lane kernels are instantiated for (15x15 windows and smaller; 9x9 -> 2 words, 13x13 -> 5, 15x15 -> 7).  The
+// matrix-core sweeps take every count up to it (svh_census_sweep_pm.hip; the RightToLeft specialisation since round 5 too).
+// Key invariant (svh_census_keys.h): cost <= 32 nWw <= 256, i.e. 9 cost bits above the 12 index bits -- a positive int32 with room to
+// spare, which is what lets the cross-shard exchange be an int32 MIN all-reduce.
 static constexpr int kMaxWords = 8;
+static_assert(32 * kMaxWords < (1 << (31 - KEY_IDX_BITS)), "the largest census cost must fit above the index bits of a positive int32 key");
 
 // LDS budget (nWw records of 256 + D - 1 pixels within the 64 KiB a block gets by default), at most 1024 disparities per
-// call, 4096 over all shards (12 index bits in the winner key), costs <= 128
+// call, 4096 over all shards (12 index bits in the winner key), costs <= 32 nWw <= 256
 bool census_lane_kernels_available(int nWw, int D) {
     return nWw <= kMaxWords && D <= 1024 && (size_t)(nWw ? nWw : 1) * sweep_records(D) * sizeof(uint32_t) <= 60 * 1024;
 }

@@ -465,6 +465,11 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         ctx->census_sweep_rl = value;
         return SVH_OK;
     }
+    if (strcmp(name, "patchmatch_search_form") == 0) {
+        if (value < 0 || value > 3) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "patchmatch_search_form: 0 .. 3");
+        ctx->patchmatch_search_form = value;
+        return SVH_OK;
+    }
     return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "unknown option %s", name);
 }
 

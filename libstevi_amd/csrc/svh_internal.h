@@ -60,6 +60,7 @@ struct svh_context {
     bool guided_shared = true;         // svh_test_set_option("guided_shared"): computeGuidedCV on grey images stages a block's processed target features in LDS (each sample subtracted / divided once) instead of once per pixel and offset
     bool feature_volume_tiled = true;  // svh_test_set_option("feature_volume_tiled"): cost volumes of float feature volumes process the features once and compare from LDS (0: the per-voxel kernel processes both vectors of every voxel)
     bool patchmatch_pred_costs = true; // svh_test_set_option("patchmatch_pred_costs"): PatchMatch sweeps take the cost of a pixel against its predecessor's unchanged solution from a parallel pre-pass (0: every step evaluates its cost)
+    int patchmatch_search_form = 1; // svh_test_set_option("patchmatch_search_form"): PatchMatch's random search: 1 the chunked kernel (64 candidates per wave, 32 features at a time through a 9 KB LDS table), 0 round 4's batched kernel, 2 / 3 a lane per candidate without LDS (fetching the target features / forming them again from the target image)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     bool cost_reduce_fused = true;     // svh_test_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
     bool sgm_cost_two_minima = true;   // svh_test_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass

@@ -36,6 +36,11 @@ struct OdVolume {
     int lower[2], upper[2];
     int Hs, Ws, Ht, Wt, nF;
     bool score;
+    // the target image itself and the decorator's two numbers per target pixel (mean, norm): a target feature is
+    // (sample - mean) / norm of a window sample -- the random search forms it again from these instead of fetching it (pm_search_image_kernel)
+    const float *timg = nullptr, *tstat = nullptr; // tstat: (Ht, Wt, 2)
+    int C = 1, h_r = 0, v_r = 0;
+    bool zm = false, nrm = false;
 };
 
 // A block takes 256 consecutive pixels: a thread per pixel walks its window once or twice for the mean and the norm (nested loops in the
@@ -44,7 +49,7 @@ struct OdVolume {
 // images and 7x7 windows (2.4 GB at 0.47 TB/s).  Same operations in the same order.
 constexpr int ODF_PX = 256;
 __global__ void __launch_bounds__(256) on_demand_features_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, bool zm, bool nrm,
-                                                                 float *__restrict__ out) {
+                                                                 float *__restrict__ out, float2 *__restrict__ stats) {
     __shared__ float s_mean[ODF_PX], s_norm[ODF_PX];
     const int64_t npx = (int64_t)H * W, p0 = (int64_t)blockIdx.x * ODF_PX;
     const int h = 2 * h_r + 1, v = 2 * v_r + 1, nF = v * h * C;
@@ -81,6 +86,7 @@ __global__ void __launch_bounds__(256) on_demand_features_kernel(const float *__
         }
         s_mean[threadIdx.x] = mean;
         s_norm[threadIdx.x] = norm;
+        if (stats) stats[p] = make_float2(mean, norm);
     }
     __syncthreads();
     // a wave per pixel, the lanes over the feature index (a pixel's nF floats are one contiguous run): which window sample a lane's
@@ -692,6 +698,318 @@ __global__ void __launch_bounds__(64) pm_search_batched_kernel(OdVolume o, uint6
     if (total && lane == 0) atomicAdd(changes, total);
 }
 
+// patchMatchSearch, 64 candidates per wave, the vectors in CHUNKS of 32 features (round 5; the default).  What the counters said about the
+// batched kernel above at 1080p RGB 7x7 (profiles/r05i_pm_search_pmc.jsonl): per round of 24 candidates a wave issues 1,180 vector and
+// 2,260 scalar instructions -- flat loops over (candidate, feature) with a division per term or a guard per load -- at four waves per
+// SIMD; the vector ALUs are active a tenth of the time, the memory system delivers 1 TB/s.  Same idea (coalesced fetches of the
+// candidates' vectors, a table of terms in LDS, lane e adds up row e in the reference's order), restructured so that a round is a few
+// hundred instructions and a CU holds many waves:
+//   * a round takes 64 candidates (lane e owns candidate e: the 64 / n_random pixels of the round times their n_random candidates);
+//   * the features go through LDS 32 at a time: a 64 x 36 float table (9 KB per wave instead of one row of nF floats per candidate);
+//   * a load instruction fetches 8 candidates x 128 bytes (lane = (candidate of the group, 16-byte piece)): 8 + 8 loads per chunk, all
+//     issued before the first term is formed; the source / target pixel of every candidate sits in registers of every lane (eight
+//     groups x one shuffle each, once per round);
+//   * lane e then adds its 32 terms to its running sum (eight 16-byte LDS reads), f = 0, 1, 2, ... as the reference does.
+// The last nF % 4 features of each vector are fetched by the candidate's own lane.  Same products / differences, same order: same bits.
+constexpr int PMC_PITCH = 36; // (32 features per chunk) row pitch of the table in floats (16-byte rows, conflict-free 16-byte column reads)
+__global__ void __launch_bounds__(64) pm_search_chunked_kernel(OdVolume o, uint64_t seed, uint32_t iter, int n_random, PmState st, int *__restrict__ changes) {
+    __shared__ __attribute__((aligned(16))) float tab[64 * PMC_PITCH];
+    const int64_t npx = (int64_t)o.Hs * o.Ws;
+    const int lane = threadIdx.x, P = 64 / n_random;
+    const int slot = lane / n_random, k = lane - slot * n_random;
+    const int cg = lane >> 3, piece = lane & 7; // phase A: candidate of the group, 16-byte piece of the chunk
+    const int nF = o.nF, nq = nF >> 2, n_chunks = (nq + 7) >> 3;
+    const int func = o.func;
+    auto term_of = [&](float a, float b) {
+        if (func == SVH_SSD || func == SVH_ZSSD) {
+            const float tmp = a - b;
+            return tmp * tmp;
+        }
+        if (func == SVH_SAD || func == SVH_ZSAD) return fabsf(a - b);
+        return a * b;
+    };
+    int total = 0;
+    for (int64_t g0 = (int64_t)blockIdx.x * P; g0 < npx; g0 += (int64_t)gridDim.x * P) { // (wave uniform)
+        // ---- this lane's candidate (patchmatch.h:287-340)
+        const int64_t p = g0 + slot;
+        const bool mine = lane < P * n_random && p < npx;
+        int c0 = 0, c1 = 0, tpx = 0;
+        bool has = false;
+        if (mine) {
+            const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+            const int base_i = o.nd == 2 ? st.sol[p * o.nd] : 0, base_j = o.nd == 2 ? st.sol[p * o.nd + 1] : st.sol[p * o.nd];
+            int disp_i = 0, disp_j;
+            if (o.nd == 1) {
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+            } else {
+                disp_i = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 1), o.lower[1], o.upper[1]);
+            }
+            int delta_i = disp_i - base_i, delta_j = disp_j - base_j; // :320-331: exploration shrunk towards the current solution
+            delta_j *= k + 1;
+            delta_j /= n_random + 1;
+            if (o.nd == 2) {
+                delta_i *= k + 1;
+                delta_i /= n_random + 1;
+            }
+            disp_i = base_i + delta_i;
+            disp_j = base_j + delta_j;
+            if (o.nd == 1) {
+                if (disp_j == base_j) disp_j = base_j + 1;
+            } else if (disp_i == base_i && disp_j == base_j) {
+                disp_i = base_i + 1;
+                disp_j = base_j + 1;
+            }
+            c0 = o.nd == 2 ? disp_i : disp_j;
+            c1 = disp_j;
+            int ti = i, tj = j;
+            if (o.nd == 2) {
+                has = c0 >= o.lower[0] && c0 <= o.upper[0] && c1 >= o.lower[1] && c1 <= o.upper[1];
+                ti += c0;
+                tj += c1;
+            } else {
+                has = c0 >= o.lower[0] && c0 <= o.upper[0];
+                tj += c0;
+            }
+            has = has && ti >= 0 && ti < o.Ht && tj >= 0 && tj < o.Wt;
+            tpx = has ? ti * o.Wt + tj : 0; // (pixels < 2^31: checked by the host)
+        }
+        // ---- the source / target pixels of the eight candidates this lane fetches pieces of (one per group)
+        const unsigned long long has_mask = __ballot(has);
+        int spx_g[8], tpx_g[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int e = 8 * g + cg;
+            tpx_g[g] = __shfl(tpx, e);
+            spx_g[g] = (int)min(g0 + e / n_random, npx - 1);
+        }
+        float c_new = 0.0f;
+        for (int ch = 0; ch < n_chunks; ch++) {
+            const int q = 8 * ch + piece; // this lane's 16-byte piece of every vector
+            Feat4 sa[8], ta[8];
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                sa[g] = ta[g] = Feat4{0.f, 0.f, 0.f, 0.f};
+                if (q < nq && ((has_mask >> (8 * g + cg)) & 1ull)) {
+                    sa[g] = *reinterpret_cast<const Feat4 *>(o.fs + (int64_t)spx_g[g] * nF + 4 * q);
+                    ta[g] = *reinterpret_cast<const Feat4 *>(o.ft + (int64_t)tpx_g[g] * nF + 4 * q);
+                }
+            }
+            __syncthreads(); // the previous chunk's readers are done with the table
+#pragma unroll
+            for (int g = 0; g < 8; g++)
+                *reinterpret_cast<float4 *>(tab + (8 * g + cg) * PMC_PITCH + 4 * piece) =
+                    make_float4(term_of(sa[g].x, ta[g].x), term_of(sa[g].y, ta[g].y), term_of(sa[g].z, ta[g].z), term_of(sa[g].w, ta[g].w));
+            __syncthreads();
+            const int quads = min(8, nq - 8 * ch); // (uniform)
+            const float4 *row = reinterpret_cast<const float4 *>(tab + lane * PMC_PITCH);
+            for (int qq = 0; qq < quads; qq++) {
+                const float4 t = row[qq];
+                c_new += t.x;
+                c_new += t.y;
+                c_new += t.z;
+                c_new += t.w;
+            }
+        }
+        if (has) { // the nF % 4 trailing features
+            const float *sv = o.fs + p * nF, *tv = o.ft + (int64_t)tpx * nF;
+            for (int f = 4 * nq; f < nF; f++) c_new += term_of(sv[f], tv[f]);
+        }
+        // ---- every lane of a pixel replays the reference's loop over the pixel's candidates, its first lane writes the outcome
+        {
+            const int leader = lane - k;
+            bool has_old = mine ? st.valid[p] != 0 : false;
+            float c_old = mine ? st.cost[p] : 0.0f;
+            int s0 = 0, s1 = 0, n_chang = 0;
+            bool changed = false;
+            for (int q = 0; q < n_random; q++) {
+                const int srcl = min(leader + q, 63);
+                const int hq = __shfl((int)has, srcl);
+                const float cq = __shfl(c_new, srcl);
+                const int q0 = __shfl(c0, srcl), q1 = __shfl(c1, srcl);
+                if (!hq) { // no value: patchMatchTestCost returns 0 (:197-199)
+                    n_chang = 0;
+                    continue;
+                }
+                bool keep;
+                if (o.score) keep = has_old ? (cq >= c_old) : true;
+                else keep = has_old ? (cq <= c_old) : false;
+                if (keep) {
+                    s0 = q0;
+                    s1 = q1;
+                    c_old = cq;
+                    has_old = true;
+                    changed = true;
+                }
+                n_chang = keep ? 1 : 0;
+            }
+            if (mine && k == 0) {
+                if (changed) {
+                    st.sol[p * o.nd] = s0;
+                    if (o.nd == 2) st.sol[p * o.nd + 1] = s1;
+                    st.cost[p] = c_old;
+                    st.valid[p] = 1;
+                }
+                total += n_chang;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+    if (total && lane == 0) atomicAdd(changes, total);
+}
+
+// patchMatchSearch with a LANE per candidate and no LDS (round 5).  The batched kernel above fetches a candidate's two vectors with all
+// 64 lanes (coalesced), parks the per-feature terms in an LDS table and lets lane e add up row e in the reference's order -- the table (one
+// row per candidate) limits a CU to a handful of waves, and a kernel that gathers scattered 588-byte vectors (1080p RGB 7x7: 147 floats)
+// lives on the number of loads it keeps in flight: 35 ms of the 75 ms chain.  Here lane e walks ITS candidate's two vectors itself,
+// 16 bytes at a time, and adds the terms as they arrive: the same products / differences, the same order (f = 0, 1, 2, ...), so the same
+// bits -- and nothing but registers, so a SIMD holds eight waves of gathers.  The four candidates of a pixel share the source vector
+// (one fetch serves the four lanes); a lane's consecutive loads walk the same cache lines.
+// IMAGE: the target vector is not fetched at all.  A candidate's 588 bytes of target features are, to a large part, bytes no other
+// candidate will ask for again soon (the targets of a pixel's candidates are spread over the search range: 82.9 M evaluations x 588 B =
+// 49 GB of gathers per 1080p RGB call), while the target IMAGE (25 MB) and the decorator's (mean, norm) pair per target pixel (16 MB)
+// stay in the caches.  The lane forms each target feature the way on_demand_features_kernel formed it -- the sample, minus the mean,
+// divided by the norm: the same float operations on the same operands, so the same bits -- and feeds it to the same ordered sum.
+// Arithmetic for bytes: about a dozen instructions per feature (the IEEE division) against a gather the memory system ran at 1.5 TB/s.
+template <bool IMAGE>
+__global__ void __launch_bounds__(256) pm_search_lanes_kernel(OdVolume o, uint64_t seed, uint32_t iter, int n_random, PmState st, int *__restrict__ changes) {
+    const int64_t npx = (int64_t)o.Hs * o.Ws;
+    const int lane = threadIdx.x & 63, P = 64 / n_random;
+    const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int slot = lane / n_random, k = lane - slot * n_random;
+    int total = 0;
+    for (int64_t g0 = wave_id * P; g0 < npx; g0 += n_waves * P) { // (wave uniform: the shuffles below see every lane)
+        const int64_t p = g0 + slot;
+        const bool mine = lane < P * n_random && p < npx;
+        int c0 = 0, c1 = 0;
+        bool has = false;
+        float c_new = 0.0f;
+        if (mine) {
+            const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
+            const int base_i = o.nd == 2 ? st.sol[p * o.nd] : 0, base_j = o.nd == 2 ? st.sol[p * o.nd + 1] : st.sol[p * o.nd];
+            int disp_i = 0, disp_j;
+            if (o.nd == 1) {
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+            } else {
+                disp_i = pm_in_range(pm_random(seed, iter, i, j, k, 0), o.lower[0], o.upper[0]);
+                disp_j = pm_in_range(pm_random(seed, iter, i, j, k, 1), o.lower[1], o.upper[1]);
+            }
+            int delta_i = disp_i - base_i, delta_j = disp_j - base_j; // :320-331: exploration shrunk towards the current solution
+            delta_j *= k + 1;
+            delta_j /= n_random + 1;
+            if (o.nd == 2) {
+                delta_i *= k + 1;
+                delta_i /= n_random + 1;
+            }
+            disp_i = base_i + delta_i;
+            disp_j = base_j + delta_j;
+            if (o.nd == 1) {
+                if (disp_j == base_j) disp_j = base_j + 1;
+            } else if (disp_i == base_i && disp_j == base_j) {
+                disp_i = base_i + 1;
+                disp_j = base_j + 1;
+            }
+            c0 = o.nd == 2 ? disp_i : disp_j;
+            c1 = disp_j;
+            int ti = i, tj = j;
+            if (o.nd == 2) {
+                has = c0 >= o.lower[0] && c0 <= o.upper[0] && c1 >= o.lower[1] && c1 <= o.upper[1];
+                ti += c0;
+                tj += c1;
+            } else {
+                has = c0 >= o.lower[0] && c0 <= o.upper[0];
+                tj += c0;
+            }
+            has = has && ti >= 0 && ti < o.Ht && tj >= 0 && tj < o.Wt;
+            if (has) { // the ordered sum of this lane's candidate (wave_cost: acc = 0; acc += term(f) for f = 0, 1, 2, ...)
+                const float *sv = o.fs + p * o.nF, *tv = o.ft + ((int64_t)ti * o.Wt + tj) * o.nF;
+                const int func = o.func;
+                auto term_of = [&](float a, float b) {
+                    if (func == SVH_SSD || func == SVH_ZSSD) {
+                        const float tmp = a - b;
+                        return tmp * tmp;
+                    }
+                    if (func == SVH_SAD || func == SVH_ZSAD) return fabsf(a - b);
+                    return a * b;
+                };
+                if constexpr (IMAGE) {
+                    const float2 ms = reinterpret_cast<const float2 *>(o.tstat)[(int64_t)ti * o.Wt + tj];
+                    const float mean = ms.x, norm = ms.y;
+                    const bool zm = o.zm, nrm = o.nrm;
+                    const int C = o.C, v = 2 * o.v_r + 1, h = 2 * o.h_r + 1;
+                    int f = 0;
+                    for (int kk = 0; kk < v; kk++) { // feature index f = (kk h + ll) C + c: the order of on_demand_features_kernel
+                        const float *rowp = o.timg + (int64_t)min(o.Ht - 1, max(0, ti + kk - o.v_r)) * o.Wt * C;
+                        for (int ll = 0; ll < h; ll++) {
+                            const float *px = rowp + min(o.Wt - 1, max(0, tj + ll - o.h_r)) * C;
+                            for (int c = 0; c < C; c++, f++) {
+                                float x = px[c];
+                                if (zm) x -= mean;
+                                if (nrm) x /= norm;
+                                c_new += term_of(sv[f], x);
+                            }
+                        }
+                    }
+                } else {
+                    int f = 0;
+#pragma unroll 4
+                    for (; f + 4 <= o.nF; f += 4) {
+                        const Feat4 a = *reinterpret_cast<const Feat4 *>(sv + f), b = *reinterpret_cast<const Feat4 *>(tv + f);
+                        c_new += term_of(a.x, b.x);
+                        c_new += term_of(a.y, b.y);
+                        c_new += term_of(a.z, b.z);
+                        c_new += term_of(a.w, b.w);
+                    }
+                    for (; f < o.nF; f++) c_new += term_of(sv[f], tv[f]);
+                }
+            }
+        }
+        // every lane of a pixel replays the reference's loop over the pixel's candidates (the shuffles need all lanes), its first lane
+        // writes the outcome: same comparisons, same order, `n_chang =` keeping only the last outcome (:345)
+        {
+            const int leader = lane - k;
+            bool has_old = mine ? st.valid[p] != 0 : false;
+            float c_old = mine ? st.cost[p] : 0.0f;
+            int s0 = 0, s1 = 0, n_chang = 0;
+            bool changed = false;
+            for (int q = 0; q < n_random; q++) {
+                const int srcl = min(leader + q, 63);
+                const int hq = __shfl((int)has, srcl);
+                const float cq = __shfl(c_new, srcl);
+                const int q0 = __shfl(c0, srcl), q1 = __shfl(c1, srcl);
+                if (!hq) { // no value: patchMatchTestCost returns 0 (:197-199)
+                    n_chang = 0;
+                    continue;
+                }
+                bool keep;
+                if (o.score) keep = has_old ? (cq >= c_old) : true;
+                else keep = has_old ? (cq <= c_old) : false;
+                if (keep) {
+                    s0 = q0;
+                    s1 = q1;
+                    c_old = cq;
+                    has_old = true;
+                    changed = true;
+                }
+                n_chang = keep ? 1 : 0;
+            }
+            if (mine && k == 0) {
+                if (changed) {
+                    st.sol[p * o.nd] = s0;
+                    if (o.nd == 2) st.sol[p * o.nd + 1] = s1;
+                    st.cost[p] = c_old;
+                    st.valid[p] = 1;
+                }
+                total += n_chang;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off);
+    if (total && lane == 0) atomicAdd(changes, total);
+}
+
 struct OdInputs {
     int func, nd, h_r, v_r, H, Ws, Ht, Wt, C;
 };
@@ -713,11 +1031,11 @@ int check_params(svh_context *ctx, const svh_on_demand_params *p, const svh_arra
     return SVH_OK;
 }
 
-int dev_on_demand_features(svh_context *ctx, int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out) {
+int dev_on_demand_features(svh_context *ctx, int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out, float2 *stats = nullptr) {
     const int64_t npx = (int64_t)H * W;
     if (npx == 0) return SVH_OK;
     SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_kernel, (int)((npx + ODF_PX - 1) / ODF_PX), 256, 0, img, H, W, C, h_r, v_r, func_zero_mean(func),
-               func_normalized(func), out);
+               func_normalized(func), out, stats);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -726,10 +1044,19 @@ int make_volume(svh_context *ctx, Scratch &scr, const svh_on_demand_params *p, c
     const int nF = (2 * in.v_r + 1) * (2 * in.h_r + 1) * in.C;
     float *fs = scr.get_n<float>((size_t)in.H * in.Ws * nF), *ft = scr.get_n<float>((size_t)in.Ht * in.Wt * nF);
     if (!fs || !ft) return SVH_ERR_OUT_OF_MEMORY;
+    float2 *tstat = scr.get_n<float2>((size_t)in.Ht * in.Wt);
+    if (!tstat) return SVH_ERR_OUT_OF_MEMORY;
     SVH_TRY(dev_on_demand_features(ctx, in.func, d_src, in.H, in.Ws, in.C, in.h_r, in.v_r, fs));
-    SVH_TRY(dev_on_demand_features(ctx, in.func, d_tgt, in.Ht, in.Wt, in.C, in.h_r, in.v_r, ft));
+    SVH_TRY(dev_on_demand_features(ctx, in.func, d_tgt, in.Ht, in.Wt, in.C, in.h_r, in.v_r, ft, tstat));
     o->fs = fs;
     o->ft = ft;
+    o->timg = d_tgt;
+    o->tstat = reinterpret_cast<const float *>(tstat);
+    o->C = in.C;
+    o->h_r = in.h_r;
+    o->v_r = in.v_r;
+    o->zm = func_zero_mean(in.func);
+    o->nrm = func_normalized(in.func);
     o->func = in.func;
     o->nd = in.nd;
     if (in.nd == 2) {
@@ -853,6 +1180,27 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
             } else {
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
                 SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);
+            }
+            if (ctx->patchmatch_search_form && n_random_search > 0 && n_random_search <= 64 && (int64_t)in.Ht * in.Wt < (1ll << 31) && npx < (1ll << 31)) {
+                // 64 candidates per wave: P = 64 / n pixels per round
+                const int P = 64 / n_random_search;
+                const int64_t waves = (npx + P - 1) / P;
+                if (ctx->patchmatch_search_form == 1) {
+                    SVH_LAUNCH(ctx, "patchmatch_search", pm_search_chunked_kernel, (int)std::min<int64_t>(waves, 256 * 32), 64, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
+                } else {
+                    const int blocks = (int)std::min<int64_t>((waves + 3) / 4, 256 * 8);
+                    if (ctx->patchmatch_search_form == 2) SVH_LAUNCH(ctx, "patchmatch_search", pm_search_lanes_kernel<false>, blocks, 256, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
+                    else SVH_LAUNCH(ctx, "patchmatch_search", pm_search_lanes_kernel<true>, blocks, 256, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
+                }
+                SVH_CHECK_LAUNCH(ctx);
+                int h_changes = 0;
+                SVH_HIP_CHECK(ctx, hipMemcpyAsync(&h_changes, changes, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                if (h_changes == 0) { // patchmatch.h:486-488
+                    it++;
+                    break;
+                }
+                continue;
             }
             // batched search when at least one pixel's candidates fit a wave and an LDS table of 60 KB
             const int pitch = o.nF | 1;

@@ -133,3 +133,25 @@ def test_patch_match_sweeps_with_predecessor_costs_same_result(rng, func, nd):
             finally:
                 sv.set_test_option(d_src, "patchmatch_pred_costs", 1)
         assert np.array_equal(host(outs[0][0]), host(outs[1][0])) and outs[0][1] == outs[1][1], (H, W, C)
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SAD, MF.SSD])
+@pytest.mark.parametrize("nd", [1, 2])
+def test_patch_match_search_lane_per_candidate_same_result(rng, func, nd):
+    """Option "patchmatch_search_form": 1 (default, round 5) 64 candidates per wave through a 32-feature LDS table; 0 round 4's batched kernel;
+    2 / 3 a lane per candidate without LDS (fetching the stored target features / forming them again from the target image).  Same
+    solutions and iteration counts -- feature counts that
+    are and are not multiples of four (25, 75, 27, 9), candidate counts that do and do not divide 64, images smaller than a wave's pixels."""
+    for (H, W, C, r, n_iter, n_random) in [(70, 150, 1, 2, 5, 4), (40, 67, 3, 2, 4, 2), (33, 50, 3, 1, 4, 3), (20, 31, 1, 1, 3, 5), (3, 5, 1, 1, 3, 7), (24, 24, 1, 2, 3, 64)]:
+        src, tgt = shifted_pair(rng, H, W, C, 0 if nd == 1 else 1, -2)
+        off = sv.searchOffset2(-3, 3, -6, 6) if nd == 2 else sv.searchOffset1(-6, 6)
+        d_src, d_tgt = dev(src), dev(tgt)
+        outs = []
+        for opt in (1, 2, 3, 0):
+            sv.set_test_option(d_src, "patchmatch_search_form", opt)
+            try:
+                outs.append(sv.cachelessPatchMatch(func, d_src, d_tgt, r, off, n_iter, n_random, 91, return_iterations=True))
+            finally:
+                sv.set_test_option(d_src, "patchmatch_search_form", 1)
+        for other in outs[1:]:
+            assert np.array_equal(host(outs[0][0]), host(other[0])) and outs[0][1] == other[1], (H, W, C, n_random)

@@ -62,6 +62,13 @@ extern "C" {
  * of the passes is fixed by sgm.h:379-389) -- instead of reading S back in extract_index / truncated_cost_volume; and when the caller did
  * not ask for sgm_cv, only the costs a later pass reads are stored at all.  0: the separate kernels.  Same maps bit for bit
  * (tests/test_gpu_sgm_score_fused.py).
+ * "patchmatch_run_batches" (default 1, with "patchmatch_pred_costs"): a sweep step that has to evaluate a cost on the spot (its candidate is
+ *   travelling) fetches the vectors of the next eight pixels of the line with it and evaluates them against the same candidate in the
+ *   time of one; the following steps read their costs from that batch until a pixel rejects the candidate; 0: one evaluation per step.
+ *   Same result.
+ * "patchmatch_lookback" (default 1, with "patchmatch_pred_costs"): from the second iteration on the pre-pass also evaluates every pixel against
+ *   the pre-sweep solutions two, three and four steps back along the sweep (only where they differ from the pixel's own), so that a candidate
+ *   that travels needs an evaluation on the spot only from its fourth accepted step on; 0: one step back only.  Same result.
  * "patchmatch_search_form" (default 1): the random search of svh_cacheless_patch_match.  1: 64 candidates per wave, their vectors fetched
  *   coalesced 32 features at a time into a 9 KB LDS table of terms, lane e adding up row e in the reference's order.  0: round 4's kernel
  *   (a table row of nF floats per candidate, 24 candidates per wave at 1080p RGB 7x7).  2 / 3: a lane per candidate and no LDS, the lane

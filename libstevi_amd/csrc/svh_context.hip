@@ -448,6 +448,8 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         {"census_tiles", &svh_context::census_tiles},
         {"cost_volume_colsum", &svh_context::cost_volume_colsum},
         {"patchmatch_pred_costs", &svh_context::patchmatch_pred_costs},
+        {"patchmatch_run_batches", &svh_context::patchmatch_run_batches},
+        {"patchmatch_lookback", &svh_context::patchmatch_lookback},
         {"feature_volume_tiled", &svh_context::feature_volume_tiled},
         {"guided_shared", &svh_context::guided_shared},
         {"sgm_score_pad", &svh_context::sgm_score_pad},

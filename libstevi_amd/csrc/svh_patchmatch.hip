@@ -250,6 +250,71 @@ __device__ __forceinline__ bool wave_cost(const OdVolume &o, int i, int j, int d
     return true;
 }
 
+// ---- 64 costs at once: lane e owns the pair (source pixel spx, target pixel tpx) -- the evaluation of pm_search_chunked_kernel below, shared
+// with the sweeps' run batches.  The vectors are fetched coalesced, 8 pairs x 128 bytes per load instruction (lane = (pair of the group,
+// 16-byte piece)), 32 features at a time, their per-feature terms parked in a 64 x PMC_PITCH float table in LDS, and lane e adds up row e in
+// the reference's order (f = 0, 1, 2, ...); the nF % 4 trailing features are fetched by the pair's own lane.  Same products / differences and
+// the same order as wave_cost: the same bits.  `has`: the lane's pair exists (its result is meaningless otherwise).  Single-wave blocks.
+struct __attribute__((packed, aligned(4))) Feat4 { // four consecutive features; global_load_dwordx4 only needs 4-byte alignment
+    float x, y, z, w;
+};
+constexpr int PMC_PITCH = 36; // (32 features per chunk) row pitch of the table in floats (16-byte rows, conflict-free 16-byte column reads)
+__device__ __forceinline__ float pm_costs64(const OdVolume &o, int spx, int tpx, bool has, float *tab) {
+    const int lane = threadIdx.x;
+    const int cg = lane >> 3, piece = lane & 7; // candidate of the group, 16-byte piece of the chunk
+    const int nF = o.nF, nq = nF >> 2, n_chunks = (nq + 7) >> 3;
+    const int func = o.func;
+    auto term_of = [&](float a, float b) {
+        if (func == SVH_SSD || func == SVH_ZSSD) {
+            const float tmp = a - b;
+            return tmp * tmp;
+        }
+        if (func == SVH_SAD || func == SVH_ZSAD) return fabsf(a - b);
+        return a * b;
+    };
+    const unsigned long long has_mask = __ballot(has);
+    int spx_g[8], tpx_g[8]; // the pairs this lane fetches pieces of (one per group of eight)
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        spx_g[g] = __shfl(spx, 8 * g + cg);
+        tpx_g[g] = __shfl(tpx, 8 * g + cg);
+    }
+    float c_new = 0.0f;
+    for (int ch = 0; ch < n_chunks; ch++) {
+        const int q = 8 * ch + piece; // this lane's 16-byte piece of every vector
+        Feat4 sa[8], ta[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            sa[g] = ta[g] = Feat4{0.f, 0.f, 0.f, 0.f};
+            if (q < nq && ((has_mask >> (8 * g + cg)) & 1ull)) {
+                sa[g] = *reinterpret_cast<const Feat4 *>(o.fs + (int64_t)spx_g[g] * nF + 4 * q);
+                ta[g] = *reinterpret_cast<const Feat4 *>(o.ft + (int64_t)tpx_g[g] * nF + 4 * q);
+            }
+        }
+        __syncthreads(); // the previous chunk's readers are done with the table
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+            *reinterpret_cast<float4 *>(tab + (8 * g + cg) * PMC_PITCH + 4 * piece) =
+                make_float4(term_of(sa[g].x, ta[g].x), term_of(sa[g].y, ta[g].y), term_of(sa[g].z, ta[g].z), term_of(sa[g].w, ta[g].w));
+        __syncthreads();
+        const int quads = min(8, nq - 8 * ch); // (uniform)
+        const float4 *row = reinterpret_cast<const float4 *>(tab + lane * PMC_PITCH);
+        for (int qq = 0; qq < quads; qq++) {
+            const float4 t = row[qq];
+            c_new += t.x;
+            c_new += t.y;
+            c_new += t.z;
+            c_new += t.w;
+        }
+    }
+    if (has) { // the nF % 4 trailing features
+        const float *sv = o.fs + (int64_t)spx * nF, *tv = o.ft + (int64_t)tpx * nF;
+        for (int f = 4 * nq; f < nF; f++) c_new += term_of(sv[f], tv[f]);
+    }
+    __syncthreads(); // (the table may be rewritten by the caller's next use)
+    return c_new;
+}
+
 // The cost of the current solution of every pixel is kept next to it (value + "has a value"), updated whenever the solution
 // changes: the reference recomputes it for every test (it is "cacheless"), which gives the same number each time.
 struct PmState {
@@ -349,12 +414,19 @@ __global__ void __launch_bounds__(64) pm_cols_kernel(OdVolume o, int inc, PmStat
 // Two launches: a thread per pixel settles the pixels whose predecessor holds the pixel's own solution (the cost is the pixel's own: most
 // pixels once regions agree) and lists the others; a wave per listed pixel evaluates its cost.  (A wave per pixel for both: 75 us per
 // pre-pass at 640x480 whatever the state of the solution -- two 64-bit divisions and three dependent loads per pixel before anything else.)
+// LOOK-BACK DEPTHS (round 5).  The candidate a step tests is the solution some pixel m steps back had BEFORE the sweep: that pixel kept its
+// own solution (so the candidate became fresh there) and the m - 1 pixels between accepted it.  The pre-pass above is m = 1.  With the costs
+// against the solutions 2 .. PM_DEPTH steps back evaluated beforehand as well (same kernels, `m` steps instead of one: only pixels whose own
+// solution differs are evaluated, i.e. nothing in a region that agrees), a travelling candidate needs an evaluation on the spot only from
+// its PM_DEPTH-th accepted step on -- and in the lines that never settle (image borders the true match leaves: the lines every sweep waits
+// for once the rest has converged) runs are short: a step accepts with probability about one half.
+constexpr int PM_DEPTH = 4;
 __global__ void __launch_bounds__(256) pm_pred_classify_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid,
-                                                               int32_t *__restrict__ work, int *__restrict__ n_work) {
+                                                               int32_t *__restrict__ work, int *__restrict__ n_work, int m = 1) {
     const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= o.Ws) return;
     const int64_t p = (int64_t)i * o.Ws + j;
-    const int pi = axis ? i - inc : i, pj = axis ? j : j - inc;
+    const int pi = axis ? i - m * inc : i, pj = axis ? j : j - m * inc;
     if (pi < 0 || pi >= o.Hs || pj < 0 || pj >= o.Ws) { // (no predecessor: never tested)
         pcost[p] = 0.0f;
         pvalid[p] = 0;
@@ -371,13 +443,13 @@ __global__ void __launch_bounds__(256) pm_pred_classify_kernel(OdVolume o, int a
 }
 
 __global__ void __launch_bounds__(64) pm_pred_cost_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid,
-                                                          const int32_t *__restrict__ work, const int *__restrict__ n_work) {
+                                                          const int32_t *__restrict__ work, const int *__restrict__ n_work, int m = 1) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
     const int n = *n_work;
     for (int w = blockIdx.x; w < n; w += gridDim.x) {
         const int p = work[w];
         const int j = p % o.Ws, i = p / o.Ws;
-        const int64_t pp = (int64_t)(axis ? i - inc : i) * o.Ws + (axis ? j : j - inc);
+        const int64_t pp = (int64_t)(axis ? i - m * inc : i) * o.Ws + (axis ? j : j - m * inc);
         float c = 0.0f;
         const bool ok = wave_cost(o, i, j, st.sol[pp * o.nd], o.nd == 2 ? st.sol[pp * o.nd + 1] : 0, pm_buf, &c);
         if (threadIdx.x == 0) {
@@ -391,25 +463,149 @@ __device__ __forceinline__ int pm_lane_i(int v, int k) { return __builtin_amdgcn
 __device__ __forceinline__ float pm_lane_f(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(k))); }
 
 // one sweep line: `len` pixels at p = first + t * step (t = 0 is the line's first pixel, which is not tested); (i, j) of pixel t: (i0 + t di, j0 + t dj)
+// RUN BATCHES (round 5).  What is left to evaluate on the spot are the steps behind an accepted candidate -- and while a candidate travels
+// it does not change, so the costs of the NEXT pixels of the line against it depend on nothing the sweep decides.  An evaluation is one
+// memory round trip plus nF dependent additions whatever it fetches, so the sweep fetches the vectors of the next PM_RUN pixels with it
+// (every load of the batch in flight together), parks the terms in LDS rows, and lanes 0 .. PM_RUN - 1 add up one row each in the reference's
+// order: up to PM_RUN costs in the time of one.  The following steps read theirs from a lane until a pixel rejects the candidate (which
+// drops what is left of the batch) or the batch is used up.  At 1080p RGB the first iteration evaluates 2.7 M of its 4.1 M sweep steps on
+// the spot, in runs of 31 pixels on average (the planted flow of tools/bench_patchmatch.py crossing the image); later iterations are as
+// slow as their slowest line, a border row whose pixels never agree: half of its steps evaluate, in runs of one or two, and a batch costs
+// about twice a single evaluation -- so the host asks for batches in the FIRST iteration only (rows 5.2 -> 3.0 ms, columns 2.6 -> 1.9;
+// in the later ones they made rows 1.7 -> 3.2 ms).  (A first form waited for three accepted steps and then evaluated 64 pixels through
+// pm_costs64 -- five dependent round trips: runs that ended early made it 2.4 x SLOWER.)  Same costs, same tests, same order.
+constexpr int PM_RUN = 8;
+// costs of pixels t .. t + n - 1 of a line (n <= PM_RUN) against the candidate (p0, p1): lane e < n returns the cost of pixel t + e, bit e of
+// *has_mask says whether it has a value (wave_cost's rules).  rows: n rows of `pitch` floats in LDS.
+__device__ __forceinline__ float pm_run_costs(const OdVolume &o, int64_t first, int64_t step, int i0, int j0, int di, int dj, int t, int n, int p0, int p1,
+                                              float *rows, int pitch, unsigned *has_mask) {
+    const int lane = threadIdx.x, nF = o.nF, func = o.func;
+    auto term_of = [&](float a, float b) {
+        if (func == SVH_SSD || func == SVH_ZSSD) {
+            const float tmp = a - b;
+            return tmp * tmp;
+        }
+        if (func == SVH_SAD || func == SVH_ZSAD) return fabsf(a - b);
+        return a * b;
+    };
+    bool cand_ok;
+    if (o.nd == 2) cand_ok = p0 >= o.lower[0] && p0 <= o.upper[0] && p1 >= o.lower[1] && p1 <= o.upper[1];
+    else cand_ok = p0 >= o.lower[0] && p0 <= o.upper[0];
+    const float *sv[PM_RUN], *tv[PM_RUN]; // (wave uniform)
+    unsigned mask = 0;
+#pragma unroll
+    for (int e = 0; e < PM_RUN; e++) {
+        const int tt = t + e, ii = i0 + tt * di, jj = j0 + tt * dj;
+        const int ti = o.nd == 2 ? ii + p0 : ii, tj = o.nd == 2 ? jj + p1 : jj + p0;
+        const bool has = e < n && cand_ok && ti >= 0 && ti < o.Ht && tj >= 0 && tj < o.Wt;
+        mask |= has ? 1u << e : 0u;
+        sv[e] = o.fs + (first + (int64_t)(e < n ? tt : t) * step) * nF;
+        tv[e] = o.ft + ((int64_t)(has ? ti : 0) * o.Wt + (has ? tj : 0)) * nF;
+    }
+    __syncthreads(); // the previous batch's readers are done with the rows
+    for (int f0 = 0; f0 < nF; f0 += 128) { // two rounds of 64 features at a time: 2 x 2 x PM_RUN loads in flight
+        float a[2][PM_RUN], b[2][PM_RUN];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int e = 0; e < PM_RUN; e++) {
+                const int f = f0 + 64 * r + lane;
+                a[r][e] = b[r][e] = 0.0f;
+                if (f < nF && ((mask >> e) & 1u)) {
+                    a[r][e] = sv[e][f];
+                    b[r][e] = tv[e][f];
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int e = 0; e < PM_RUN; e++) {
+                const int f = f0 + 64 * r + lane;
+                if (f < nF) rows[e * pitch + f] = term_of(a[r][e], b[r][e]);
+            }
+    }
+    __syncthreads();
+    float acc = 0.0f;
+    if (lane < PM_RUN) { // the ordered sum of row `lane` (wave_cost: acc = 0; acc += term(f) for f = 0, 1, 2, ...)
+        const float *row = rows + lane * pitch;
+        int f = 0;
+        for (; f + 4 <= nF; f += 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(row + f);
+            acc += q.x;
+            acc += q.y;
+            acc += q.z;
+            acc += q.w;
+        }
+        for (; f < nF; f++) acc += row[f];
+    }
+    *has_mask = mask;
+    return acc;
+}
+
 __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
-                                             int64_t first, int64_t step, int i0, int j0, int di, int dj, int t_end, float *buf) {
+                                             int64_t first, int64_t step, int i0, int j0, int di, int dj, int t_end, float *buf, int run_pitch, int depths,
+                                             int64_t npx) {
     const int lane = threadIdx.x;
     int n = 0;
+    int age = 1;           // the running candidate is the pre-sweep solution of the pixel `age` steps back (1: fresh)
+    float r_pd[PM_DEPTH - 1] = {}; // costs against the solutions 2 .. PM_DEPTH steps back, this chunk's pixels (their "has a value" bits: r_flags bits 2 ..)
+    int b_t0 = 0, b_n = 0; // the batch in hand: pixels b_t0 .. b_t0 + b_n - 1 of the line against the travelling candidate
+    float b_cost = 0.0f;
+    unsigned b_has = 0u;
     int p0 = st.sol[first * o.nd], p1 = o.nd == 2 ? st.sol[first * o.nd + 1] : 0; // solution of the line's first pixel (it has no predecessor)
     bool fresh = true; // the running candidate is the predecessor's solution of before the sweep
     float r_pc = 0.0f, r_oc = 0.0f;
     int r_flags = 0, r_s0 = 0, r_s1 = 0;
+    // What the steps of a chunk decide is written once per chunk, by the lanes of the pixels that changed: a step used to have lane 0 store
+    // the solution, the cost and the flag of its pixel -- four one-lane stores into the cache line the previous step had just written, 0.46 us
+    // per step in lines that walk step by step.  (A pixel's entries are read by the chunk load of ITS chunk and by later kernels only.)
+    int w_t0 = 1, w_s0 = 0, w_s1 = 0;
+    float w_c = 0.0f;
+    bool w_set = false;
+    auto flush = [&]() {
+        if (w_set) {
+            const int64_t p = first + (int64_t)(w_t0 + lane) * step;
+            st.sol[p * o.nd] = w_s0;
+            if (o.nd == 2) st.sol[p * o.nd + 1] = w_s1;
+            st.cost[p] = w_c;
+            st.valid[p] = 1;
+        }
+        w_set = false;
+    };
     for (int t = 1; t < t_end; t++) {
         const int k = (t - 1) & 63;
         if (k == 0) { // the next 64 pixels of the line, one per lane (their entries are only written at their own steps, which come later)
+            flush();
+            w_t0 = t;
             const int tt = t + lane;
             const bool in = tt < t_end;
             const int64_t p = first + (int64_t)(in ? tt : t) * step;
             r_pc = pcost[p];
             r_oc = st.cost[p];
             r_flags = (pvalid[p] ? 1 : 0) | (st.valid[p] ? 2 : 0);
+#pragma unroll
+            for (int m = 2; m <= PM_DEPTH; m++)
+                if (m <= depths) {
+                    r_pd[m - 2] = pcost[(int64_t)(m - 1) * npx + p];
+                    r_flags |= pvalid[(int64_t)(m - 1) * npx + p] ? 1 << m : 0;
+                }
             r_s0 = st.sol[p * o.nd];
             r_s1 = o.nd == 2 ? st.sol[p * o.nd + 1] : 0;
+            // A region that agrees already: all 64 pixels hold the running candidate as their own solution, with a value that is no NaN.  Every
+            // one of their steps then tests the pixel's own cost against itself (fresh: the pre-pass copied that very cost; travelling: the
+            // branch below takes it) -- `>=` / `<=` on equal numbers: kept, nothing changes but the count, and the candidate travels on.  One
+            // ballot instead of 64 steps: most chunks of most lines once the first iterations are over (1080p RGB: 0.46 us per step,
+            // 14 of the 32 ms the sweeps took, profiles/r05l_pm_trace*.txt).
+            if (t + 63 < t_end) {
+                const bool same = r_s0 == p0 && (o.nd < 2 || r_s1 == p1) && (r_flags & 3) == 3 && r_oc == r_oc && (!fresh || lane > 0 || r_pc == r_oc);
+                if (__ballot(same) == ~0ull) {
+                    n += 64;
+                    fresh = false;
+                    age = PM_DEPTH + 1; // (further back than the pre-pass looked: irrelevant while the pixels hold the candidate themselves)
+                    t += 63; // (the loop's increment takes the 64th)
+                    continue;
+                }
+            }
         }
         const int i = i0 + t * di, j = j0 + t * dj;
         const int flags = pm_lane_i(r_flags, k);
@@ -423,6 +619,20 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
             // the same evaluation of the same two vectors
             c_new = pm_lane_f(r_oc, k);
             has_new = (flags & 2) != 0;
+        } else if (age <= depths) { // evaluated by the pre-pass: the candidate is the pre-sweep solution of the pixel `age` steps back
+            float v = r_pd[0];
+#pragma unroll
+            for (int m = 3; m <= PM_DEPTH; m++) v = age == m ? r_pd[m - 2] : v;
+            c_new = pm_lane_f(v, k);
+            has_new = ((flags >> age) & 1) != 0;
+        } else if (run_pitch > 0) {
+            if (t < b_t0 || t >= b_t0 + b_n) { // this pixel and the next ones of the line against the travelling candidate
+                b_t0 = t;
+                b_n = min(PM_RUN, t_end - t);
+                b_cost = pm_run_costs(o, first, step, i0, j0, di, dj, t, b_n, p0, p1, buf, run_pitch, &b_has);
+            }
+            c_new = pm_lane_f(b_cost, t - b_t0);
+            has_new = ((b_has >> (t - b_t0)) & 1u) != 0;
         } else {
             has_new = wave_cost(o, i, j, p0, p1, buf, &c_new);
         }
@@ -434,12 +644,11 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
             if (o.score) keep = has_old ? (c_new >= c_old) : true;
             else keep = has_old ? (c_new <= c_old) : false;
             if (keep) {
-                if (lane == 0) {
-                    const int64_t p = first + (int64_t)t * step;
-                    st.sol[p * o.nd] = p0;
-                    if (o.nd == 2) st.sol[p * o.nd + 1] = p1;
-                    st.cost[p] = c_new;
-                    st.valid[p] = 1;
+                if (lane == k) { // (written with the rest of the chunk: flush)
+                    w_s0 = p0;
+                    w_s1 = p1;
+                    w_c = c_new;
+                    w_set = true;
                 }
                 kept = 1;
             }
@@ -449,31 +658,35 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
             p0 = pm_lane_i(r_s0, k);
             p1 = pm_lane_i(r_s1, k);
             fresh = true;
+            age = 1;
+            b_n = 0; // (what is left of a batch was for the candidate that just ended)
         } else {
             fresh = false;
+            age++;
         }
     }
+    flush();
     return n;
 }
 
 __global__ void __launch_bounds__(64) pm_rows_fast_kernel(OdVolume o, int inc, PmState st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
-                                                          int *__restrict__ changes) {
+                                                          int *__restrict__ changes, int run_pitch, int depths) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
     const int i = blockIdx.x;
     const int jfirst = inc > 0 ? 0 : o.Ws - 1;
     // going right: pixels 1 .. Ws - 1; going left: Ws - 2 .. 1 (`j != final` stops before column 0)
     const int t_end = inc > 0 ? o.Ws : o.Ws - 1;
-    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)i * o.Ws + jfirst, inc, i, jfirst, 0, inc, t_end, pm_buf);
+    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)i * o.Ws + jfirst, inc, i, jfirst, 0, inc, t_end, pm_buf, run_pitch, depths, (int64_t)o.Hs * o.Ws);
     if (n && threadIdx.x == 0) atomicAdd(changes, n);
 }
 
 __global__ void __launch_bounds__(64) pm_cols_fast_kernel(OdVolume o, int inc, PmState st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
-                                                          int *__restrict__ changes) {
+                                                          int *__restrict__ changes, int run_pitch, int depths) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
     const int j = blockIdx.x;
     const int ifirst = inc > 0 ? 0 : o.Hs - 1;
     const int t_end = inc > 0 ? o.Hs : o.Hs - 1;
-    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)ifirst * o.Ws + j, (int64_t)inc * o.Ws, ifirst, j, inc, 0, t_end, pm_buf);
+    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)ifirst * o.Ws + j, (int64_t)inc * o.Ws, ifirst, j, inc, 0, t_end, pm_buf, run_pitch, depths, (int64_t)o.Hs * o.Ws);
     if (n && threadIdx.x == 0) atomicAdd(changes, n);
 }
 
@@ -515,10 +728,6 @@ __global__ void __launch_bounds__(64) pm_search_kernel(OdVolume o, uint64_t seed
     }
     if (total && threadIdx.x == 0) atomicAdd(changes, total);
 }
-
-struct __attribute__((packed, aligned(4))) Feat4 { // four consecutive features; global_load_dwordx4 only needs 4-byte alignment
-    float x, y, z, w;
-};
 
 // patchMatchSearch for up to 64 candidates per wave at a time: the n_random candidates of a pixel are all derived from the
 // solution the pixel had when its loop started (patchmatch.h:287-340), so their costs do not depend on one another -- only the
@@ -711,23 +920,11 @@ __global__ void __launch_bounds__(64) pm_search_batched_kernel(OdVolume o, uint6
 //     groups x one shuffle each, once per round);
 //   * lane e then adds its 32 terms to its running sum (eight 16-byte LDS reads), f = 0, 1, 2, ... as the reference does.
 // The last nF % 4 features of each vector are fetched by the candidate's own lane.  Same products / differences, same order: same bits.
-constexpr int PMC_PITCH = 36; // (32 features per chunk) row pitch of the table in floats (16-byte rows, conflict-free 16-byte column reads)
 __global__ void __launch_bounds__(64) pm_search_chunked_kernel(OdVolume o, uint64_t seed, uint32_t iter, int n_random, PmState st, int *__restrict__ changes) {
     __shared__ __attribute__((aligned(16))) float tab[64 * PMC_PITCH];
     const int64_t npx = (int64_t)o.Hs * o.Ws;
     const int lane = threadIdx.x, P = 64 / n_random;
     const int slot = lane / n_random, k = lane - slot * n_random;
-    const int cg = lane >> 3, piece = lane & 7; // phase A: candidate of the group, 16-byte piece of the chunk
-    const int nF = o.nF, nq = nF >> 2, n_chunks = (nq + 7) >> 3;
-    const int func = o.func;
-    auto term_of = [&](float a, float b) {
-        if (func == SVH_SSD || func == SVH_ZSSD) {
-            const float tmp = a - b;
-            return tmp * tmp;
-        }
-        if (func == SVH_SAD || func == SVH_ZSAD) return fabsf(a - b);
-        return a * b;
-    };
     int total = 0;
     for (int64_t g0 = (int64_t)blockIdx.x * P; g0 < npx; g0 += (int64_t)gridDim.x * P) { // (wave uniform)
         // ---- this lane's candidate (patchmatch.h:287-340)
@@ -774,47 +971,7 @@ __global__ void __launch_bounds__(64) pm_search_chunked_kernel(OdVolume o, uint6
             has = has && ti >= 0 && ti < o.Ht && tj >= 0 && tj < o.Wt;
             tpx = has ? ti * o.Wt + tj : 0; // (pixels < 2^31: checked by the host)
         }
-        // ---- the source / target pixels of the eight candidates this lane fetches pieces of (one per group)
-        const unsigned long long has_mask = __ballot(has);
-        int spx_g[8], tpx_g[8];
-#pragma unroll
-        for (int g = 0; g < 8; g++) {
-            const int e = 8 * g + cg;
-            tpx_g[g] = __shfl(tpx, e);
-            spx_g[g] = (int)min(g0 + e / n_random, npx - 1);
-        }
-        float c_new = 0.0f;
-        for (int ch = 0; ch < n_chunks; ch++) {
-            const int q = 8 * ch + piece; // this lane's 16-byte piece of every vector
-            Feat4 sa[8], ta[8];
-#pragma unroll
-            for (int g = 0; g < 8; g++) {
-                sa[g] = ta[g] = Feat4{0.f, 0.f, 0.f, 0.f};
-                if (q < nq && ((has_mask >> (8 * g + cg)) & 1ull)) {
-                    sa[g] = *reinterpret_cast<const Feat4 *>(o.fs + (int64_t)spx_g[g] * nF + 4 * q);
-                    ta[g] = *reinterpret_cast<const Feat4 *>(o.ft + (int64_t)tpx_g[g] * nF + 4 * q);
-                }
-            }
-            __syncthreads(); // the previous chunk's readers are done with the table
-#pragma unroll
-            for (int g = 0; g < 8; g++)
-                *reinterpret_cast<float4 *>(tab + (8 * g + cg) * PMC_PITCH + 4 * piece) =
-                    make_float4(term_of(sa[g].x, ta[g].x), term_of(sa[g].y, ta[g].y), term_of(sa[g].z, ta[g].z), term_of(sa[g].w, ta[g].w));
-            __syncthreads();
-            const int quads = min(8, nq - 8 * ch); // (uniform)
-            const float4 *row = reinterpret_cast<const float4 *>(tab + lane * PMC_PITCH);
-            for (int qq = 0; qq < quads; qq++) {
-                const float4 t = row[qq];
-                c_new += t.x;
-                c_new += t.y;
-                c_new += t.z;
-                c_new += t.w;
-            }
-        }
-        if (has) { // the nF % 4 trailing features
-            const float *sv = o.fs + p * nF, *tv = o.ft + (int64_t)tpx * nF;
-            for (int f = 4 * nq; f < nF; f++) c_new += term_of(sv[f], tv[f]);
-        }
+        const float c_new = pm_costs64(o, (int)min(p, npx - 1), tpx, has, tab);
         // ---- every lane of a pixel replays the reference's loop over the pixel's candidates, its first lane writes the outcome
         {
             const int leader = lane - k;
@@ -1156,12 +1313,16 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
         int32_t *work = nullptr;
         int *n_work = nullptr;
         if (ctx->patchmatch_pred_costs && npx < (1ll << 31) && in.H <= 65535) {
-            pcost = scr.get_n<float>((size_t)npx);
-            pvalid = scr.get_n<uint8_t>((size_t)npx);
+            pcost = scr.get_n<float>((size_t)npx * PM_DEPTH);   // [depth][pixel]: the cost against the pre-sweep solution `depth + 1` steps back
+            pvalid = scr.get_n<uint8_t>((size_t)npx * PM_DEPTH);
             work = scr.get_n<int32_t>((size_t)npx);
             n_work = scr.get_n<int>(2);
             if (!pcost || !pvalid || !work || !n_work) return SVH_ERR_OUT_OF_MEMORY;
         }
+        // run batches of the sweeps: PM_RUN rows of terms in LDS (row pitch an odd number of 16-byte pieces: the eight rows' reads fall into different banks)
+        const int run_pitch = ctx->patchmatch_run_batches ? 4 * (((o.nF + 3) / 4) | 1) : 0;
+        const bool run_batches = run_pitch > 0 && (size_t)PM_RUN * run_pitch * sizeof(float) <= 48 * 1024;
+        const size_t sweep_shmem = run_batches ? (size_t)PM_RUN * run_pitch * sizeof(float) : shmem;
         SVH_LAUNCH(ctx, "patchmatch_init", pm_init_kernel, px_grid, 64, shmem, o, seed, st);
         for (; it < n_iter; it++) {
             SVH_HIP_CHECK(ctx, hipMemsetAsync(changes, 0, sizeof(int), ctx->stream));
@@ -1171,12 +1332,22 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
             if (pcost) { // the cost of every pixel against its predecessor's solution, in parallel; then the sweep (pm_pred_cost_kernel)
                 const dim3 cgrid(ceil_div(in.Ws, 256), in.H);
                 SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work, 0, 2 * sizeof(int), ctx->stream));
-                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 0, inc1, st, pcost, pvalid, work, n_work);
-                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost, pvalid, work, n_work);
-                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, shmem, o, inc1, st, pcost, pvalid, changes);
-                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 1, inc0, st, pcost, pvalid, work, n_work + 1);
-                SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost, pvalid, work, n_work + 1);
-                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, shmem, o, inc0, st, pcost, pvalid, changes);
+                // iteration 0 starts from random solutions: what travels there travels far (batches); afterwards the lines that still evaluate
+                // are the ones that never settle, in short runs (look-back depths)
+                const int depths = (it == 0 || !ctx->patchmatch_lookback) ? 1 : PM_DEPTH;
+                const int rp = run_batches && it == 0 ? run_pitch : 0;
+                for (int m = 1; m <= depths; m++) {
+                    if (m > 1) SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work, 0, sizeof(int), ctx->stream));
+                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 0, inc1, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work, m);
+                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work, m);
+                }
+                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, sweep_shmem, o, inc1, st, pcost, pvalid, changes, rp, depths);
+                for (int m = 1; m <= depths; m++) {
+                    if (m > 1) SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work + 1, 0, sizeof(int), ctx->stream));
+                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 1, inc0, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work + 1, m);
+                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work + 1, m);
+                }
+                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, sweep_shmem, o, inc0, st, pcost, pvalid, changes, rp, depths);
             } else {
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
                 SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);
@@ -1196,6 +1367,7 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
                 int h_changes = 0;
                 SVH_HIP_CHECK(ctx, hipMemcpyAsync(&h_changes, changes, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+
                 if (h_changes == 0) { // patchmatch.h:486-488
                     it++;
                     break;

@@ -155,3 +155,28 @@ def test_patch_match_search_lane_per_candidate_same_result(rng, func, nd):
                 sv.set_test_option(d_src, "patchmatch_search_form", 1)
         for other in outs[1:]:
             assert np.array_equal(host(outs[0][0]), host(other[0])) and outs[0][1] == other[1], (H, W, C, n_random)
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SAD])
+@pytest.mark.parametrize("nd", [1, 2])
+def test_patch_match_run_batches_same_result(rng, func, nd):
+    """Option "patchmatch_run_batches" (default, round 5): a step that evaluates a cost on the spot evaluates the next eight pixels of its line
+    against the same travelling candidate with it (first iteration); "patchmatch_lookback": the pre-pass evaluates against the solutions up to
+    four steps back (later iterations), and chunks of 64 pixels that agree are skipped; 0 / 0: one evaluation per step.  Same solutions and iteration counts on images whose
+    planted shift makes candidates travel along whole lines (lines longer than one batch, shorter than one, both sweep directions), with
+    a border the candidate's targets leave, grey and colour."""
+    for (H, W, C, r, n_iter, n_random) in [(40, 300, 1, 2, 4, 2), (150, 70, 3, 1, 5, 4), (5, 700, 1, 1, 4, 0), (260, 6, 1, 1, 4, 1), (64, 64, 1, 2, 6, 3)]:
+        src, tgt = shifted_pair(rng, H, W, C, 0 if nd == 1 else 2, -3)
+        off = sv.searchOffset2(-3, 3, -6, 6) if nd == 2 else sv.searchOffset1(-6, 6)
+        d_src, d_tgt = dev(src), dev(tgt)
+        outs = []
+        for batches, lookback in ((1, 1), (0, 0), (1, 0), (0, 1)):
+            sv.set_test_option(d_src, "patchmatch_run_batches", batches)
+            sv.set_test_option(d_src, "patchmatch_lookback", lookback)
+            try:
+                outs.append(sv.cachelessPatchMatch(func, d_src, d_tgt, r, off, n_iter, n_random, 5, return_iterations=True))
+            finally:
+                sv.set_test_option(d_src, "patchmatch_run_batches", 1)
+                sv.set_test_option(d_src, "patchmatch_lookback", 1)
+        for other in outs[1:]:
+            assert np.array_equal(host(outs[0][0]), host(other[0])) and outs[0][1] == other[1], (H, W, C, n_random)

@@ -458,7 +458,7 @@ int svh_census_exchange_keys(svh_context *ctx, void *nccl_comm, svh_array *keys,
  * disparity map are independent and GPUs can split them with no exchange at all: rank r calls this with its band and holds rows
  * of the map that are bit-identical to the single call's.  img_l / img_r are the WHOLE images (the band's census windows read
  * v_radius rows beyond it); disp_band (row_count, W) i32.  Census costs in the exact regime, the whole disparity range
- * (a multiple of 32 up to 992), no refinement; otherwise SVH_ERR_UNSUPPORTED (use svh_stereo_match / the disparity shards). */
+ * (a multiple of 32 up to 992; RightToLeft ranges that end at the target image's edge: any count from 33 to 512), no refinement; otherwise SVH_ERR_UNSUPPORTED (use svh_stereo_match / the disparity shards). */
 int svh_census_band_match(svh_context *ctx, const svh_stereo_params *params, const svh_array *img_l, const svh_array *img_r,
                           int32_t row_begin, int32_t row_count, svh_array *disp_band);
 

@@ -1139,7 +1139,7 @@ int dev_census_winner(svh_context *ctx, Scratch &scr, const SgmArgs &a, const Co
         int status = SVH_OK;
         if (launch_sweep_pm(ctx, g, a.Pout, nullptr, nullptr, &status, &sw)) return status;
     }
-    if (band) return fail(ctx, SVH_ERR_UNSUPPORTED, "row bands need the matrix-core sweep (disparity count a multiple of 32 up to 992, at most 8 census words)");
+    if (band) return fail(ctx, SVH_ERR_UNSUPPORTED, "row bands need the matrix-core sweep (disparity count a multiple of 32 up to 992, or 33 .. 512 for a RightToLeft range that ends at the image edge; at most 8 census words)");
     uint2 *keys = scr.get_n<uint2>((size_t)a.H * a.W);
     if (!keys) return SVH_ERR_OUT_OF_MEMORY;
     SVH_TRY(sweep_dispatch(ctx, g, a.Pout, keys, nullptr));

@@ -536,8 +536,16 @@ def test_census_row_bands_equal_single_call(D, ddir):
 def test_census_row_bands_unsupported_cases():
     from libstevi_amd._capi import SvhError, ERR_UNSUPPORTED, ERR_INVALID_ARGUMENT
     src, tgt, _ = parallax_pair(20, 100, 6, 5, 8, 1, 4, seed=3)
-    with pytest.raises(SvhError) as e:  # 40 disparities: not a whole number of the matrix-core sweep's row tiles
-        sv.censusBandMatch(tgt, src, 4, 4, 40, (0, 10))
+    # 40 disparities: no whole number of the matrix-core sweep's row tiles -- taken since round 5 (the RightToLeft sweep masks the cells past
+    # the range): the band equals the rows of the whole map
+    d_src, d_tgt = torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV)
+    whole = sv.stereoMatch(MF.CENSUS, d_tgt, d_src, 4, 4, 40, sgmDirections=8)["disp"]
+    assert torch.equal(sv.censusBandMatch(d_tgt, d_src, 4, 4, 40, (3, 10)), whole[3:13])
+    with pytest.raises(SvhError) as e:  # 20 disparities: fewer than the sweep's smallest range
+        sv.censusBandMatch(tgt, src, 4, 4, 20, (0, 10))
+    assert e.value.status == ERR_UNSUPPORTED
+    with pytest.raises(SvhError) as e:  # LeftToRight, no multiple of 32: the general kernel's tiles only
+        sv.censusBandMatch(src, tgt, 4, 4, 40, (0, 10), dDir=sv.dispDirection.LeftToRight)
     assert e.value.status == ERR_UNSUPPORTED
     with pytest.raises(SvhError) as e:  # non-integer Pout: outside the exact regime
         sv.censusBandMatch(tgt, src, 4, 4, 64, (0, 10), Pout=2.5)

@@ -753,10 +753,16 @@ def main():
         # the communicator as the backend itself reports it: a SUM all-reduce of ones counts the ranks that took part
         ones = torch.ones(1, dtype=torch.int32, device=dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        devs = [None] * world
-        dist.all_gather_object(devs, f"{torch.cuda.get_device_name(dev_index)} #{dev_index}")
-        rccl = {"backend": dist.get_backend(), "ranks_in_all_reduce": int(ones.item()), "world_size": dist.get_world_size(),
-                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None, "devices": devs}
+        rccl = {"backend": dist.get_backend(), "ranks_in_all_reduce": int(ones.item()), "world_size": dist.get_world_size()}
+        try:  # (informational fields: nothing here may take the headline down)
+            idx = torch.tensor([dev_index], dtype=torch.int32, device=dev)
+            all_idx = [torch.zeros_like(idx) for _ in range(world)]
+            dist.all_gather(all_idx, idx)
+            rccl["device_of_rank"] = [int(t.item()) for t in all_idx]
+            rccl["device_name"] = torch.cuda.get_device_name(dev_index)
+            rccl["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception as e:  # noqa: BLE001
+            rccl["note"] = f"{type(e).__name__}: {e}"
 
     # ---- N > 1, opt-in: the exchange through the C ABI on a communicator of our own (the C++ host's path)
     c_abi = None
@@ -832,7 +838,7 @@ def main():
             ops = 2.0 * bits * vox_launch
             ach = ops / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": KERNEL_SYMBOL.get(dom_name, dom_name), "library_label": dom_name,
-                    "kernel_is": "the symbol rocprofv3 prints (profiles/r04_bench_kernel_stats.csv, profiles/traffic.json)", "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
+                    "kernel_is": "the symbol rocprofv3 prints (profiles/r05_bench_kernel_stats.csv, profiles/traffic.json)", "launches": dom_n, "avg_ms": round(avg_ms, 5), "avg_ms_bracket": round(avg_raw_ms, 5),
                     "event_pair_ms": round(pair_ms, 5), "avg_ms_is": "the event bracket as read (over-reads the kernel by 0 .. one event pair)",
                     "avg_ms_minus_half_pair": round(avg_ms_mid, 5), "frac_minus_half_pair": round(ops / (avg_ms_mid * 1e-3) / 1e12 / peak, 4),
                     "bracketed": f"every {every}. launch inside the timed region", "achieved": round(ach, 1),

@@ -140,6 +140,8 @@ def load():
         "svh_device_cache_trim": (C.c_int, [C.c_int]),
         "svh_device_alloc": (C.c_int, [ctx, C.c_size_t, P(C.c_void_p)]),
         "svh_device_free": (C.c_int, [ctx, C.c_void_p]),
+        "svh_device_upload": (C.c_int, [ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
+        "svh_device_download": (C.c_int, [ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
         "svh_host_alloc": (C.c_int, [C.c_size_t, P(C.c_void_p)]),
         "svh_host_free": (C.c_int, [C.c_void_p]),
         "svh_host_cache_trim": (C.c_int, []),

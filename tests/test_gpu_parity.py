@@ -1196,3 +1196,45 @@ def test_census_windows_of_five_words(rng, h_r, v_r):
             keys = k if keys is None else torch.minimum(keys, k)
         vol = so.sgm(cv, 8, so.COST, 3.0, 17.0, (0, 0, 0, 0), 100.0)
         assert np.array_equal(host(sv.censusShardFinish(dl, dr, keys, h_r, v_r, D, **kw)["disp"]), so.index_to_disp(so.extract_index(vol, so.COST)))
+
+
+# ------------------------------------------------------------------------------------------------ the float chain, end to end
+@pytest.mark.parametrize("func, so_func", [(MF.NCC, so.NCC), (MF.ZNCC, so.ZNCC)])
+def test_float_chain_against_the_oracles_own_chain(func, so_func):
+    """NCC / ZNCC -> SGM-8 (Score) -> argmax -> truncatedCostVolume -> parabola, the GPU's chain against the ORACLE'S OWN chain from the images
+    (the C4 checks feed the oracle the GPU's cost band, so nothing held the chain end to end).  Float costs agree to 1e-4, not to
+    the bit, so the aggregated volumes are held to a tolerance (six passes of values of magnitude one), the winner to the oracle's volume --
+    the GPU's winner must be within that tolerance of the oracle's maximum at its pixel (a near-tie may flip; an exact tie may not pick a
+    smaller index) -- and the refined map to 1e-3 where the two winners agree and the parabola is well conditioned."""
+    H, W, D, r = 60, 150, 48, 3
+    src, tgt, _ = parallax_pair(H, W, 20, 15, 40, 3, 17, seed=123)
+    P1, P2, Pout = 0.001, 0.01, 100.0
+    res = sv.stereoMatch(func, dev(tgt), dev(src), r, r, D, sgmDirections=8, P1=P1, P2=P2, Pout=Pout, refineKernel=sv.InterpolationKernel.Parabola,
+                         refine_h_radius=r, refine_v_radius=r, want_cv=True, want_sgm_cv=True)
+    cv = so.unfold_cost_volume(so_func, tgt, src, r, r, D)
+    S = so.sgm(cv, 8, so.SCORE, P1, P2, (0, 0, 0, 0), Pout)
+    idx = so.extract_index(S, so.SCORE)
+    refined = so.refine_disp(so.truncated_cost_volume(S, idx, r, r, 1), idx, so.PARABOLA)
+    g_cv, g_S, g_disp, g_ref = host(res["cv"]), host(res["sgm_cv"]), host(res["disp"]), host(res["refined"])
+    assert np.array_equal(np.isnan(g_cv), np.isnan(cv))
+    ok = ~np.isnan(cv)
+    assert np.max(np.abs(g_cv[ok] - cv[ok])) <= 1e-4
+    okS = np.isfinite(S)
+    assert np.array_equal(np.isfinite(g_S), okS)
+    tol = 1e-3  # six passes, each adding a contribution formed from costs that agree to 1e-4 (in practice the volumes agree to a few 1e-6)
+    assert np.max(np.abs(g_S[okS] - S[okS])) <= tol
+    want = so.index_to_disp(idx)
+    differ = g_disp != want
+    assert differ.mean() <= 0.01, differ.mean()
+    ii, jj = np.nonzero(differ)
+    s_at_gpu = S[ii, jj, g_disp[ii, jj]]       # (RightToLeft, offset 0: the disparity is the index)
+    s_at_want = S[ii, jj, want[ii, jj]]
+    assert np.all(s_at_want - s_at_gpu <= 2 * tol), "a winner of the GPU's chain is not a near-tie of the oracle's volume"
+    same = ~differ & ~np.isnan(refined) & ~np.isnan(g_ref)
+    assert np.array_equal(np.isnan(refined[~differ]), np.isnan(g_ref[~differ]))
+    # the parabola divides by the second difference of three aggregated values: compare where it is not tiny
+    tcv = so.truncated_cost_volume(S, idx, r, r, 1)
+    curv = np.abs(tcv[..., 0] - 2 * tcv[..., 1] + tcv[..., 2])
+    well = same & (curv > 0.05)
+    assert well.sum() > 0.5 * same.sum()
+    assert np.max(np.abs(g_ref[well] - refined[well])) <= 1e-3

@@ -17,6 +17,7 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <system_error>
 #include <thread>
 
 #include "svh_internal.h"
@@ -130,10 +131,21 @@ void staging_destroy(svh_context *ctx) {
 
 static constexpr size_t kPipelineFrom = size_t(8) << 20; // smaller pageable copies: one hipMemcpyAsync (the runtime's own staging)
 
+// one copy on the context's stream, waited for (page-locked memory: the DMA engines directly; small pageable arrays: the runtime's own staging)
+static int plain_copy(svh_context *ctx, void *device, void *host, size_t bytes, bool h2d) {
+    SVH_HIP_CHECK(ctx, h2d ? hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, ctx->stream) : hipMemcpyAsync(host, device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // (H2D: the source may be reused or freed by the caller right after we return)
+    return SVH_OK;
+}
+
 // pageable host memory <-> device through the ring; h2d: `host` is the source
 static int pipelined_copy(svh_context *ctx, void *device, void *host, size_t bytes, bool h2d) {
     Staging *s = nullptr;
-    SVH_TRY(staging_get(ctx, &s));
+    if (staging_get(ctx, &s) != SVH_OK) { // no page-locked memory for the ring: the runtime's own staging then
+        (void)hipGetLastError();
+        staging_destroy(ctx);
+        return plain_copy(ctx, device, host, bytes, h2d);
+    }
     const int T = s->threads;
     const size_t nchunks = (bytes + Staging::kSlotBytes - 1) / Staging::kSlotBytes;
     // the copy streams start after everything the context's stream holds: the kernels that wrote `device` (D2H), or the last readers of the
@@ -196,9 +208,18 @@ static int pipelined_copy(svh_context *ctx, void *device, void *host, size_t byt
     };
     std::thread pool[Staging::kMaxThreads];
     const int used = (int)std::min<size_t>(T, nchunks);
-    for (int t = 1; t < used; t++) pool[t] = std::thread(worker, t);
+    int started = 1; // (worker 0 is this thread)
+    for (int t = 1; t < used; t++) {
+        try {
+            pool[t] = std::thread(worker, t);
+            started = t + 1;
+        } catch (const std::system_error &) { // no more threads to be had: the remaining chunk sets run on this thread, after its own
+            break;
+        }
+    }
     worker(0);
-    for (int t = 1; t < used; t++) pool[t].join();
+    for (int t = started; t < used; t++) worker(t);
+    for (int t = 1; t < started; t++) pool[t].join();
     if (err.load() != (int)hipSuccess) {
         for (int k = 0; k < 2; k++) (void)hipStreamSynchronize(s->copy[k]);
         for (auto &p : s->pending) p = false;
@@ -218,18 +239,14 @@ static int pipelined_copy(svh_context *ctx, void *device, void *host, size_t byt
 int copy_h2d(svh_context *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return SVH_OK;
     if (bytes >= kPipelineFrom && !host_range_is_pinned(src, bytes)) return pipelined_copy(ctx, dst, const_cast<void *>(src), bytes, true);
-    SVH_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); // the source may be reused (or freed) by the caller right after we return
-    return SVH_OK;
+    return plain_copy(ctx, dst, const_cast<void *>(src), bytes, true);
 }
 
 // Returns when `dst` holds the data (everything enqueued on the context's stream before the call has run).
 int copy_d2h(svh_context *ctx, void *dst, const void *src, size_t bytes) {
     if (bytes == 0) return SVH_OK;
     if (bytes >= kPipelineFrom && !host_range_is_pinned(dst, bytes)) return pipelined_copy(ctx, const_cast<void *>(src), dst, bytes, false);
-    SVH_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SVH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return SVH_OK;
+    return plain_copy(ctx, const_cast<void *>(src), dst, bytes, false);
 }
 
 } // namespace svh

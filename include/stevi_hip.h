@@ -396,6 +396,21 @@ int svh_on_demand_truncated_cost_volume(svh_context *ctx, const svh_on_demand_pa
  * branch (|v % range| + lower), so equal seeds give equal results, bit-identical to oracle/stevi_oracle.c. */
 int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
                               int n_iter, int n_random_search, uint64_t seed, svh_array *disp, int32_t *iterations_run);
+/* The same with the caller's initial solution in place of the random draw (the reference's `initializer` callback, patchmatch.h:598-605,
+ * evaluated by the caller): initial_disp (H,W,search_dims) i32, NULL = draw. */
+int svh_cacheless_patch_match_init(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
+                                   int n_iter, int n_random_search, uint64_t seed, const svh_array *initial_disp, svh_array *disp,
+                                   int32_t *iterations_run);
+/* patchMatch<matchFunc, searchSpaceDim>(feature_vol_s, feature_vol_t, searchOffset, nIter, nRandomSearch, initializer, randcache)
+ *                                                                                 correlation/patchmatch.h:496-558
+ * The iteration of svh_cacheless_patch_match on FEATURE VOLUMES the caller built -- (H,W,F) f32, e.g. unfolded images
+ * (benchmarkStereoMatchingModels.cpp:187-199) -- through the reference's cached cost volume, whose values are featureComparison of the
+ * processed vectors (the cache changes no value).  Zero-mean / normalised functions process the vectors twice, as the reference does
+ * (:522-523 and on_demand_cost_volume.h:62-67).  params: match_func, search_dims and the offsets; the radii are not used.  Feature counts
+ * that differ, or row counts with search_dims 1 -> SVH_EMPTY_RESULT (:529-537).  initial_disp: NULL = the random draw.  Random stream
+ * as svh_cacheless_patch_match (the reference's `randcache` has no counterpart: its own stream is not reproducible). */
+int svh_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *feat_source, const svh_array *feat_target, int n_iter,
+                    int n_random_search, uint64_t seed, const svh_array *initial_disp, svh_array *disp, int32_t *iterations_run);
 
 /* ---- fused pipeline: the benchmark / stereo_refine_test call chain kept on the device ------------------
  * unfoldBasedCostVolume -> [sgmCostVolume] -> extractSelectedIndex -> selectedIndexToDisp

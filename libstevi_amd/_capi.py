@@ -31,7 +31,7 @@ EXPORTS = [
     "svh_refine_disp_cost_interpolation", "svh_stereo_match", "svh_keys_to_index", "svh_census_shard_keys",
     "svh_census_shard_region1_is_global", "svh_census_shard_finish", "svh_census_exchange_keys", "svh_census_band_match", "svh_unfold_cost_volume_2d", "svh_extract_selected_2d_index", "svh_selected_2d_index_to_disp",
     "svh_truncated_bidirectional_cost_volume", "svh_refine_disp_2d_cost_interpolation", "svh_refine_disp_2d_cost_patch_interpolation",
-    "svh_on_demand_features", "svh_on_demand_truncated_cost_volume", "svh_cacheless_patch_match",
+    "svh_on_demand_features", "svh_on_demand_truncated_cost_volume", "svh_cacheless_patch_match", "svh_cacheless_patch_match_init", "svh_patch_match",
     "svh_feature_cost_volume_2d", "svh_average_pooling_downsample", "svh_unfold_compressed", "svh_unfold_compressed_shape",
     "svh_channels_mean", "svh_channels_norm", "svh_channels_zero_mean_norm", "svh_zeromean_feature_volume", "svh_normalized_feature_volume",
     "svh_zeromean_normalized_feature_volume", "svh_feature_volume_for_match_func", "svh_guided_cost_volume", "svh_hierarchical_truncated_cost_volume",
@@ -164,6 +164,8 @@ def load():
         "svh_on_demand_features": (C.c_int, [ctx, C.c_int, A, C.c_int, C.c_int, A]),
         "svh_on_demand_truncated_cost_volume": (C.c_int, [ctx, P(SvhOnDemandParams), A, A, A, C.c_int, A]),
         "svh_cacheless_patch_match": (C.c_int, [ctx, P(SvhOnDemandParams), A, A, C.c_int, C.c_int, C.c_uint64, A, P(i32)]),
+        "svh_cacheless_patch_match_init": (C.c_int, [ctx, P(SvhOnDemandParams), A, A, C.c_int, C.c_int, C.c_uint64, A, A, P(i32)]),
+        "svh_patch_match": (C.c_int, [ctx, P(SvhOnDemandParams), A, A, C.c_int, C.c_int, C.c_uint64, A, A, P(i32)]),
         "svh_unfold_compressed": (C.c_int, [ctx, A, P(i32), C.c_int, C.c_int, P(i32), A]),
         "svh_unfold_compressed_shape": (C.c_int, [A, P(i32), C.c_int, C.c_int, P(i32), P(C.c_int64)]),
         "svh_channels_mean": (C.c_int, [ctx, A, A]),

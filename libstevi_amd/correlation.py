@@ -977,22 +977,44 @@ def onDemandFeatures(matchFunc, img, radius):
     return out
 
 
-def cachelessPatchMatch(matchFunc, img_source, img_target, radius, searchOffset, nIter=5, nRandomSearch=4, seed=0, return_iterations=False):
-    """cachelessPatchMatch<matchFunc, searchSpaceDim>(OnDemand features of img_source / img_target, searchOffset, nIter, nRandomSearch)
+def cachelessPatchMatch(matchFunc, img_source, img_target, radius, searchOffset, nIter=5, nRandomSearch=4, seed=0, return_iterations=False, initial=None):
+    """cachelessPatchMatch<matchFunc, searchSpaceDim>(OnDemand features of img_source / img_target, searchOffset, nIter, nRandomSearch, initializer)
     -- correlation/patchmatch.h:560-621.  searchOffset: searchOffset2 (flow, disp (H,W,2)) or searchOffset1 / (lower, upper)
-    (stereo, disp (H,W,1)).  The random stream is a function of `seed` (the reference's is not reproducible)."""
+    (stereo, disp (H,W,1)).  The random stream is a function of `seed` (the reference's is not reproducible).
+    initial: an (H, W, search_dims) int32 array in the images' memory space, used instead of the random draw (what the reference's
+    `initializer` callback returns, :598-605)."""
     lib = _capi.load()
     s, t = _prep(img_source, np.float32), _prep(img_target, np.float32)
     ctx = context_for(s)
     p = _on_demand_params(matchFunc, radius, searchOffset)
     out = _like(s, (s.shape[0], s.shape[1], p.search_dims), "i32")
     its = C.c_int32(0)
-    st = _check(ctx, lib.svh_cacheless_patch_match(ctx, C.byref(p), C.byref(_desc(s)), C.byref(_desc(t)), int(nIter), int(nRandomSearch), C.c_uint64(seed),
-                                                   C.byref(_desc(out)), C.byref(its)))
+    ini = None if initial is None else _prep(initial, np.int32)
+    st = _check(ctx, lib.svh_cacheless_patch_match_init(ctx, C.byref(p), C.byref(_desc(s)), C.byref(_desc(t)), int(nIter), int(nRandomSearch), C.c_uint64(seed),
+                                                        None if ini is None else C.byref(_desc(ini)), C.byref(_desc(out)), C.byref(its)))
     if st != _capi.OK:
         out = _empty_like(s, 3, "i32")
     return (out, its.value) if return_iterations else out
 
+
+def patchMatch(matchFunc, feature_vol_s, feature_vol_t, searchOffset, nIter=5, nRandomSearch=4, seed=0, return_iterations=False, initial=None):
+    """patchMatch<matchFunc, searchSpaceDim>(feature_vol_s, feature_vol_t, searchOffset, nIter, nRandomSearch, initializer, randcache) --
+    correlation/patchmatch.h:496-558: PatchMatch on feature volumes (H, W, F) the caller built (benchmarkStereoMatchingModels.cpp:187-199
+    passes unfolded images), the reference's cached cost volume behind it (the cache changes no value).  Zero-mean / normalised functions
+    process the vectors twice, as the reference does.  Float matching functions.  `initial` as in cachelessPatchMatch; the reference's
+    `randcache` has no counterpart (the random stream is a function of `seed`)."""
+    lib = _capi.load()
+    s, t = _prep(feature_vol_s, np.float32), _prep(feature_vol_t, np.float32)
+    ctx = context_for(s)
+    p = _on_demand_params(matchFunc, 0, searchOffset)
+    out = _like(s, (s.shape[0], s.shape[1], p.search_dims), "i32")
+    its = C.c_int32(0)
+    ini = None if initial is None else _prep(initial, np.int32)
+    st = _check(ctx, lib.svh_patch_match(ctx, C.byref(p), C.byref(_desc(s)), C.byref(_desc(t)), int(nIter), int(nRandomSearch), C.c_uint64(seed),
+                                         None if ini is None else C.byref(_desc(ini)), C.byref(_desc(out)), C.byref(its)))
+    if st != _capi.OK:
+        out = _empty_like(s, 3, "i32")
+    return (out, its.value) if return_iterations else out
 
 def onDemandTruncatedCostVolume(matchFunc, img_source, img_target, radius, searchOffset, disp, cv_radius=1):
     """CachelessOnDemand{ImageFlow,Stereo}CostVolume(features_source, features_target, searchSpace).truncatedCostVolume(disp, radius)

@@ -119,6 +119,20 @@ int transform_volume(svh_context *ctx, const svh_array *feat, const svh_array *m
 
 using namespace svh;
 
+namespace svh {
+// getFeatureVolumeForMatchFunc for a float function on device arrays (dense (H, W, F)): v, v - mean, v / norm or (v - mean) / norm
+int dev_feature_volume_for_match_func(svh_context *ctx, Scratch &scr, int match_func, const float *feat, int H, int W, int F, float *out) {
+    const int64_t npx = (int64_t)H * W;
+    if (npx * F == 0) return SVH_OK;
+    const bool zm = func_zero_mean(match_func), nrm = func_normalized(match_func);
+    float *m = nullptr, *n = nullptr;
+    if (zm && !(m = scr.get_n<float>((size_t)npx))) return SVH_ERR_OUT_OF_MEMORY;
+    if (nrm && !(n = scr.get_n<float>((size_t)npx))) return SVH_ERR_OUT_OF_MEMORY;
+    if (zm || nrm) SVH_TRY(launch_stats(ctx, FeatVolume{feat, W, F}, H, W, zm, nrm, m, n));
+    return dev_affine(ctx, feat, m, n, npx, F, out); // plain copy (cast) when neither applies, cross_correlations.h:716-720
+}
+} // namespace svh
+
 extern "C" {
 
 int svh_channels_mean(svh_context *ctx, const svh_array *feat, svh_array *mean) { return channel_statistic(ctx, 0, feat, nullptr, mean); }
@@ -158,12 +172,7 @@ int svh_feature_volume_for_match_func(svh_context *ctx, int match_func, const sv
     if (census) {
         SVH_TRY(dev_census_from_features(ctx, (const float *)df, H, W, F, Fo, false, (uint32_t *)os.dptr));
     } else if (npx * F > 0) {
-        const bool zm = func_zero_mean(match_func), nrm = func_normalized(match_func);
-        float *m = nullptr, *n = nullptr;
-        if (zm && !(m = scr.get_n<float>((size_t)npx))) return SVH_ERR_OUT_OF_MEMORY;
-        if (nrm && !(n = scr.get_n<float>((size_t)npx))) return SVH_ERR_OUT_OF_MEMORY;
-        if (zm || nrm) SVH_TRY(launch_stats(ctx, FeatVolume{(const float *)df, W, F}, H, W, zm, nrm, m, n));
-        SVH_TRY(dev_affine(ctx, (const float *)df, m, n, npx, F, (float *)os.dptr)); // plain copy (cast) when neither applies, :716-720
+        SVH_TRY(dev_feature_volume_for_match_func(ctx, scr, match_func, (const float *)df, H, W, F, (float *)os.dptr));
     }
     return finish_out(ctx, os);
 }

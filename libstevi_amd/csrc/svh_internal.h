@@ -182,6 +182,8 @@ int copy_d2h(svh_context *ctx, void *dst, const void *src, size_t bytes);
 void staging_destroy(svh_context *ctx);
 // (svh_context.hip) give the device's cache of released svh_device_alloc blocks back to the device: the out-of-memory retry of every allocator
 void device_cache_release_all(int device);
+// (svh_feature_transforms.hip) getFeatureVolumeForMatchFunc of a float matching function on dense device arrays (H, W, F)
+int dev_feature_volume_for_match_func(svh_context *ctx, Scratch &scr, int match_func, const float *feat, int H, int W, int F, float *out);
 int stage_out(svh_context *ctx, Scratch &scr, const svh_array &a, OutStage *st);
 int finish_out(svh_context *ctx, const OutStage &st);
 // true when any host array took part (the call must synchronise before returning)

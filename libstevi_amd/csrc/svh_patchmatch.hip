@@ -343,13 +343,14 @@ __device__ __forceinline__ int pm_test(const OdVolume &o, const PmState &st, int
 }
 
 // randomDispInit, :61-160 (NumbersCache branch), plus the cost of the initial solution; a wave per pixel
-__global__ void __launch_bounds__(64) pm_init_kernel(OdVolume o, uint64_t seed, PmState st) {
+// init != nullptr: the caller's initial solution (the reference's `initializer` callback, patchmatch.h:538-545 / :598-605) instead of the draw
+__global__ void __launch_bounds__(64) pm_init_kernel(OdVolume o, uint64_t seed, PmState st, const int32_t *__restrict__ init) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
     const int64_t npx = (int64_t)o.Hs * o.Ws;
     for (int64_t p = blockIdx.x; p < npx; p += gridDim.x) {
         const int j = (int)(p % o.Ws), i = (int)(p / o.Ws);
         int d[2] = {0, 0};
-        for (int s = 0; s < o.nd; s++) d[s] = pm_in_range(pm_random(seed, 0xFFFFFFFFu, i, j, 0, s), o.lower[s], o.upper[s]);
+        for (int s = 0; s < o.nd; s++) d[s] = init ? init[p * o.nd + s] : pm_in_range(pm_random(seed, 0xFFFFFFFFu, i, j, 0, s), o.lower[s], o.upper[s]);
         float c = 0.0f;
         const bool ok = wave_cost(o, i, j, d[0], d[1], pm_buf, &c);
         if (threadIdx.x == 0) {
@@ -1282,27 +1283,15 @@ extern "C" int svh_on_demand_truncated_cost_volume(svh_context *ctx, const svh_o
     return finish_out(ctx, os);
 }
 
-extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
-                                         int n_iter, int n_random_search, uint64_t seed, svh_array *disp, int32_t *iterations_run) {
-    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
-    OdInputs in;
-    SVH_TRY(check_params(ctx, params, img_source, img_target, &in));
-    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 3, 3));
-    if (n_iter < 0 || n_random_search < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "iteration counts must be non-negative");
-    if (disp->shape[0] != in.H || disp->shape[1] != in.Ws || disp->shape[2] != in.nd)
-        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
-    Scratch scr(ctx);
-    void *ds, *dt;
-    OutStage os;
-    SVH_TRY(stage_in(ctx, scr, *img_source, &ds));
-    SVH_TRY(stage_in(ctx, scr, *img_target, &dt));
-    SVH_TRY(stage_out(ctx, scr, *disp, &os));
-    int32_t *sol = (int32_t *)os.dptr;
+namespace svh {
+namespace {
+// patchMatchImpl (patchmatch.h:447-493) on a volume of feature vectors: initial solution (drawn, or the caller's), then n_iter rounds of
+// row sweep, column sweep and random search.  `sol`: (H, Ws, nd) int32 on the device; *it_out: iterations run.
+int run_patch_match(svh_context *ctx, Scratch &scr, const OdInputs &in, const OdVolume &o, int n_iter, int n_random_search, uint64_t seed,
+                    const int32_t *d_init, int32_t *sol, int *it_out) {
     int it = 0;
     const int64_t npx = (int64_t)in.H * in.Ws;
     if (npx > 0) {
-        OdVolume o;
-        SVH_TRY(make_volume(ctx, scr, params, in, (const float *)ds, (const float *)dt, &o));
         int *changes = scr.get_n<int>(1);
         PmState st{sol, scr.get_n<float>((size_t)npx), scr.get_n<uint8_t>((size_t)npx)};
         if (!changes || !st.cost || !st.valid) return SVH_ERR_OUT_OF_MEMORY;
@@ -1323,7 +1312,7 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
         const int run_pitch = ctx->patchmatch_run_batches ? 4 * (((o.nF + 3) / 4) | 1) : 0;
         const bool run_batches = run_pitch > 0 && (size_t)PM_RUN * run_pitch * sizeof(float) <= 48 * 1024;
         const size_t sweep_shmem = run_batches ? (size_t)PM_RUN * run_pitch * sizeof(float) : shmem;
-        SVH_LAUNCH(ctx, "patchmatch_init", pm_init_kernel, px_grid, 64, shmem, o, seed, st);
+        SVH_LAUNCH(ctx, "patchmatch_init", pm_init_kernel, px_grid, 64, shmem, o, seed, st, d_init);
         for (; it < n_iter; it++) {
             SVH_HIP_CHECK(ctx, hipMemsetAsync(changes, 0, sizeof(int), ctx->stream));
             const int inc0 = (it % 4) < 2 ? 1 : -1, inc1 = (it % 2) == 0 ? 1 : -1; // propagation_direction.h:64-86, patchmatch.h:462-479
@@ -1360,7 +1349,7 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
                     SVH_LAUNCH(ctx, "patchmatch_search", pm_search_chunked_kernel, (int)std::min<int64_t>(waves, 256 * 32), 64, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
                 } else {
                     const int blocks = (int)std::min<int64_t>((waves + 3) / 4, 256 * 8);
-                    if (ctx->patchmatch_search_form == 2) SVH_LAUNCH(ctx, "patchmatch_search", pm_search_lanes_kernel<false>, blocks, 256, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
+                    if (ctx->patchmatch_search_form == 2 || !o.timg) SVH_LAUNCH(ctx, "patchmatch_search", pm_search_lanes_kernel<false>, blocks, 256, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
                     else SVH_LAUNCH(ctx, "patchmatch_search", pm_search_lanes_kernel<true>, blocks, 256, 0, o, seed, (uint32_t)it, n_random_search, st, changes);
                 }
                 SVH_CHECK_LAUNCH(ctx);
@@ -1395,6 +1384,112 @@ extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_p
                 break;
             }
         }
+    }
+    *it_out = it;
+    return SVH_OK;
+}
+} // namespace
+} // namespace svh
+
+extern "C" int svh_cacheless_patch_match_init(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
+                                              int n_iter, int n_random_search, uint64_t seed, const svh_array *initial_disp, svh_array *disp,
+                                              int32_t *iterations_run) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    OdInputs in;
+    SVH_TRY(check_params(ctx, params, img_source, img_target, &in));
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 3, 3));
+    if (n_iter < 0 || n_random_search < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "iteration counts must be non-negative");
+    if (disp->shape[0] != in.H || disp->shape[1] != in.Ws || disp->shape[2] != in.nd)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
+    if (initial_disp) {
+        SVH_TRY(validate(ctx, initial_disp, "initial_disp", SVH_I32, 3, 3));
+        if (initial_disp->shape[0] != in.H || initial_disp->shape[1] != in.Ws || initial_disp->shape[2] != in.nd)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "initial_disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
+    }
+    Scratch scr(ctx);
+    void *ds, *dt, *di = nullptr;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *img_source, &ds));
+    SVH_TRY(stage_in(ctx, scr, *img_target, &dt));
+    if (initial_disp) SVH_TRY(stage_in(ctx, scr, *initial_disp, &di));
+    SVH_TRY(stage_out(ctx, scr, *disp, &os));
+    int it = 0;
+    if ((int64_t)in.H * in.Ws > 0) {
+        OdVolume o;
+        SVH_TRY(make_volume(ctx, scr, params, in, (const float *)ds, (const float *)dt, &o));
+        SVH_TRY(run_patch_match(ctx, scr, in, o, n_iter, n_random_search, seed, (const int32_t *)di, (int32_t *)os.dptr, &it));
+    }
+    if (iterations_run) *iterations_run = it;
+    return finish_out(ctx, os);
+}
+
+extern "C" int svh_cacheless_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *img_source, const svh_array *img_target,
+                                         int n_iter, int n_random_search, uint64_t seed, svh_array *disp, int32_t *iterations_run) {
+    return svh_cacheless_patch_match_init(ctx, params, img_source, img_target, n_iter, n_random_search, seed, nullptr, disp, iterations_run);
+}
+
+// patchMatch (patchmatch.h:496-558): the same iteration on FEATURE VOLUMES the caller built (benchmarkStereoMatchingModels.cpp:187-199 passes
+// unfolded images), through the reference's cached cost volume -- whose values are featureComparison of the processed vectors, cached or
+// not.  The vectors are processed TWICE when the function is zero-mean or normalised: the entry point calls getFeatureVolumeForMatchFunc
+// (:522-523) and the cost volume's constructor calls it again on the result (on_demand_cost_volume.h:62-67); both passes are run here.
+extern "C" int svh_patch_match(svh_context *ctx, const svh_on_demand_params *params, const svh_array *feat_source, const svh_array *feat_target, int n_iter,
+                               int n_random_search, uint64_t seed, const svh_array *initial_disp, svh_array *disp, int32_t *iterations_run) {
+    if (!ctx) return SVH_ERR_INVALID_ARGUMENT;
+    if (!params) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "null parameters");
+    SVH_TRY(validate(ctx, feat_source, "feature_vol_s", SVH_F32, 3, 3));
+    SVH_TRY(validate(ctx, feat_target, "feature_vol_t", SVH_F32, 3, 3));
+    if (!func_supported(params->match_func) || func_census(params->match_func))
+        return fail(ctx, SVH_ERR_UNSUPPORTED, "PatchMatch takes the float matching functions (CC ... ZSAD), not %d", params->match_func);
+    if (params->search_dims != 1 && params->search_dims != 2) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "search_dims must be 1 (stereo) or 2 (flow)");
+    if (feat_source->shape[2] != feat_target->shape[2]) return fail(ctx, SVH_EMPTY_RESULT, "feature counts differ"); // patchmatch.h:529-531
+    if (params->search_dims == 1 && feat_source->shape[0] != feat_target->shape[0]) return fail(ctx, SVH_EMPTY_RESULT, "row counts differ"); // :533-537
+    if (params->upper1 < params->lower1 || (params->search_dims == 2 && params->upper0 < params->lower0)) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "empty search range");
+    if (n_iter < 0 || n_random_search < 0) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "iteration counts must be non-negative");
+    OdInputs in{params->match_func, params->search_dims, 0, 0, (int)feat_source->shape[0], (int)feat_source->shape[1], (int)feat_target->shape[0],
+                (int)feat_target->shape[1], 1};
+    const int F = (int)feat_source->shape[2];
+    SVH_TRY(validate(ctx, disp, "disp", SVH_I32, 3, 3));
+    if (disp->shape[0] != in.H || disp->shape[1] != in.Ws || disp->shape[2] != in.nd)
+        return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
+    if (initial_disp) {
+        SVH_TRY(validate(ctx, initial_disp, "initial_disp", SVH_I32, 3, 3));
+        if (initial_disp->shape[0] != in.H || initial_disp->shape[1] != in.Ws || initial_disp->shape[2] != in.nd)
+            return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "initial_disp must have shape (%d,%d,%d)", in.H, in.Ws, in.nd);
+    }
+    Scratch scr(ctx);
+    void *ds, *dt, *di = nullptr;
+    OutStage os;
+    SVH_TRY(stage_in(ctx, scr, *feat_source, &ds));
+    SVH_TRY(stage_in(ctx, scr, *feat_target, &dt));
+    if (initial_disp) SVH_TRY(stage_in(ctx, scr, *initial_disp, &di));
+    SVH_TRY(stage_out(ctx, scr, *disp, &os));
+    int it = 0;
+    if ((int64_t)in.H * in.Ws > 0 && F > 0) {
+        const float *fs = (const float *)ds, *ft = (const float *)dt;
+        if (func_zero_mean(in.func) || func_normalized(in.func)) { // processed twice (see above)
+            float *ps = scr.get_n<float>((size_t)in.H * in.Ws * F), *pt = scr.get_n<float>((size_t)in.Ht * in.Wt * F);
+            float *tmp = scr.get_n<float>((size_t)std::max((int64_t)in.H * in.Ws, (int64_t)in.Ht * in.Wt) * F);
+            if (!ps || !pt || !tmp) return SVH_ERR_OUT_OF_MEMORY;
+            SVH_TRY(dev_feature_volume_for_match_func(ctx, scr, in.func, fs, in.H, in.Ws, F, tmp));
+            SVH_TRY(dev_feature_volume_for_match_func(ctx, scr, in.func, tmp, in.H, in.Ws, F, ps));
+            SVH_TRY(dev_feature_volume_for_match_func(ctx, scr, in.func, ft, in.Ht, in.Wt, F, tmp));
+            SVH_TRY(dev_feature_volume_for_match_func(ctx, scr, in.func, tmp, in.Ht, in.Wt, F, pt));
+            fs = ps;
+            ft = pt;
+        }
+        OdVolume o;
+        o.fs = fs;
+        o.ft = ft;
+        o.func = in.func;
+        o.nd = in.nd;
+        if (in.nd == 2) {
+            o.lower[0] = params->lower0; o.upper[0] = params->upper0; o.lower[1] = params->lower1; o.upper[1] = params->upper1;
+        } else {
+            o.lower[0] = params->lower1; o.upper[0] = params->upper1; o.lower[1] = 0; o.upper[1] = 0;
+        }
+        o.Hs = in.H; o.Ws = in.Ws; o.Ht = in.Ht; o.Wt = in.Wt; o.nF = F;
+        o.score = func_strategy(in.func) == SVH_SCORE;
+        SVH_TRY(run_patch_match(ctx, scr, in, o, n_iter, n_random_search, seed, (const int32_t *)di, (int32_t *)os.dptr, &it));
     }
     if (iterations_run) *iterations_run = it;
     return finish_out(ctx, os);

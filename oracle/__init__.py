@@ -501,12 +501,31 @@ def pm_random(seed, it, i, j, k, dim):
     return int(lib().so_pm_random(C.c_uint64(seed), C.c_uint32(it & 0xFFFFFFFF), C.c_uint32(i), C.c_uint32(j), C.c_uint32(k), C.c_uint32(dim)))
 
 
-def cacheless_patch_match(func, search_dims, img_s, img_t, h_r, v_r, search_range, n_iter=5, n_random=4, seed=0):
+def cacheless_patch_match(func, search_dims, img_s, img_t, h_r, v_r, search_range, n_iter=5, n_random=4, seed=0, init=None):
+    """init: (H, W, search_dims) int32 initial solution in place of the random draw (the reference's `initializer` callback's map)."""
     s, t = _img3(img_s), _img3(img_t)
     sol = np.empty(s.shape[:2] + (search_dims,), np.int32)
     its = C.c_int(0)
-    rc = lib().so_cacheless_patch_match(int(func), int(search_dims), _p(s), s.shape[0], s.shape[1], _p(t), t.shape[0], t.shape[1], s.shape[2], int(h_r),
-                                        int(v_r), _od_range(search_dims, search_range), int(n_iter), int(n_random), C.c_uint64(seed), _p(sol), C.byref(its))
+    ini = None if init is None else _i32(init)
+    rc = lib().so_cacheless_patch_match_init(int(func), int(search_dims), _p(s), s.shape[0], s.shape[1], _p(t), t.shape[0], t.shape[1], s.shape[2], int(h_r),
+                                             int(v_r), _od_range(search_dims, search_range), int(n_iter), int(n_random), C.c_uint64(seed),
+                                             None if ini is None else _p(ini), _p(sol), C.byref(its))
+    if rc:
+        return np.empty((0, 0, 0), np.int32), 0
+    return sol, its.value
+
+
+def patch_match(func, search_dims, feat_s, feat_t, search_range, n_iter=5, n_random=4, seed=0, init=None):
+    """patchMatch (patchmatch.h:496-558) on feature volumes (H, W, F) float32."""
+    s, t = np.ascontiguousarray(feat_s, np.float32), np.ascontiguousarray(feat_t, np.float32)
+    if s.shape[2] != t.shape[2]:
+        return np.empty((0, 0, 0), np.int32), 0
+    sol = np.empty(s.shape[:2] + (search_dims,), np.int32)
+    its = C.c_int(0)
+    ini = None if init is None else _i32(init)
+    rc = lib().so_patch_match(int(func), int(search_dims), _p(s), s.shape[0], s.shape[1], _p(t), t.shape[0], t.shape[1], s.shape[2],
+                              _od_range(search_dims, search_range), int(n_iter), int(n_random), C.c_uint64(seed), None if ini is None else _p(ini),
+                              _p(sol), C.byref(its))
     if rc:
         return np.empty((0, 0, 0), np.int32), 0
     return sol, its.value

@@ -1570,17 +1570,15 @@ static int pm_test(const od_volume *o, int32_t *sol, int i, int j, const int *ca
     return keep;
 }
 
-int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int Hs, int Ws, const float *img_t, int Ht, int Wt, int C, int h_r,
-                             int v_r, const int *range, int n_iter, int n_random, uint64_t seed, int32_t *sol, int *iterations_run) {
-    od_volume o;
-    int r2[4] = {range[0], range[1], range[2], range[3]};
-    if (search_dims == 1) { r2[0] = range[2]; r2[1] = range[3]; }
-    int rc = od_setup(&o, func, search_dims, img_s, Hs, Ws, img_t, Ht, Wt, C, h_r, v_r, r2);
-    if (rc) return rc;
-    const int nd = search_dims;
+/* patchMatchImpl, :447-493, on a set-up volume: initial solution (the draw, or `init`), then the iterations */
+static int pm_run(const od_volume *op, int n_iter, int n_random, uint64_t seed, const int32_t *init, int32_t *sol) {
+    const int nd = op->search_dims, Hs = op->Hs, Ws = op->Ws;
     for (int i = 0; i < Hs; i++) /* randomDispInit, the NumbersCache branch with a search offset: :110-118 */
         for (int j = 0; j < Ws; j++)
-            for (int s = 0; s < nd; s++) sol[((size_t)i * Ws + j) * nd + s] = pm_in_range(pm_random(seed, 0xFFFFFFFFu, i, j, 0, s), o.lower[s], o.upper[s]);
+            for (int s = 0; s < nd; s++) {
+                const size_t e = ((size_t)i * Ws + j) * nd + s;
+                sol[e] = init ? init[e] : pm_in_range(pm_random(seed, 0xFFFFFFFFu, i, j, 0, s), op->lower[s], op->upper[s]); /* (init: the `initializer` callback's map, :598-605) */
+            }
     int it = 0;
     for (; it < n_iter; it++) {
         long changes = 0;
@@ -1593,7 +1591,7 @@ int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int 
                 if (pj < 0 || pj >= Ws) continue;
                 const int32_t *pv = sol + ((size_t)i * Ws + pj) * nd;
                 int cand[2] = {pv[0], nd == 2 ? pv[1] : 0};
-                changes += pm_test(&o, sol, i, j, cand);
+                changes += pm_test(op, sol, i, j, cand);
             }
         /* column scans, :412-437 */
 #pragma omp parallel for reduction(+ : changes)
@@ -1603,7 +1601,7 @@ int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int 
                 if (pi < 0 || pi >= Hs) continue;
                 const int32_t *pv = sol + ((size_t)pi * Ws + j) * nd;
                 int cand[2] = {pv[0], nd == 2 ? pv[1] : 0};
-                changes += pm_test(&o, sol, i, j, cand);
+                changes += pm_test(op, sol, i, j, cand);
             }
         /* random search, :226-363 */
 #pragma omp parallel for reduction(+ : changes)
@@ -1614,10 +1612,10 @@ int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int 
                 int n_chang = 0;
                 for (int k = 0; k < n_random; k++) {
                     int disp_i = 0, disp_j;
-                    if (nd == 1) disp_j = pm_in_range(pm_random(seed, it, i, j, k, 0), o.lower[0], o.upper[0]);
+                    if (nd == 1) disp_j = pm_in_range(pm_random(seed, it, i, j, k, 0), op->lower[0], op->upper[0]);
                     else {
-                        disp_i = pm_in_range(pm_random(seed, it, i, j, k, 0), o.lower[0], o.upper[0]);
-                        disp_j = pm_in_range(pm_random(seed, it, i, j, k, 1), o.lower[1], o.upper[1]);
+                        disp_i = pm_in_range(pm_random(seed, it, i, j, k, 0), op->lower[0], op->upper[0]);
+                        disp_j = pm_in_range(pm_random(seed, it, i, j, k, 1), op->lower[1], op->upper[1]);
                     }
                     int delta_i = disp_i - base_i, delta_j = disp_j - base_j; /* :320-331: exploration shrunk towards the solution */
                     delta_j *= k + 1;
@@ -1628,12 +1626,58 @@ int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int 
                     if (nd == 1) { if (disp_j == base_j) disp_j = base_j + 1; }
                     else if (disp_i == base_i && disp_j == base_j) { disp_i = base_i + 1; disp_j = base_j + 1; }
                     int cand[2] = {nd == 2 ? disp_i : disp_j, disp_j};
-                    n_chang = pm_test(&o, sol, i, j, cand); /* `=`, not `+=` (:345): only the last draw's outcome is counted */
+                    n_chang = pm_test(op, sol, i, j, cand); /* `=`, not `+=` (:345): only the last draw's outcome is counted */
                 }
                 changes += n_chang;
             }
         if (changes == 0) { it++; break; } /* :486-488 */
     }
+    return it;
+}
+
+int so_cacheless_patch_match_init(int func, int search_dims, const float *img_s, int Hs, int Ws, const float *img_t, int Ht, int Wt, int C, int h_r,
+                                  int v_r, const int *range, int n_iter, int n_random, uint64_t seed, const int32_t *init, int32_t *sol,
+                                  int *iterations_run) {
+    od_volume o;
+    int r2[4] = {range[0], range[1], range[2], range[3]};
+    if (search_dims == 1) { r2[0] = range[2]; r2[1] = range[3]; }
+    int rc = od_setup(&o, func, search_dims, img_s, Hs, Ws, img_t, Ht, Wt, C, h_r, v_r, r2);
+    if (rc) return rc;
+    const int it = pm_run(&o, n_iter, n_random, seed, init, sol);
+    if (iterations_run) *iterations_run = it;
+    od_free(&o);
+    return 0;
+}
+
+int so_cacheless_patch_match(int func, int search_dims, const float *img_s, int Hs, int Ws, const float *img_t, int Ht, int Wt, int C, int h_r,
+                             int v_r, const int *range, int n_iter, int n_random, uint64_t seed, int32_t *sol, int *iterations_run) {
+    return so_cacheless_patch_match_init(func, search_dims, img_s, Hs, Ws, img_t, Ht, Wt, C, h_r, v_r, range, n_iter, n_random, seed, NULL, sol, iterations_run);
+}
+
+/* patchMatch, correlation/patchmatch.h:496-558: the same iteration on feature volumes the caller built, through the cached cost volume
+ * (on_demand_cost_volume.h:35-327: costValue :105-178 has the rules of the cacheless one -- range, target inside -- and caches what
+ * featureComparison returns).  The vectors pass getFeatureVolumeForMatchFunc TWICE for zero-mean / normalised functions: in the entry
+ * point (:522-523) and again in the cost volume's constructor (on_demand_cost_volume.h:62-67).  feat_s [Hs][Ws][F], feat_t [Ht][Wt][F]. */
+int so_patch_match(int func, int search_dims, const float *feat_s, int Hs, int Ws, const float *feat_t, int Ht, int Wt, int F, const int *range,
+                   int n_iter, int n_random, uint64_t seed, const int32_t *init, int32_t *sol, int *iterations_run) {
+    if (!so_func_supported(func) || func_census(func) || (search_dims != 1 && search_dims != 2)) return 1;
+    if (search_dims == 1 && Hs != Ht) return 1; /* :533-537 */
+    od_volume o;
+    o.func = func; o.search_dims = search_dims; o.h_r = 0; o.v_r = 0;
+    if (search_dims == 1) { o.lower[0] = range[2]; o.upper[0] = range[3]; o.lower[1] = 0; o.upper[1] = 0; }
+    else { o.lower[0] = range[0]; o.upper[0] = range[1]; o.lower[1] = range[2]; o.upper[1] = range[3]; }
+    o.Hs = Hs; o.Ws = Ws; o.Ht = Ht; o.Wt = Wt; o.C = 1; o.nF = F;
+    float *fs = (float *)malloc((size_t)Hs * Ws * F * sizeof(float)), *ft = (float *)malloc((size_t)Ht * Wt * F * sizeof(float));
+    float *tmp = (float *)malloc((size_t)(Hs * Ws > Ht * Wt ? Hs * Ws : Ht * Wt) * F * sizeof(float));
+    if (!fs || !ft || !tmp) { free(fs); free(ft); free(tmp); return 2; }
+    const int twice = func_zero_mean(func) || func_normalized(func);
+    so_feature_volume_for_match_func(func, feat_s, Hs, Ws, F, twice ? (void *)tmp : (void *)fs);
+    if (twice) so_feature_volume_for_match_func(func, tmp, Hs, Ws, F, fs);
+    so_feature_volume_for_match_func(func, feat_t, Ht, Wt, F, twice ? (void *)tmp : (void *)ft);
+    if (twice) so_feature_volume_for_match_func(func, tmp, Ht, Wt, F, ft);
+    free(tmp);
+    o.fs = fs; o.ft = ft;
+    const int it = pm_run(&o, n_iter, n_random, seed, init, sol);
     if (iterations_run) *iterations_run = it;
     od_free(&o);
     return 0;

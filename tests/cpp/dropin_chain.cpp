@@ -13,6 +13,7 @@
 #include <correlation/cross_correlations.h>
 #include <correlation/hierarchical.h>
 #include <correlation/patchmatch.h>
+#include <utils/randomcache.h>
 #include <correlation/sgm.h>
 
 namespace SC = StereoVision::Correlation;
@@ -302,6 +303,35 @@ int main(int argc, char **argv) {
         if (refinedDisp.shape()[2] != 2) return 11;
         dump(out + "_pm_disp.i32", FE(pm), pm.flatLenght());
         dump(out + "_pm_refined.f32", FE(refinedDisp), refinedDisp.flatLenght());
+    }
+    { // benchmarkStereoMatchingModels.cpp:176-206: patchMatch on unfolded images, with a NumbersCache and (second call) an initializer callback
+        using namespace StereoVision::Correlation;
+        Multidim::Array<float, 3> img_left(H, W, 1), img_right(H, W, 1);
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++) {
+                img_left.atUnchecked(i, j, 0) = target.valueUnchecked(i, j);
+                img_right.atUnchecked(i, j, 0) = source.valueUnchecked(i, j);
+            }
+        Multidim::Array<float, 3> fVolLeft = unfold<float, float>(2, 2, img_left), fVolRight = unfold<float, float>(2, 2, img_right);
+        std::mt19937 re(5);
+        StereoVision::Random::NumbersCache<int> cache(1 << 10, [&re]() { return static_cast<int>(re() >> 1); });
+        std::optional<StereoVision::Random::NumbersCache<int>> optCache = cache;
+        HipBridge::patchMatchSeed() = 77;
+        Multidim::Array<disp_t, 3> out1 = patchMatch<matchingFunctions::ZNCC, 1>(fVolRight, fVolLeft, searchOffset<1>(0, 12), 5, 4, std::nullopt, optCache);
+        if (out1.shape()[0] != H || out1.shape()[1] != W || out1.shape()[2] != 1) return 13;
+        std::optional<std::function<Multidim::Array<disp_t, 3>(Multidim::Array<float, 3> const &, Multidim::Array<float, 3> const &)>> initializer =
+            [](Multidim::Array<float, 3> const &fs, Multidim::Array<float, 3> const &) {
+                Multidim::Array<disp_t, 3> d(fs.shape()[0], fs.shape()[1], 1);
+                for (int i = 0; i < fs.shape()[0]; i++)
+                    for (int j = 0; j < fs.shape()[1]; j++) d.atUnchecked(i, j, 0) = (i + 2 * j) % 13;
+                return d;
+            };
+        Multidim::Array<disp_t, 3> out2 = patchMatch<matchingFunctions::SAD, 1>(fVolRight, fVolLeft, searchOffset<1>(0, 12), 4, 3, initializer, std::nullopt);
+        if (out2.shape()[0] != H || out2.shape()[1] != W || out2.shape()[2] != 1) return 14;
+        dump(out + "_pmf_fvol_left.f32", FE(fVolLeft), fVolLeft.flatLenght());
+        dump(out + "_pmf_fvol_right.f32", FE(fVolRight), fVolRight.flatLenght());
+        dump(out + "_pmf_zncc.i32", FE(out1), out1.flatLenght());
+        dump(out + "_pmf_sad_init.i32", FE(out2), out2.flatLenght());
     }
     { // uint8 images: the byte versions of the pair (values scaled into 0..255), SAD volume, census words, unfold<uint8, uint8>
         Multidim::Array<uint8_t, 2> target8(H, W), source8(H, W);

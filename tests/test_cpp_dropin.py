@@ -101,6 +101,15 @@ def test_reference_call_chain_matches_oracle(tmp_path):
     pm_ref = so.refine_disp_2d(pm_tcv, pm, so.EQUIANGULAR, so.ISOTROPIC)
     bad, flipped = refined_2d_mismatch(np.fromfile(tmp_path / "o_pm_refined.f32", np.float32).reshape(H, W, 2), pm_ref, pm)
     assert bad == 0.0 and flipped <= 0.01
+    # patchMatch on unfolded images with a NumbersCache / an initializer callback (benchmarkStereoMatchingModels.cpp:176-206)
+    fl, fr = so.unfold(tgt, 2, 2), so.unfold(src, 2, 2)
+    assert np.array_equal(np.fromfile(tmp_path / "o_pmf_fvol_left.f32", np.float32).reshape(fl.shape), fl)
+    pmf, _ = so.patch_match(so.ZNCC, 1, fr, fl, (0, 12), 5, 4, seed=77)
+    assert np.array_equal(np.fromfile(tmp_path / "o_pmf_zncc.i32", np.int32).reshape(H, W, 1), pmf)
+    ii, jj = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    init = ((ii + 2 * jj) % 13).astype(np.int32)[:, :, None]
+    pmi, _ = so.patch_match(so.SAD, 1, fr, fl, (0, 12), 4, 3, seed=77, init=init)
+    assert np.array_equal(np.fromfile(tmp_path / "o_pmf_sad_init.i32", np.int32).reshape(H, W, 1), pmi)
     ncc = so.unfold_cost_volume(so.NCC, tgt, src, 4, 4, D)
     got_ncc = np.fromfile(tmp_path / "o_ncc_cv.f32", np.float32).reshape(H, W, D)
     assert np.max(np.abs(got_ncc - ncc)) <= 1e-4

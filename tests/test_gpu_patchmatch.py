@@ -180,3 +180,47 @@ def test_patch_match_run_batches_same_result(rng, func, nd):
                 sv.set_test_option(d_src, "patchmatch_lookback", 1)
         for other in outs[1:]:
             assert np.array_equal(host(outs[0][0]), host(other[0])) and outs[0][1] == other[1], (H, W, C, n_random)
+
+
+@pytest.mark.parametrize("func, so_func", [(MF.ZNCC, so.ZNCC), (MF.NCC, so.NCC), (MF.SAD, so.SAD), (MF.ZSSD, so.ZSSD), (MF.CC, so.CC)])
+@pytest.mark.parametrize("nd", [1, 2])
+def test_patch_match_on_feature_volumes_bit_identical_to_oracle(rng, func, so_func, nd):
+    """patchMatch (patchmatch.h:496-558): PatchMatch on feature volumes the caller built, the reference's cached cost volume behind it.  The
+    oracle restates the entry point (features processed twice for zero-mean / normalised functions) and shares the iteration with
+    cachelessPatchMatch; host and device arrays, grey and colour unfolds, with and without an initial solution."""
+    for (H, W, C, r, n_iter, n_random) in [(30, 47, 1, 2, 4, 4), (21, 33, 3, 1, 3, 2)]:
+        src, tgt = shifted_pair(rng, H, W, C, 0 if nd == 1 else 1, -2)
+        fs, ft = so.unfold(src, r, r), so.unfold(tgt, r, r)
+        off = sv.searchOffset2(-3, 3, -6, 6) if nd == 2 else sv.searchOffset1(-6, 6)
+        rng_t = ((-3, 3), (-6, 6)) if nd == 2 else (-6, 6)
+        want, its = so.patch_match(so_func, nd, fs, ft, rng_t, n_iter, n_random, seed=31)
+        for a, b in ((fs, ft), (dev(fs), dev(ft))):
+            got, gits = sv.patchMatch(func, a, b, off, n_iter, n_random, seed=31, return_iterations=True)
+            assert np.array_equal(host(got), want) and gits == its, (H, W, C)
+        init = rng.integers(-6, 7, (H, W, nd)).astype(np.int32)
+        if nd == 2:
+            init[..., 0] = np.clip(init[..., 0], -3, 3)
+        want_i, _ = so.patch_match(so_func, nd, fs, ft, rng_t, n_iter, n_random, seed=31, init=init)
+        assert np.array_equal(host(sv.patchMatch(func, dev(fs), dev(ft), off, n_iter, n_random, seed=31, initial=dev(init))), want_i)
+        assert np.array_equal(sv.patchMatch(func, fs, ft, off, n_iter, n_random, seed=31, initial=init), want_i)
+    # argument rules: feature counts that differ, row counts with a stereo search -> empty (patchmatch.h:529-537)
+    a = rng.uniform(0, 1, (8, 9, 5)).astype(np.float32)
+    assert sv.patchMatch(MF.ZNCC, a, a[:, :, :4].copy(), sv.searchOffset1(-1, 1)).size == 0
+    assert sv.patchMatch(MF.ZNCC, a, a[:7].copy(), sv.searchOffset1(-1, 1)).size == 0
+    assert sv.patchMatch(MF.ZNCC, a, a[:7].copy(), sv.searchOffset2(-1, 1, -1, 1)).shape == (8, 9, 2)
+
+
+def test_cacheless_patch_match_with_an_initial_solution(rng):
+    """the reference's `initializer` callback (patchmatch.h:598-605): its map replaces the random draw"""
+    H, W, C, r = 26, 41, 3, 1
+    src, tgt = shifted_pair(rng, H, W, C, 1, -2)
+    off = sv.searchOffset2(-3, 3, -6, 6)
+    init = np.stack([rng.integers(-3, 4, (H, W)), rng.integers(-6, 7, (H, W))], -1).astype(np.int32)
+    want, its = so.cacheless_patch_match(so.ZNCC, 2, src, tgt, r, r, ((-3, 3), (-6, 6)), 4, 3, seed=8, init=init)
+    got, gits = sv.cachelessPatchMatch(MF.ZNCC, dev(src), dev(tgt), r, off, 4, 3, seed=8, return_iterations=True, initial=dev(init))
+    assert np.array_equal(host(got), want) and gits == its
+    assert np.array_equal(sv.cachelessPatchMatch(MF.ZNCC, src, tgt, r, off, 4, 3, seed=8, initial=init), want)
+    # an initial solution outside the search range has no value: a score function replaces it at the first candidate that has one
+    far = np.full((H, W, 2), 50, np.int32)
+    want_f, _ = so.cacheless_patch_match(so.ZNCC, 2, src, tgt, r, r, ((-3, 3), (-6, 6)), 3, 2, seed=8, init=far)
+    assert np.array_equal(host(sv.cachelessPatchMatch(MF.ZNCC, dev(src), dev(tgt), r, off, 3, 2, seed=8, initial=dev(far))), want_f)

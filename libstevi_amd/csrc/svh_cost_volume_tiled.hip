@@ -207,14 +207,13 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                                                                  const float *__restrict__ mean_t, const float *__restrict__ norm_s,
                                                                  const float *__restrict__ norm_t, const float *__restrict__ zcost, int row_off,
                                                                  int64_t px_stride, int64_t out_off, float *__restrict__ cv, int row0, ColsumReduce rd, int n_dh, int C) {
-    static_assert(!(MC && FOLD), "colour images build 2-D volumes one vertical offset at a time");
     constexpr int DB = CS_DB, OUT = CS_COLS - 2 * HR;
     extern __shared__ float lds[];
     const int v = MC ? (2 * v_r + 1) * C : 2 * v_r + 1; // rows the kernel walks (window rows x channels)
     const bool ext = FOLD && D > DB && (D & 1);       // the last block of an offset is seventeen wide
     const int nbw = (D - (ext ? 1 : 0) + DB - 1) / DB; // blocks of one vertical offset
     const int n_blocks = FOLD ? nbw * n_dh : nbw;
-    const int n_off = FOLD ? n_dh : 1, tv = v + n_off - 1; // vertical offsets of the launch, target rows staged
+    const int n_off = FOLD ? n_dh : 1, tv = v + (n_off - 1) * (MC ? C : 1); // vertical offsets of the launch, target rows staged (MC: C tile rows per image row)
     const int tw = CS_COLS + nbw * DB; // target tile columns (even: 8-byte aligned pairs)
     float *stile = lds, *ttile = lds + v * CS_COLS, *tmean = ttile + tv * tw, *tinv = tmean + (ZM ? n_off * tw : 0); // (tmean / tinv: ZM / NRM only)
     float *xpose = tinv + (NRM ? n_off * tw : 0) + (threadIdx.x >> 6) * (64 * CS_XP); // this wave's area for turning 64 pixels x DB costs around
@@ -290,7 +289,7 @@ __global__ void __launch_bounds__(64 * WAVES, RED ? 4 : 1) cost_volume_colsum_ke
                 ext_b = ext;
             }
         }
-        const float *ttile_b = FOLD ? ttile + dh * tw : ttile, *tmean_b = FOLD ? tmean + dh * tw : tmean, *tinv_b = FOLD ? tinv + dh * tw : tinv;
+        const float *ttile_b = FOLD ? ttile + dh * (MC ? C : 1) * tw : ttile, *tmean_b = FOLD ? tmean + dh * tw : tmean, *tinv_b = FOLD ? tinv + dh * tw : tinv;
         const bool trow_in_b = FOLD ? (it + dh >= 0 && it + dh < H) : trow_in;
         const int64_t out_b = FOLD ? out_off + (int64_t)dh * D : out_off;
         // Column sums as register PAIRS (v_pk_fma_f32 takes aligned pairs): the row's target samples t[0 .. DB + 1] arrive as the
@@ -582,7 +581,7 @@ inline int colsum_waves(int D) { return (D + CS_DB - 1) / CS_DB >= 16 ? 8 : 4; }
 inline int colsum_waves(int D, int n_dh) { return n_dh * ((D + CS_DB - 1) / CS_DB) >= 16 ? 8 : 4; }
 inline size_t colsum_shmem(int v_r, int D, bool zm, bool nrm, int n_dh = 1, int C = 1) {
     const int v = (2 * v_r + 1) * C, nb = (D + CS_DB - 1) / CS_DB, tw = CS_COLS + nb * CS_DB;
-    return (size_t)(v * CS_COLS + (v + n_dh - 1) * tw + (zm ? n_dh * tw : 0) + (nrm ? n_dh * tw : 0) + colsum_waves(D, n_dh) * 64 * CS_XP) * sizeof(float);
+    return (size_t)(v * CS_COLS + (v + (n_dh - 1) * C) * tw + (zm ? n_dh * tw : 0) + (nrm ? n_dh * tw : 0) + colsum_waves(D, n_dh) * 64 * CS_XP) * sizeof(float);
 }
 
 template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
@@ -607,18 +606,19 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
         SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD>), grid, 64 * WV, shmem, src, tgt, a.H,   \
                    a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, a.n_dh, 1); \
     } while (0)
-#define SVH_CS_LAUNCH_MC(SG, WV)                                                                                                                    \
+#define SVH_CS_LAUNCH_MCF(SG, WV, FD)                                                                                                               \
     do {                                                                                                                                           \
         static int big_lds[64] = {};                                                                                                               \
         if (shmem > 64 * 1024 && !__atomic_load_n(&big_lds[ctx->device & 63], __ATOMIC_ACQUIRE)) {                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, false, true>),        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, FD, true>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                     \
             __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
         }                                                                                                                                          \
-        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, false, true>), grid, 64 * WV, shmem, src, tgt, \
-                   a.H, a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, 1,   \
-                   a.C);                                                                                                                           \
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, FD, true>), grid, 64 * WV, shmem, src, tgt,   \
+                   a.H, a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd,      \
+                   a.n_dh, a.C);                                                                                                                   \
     } while (0)
+#define SVH_CS_LAUNCH_MC(SG, WV) SVH_CS_LAUNCH_MCF(SG, WV, false)
 #define SVH_CS_LAUNCH_R(SG, WV, RD) SVH_CS_LAUNCH_RF(SG, WV, RD, false)
 #define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
     do {                                                                                                                                           \
@@ -626,7 +626,10 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
         else if (rd.mode == 2) SVH_CS_LAUNCH_R(SG, WV, 2);                                                                                         \
         else SVH_CS_LAUNCH_R(SG, WV, 0);                                                                                                           \
     } while (0)
-    if (a.C > 1) { // interleaved channels: their own instantiations (the grey kernels stay as they are, register for register)
+    if (a.C > 1 && a.n_dh > 1) { // colour images, several vertical offsets of a 2-D volume in one launch (round 5; sign +1 there)
+        if (colsum_waves(a.D, a.n_dh) == 8) SVH_CS_LAUNCH_MCF(1, 8, true);
+        else SVH_CS_LAUNCH_MCF(1, 4, true);
+    } else if (a.C > 1) { // interleaved channels: their own instantiations (the grey kernels stay as they are, register for register)
         if (colsum_waves(a.D) == 8) {
             if (sign > 0) SVH_CS_LAUNCH_MC(1, 8);
             else SVH_CS_LAUNCH_MC(-1, 8);
@@ -648,6 +651,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
 #undef SVH_CS_LAUNCH_R
 #undef SVH_CS_LAUNCH_RF
 #undef SVH_CS_LAUNCH_MC
+#undef SVH_CS_LAUNCH_MCF
 }
 template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                        const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {
@@ -730,7 +734,6 @@ template <int CMP, bool ZM> bool dispatch_hr(svh_context *ctx, int h_r, const Co
 
 bool cost_volume_colsum_applies(const svh_context *ctx, const CostVolumeArgs &a, ImageDesc src, ImageDesc tgt, int h_r, int v_r) {
     if (a.literal || src.C != tgt.C || src.C < 1 || src.C > 4 || h_r < 1 || h_r > 7 || func_census(a.func) || a.func == SVH_ZSAD || !ctx->cost_volume_colsum) return false;
-    if (src.C > 1 && a.n_dh > 1) return false; // (colour images: one vertical offset per launch)
     return colsum_shmem(v_r, a.D, func_zero_mean(a.func), func_normalized(a.func), a.n_dh, src.C) <= 78 * 1024 && (int64_t)a.H * a.Ws * a.D > 0;
 }
 

@@ -234,3 +234,32 @@ def test_2d_volume_folded_offsets_same_bits(rng, func):
         assert np.array_equal(np.isnan(folded), np.isnan(exp))
         ok = ~np.isnan(exp)
         assert np.all(np.abs(folded[ok] - exp[ok]) <= 1e-4 * np.maximum(1, np.abs(exp[ok])))
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.SSD, MF.ZSSD, MF.SAD, MF.CC])
+def test_2d_volume_folded_offsets_colour_images_same_bits(rng, func):
+    """the same for images of interleaved channels (round 5: the column-sum kernel takes several vertical offsets of a colour image in one
+    launch too -- the channels are tile rows of their own, an image row down is C tile rows down): folded against a launch per offset, bit
+    for bit, and against the oracle within the float tolerance; two, three and four channels."""
+    cases = [((25, 200, 3), 3, 3, (-4, 4), (-16, 16)),  # 9 x 33 on RGB: what examples/stereo-match-style flow volumes use
+             ((19, 140, 3), 2, 1, (-2, 3), (-8, 8)),    # 17
+             ((14, 131, 2), 1, 2, (-1, 1), (0, 15)),
+             ((12, 130, 4), 2, 2, (-6, 5), (-4, 4)),    # several groups; shorter than a block
+             ((10, 129, 3), 1, 1, (-1, 0), (-17, 17))]  # 35: the seventeen-wide last block
+    for (shape, h_r, v_r, r0, r1) in cases:
+        left = rng.uniform(-1, 1, shape).astype(np.float32)
+        right = rng.uniform(-1, 1, shape).astype(np.float32)
+        dl, dr = dev(left), dev(right)
+        off = sv.searchOffset2(r0[0], r0[1], r1[0], r1[1])
+        sv.set_test_option(dl, "fold_2d_offsets", 0)
+        try:
+            per_offset = host(sv.unfoldBased2dDisparityCostVolume(func, dl, dr, h_r, v_r, off))
+        finally:
+            sv.set_test_option(dl, "fold_2d_offsets", 1)
+        folded = host(sv.unfoldBased2dDisparityCostVolume(func, dl, dr, h_r, v_r, off))
+        assert folded.shape == per_offset.shape == (shape[0], shape[1], r0[1] - r0[0] + 1, r1[1] - r1[0] + 1)
+        assert np.array_equal(folded.view(np.uint32), per_offset.view(np.uint32)), (shape, h_r, v_r, r0, r1)
+        exp = so.unfold_cost_volume_2d(int(func), left, right, h_r, v_r, r0, r1)
+        assert np.array_equal(np.isnan(folded), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.all(np.abs(folded[ok] - exp[ok]) <= 1e-4 * np.maximum(1, np.abs(exp[ok])))

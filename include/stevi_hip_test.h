@@ -28,9 +28,11 @@ extern "C" {
  * (mean subtracted, divided by the norm: the values of the reference's normalised volumes) and compares 64 pixels of a row with their
  * target records from LDS; 0: the per-voxel kernel processes both vectors of every voxel.  Same bits.
  * "guided_shared" (default 1): svh_compute_guided_cv / svh_hierarchical_truncated_cost_volume on grey images with a search radius of at most
- * 3: a block of 256 pixels stages the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of
- * the target windows its pixels look at in LDS once, instead of every pixel processing every sample of every offset again; 0: the
- * per-pixel walk.  Same bits (tests/test_gpu_hierarchical.py).
+ * 3 stage the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of the target windows a group
+ * of pixels looks at in LDS once, instead of every pixel processing every sample of every offset again.  1: a wave per 64 pixels, which
+ * divides by a norm through its double reciprocal (the same quotient bits), where the grid fills the chip several times over, and a
+ * block of 256 pixels with float divisions (round 4) on smaller grids; 2: the blocks always; 3: the waves always; 0: the per-pixel walk.
+ * Same bits (tests/test_gpu_hierarchical.py).
  * "sgm_score_pad" (default 1): svh_sgm_cost_volume / svh_stereo_match, Score strategy, on 65 .. 511 disparities that are no multiple of 64
  * (the reference's own benchmark uses 160) aggregate a copy of the volume whose rows are padded to the next multiple of 64 with -inf
  * -- a pad never enters a maximum, and cost + anything stays -inf along every line -- so that the vector kernels, the banded sweep and

@@ -451,7 +451,6 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         {"patchmatch_run_batches", &svh_context::patchmatch_run_batches},
         {"patchmatch_lookback", &svh_context::patchmatch_lookback},
         {"feature_volume_tiled", &svh_context::feature_volume_tiled},
-        {"guided_shared", &svh_context::guided_shared},
         {"sgm_score_pad", &svh_context::sgm_score_pad},
         {"fold_2d_offsets", &svh_context::fold_2d_offsets},
         {"cost_reduce_fused", &svh_context::cost_reduce_fused},
@@ -465,6 +464,11 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         }
     if (strcmp(name, "census_sweep_rl") == 0) {
         ctx->census_sweep_rl = value;
+        return SVH_OK;
+    }
+    if (strcmp(name, "guided_shared") == 0) {
+        if (value < 0 || value > 3) return fail(ctx, SVH_ERR_INVALID_ARGUMENT, "guided_shared: 0 .. 3");
+        ctx->guided_shared = value;
         return SVH_OK;
     }
     if (strcmp(name, "patchmatch_search_form") == 0) {

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "svh_compare.h"
+#include "svh_guided_wave.h"
 #include "svh_internal.h"
 
 namespace svh {
@@ -47,32 +48,6 @@ __global__ void downsample_kernel(const float *__restrict__ img, int H, int W, i
     }
 }
 
-// hierarchical.h:106-150: bilinear upsampling of the integer guide (taps clamped as written), times two, rounded half away
-// from zero; float operations in the reference's order
-__device__ __forceinline__ int guided_base_disp(const int32_t *__restrict__ guide, int Hg, int Wg, int h, int w, int i, int j, int dirSign) {
-    const float v_pos = (float)(i * (Hg - 1)) / (float)(h - 1);
-    int v0 = (int)floorf(v_pos), v1 = (int)ceilf(v_pos);
-    if (v0 == v1) v1 += 1;
-    if (v1 == Hg) {
-        v0 -= 1;
-        v1 -= 1;
-    }
-    const float h_pos = (float)(j * (Wg - 1)) / (float)(w - 1);
-    int h0 = (int)floorf(h_pos), h1 = (int)ceilf(h_pos);
-    if (h0 == h1) h1 += 1;
-    if (h1 == Wg) {
-        h0 -= 1;
-        h1 -= 1;
-    }
-    float interp = 0.0f;
-    interp += (v_pos - (float)v0) * (h_pos - (float)h0) * (float)guide[(int64_t)v1 * Wg + h1];
-    interp += ((float)v1 - v_pos) * (h_pos - (float)h0) * (float)guide[(int64_t)v0 * Wg + h1];
-    interp += (v_pos - (float)v0) * ((float)h1 - h_pos) * (float)guide[(int64_t)v1 * Wg + h0];
-    interp += ((float)v1 - v_pos) * ((float)h1 - h_pos) * (float)guide[(int64_t)v0 * Wg + h0];
-    interp *= 2.0f;
-    return dirSign * (int)roundf(interp);
-}
-
 // Hamming distance between exact words (the target is gathered as uint32 here, no float round trip: hierarchical.h:175-178)
 struct WordVolume {
     const uint32_t *w;
@@ -87,11 +62,6 @@ __device__ __forceinline__ float compare_words(const WordVolume &src, const Word
     return (float)(uint16_t)score; // hamming_cv_t, matching_costs.h:234
 }
 
-struct GuideArgs {
-    const int32_t *guide;
-    int Hg, Wg, radius, dirSign;
-    bool cost;
-};
 
 template <class CmpFn>
 __device__ __forceinline__ void guided_select_body(CmpFn cmp, int H, int Ws, const GuideArgs &g, int32_t *__restrict__ disp) {
@@ -152,77 +122,6 @@ __global__ void guided_volume_words_kernel(WordVolume src, WordVolume tgt, int H
 // the winner is searched over the middle 2R + 1 (strict comparison in increasing offset, as the reference does), and the
 // re-centred volume d_r - R .. d_r + R always lies inside the evaluated span.  The per-offset sums see exactly the terms, in
 // exactly the order, of compare_features, so the result equals the two-pass form bit for bit.
-// one pixel of the one-pass form, everything from global memory (the per-lane walk; also what a block of guided_shared_kernel falls back
-// to when its pixels' guides point too far apart for the staged target features)
-template <int CMP, bool ZM, bool NORM, int R>
-__device__ __forceinline__ void guided_fused_px(const FeatImage &src, const FeatImage &tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
-                                                const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt, const GuideArgs &g,
-                                                int32_t *__restrict__ disp, float *__restrict__ tcv, int64_t p, int i, int j, int d0) {
-    constexpr int NC = 4 * R + 1, T = 2 * R + 1;
-    const int C = src.C, h = 2 * src.h_r + 1, v = 2 * src.v_r + 1;
-    const float ms = ZM ? mean_s[p] : 0.0f, ns = NORM ? norm_s[p] : 1.0f;
-    float mt[NC], nt[NC], acc[NC];
-    bool tin[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int jt = j + d0 + c - 2 * R;
-        tin[c] = jt >= 0 && jt < Wt;
-        const int64_t pt = (int64_t)i * Wt + (tin[c] ? jt : 0);
-        mt[c] = (ZM && tin[c]) ? mean_t[pt] : 0.0f;
-        nt[c] = (NORM && tin[c]) ? norm_t[pt] : 1.0f;
-        acc[c] = 0.0f;
-    }
-    for (int k = 0; k < v; k++) {
-        const int ii = i - src.v_r + k;
-        const bool row_in = ii >= 0 && ii < H;
-        for (int l = 0; l < h; l++) {
-            const int jj = j - src.h_r + l;
-            for (int ch = 0; ch < C; ch++) {
-                float s = (row_in && jj >= 0 && jj < Ws) ? src.img[((int64_t)ii * Ws + jj) * C + ch] : 0.0f;
-                if (ZM) s = s - ms;
-                if (NORM) s = s / ns;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    const int jc = jj + d0 + c - 2 * R;
-                    float t = 0.0f;
-                    if (tin[c]) {
-                        t = (row_in && jc >= 0 && jc < Wt) ? tgt.img[((int64_t)ii * Wt + jc) * C + ch] : 0.0f;
-                        if (ZM) t = t - mt[c];
-                        if (NORM) t = t / nt[c];
-                    }
-                    if (CMP == CMP_DOT) {
-                        acc[c] += s * t;
-                    } else if (CMP == CMP_SSD) {
-                        const float tmp = s - t;
-                        acc[c] += tmp * tmp;
-                    } else {
-                        acc[c] += fabsf(s - t);
-                    }
-                }
-            }
-        }
-    }
-    float score = g.cost ? INFINITY : -INFINITY;
-    int best = 0; // offset of the winner relative to d0
-#pragma unroll
-    for (int c = R; c <= 3 * R; c++) {
-        if (g.cost ? (acc[c] < score) : (acc[c] > score)) {
-            score = acc[c];
-            best = c - 2 * R;
-        }
-    }
-    disp[p] = g.dirSign * (d0 + best);
-#pragma unroll
-    for (int dd = 0; dd < T; dd++) {
-        const int want = best + g.dirSign * (dd - R) + 2 * R;
-        float val = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-            if (c == want) val = acc[c];
-        tcv[p * T + dd] = val;
-    }
-}
-
 template <int CMP, bool ZM, bool NORM, int R>
 __global__ void __launch_bounds__(256) guided_fused_kernel(FeatImage src, FeatImage tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
                                                            const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
@@ -391,7 +290,14 @@ bool launch_guided_fused(svh_context *ctx, FeatImage src, FeatImage tgt, const f
     // grey images, windows up to 7 wide: the processed target features shared by a block; otherwise every lane on its own
     if (ctx->guided_shared && src.C == 1 && tgt.C == 1 && H <= 65535 && src.h_r == tgt.h_r && src.v_r == tgt.v_r) {
         bool ran = false;
-        switch (src.h_r) {
+        // 1 (the default): a wave per 64 pixels where the grid fills the chip several times over (a wave per SIMD is 1 024 waves) and runs at the
+        // rate of its instructions; a smaller grid -- 640 x 480, the coarse levels of a pyramid -- is as long as its slowest block, and
+        // the blocks of four waves below with their wider span are shorter (measured crossover: 960 x 540).  3: a wave per 64 pixels always.
+        const bool waves_fill_the_chip = (int64_t)ceil_div(Ws, 64) * H >= 8192;
+        if (((ctx->guided_shared == 1 && waves_fill_the_chip) || ctx->guided_shared == 3) &&
+            launch_guided_wave(ctx, CMP, ZM, NORM, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv))
+            return true;
+        switch (src.h_r) { // 2: a block of four waves per 256 pixels (round 4)
         case 1: ran = launch_guided_shared<CMP, ZM, NORM, 1>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); break;
         case 2: ran = launch_guided_shared<CMP, ZM, NORM, 2>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); break;
         case 3: ran = launch_guided_shared<CMP, ZM, NORM, 3>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); break;

@@ -135,22 +135,50 @@ def test_reference_testMatchingFilter_on_gpu(depth):
 
 @pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.CC, MF.SSD, MF.ZSSD, MF.SAD, MF.ZSAD])
 def test_guided_shared_features_same_bits_as_the_per_pixel_walk(func):
-    """Option "guided_shared" (default): a block of 256 pixels stages the processed target feature vectors its pixels look at in LDS;
-    0: every pixel processes every sample of every offset itself.  Same estimates and costs bit for bit: images wider than a block,
-    a last block that is not full, search radii 1 - 3, windows 3x3 - 9x9 (the last too wide for the staged form), both directions, a
-    foreground square whose parallax differs from the background's by more than the staged span holds (blocks that fall back), guides
-    that point outside the image."""
-    for (H, W, r, radius, bg, sq) in [(40, 700, 3, 2, 4, 12), (33, 530, 2, 3, 2, 300), (21, 300, 1, 1, 0, 40), (18, 600, 4, 2, 3, 9), (9, 257, 3, 3, 120, 5)]:
+    """Option "guided_shared": 3 a wave of 64 pixels stages the processed target feature vectors its pixels look at in LDS and divides by
+    the norms through their double reciprocals; 2: a block of 256 pixels, float divisions (round 4); 1 (default): the waves on large
+    grids, the blocks on small ones; 0: every pixel processes every sample of every offset itself.  Same estimates and costs bit for
+    bit: images wider than a block, a last block that is not full, search radii 1 - 3, windows 3x3 - 9x9 (the last too wide for the
+    staged forms), both directions, a foreground square whose parallax differs from the background's by more than the staged span holds
+    (waves that take two passes or walk, blocks that fall back), guides that point outside the image."""
+    for (H, W, r, radius, bg, sq) in [(40, 700, 3, 2, 4, 12), (33, 530, 2, 3, 2, 300), (21, 300, 1, 1, 0, 40), (18, 600, 4, 2, 3, 9), (9, 257, 3, 3, 120, 5),
+                                      (30, 333, 2, 2, 6, 30)]:
         src, tgt, _ = parallax_pair(H, W, max(H // 2, 2), H // 4, W // 3, bg, sq, seed=H + W)
         d_src, d_tgt = dev(src), dev(tgt)
         for ddir in (R2L, L2R):
             outs = []
-            for shared in (1, 0):
+            for shared in (0, 3, 2, 1):
                 sv.set_test_option(d_src, "guided_shared", shared)
                 try:
                     res = sv.hiearchicalTruncatedCostVolume(func, 2, d_tgt, d_src, r, r, 2 * max(bg, sq) + 8, radius, ddir)
                 finally:
                     sv.set_test_option(d_src, "guided_shared", 1)
                 outs.append((host(res.disp_estimate), host(res.truncated_cost_volume)))
-            assert np.array_equal(outs[0][0], outs[1][0]), (H, W, r, radius)
-            assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)), (H, W, r, radius)
+            for o in outs[1:]:
+                assert np.array_equal(outs[0][0], o[0]), (H, W, r, radius)
+                assert np.array_equal(outs[0][1].view(np.uint32), o[1].view(np.uint32)), (H, W, r, radius)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e-19, 1.0, 1e18])
+def test_guided_wave_divisions_by_shared_reciprocals_same_bits(scale):
+    """div_by_shared (svh_hierarchical.hip): (float)((double)x * (1.0 / (double)y)) against x / y of the per-pixel walk, bit for bit, with
+    images scaled so that the normalised samples and the norms run through large, small and denormal magnitudes."""
+    H, W, r, radius = 24, 400, 2, 2
+    src, tgt, _ = parallax_pair(H, W, H // 2, H // 4, W // 3, 3, 9, seed=77)
+    rng = np.random.default_rng(5)
+    src = (src * rng.uniform(0.5, 1.5, src.shape)).astype(np.float32) * np.float32(scale)
+    tgt = (tgt * rng.uniform(0.5, 1.5, tgt.shape)).astype(np.float32) * np.float32(scale)
+    src[3, 40:60] = 0.0  # windows with zero samples
+    tgt[10:16, 100:140] = 0.0  # windows whose norm is 0: 0 / 0
+    d_src, d_tgt = dev(src), dev(tgt)
+    for func in (MF.ZNCC, MF.NCC):
+        outs = []
+        for shared in (0, 3):
+            sv.set_test_option(d_src, "guided_shared", shared)
+            try:
+                res = sv.hiearchicalTruncatedCostVolume(func, 1, d_tgt, d_src, r, r, 24, radius)
+            finally:
+                sv.set_test_option(d_src, "guided_shared", 1)
+            outs.append((host(res.disp_estimate), host(res.truncated_cost_volume)))
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))

@@ -41,6 +41,8 @@ def test_test_switches_are_not_on_the_public_entry_point():
         sv.set_test_option(t, name, 1)
     sv.set_test_option(t, "sgm_score_fused", 3)
     sv.set_test_option(t, "sgm_score_fused", 1)
+    sv.set_test_option(t, "guided_shared", 3)
+    sv.set_test_option(t, "guided_shared", 1)
     for name, v in DEFAULTS.items():  # the test entry point drives the public options too
         sv.set_test_option(t, name, v)
     with pytest.raises(_capi.SvhError):

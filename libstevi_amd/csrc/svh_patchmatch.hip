@@ -143,6 +143,120 @@ __global__ void __launch_bounds__(256) on_demand_features_kernel(const float *__
     }
 }
 
+// x / y through the double reciprocal rd = 1.0 / (double)y of a divisor many samples share (svh_guided_wave_impl.h, div_by_shared, has the
+// argument: the float nearest to (double)x * rd is the correctly rounded quotient whenever that is 0 or a normal number): a fifth of a float
+// division's cycles.  A nonzero denormal result takes the division itself.
+__device__ __forceinline__ float div_by_shared_or_divide(float x, float y, double rd) {
+    float q = (float)((double)x * rd);
+    if (__builtin_amdgcn_classf(q, 0x090)) q = x / y;
+    return q;
+}
+
+// Round 5: the same with the window rows of the block's pixels in LDS.  The kernel above walks every window through the caches twice (mean,
+// norm: a dependent load per sample) and a third time for the features, and divides every sample by the norm: 3.1 ms for two 1080p RGB
+// images and 7x7 windows, whose 2.4 GB of features take 0.4 ms to write.  Here a block owns up to 256 consecutive pixels of ONE image row;
+// the v window rows of those pixels (256 + h - 1 pixels each, border pixels repeated: features_volume.h:128-133) are copied to LDS once --
+// one contiguous run per row away from the image's left and right borders -- and the three walks read them there; the divisions go
+// through the norm's double reciprocal.  Same operations on the same operands in the same order.
+__global__ void __launch_bounds__(256) on_demand_features_tiled_kernel(const float *__restrict__ img, int H, int W, int C, int h_r, int v_r, bool zm, bool nrm,
+                                                                       float *__restrict__ out, float2 *__restrict__ stats) {
+    extern __shared__ float tile[]; // [v][(256 + h - 1) C]
+    __shared__ float s_mean[ODF_PX], s_norm[ODF_PX];
+    __shared__ double s_rd[ODF_PX];
+    const int i = blockIdx.y, j0 = blockIdx.x * ODF_PX, n_px = min(ODF_PX, W - j0);
+    const int h = 2 * h_r + 1, v = 2 * v_r + 1, hc = h * C, nF = v * hc, TWc = (ODF_PX + h - 1) * C;
+    const int n_cols = (n_px + h - 1) * C; // what of a tile row this block reads
+    const bool inside = j0 - h_r >= 0 && j0 + n_px - 1 + h_r < W; // (block uniform)
+    for (int k = 0; k < v; k++) {
+        const float *row = img + (int64_t)min(H - 1, max(0, i + k - v_r)) * W * C;
+        if (inside) {
+            const float *from = row + (int64_t)(j0 - h_r) * C;
+            for (int r = threadIdx.x; r < n_cols; r += 256) tile[k * TWc + r] = from[r];
+        } else {
+            for (int r = threadIdx.x; r < n_cols; r += 256) {
+                const int x = r / C, c = r - x * C;
+                tile[k * TWc + r] = row[(int64_t)min(W - 1, max(0, j0 - h_r + x)) * C + c];
+            }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_px) {
+        const float *win = tile + threadIdx.x * C; // this pixel's window: rows k of hc consecutive floats (feature index order: k, l, c)
+        float mean = 0.0f, norm = 1.0f;
+        if (zm) { // :183-192
+            for (int k = 0; k < v; k++) {
+#pragma unroll 4
+                for (int m = 0; m < hc; m++) mean += win[k * TWc + m];
+            }
+            mean /= (float)nF;
+        }
+        if (nrm) { // :194-207
+            float acc = 0.0f;
+            for (int k = 0; k < v; k++) {
+#pragma unroll 4
+                for (int m = 0; m < hc; m++) {
+                    float x = win[k * TWc + m];
+                    if (zm) x -= mean;
+                    acc += x * x;
+                }
+            }
+            acc /= (float)nF;
+            norm = sqrtf(acc);
+        }
+        s_mean[threadIdx.x] = mean;
+        s_norm[threadIdx.x] = norm;
+        s_rd[threadIdx.x] = 1.0 / (double)norm;
+        if (stats) stats[(int64_t)i * W + j0 + threadIdx.x] = make_float2(mean, norm);
+    }
+    __syncthreads();
+    float *o_blk = out + ((int64_t)i * W + j0) * nF;
+    if (nF < 48) { // short vectors would leave most of a wave's lanes idle: one flat run of elements instead (a few divisions per element)
+        for (int e = threadIdx.x; e < n_px * nF; e += 256) {
+            const int q = e / nF, f = e - q * nF;
+            const int k = f / hc, m = f - k * hc;
+            float x = tile[k * TWc + q * C + m];
+            if (zm) x -= s_mean[q];
+            if (nrm) x = div_by_shared_or_divide(x, s_norm[q], s_rd[q]);
+            o_blk[e] = x;
+        }
+        return;
+    }
+    // a wave per pixel, the lanes over the feature index (a pixel's nF floats are one contiguous run): where in the tile a lane's features
+    // sit relative to the pixel is the same for every pixel -- decoded once
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int MAXCH = 4;
+    int at[MAXCH];
+#pragma unroll
+    for (int m = 0; m < MAXCH; m++) {
+        const int f = min(lane + 64 * m, nF - 1);
+        const int k = f / hc;
+        at[m] = k * TWc + (f - k * hc);
+    }
+    for (int q = wave; q < n_px; q += 4) {
+        const float mean = s_mean[q], norm = s_norm[q];
+        const double rd = s_rd[q];
+        const float *win = tile + q * C;
+        float *o = o_blk + (int64_t)q * nF;
+#pragma unroll
+        for (int m = 0; m < MAXCH; m++) {
+            const int f = lane + 64 * m;
+            if (f < nF) {
+                float x = win[at[m]];
+                if (zm) x -= mean;
+                if (nrm) x = div_by_shared_or_divide(x, norm, rd);
+                o[f] = x;
+            }
+        }
+        for (int f = lane + 64 * MAXCH; f < nF; f += 64) { // (more than 256 features: decoded on the spot)
+            const int k = f / hc;
+            float x = win[k * TWc + (f - k * hc)];
+            if (zm) x -= mean;
+            if (nrm) x = div_by_shared_or_divide(x, norm, rd);
+            o[f] = x;
+        }
+    }
+}
+
 // costValue, on_demand_cost_volume.h:409-468.  disp[0] = rows, disp[1] = columns (flow); disp[0] = columns (stereo).
 __device__ __forceinline__ bool od_cost(const OdVolume &o, int i, int j, int d0, int d1, float *cost) {
     int ti = i, tj = j;
@@ -1192,8 +1306,14 @@ int check_params(svh_context *ctx, const svh_on_demand_params *p, const svh_arra
 int dev_on_demand_features(svh_context *ctx, int func, const float *img, int H, int W, int C, int h_r, int v_r, float *out, float2 *stats = nullptr) {
     const int64_t npx = (int64_t)H * W;
     if (npx == 0) return SVH_OK;
-    SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_kernel, (int)((npx + ODF_PX - 1) / ODF_PX), 256, 0, img, H, W, C, h_r, v_r, func_zero_mean(func),
-               func_normalized(func), out, stats);
+    const size_t tile_bytes = (size_t)(2 * v_r + 1) * (ODF_PX + 2 * h_r) * C * sizeof(float);
+    if (tile_bytes <= 56 * 1024 && H <= 65535) { // the window rows of a block's pixels in LDS
+        SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_tiled_kernel, dim3(ceil_div(W, ODF_PX), H), 256, tile_bytes, img, H, W, C, h_r, v_r,
+                   func_zero_mean(func), func_normalized(func), out, stats);
+    } else {
+        SVH_LAUNCH(ctx, "on_demand_features", on_demand_features_kernel, (int)((npx + ODF_PX - 1) / ODF_PX), 256, 0, img, H, W, C, h_r, v_r,
+                   func_zero_mean(func), func_normalized(func), out, stats);
+    }
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }

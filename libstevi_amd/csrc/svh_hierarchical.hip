@@ -425,12 +425,29 @@ int dev_hierarchical(svh_context *ctx, Scratch &scr, int func, int ddir, int dep
     if (!guide) return SVH_ERR_OUT_OF_MEMORY;
     if (depth == 1) { // full search at the coarsest level, :253-260
         const int D0 = (disp_width + 1) / 2;
-        float *cv = scr.get_n<float>((size_t)Hd * Wsd * D0);
-        if (!cv) return SVH_ERR_OUT_OF_MEMORY;
         CostVolumeArgs a{func, ddir, Hd, Wsd, r2l ? Wld : Wrd, 0, D0};
         a.literal = ctx->literal_cost_volumes;
-        SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, r2l ? sr : sl, r2l ? sl : sr, h_radii[0], v_radii[0], cv));
-        SVH_TRY(dev_extract_index(ctx, func_strategy(func), cv, (int64_t)Hd * Wsd, D0, guide, nullptr, 0, 0));
+        const ImageDesc csrc = r2l ? sr : sl, ctgt = r2l ? sl : sr;
+        // the coarsest level wants the winner of every pixel and nothing else of its volume: where the column-sum kernel runs (grey
+        // images, float functions) it picks the winner while it holds the costs and the volume is never written (CostReduce mode 1)
+        bool winner_done = false;
+        if (ctx->cost_reduce_fused && C == 1 && cost_volume_colsum_applies(ctx, a, csrc, ctgt, h_radii[0], v_radii[0])) {
+            CostReduce red;
+            red.mode = 1;
+            red.score = func_strategy(func) != SVH_COST;
+            red.idx = guide;
+            red.store = false;
+            a.reduce = &red;
+            SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, csrc, ctgt, h_radii[0], v_radii[0], nullptr));
+            winner_done = red.done;
+            a.reduce = nullptr;
+        }
+        if (!winner_done) {
+            float *cv = scr.get_n<float>((size_t)Hd * Wsd * D0);
+            if (!cv) return SVH_ERR_OUT_OF_MEMORY;
+            SVH_TRY(dev_cost_volume_from_images(ctx, scr, a, csrc, ctgt, h_radii[0], v_radii[0], cv));
+            SVH_TRY(dev_extract_index(ctx, func_strategy(func), cv, (int64_t)Hd * Wsd, D0, guide, nullptr, 0, 0));
+        }
     } else { // :268-286: the radii of the coarser levels are the leading entries
         float *tprev = scr.get_n<float>((size_t)Hd * Wsd * (2 * radius + 1));
         if (!tprev) return SVH_ERR_OUT_OF_MEMORY;

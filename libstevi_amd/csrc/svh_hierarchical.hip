@@ -177,17 +177,32 @@ __global__ void __launch_bounds__(256) guided_shared_kernel(FeatImage src, FeatI
         return;
     }
     const int span = (int)span64;
-    // raw rows: a sample outside its image is 0 (before it is processed)
-    for (int k = 0; k < v; k++) {
-        const int ii = i - src.v_r + k;
-        const bool row_in = ii >= 0 && ii < H;
-        for (int x = threadIdx.x; x < SW; x += 256) {
-            const int jj = j0 - HR + x;
-            stile[k * SW + x] = (row_in && jj >= 0 && jj < Ws) ? src.img[(int64_t)ii * Ws + jj] : 0.0f;
+    // raw rows: a sample outside its image is 0 (before it is processed).  Eight window rows' loads are issued before the first is stored (a
+    // row-by-row loop waits for memory once per row, and on the small grids this form is kept for a block is as long as its waits); a load
+    // outside the image reads a clamped address and is replaced by 0
+    for (int k0 = 0; k0 < v; k0 += 8) {
+        float got_s[8][2], got_t[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int ii = i - src.v_r + k0 + r;
+            const bool row_in = k0 + r < v && ii >= 0 && ii < H; // (block uniform)
+            const int64_t ic = min(max(ii, 0), H - 1);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int x = threadIdx.x + 256 * u, jj = j0 - HR + x, jc = lo - HR + x;
+                const float gs = src.img[ic * Ws + min(max(jj, 0), Ws - 1)], gt = tgt.img[ic * Wt + min(max(jc, 0), Wt - 1)];
+                got_s[r][u] = (row_in && jj >= 0 && jj < Ws) ? gs : 0.0f;
+                got_t[r][u] = (row_in && jc >= 0 && jc < Wt) ? gt : 0.0f;
+            }
         }
-        for (int x = threadIdx.x; x < span + h - 1; x += 256) {
-            const int jc = lo - HR + x;
-            ttile[k * TW + x] = (row_in && jc >= 0 && jc < Wt) ? tgt.img[(int64_t)ii * Wt + jc] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int x = threadIdx.x + 256 * u;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if (k0 + r < v && x < SW) stile[(k0 + r) * SW + x] = got_s[r][u];
+                if (k0 + r < v && x < span + h - 1) ttile[(k0 + r) * TW + x] = got_t[r][u];
+            }
         }
     }
     // the centres this thread processes (span_max <= 512): a centre outside the image is the all-zero vector (hierarchical.h:175-178)

@@ -249,9 +249,11 @@ __global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a,
         const int jj = j0 - a.h_r + e;
         float A = 0.0f, Z = 0.0f;
         if (jj >= 0 && jj < a.W) {
-            for (int k = 0; k < v; k++) {
+#pragma unroll 4
+            for (int k = 0; k < v; k++) { // (clamped address, then 0 outside: four rows' loads in flight instead of a wait per row)
                 const int ii = i - a.v_r + k;
-                const float x = (ii >= 0 && ii < a.H) ? a.img[(int64_t)ii * a.W + jj] : 0.0f;
+                const float got = a.img[(int64_t)min(max(ii, 0), a.H - 1) * a.W + jj];
+                const float x = (ii >= 0 && ii < a.H) ? got : 0.0f;
                 A += x * x;
                 if (CMP == CMP_DOT) Z += x * 0.0f;
                 else if (CMP == CMP_SAD) Z += fabsf(x);

@@ -24,6 +24,10 @@ extern "C" {
  * the cost of the pixel against its predecessor's solution; the sweep uses it wherever the predecessor kept that solution (most pixels
  * after the first iterations) and evaluates a cost on the spot only behind an accepted candidate.  0: every step of a sweep evaluates
  * its cost.  Same result.
+ * "patchmatch_scan_chunks" (default 1): from the second iteration on a propagation line decides the steps of 64 pixels at once: every pixel
+ * knows from the pre-pass, for each state it can receive (the travelling candidate was picked up 1 .. 4 steps back, or further), whether
+ * it keeps the candidate; those tables are composed by a prefix scan over the wave, and a cost is evaluated on the spot only where a
+ * candidate from further back meets a pixel with a different solution.  0: step by step.  Same result.
  * "feature_volume_tiled" (default 1): svh_feature_cost_volume(_2d) with a float matching function processes the two feature volumes once
  * (mean subtracted, divided by the norm: the values of the reference's normalised volumes) and compares 64 pixels of a row with their
  * target records from LDS; 0: the per-voxel kernel processes both vectors of every voxel.  Same bits.

@@ -450,6 +450,7 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         {"patchmatch_pred_costs", &svh_context::patchmatch_pred_costs},
         {"patchmatch_run_batches", &svh_context::patchmatch_run_batches},
         {"patchmatch_lookback", &svh_context::patchmatch_lookback},
+        {"patchmatch_scan_chunks", &svh_context::patchmatch_scan_chunks},
         {"feature_volume_tiled", &svh_context::feature_volume_tiled},
         {"sgm_score_pad", &svh_context::sgm_score_pad},
         {"fold_2d_offsets", &svh_context::fold_2d_offsets},

@@ -63,6 +63,7 @@ struct svh_context {
     int patchmatch_search_form = 1; // svh_test_set_option("patchmatch_search_form"): PatchMatch's random search: 1 the chunked kernel (64 candidates per wave, 32 features at a time through a 9 KB LDS table), 0 round 4's batched kernel, 2 / 3 a lane per candidate without LDS (fetching the target features / forming them again from the target image)
     bool patchmatch_run_batches = true; // svh_test_set_option("patchmatch_run_batches"): a PatchMatch sweep step that evaluates a cost on the spot evaluates the next eight pixels of its line against the same travelling candidate with it (0: one evaluation per step)
     bool patchmatch_lookback = true; // svh_test_set_option("patchmatch_lookback"): after the first iteration PatchMatch's pre-pass also evaluates every pixel against the pre-sweep solutions two to four steps back, so that a travelling candidate needs no evaluation on the spot before its fourth accepted step (0: one step back only)
+    bool patchmatch_scan_chunks = true; // svh_test_set_option("patchmatch_scan_chunks"): from the second iteration on a sweep line decides 64 steps at a time by a prefix scan over per-pixel transition tables (0: step by step)
     bool literal_cost_volumes = false; // svh_context_set_option("literal_cost_volumes"): hierarchical matching uses the per-voxel kernel
     bool cost_reduce_fused = true;     // svh_test_set_option("cost_reduce_fused"): svh_stereo_match lets the float cost kernel reduce over the disparity axis while it holds the costs -- the winner of a call without SGM (no volume written), the regional minima of a Cost-branch SGM (no probing read) -- 0: separate kernels read the volume back
     bool sgm_cost_two_minima = true;   // svh_test_set_option("sgm_cost_two_minima"): the Cost branch on a float volume runs its line recurrences on the two regional minima of every pixel (one read of the volume) instead of sweeping the volume once per pass

@@ -590,6 +590,7 @@ __device__ __forceinline__ float pm_lane_f(float v, int k) { return __builtin_bi
 // in the later ones they made rows 1.7 -> 3.2 ms).  (A first form waited for three accepted steps and then evaluated 64 pixels through
 // pm_costs64 -- five dependent round trips: runs that ended early made it 2.4 x SLOWER.)  Same costs, same tests, same order.
 constexpr int PM_RUN = 8;
+constexpr int PM_SCAN_EVALS = 12; // evaluations a scanned chunk makes before the step-by-step walk takes the rest of it
 // costs of pixels t .. t + n - 1 of a line (n <= PM_RUN) against the candidate (p0, p1): lane e < n returns the cost of pixel t + e, bit e of
 // *has_mask says whether it has a value (wave_cost's rules).  rows: n rows of `pitch` floats in LDS.
 __device__ __forceinline__ float pm_run_costs(const OdVolume &o, int64_t first, int64_t step, int i0, int j0, int di, int dj, int t, int n, int p0, int p1,
@@ -659,7 +660,7 @@ __device__ __forceinline__ float pm_run_costs(const OdVolume &o, int64_t first, 
 
 __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
                                              int64_t first, int64_t step, int i0, int j0, int di, int dj, int t_end, float *buf, int run_pitch, int depths,
-                                             int64_t npx) {
+                                             int64_t npx, bool scan) {
     const int lane = threadIdx.x;
     int n = 0;
     int age = 1;           // the running candidate is the pre-sweep solution of the pixel `age` steps back (1: fresh)
@@ -687,11 +688,16 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
         }
         w_set = false;
     };
+    int prev_s0 = p0, prev_s1 = p1; // the pre-sweep solutions of the chunk before (lane 63: the pixel just before this chunk)
     for (int t = 1; t < t_end; t++) {
         const int k = (t - 1) & 63;
         if (k == 0) { // the next 64 pixels of the line, one per lane (their entries are only written at their own steps, which come later)
             flush();
             w_t0 = t;
+            if (t > 1) {
+                prev_s0 = r_s0;
+                prev_s1 = r_s1;
+            }
             const int tt = t + lane;
             const bool in = tt < t_end;
             const int64_t p = first + (int64_t)(in ? tt : t) * step;
@@ -721,6 +727,123 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
                     continue;
                 }
             }
+        }
+        if (k == 0 && scan && run_pitch == 0) {
+            // SCANNED CHUNK (round 5).  What a step decides is a function of the state it receives -- how many steps back the travelling
+            // candidate was picked up: 1 .. depths (the pre-pass evaluated those), or further (`B`) -- and of numbers the chunk load already
+            // holds: for each received state a lane knows whether its pixel keeps the candidate (-> state + 1) or not (-> 1, its own
+            // solution travels on).  Those per-lane tables compose associatively, so a prefix scan over the 64 lanes gives every pixel
+            // the state it receives in six shuffles instead of 64 dependent steps (0.27 us each on a wave that has its SIMD to itself; the
+            // slowest line of a sweep -- an image border whose pixels never agree -- walked all of its 1 918 steps: 0.52 of its 0.72 ms).
+            // A candidate further back than the pre-pass looked is known to be kept when it equals the pixel's own solution; the table
+            // assumes that, the scan's result is checked, and the first lane where it does not hold gets its cost evaluated on the spot
+            // (wave_cost, as the step-by-step walk would) and a constant table; the lanes before it are final, the scan is repeated.
+            const int D = depths, B = depths + 1, chunk = min(64, t_end - t);
+            const bool in = lane < chunk;
+            auto keep_rule = [&](float cn, bool has) { // patchMatchTestCost, patchmatch.h:162-224
+                if (!has) return false;
+                const bool has_old = (r_flags & 2) != 0;
+                return o.score ? (has_old ? cn >= r_oc : true) : (has_old ? cn <= r_oc : false);
+            };
+            constexpr uint32_t IDENT = 076543210u; // entry a (three bits at 3 a): a
+            auto compose = [](uint32_t first_t, uint32_t then_t) { // (then o first)[a] = then[first[a]]
+                uint32_t r = 0;
+#pragma unroll
+                for (int a = 1; a <= PM_DEPTH + 1; a++) r |= ((then_t >> (3 * ((first_t >> (3 * a)) & 7u))) & 7u) << (3 * a);
+                return r;
+            };
+            uint32_t T = (uint32_t)(keep_rule(r_pc, (r_flags & 1) != 0) ? min(2, B) : 1) << 3;
+#pragma unroll
+            for (int a = 2; a <= PM_DEPTH; a++) {
+                if (a <= D) {
+                    int c0 = __shfl_up(r_s0, a), c1 = o.nd == 2 ? __shfl_up(r_s1, a) : 0;
+                    const int q0 = __shfl(prev_s0, (64 + lane - a) & 63), q1 = o.nd == 2 ? __shfl(prev_s1, (64 + lane - a) & 63) : 0;
+                    if (lane < a) {
+                        c0 = q0;
+                        c1 = q1;
+                    }
+                    const bool eq = c0 == r_s0 && (o.nd < 2 || c1 == r_s1);
+                    const bool ka = keep_rule(eq ? r_oc : r_pd[a - 2], eq ? (r_flags & 2) != 0 : ((r_flags >> a) & 1) != 0);
+                    T |= (uint32_t)(ka ? min(a + 1, B) : 1) << (3 * a);
+                }
+            }
+            T |= (uint32_t)(keep_rule(r_oc, (r_flags & 2) != 0) ? B : 1) << (3 * B);
+            if (!in) T = IDENT;
+            const int a0 = age <= D ? age : B;
+            bool fixed = false, kept_l = false, eqc = false;
+            float fix_cost = 0.0f;
+            int a_in = 1, cand0 = 0, cand1 = 0, evaluated = 0, stop_at = -1;
+            for (;;) {
+                uint32_t I = T;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t before = __shfl_up(I, off);
+                    if (lane >= off) I = compose(before, I);
+                }
+                uint32_t E = __shfl_up(I, 1);
+                if (lane == 0) E = IDENT;
+                a_in = (int)((E >> (3 * a0)) & 7u);
+                kept_l = in && ((T >> (3 * a_in)) & 7u) != 1u;
+                // the candidate a lane receives: the own solution of the last lane before it that did not keep its candidate, or what the chunk received
+                const unsigned long long resets = __ballot(in && !kept_l), below = resets & ((1ull << lane) - 1ull);
+                const int s_lane = below ? 63 - __clzll((long long)below) : 0;
+                const int g0 = __shfl(r_s0, s_lane), g1 = o.nd == 2 ? __shfl(r_s1, s_lane) : 0;
+                cand0 = below ? g0 : p0;
+                cand1 = below ? g1 : p1;
+                eqc = cand0 == r_s0 && (o.nd < 2 || cand1 == r_s1);
+                const unsigned long long need = __ballot(in && !fixed && a_in == B && !eqc);
+                if (need == 0) break;
+                const int f = __ffsll((long long)need) - 1; // (wave uniform) everything before lane f is final
+                float cn = 0.0f;
+                const bool has = wave_cost(o, i0 + (t + f) * di, j0 + (t + f) * dj, pm_lane_i(cand0, f), pm_lane_i(cand1, f), buf, &cn);
+                const bool kept_f = pm_lane_i(keep_rule(cn, has) ? 1 : 0, f) != 0;
+                if (lane == f) {
+                    fixed = true;
+                    fix_cost = cn;
+                    T = (kept_f ? (uint32_t)B : 1u) * 011111110u; // every entry: where this pixel sends the candidate
+                }
+                if (++evaluated > PM_SCAN_EVALS && f + 1 < chunk) {
+                    // a chunk that keeps evaluating (a candidate crossing a region that disagrees with it: every step an evaluation) is
+                    // cheaper step by step than a scan per evaluation: what is decided up to lane f is written, the walk takes over behind it
+                    if (lane == f) kept_l = kept_f;
+                    stop_at = f;
+                    break;
+                }
+            }
+            if (stop_at >= 0 && lane > stop_at) kept_l = false;
+            if (kept_l) {
+                float cn = r_oc; // (a candidate that equals the pixel's own solution: the pixel's own cost)
+                if (fixed) cn = fix_cost;
+                else if (a_in == 1) cn = r_pc;
+                else if (!eqc) {
+                    cn = r_pd[0];
+#pragma unroll
+                    for (int m = 3; m <= PM_DEPTH; m++) cn = a_in == m ? r_pd[m - 2] : cn;
+                }
+                const int64_t p = first + (int64_t)(t + lane) * step;
+                st.sol[p * o.nd] = cand0;
+                if (o.nd == 2) st.sol[p * o.nd + 1] = cand1;
+                st.cost[p] = cn;
+                st.valid[p] = 1;
+            }
+            n += __popcll(__ballot(kept_l));
+            // what the next pixel receives: from the chunk's last pixel (or from the lane the walk takes over behind)
+            const int last = stop_at >= 0 ? stop_at : chunk - 1;
+            const bool kept_last = pm_lane_i(kept_l ? 1 : 0, last) != 0;
+            if (kept_last) {
+                p0 = pm_lane_i(cand0, last);
+                p1 = pm_lane_i(cand1, last);
+                age = min(pm_lane_i(a_in, last) + 1, B);
+                fresh = false;
+            } else {
+                p0 = pm_lane_i(r_s0, last);
+                p1 = pm_lane_i(r_s1, last);
+                age = 1;
+                fresh = true;
+            }
+            b_n = 0;
+            t += last; // (the loop's increment takes the last)
+            continue;
         }
         const int i = i0 + t * di, j = j0 + t * dj;
         const int flags = pm_lane_i(r_flags, k);
@@ -785,23 +908,23 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
 }
 
 __global__ void __launch_bounds__(64) pm_rows_fast_kernel(OdVolume o, int inc, PmState st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
-                                                          int *__restrict__ changes, int run_pitch, int depths) {
+                                                          int *__restrict__ changes, int run_pitch, int depths, int scan) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
     const int i = blockIdx.x;
     const int jfirst = inc > 0 ? 0 : o.Ws - 1;
     // going right: pixels 1 .. Ws - 1; going left: Ws - 2 .. 1 (`j != final` stops before column 0)
     const int t_end = inc > 0 ? o.Ws : o.Ws - 1;
-    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)i * o.Ws + jfirst, inc, i, jfirst, 0, inc, t_end, pm_buf, run_pitch, depths, (int64_t)o.Hs * o.Ws);
+    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)i * o.Ws + jfirst, inc, i, jfirst, 0, inc, t_end, pm_buf, run_pitch, depths, (int64_t)o.Hs * o.Ws, scan != 0);
     if (n && threadIdx.x == 0) atomicAdd(changes, n);
 }
 
 __global__ void __launch_bounds__(64) pm_cols_fast_kernel(OdVolume o, int inc, PmState st, const float *__restrict__ pcost, const uint8_t *__restrict__ pvalid,
-                                                          int *__restrict__ changes, int run_pitch, int depths) {
+                                                          int *__restrict__ changes, int run_pitch, int depths, int scan) {
     extern __shared__ __attribute__((aligned(16))) float pm_buf[];
     const int j = blockIdx.x;
     const int ifirst = inc > 0 ? 0 : o.Hs - 1;
     const int t_end = inc > 0 ? o.Hs : o.Hs - 1;
-    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)ifirst * o.Ws + j, (int64_t)inc * o.Ws, ifirst, j, inc, 0, t_end, pm_buf, run_pitch, depths, (int64_t)o.Hs * o.Ws);
+    const int n = pm_sweep_line(o, st, pcost, pvalid, (int64_t)ifirst * o.Ws + j, (int64_t)inc * o.Ws, ifirst, j, inc, 0, t_end, pm_buf, run_pitch, depths, (int64_t)o.Hs * o.Ws, scan != 0);
     if (n && threadIdx.x == 0) atomicAdd(changes, n);
 }
 
@@ -1450,13 +1573,13 @@ int run_patch_match(svh_context *ctx, Scratch &scr, const OdInputs &in, const Od
                     SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 0, inc1, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work, m);
                     SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work, m);
                 }
-                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, sweep_shmem, o, inc1, st, pcost, pvalid, changes, rp, depths);
+                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, sweep_shmem, o, inc1, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks ? 1 : 0);
                 for (int m = 1; m <= depths; m++) {
                     if (m > 1) SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work + 1, 0, sizeof(int), ctx->stream));
                     SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 1, inc0, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work + 1, m);
                     SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work + 1, m);
                 }
-                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, sweep_shmem, o, inc0, st, pcost, pvalid, changes, rp, depths);
+                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, sweep_shmem, o, inc0, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks ? 1 : 0);
             } else {
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
                 SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);

@@ -182,6 +182,35 @@ def test_patch_match_run_batches_same_result(rng, func, nd):
             assert np.array_equal(host(outs[0][0]), host(other[0])) and outs[0][1] == other[1], (H, W, C, n_random)
 
 
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.SAD, MF.SSD])
+@pytest.mark.parametrize("nd", [1, 2])
+def test_patch_match_scanned_chunks_same_result(rng, func, nd):
+    """Option "patchmatch_scan_chunks" (default, round 5): from the second iteration on a sweep line decides the steps of 64 pixels at once --
+    per-pixel transition tables (which received state keeps the travelling candidate) composed by a prefix scan, on-the-spot evaluations
+    only where a candidate from further back than the pre-pass looked meets a different solution -- with and without the look-back depths;
+    0: step by step.  Same solutions, costs and iteration counts: lines longer and shorter than a chunk, a last chunk that is not full,
+    both sweep directions over the iterations, candidates that travel across whole lines (planted shift) and lines that never settle
+    (noise), borders the candidate's targets leave, grey and colour."""
+    for (H, W, C, r, n_iter, n_random, noise) in [(40, 300, 1, 2, 6, 2, 0.0), (150, 70, 3, 1, 6, 4, 0.0), (5, 700, 1, 1, 5, 0, 0.0), (260, 6, 1, 1, 5, 1, 0.0),
+                                                  (64, 129, 1, 2, 8, 3, 0.5), (33, 200, 1, 1, 9, 0, 1.0)]:
+        src, tgt = shifted_pair(rng, H, W, C, 0 if nd == 1 else 2, -3)
+        if noise:
+            tgt = (tgt + noise * rng.uniform(-1, 1, tgt.shape)).astype(np.float32)
+        off = sv.searchOffset2(-3, 3, -6, 6) if nd == 2 else sv.searchOffset1(-6, 6)
+        d_src, d_tgt = dev(src), dev(tgt)
+        outs = []
+        for scan, lookback in ((1, 1), (0, 1), (1, 0), (0, 0)):
+            sv.set_test_option(d_src, "patchmatch_scan_chunks", scan)
+            sv.set_test_option(d_src, "patchmatch_lookback", lookback)
+            try:
+                outs.append(sv.cachelessPatchMatch(func, d_src, d_tgt, r, off, n_iter, n_random, 5, return_iterations=True))
+            finally:
+                sv.set_test_option(d_src, "patchmatch_scan_chunks", 1)
+                sv.set_test_option(d_src, "patchmatch_lookback", 1)
+        for other in outs[1:]:
+            assert np.array_equal(host(outs[0][0]), host(other[0])) and outs[0][1] == other[1], (H, W, C, n_random, noise)
+
+
 @pytest.mark.parametrize("func, so_func", [(MF.ZNCC, so.ZNCC), (MF.NCC, so.NCC), (MF.SAD, so.SAD), (MF.ZSSD, so.ZSSD), (MF.CC, so.CC)])
 @pytest.mark.parametrize("nd", [1, 2])
 def test_patch_match_on_feature_volumes_bit_identical_to_oracle(rng, func, so_func, nd):

@@ -574,6 +574,56 @@ __global__ void __launch_bounds__(64) pm_pred_cost_kernel(OdVolume o, int axis, 
     }
 }
 
+// The same for all look-back depths in one pair of launches (round 5: eight launches of 10 - 22 us per sweep were 5.2 ms of the 1080p chain):
+// a thread per pixel settles, for m = 1 .. depths, the pixels whose m-th predecessor holds the pixel's own solution and lists the other
+// (pixel, m) pairs -- the depth in the three bits above the pixel index (fewer than 2^29 pixels: checked by the host) --, a wave per listed
+// pair evaluates its cost.  pcost / pvalid: [depth - 1][pixel].
+__global__ void __launch_bounds__(256) pm_pred_classify_depths_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost,
+                                                                      uint8_t *__restrict__ pvalid, int64_t npx, uint32_t *__restrict__ work,
+                                                                      int *__restrict__ n_work, int depths) {
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= o.Ws) return;
+    const int64_t p = (int64_t)i * o.Ws + j;
+    const int s0 = st.sol[p * o.nd], s1 = o.nd == 2 ? st.sol[p * o.nd + 1] : 0;
+    const float own_cost = st.cost[p];
+    const uint8_t own_valid = st.valid[p];
+    for (int m = 1; m <= depths; m++) {
+        float *pc = pcost + (int64_t)(m - 1) * npx;
+        uint8_t *pv = pvalid + (int64_t)(m - 1) * npx;
+        const int pi = axis ? i - m * inc : i, pj = axis ? j : j - m * inc;
+        if (pi < 0 || pi >= o.Hs || pj < 0 || pj >= o.Ws) { // (no such predecessor: never tested)
+            pc[p] = 0.0f;
+            pv[p] = 0;
+            continue;
+        }
+        const int64_t pp = (int64_t)pi * o.Ws + pj;
+        const int c0 = st.sol[pp * o.nd], c1 = o.nd == 2 ? st.sol[pp * o.nd + 1] : 0;
+        if (c0 == s0 && (o.nd < 2 || c1 == s1)) { // the pixel's own solution: its own cost (the same evaluation)
+            pc[p] = own_cost;
+            pv[p] = own_valid;
+        } else {
+            work[atomicAdd(n_work, 1)] = (uint32_t)p | (uint32_t)(m - 1) << 29;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) pm_pred_cost_depths_kernel(OdVolume o, int axis, int inc, PmState st, float *__restrict__ pcost, uint8_t *__restrict__ pvalid,
+                                                                 int64_t npx, const uint32_t *__restrict__ work, const int *__restrict__ n_work) {
+    extern __shared__ __attribute__((aligned(16))) float pm_buf[];
+    const int n = *n_work;
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int p = (int)(work[w] & 0x1fffffffu), m = (int)(work[w] >> 29) + 1;
+        const int j = p % o.Ws, i = p / o.Ws;
+        const int64_t pp = (int64_t)(axis ? i - m * inc : i) * o.Ws + (axis ? j : j - m * inc);
+        float c = 0.0f;
+        const bool ok = wave_cost(o, i, j, st.sol[pp * o.nd], o.nd == 2 ? st.sol[pp * o.nd + 1] : 0, pm_buf, &c);
+        if (threadIdx.x == 0) {
+            pcost[(int64_t)(m - 1) * npx + p] = c;
+            pvalid[(int64_t)(m - 1) * npx + p] = ok ? 1 : 0;
+        }
+    }
+}
+
 __device__ __forceinline__ int pm_lane_i(int v, int k) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(k)); }
 __device__ __forceinline__ float pm_lane_f(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(k))); }
 
@@ -1547,7 +1597,7 @@ int run_patch_match(svh_context *ctx, Scratch &scr, const OdInputs &in, const Od
         if (ctx->patchmatch_pred_costs && npx < (1ll << 31) && in.H <= 65535) {
             pcost = scr.get_n<float>((size_t)npx * PM_DEPTH);   // [depth][pixel]: the cost against the pre-sweep solution `depth + 1` steps back
             pvalid = scr.get_n<uint8_t>((size_t)npx * PM_DEPTH);
-            work = scr.get_n<int32_t>((size_t)npx);
+            work = scr.get_n<int32_t>((size_t)npx * PM_DEPTH); // (pixel, depth) pairs the pre-pass evaluates
             n_work = scr.get_n<int>(2);
             if (!pcost || !pvalid || !work || !n_work) return SVH_ERR_OUT_OF_MEMORY;
         }
@@ -1568,17 +1618,23 @@ int run_patch_match(svh_context *ctx, Scratch &scr, const OdInputs &in, const Od
                 // are the ones that never settle, in short runs (look-back depths)
                 const int depths = (it == 0 || !ctx->patchmatch_lookback) ? 1 : PM_DEPTH;
                 const int rp = run_batches && it == 0 ? run_pitch : 0;
-                for (int m = 1; m <= depths; m++) {
-                    if (m > 1) SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work, 0, sizeof(int), ctx->stream));
-                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 0, inc1, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work, m);
-                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 0, inc1, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work, m);
-                }
+                // the pre-pass of a sweep: one pair of launches for all depths (fewer than 2^29 pixels), or a pair per depth
+                auto pre_pass = [&](int axis, int inc, int *counter) -> int {
+                    if (depths > 1 && npx < (1ll << 29)) {
+                        SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_depths_kernel, cgrid, 256, 0, o, axis, inc, st, pcost, pvalid, npx, (uint32_t *)work, counter, depths);
+                        SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_depths_kernel, px_grid, 64, shmem, o, axis, inc, st, pcost, pvalid, npx, (const uint32_t *)work, counter);
+                        return SVH_OK;
+                    }
+                    for (int m = 1; m <= depths; m++) {
+                        if (m > 1) SVH_HIP_CHECK(ctx, hipMemsetAsync(counter, 0, sizeof(int), ctx->stream));
+                        SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, axis, inc, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, counter, m);
+                        SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, axis, inc, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, counter, m);
+                    }
+                    return SVH_OK;
+                };
+                SVH_TRY(pre_pass(0, inc1, n_work));
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, sweep_shmem, o, inc1, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks ? 1 : 0);
-                for (int m = 1; m <= depths; m++) {
-                    if (m > 1) SVH_HIP_CHECK(ctx, hipMemsetAsync(n_work + 1, 0, sizeof(int), ctx->stream));
-                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_classify_kernel, cgrid, 256, 0, o, 1, inc0, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work + 1, m);
-                    SVH_LAUNCH(ctx, "patchmatch_pred_cost", pm_pred_cost_kernel, px_grid, 64, shmem, o, 1, inc0, st, pcost + (size_t)(m - 1) * npx, pvalid + (size_t)(m - 1) * npx, work, n_work + 1, m);
-                }
+                SVH_TRY(pre_pass(1, inc0, n_work + 1));
                 SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, sweep_shmem, o, inc0, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks ? 1 : 0);
             } else {
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);

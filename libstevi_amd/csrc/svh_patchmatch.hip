@@ -805,6 +805,7 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
         w_set = false;
     };
     int prev_s0 = p0, prev_s1 = p1; // the pre-sweep solutions of the chunk before (lane 63: the pixel just before this chunk)
+    bool batches_on = !scan; // run batches: the whole first iteration; with scanned chunks only where the walk takes over a chunk that keeps evaluating
     for (int t = 1; t < t_end; t++) {
         const int k = (t - 1) & 63;
         if (k == 0) { // the next 64 pixels of the line, one per lane (their entries are only written at their own steps, which come later)
@@ -814,6 +815,7 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
                 prev_s0 = r_s0;
                 prev_s1 = r_s1;
             }
+            if (scan) batches_on = false;
             const int tt = t + lane;
             const bool in = tt < t_end;
             const int64_t p = first + (int64_t)(in ? tt : t) * step;
@@ -844,7 +846,7 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
                 }
             }
         }
-        if (k == 0 && scan && run_pitch == 0) {
+        if (k == 0 && scan) {
             // SCANNED CHUNK (round 5).  What a step decides is a function of the state it receives -- how many steps back the travelling
             // candidate was picked up: 1 .. depths (the pre-pass evaluated those), or further (`B`) -- and of numbers the chunk load already
             // holds: for each received state a lane knows whether its pixel keeps the candidate (-> state + 1) or not (-> 1, its own
@@ -923,6 +925,7 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
                     // cheaper step by step than a scan per evaluation: what is decided up to lane f is written, the walk takes over behind it
                     if (lane == f) kept_l = kept_f;
                     stop_at = f;
+                    batches_on = true; // (such a chunk evaluates in runs: the next pixels against the same candidate with it)
                     break;
                 }
             }
@@ -979,7 +982,7 @@ __device__ __forceinline__ int pm_sweep_line(const OdVolume &o, const PmState &s
             for (int m = 3; m <= PM_DEPTH; m++) v = age == m ? r_pd[m - 2] : v;
             c_new = pm_lane_f(v, k);
             has_new = ((flags >> age) & 1) != 0;
-        } else if (run_pitch > 0) {
+        } else if (run_pitch > 0 && batches_on) {
             if (t < b_t0 || t >= b_t0 + b_n) { // this pixel and the next ones of the line against the travelling candidate
                 b_t0 = t;
                 b_n = min(PM_RUN, t_end - t);
@@ -1688,7 +1691,7 @@ int run_patch_match(svh_context *ctx, Scratch &scr, const OdInputs &in, const Od
                 // iteration 0 starts from random solutions: what travels there travels far (batches); afterwards the lines that still evaluate
                 // are the ones that never settle, in short runs (look-back depths)
                 const int depths = (it == 0 || !ctx->patchmatch_lookback) ? 1 : PM_DEPTH;
-                const int rp = run_batches && it == 0 ? run_pitch : 0;
+                const int rp = run_batches && (it == 0 || ctx->patchmatch_scan_chunks) ? run_pitch : 0;
                 // the pre-pass of a sweep: one pair of launches for all depths (fewer than 2^29 pixels), or a pair per depth
                 auto pre_pass = [&](int axis, int inc, int *counter) -> int {
                     if (npx < (1ll << 29)) {
@@ -1705,9 +1708,9 @@ int run_patch_match(svh_context *ctx, Scratch &scr, const OdInputs &in, const Od
                     return SVH_OK;
                 };
                 SVH_TRY(pre_pass(0, inc1, n_work));
-                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, sweep_shmem, o, inc1, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks ? 1 : 0);
+                SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_fast_kernel, in.H, 64, sweep_shmem, o, inc1, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks && it > 0 ? 1 : 0);
                 SVH_TRY(pre_pass(1, inc0, n_work + 1));
-                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, sweep_shmem, o, inc0, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks ? 1 : 0);
+                SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_fast_kernel, in.Ws, 64, sweep_shmem, o, inc0, st, pcost, pvalid, changes, rp, depths, ctx->patchmatch_scan_chunks && it > 0 ? 1 : 0);
             } else {
                 SVH_LAUNCH(ctx, "patchmatch_rows", pm_rows_kernel, in.H, 64, shmem, o, inc1, st, changes);
                 SVH_LAUNCH(ctx, "patchmatch_cols", pm_cols_kernel, in.Ws, 64, shmem, o, inc0, st, changes);

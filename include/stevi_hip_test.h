@@ -31,6 +31,10 @@ extern "C" {
  * "feature_volume_tiled" (default 1): svh_feature_cost_volume(_2d) with a float matching function processes the two feature volumes once
  * (mean subtracted, divided by the norm: the values of the reference's normalised volumes) and compares 64 pixels of a row with their
  * target records from LDS; 0: the per-voxel kernel processes both vectors of every voxel.  Same bits.
+ * "feature_volume_records" (default 1): behind "feature_volume_tiled", feature vectors of up to 32 floats (the 17 superpixel means of the
+ * reference's compressors, 3x3 / 5x5 unfolds) are compared with the TARGET record in registers -- a lane owns a record and walks the source
+ * pixels that look at it, two at a time with packed multiplies and adds; 0: every target feature of every voxel is read from LDS (round 4).
+ * Same bits.
  * "guided_shared" (default 1): svh_compute_guided_cv / svh_hierarchical_truncated_cost_volume on grey images with a search radius of at most
  * 3 stage the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of the target windows a group
  * of pixels looks at in LDS once, instead of every pixel processing every sample of every offset again.  1: a wave per 64 pixels, which

@@ -452,6 +452,7 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         {"patchmatch_lookback", &svh_context::patchmatch_lookback},
         {"patchmatch_scan_chunks", &svh_context::patchmatch_scan_chunks},
         {"feature_volume_tiled", &svh_context::feature_volume_tiled},
+        {"feature_volume_records", &svh_context::feature_volume_records},
         {"sgm_score_pad", &svh_context::sgm_score_pad},
         {"fold_2d_offsets", &svh_context::fold_2d_offsets},
         {"cost_reduce_fused", &svh_context::cost_reduce_fused},

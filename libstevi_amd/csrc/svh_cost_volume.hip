@@ -255,6 +255,36 @@ __global__ void __launch_bounds__(256) process_features_kernel(const float *__re
     }
 }
 
+// the HV_TP + D - 1 target records a block looks at (record y: target column j0 + disp_lower + y, or j0 + HV_TP - 1 - disp_lower - y when the
+// disparities run leftwards) into LDS with stride FS, zero vectors outside the image.  Eight loads in flight per thread and no division in
+// the loop (e = y F + c is advanced by 256 at a time): one load, one wait, one store per element with an integer division in between made
+// this copy -- 25 elements per thread at 1080p x 320 x 17 -- as long as the comparisons behind it.
+__device__ __forceinline__ void stage_target_records(float *flds, const float *__restrict__ trow, bool row_in, int n_rec, int F, int FS, int sign, int jt0, int Wt) {
+    const int n = n_rec * F, dq = 256 / F, dr = 256 - dq * F;
+    int y = (int)threadIdx.x / F, c = (int)threadIdx.x - y * F;
+    for (int e0 = threadIdx.x; e0 < n; e0 += 8 * 256) {
+        float got[8];
+        int at[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int jt = jt0 + sign * y;
+            const bool ok = e0 + 256 * k < n && row_in && jt >= 0 && jt < Wt;
+            const float x = trow[(int64_t)min(max(jt, 0), Wt - 1) * F + c];
+            got[k] = ok ? x : 0.0f;
+            at[k] = e0 + 256 * k < n ? y * FS + c : -1;
+            y += dq;
+            c += dr;
+            if (c >= F) {
+                c -= F;
+                y++;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (at[k] >= 0) flds[at[k]] = got[k];
+    }
+}
+
 // FV_Q disparities per lane (d, d + 64, ...): a source feature is read once for all of them
 constexpr int FV_Q = 4;
 template <int CMP>
@@ -268,11 +298,7 @@ __global__ void __launch_bounds__(256) feature_volume_tiled_kernel(const float *
     const bool row_in = it >= 0 && it < H; // a target outside the image is the zero vector (cross_correlations.h:235)
     const float *trow = pt + (int64_t)(row_in ? it : 0) * Wt * F;
     float *lsrc = flds + n_rec * FS;
-    for (int e = threadIdx.x; e < n_rec * F; e += blockDim.x) {
-        const int y = e / F, c = e - y * F;
-        const int jt = sign > 0 ? j0 + disp_lower + y : j0 + (HV_TP - 1) - disp_lower - y;
-        flds[y * FS + c] = (row_in && jt >= 0 && jt < Wt) ? trow[(int64_t)jt * F + c] : 0.0f;
-    }
+    stage_target_records(flds, trow, row_in, n_rec, F, FS, sign > 0 ? 1 : -1, sign > 0 ? j0 + disp_lower : j0 + (HV_TP - 1) - disp_lower, Wt);
     const int n_src = min(HV_TP, Ws - j0) * F;
     for (int e = threadIdx.x; e < n_src; e += blockDim.x) lsrc[e] = ps[((int64_t)i * Ws + j0) * F + e];
     __syncthreads();
@@ -312,6 +338,82 @@ __global__ void __launch_bounds__(256) feature_volume_tiled_kernel(const float *
     }
 }
 
+// Round 5: short feature vectors (up to FMAX features: the 17 superpixel means of the reference's GrPix17 compressors, 3x3 / 5x5 unfolds)
+// with the TARGET record in registers.  The kernel above reads every target feature of every voxel from LDS -- 4 bytes per multiply-add:
+// 45 GB at 1080p x 320 x 17, 0.57 ms of LDS bandwidth under 0.57 ms of vector issue, 1.8 ms measured.  Here a lane owns a target record
+// (its F features in registers) and walks the source pixels of the tile that look at it -- d = record - pixel --, two at a time: a source
+// feature is one broadcast LDS read for 64 voxels, and the multiply and the add of two voxels are one packed instruction each.  Same
+// products added in the same order (c = 0, 1, 2, ...): same bits.
+static inline int func_cmp(int func) { // the comparison of a float matching function
+    switch (func) {
+    case SVH_CC: case SVH_NCC: case SVH_ZCC: case SVH_ZNCC: return CMP_DOT;
+    case SVH_SSD: case SVH_ZSSD: return CMP_SSD;
+    case SVH_SAD: case SVH_ZSAD: return CMP_SAD;
+    default: return -1;
+    }
+}
+typedef float fv_f32x2 __attribute__((ext_vector_type(2)));
+template <int CMP, int FMAX>
+__global__ void __launch_bounds__(256) feature_volume_records_kernel(const float *__restrict__ ps, const float *__restrict__ pt, int H, int Ws, int Wt, int F,
+                                                                     int D, int sign, int disp_lower, int row_off, int64_t px_stride, int64_t out_off,
+                                                                     float *__restrict__ cv) {
+    extern __shared__ __attribute__((aligned(16))) float flds[];
+    const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
+    const int n_rec = HV_TP + D - 1, FS = F | 1; // record stride (odd: a wave's 64 records fall into different banks)
+    const int it = i + row_off;
+    const bool row_in = it >= 0 && it < H; // a target outside the image is the zero vector (cross_correlations.h:235)
+    const float *trow = pt + (int64_t)(row_in ? it : 0) * Wt * F;
+    float *lsrc = flds + ((n_rec * FS + 3) & ~3); // source features, feature-major: feature c of the tile's pixel u at lsrc[c * HV_TP + u] (16-byte rows)
+    stage_target_records(flds, trow, row_in, n_rec, F, FS, sign > 0 ? 1 : -1, sign > 0 ? j0 + disp_lower : j0 + (HV_TP - 1) - disp_lower, Wt);
+    const int n_px = min(HV_TP, Ws - j0);
+    for (int e = threadIdx.x; e < HV_TP * F; e += blockDim.x) {
+        const int u = e / F, c = e - u * F;
+        lsrc[c * HV_TP + u] = u < n_px ? ps[((int64_t)i * Ws + j0) * F + e] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int y0 = 0; y0 < n_rec; y0 += 64) { // (block uniform) 64 target records at a time, one per lane
+        const int y = y0 + lane;
+        float t[FMAX];
+#pragma unroll
+        for (int c = 0; c < FMAX; c++) t[c] = (c < F && y < n_rec) ? flds[min(y, n_rec - 1) * FS + c] : 0.0f;
+        // the source pixels whose ranges touch these records -- pixel u's disparity 0 is record b(u) = u (sign > 0) or HV_TP - 1 - u --, four
+        // at a time: this wave takes the groups wave, wave + 4, ...
+        for (int u = 4 * wave; u < n_px; u += 16) {
+            const int b_lo = sign > 0 ? u : HV_TP - 4 - u; // the smallest b of the group's four pixels
+            if (y0 + 63 < b_lo || y0 >= b_lo + 3 + D) continue; // (wave uniform) none of the four windows touches the chunk
+            const float4 *s4 = reinterpret_cast<const float4 *>(lsrc + u);
+            fv_f32x2 acc01{0.0f, 0.0f}, acc23{0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < FMAX; c++) {
+                if (c < F) { // (uniform)
+                    const float4 sv = s4[c * (HV_TP / 4)];
+                    const fv_f32x2 s01{sv.x, sv.y}, s23{sv.z, sv.w}, tv{t[c], t[c]};
+                    if (CMP == CMP_DOT) {
+                        acc01 += s01 * tv;
+                        acc23 += s23 * tv;
+                    } else if (CMP == CMP_SSD) {
+                        const fv_f32x2 d01 = s01 - tv, d23 = s23 - tv;
+                        acc01 += d01 * d01;
+                        acc23 += d23 * d23;
+                    } else {
+                        const fv_f32x2 d01 = s01 - tv, d23 = s23 - tv;
+                        acc01 += fv_f32x2{fabsf(d01.x), fabsf(d01.y)};
+                        acc23 += fv_f32x2{fabsf(d23.x), fabsf(d23.y)};
+                    }
+                }
+            }
+            const float res[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+            float *o = cv + ((int64_t)i * Ws + j0 + u) * px_stride + out_off;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int d = y - (sign > 0 ? u + k : HV_TP - 1 - u - k);
+                if (u + k < n_px && d >= 0 && d < D) o[k * px_stride + d] = res[k];
+            }
+        }
+    }
+}
+
 // SVH_ERR_UNSUPPORTED (nothing launched): the records do not fit the LDS budget
 static int cost_volume_features_tiled(svh_context *ctx, Scratch &scr, const CostVolumeArgs &a, const float *feat_src, const float *feat_tgt, int F, float *cv) {
     if (!ctx->feature_volume_tiled || a.H > 65535 || F < 1) return SVH_ERR_UNSUPPORTED;
@@ -347,6 +449,23 @@ static int cost_volume_features_tiled(svh_context *ctx, Scratch &scr, const Cost
     for (int d0 = 0; d0 < a.D; d0 += chunk) {
         const int Dc = std::min(chunk, a.D - d0), lower = a.disp_lower + d0;
         const int64_t off = a.out_off + d0;
+        if (F <= 32 && ctx->feature_volume_records) { // the target record in registers
+            const int fmax = F <= 20 ? 20 : 32;
+            const size_t rshmem = ((((size_t)(HV_TP + Dc - 1) * (F | 1) + 3) & ~(size_t)3) + (size_t)HV_TP * F) * sizeof(float);
+            const int cmp = func_cmp(a.func);
+            if (rshmem <= budget + 4096 && cmp >= 0) {
+#define SVH_FVR(CMPV)                                                                                                                                       \
+    do {                                                                                                                                                    \
+        if (fmax == 20) SVH_LAUNCH(ctx, "feature_volume_tiled", (feature_volume_records_kernel<CMPV, 20>), grid, 256, rshmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off, a.px_stride(), off, cv); \
+        else SVH_LAUNCH(ctx, "feature_volume_tiled", (feature_volume_records_kernel<CMPV, 32>), grid, 256, rshmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off, a.px_stride(), off, cv);    \
+    } while (0)
+                if (cmp == CMP_DOT) SVH_FVR(CMP_DOT);
+                else if (cmp == CMP_SSD) SVH_FVR(CMP_SSD);
+                else SVH_FVR(CMP_SAD);
+#undef SVH_FVR
+                continue;
+            }
+        }
         const size_t shmem = ((size_t)(HV_TP + Dc - 1) * (F | 1) + (size_t)HV_TP * F) * sizeof(float);
         switch (a.func) {
         case SVH_CC: case SVH_NCC: case SVH_ZCC: case SVH_ZNCC:

@@ -1063,6 +1063,8 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
     than the source, rows wider than a block, disparity ranges that leave the image, the reference's compressor chain (17 features)."""
     for (H, Ws, Wt, F, D, ddir) in [(9, 150, 150, 17, 40, sv.dispDirection.RightToLeft), (7, 130, 100, 16, 33, sv.dispDirection.LeftToRight),
                                      (5, 70, 90, 1, 70, sv.dispDirection.RightToLeft), (6, 200, 200, 25, 128, sv.dispDirection.LeftToRight),
+                                     (4, 333, 333, 20, 320, sv.dispDirection.RightToLeft), (3, 131, 140, 21, 65, sv.dispDirection.LeftToRight), (3, 65, 65, 32, 64, sv.dispDirection.RightToLeft),
+                                     (2, 129, 129, 33, 50, sv.dispDirection.RightToLeft),
                                      # long vectors (9x9, 11x11 unfolded and more): the range in chunks, fewer pixels per processing block
                                      (5, 100, 100, 81, 140, sv.dispDirection.RightToLeft), (4, 90, 80, 121, 70, sv.dispDirection.LeftToRight),
                                      (3, 70, 70, 200, 33, sv.dispDirection.RightToLeft)]:
@@ -1070,15 +1072,18 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
         fr = rng.uniform(-1, 1, (H, Ws if ddir == sv.dispDirection.RightToLeft else Wt, F)).astype(np.float32)
         dl, dr = dev(fl), dev(fr)
         outs = []
-        for tiled in (1, 0):
+        for tiled, records in ((1, 1), (0, 1), (1, 0)):  # (records: vectors of up to 32 floats with the target record in registers, round 5)
             sv.set_test_option(dl, "feature_volume_tiled", tiled)
+            sv.set_test_option(dl, "feature_volume_records", records)
             try:
                 outs.append(host(sv.featureVolume2CostVolume(func, dl, dr, D, ddir)))
             finally:
                 sv.set_test_option(dl, "feature_volume_tiled", 1)
-        assert np.array_equal(np.isnan(outs[0]), np.isnan(outs[1]))
-        ok = ~np.isnan(outs[0])
-        assert np.array_equal(outs[0][ok].view(np.uint32), outs[1][ok].view(np.uint32)), (H, Ws, Wt, F, D)
+                sv.set_test_option(dl, "feature_volume_records", 1)
+        for other in outs[1:]:
+            assert np.array_equal(np.isnan(outs[0]), np.isnan(other))
+            ok = ~np.isnan(outs[0])
+            assert np.array_equal(outs[0][ok].view(np.uint32), other[ok].view(np.uint32)), (H, Ws, Wt, F, D)
         assert_close(outs[0], so.feature_cost_volume(int(func), fl, fr, D, int(ddir)))
     img_l = rng.uniform(-1, 1, (20, 140)).astype(np.float32)
     img_r = rng.uniform(-1, 1, (20, 140)).astype(np.float32)

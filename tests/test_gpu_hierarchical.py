@@ -182,3 +182,31 @@ def test_guided_wave_divisions_by_shared_reciprocals_same_bits(scale):
             outs.append((host(res.disp_estimate), host(res.truncated_cost_volume)))
         assert np.array_equal(outs[0][0], outs[1][0])
         assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.ZSSD, MF.SAD])
+def test_guided_forms_same_bits_on_special_values(func):
+    """NaN, +-inf, zeros, denormal-range and near-overflow samples in both images, images narrower than a wave, one row: the three staged
+    forms of computeGuidedCV ("guided_shared" 3 / 2 / 1) return the bits of the per-pixel walk (0), NaN payloads included."""
+    for trial, (H, W, r, radius) in enumerate([(40, 500, 3, 2), (7, 65, 2, 3), (1, 200, 1, 1), (50, 64, 2, 2)]):
+        src, tgt, _ = parallax_pair(H, W, max(H // 3, 1), H // 4, W // 3, 5, 21, seed=trial)
+        src, tgt = src.copy(), tgt.copy()
+        if H > 5:
+            src[2, 10:30] = np.nan
+            tgt[H // 2, 40:60] = np.inf
+            src[H - 2, 5:9] = -np.inf
+            tgt[1:4, 30:50] = 0.0
+            src[0:3, 20:60] = 1e-38
+            tgt[3:6, 10:40] = 3e38
+        d_src, d_tgt = dev(src), dev(tgt)
+        outs = []
+        for form in (0, 3, 2, 1):
+            sv.set_test_option(d_src, "guided_shared", form)
+            try:
+                res = sv.hiearchicalTruncatedCostVolume(func, 2, d_tgt, d_src, r, r, 64, radius)
+            finally:
+                sv.set_test_option(d_src, "guided_shared", 1)
+            outs.append((host(res.disp_estimate), host(res.truncated_cost_volume).view(np.uint32)))
+        for o in outs[1:]:
+            assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]), (H, W, r, radius)
+

@@ -186,9 +186,9 @@ def test_guided_wave_divisions_by_shared_reciprocals_same_bits(scale):
 
 @pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.ZSSD, MF.SAD])
 def test_guided_forms_same_bits_on_special_values(func):
-    """NaN, +-inf, zeros, denormal-range and near-overflow samples in both images, images narrower than a wave, one row: the three staged
+    """NaN, +-inf, zeros, denormal-range and near-overflow samples in both images, images barely wider than a wave: the three staged
     forms of computeGuidedCV ("guided_shared" 3 / 2 / 1) return the bits of the per-pixel walk (0), NaN payloads included."""
-    for trial, (H, W, r, radius) in enumerate([(40, 500, 3, 2), (7, 65, 2, 3), (1, 200, 1, 1), (50, 64, 2, 2)]):
+    for trial, (H, W, r, radius, depth) in enumerate([(40, 500, 3, 2, 2), (16, 65, 2, 3, 1), (9, 200, 1, 1, 1), (50, 64, 2, 2, 2)]):
         src, tgt, _ = parallax_pair(H, W, max(H // 3, 1), H // 4, W // 3, 5, 21, seed=trial)
         src, tgt = src.copy(), tgt.copy()
         if H > 5:
@@ -203,7 +203,7 @@ def test_guided_forms_same_bits_on_special_values(func):
         for form in (0, 3, 2, 1):
             sv.set_test_option(d_src, "guided_shared", form)
             try:
-                res = sv.hiearchicalTruncatedCostVolume(func, 2, d_tgt, d_src, r, r, 64, radius)
+                res = sv.hiearchicalTruncatedCostVolume(func, depth, d_tgt, d_src, r, r, 64, radius)
             finally:
                 sv.set_test_option(d_src, "guided_shared", 1)
             outs.append((host(res.disp_estimate), host(res.truncated_cost_volume).view(np.uint32)))

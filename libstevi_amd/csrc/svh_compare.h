@@ -150,10 +150,18 @@ enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
 // target vector, which aggregateCost uses where the target column leaves the image (cross_correlations.h:235).
 constexpr int WS_TP = 256;
 
-template <int CMP>
+// WIN > 0: a grey image and a square window of that radius, known at compile time (the window loops unrolled: 5x5 and 7x7, the windows of the
+// reference's benchmark rows); 0: whatever the FeatImage says
+template <int CMP, int WIN>
 __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, bool zero_mean, bool normalized, float *__restrict__ mean,
                                                                    float *__restrict__ norm, float *__restrict__ zcost, int *__restrict__ odd_norm_flag) {
     extern __shared__ float ws_tile[];
+    if (WIN > 0) {
+        a.h_r = WIN;
+        a.v_r = WIN;
+        a.C = 1;
+    }
+    constexpr int UNROLL_ROWS = WIN > 0 ? 2 * WIN + 1 : 1, UNROLL_COLS = WIN > 0 ? 2 * WIN + 1 : 4;
     const int h = 2 * a.h_r + 1, v = 2 * a.v_r + 1, C = a.C, F = h * v * C;
     const int tw = (WS_TP + h - 1) * C; // floats per tile row
     const int i = blockIdx.y, j0 = blockIdx.x * WS_TP;
@@ -197,8 +205,9 @@ __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, 
     const float scale = (float)(1. / (double)(float)F);
     float m = 0.0f, n = 1.0f;
     if (zero_mean) {
+#pragma unroll UNROLL_ROWS
         for (int k = 0; k < v; k++) {
-#pragma unroll 4
+#pragma unroll UNROLL_COLS
             for (int q = 0; q < hc; q++) m += win[k * tw + q];
         }
         m *= scale;
@@ -206,8 +215,9 @@ __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, 
     }
     if (normalized) {
         float acc = 0.0f;
+#pragma unroll UNROLL_ROWS
         for (int k = 0; k < v; k++)
-#pragma unroll 4
+#pragma unroll UNROLL_COLS
             for (int q = 0; q < hc; q++) {
                 const float tmp = win[k * tw + q] - m; // m == 0 without zero-mean: x - 0 is exact
                 acc += tmp * tmp;
@@ -300,9 +310,17 @@ inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm,
     const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
     if (shmem <= 60 * 1024) {
         dim3 grid(ceil_div(a.W, WS_TP), a.H);
-        if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SSD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);
-        else if (cmp == CMP_SAD) SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_SAD>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);
-        else SVH_LAUNCH(ctx, "window_stats", window_stats_tiled_kernel<CMP_DOT>, grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);
+        const int win = (a.C == 1 && a.h_r == a.v_r && (a.h_r == 2 || a.h_r == 3)) ? a.h_r : 0; // compile-time windows: 5x5, 7x7 grey
+#define SVH_WS_TILED(CMPV)                                                                                                                          \
+    do {                                                                                                                                            \
+        if (win == 2) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 2>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);      \
+        else if (win == 3) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 3>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag); \
+        else SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 0>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);               \
+    } while (0)
+        if (cmp == CMP_SSD) SVH_WS_TILED(CMP_SSD);
+        else if (cmp == CMP_SAD) SVH_WS_TILED(CMP_SAD);
+        else SVH_WS_TILED(CMP_DOT);
+#undef SVH_WS_TILED
         SVH_CHECK_LAUNCH(ctx);
         return SVH_OK;
     }

@@ -35,6 +35,9 @@ extern "C" {
  * reference's compressors, 3x3 / 5x5 unfolds) are compared with the TARGET record in registers -- a lane owns a record and walks the source
  * pixels that look at it, two at a time with packed multiplies and adds; 0: every target feature of every voxel is read from LDS (round 4).
  * Same bits.
+ * "extract_index_wide" (default 1): svh_extract_selected_index (and every call that picks winners from a float volume) on rows of up to
+ * 1 024 costs the packed kernel does not take -- more than 256 costs, or a count that is no multiple of four (2-D volumes: 289, 297) --
+ * keeps up to sixteen costs per lane and combines by two all-reduces per pixel; 0: the wave-per-pixel kernel of round 1.  Same result.
  * "guided_shared" (default 1): svh_compute_guided_cv / svh_hierarchical_truncated_cost_volume on grey images with a search radius of at most
  * 3 stage the processed feature vectors (mean subtracted, divided by the norm: the reference's operations) of the target windows a group
  * of pixels looks at in LDS once, instead of every pixel processing every sample of every offset again.  1: a wave per 64 pixels, which

@@ -453,6 +453,7 @@ int svh_test_set_option(svh_context *ctx, const char *name, int value) {
         {"patchmatch_scan_chunks", &svh_context::patchmatch_scan_chunks},
         {"feature_volume_tiled", &svh_context::feature_volume_tiled},
         {"feature_volume_records", &svh_context::feature_volume_records},
+        {"extract_index_wide", &svh_context::extract_index_wide},
         {"sgm_score_pad", &svh_context::sgm_score_pad},
         {"fold_2d_offsets", &svh_context::fold_2d_offsets},
         {"cost_reduce_fused", &svh_context::cost_reduce_fused},

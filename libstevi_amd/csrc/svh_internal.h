@@ -59,6 +59,7 @@ struct svh_context {
     bool sgm_score_pad = true;         // svh_test_set_option("sgm_score_pad"): Score-branch SGM on 65 .. 511 disparities that are no multiple of 64 runs on copies padded to the next multiple (pads -inf: inert), so that the vector kernels apply (0: the masked forms)
     int guided_shared = 1;             // svh_test_set_option("guided_shared"): computeGuidedCV on grey images shares the processed target features (each sample subtracted / divided once) through LDS: 1 per wave of 64 pixels on large grids and per block of 256 on small ones, 2 per block always (round 4), 3 per wave always, 0 every pixel and offset on its own
     bool feature_volume_tiled = true;  // svh_test_set_option("feature_volume_tiled"): cost volumes of float feature volumes process the features once and compare from LDS (0: the per-voxel kernel processes both vectors of every voxel)
+    bool extract_index_wide = true;    // svh_test_set_option("extract_index_wide"): extractSelectedIndex on rows of up to 1 024 costs that the packed kernel does not take (more than 256 costs, or no multiple of four) combines by two all-reduces per pixel (0: six rounds of value / index exchanges)
     bool feature_volume_records = true; // svh_test_set_option("feature_volume_records"): feature vectors of up to 32 floats are compared with the target record in registers (a lane per record walks the source pixels that look at it); 0: every target feature of every voxel read from LDS (round 4)
     bool patchmatch_pred_costs = true; // svh_test_set_option("patchmatch_pred_costs"): PatchMatch sweeps take the cost of a pixel against its predecessor's unchanged solution from a parallel pre-pass (0: every step evaluates its cost)
     int patchmatch_search_form = 1; // svh_test_set_option("patchmatch_search_form"): PatchMatch's random search: 1 the chunked kernel (64 candidates per wave, 32 features at a time through a 9 KB LDS table), 0 round 4's batched kernel, 2 / 3 a lane per candidate without LDS (fetching the target features / forming them again from the target image)

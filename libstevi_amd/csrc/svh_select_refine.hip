@@ -161,6 +161,85 @@ __global__ void __launch_bounds__(256) extract_index_packed_kernel(const float *
     }
 }
 
+// Rows of any length up to 1 024 costs (2-D volumes flatten to 17 x 17 = 289, 9 x 33 = 297; the reference's 1080p benchmark rows search 320
+// disparities) with the packed kernel's combine: a wave per pixel, NQ pieces of four costs per lane (cost d of the pixel in lane (d % 256) / 4,
+// piece d / 256), the extremum by one all-reduce, the largest index among the costs EQUAL to it by a second.  The wave-per-pixel kernel above
+// spends six rounds of (value, index) exchanges per pixel and fetches what lies beyond the first 256 costs in a dependent second round:
+// 0.66 ms for 1080p x 320 (4.0 TB/s).  A piece that would reach past its row is read cost by cost.
+template <bool COST, int NQ>
+__global__ void __launch_bounds__(256) extract_index_wide_kernel(const float *__restrict__ cv, int64_t npx, int D, int32_t *__restrict__ idx,
+                                                                unsigned long long *__restrict__ keys, int key_offset, int key_total) {
+    constexpr int G = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const bool fold_first_nan = !keys || key_offset == 0; // (a later shard's key ignores the rule, its index map does not: reduced separately then)
+    constexpr int FIRST_NAN = 1 << 20;
+    for (int64_t p0 = wave * G; p0 < npx; p0 += nwaves * G) {
+        Costs4 v[G][NQ];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const float *row = cv + min(p0 + g, npx - 1) * D;
+#pragma unroll
+            for (int n = 0; n < NQ; n++) {
+                const int d = 4 * lane + 256 * n;
+                if (d + 3 < D) {
+                    v[g][n] = *reinterpret_cast<const Costs4 *>(row + d);
+                } else { // (the row's last piece, or past the row: never read beyond the row's end)
+                    v[g][n].x = d < D ? row[d] : 0.0f;
+                    v[g][n].y = d + 1 < D ? row[d + 1] : 0.0f;
+                    v[g][n].z = d + 2 < D ? row[d + 2] : 0.0f;
+                    v[g][n].w = 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (p0 + g >= npx) break; // (wave-uniform)
+            const int64_t p = p0 + g;
+            float A = COST ? INFINITY : -INFINITY;
+#pragma unroll
+            for (int n = 0; n < NQ; n++) {
+                const float s[4] = {v[g][n].x, v[g][n].y, v[g][n].z, v[g][n].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (4 * lane + 256 * n + k < D) A = COST ? fminf(A, s[k]) : fmaxf(A, s[k]); // (a NaN never enters)
+            }
+            const float M = pixel_allreduce_f32<64, COST>(A);
+            int key = 0; // 1 + the largest index among this lane's costs equal to the extremum
+#pragma unroll
+            for (int n = 0; n < NQ; n++) {
+                const float s[4] = {v[g][n].x, v[g][n].y, v[g][n].z, v[g][n].w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int d = 4 * lane + 256 * n + k;
+                    if (d < D && s[k] == M) key = d + 1;
+                }
+            }
+            const bool first_nan_here = lane == 0 && isnan(v[g][0].x);
+            if (fold_first_nan && first_nan_here) key = FIRST_NAN;
+            const int best = pixel_allreduce_max<64>(key);
+            int first_nan = best == FIRST_NAN;
+            if (!fold_first_nan) first_nan = pixel_allreduce_max<64>(first_nan_here ? 1 : 0); // (wave-uniform branch)
+            const bool writer = (best == 0 || best == FIRST_NAN) ? lane == 0 : key == best;
+            if (writer) {
+                const int bd = (best == 0 || best == FIRST_NAN) ? -1 : best - 1;
+                if (idx) idx[p] = (first_nan || bd < 0) ? 0 : bd;
+                if (keys) {
+                    unsigned long long kk;
+                    if (key_offset == 0 && first_nan) kk = COST ? (unsigned long long)(uint32_t)(key_total - 1) : (0xFFFFFFFFull << 32);
+                    else if (bd < 0) kk = COST ? ~0ull : 0ull;
+                    else {
+                        const uint32_t gd = (uint32_t)(key_offset + bd);
+                        kk = ((unsigned long long)order_key(M) << 32) | (COST ? (uint32_t)(key_total - 1) - gd : gd);
+                    }
+                    keys[p] = kk;
+                }
+            }
+        }
+    }
+}
+
 __global__ void keys_to_index_kernel(const unsigned long long *__restrict__ keys, int64_t n, int total, bool cost,
                                      int32_t *__restrict__ idx) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
@@ -418,6 +497,23 @@ int dev_extract_index(svh_context *ctx, int strategy, const float *cv, int64_t n
             else SVH_EXTRACT_P(false, 64);
         }
 #undef SVH_EXTRACT_P
+        SVH_CHECK_LAUNCH(ctx);
+        return SVH_OK;
+    }
+    if (D >= 1 && D <= 1024 && ctx->extract_index_wide) { // a wave per pixel, up to four pieces of four costs per lane
+        const int nq = D <= 256 ? 1 : D <= 512 ? 2 : 4;
+        const int gridw = grid_for(ceil_div(n_pixels, 4), 4, 256 * 8 * 4);
+#define SVH_EXTRACT_W(C, N) SVH_LAUNCH(ctx, "extract_index", (extract_index_wide_kernel<C, N>), gridw, 256, 0, cv, n_pixels, D, idx, keys, key_index_offset, key_total_D)
+        if (strategy == SVH_COST) {
+            if (nq == 1) SVH_EXTRACT_W(true, 1);
+            else if (nq == 2) SVH_EXTRACT_W(true, 2);
+            else SVH_EXTRACT_W(true, 4);
+        } else {
+            if (nq == 1) SVH_EXTRACT_W(false, 1);
+            else if (nq == 2) SVH_EXTRACT_W(false, 2);
+            else SVH_EXTRACT_W(false, 4);
+        }
+#undef SVH_EXTRACT_W
         SVH_CHECK_LAUNCH(ctx);
         return SVH_OK;
     }

@@ -13,7 +13,7 @@ import libstevi_amd as sv  # noqa: E402
 from libstevi_amd import _capi  # noqa: E402
 
 PUBLIC = {"census_float_overflow": (0, 1), "census_winner_shortcut": (0, 1), "census_sweep": (0, 1, 3), "sgm_score_fused": (0, 1, 2), "literal_cost_volumes": (0, 1)}
-TEST_ONLY = ["census_fast_path", "census_sweep_rl", "census_tiles", "cost_volume_colsum", "patchmatch_pred_costs", "patchmatch_run_batches", "patchmatch_lookback", "patchmatch_scan_chunks", "patchmatch_search_form", "feature_volume_tiled", "feature_volume_records", "guided_shared",
+TEST_ONLY = ["census_fast_path", "census_sweep_rl", "census_tiles", "cost_volume_colsum", "patchmatch_pred_costs", "patchmatch_run_batches", "patchmatch_lookback", "patchmatch_scan_chunks", "patchmatch_search_form", "feature_volume_tiled", "feature_volume_records", "extract_index_wide", "guided_shared",
              "sgm_score_pad", "fold_2d_offsets", "cost_reduce_fused", "sgm_cost_two_minima", "sgm_score_finish_fused"]
 DEFAULTS = {"census_float_overflow": 0, "census_winner_shortcut": 1, "census_sweep": 0, "sgm_score_fused": 1, "literal_cost_volumes": 0}
 

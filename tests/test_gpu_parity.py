@@ -267,9 +267,11 @@ def test_sgm_rejects_16_directions(rng):
 
 
 # ------------------------------------------------------------------------------------------------ A10-A12
-@pytest.mark.parametrize("D", [1, 2, 4, 8, 60, 63, 64, 65, 128, 132, 200, 256, 260, 513])
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 8, 60, 63, 64, 65, 128, 132, 200, 255, 256, 257, 260, 289, 297, 320, 511, 512, 513, 1000, 1023, 1024, 1025, 1500])
 def test_extract_index(rng, D):
-    """(rows of 4 ... 256 costs, a multiple of four, take the kernel that packs several pixels into a wave: extract_index_packed_kernel)"""
+    """(rows of 4 ... 256 costs, a multiple of four, take the kernel that packs several pixels into a wave: extract_index_packed_kernel; other
+    rows of up to 1 024 costs a wave per pixel with up to sixteen costs per lane: extract_index_wide_kernel, option "extract_index_wide"; the
+    rest -- and that option at 0 -- the wave-per-pixel kernel of round 1)"""
     cv = rng.integers(0, 6, (11, 14, D)).astype(np.float32)  # few levels -> many ties
     cv[0, 0, 0] = np.nan
     if D > 2:
@@ -290,6 +292,12 @@ def test_extract_index(rng, D):
         exp = so.extract_index(cv, strategy)
         assert_bits(sv.extractSelectedIndex(strategy, cv), exp)
         assert_bits(sv.extractSelectedIndex(strategy, dev(cv)), exp)
+        d_cv = dev(cv)
+        sv.set_test_option(d_cv, "extract_index_wide", 0)
+        try:
+            assert_bits(sv.extractSelectedIndex(strategy, d_cv), exp)
+        finally:
+            sv.set_test_option(d_cv, "extract_index_wide", 1)
     const = np.ones((3, 4, D), np.float32)
     assert np.all(host(sv.extractSelectedIndex(so.COST, const)) == D - 1)  # all ties -> largest index (F9)
 

@@ -119,13 +119,21 @@ __global__ void __launch_bounds__(256) unfold_compressed_tiled_kernel(const floa
     __syncthreads();
     const int F = C * nF, n = n_px * F;
     float *orow = out + ((int64_t)i * Wo + j0) * F;
+    // e = j F + fo is advanced by 256 at a time without a division per element (two of them were two thirds of this loop's instructions)
+    const int dq = 256 / F, dr = 256 - dq * F;
+    int j = (int)threadIdx.x / F, fo = (int)threadIdx.x - j * F;
     for (int e = threadIdx.x; e < n; e += 256) {
-        const int j = e / F, fo = e - j * F;
-        const int in_c = fo / nF, f = fo - in_c * nF;
+        const int in_c = C == 1 ? 0 : fo / nF, f = fo - in_c * nF;
         const float *at = tile + j * C + in_c;
         float acc = 0.0f;
         for (int k = fst[f]; k < fst[f + 1]; k++) acc += wgt[k] * at[off[k]];
         orow[e] = acc;
+        j += dq;
+        fo += dr;
+        if (fo >= F) {
+            fo -= F;
+            j++;
+        }
     }
 }
 

@@ -152,10 +152,19 @@ constexpr int WS_TP = 256;
 
 // WIN > 0: a grey image and a square window of that radius, known at compile time (the window loops unrolled: 5x5 and 7x7, the windows of the
 // reference's benchmark rows); 0: whatever the FeatImage says
+// grid slice z = 1: the second image of a pair (same window; its own size and outputs, no zcost) -- the two images of a matching call in one launch
 template <int CMP, int WIN>
 __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, bool zero_mean, bool normalized, float *__restrict__ mean,
-                                                                   float *__restrict__ norm, float *__restrict__ zcost, int *__restrict__ odd_norm_flag) {
+                                                                   float *__restrict__ norm, float *__restrict__ zcost, int *__restrict__ odd_norm_flag,
+                                                                   FeatImage b, float *__restrict__ mean_b, float *__restrict__ norm_b) {
     extern __shared__ float ws_tile[];
+    if (blockIdx.z == 1) {
+        a = b;
+        mean = mean_b;
+        norm = norm_b;
+        zcost = nullptr;
+    }
+    if ((int)blockIdx.y >= a.H || (int)blockIdx.x * WS_TP >= a.W) return; // (the grid covers the larger image of a pair)
     if (WIN > 0) {
         a.h_r = WIN;
         a.v_r = WIN;
@@ -297,8 +306,9 @@ __global__ void __launch_bounds__(WS_TP) window_stats_colsum_kernel(FeatImage a,
 
 // image statistics: the LDS-tiled kernel when the tile fits, the per-lane global walk otherwise; cmp only matters for zcost
 inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm, float *mean, float *norm, float *zcost, int cmp, bool colsum = false,
-                               int *odd_norm_flag = nullptr) {
+                               int *odd_norm_flag = nullptr, const FeatImage *second = nullptr, float *mean_b = nullptr, float *norm_b = nullptr) {
     if ((int64_t)a.H * a.W == 0 || (!zm && !nrm && !zcost)) return SVH_OK;
+    const FeatImage b = second ? *second : a;
     if (colsum && !zm && a.C == 1 && a.h_r <= 255 && !(nrm && cmp != CMP_DOT)) {
         dim3 grid(ceil_div(a.W, WS_TP), a.H);
         if (cmp == CMP_SSD) SVH_LAUNCH(ctx, "window_stats", window_stats_colsum_kernel<CMP_SSD>, grid, WS_TP, 0, a, nrm, norm, zcost, odd_norm_flag);
@@ -309,13 +319,13 @@ inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm,
     }
     const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
     if (shmem <= 60 * 1024) {
-        dim3 grid(ceil_div(a.W, WS_TP), a.H);
+        dim3 grid(ceil_div(second ? (a.W > b.W ? a.W : b.W) : a.W, WS_TP), second ? (a.H > b.H ? a.H : b.H) : a.H, second ? 2 : 1);
         const int win = (a.C == 1 && a.h_r == a.v_r && (a.h_r == 2 || a.h_r == 3)) ? a.h_r : 0; // compile-time windows: 5x5, 7x7 grey
 #define SVH_WS_TILED(CMPV)                                                                                                                          \
     do {                                                                                                                                            \
-        if (win == 2) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 2>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);      \
-        else if (win == 3) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 3>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag); \
-        else SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 0>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag);               \
+        if (win == 2) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 2>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b);      \
+        else if (win == 3) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 3>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b); \
+        else SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 0>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b);               \
     } while (0)
         if (cmp == CMP_SSD) SVH_WS_TILED(CMP_SSD);
         else if (cmp == CMP_SAD) SVH_WS_TILED(CMP_SAD);
@@ -332,6 +342,17 @@ inline int launch_stats(svh_context *ctx, FeatImage acc, int H, int W, bool zm, 
     (void)W;
     if (!zm && !nrm) return SVH_OK;
     return launch_window_stats(ctx, acc, zm, nrm, mean, norm, nullptr, CMP_DOT);
+}
+// means and norms of the two images of a matching call in ONE launch where both take the LDS-tiled kernel (same window, same channels:
+// the grid's third dimension is the image); two launches otherwise
+inline int launch_stats_pair(svh_context *ctx, FeatImage a, FeatImage b, bool zm, bool nrm, float *mean_a, float *norm_a, float *mean_b, float *norm_b) {
+    if (!zm && !nrm) return SVH_OK;
+    const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
+    const bool same = a.h_r == b.h_r && a.v_r == b.v_r && a.C == b.C && (int64_t)a.H * a.W > 0 && (int64_t)b.H * b.W > 0;
+    if (same && shmem <= 60 * 1024) return launch_window_stats(ctx, a, zm, nrm, mean_a, norm_a, nullptr, CMP_DOT, false, nullptr, &b, mean_b, norm_b);
+    const int st = launch_window_stats(ctx, a, zm, nrm, mean_a, norm_a, nullptr, CMP_DOT);
+    if (st != SVH_OK) return st;
+    return launch_window_stats(ctx, b, zm, nrm, mean_b, norm_b, nullptr, CMP_DOT);
 }
 
 // cmp(src(i,j,:), tgt(it,jt,:)) on the processed features (zero-mean / normalised per element, cross_correlations.h:416-594), with

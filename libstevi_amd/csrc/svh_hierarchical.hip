@@ -25,7 +25,15 @@ namespace {
 
 // averagePoolingDownsample as written (downsampling.h:78-114, :131-176): the row loop of the window runs over the
 // HORIZONTAL window size, the column offset is derived from the ROW remainder and vice versa; mean over the valid samples.
-__global__ void downsample_kernel(const float *__restrict__ img, int H, int W, int C, int win_h, int win_v, int Ho, int Wo, float *__restrict__ out) {
+// (grid slice y = 1: the second image of a pair, same window)
+__global__ void downsample_kernel(const float *__restrict__ img, int H, int W, int C, int win_h, int win_v, int Ho, int Wo, float *__restrict__ out,
+                                  const float *__restrict__ img_b, int W_b, int Wo_b, float *__restrict__ out_b) {
+    if (blockIdx.y == 1) {
+        img = img_b;
+        W = W_b;
+        Wo = Wo_b;
+        out = out_b;
+    }
     const int64_t n = (int64_t)Ho * Wo * C;
     const int hRem = Ho * win_v - H, vRem = Wo * win_h - W;
     const int initialHOffset = hRem / 2, initialVOffset = vRem / 2;
@@ -365,8 +373,12 @@ int guided_float(svh_context *ctx, Scratch &scr, int func, bool processed, A src
         if (!ns || !nt) return SVH_ERR_OUT_OF_MEMORY;
     }
     if (zm || nrm) {
-        SVH_TRY(launch_stats(ctx, src, H, Ws, zm, nrm, ms, ns));
-        SVH_TRY(launch_stats(ctx, tgt, H, Wt, zm, nrm, mt, nt));
+        if constexpr (std::is_same_v<A, FeatImage>) {
+            SVH_TRY(launch_stats_pair(ctx, src, tgt, zm, nrm, ms, ns, mt, nt)); // (both images in one launch)
+        } else {
+            SVH_TRY(launch_stats(ctx, src, H, Ws, zm, nrm, ms, ns));
+            SVH_TRY(launch_stats(ctx, tgt, H, Wt, zm, nrm, mt, nt));
+        }
     }
 #define SVH_GUIDED(CMPV)                                                                                                     \
     do {                                                                                                                     \
@@ -396,7 +408,18 @@ int dev_downsample(svh_context *ctx, const float *img, int H, int W, int C, int 
     const int Ho = (H + win_v - 1) / win_v, Wo = (W + win_h - 1) / win_h;
     const int64_t n = (int64_t)Ho * Wo * C;
     if (n == 0) return SVH_OK;
-    SVH_LAUNCH(ctx, "average_pooling_downsample", downsample_kernel, grid_for(n, 256, 16384), 256, 0, img, H, W, C, win_h, win_v, Ho, Wo, out);
+    SVH_LAUNCH(ctx, "average_pooling_downsample", downsample_kernel, grid_for(n, 256, 16384), 256, 0, img, H, W, C, win_h, win_v, Ho, Wo, out, img, W, Wo, out);
+    SVH_CHECK_LAUNCH(ctx);
+    return SVH_OK;
+}
+
+// the two images of a pair (same height and channels) by halves in one launch
+int dev_downsample_pair(svh_context *ctx, const float *img_a, int W_a, const float *img_b, int W_b, int H, int C, float *out_a, float *out_b) {
+    const int Ho = (H + 1) / 2, Wo_a = (W_a + 1) / 2, Wo_b = (W_b + 1) / 2;
+    const int64_t n = (int64_t)Ho * std::max(Wo_a, Wo_b) * C;
+    if (n == 0) return SVH_OK;
+    SVH_LAUNCH(ctx, "average_pooling_downsample", downsample_kernel, dim3(grid_for(n, 256, 16384), 2), 256, 0, img_a, H, W_a, C, 2, 2, Ho, Wo_a, out_a, img_b, W_b, Wo_b,
+               out_b);
     SVH_CHECK_LAUNCH(ctx);
     return SVH_OK;
 }
@@ -432,8 +455,12 @@ int dev_hierarchical(svh_context *ctx, Scratch &scr, int func, int ddir, int dep
     const int Hd = (img_l.H + 1) / 2, Wld = (img_l.W + 1) / 2, Wrd = (img_r.W + 1) / 2, C = img_l.C;
     float *dl = scr.get_n<float>((size_t)Hd * Wld * C), *dr = scr.get_n<float>((size_t)Hd * Wrd * C);
     if (!dl || !dr) return SVH_ERR_OUT_OF_MEMORY;
-    SVH_TRY(dev_downsample(ctx, img_l.data, img_l.H, img_l.W, C, 2, 2, dl)); // :248-249
-    SVH_TRY(dev_downsample(ctx, img_r.data, img_r.H, img_r.W, C, 2, 2, dr));
+    if (img_l.H == img_r.H) {
+        SVH_TRY(dev_downsample_pair(ctx, img_l.data, img_l.W, img_r.data, img_r.W, img_l.H, C, dl, dr)); // :248-249
+    } else {
+        SVH_TRY(dev_downsample(ctx, img_l.data, img_l.H, img_l.W, C, 2, 2, dl));
+        SVH_TRY(dev_downsample(ctx, img_r.data, img_r.H, img_r.W, C, 2, 2, dr));
+    }
     const ImageDesc sl{dl, Hd, Wld, C}, sr{dr, Hd, Wrd, C};
     const int Wsd = r2l ? Wrd : Wld;
     int32_t *guide = scr.get_n<int32_t>((size_t)Hd * Wsd);

@@ -353,11 +353,14 @@ static inline int func_cmp(int func) { // the comparison of a float matching fun
     }
 }
 typedef float fv_f32x2 __attribute__((ext_vector_type(2)));
-template <int CMP, int FMAX>
-__global__ void __launch_bounds__(256) feature_volume_records_kernel(const float *__restrict__ ps, const float *__restrict__ pt, int H, int Ws, int Wt, int F,
+// EXACT: F == FMAX, known at compile time (17: the GrPix17 compressors; 9, 25: 3x3 and 5x5 unfolds; 27: 3x3 RGB) -- no guard per feature, so the
+// source reads of a step are issued together instead of one wait per feature
+template <int CMP, int FMAX, bool EXACT>
+__global__ void __launch_bounds__(256) feature_volume_records_kernel(const float *__restrict__ ps, const float *__restrict__ pt, int H, int Ws, int Wt, int F_arg,
                                                                      int D, int sign, int disp_lower, int row_off, int64_t px_stride, int64_t out_off,
                                                                      float *__restrict__ cv) {
     extern __shared__ __attribute__((aligned(16))) float flds[];
+    const int F = EXACT ? FMAX : F_arg;
     const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
     const int n_rec = HV_TP + D - 1, FS = F | 1; // record stride (odd: a wave's 64 records fall into different banks)
     const int it = i + row_off;
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(256) feature_volume_records_kernel(const float
         const int y = y0 + lane;
         float t[FMAX];
 #pragma unroll
-        for (int c = 0; c < FMAX; c++) t[c] = (c < F && y < n_rec) ? flds[min(y, n_rec - 1) * FS + c] : 0.0f;
+        for (int c = 0; c < FMAX; c++) t[c] = ((EXACT || c < F) && y < n_rec) ? flds[min(y, n_rec - 1) * FS + c] : 0.0f;
         // the source pixels whose ranges touch these records -- pixel u's disparity 0 is record b(u) = u (sign > 0) or HV_TP - 1 - u --, four
         // at a time: this wave takes the groups wave, wave + 4, ...
         for (int u = 4 * wave; u < n_px; u += 16) {
@@ -386,7 +389,7 @@ __global__ void __launch_bounds__(256) feature_volume_records_kernel(const float
             fv_f32x2 acc01{0.0f, 0.0f}, acc23{0.0f, 0.0f};
 #pragma unroll
             for (int c = 0; c < FMAX; c++) {
-                if (c < F) { // (uniform)
+                if (EXACT || c < F) { // (uniform)
                     const float4 sv = s4[c * (HV_TP / 4)];
                     const fv_f32x2 s01{sv.x, sv.y}, s23{sv.z, sv.w}, tv{t[c], t[c]};
                     if (CMP == CMP_DOT) {
@@ -450,19 +453,26 @@ static int cost_volume_features_tiled(svh_context *ctx, Scratch &scr, const Cost
         const int Dc = std::min(chunk, a.D - d0), lower = a.disp_lower + d0;
         const int64_t off = a.out_off + d0;
         if (F <= 32 && ctx->feature_volume_records) { // the target record in registers
-            const int fmax = F <= 20 ? 20 : 32;
             const size_t rshmem = ((((size_t)(HV_TP + Dc - 1) * (F | 1) + 3) & ~(size_t)3) + (size_t)HV_TP * F) * sizeof(float);
             const int cmp = func_cmp(a.func);
             if (rshmem <= budget + 4096 && cmp >= 0) {
-#define SVH_FVR(CMPV)                                                                                                                                       \
-    do {                                                                                                                                                    \
-        if (fmax == 20) SVH_LAUNCH(ctx, "feature_volume_tiled", (feature_volume_records_kernel<CMPV, 20>), grid, 256, rshmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off, a.px_stride(), off, cv); \
-        else SVH_LAUNCH(ctx, "feature_volume_tiled", (feature_volume_records_kernel<CMPV, 32>), grid, 256, rshmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, a.tgt_row_off, a.px_stride(), off, cv);    \
+#define SVH_FVR_AS(CMPV, FM, EX)                                                                                                                            \
+    SVH_LAUNCH(ctx, "feature_volume_tiled", (feature_volume_records_kernel<CMPV, FM, EX>), grid, 256, rshmem, ps, pt, a.H, a.Ws, a.Wt, F, Dc, sign, lower, \
+               a.tgt_row_off, a.px_stride(), off, cv)
+#define SVH_FVR(CMPV)                                    \
+    do {                                                 \
+        if (F == 17) SVH_FVR_AS(CMPV, 17, true);         \
+        else if (F == 25) SVH_FVR_AS(CMPV, 25, true);    \
+        else if (F == 9) SVH_FVR_AS(CMPV, 9, true);      \
+        else if (F == 27) SVH_FVR_AS(CMPV, 27, true);    \
+        else if (F <= 20) SVH_FVR_AS(CMPV, 20, false);   \
+        else SVH_FVR_AS(CMPV, 32, false);                \
     } while (0)
                 if (cmp == CMP_DOT) SVH_FVR(CMP_DOT);
                 else if (cmp == CMP_SSD) SVH_FVR(CMP_SSD);
                 else SVH_FVR(CMP_SAD);
 #undef SVH_FVR
+#undef SVH_FVR_AS
                 continue;
             }
         }

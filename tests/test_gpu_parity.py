@@ -1073,6 +1073,7 @@ def test_feature_cost_volume_tiled_same_bits_as_per_voxel(rng, func):
                                      (5, 70, 90, 1, 70, sv.dispDirection.RightToLeft), (6, 200, 200, 25, 128, sv.dispDirection.LeftToRight),
                                      (4, 333, 333, 20, 320, sv.dispDirection.RightToLeft), (3, 131, 140, 21, 65, sv.dispDirection.LeftToRight), (3, 65, 65, 32, 64, sv.dispDirection.RightToLeft),
                                      (2, 129, 129, 33, 50, sv.dispDirection.RightToLeft),
+                                     (3, 100, 100, 9, 48, sv.dispDirection.LeftToRight), (2, 70, 80, 27, 30, sv.dispDirection.RightToLeft),
                                      # long vectors (9x9, 11x11 unfolded and more): the range in chunks, fewer pixels per processing block
                                      (5, 100, 100, 81, 140, sv.dispDirection.RightToLeft), (4, 90, 80, 121, 70, sv.dispDirection.LeftToRight),
                                      (3, 70, 70, 200, 33, sv.dispDirection.RightToLeft)]:

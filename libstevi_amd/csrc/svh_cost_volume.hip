@@ -7,6 +7,8 @@
 // volume is ever written.  Volumes are stored (row, col, disparity) with the disparity fastest: one pixel's D
 // costs are contiguous, which is what the per-line SGM kernels and the winner scan want.
 #include "svh_internal.h"
+#include <climits>
+
 #include "svh_compare.h"
 #include "svh_sgm_lines.h"
 
@@ -61,7 +63,8 @@ constexpr int HV_TP = 64;
 template <int NW>
 __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_t *__restrict__ sw, const uint32_t *__restrict__ tw, int H,
                                                                    int Ws, int Wt, int D, int sign, int disp_lower, int row_off, int64_t px_stride,
-                                                                   int64_t out_off, float *__restrict__ cv, float2 *__restrict__ minima) {
+                                                                   int64_t out_off, float *__restrict__ cv, float2 *__restrict__ minima,
+                                                                   int32_t *__restrict__ win_idx, int store) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int i = blockIdx.y, j0 = blockIdx.x * HV_TP;
     const int n_rec = HV_TP + D - 1;
@@ -85,6 +88,28 @@ __global__ void __launch_bounds__(256) hamming_volume_tiled_kernel(const uint32_
         for (int w = 0; w < NW; w++) s[w] = lsrc[u * NW + w];
         const uint32_t *base = lds + (sign > 0 ? u : HV_TP - 1 - u) * NW;
         float *out = cv + p * px_stride + out_off;
+        if (win_idx) { // (uniform) CostReduce mode 1: extractSelectedIndex of the pixel's costs while a wave holds them -- the smallest distance, ties to
+            // the larger index (a distance is never NaN) -- and, when nobody wants the volume itself (store == 0), nothing else is written
+            int best = INT_MAX, bd = 0;
+            for (int d = lane; d < D; d += 64) {
+                uint32_t score = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) score += __popc(s[w] ^ base[d * NW + w]);
+                if (store) out[d] = (float)score;
+                if ((int)score <= best) { // (d grows: a later equal distance takes over)
+                    best = (int)score;
+                    bd = d;
+                }
+            }
+            int m = best;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) m = min(m, __shfl_xor(m, off));
+            int key = best == m ? bd + 1 : 0; // (a lane without a cost holds INT_MAX: D >= 1 gives lane 0 one)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) key = max(key, __shfl_xor(key, off));
+            if (lane == 0) win_idx[p] = key - 1;
+            continue;
+        }
         if (!minima) { // (uniform)
             for (int d = lane; d < D; d += 64) {
                 uint32_t score = 0;
@@ -125,8 +150,13 @@ template <int NW>
 static void launch_hamming_tiled(svh_context *ctx, const CostVolumeArgs &a, const uint32_t *sw, const uint32_t *tw, int sign, float *cv) {
     dim3 grid(ceil_div(a.Ws, HV_TP), a.H);
     const size_t shmem = (size_t)NW * (2 * HV_TP + a.D - 1) * sizeof(uint32_t);
+    // CostReduce mode 1 (the winner): whole 1-D volumes only (one launch holds a pixel's whole range)
+    const bool winner = a.reduce && a.reduce->mode == 1 && !a.reduce->score && a.reduce->idx && !a.reduce->disp && a.n_dh == 1 && a.out_off == 0 &&
+                        (a.reduce->store ? cv != nullptr : true);
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_tiled_kernel<NW>, grid, 256, shmem, sw, tw, a.H, a.Ws, a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off,
-               a.px_stride(), a.out_off, cv, reinterpret_cast<float2 *>(a.minima));
+               a.px_stride(), a.out_off, cv, winner ? nullptr : reinterpret_cast<float2 *>(a.minima), winner ? a.reduce->idx : nullptr,
+               winner && !a.reduce->store ? 0 : 1);
+    if (winner) a.reduce->done = true;
 }
 
 // 2-D search ranges (aggregateCost(searchOffset<2>), cross_correlations.h:310-374): every vertical offset's target records are
@@ -548,6 +578,7 @@ int dev_hamming_volume(svh_context *ctx, const CostVolumeArgs &a, const uint32_t
         if (a.minima_written) *a.minima_written = a.minima != nullptr;
         return SVH_OK;
     }
+    if (!cv) return fail(ctx, SVH_ERR_HIP, "internal: the Hamming kernel for these records writes the volume");
     SVH_LAUNCH(ctx, "hamming_volume", hamming_volume_kernel, grid_for(n, 256, 65536), 256, 0, src_words, tgt_words, nWw, a.H, a.Ws,
                a.Wt, a.D, sign, a.disp_lower, a.tgt_row_off, a.px_stride(), a.out_off, cv);
     SVH_CHECK_LAUNCH(ctx);

@@ -471,9 +471,13 @@ int dev_hierarchical(svh_context *ctx, Scratch &scr, int func, int ddir, int dep
         a.literal = ctx->literal_cost_volumes;
         const ImageDesc csrc = r2l ? sr : sl, ctgt = r2l ? sl : sr;
         // the coarsest level wants the winner of every pixel and nothing else of its volume: where the column-sum kernel runs (grey
-        // images, float functions) it picks the winner while it holds the costs and the volume is never written (CostReduce mode 1)
+        // images, float functions) or the tiled Hamming kernel (census: up to eight words) it picks the winner while it holds the costs and
+        // the volume is never written (CostReduce mode 1)
         bool winner_done = false;
-        if (ctx->cost_reduce_fused && C == 1 && cost_volume_colsum_applies(ctx, a, csrc, ctgt, h_radii[0], v_radii[0])) {
+        const int census_words = func_census(func) ? census_words_written((2 * h_radii[0] + 1) * (2 * v_radii[0] + 1) * C) : 0;
+        const bool hamming_reduces = func_census(func) && census_words >= 1 && census_words <= 8 &&
+                                     (size_t)census_words * (2 * 64 + D0 - 1) * sizeof(uint32_t) <= 60 * 1024; // (the tiled Hamming kernel: dev_hamming_volume)
+        if (ctx->cost_reduce_fused && (hamming_reduces || (!func_census(func) && C == 1 && cost_volume_colsum_applies(ctx, a, csrc, ctgt, h_radii[0], v_radii[0])))) {
             CostReduce red;
             red.mode = 1;
             red.score = func_strategy(func) != SVH_COST;

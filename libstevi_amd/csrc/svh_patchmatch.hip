@@ -336,18 +336,31 @@ __device__ __forceinline__ bool wave_cost(const OdVolume &o, int i, int j, int d
     const float *s = o.fs + ((int64_t)i * o.Ws + j) * o.nF, *t = o.ft + ((int64_t)ti * o.Wt + tj) * o.nF;
     const int lane = threadIdx.x;
     __syncthreads(); // the previous cost's readers are done with buf
-    for (int f = lane; f < o.nF; f += 64) {
-        const float a = s[f], b = t[f];
-        float term;
-        if (o.func == SVH_SSD || o.func == SVH_ZSSD) {
-            const float tmp = a - b;
-            term = tmp * tmp;
-        } else if (o.func == SVH_SAD || o.func == SVH_ZSAD) {
-            term = fabsf(a - b);
-        } else {
-            term = a * b;
+    for (int f0 = 0; f0 < o.nF; f0 += 256) { // four rounds of 64 features per wait: eight loads in flight (a load, a wait, a store per round: three waits at 7x7 RGB)
+        float a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            a[r] = b[r] = 0.0f;
+            if (f0 + 64 * r < o.nF) { // (wave uniform: short vectors load one round)
+                const int f = min(f0 + 64 * r + lane, o.nF - 1);
+                a[r] = s[f];
+                b[r] = t[f];
+            }
         }
-        buf[f] = term;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = f0 + 64 * r + lane;
+            float term;
+            if (o.func == SVH_SSD || o.func == SVH_ZSSD) {
+                const float tmp = a[r] - b[r];
+                term = tmp * tmp;
+            } else if (o.func == SVH_SAD || o.func == SVH_ZSAD) {
+                term = fabsf(a[r] - b[r]);
+            } else {
+                term = a[r] * b[r];
+            }
+            if (f < o.nF) buf[f] = term;
+        }
     }
     __syncthreads();
     float acc = 0.0f;

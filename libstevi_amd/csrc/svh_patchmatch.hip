@@ -167,16 +167,21 @@ __global__ void __launch_bounds__(256) on_demand_features_tiled_kernel(const flo
     const int h = 2 * h_r + 1, v = 2 * v_r + 1, hc = h * C, nF = v * hc, TWc = (ODF_PX + h - 1) * C;
     const int n_cols = (n_px + h - 1) * C; // what of a tile row this block reads
     const bool inside = j0 - h_r >= 0 && j0 + n_px - 1 + h_r < W; // (block uniform)
-    for (int k = 0; k < v; k++) {
-        const float *row = img + (int64_t)min(H - 1, max(0, i + k - v_r)) * W * C;
-        if (inside) {
-            const float *from = row + (int64_t)(j0 - h_r) * C;
-            for (int r = threadIdx.x; r < n_cols; r += 256) tile[k * TWc + r] = from[r];
-        } else {
-            for (int r = threadIdx.x; r < n_cols; r += 256) {
-                const int x = r / C, c = r - x * C;
-                tile[k * TWc + r] = row[(int64_t)min(W - 1, max(0, j0 - h_r + x)) * C + c];
+    // four window rows' loads before the first store (a row-by-row copy waits for memory once per window row)
+    for (int r0 = 0; r0 < n_cols; r0 += 256) {
+        const int r = r0 + threadIdx.x;
+        const int x = r / C, c = r - x * C;
+        const int64_t at = inside ? (int64_t)(j0 - h_r) * C + r : (int64_t)min(W - 1, max(0, j0 - h_r + x)) * C + c; // (clamped: the border pixels repeat)
+        for (int k0 = 0; k0 < v; k0 += 4) {
+            float got[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float *row = img + (int64_t)min(H - 1, max(0, i + min(k0 + q, v - 1) - v_r)) * W * C;
+                got[q] = row[r < n_cols ? at : 0];
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (k0 + q < v && r < n_cols) tile[(k0 + q) * TWc + r] = got[q];
         }
     }
     __syncthreads();

@@ -774,21 +774,21 @@ __device__ __forceinline__ float pm_run_costs(const OdVolume &o, int64_t first, 
         tv[e] = o.ft + ((int64_t)(has ? ti : 0) * o.Wt + (has ? tj : 0)) * nF;
     }
     __syncthreads(); // the previous batch's readers are done with the rows
-    for (int f0 = 0; f0 < nF; f0 += 128) { // two rounds of 64 features at a time: 2 x 2 x PM_RUN loads in flight
-        float a[2][PM_RUN], b[2][PM_RUN];
+    for (int f0 = 0; f0 < nF; f0 += 192) { // three rounds of 64 features per wait: 3 x 2 x PM_RUN loads in flight (7x7 RGB, 147 features: one wait instead of two)
+        float a[3][PM_RUN], b[3][PM_RUN];
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int e = 0; e < PM_RUN; e++) {
                 const int f = f0 + 64 * r + lane;
                 a[r][e] = b[r][e] = 0.0f;
-                if (f < nF && ((mask >> e) & 1u)) {
+                if (f0 + 64 * r < nF && f < nF && ((mask >> e) & 1u)) {
                     a[r][e] = sv[e][f];
                     b[r][e] = tv[e][f];
                 }
             }
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 3; r++)
 #pragma unroll
             for (int e = 0; e < PM_RUN; e++) {
                 const int f = f0 + 64 * r + lane;

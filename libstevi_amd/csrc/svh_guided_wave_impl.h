@@ -99,7 +99,7 @@ __device__ __forceinline__ void emit_pixel(const float (&acc)[4 * R + 1], const 
 // lane + 64 u -- and `commit` stores them.  A wave of this kernel is as long as its dependent trips to memory (the guide; then the target rows
 // the guide points at), so everything a trip can carry is issued before anything waits; every load reads a clamped address and is replaced
 // by 0 afterwards where it was outside (no branch per load).
-template <int NUX> struct StagedRows {
+template <int NUX, int C> struct StagedRows { // (row_len, PITCH and the lanes' columns count floats: C per pixel; c0: the first PIXEL column)
     float val[8][NUX];
     template <int PITCH>
     __device__ __forceinline__ void issue(const float *__restrict__ img, int H, int W, int i0, int c0, int k0, int row_len, int lane) {
@@ -107,11 +107,11 @@ template <int NUX> struct StagedRows {
         for (int r = 0; r < 8; r++) {
             const int ii = i0 + k0 + r;
             const bool row_ok = ii >= 0 && ii < H; // (wave uniform)
-            const float *rowp = img + (int64_t)min(max(ii, 0), H - 1) * W;
+            const float *rowp = img + (int64_t)min(max(ii, 0), H - 1) * W * C;
 #pragma unroll
             for (int u = 0; u < NUX; u++) {
-                const int x = lane + 64 * u, jj = c0 + x;
-                const float got = rowp[min(max(jj, 0), W - 1)];
+                const int x = lane + 64 * u, px = x / C, ch = x - px * C, jj = c0 + px;
+                const float got = rowp[min(max(jj, 0), W - 1) * C + ch];
                 val[r][u] = (row_ok && x < row_len && jj >= 0 && jj < W) ? got : 0.0f;
             }
         }
@@ -144,13 +144,13 @@ template <bool MIN> __device__ __forceinline__ int wave_extremum_i32(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-// The per-lane walk of the offsets C0 .. C0 + G - 1 (G <= 5 at a time keeps the registers of the whole kernel at the passes' level): the G
-// windows of a row overlap in h + G - 1 raw samples, loaded once per row; the source samples come from the staged rows (`srow`: this
-// lane's first sample of row 0).
-template <int CMP, bool ZM, bool NORM, int HR, int NC, int C0>
+// The per-lane walk of the offsets C0 .. C0 + G - 1 (a few at a time keeps the registers of the whole kernel at the passes' level): the G
+// windows of a row overlap in h + G - 1 raw pixels, loaded once per row; the source samples come from the staged rows (`srow`: this
+// lane's first sample of row 0).  C: interleaved channels (the feature index runs rows, columns, channels: unfold.h:180).
+template <int CMP, bool ZM, bool NORM, int HR, int C, int NC, int C0>
 __device__ __forceinline__ void walk_offsets(const FeatImage &tgt, const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Wt,
                                              const float *srow, int SW, int v, int v_r, int i, int first, float ms, double rs, float (&acc)[NC], bool &bad) {
-    constexpr int h = 2 * HR + 1, G = NC - C0 < 5 ? NC - C0 : 5, NRAW = h + G - 1;
+    constexpr int h = 2 * HR + 1, GMAX = C == 1 ? 5 : 2, G = NC - C0 < GMAX ? NC - C0 : GMAX, NRAW = (h + G - 1) * C;
     float mt[G];
     double rd[G];
     bool tin[G];
@@ -168,8 +168,8 @@ __device__ __forceinline__ void walk_offsets(const FeatImage &tgt, const float *
         const bool row_in = k < v && ii >= 0 && ii < H;
 #pragma unroll
         for (int x = 0; x < NRAW; x++) {
-            const int jc = first + C0 - HR + x;
-            row[x] = (row_in && jc >= 0 && jc < Wt) ? tgt.img[(int64_t)ii * Wt + jc] : 0.0f;
+            const int jc = first + C0 - HR + x / C;
+            row[x] = (row_in && jc >= 0 && jc < Wt) ? tgt.img[((int64_t)ii * Wt + jc) * C + x % C] : 0.0f;
         }
     };
     load_row(0, ahead);
@@ -178,15 +178,15 @@ __device__ __forceinline__ void walk_offsets(const FeatImage &tgt, const float *
         for (int x = 0; x < NRAW; x++) raw[x] = ahead[x];
         load_row(k + 1, ahead);
 #pragma unroll
-        for (int l = 0; l < h; l++) {
-            float s = srow[k * SW + l];
+        for (int m = 0; m < h * C; m++) { // (sample m: column m / C, channel m % C)
+            float s = srow[k * SW + m];
             if (ZM) s = s - ms;
             if (NORM) s = div_by_shared(s, rs, bad);
 #pragma unroll
             for (int c = 0; c < G; c++) {
                 float t = 0.0f; // a centre outside the image is the all-zero vector
                 if (tin[c]) {
-                    t = raw[l + c];
+                    t = raw[m + c * C];
                     if (ZM) t = t - mt[c];
                     if (NORM) t = div_by_shared(t, rd[c], bad);
                 }
@@ -194,16 +194,16 @@ __device__ __forceinline__ void walk_offsets(const FeatImage &tgt, const float *
             }
         }
     }
-    if constexpr (C0 + G < NC) walk_offsets<CMP, ZM, NORM, HR, NC, C0 + G>(tgt, mean_t, norm_t, H, Wt, srow, SW, v, v_r, i, first, ms, rs, acc, bad);
+    if constexpr (C0 + G < NC) walk_offsets<CMP, ZM, NORM, HR, C, NC, C0 + G>(tgt, mean_t, norm_t, H, Wt, srow, SW, v, v_r, i, first, ms, rs, acc, bad);
 }
 
 // SPAN: the target centres a pass stages -- 64 pixels + 4R + 1 offsets + room for the guide to move
-template <int CMP, bool ZM, bool NORM, int R, int HR, int SPAN>
+template <int CMP, bool ZM, bool NORM, int R, int HR, int SPAN, int C>
 __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImage tgt, const float *__restrict__ mean_s, const float *__restrict__ norm_s,
                                                          const float *__restrict__ mean_t, const float *__restrict__ norm_t, int H, int Ws, int Wt,
                                                          GuideArgs g, int32_t *__restrict__ disp, float *__restrict__ tcv) {
-    constexpr int NC = 4 * R + 1, NP = (NC + 1) / 2, h = 2 * HR + 1, SW = 64 + h - 1;
-    constexpr int TW = SPAN + 2 * h - 1;            // a staged target row: span + h - 1 raw samples and h zeros (what a centre outside the image reads, hierarchical.h:175-178)
+    constexpr int NC = 4 * R + 1, NP = (NC + 1) / 2, h = 2 * HR + 1, hc = h * C, SW = (64 + h - 1) * C; // (floats: C interleaved channels per pixel)
+    constexpr int TW = (SPAN + 2 * h - 1) * C;      // a staged target row: span + h - 1 raw pixels and h zero pixels (what a centre outside the image reads, hierarchical.h:175-178)
     constexpr int SP = SPAN + 1;                    // strip pitch (odd: a lane's centre q and sample l -> word l * SP + q)
     extern __shared__ float lds_d[];
     const int lane = threadIdx.x, i = blockIdx.y, j0 = blockIdx.x * 64, j = j0 + lane;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
     const bool px = j < Ws;
     const int64_t p = (int64_t)i * Ws + (px ? j : Ws - 1);
     // first trip to memory: the source rows, the guide, this pixel's mean and norm
-    StagedRows<2> srows;
+    StagedRows<(SW + 63) / 64, C> srows;
     srows.template issue<SW>(src.img, H, Ws, i - src.v_r, j0 - HR, 0, SW, lane);
     const int d0 = px ? guided_base_disp(g.guide, g.Hg, g.Wg, H, Ws, i, j, g.dirSign) : 0;
     const float ms = ZM ? mean_s[p] : 0.0f, ns = NORM ? norm_s[p] : 1.0f;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
         srows.template issue<SW>(src.img, H, Ws, i - src.v_r, j0 - HR, k0, SW, lane);
         srows.template commit<SW>(stile, v, k0, SW, lane);
     }
-    for (int x = lane; x < v * h; x += 64) ttile[(x / h) * TW + TW - h + x % h] = 0.0f;
+    for (int x = lane; x < v * hc; x += 64) ttile[(x / hc) * TW + TW - hc + x % hc] = 0.0f;
     const int first = j + d0 - 2 * R; // this pixel's first target centre
     const double rs = 1.0 / (double)ns;
     bool todo = px, redo = false;
@@ -237,8 +237,8 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
         // second trip: the target rows behind lo; the means and norms of the centres this lane processes -- lane, 64 + lane, ... of the span
         // (a centre outside the image reads the row's zeros)
         constexpr int NU = (SPAN + 63) / 64;
-        StagedRows<(SPAN + h - 1 + 63) / 64> trows;
-        trows.template issue<TW>(tgt.img, H, Wt, i - src.v_r, lo - HR, 0, span + h - 1, lane);
+        StagedRows<((SPAN + h - 1) * C + 63) / 64, C> trows;
+        trows.template issue<TW>(tgt.img, H, Wt, i - src.v_r, lo - HR, 0, (span + h - 1) * C, lane);
         float cm[NU], cn[NU];
         int cin[NU];
 #pragma unroll
@@ -249,12 +249,12 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
             const float got_m = ZM ? mean_t[pt] : 0.0f, got_n = NORM ? norm_t[pt] : 1.0f;
             cm[u] = tin ? got_m : 0.0f;
             cn[u] = tin ? got_n : 1.0f;
-            cin[u] = tin ? q : TW - h;
+            cin[u] = tin ? q * C : TW - hc;
         }
-        trows.template commit<TW>(ttile, v, 0, span + h - 1, lane);
+        trows.template commit<TW>(ttile, v, 0, (span + h - 1) * C, lane);
         for (int k0 = 8; k0 < v; k0 += 8) {
-            trows.template issue<TW>(tgt.img, H, Wt, i - src.v_r, lo - HR, k0, span + h - 1, lane);
-            trows.template commit<TW>(ttile, v, k0, span + h - 1, lane);
+            trows.template issue<TW>(tgt.img, H, Wt, i - src.v_r, lo - HR, k0, (span + h - 1) * C, lane);
+            trows.template commit<TW>(ttile, v, k0, (span + h - 1) * C, lane);
         }
         double cr[NU];
 #pragma unroll
@@ -267,12 +267,12 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
         bool bad_centre = false, bad_px = false;
         for (int k = 0; k < v; k++) {
             const float *trow = ttile + k * TW;
-            float t[NU][h];
+            float t[NU][hc];
 #pragma unroll
             for (int u = 0; u < NU; u++) {
                 if (u == 0 || span > 64 * u) { // (wave uniform)
 #pragma unroll
-                    for (int l = 0; l < h; l++) {
+                    for (int l = 0; l < hc; l++) {
                         t[u][l] = trow[cin[u] + l];
                         if (ZM) t[u][l] = t[u][l] - cm[u];
                         if (NORM) t[u][l] = div_by_shared(t[u][l], cr[u], bad_centre);
@@ -284,13 +284,13 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
             for (int u = 0; u < NU; u++) {
                 if ((u == 0 || span > 64 * u) && lane + 64 * u < SPAN) {
 #pragma unroll
-                    for (int l = 0; l < h; l++) strip[l * SP + 64 * u + lane] = t[u][l];
+                    for (int l = 0; l < hc; l++) strip[l * SP + 64 * u + lane] = t[u][l];
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int l = 0; l < h; l++) {
-                float s = stile[k * SW + lane + l];
+            for (int l = 0; l < hc; l++) { // (sample l: column l / C, channel l % C)
+                float s = stile[k * SW + lane * C + l];
                 if (ZM) s = s - ms;
                 if (NORM) s = div_by_shared(s, rs, bad_px);
                 int row_at = l * SP + qb; // (opaque: one address per sample row and small offsets behind it, not a constant beyond the offset field per read)
@@ -313,33 +313,35 @@ __global__ void __launch_bounds__(64) guided_wave_kernel(FeatImage src, FeatImag
         bool bad = false;
 #pragma unroll
         for (int c = 0; c < NC; c++) acc[c] = 0.0f;
-        walk_offsets<CMP, ZM, NORM, HR, NC, 0>(tgt, mean_t, norm_t, H, Wt, stile + lane, SW, v, src.v_r, i, first, ms, rs, acc, bad);
+        walk_offsets<CMP, ZM, NORM, HR, C, NC, 0>(tgt, mean_t, norm_t, H, Wt, stile + lane * C, SW, v, src.v_r, i, first, ms, rs, acc, bad);
         if (bad) redo = true;
         else emit_pixel<R>(acc, g, d0, p, disp, tcv);
     }
     if (redo) guided_fused_px<CMP, ZM, NORM, R>(src, tgt, mean_s, norm_s, mean_t, norm_t, H, Ws, Wt, g, disp, tcv, p, i, j, d0);
 }
 
-template <int CMP, bool ZM, bool NORM, int HR, int SPAN>
+template <int CMP, bool ZM, bool NORM, int HR, int SPAN, int C>
 bool launch_guided_wave_span(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws,
                              int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
     constexpr int h = 2 * HR + 1;
     const int v = 2 * src.v_r + 1;
-    const size_t shmem = (size_t)(v * (64 + h - 1) + v * (SPAN + 2 * h - 1) + h * (SPAN + 1)) * sizeof(float);
+    const size_t shmem = (size_t)(v * (64 + h - 1) * C + v * (SPAN + 2 * h - 1) * C + h * C * (SPAN + 1)) * sizeof(float);
     if (shmem > 60 * 1024) return false;
     const dim3 grid(ceil_div(Ws, 64), H);
     switch (g.radius) {
-    case 1: SVH_LAUNCH(ctx, "guided_fused", (guided_wave_kernel<CMP, ZM, NORM, 1, HR, SPAN>), grid, 64, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
-    case 2: SVH_LAUNCH(ctx, "guided_fused", (guided_wave_kernel<CMP, ZM, NORM, 2, HR, SPAN>), grid, 64, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
-    case 3: SVH_LAUNCH(ctx, "guided_fused", (guided_wave_kernel<CMP, ZM, NORM, 3, HR, SPAN>), grid, 64, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
+    case 1: SVH_LAUNCH(ctx, "guided_fused", (guided_wave_kernel<CMP, ZM, NORM, 1, HR, SPAN, C>), grid, 64, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
+    case 2: SVH_LAUNCH(ctx, "guided_fused", (guided_wave_kernel<CMP, ZM, NORM, 2, HR, SPAN, C>), grid, 64, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
+    case 3: SVH_LAUNCH(ctx, "guided_fused", (guided_wave_kernel<CMP, ZM, NORM, 3, HR, SPAN, C>), grid, 64, shmem, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv); return true;
     default: return false;
     }
 }
 
+// grey images: 96 staged centres; RGB: 80 (three times the rows and the strip in LDS: a CU holds seven waves of it)
 template <int CMP, bool ZM, bool NORM, int HR>
 bool launch_guided_wave_radius(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H,
                                int Ws, int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
-    return launch_guided_wave_span<CMP, ZM, NORM, HR, 96>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
+    if (src.C == 3) return launch_guided_wave_span<CMP, ZM, NORM, HR, 80, 3>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
+    return launch_guided_wave_span<CMP, ZM, NORM, HR, 96, 1>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
 }
 
 // the eight combinations the matching functions have: CC / NCC / ZCC / ZNCC, SSD / ZSSD, SAD / ZSAD

@@ -311,6 +311,10 @@ template <int CMP, bool ZM, bool NORM>
 bool launch_guided_fused(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H, int Ws,
                          int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
     // grey images, windows up to 7 wide: the processed target features shared by a block; otherwise every lane on its own
+    // RGB images: the wave form at every size (the alternative is the per-pixel walk; the blocks below take grey images only)
+    if (ctx->guided_shared && src.C == 3 && tgt.C == 3 && ctx->guided_shared != 2 &&
+        launch_guided_wave(ctx, CMP, ZM, NORM, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv))
+        return true;
     if (ctx->guided_shared && src.C == 1 && tgt.C == 1 && H <= 65535 && src.h_r == tgt.h_r && src.v_r == tgt.v_r) {
         bool ran = false;
         // 1 (the default): a wave per 64 pixels where the grid fills the chip several times over (a wave per SIMD is 1 024 waves) and runs at the

@@ -210,3 +210,33 @@ def test_guided_forms_same_bits_on_special_values(func):
         for o in outs[1:]:
             assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]), (H, W, r, radius)
 
+
+@pytest.mark.parametrize("func", [MF.ZNCC, MF.NCC, MF.CC, MF.SSD, MF.ZSSD, MF.SAD, MF.ZSAD])
+def test_guided_wave_form_on_rgb_images_same_bits_as_the_per_pixel_walk(func):
+    """RGB images take the wave form of computeGuidedCV (round 5: the channels are three times the samples of a window row, feature index
+    = row, column, channel: unfold.h:180) at every image size; "guided_shared" 0: every pixel and offset on its own.  Same estimates and
+    costs bit for bit -- windows 3x3 - 7x7 (9x9: too wide, both forms walk), radii 1 - 3, both directions, a parallax edge wider than the
+    staged span, a last wave that is not full -- and the oracle's estimates."""
+    for (H, W, r, radius, bg, sq) in [(24, 300, 3, 2, 4, 12), (20, 200, 2, 3, 2, 90), (12, 130, 1, 1, 0, 30), (10, 150, 4, 2, 3, 9)]:
+        g_src, g_tgt, _ = parallax_pair(H, W, max(H // 2, 2), H // 4, W // 3, bg, sq, seed=H + W)
+        rng = np.random.default_rng(H)
+        gains = np.array([1.0, 0.7, 1.3], np.float32)
+        src = (g_src[..., None] * gains + 0.05 * rng.uniform(-1, 1, g_src.shape + (3,))).astype(np.float32)
+        tgt = (g_tgt[..., None] * gains + 0.05 * rng.uniform(-1, 1, g_tgt.shape + (3,))).astype(np.float32)
+        d_src, d_tgt = dev(src), dev(tgt)
+        for ddir in (R2L, L2R):
+            outs = []
+            for shared in (0, 1):
+                sv.set_test_option(d_src, "guided_shared", shared)
+                try:
+                    res = sv.hiearchicalTruncatedCostVolume(func, 1, d_tgt, d_src, r, r, 2 * max(bg, sq) + 8, radius, ddir)
+                finally:
+                    sv.set_test_option(d_src, "guided_shared", 1)
+                outs.append((host(res.disp_estimate), host(res.truncated_cost_volume)))
+            assert np.array_equal(outs[0][0], outs[1][0]), (H, W, r, radius)
+            assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32)), (H, W, r, radius)
+    _, edisp = so.hierarchical_truncated_cv(int(func), 1, tgt, src, r, r, 2 * max(bg, sq) + 8, radius)
+    sv.set_test_option(d_src, "guided_shared", 1)
+    got = host(sv.hiearchicalTruncatedCostVolume(func, 1, d_tgt, d_src, r, r, 2 * max(bg, sq) + 8, radius, R2L).disp_estimate)
+    assert (got == edisp).mean() > 0.995
+

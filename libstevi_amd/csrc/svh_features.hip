@@ -300,13 +300,18 @@ static void launch_census_grey(svh_context *ctx, const CensusJob &a, const Censu
 }
 
 static bool census_grey_dispatch(svh_context *ctx, int h_r, int v_r, const CensusJob &a, const CensusJob *b, int pl, int pt, int n_out) {
-    if (h_r != v_r) return false;
-    switch (h_r) {
-    case 3: launch_census_grey<3, 3>(ctx, a, b, pl, pt, n_out); return true;
-    case 4: launch_census_grey<4, 4>(ctx, a, b, pl, pt, n_out); return true;
-    case 5: launch_census_grey<5, 5>(ctx, a, b, pl, pt, n_out); return true;
-    default: return false;
+    // square windows 7x7 - 11x11 and (round 5) the rectangles with half-widths 2 .. 5 on either side (5x7 ... 11x9: the general tiled kernel
+    // took two to three times as long for them)
+#define SVH_CG(HRV, VRV)                                       \
+    if (h_r == HRV && v_r == VRV) {                            \
+        launch_census_grey<HRV, VRV>(ctx, a, b, pl, pt, n_out); \
+        return true;                                           \
     }
+    SVH_CG(3, 3) SVH_CG(4, 4) SVH_CG(5, 5)
+    SVH_CG(2, 3) SVH_CG(3, 2) SVH_CG(2, 4) SVH_CG(4, 2) SVH_CG(2, 5) SVH_CG(5, 2)
+    SVH_CG(3, 4) SVH_CG(4, 3) SVH_CG(3, 5) SVH_CG(5, 3) SVH_CG(4, 5) SVH_CG(5, 4)
+#undef SVH_CG
+    return false;
 }
 
 // Compile-time windows the register-blocked grey kernel does not take -- colour images (the channels of a window row are the next

@@ -64,13 +64,19 @@ def test_unfold(rng, h_r, v_r, channels):
         assert_bits(sv.unfold(h_r, v_r, img, sv.PaddingMargins(0)), so.unfold(img, h_r, v_r, (0, 0, 0, 0)))
 
 
-@pytest.mark.parametrize("h_r,v_r", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 2), (4, 3), (7, 7)])
+@pytest.mark.parametrize("h_r,v_r", [(1, 1), (2, 2), (3, 3), (4, 4), (5, 2), (4, 3), (7, 7), (2, 3), (3, 2), (2, 4), (4, 2), (2, 5), (3, 4), (3, 5), (5, 3), (4, 5), (5, 4)])
 def test_census_transform(rng, h_r, v_r):
     img = rng.uniform(-1, 1, (17, 23)).astype(np.float32)
     img[3, 5] = np.nan
     exp = so.census_transform(img, h_r, v_r)
     assert_bits(sv.censusTransform2D(img, h_r, v_r), exp)
     assert_bits(sv.censusTransform2D(dev(img), h_r, v_r), exp)
+    # several tiles of the register-blocked grey kernel (squares 7x7 - 11x11, rectangles with half-widths 2 .. 5), all samples finite and not
+    big = rng.uniform(-1, 1, (37, 700)).astype(np.float32)
+    assert_bits(sv.censusTransform2D(dev(big), h_r, v_r), so.census_transform(big, h_r, v_r))
+    big[20, 300] = np.inf
+    big[5, 650] = np.nan
+    assert_bits(sv.censusTransform2D(dev(big), h_r, v_r), so.census_transform(big, h_r, v_r))
     # colour image and explicit padding
     rgb = rng.uniform(-1, 1, (19, 21, 3)).astype(np.float32)
     assert_bits(sv.censusTransform2D(rgb, h_r, v_r, sv.PaddingMargins(2, 1, 0, 3)), so.census_transform(rgb, h_r, v_r, (2, 1, 0, 3)))

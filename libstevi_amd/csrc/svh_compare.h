@@ -150,10 +150,10 @@ enum { CMP_DOT = 0, CMP_SSD = 1, CMP_SAD = 2 };
 // target vector, which aggregateCost uses where the target column leaves the image (cross_correlations.h:235).
 constexpr int WS_TP = 256;
 
-// WIN > 0: a grey image and a square window of that radius, known at compile time (the window loops unrolled: 5x5 and 7x7, the windows of the
-// reference's benchmark rows); 0: whatever the FeatImage says
+// WIN > 0: a square window of that radius on an image of WC channels (1 or 3), known at compile time (the window loops unrolled: 5x5 and 7x7, the
+// windows of the reference's benchmark rows); 0: whatever the FeatImage says
 // grid slice z = 1: the second image of a pair (same window; its own size and outputs, no zcost) -- the two images of a matching call in one launch
-template <int CMP, int WIN>
+template <int CMP, int WIN, int WC>
 __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, bool zero_mean, bool normalized, float *__restrict__ mean,
                                                                    float *__restrict__ norm, float *__restrict__ zcost, int *__restrict__ odd_norm_flag,
                                                                    FeatImage b, float *__restrict__ mean_b, float *__restrict__ norm_b) {
@@ -168,9 +168,9 @@ __global__ void __launch_bounds__(WS_TP) window_stats_tiled_kernel(FeatImage a, 
     if (WIN > 0) {
         a.h_r = WIN;
         a.v_r = WIN;
-        a.C = 1;
+        a.C = WC;
     }
-    constexpr int UNROLL_ROWS = WIN > 0 ? 2 * WIN + 1 : 1, UNROLL_COLS = WIN > 0 ? 2 * WIN + 1 : 4;
+    constexpr int UNROLL_ROWS = WIN > 0 ? 2 * WIN + 1 : 1, UNROLL_COLS = WIN > 0 ? (2 * WIN + 1) * WC : 4;
     const int h = 2 * a.h_r + 1, v = 2 * a.v_r + 1, C = a.C, F = h * v * C;
     const int tw = (WS_TP + h - 1) * C; // floats per tile row
     const int i = blockIdx.y, j0 = blockIdx.x * WS_TP;
@@ -320,17 +320,21 @@ inline int launch_window_stats(svh_context *ctx, FeatImage a, bool zm, bool nrm,
     const size_t shmem = (size_t)(2 * a.v_r + 1) * (WS_TP + 2 * a.h_r) * a.C * sizeof(float);
     if (shmem <= 60 * 1024) {
         dim3 grid(ceil_div(second ? (a.W > b.W ? a.W : b.W) : a.W, WS_TP), second ? (a.H > b.H ? a.H : b.H) : a.H, second ? 2 : 1);
-        const int win = (a.C == 1 && a.h_r == a.v_r && (a.h_r == 2 || a.h_r == 3)) ? a.h_r : 0; // compile-time windows: 5x5, 7x7 grey
-#define SVH_WS_TILED(CMPV)                                                                                                                          \
-    do {                                                                                                                                            \
-        if (win == 2) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 2>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b);      \
-        else if (win == 3) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 3>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b); \
-        else SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, 0>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b);               \
+        const int win = ((a.C == 1 || a.C == 3) && a.h_r == a.v_r && (a.h_r == 2 || a.h_r == 3)) ? a.h_r : 0; // compile-time windows: 5x5, 7x7, grey and RGB
+#define SVH_WS_AS(CMPV, WINV, WCV) SVH_LAUNCH(ctx, "window_stats", (window_stats_tiled_kernel<CMPV, WINV, WCV>), grid, WS_TP, shmem, a, zm, nrm, mean, norm, zcost, odd_norm_flag, b, mean_b, norm_b)
+#define SVH_WS_TILED(CMPV)                                   \
+    do {                                                     \
+        if (win == 2 && a.C == 1) SVH_WS_AS(CMPV, 2, 1);     \
+        else if (win == 3 && a.C == 1) SVH_WS_AS(CMPV, 3, 1); \
+        else if (win == 2) SVH_WS_AS(CMPV, 2, 3);            \
+        else if (win == 3) SVH_WS_AS(CMPV, 3, 3);            \
+        else SVH_WS_AS(CMPV, 0, 1);                          \
     } while (0)
         if (cmp == CMP_SSD) SVH_WS_TILED(CMP_SSD);
         else if (cmp == CMP_SAD) SVH_WS_TILED(CMP_SAD);
         else SVH_WS_TILED(CMP_DOT);
 #undef SVH_WS_TILED
+#undef SVH_WS_AS
         SVH_CHECK_LAUNCH(ctx);
         return SVH_OK;
     }

@@ -593,7 +593,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
     const size_t shmem = colsum_shmem(v_r, a.D, ZM, NRM, a.n_dh, a.C);
     ColsumReduce rd{};
     rd.store = 1;
-    if (a.C == 1 && a.reduce && a.reduce->mode && a.tgt_row_off == 0 && a.out_off == 0 && a.row_count == 0) { // (1-D volumes of whole grey images)
+    if (a.reduce && a.reduce->mode && (a.C == 1 || a.reduce->mode == 1) && a.tgt_row_off == 0 && a.out_off == 0 && a.row_count == 0 && a.n_dh == 1) { // (1-D volumes of whole images; colour images: the winner only)
         const CostReduce &r = *a.reduce;
         rd = ColsumReduce{r.mode, r.score ? 1 : 0, r.store ? 1 : 0, r.idx, r.disp, r.disp_sign, r.disp_offset, reinterpret_cast<float2 *>(r.minima), r.flag, r.big};
         a.reduce->done = true;
@@ -610,19 +610,24 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
         SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD>), grid, 64 * WV, shmem, src, tgt, a.H,   \
                    a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd, a.n_dh, 1); \
     } while (0)
-#define SVH_CS_LAUNCH_MCF(SG, WV, FD)                                                                                                               \
+#define SVH_CS_LAUNCH_MCRF(SG, WV, RD, FD)                                                                                                          \
     do {                                                                                                                                           \
         static int big_lds[64] = {};                                                                                                               \
         if (shmem > 64 * 1024 && !__atomic_load_n(&big_lds[ctx->device & 63], __ATOMIC_ACQUIRE)) {                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, FD, true>),           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD, true>),          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                                     \
             __atomic_store_n(&big_lds[ctx->device & 63], 1, __ATOMIC_RELEASE);                                                                     \
         }                                                                                                                                          \
-        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, 0, FD, true>), grid, 64 * WV, shmem, src, tgt,   \
+        SVH_LAUNCH(ctx, "cost_volume_tiled", (cost_volume_colsum_kernel<CMP, ZM, NRM, HR, SG, WV, RD, FD, true>), grid, 64 * WV, shmem, src, tgt,  \
                    a.H, a.Ws, a.Wt, v_r, a.D, a.disp_lower, ms, mt, ns, nt, zc, a.tgt_row_off, a.px_stride(), a.out_off, cv, a.row_begin, rd,      \
                    a.n_dh, a.C);                                                                                                                   \
     } while (0)
-#define SVH_CS_LAUNCH_MC(SG, WV) SVH_CS_LAUNCH_MCF(SG, WV, false)
+#define SVH_CS_LAUNCH_MCF(SG, WV, FD) SVH_CS_LAUNCH_MCRF(SG, WV, 0, FD)
+#define SVH_CS_LAUNCH_MC(SG, WV)                                                                                                                   \
+    do { /* (colour images: the plain kernel or the winner) */                                                                                    \
+        if (rd.mode == 1) SVH_CS_LAUNCH_MCRF(SG, WV, 1, false);                                                                                    \
+        else SVH_CS_LAUNCH_MCRF(SG, WV, 0, false);                                                                                                 \
+    } while (0)
 #define SVH_CS_LAUNCH_R(SG, WV, RD) SVH_CS_LAUNCH_RF(SG, WV, RD, false)
 #define SVH_CS_LAUNCH(SG, WV)                                                                                                                      \
     do {                                                                                                                                           \
@@ -656,6 +661,7 @@ template <int CMP, bool ZM, bool NRM, int HR> void launch_colsum_n(svh_context *
 #undef SVH_CS_LAUNCH_RF
 #undef SVH_CS_LAUNCH_MC
 #undef SVH_CS_LAUNCH_MCF
+#undef SVH_CS_LAUNCH_MCRF
 }
 template <int CMP, bool ZM, int HR> void launch_colsum(svh_context *ctx, const CostVolumeArgs &a, const float *src, const float *tgt, int v_r, int sign,
                                                        const float *ms, const float *mt, const float *ns, const float *nt, const float *zc, float *cv) {

@@ -481,7 +481,7 @@ int dev_hierarchical(svh_context *ctx, Scratch &scr, int func, int ddir, int dep
         const int census_words = func_census(func) ? census_words_written((2 * h_radii[0] + 1) * (2 * v_radii[0] + 1) * C) : 0;
         const bool hamming_reduces = func_census(func) && census_words >= 1 && census_words <= 8 &&
                                      (size_t)census_words * (2 * 64 + D0 - 1) * sizeof(uint32_t) <= 60 * 1024; // (the tiled Hamming kernel: dev_hamming_volume)
-        if (ctx->cost_reduce_fused && (hamming_reduces || (!func_census(func) && C == 1 && cost_volume_colsum_applies(ctx, a, csrc, ctgt, h_radii[0], v_radii[0])))) {
+        if (ctx->cost_reduce_fused && (hamming_reduces || (!func_census(func) && cost_volume_colsum_applies(ctx, a, csrc, ctgt, h_radii[0], v_radii[0])))) {
             CostReduce red;
             red.mode = 1;
             red.score = func_strategy(func) != SVH_COST;

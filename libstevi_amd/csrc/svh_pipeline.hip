@@ -142,9 +142,9 @@ extern "C" int svh_stereo_match(svh_context *ctx, const svh_stereo_params *prm, 
         //   Cost-branch SGM: the two regional minima the line recurrences run on -- no probing read of the volume.
         CostReduce red;
         CostVolumeArgs cva_r = cva;
-        const bool colsum = ctx->cost_reduce_fused && isrc.C == 1 && cost_volume_colsum_applies(ctx, cva, isrc, itgt, prm->h_radius, prm->v_radius); // (the reducing forms of the kernel take grey images)
-        const bool winner_in_cost = colsum && !sgm && !cv && !want_refine && !keys && disp && !sharded;
-        const bool minima_in_cost = colsum && sgm && strategy == SVH_COST && ctx->sgm_cost_two_minima && !sharded;
+        const bool colsum = ctx->cost_reduce_fused && cost_volume_colsum_applies(ctx, cva, isrc, itgt, prm->h_radius, prm->v_radius);
+        const bool winner_in_cost = colsum && !sgm && !cv && !want_refine && !keys && disp && !sharded; // (grey and colour images)
+        const bool minima_in_cost = colsum && isrc.C == 1 && sgm && strategy == SVH_COST && ctx->sgm_cost_two_minima && !sharded; // (grey images)
         if (winner_in_cost) {
             red.mode = 1;
             red.score = strategy != SVH_COST;

@@ -737,6 +737,32 @@ def test_winner_and_minima_reduced_inside_the_cost_kernel(func):
         assert np.array_equal(host(a["disp"]), so.index_to_disp(so.extract_index(cvh, strat)))
 
 
+@pytest.mark.parametrize("func", [MF.SAD, MF.SSD, MF.NCC, MF.ZNCC, MF.ZSSD])
+def test_winner_reduced_inside_the_cost_kernel_on_colour_images(rng, func):
+    """The same for RGB images (round 5: the column-sum kernel of interleaved channels has a winner form too): a disparity-only call without
+    SGM writes no volume and launches no extract_index; same map as with the option off and as the oracle's selection on the library's
+    own volume; two- and three-channel images, both directions, ranges off the multiples of 16."""
+    strat = sv.matchFuncStrategy(func)
+    for (H, W, C), D, r, ddir in (((30, 150, 3), 64, 2, sv.dispDirection.RightToLeft), ((17, 131, 3), 40, 3, sv.dispDirection.LeftToRight), ((12, 200, 2), 23, 1, sv.dispDirection.RightToLeft)):
+        g_src, g_tgt, _ = parallax_pair(H, W, max(2, H // 4), H // 4, W // 4, 2, 9, seed=H + W + D)
+        gains = np.linspace(0.7, 1.3, C).astype(np.float32)
+        src = (g_src[:H, :W, None] * gains + 0.05 * rng.uniform(-1, 1, (H, W, C))).astype(np.float32)
+        tgt = (g_tgt[:H, :W, None] * gains + 0.05 * rng.uniform(-1, 1, (H, W, C))).astype(np.float32)
+        l, r_ = dev(tgt), dev(src)
+        run = lambda **kw: sv.stereoMatch(func, l, r_, r, r, D, dDir=ddir, **kw)  # noqa: E731
+        sv.profile_reset(l)
+        sv.profile_enable(l, True)
+        a = run()
+        sv.profile_enable(l, False)
+        kernels = sv.profile_collect(l)
+        assert "extract_index" not in kernels and "index_to_disp" not in kernels, kernels.keys()
+        b = _with_option(l, "cost_reduce_fused", 0, run)
+        assert np.array_equal(host(a["disp"]), host(b["disp"])), (func, H, W, C, D)
+        full = run(want_cv=True)
+        exp = so.index_to_disp(so.extract_index(host(full["cv"]), strat), int(ddir))
+        assert np.array_equal(host(a["disp"]), exp)
+
+
 @pytest.mark.parametrize("strategy", [so.COST, so.SCORE])
 def test_winner_travels_with_the_aggregated_volume(rng, strategy):
     """sgmCostVolume(..., keep_winner=True) on a device tensor keeps, with the volume it returns, the index map extractSelectedIndex would

@@ -336,11 +336,14 @@ bool launch_guided_wave_span(svh_context *ctx, FeatImage src, FeatImage tgt, con
     }
 }
 
-// grey images: 96 staged centres; RGB: 80 (three times the rows and the strip in LDS: a CU holds seven waves of it)
+// grey images: 96 staged centres; RGB: 76 or 80 (three times the rows and the strip in LDS: a CU holds eight or seven waves of it)
 template <int CMP, bool ZM, bool NORM, int HR>
 bool launch_guided_wave_radius(svh_context *ctx, FeatImage src, FeatImage tgt, const float *ms, const float *ns, const float *mt, const float *nt, int H,
                                int Ws, int Wt, const GuideArgs &g, int32_t *disp, float *tcv) {
-    if (src.C == 3) return launch_guided_wave_span<CMP, ZM, NORM, HR, 80, 3>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
+    if (src.C == 3) { // (76 centres: eight waves per CU instead of seven; the thirteen offsets of radius 3 keep four centres of room)
+        if (g.radius <= 2) return launch_guided_wave_span<CMP, ZM, NORM, HR, 76, 3>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
+        return launch_guided_wave_span<CMP, ZM, NORM, HR, 80, 3>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
+    }
     return launch_guided_wave_span<CMP, ZM, NORM, HR, 96, 1>(ctx, src, tgt, ms, ns, mt, nt, H, Ws, Wt, g, disp, tcv);
 }
 
